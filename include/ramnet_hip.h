@@ -1,0 +1,156 @@
+/*
+ * ramnet_hip.h — C ABI of librpg_ramnet_hip.so (MI355X / gfx950 RAM-Net hot path).
+ *
+ * The reference (uzh-rpg/rpg_ramnet) is pure Python on torch.nn ops and has no FFI; each entry
+ * point below names the reference code it replaces (file:line relative to RAM_Net/).  All
+ * pointers are DEVICE pointers (fp32 unless noted), `stream` is a hipStream_t passed as void*,
+ * every function returns 0 on success or a non-zero code (hipError_t value, or RAMNET_E_*);
+ * ramnet_last_error() returns a static, thread-local message for the last failure.
+ *
+ * Activation layout: NHWC ("channels_last") — element (b, y, x, c) of a tensor with leading
+ * dimension ld lives at ((b*H + y)*W + x)*ld + c.  `ld` lets a tensor be a channel slice of a
+ * wider one.  Weights are given in PyTorch OIHW and re-packed by ramnet_pack_weight().
+ */
+#ifndef RAMNET_HIP_H
+#define RAMNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAMNET_ABI_VERSION 1
+#define RAMNET_E_BADARG 10001
+#define RAMNET_E_UNSUPPORTED 10002
+
+/* ---- input-tile sources of the implicit-GEMM convolution (what feeds the LDS patch) ---------- */
+enum ramnet_in_mode {
+    RAMNET_IN_PLAIN = 0,     /* x0[C0]                                                          */
+    RAMNET_IN_CAT = 1,       /* cat(x0[C0], x1[C1])            ConvGRU/ConvLSTM  submodules.py:343,447 */
+    RAMNET_IN_CAT_MUL = 2,   /* cat(x0[C0], x1[C1] * xm[C1])   ConvGRU candidate submodules.py:450  */
+    RAMNET_IN_UP2X = 3,      /* bilinear x2 (align_corners=False) of x0          submodules.py:88   */
+    RAMNET_IN_UP2X_SKIP = 4, /* bilinear x2 of (x0 + x1)       decoder skip sum  statenet.py:305-308 */
+    RAMNET_IN_RELUMASK = 5   /* x0 * (xm > 0)                  backward through a ReLU             */
+};
+
+/* ---- fused epilogues ------------------------------------------------------------------------- */
+enum ramnet_epilogue {
+    RAMNET_EPI_LINEAR = 0,    /* acc + bias                                                      */
+    RAMNET_EPI_RELU = 1,      /* relu(acc + bias)                    ConvLayer submodules.py:26-35 */
+    RAMNET_EPI_SIGMOID = 2,   /* sigmoid(acc + bias)                 GRU gates submodules.py:448-449 */
+    RAMNET_EPI_RES_RELU = 3,  /* relu(acc + bias + e0)               ResidualBlock submodules.py:212-214 */
+    RAMNET_EPI_GRU_BLEND = 4, /* o=tanh(acc+bias); out=h*(1-u)+o*u   submodules.py:450-452; e0=u, e1=h, o1<-o */
+    RAMNET_EPI_LSTM = 5       /* i,f,o,g -> c'=f*c+i*g, h'=o*tanh(c') submodules.py:346-358; e1=c, out<-h', o1<-c', o2<-gates */
+};
+
+/* One convolution launch.  out(a,b) = epi( sum_t sum_c in(a*stride+dy[t], b*stride+dx[t], c) * W[wtap[t]][c][n] ).
+ * A plain KxK conv is the tap list dy,dx in [-pad, K-1-pad]; a transposed (backward-data) conv of a
+ * stride-2 layer is four such launches, one per output parity class (os?/oo? below).            */
+typedef struct ramnet_conv_desc {
+    const float *x0, *x1, *xm;      /* input sources, see ramnet_in_mode                            */
+    int ld0, ld1, ldm;              /* their leading dimensions (floats per pixel)                  */
+    int C0, C1;                     /* channel counts (multiples of 4); Cin = C0 (+ C1 for CAT*)    */
+    int in_mode;
+    int B, Hin, Win;                /* logical input extent (AFTER the x2 upsample for UP2X*)       */
+    int ntaps, stride;
+    int8_t dy[25], dx[25];          /* tap offsets in input pixels                                  */
+    uint8_t wtap[25];               /* which packed weight slice each tap multiplies with           */
+    const float *w;                 /* packed weights from ramnet_pack_weight()                     */
+    const float *bias;              /* [Cout] or NULL                                               */
+    int Cout;                       /* real output channels (LSTM: hidden size C, weights hold 4C)  */
+    int Ho, Wo;                     /* extent of the (a,b) grid                                     */
+    int HoF, WoF;                   /* full output tensor extent                                    */
+    int osy, osx, ooy, oox;         /* output pixel = (a*osy+ooy, b*osx+oox)                        */
+    int epi;
+    float beta;                     /* out = value + beta*out_old (LINEAR only; 0 = overwrite)      */
+    const float *e0, *e1;           /* epilogue operands                                            */
+    int lde0, lde1;
+    float *out, *o1, *o2;
+    int ldo, ldo1, ldo2;
+} ramnet_conv_desc;
+
+/* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
+ * where g = dout (optionally * (gmask > 0)).  Accumulates (atomically) into a [ntaps][Cin][Cout] fp32
+ * workspace and, when dbias != NULL, sum_pixels g into dbias[Cout].                               */
+typedef struct ramnet_wgrad_desc {
+    const float *x0, *x1, *xm;
+    int ld0, ld1, ldm, C0, C1, in_mode;
+    int B, Hin, Win;
+    int ntaps, stride;
+    int8_t dy[25], dx[25];
+    const float *dout, *gmask;      /* gradient wrt the layer's pre-activation output (+ ReLU mask)  */
+    int ldg, ldgm;
+    int Cout, Ho, Wo;
+    float *dw;                      /* [ntaps][Cin][Cout] accumulation workspace                    */
+    float *dbias;                   /* [Cout] or NULL                                               */
+} ramnet_wgrad_desc;
+
+const char *ramnet_last_error(void);
+int ramnet_abi_version(void);
+
+/* ---- layout plumbing -------------------------------------------------------------------------- */
+/* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] zero-padded (model inputs: model.py:177,200 `.to(self.gpu)`). */
+int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream);
+/* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
+size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
+/* OIHW -> kernel layout [tap][chunk][n][16].  transposed=1 packs the backward-data operator
+ * (reduce over O, produce I).  gates=4 interleaves ConvLSTM gate blocks so that one wave owns
+ * i,f,o,g of a channel (forward only).  CinValid rows beyond Cin are zero (padded inputs).        */
+int ramnet_pack_weight(const float *w_oihw, float *wp, int Cout, int Cin, int KH, int KW,
+                       int transposed, int gates, void *stream);
+/* [tap][CinWs][CoutWs] gradient workspace -> OIHW: grad_oihw[n][c][tap] += ws[tap][c][n_off + n].
+ * (CoutWs/n_off: fused launches such as the GRU's update|reset gates share one workspace.)        */
+int ramnet_unpack_wgrad(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
+                        int KH, int KW, void *stream);
+
+/* ---- the two MFMA kernels ----------------------------------------------------------------------- */
+int ramnet_conv_launch(const ramnet_conv_desc *d, void *stream);    /* forward and backward-data   */
+int ramnet_wgrad_launch(const ramnet_wgrad_desc *d, void *stream);  /* backward-weights (+bias)    */
+
+/* ---- HBM-bound point-wise / reduction kernels ------------------------------------------------- */
+/* pred = sigmoid(conv1x1(x) + b): statenet.py:116-117,313.  x NHWC [npix, C], y [npix].            */
+int ramnet_pred_sigmoid_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y,
+                            size_t npix, void *stream);
+/* backward of the above: dx[npix,C] = dz*w, dw[C] += sum dz*x, db += sum dz, dz = dy*y*(1-y).      */
+int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy,
+                            float *dx, int lddx, float *dw, float *db, size_t npix, void *stream);
+/* dx = dy * (y > 0) */
+int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *stream);
+/* Adjoint of the bilinear x2 upsample: dup [B,2H,2W,C] -> dx [B,H,W,C] (backward of submodules.py:88). */
+int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream);
+/* ConvGRU backward, point-wise parts (derivation in DESIGN.md):
+ *  stage A: from dh' and saved u,o,h: dpo = dh'*u*(1-o^2) ; dpu = dh'*(o-h)*u*(1-u) ; dh = dh'*(1-u)
+ *  stage B: from d(h*r) (dgrad of the candidate conv) : dpr = dhr*h*r*(1-r) ; dh += dhr*r            */
+int ramnet_gru_bwd_a(const float *dhn, const float *ur, const float *o, const float *h, float *dpo,
+                     float *dpur, float *dh, size_t npix, int C, void *stream);
+int ramnet_gru_bwd_b(const float *dxhr, const float *ur, const float *h, float *dpur, float *dh,
+                     size_t npix, int C, void *stream);
+/* ConvLSTM backward point-wise: gates [npix,4C] (activated i,f,o,g), c_prev, c_new, dh', dc' ->
+ * dgates_pre [npix,4C], dc_prev.                                                                   */
+int ramnet_lstm_bwd(const float *gates, const float *cprev, const float *cnew, const float *dhn,
+                    const float *dcn, float *dpre, float *dcprev, size_t npix, int C, void *stream);
+/* y = a + b (gradient fan-in) */
+int ramnet_add(const float *a, const float *b, float *y, size_t n, void *stream);
+
+/* ---- scale-invariant loss: model/loss.py:6-9 -------------------------------------------------- */
+/* stats[0..2] = (sum d, sum d^2, count) over non-NaN d = pred - target; loss = w*(S2/n - lambda*(S1/n)^2). */
+int ramnet_si_loss_fwd(const float *pred, const float *target, size_t n, float weight, float lambda,
+                       double *stats, float *loss, void *stream);
+/* dpred = gscale * w * (2 d/n - 2 lambda mean/n) on valid pixels, 0 elsewhere (gscale: device scalar). */
+int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float weight, float lambda,
+                       const double *stats, const float *gscale, float *dpred, void *stream);
+
+/* ---- event -> voxel grid: utils/event_tensor_utils.py:120-187, :52-66 ----------------------- */
+/* events: [N,4] float64 rows (t,x,y,p) sorted by t, on device.  grid [bins,H,W] fp32 is zeroed here. */
+int ramnet_voxelize(const double *events, size_t n_events, int bins, int W, int H, float *grid, void *stream);
+/* same index arithmetic, but emits the int64 flat indices (or -1) for bit-exactness tests.        */
+int ramnet_voxel_indices(const double *events, size_t n_events, int bins, int W, int H,
+                         long long *idx_left, long long *idx_right, void *stream);
+/* zero-mean/unit-std over non-zero entries, in place; scratch: 3 doubles.                          */
+int ramnet_normalize_nonzero(float *grid, size_t n, double *scratch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

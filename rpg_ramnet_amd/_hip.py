@@ -1,0 +1,103 @@
+"""ctypes binding of librpg_ramnet_hip.so (the C ABI declared in include/ramnet_hip.h).
+
+The product path has NO CPU fallback: importing works without the library (so that `-m "not gpu"` host-logic
+tests can run), but the first kernel call raises if the library is missing.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librpg_ramnet_hip.so")
+
+IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK = range(6)
+EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
+
+_fp = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x0", _fp), ("x1", _fp), ("xm", _fp),
+        ("ld0", C.c_int), ("ld1", C.c_int), ("ldm", C.c_int),
+        ("C0", C.c_int), ("C1", C.c_int), ("in_mode", C.c_int),
+        ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int),
+        ("ntaps", C.c_int), ("stride", C.c_int),
+        ("dy", C.c_int8 * 25), ("dx", C.c_int8 * 25), ("wtap", C.c_uint8 * 25),
+        ("w", _fp), ("bias", _fp),
+        ("Cout", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("HoF", C.c_int), ("WoF", C.c_int),
+        ("osy", C.c_int), ("osx", C.c_int), ("ooy", C.c_int), ("oox", C.c_int),
+        ("epi", C.c_int), ("beta", C.c_float),
+        ("e0", _fp), ("e1", _fp), ("lde0", C.c_int), ("lde1", C.c_int),
+        ("out", _fp), ("o1", _fp), ("o2", _fp),
+        ("ldo", C.c_int), ("ldo1", C.c_int), ("ldo2", C.c_int),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x0", _fp), ("x1", _fp), ("xm", _fp),
+        ("ld0", C.c_int), ("ld1", C.c_int), ("ldm", C.c_int),
+        ("C0", C.c_int), ("C1", C.c_int), ("in_mode", C.c_int),
+        ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int),
+        ("ntaps", C.c_int), ("stride", C.c_int),
+        ("dy", C.c_int8 * 25), ("dx", C.c_int8 * 25),
+        ("dout", _fp), ("gmask", _fp), ("ldg", C.c_int), ("ldgm", C.c_int),
+        ("Cout", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+        ("dw", _fp), ("dbias", _fp),
+    ]
+
+
+_SIGS = {
+    "ramnet_abi_version": (C.c_int, []),
+    "ramnet_last_error": (C.c_char_p, []),
+    "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
+    "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
+    "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),
+    "ramnet_pred_sigmoid_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_pred_sigmoid_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_relu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_upsample2x_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_gru_bwd_a": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
+    "ramnet_gru_bwd_b": (C.c_int, [_fp] * 5 + [C.c_size_t, C.c_int, _fp]),
+    "ramnet_lstm_bwd": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
+    "ramnet_add": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_si_loss_fwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp]),
+    "ramnet_si_loss_bwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp, _fp]),
+    "ramnet_voxelize": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ramnet_voxel_indices": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "ramnet_normalize_nonzero": (C.c_int, [_fp, C.c_size_t, _fp, _fp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). rpg_ramnet_amd has no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        if l.ramnet_abi_version() != 1:
+            raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().ramnet_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, code, msg.decode() if msg else "?"))

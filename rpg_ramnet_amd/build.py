@@ -1,0 +1,39 @@
+"""Build librpg_ramnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "pointwise.hip", "loss_voxel.hip"]
+LIB = os.path.join(PKG, "librpg_ramnet_hip.so")
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "ramnet_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library (C ABI, no torch dependency)."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building %s" % LIB)
+    if verbose:
+        sys.stderr.write(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose="-v" in sys.argv))

@@ -1,0 +1,101 @@
+// Shared device/host helpers for the gfx950 RAM-Net kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ramnet_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace ramnet {
+
+constexpr int CK = 16;        // input channels staged per chunk by the forward / backward-data kernel
+constexpr int LDP = CK + 4;   // padded LDS row (floats) of a patch pixel / weight row: conflict-free b128 reads
+constexpr int TWID = 16;      // output tile width in pixels (tile = TH x 16)
+constexpr int WCK = 32;       // input channels per block of the weight-gradient kernel
+
+void set_error(const char *fmt, ...);
+
+#define RAMNET_CHECK_ARG(cond)                                                        \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            ramnet::set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond);  \
+            return RAMNET_E_BADARG;                                                   \
+        }                                                                             \
+    } while (0)
+
+#define RAMNET_HIP(call)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            ramnet::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return (int)e_;                                                                     \
+        }                                                                                       \
+    } while (0)
+
+#define RAMNET_LAUNCH_CHECK() RAMNET_HIP(hipGetLastError())
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Everything the patch loader needs to know about the logical input of a convolution.
+struct InSrc {
+    const float *x0, *x1, *xm;
+    int ld0, ld1, ldm, C0, Cin, mode, Hin, Win;
+};
+
+// Source row/col and blend weight of one output coordinate of F.interpolate(scale_factor=2,
+// mode='bilinear', align_corners=False): src = max(0.5*(dst+0.5)-0.5, 0).
+__device__ __forceinline__ void up2x_coord(int d, int n_src, int &i0, int &i1, float &l1) {
+    float s = fmaxf(0.5f * (float)d - 0.25f, 0.0f);
+    i0 = (int)s;
+    i1 = i0 + (i0 < n_src - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+// Four consecutive input channels c..c+3 of logical input pixel (b, iy, ix); zero outside the image
+// (the convolution's zero padding) and beyond the last channel (chunk padding).
+__device__ __forceinline__ float4 load_in4(const InSrc &s, int b, int iy, int ix, int c) {
+    if ((unsigned)iy >= (unsigned)s.Hin || (unsigned)ix >= (unsigned)s.Win || c >= s.Cin) return f4zero();
+    if (s.mode == RAMNET_IN_UP2X || s.mode == RAMNET_IN_UP2X_SKIP) {
+        const int Hs = s.Hin >> 1, Ws = s.Win >> 1;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up2x_coord(iy, Hs, y0, y1, ly);
+        up2x_coord(ix, Ws, x0, x1, lx);
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const size_t r0 = ((size_t)b * Hs + y0) * Ws, r1 = ((size_t)b * Hs + y1) * Ws;
+        float4 v00 = ld4(s.x0 + (r0 + x0) * s.ld0 + c), v01 = ld4(s.x0 + (r0 + x1) * s.ld0 + c);
+        float4 v10 = ld4(s.x0 + (r1 + x0) * s.ld0 + c), v11 = ld4(s.x0 + (r1 + x1) * s.ld0 + c);
+        if (s.mode == RAMNET_IN_UP2X_SKIP) {
+            v00 = f4add(v00, ld4(s.x1 + (r0 + x0) * s.ld1 + c));
+            v01 = f4add(v01, ld4(s.x1 + (r0 + x1) * s.ld1 + c));
+            v10 = f4add(v10, ld4(s.x1 + (r1 + x0) * s.ld1 + c));
+            v11 = f4add(v11, ld4(s.x1 + (r1 + x1) * s.ld1 + c));
+        }
+        float4 top = f4add(f4scale(v00, hx), f4scale(v01, lx));
+        float4 bot = f4add(f4scale(v10, hx), f4scale(v11, lx));
+        return f4add(f4scale(top, hy), f4scale(bot, ly));
+    }
+    const size_t pix = ((size_t)b * s.Hin + iy) * s.Win + ix;
+    if (s.mode == RAMNET_IN_PLAIN) return ld4(s.x0 + pix * s.ld0 + c);
+    if (s.mode == RAMNET_IN_RELUMASK) {
+        float4 v = ld4(s.x0 + pix * s.ld0 + c), m = ld4(s.xm + pix * s.ldm + c);
+        return make_float4(m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f, m.w > 0.f ? v.w : 0.f);
+    }
+    // CAT / CAT_MUL
+    if (c < s.C0) return ld4(s.x0 + pix * s.ld0 + c);
+    float4 v = ld4(s.x1 + pix * s.ld1 + (c - s.C0));
+    if (s.mode == RAMNET_IN_CAT_MUL) v = f4mul(v, ld4(s.xm + pix * s.ldm + (c - s.C0)));
+    return v;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int roundup(int a, int b) { return cdiv(a, b) * b; }
+
+}  // namespace ramnet

@@ -1,0 +1,254 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): forward and backward-data of every conv on the
+// RAM-Net path (5x5 s1/s2 encoders, 3x3 ConvGRU/ConvLSTM gates, residual blocks, upsample-conv
+// decoders), fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).
+//
+// Formulation ("halo patch"): a workgroup (4 waves) owns TH x 16 output pixels x BN output
+// channels.  For every chunk of 16 input channels it stages the input patch (tile + halo) ONCE in
+// LDS — concatenation [x,h], the h*r product of the GRU candidate, the bilinear x2 upsample (+skip
+// sum) of the decoders and the ReLU mask of the backward pass are all applied while staging — and
+// then walks the filter taps; each tap is a K=16 slab of the GEMM whose A operand is the patch
+// shifted by the tap offset (no im2col traffic: the patch is read from HBM/L2 once per 16 channels
+// instead of once per tap) and whose B operand is a [BN][16] weight tile streamed through a
+// double-buffered LDS ring (global loads of tap t+1 are in flight under the MFMAs of tap t).
+// Fused epilogues: bias/ReLU/sigmoid, residual add, GRU blend, full LSTM cell.
+#include "common.hpp"
+
+namespace ramnet {
+
+struct ConvDerived {
+    InSrc src;
+    int nchunks, CoutPad;            // weight geometry
+    int PH, PW, dymin, dxmin;        // LDS patch geometry
+    int patch_floats;                // PH*PW*LDP (multiple of 4)
+    int tiles_x, tiles_y;
+    int toff[25];                    // per-tap patch offset (floats)
+    unsigned woff[25];               // per-tap weight slice offset / CK (in 16-float rows)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvDerived q) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int TH = BM / TWID;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                    // [PH*PW][LDP]
+    float *wsm = smem + q.patch_floats;     // [2][BN][LDP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tx_i = bid % q.tiles_x;
+    bid /= q.tiles_x;
+    const int ty_i = bid % q.tiles_y;
+    const int b = bid / q.tiles_y;
+    const int n0 = blockIdx.y * BN;
+    const int oy0 = ty_i * TH, ox0 = tx_i * TWID;
+    const int iy0 = oy0 * p.stride + q.dymin, ix0 = ox0 * p.stride + q.dxmin;
+
+    int aBase[TM], bBase[TN];
+#pragma unroll
+    for (int ms = 0; ms < TM; ++ms) {
+        const int m = (wm * TM + ms) * 32 + l31;
+        aBase[ms] = (((m >> 4) * p.stride) * q.PW + (m & 15) * p.stride) * LDP + 4 * kk;
+    }
+#pragma unroll
+    for (int ns = 0; ns < TN; ++ns) bBase[ns] = ((wn * TN + ns) * 32 + l31) * LDP + 4 * kk;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int ms = 0; ms < TM; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < TN; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
+
+    // ---- weight tile ring: [BN][16] floats per (chunk, tap), contiguous in global memory
+    constexpr int WF4 = BN * CK / 4;
+    constexpr int WPT = (WF4 + 255) / 256;
+    float4 wreg[WPT];
+    auto load_w = [&](int chunk, int t) {
+        const float *src = p.w + ((size_t)q.woff[t] + ((size_t)chunk * q.CoutPad + n0)) * CK;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int f = tid + i * 256;
+            if (WF4 % 256 == 0 || f < WF4) wreg[i] = ld4(src + (size_t)f * 4);
+        }
+    };
+    auto store_w = [&](int buf) {
+        float *dst = wsm + buf * (BN * LDP);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int f = tid + i * 256;
+            if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[i]);
+        }
+    };
+
+    const int ntaps = p.ntaps;
+    load_w(0, 0);
+    int buf = 0;
+    const int nslots = q.PH * q.PW * (CK / 4);
+    for (int chunk = 0; chunk < q.nchunks; ++chunk) {
+        __syncthreads();   // every wave is done reading the previous chunk's patch
+        const int c0 = chunk * CK;
+        for (int s = tid; s < nslots; s += 256) {
+            const int pix = s >> 2, qd = s & 3;
+            const int py = pix / q.PW, px = pix - py * q.PW;
+            st4(patch + pix * LDP + qd * 4, load_in4(q.src, b, iy0 + py, ix0 + px, c0 + qd * 4));
+        }
+        for (int t = 0; t < ntaps; ++t) {
+            store_w(buf);
+            __syncthreads();   // patch + weight tile visible; the other ring slot is free again
+            if (t + 1 < ntaps) load_w(chunk, t + 1);
+            else if (chunk + 1 < q.nchunks) load_w(chunk + 1, 0);
+            const float *pa = patch + q.toff[t];
+            const float *wb = wsm + buf * (BN * LDP);
+#pragma unroll
+            for (int k8 = 0; k8 < CK / 8; ++k8) {
+                float4 a[TM], bb[TN];
+#pragma unroll
+                for (int ms = 0; ms < TM; ++ms) a[ms] = ld4(pa + aBase[ms] + k8 * 8);
+#pragma unroll
+                for (int ns = 0; ns < TN; ++ns) bb[ns] = ld4(wb + bBase[ns] + k8 * 8);
+                // lanes 0-31 feed channels k8*8+j, lanes 32-63 channels k8*8+4+j: 4 MFMAs cover 8 channels
+#pragma unroll
+                for (int ms = 0; ms < TM; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < TN; ++ns) {
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].x, bb[ns].x, acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].y, bb[ns].y, acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].z, bb[ns].z, acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].w, bb[ns].w, acc[ms][ns], 0, 0, 0);
+                    }
+            }
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue.  D layout of 32x32 MFMA: col = lane&31 (output channel), row = (r&3)+8*(r>>2)+4*(lane>>5) (pixel)
+    const int epi = p.epi;
+#pragma unroll
+    for (int ms = 0; ms < TM; ++ms) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (wm * TM + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
+            if (epi == RAMNET_EPI_LSTM) {
+                if constexpr (TN == 4) {
+                    // packed N order = (channel block of 32, gate, channel): ns is the gate (i, f, o, g)
+                    const int C = p.Cout, ch = blockIdx.y * 32 + l31;
+                    if (ch < C) {
+                        const float gi = sigmoidf_(acc[ms][0][r] + p.bias[ch]);
+                        const float gf = sigmoidf_(acc[ms][1][r] + p.bias[C + ch]);
+                        const float go = sigmoidf_(acc[ms][2][r] + p.bias[2 * C + ch]);
+                        const float gc = tanhf(acc[ms][3][r] + p.bias[3 * C + ch]);
+                        const float cp = p.e1 ? p.e1[pix * p.lde1 + ch] : 0.f;
+                        const float cn = gf * cp + gi * gc;
+                        p.out[pix * p.ldo + ch] = go * tanhf(cn);
+                        p.o1[pix * p.ldo1 + ch] = cn;
+                        if (p.o2) {
+                            float *g = p.o2 + pix * p.ldo2 + ch;
+                            g[0] = gi, g[C] = gf, g[2 * C] = go, g[3 * C] = gc;
+                        }
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int ns = 0; ns < TN; ++ns) {
+                const int n = n0 + (wn * TN + ns) * 32 + l31;
+                if (n >= p.Cout) continue;
+                float v = acc[ms][ns][r] + (p.bias ? p.bias[n] : 0.f);
+                if (epi == RAMNET_EPI_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (epi == RAMNET_EPI_SIGMOID) {
+                    v = sigmoidf_(v);
+                } else if (epi == RAMNET_EPI_RES_RELU) {
+                    v = fmaxf(v + p.e0[pix * p.lde0 + n], 0.f);
+                } else if (epi == RAMNET_EPI_GRU_BLEND) {
+                    const float o = tanhf(v);
+                    const float u = p.e0[pix * p.lde0 + n];
+                    const float h = p.e1 ? p.e1[pix * p.lde1 + n] : 0.f;
+                    if (p.o1) p.o1[pix * p.ldo1 + n] = o;
+                    v = h * (1.0f - u) + o * u;
+                } else if (p.beta != 0.f) {
+                    v += p.beta * p.out[pix * p.ldo + n];
+                }
+                p.out[pix * p.ldo + n] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+    const size_t lds = ((size_t)q.patch_floats + 2 * BN * LDP) * sizeof(float);
+    static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation (monotone)
+    if (lds > lds_set) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_set = 160 * 1024;
+    }
+    if (lds > 160 * 1024) {
+        set_error("conv patch does not fit LDS (%zu bytes)", lds);
+        return RAMNET_E_UNSUPPORTED;
+    }
+    dim3 grid(q.tiles_x * q.tiles_y * d.B, q.CoutPad / BN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, q);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
+    RAMNET_CHECK_ARG(dp != nullptr);
+    const ramnet_conv_desc &d = *dp;
+    RAMNET_CHECK_ARG(d.x0 && d.w && d.out);
+    RAMNET_CHECK_ARG(d.ntaps >= 1 && d.ntaps <= 25 && (d.stride == 1 || d.stride == 2));
+    RAMNET_CHECK_ARG(d.B > 0 && d.Ho > 0 && d.Wo > 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0);
+    RAMNET_CHECK_ARG(d.C0 > 0 && d.C0 % 4 == 0 && d.ld0 % 4 == 0 && d.ldo > 0);
+    RAMNET_CHECK_ARG(d.osy >= 1 && d.osx >= 1);
+    const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
+    if (cat) RAMNET_CHECK_ARG(d.x1 && d.C1 > 0 && d.C1 % 4 == 0 && d.ld1 % 4 == 0);
+    if (d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK) RAMNET_CHECK_ARG(d.xm && d.ldm % 4 == 0);
+    if (d.in_mode == RAMNET_IN_UP2X_SKIP) RAMNET_CHECK_ARG(d.x1 && d.ld1 % 4 == 0);
+    if (d.in_mode == RAMNET_IN_UP2X || d.in_mode == RAMNET_IN_UP2X_SKIP) RAMNET_CHECK_ARG(d.Hin % 2 == 0 && d.Win % 2 == 0);
+    if (d.epi == RAMNET_EPI_RES_RELU) RAMNET_CHECK_ARG(d.e0);
+    if (d.epi == RAMNET_EPI_GRU_BLEND) RAMNET_CHECK_ARG(d.e0);
+    if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
+
+    ConvDerived q;
+    q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
+    q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
+    q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
+    q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    q.nchunks = cdiv(q.src.Cin, CK);
+    q.CoutPad = d.epi == RAMNET_EPI_LSTM ? 4 * roundup(d.Cout, 32) : roundup(d.Cout, 32);
+    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
+    for (int t = 0; t < d.ntaps; ++t) {
+        dymin = d.dy[t] < dymin ? d.dy[t] : dymin, dymax = d.dy[t] > dymax ? d.dy[t] : dymax;
+        dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin, dxmax = d.dx[t] > dxmax ? d.dx[t] : dxmax;
+    }
+    constexpr int TH = 8;   // BM = 128 in every configuration below
+    q.dymin = dymin, q.dxmin = dxmin;
+    q.PH = (TH - 1) * d.stride + (dymax - dymin) + 1;
+    q.PW = (TWID - 1) * d.stride + (dxmax - dxmin) + 1;
+    q.patch_floats = q.PH * q.PW * LDP;
+    q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, TH);
+    for (int t = 0; t < d.ntaps; ++t) {
+        q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * LDP;
+        q.woff[t] = (unsigned)d.wtap[t] * (unsigned)q.nchunks * (unsigned)q.CoutPad;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (d.epi == RAMNET_EPI_LSTM) return launch_cfg<128, 128, 4, 1>(d, q, st);
+    if (q.CoutPad % 128 == 0) return launch_cfg<128, 128, 2, 2>(d, q, st);
+    if (q.CoutPad % 64 == 0) return launch_cfg<128, 64, 2, 2>(d, q, st);
+    return launch_cfg<128, 32, 4, 1>(d, q, st);
+}

@@ -1,0 +1,182 @@
+// Backward-weights (+bias) of every convolution on the RAM-Net path, gfx950 fp32 MFMA.
+//
+//   dW[t][c][n] += sum_{b,oy,ox} in(b, oy*s+dy[t], ox*s+dx[t], c) * g(b, oy, ox, n)
+//
+// GEMM view: M = input channel (32 per workgroup), N = output channel (64 per workgroup), K = pixels.
+// A workgroup walks TH x 16 pixel tiles; per tile it stages the input patch (tile + halo, 32
+// channels; same fused loaders as the forward kernel: concat, h*r, bilinear x2 (+skip), ReLU mask)
+// and the 128 x 64 gradient tile in LDS, then every filter tap is one 32x32 accumulator whose A
+// operand is the patch shifted by the tap offset.  The taps x 2 N-halves accumulators are spread
+// over the 4 waves (wave w: N-half w&1, taps (w>>1), (w>>1)+2, ...) and stay in registers for the
+// whole pixel range of the workgroup; partial sums of the pixel splits meet in a [tap][Cin][Cout]
+// fp32 workspace through coalesced atomic adds.  The bias gradient (column sums of g) rides along.
+#include "common.hpp"
+
+namespace ramnet {
+
+constexpr int WTH = 8;          // pixel tile = 8 x 16
+constexpr int WBN = 64;         // output channels per workgroup
+
+struct WgradDerived {
+    InSrc src;
+    int PH, PW, dymin, dxmin;
+    int tiles_x, tiles_y, ntiles;   // pixel tiles per image / total
+    int toff[25];
+};
+
+template <int MAXT>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_desc p, const WgradDerived q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                         // [PH*PW][32]
+    float *gsm = smem + q.PH * q.PW * WCK;       // [128][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ns = wave & 1, tap0 = wave >> 1;
+    const int ntw = (p.ntaps - tap0 + 1) / 2;    // taps owned by this wave: tap0, tap0+2, ...
+    const int c0 = blockIdx.y * WCK, n0 = blockIdx.z * WBN;
+
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int toffw[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) toffw[j] = j < ntw ? q.toff[tap0 + 2 * j] : 0;
+
+    float4 bsum = f4zero();                      // bias gradient partial: fixed channel quad (tid & 15)
+    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0;
+    const int nslots = q.PH * q.PW * (WCK / 4);
+
+    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+        int tt = tile;
+        const int tx_i = tt % q.tiles_x;
+        tt /= q.tiles_x;
+        const int ty_i = tt % q.tiles_y;
+        const int b = tt / q.tiles_y;
+        const int oy0 = ty_i * WTH, ox0 = tx_i * TWID;
+        const int iy0 = oy0 * p.stride + q.dymin, ix0 = ox0 * p.stride + q.dxmin;
+        __syncthreads();
+        for (int s = tid; s < nslots; s += 256) {
+            const int pix = s >> 3, qd = s & 7;
+            const int py = pix / q.PW, px = pix - py * q.PW;
+            st4(patch + pix * WCK + qd * 4, load_in4(q.src, b, iy0 + py, ix0 + px, c0 + qd * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {            // 128 pixels x 16 channel quads
+            const int s = tid + i * 256;
+            const int m = s >> 4, qd = s & 15;
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
+            float4 g = f4zero();
+            if (oy < p.Ho && ox < p.Wo && n < p.Cout) {
+                const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+                g = ld4(p.dout + pix * p.ldg + n);
+                if (p.gmask) {
+                    const float4 y = ld4(p.gmask + pix * p.ldgm + n);
+                    g = make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+                }
+            }
+            st4(gsm + m * WBN + qd * 4, g);
+            bsum = f4add(bsum, g);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 64; ++i) {           // K step = 2 pixels (lanes 0-31: pixel 2i, lanes 32-63: pixel 2i+1)
+            const int m = 2 * i + kk;
+            const float bv = gsm[m * WBN + ns * 32 + l31];
+            const float *pa = patch + (((m >> 4) * p.stride) * q.PW + (m & 15) * p.stride) * WCK + l31;
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j)
+                if (j < ntw) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[toffw[j]], bv, acc[j], 0, 0, 0);
+        }
+    }
+
+    // D[row = input channel][col = output channel] -> ws[(tap*Cin + c)*Cout + n]
+    const int Cin = q.src.Cin;
+    const int n = n0 + ns * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        if (j >= ntw) continue;
+        const int t = tap0 + 2 * j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)t * Cin + c) * p.Cout + n, acc[j][r]);
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        float *red = smem;                        // [16][64]
+        st4(red + (tid >> 4) * WBN + (tid & 15) * 4, bsum);
+        __syncthreads();
+        if (tid < WBN) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += red[g * WBN + tid];
+            if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, s);
+        }
+    }
+}
+
+template <int MAXT>
+static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipStream_t st) {
+    auto kern = conv_wgrad_kernel<MAXT>;
+    size_t lds = ((size_t)q.PH * q.PW * WCK + 128 * WBN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) {
+        set_error("wgrad patch does not fit LDS (%zu bytes)", lds);
+        return RAMNET_E_UNSUPPORTED;
+    }
+    const int gy = cdiv(q.src.Cin, WCK), gz = cdiv(d.Cout, WBN);
+    int splits = cdiv(1024, gy * gz);             // ~4 workgroups per CU worth of parallelism
+    if (splits > q.ntiles) splits = q.ntiles;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(kern, dim3(splits, gy, gz), dim3(256), lds, st, d, q);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
+    RAMNET_CHECK_ARG(dp != nullptr);
+    const ramnet_wgrad_desc &d = *dp;
+    RAMNET_CHECK_ARG(d.x0 && d.dout && d.dw);
+    RAMNET_CHECK_ARG(d.ntaps >= 1 && d.ntaps <= 25 && (d.stride == 1 || d.stride == 2));
+    RAMNET_CHECK_ARG(d.B > 0 && d.Ho > 0 && d.Wo > 0 && d.Cout > 0 && d.Cout % 4 == 0 && d.ldg % 4 == 0);
+    RAMNET_CHECK_ARG(d.C0 > 0 && d.C0 % 4 == 0 && d.ld0 % 4 == 0);
+    const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
+    if (cat) RAMNET_CHECK_ARG(d.x1 && d.C1 > 0 && d.C1 % 4 == 0 && d.ld1 % 4 == 0);
+    if (d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK) RAMNET_CHECK_ARG(d.xm && d.ldm % 4 == 0);
+    if (d.in_mode == RAMNET_IN_UP2X_SKIP) RAMNET_CHECK_ARG(d.x1 && d.ld1 % 4 == 0);
+    if (d.gmask) RAMNET_CHECK_ARG(d.ldgm % 4 == 0);
+
+    WgradDerived q;
+    q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
+    q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
+    q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
+    q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
+    for (int t = 0; t < d.ntaps; ++t) {
+        dymin = d.dy[t] < dymin ? d.dy[t] : dymin, dymax = d.dy[t] > dymax ? d.dy[t] : dymax;
+        dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin, dxmax = d.dx[t] > dxmax ? d.dx[t] : dxmax;
+    }
+    q.dymin = dymin, q.dxmin = dxmin;
+    q.PH = (WTH - 1) * d.stride + (dymax - dymin) + 1;
+    q.PW = (TWID - 1) * d.stride + (dxmax - dxmin) + 1;
+    q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, WTH);
+    q.ntiles = q.tiles_x * q.tiles_y * d.B;
+    for (int t = 0; t < d.ntaps; ++t) q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * WCK;
+    hipStream_t st = (hipStream_t)stream;
+    const int per_wave = (d.ntaps + 1) / 2;       // wave 0/1 own ceil(ntaps/2) taps
+    if (per_wave <= 1) return launch_wgrad<1>(d, q, st);
+    if (per_wave <= 5) return launch_wgrad<5>(d, q, st);
+    return launch_wgrad<13>(d, q, st);
+}

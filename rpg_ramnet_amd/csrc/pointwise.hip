@@ -1,0 +1,382 @@
+// HBM-bound kernels of the RAM-Net path: layout packing, the 1x1 prediction head, gate
+// backward formulas, the adjoint of the bilinear upsample.  All are float4-vectorised grid-stride
+// loops (coalesced 16 B per lane, 1 KiB per wavefront instruction).
+#include <stdarg.h>
+#include "common.hpp"
+
+namespace ramnet {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int grid_for(size_t n_items, int block = 256) {
+    size_t g = (n_items + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;   // 256 CUs x 8 workgroups, grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_pad_kernel(const float *__restrict__ src, float *__restrict__ dst, int B, int C, int HW, int Cpad) {
+    const size_t npix = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, s = i - b * HW;
+        const float *in = src + b * C * HW + s;
+        float *out = dst + i * Cpad;
+        for (int c = 0; c < Cpad; c += 4) {
+            float4 v;
+            v.x = c + 0 < C ? in[(size_t)(c + 0) * HW] : 0.f;
+            v.y = c + 1 < C ? in[(size_t)(c + 1) * HW] : 0.f;
+            v.z = c + 2 < C ? in[(size_t)(c + 2) * HW] : 0.f;
+            v.w = c + 3 < C ? in[(size_t)(c + 3) * HW] : 0.f;
+            st4(out + c, v);
+        }
+    }
+}
+
+// OIHW -> [tap][chunk][n][16].  transposed: reduce over O (backward-data), outputs = I.
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int T,
+                                   int transposed, int gates, int R, int N, int nchunks, int NPad, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ck = (int)(i % CK);
+        size_t j = i / CK;
+        const int n = (int)(j % NPad);
+        j /= NPad;
+        const int chunk = (int)(j % nchunks);
+        const int t = (int)(j / nchunks);
+        const int r = chunk * CK + ck;
+        int no = n;
+        bool ok = r < R;
+        if (gates > 1) {   // packed n = (channel block of 32, gate, channel in block) -> original gate*C + channel
+            const int C = N / gates, blk = n / (32 * gates), g = (n / 32) % gates, ch = blk * 32 + (n % 32);
+            ok = ok && ch < C;
+            no = g * C + ch;
+        } else {
+            ok = ok && n < N;
+        }
+        float v = 0.f;
+        if (ok) v = transposed ? w[((size_t)r * Cin + no) * T + t] : w[((size_t)no * Cin + r) * T + t];
+        wp[i] = v;
+    }
+}
+
+// ws [T][CinWs][Cout] -> grad OIHW [Cout][Cin][T] (+=)
+__global__ void unpack_wgrad_kernel(const float *__restrict__ ws, float *__restrict__ g, int Cout, int Cin, int CinWs, int CoutWs,
+                                    int n_off, int T, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % T);
+        const size_t j = i / T;
+        const int c = (int)(j % Cin), n = (int)(j / Cin);
+        g[i] += ws[((size_t)t * CinWs + c) * CoutWs + n_off + n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ simple maps
+__global__ void relu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dx, size_t n) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n4; i += stride) {
+        const float4 g = ld4(dy + 4 * i), v = ld4(y + 4 * i);
+        st4(dx + 4 * i, make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f));
+    }
+    for (size_t i = n4 * 4 + i0; i < n; i += stride) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, size_t n) {
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x, i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n4; i += stride) st4(y + 4 * i, f4add(ld4(a + 4 * i), ld4(b + 4 * i)));
+    for (size_t i = n4 * 4 + i0; i < n; i += stride) y[i] = a[i] + b[i];
+}
+
+// ------------------------------------------------------------------------------------------ prediction head
+// 8 lanes per pixel, each owns channel quads q, q+8, ...; butterfly over the 8 lanes.
+__global__ void pred_sigmoid_fwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
+                                        const float *__restrict__ bias, float *__restrict__ y, size_t npix) {
+    const int sub = threadIdx.x & 7;
+    const size_t stride = (size_t)gridDim.x * blockDim.x / 8;
+    const float b0 = bias ? bias[0] : 0.f;
+    for (size_t pix = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) / 8; pix < npix; pix += stride) {
+        float s = 0.f;
+        for (int c = sub * 4; c < C; c += 32) {
+                const float4 v = ld4(x + pix * ldx + c), ww = ld4(w + c);
+                s += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) y[pix] = sigmoidf_(s + b0);
+    }
+}
+
+__global__ void pred_sigmoid_bwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
+                                        const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                                        int lddx, float *__restrict__ dw, float *__restrict__ db, size_t npix) {
+    // thread (pixel slot, channel quad q = sub): fixed channel quads per thread -> private dw partials
+    __shared__ float red[32 * 4 * 8 + 32];
+    const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    const size_t stride = (size_t)gridDim.x * (blockDim.x / 8);
+    float4 dwp[4] = {f4zero(), f4zero(), f4zero(), f4zero()};   // C <= 128
+    float dbp = 0.f;
+    for (size_t pix = blockIdx.x * (size_t)(blockDim.x / 8) + slot; pix < npix; pix += stride) {
+        const float yy = y[pix];
+        const float dz = dy[pix] * yy * (1.0f - yy);
+        if (sub == 0) dbp += dz;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {            // static register indices (C <= 128)
+            const int c = sub * 4 + 32 * k;
+            if (c < C) {
+                const float4 v = ld4(x + pix * ldx + c), ww = ld4(w + c);
+                if (dx) st4(dx + pix * lddx + c, f4scale(ww, dz));
+                dwp[k] = f4add(dwp[k], f4scale(v, dz));
+            }
+        }
+    }
+    // reduce over the 32 pixel slots of the block, then one atomic per channel
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k * 32 >= C) break;
+        __syncthreads();
+        st4(red + (slot * 8 + sub) * 4, dwp[k]);
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int c = k * 32 + threadIdx.x;
+            float s = 0.f;
+            for (int g = 0; g < 32; ++g) s += red[g * 32 + threadIdx.x];
+            if (c < C) atomicAdd(dw + c, s);
+        }
+    }
+    __syncthreads();
+    if (sub == 0) red[slot] = dbp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int g = 0; g < 32; ++g) s += red[g];
+        atomicAdd(db, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ upsample adjoint
+__device__ __forceinline__ float up2x_weight(int dst, int src, int n_src) {
+    int i0, i1;
+    float l1;
+    up2x_coord(dst, n_src, i0, i1, l1);
+    return (i0 == src ? 1.0f - l1 : 0.f) + (i1 == src ? l1 : 0.f);
+}
+
+__global__ void upsample2x_bwd_kernel(const float *__restrict__ dup, float *__restrict__ dx, int B, int H, int W, int C) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        size_t j = i / C4;
+        const int x = (int)(j % W);
+        j /= W;
+        const int y = (int)(j % H), b = (int)(j / H);
+        float4 s = f4zero();
+        for (int Y = 2 * y - 1; Y <= 2 * y + 2; ++Y) {
+            if (Y < 0 || Y >= 2 * H) continue;
+            const float wy = up2x_weight(Y, y, H);
+            if (wy == 0.f) continue;
+            for (int X = 2 * x - 1; X <= 2 * x + 2; ++X) {
+                if (X < 0 || X >= 2 * W) continue;
+                const float wgt = wy * up2x_weight(X, x, W);
+                if (wgt == 0.f) continue;
+                s = f4add(s, f4scale(ld4(dup + (((size_t)b * 2 * H + Y) * 2 * W + X) * C + c), wgt));
+            }
+        }
+        st4(dx + i * 4, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GRU / LSTM backward maps
+// ur = [u | r] (2C per pixel).  dpur = [dpu | dpr].
+__global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__restrict__ ur, const float *__restrict__ o,
+                                 const float *__restrict__ h, float *__restrict__ dpo, float *__restrict__ dpur,
+                                 float *__restrict__ dh, size_t npix, int C) {
+    const int C4 = C / 4;
+    const size_t total = npix * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C4;
+        const int c = (int)(i - pix * C4) * 4;
+        const float4 g = ld4(dhn + pix * C + c), u = ld4(ur + pix * 2 * C + c), oo = ld4(o + pix * C + c);
+        const float4 hh = h ? ld4(h + pix * C + c) : f4zero();
+        float4 a, bq, d;
+#define RN_ONE(f)                                   \
+    a.f = g.f * u.f * (1.0f - oo.f * oo.f);         \
+    bq.f = g.f * (oo.f - hh.f) * u.f * (1.0f - u.f); \
+    d.f = g.f * (1.0f - u.f);
+        RN_ONE(x) RN_ONE(y) RN_ONE(z) RN_ONE(w)
+#undef RN_ONE
+        st4(dpo + pix * C + c, a);
+        st4(dpur + pix * 2 * C + c, bq);
+        st4(dh + pix * C + c, d);
+    }
+}
+
+// dxhr = [dx1 | d(h*r)] from the candidate conv's backward-data.  In place: second half <- dh_direct + dhr*r.
+__global__ void gru_bwd_b_kernel(float *__restrict__ dxhr, const float *__restrict__ ur, const float *__restrict__ h,
+                                 float *__restrict__ dpur, const float *__restrict__ dh, size_t npix, int C) {
+    const int C4 = C / 4;
+    const size_t total = npix * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C4;
+        const int c = (int)(i - pix * C4) * 4;
+        const float4 dhr = ld4(dxhr + pix * 2 * C + C + c), r = ld4(ur + pix * 2 * C + C + c), d0 = ld4(dh + pix * C + c);
+        const float4 hh = h ? ld4(h + pix * C + c) : f4zero();
+        float4 pr, d;
+#define RN_ONE(f)                                   \
+    pr.f = dhr.f * hh.f * r.f * (1.0f - r.f);       \
+    d.f = d0.f + dhr.f * r.f;
+        RN_ONE(x) RN_ONE(y) RN_ONE(z) RN_ONE(w)
+#undef RN_ONE
+        st4(dpur + pix * 2 * C + C + c, pr);
+        st4(dxhr + pix * 2 * C + C + c, d);
+    }
+}
+
+// gates = activated [i|f|o|g] (4C per pixel), natural order.
+__global__ void lstm_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ cprev, const float *__restrict__ cnew,
+                                const float *__restrict__ dhn, const float *__restrict__ dcn, float *__restrict__ dpre,
+                                float *__restrict__ dcprev, size_t npix, int C) {
+    const int C4 = C / 4;
+    const size_t total = npix * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C4;
+        const int c = (int)(i - pix * C4) * 4;
+        const float *gp = gates + pix * 4 * C + c;
+        const float4 gi = ld4(gp), gf = ld4(gp + C), go = ld4(gp + 2 * C), gc = ld4(gp + 3 * C);
+        const float4 cp = cprev ? ld4(cprev + pix * C + c) : f4zero(), cn = ld4(cnew + pix * C + c);
+        const float4 dh = dhn ? ld4(dhn + pix * C + c) : f4zero(), dc = dcn ? ld4(dcn + pix * C + c) : f4zero();
+        float4 pi, pf, po, pg, dp;
+#define RN_ONE(f)                                                   \
+    {                                                               \
+        const float tc = tanhf(cn.f);                               \
+        const float dct = dc.f + dh.f * go.f * (1.0f - tc * tc);    \
+        po.f = dh.f * tc * go.f * (1.0f - go.f);                    \
+        pf.f = dct * cp.f * gf.f * (1.0f - gf.f);                   \
+        pi.f = dct * gc.f * gi.f * (1.0f - gi.f);                   \
+        pg.f = dct * gi.f * (1.0f - gc.f * gc.f);                   \
+        dp.f = dct * gf.f;                                          \
+    }
+        RN_ONE(x) RN_ONE(y) RN_ONE(z) RN_ONE(w)
+#undef RN_ONE
+        float *op = dpre + pix * 4 * C + c;
+        st4(op, pi), st4(op + C, pf), st4(op + 2 * C, po), st4(op + 3 * C, pg);
+        st4(dcprev + pix * C + c, dp);
+    }
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" const char *ramnet_last_error(void) { return g_err; }
+extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
+
+extern "C" int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream) {
+    RAMNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 4 == 0);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H * W, Cpad);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+static void pack_geometry(int Cout, int Cin, int transposed, int gates, int &R, int &N, int &nchunks, int &NPad) {
+    R = transposed ? Cout : Cin;    // reduction extent
+    N = transposed ? Cin : Cout;    // produced channels
+    nchunks = cdiv(R, CK);
+    NPad = gates > 1 ? gates * roundup(N / gates, 32) : roundup(N, 32);
+}
+
+extern "C" size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates) {
+    int R, N, nchunks, NPad;
+    pack_geometry(Cout, Cin, transposed, gates, R, N, nchunks, NPad);
+    return (size_t)KH * KW * nchunks * NPad * CK;
+}
+
+extern "C" int ramnet_pack_weight(const float *w, float *wp, int Cout, int Cin, int KH, int KW, int transposed, int gates, void *stream) {
+    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 25);
+    RAMNET_CHECK_ARG(gates == 1 || (gates == 4 && !transposed && Cout % 4 == 0));
+    int R, N, nchunks, NPad;
+    pack_geometry(Cout, Cin, transposed, gates, R, N, nchunks, NPad);
+    const size_t total = (size_t)KH * KW * nchunks * NPad * CK;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KH * KW,
+                       transposed, gates, R, N, nchunks, NPad, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_unpack_wgrad(const float *ws, float *grad, int Cout, int Cin, int CinWs, int CoutWs, int n_off, int KH, int KW,
+                                   void *stream) {
+    RAMNET_CHECK_ARG(ws && grad && Cout > 0 && Cin > 0 && CinWs >= Cin && n_off >= 0 && CoutWs >= n_off + Cout);
+    const size_t total = (size_t)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ws, grad, Cout, Cin, CinWs, CoutWs, n_off, KH * KW, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *stream) {
+    RAMNET_CHECK_ARG(dy && y && dx);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_add(const float *a, const float *b, float *y, size_t n, void *stream) {
+    RAMNET_CHECK_ARG(a && b && y);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pred_sigmoid_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(x && w && y && C > 0 && C % 4 == 0 && ldx % 4 == 0);
+    hipLaunchKernelGGL(pred_sigmoid_fwd_kernel, dim3(grid_for(npix * 8)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, y, npix);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, float *dx,
+                                       int lddx, float *dw, float *db, size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
+    if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
+    int g = grid_for(npix * 8);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(pred_sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, dx, lddx, dw, db, npix);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream) {
+    RAMNET_CHECK_ARG(dup && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dup, dx, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_gru_bwd_a(const float *dhn, const float *ur, const float *o, const float *h, float *dpo, float *dpur,
+                                float *dh, size_t npix, int C, void *stream) {
+    RAMNET_CHECK_ARG(dhn && ur && o && dpo && dpur && dh && C % 4 == 0);
+    hipLaunchKernelGGL(gru_bwd_a_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ur, o, h, dpo, dpur, dh, npix, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_gru_bwd_b(const float *dxhr, const float *ur, const float *h, float *dpur, float *dh, size_t npix, int C, void *stream) {
+    RAMNET_CHECK_ARG(dxhr && ur && dpur && dh && C % 4 == 0);
+    hipLaunchKernelGGL(gru_bwd_b_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, const_cast<float *>(dxhr), ur, h, dpur, dh, npix, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_lstm_bwd(const float *gates, const float *cprev, const float *cnew, const float *dhn, const float *dcn,
+                               float *dpre, float *dcprev, size_t npix, int C, void *stream) {
+    RAMNET_CHECK_ARG(gates && cnew && dpre && dcprev && C % 4 == 0);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, gates, cprev, cnew, dhn, dcn, dpre, dcprev, npix, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,158 @@
+"""Drop-in for RAM_Net/model/model.py: ``ERGB2DepthRecurrent`` / ``ERGB2Depth`` with the reference's constructor
+(config dict, same keys/defaults, model.py:12-77), call contract (model.py:141-219, :93-111), return structure and
+``state_dict`` layout — computed by hand-written HIP kernels on MI355X.
+
+    preds, super_states, states_lstm = model(item, prev_super_states, prev_states_lstm)
+
+`item` holds NCHW float tensors (CPU or device) exactly as the reference's data loader yields them; predictions are
+NCHW [B,1,H,W] in [0,1]; states are returned as NCHW-shaped views of the NHWC (channels_last) device buffers and
+are accepted back unchanged (zero copy).  A previous state is never modified in place.
+"""
+import logging
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .statenet import StateNetPhasedRecurrent
+from .unet import UNet
+
+
+class BaseModel(nn.Module):
+    """Same surface as RAM_Net/base/base_model.py:6-30 (config, logger, summary())."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.logger = logging.getLogger(self.__class__.__name__)
+
+    def forward(self, *input):
+        raise NotImplementedError
+
+    def summary(self):
+        params = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
+        self.logger.info('Trainable parameters: {}'.format(params))
+        self.logger.info(self)
+
+
+def _to_nchw(s):
+    """NHWC buffer -> NCHW-shaped view (what callers of the reference expect to index/plot)."""
+    if s is None:
+        return None
+    if isinstance(s, (list, tuple)):
+        return type(s)(_to_nchw(t) for t in s)
+    return s.permute(0, 3, 1, 2)
+
+
+def _to_nhwc(s):
+    if s is None:
+        return None
+    if isinstance(s, (list, tuple)):
+        return type(s)(_to_nhwc(t) for t in s)
+    return s.permute(0, 2, 3, 1)
+
+
+class BaseERGB2Depth(BaseModel):
+    def __init__(self, config):
+        super().__init__(config)
+        assert ('num_bins_rgb' in config)
+        self.num_bins_rgb = int(config['num_bins_rgb'])
+        assert ('num_bins_events' in config)
+        self.num_bins_events = int(config['num_bins_events'])
+        self.skip_type = str(config.get('skip_type', 'sum'))
+        self.state_combination = str(config.get('state_combination', 'sum'))
+        self.num_encoders = int(config.get('num_encoders', 4))
+        self.base_num_channels = int(config.get('base_num_channels', 32))
+        self.num_residual_blocks = int(config.get('num_residual_blocks', 2))
+        self.recurrent_block_type = str(config.get('recurrent_block_type', 'convlstm'))
+        self.norm = str(config['norm']) if 'norm' in config else None
+        self.use_upsample_conv = bool(config.get('use_upsample_conv', True))
+        self.every_x_rgb_frame = config.get('every_x_rgb_frame', 1)
+        self.baseline = config.get('baseline', False)
+        self.loss_composition = config.get('loss_composition', False)
+        self.kernel_size = int(config.get('kernel_size', 5))
+        self.gpu = torch.device('cuda:' + str(config['gpu']))     # KeyError when absent, like model.py:77
+
+
+class ERGB2Depth(BaseERGB2Depth):
+    def __init__(self, config):
+        super().__init__(config)
+        self.unet = UNet(num_input_channels=self.num_bins_rgb, num_output_channels=1, skip_type=self.skip_type,
+                         activation='sigmoid', num_encoders=self.num_encoders,
+                         base_num_channels=self.base_num_channels, num_residual_blocks=self.num_residual_blocks,
+                         norm=self.norm, use_upsample_conv=self.use_upsample_conv)
+
+    def forward(self, item, prev_super_states, prev_states_lstm):
+        x = ops.pack_input(item["image"], self.gpu)
+        return {"image": self.unet(x)}, {'image': None}, prev_states_lstm
+
+
+class ERGB2DepthRecurrent(BaseERGB2Depth):
+    """Recurrent asynchronous multimodal network: per-modality encoders update a shared multi-scale state."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.statenetphasedrecurrent = StateNetPhasedRecurrent(
+            num_input_channels_rgb=self.num_bins_rgb, num_input_channels_events=self.num_bins_events,
+            num_output_channels=1, skip_type=self.skip_type, state_combination=self.state_combination,
+            activation='sigmoid', num_encoders=self.num_encoders, base_num_channels=self.base_num_channels,
+            num_residual_blocks=self.num_residual_blocks, norm=self.norm, use_upsample_conv=self.use_upsample_conv,
+            recurrent_block_type=self.recurrent_block_type, baseline=self.baseline)
+        self.max_num_channels = self.base_num_channels * pow(2, self.num_encoders)
+
+    # -- primitive API for irregular schedules (BASELINE.json config 4): one modality update / one decode per call
+    def init_states(self, B, H, W):
+        pair = (not bool(self.baseline)) and self.state_combination == 'convlstm'
+        out = []
+        for i in range(self.num_encoders):
+            shp = [B, int(H / pow(2, i + 1)), int(W / pow(2, i + 1)), int(self.base_num_channels * pow(2, i + 1))]
+            out.append([torch.zeros(shp, device=self.gpu), torch.zeros(shp, device=self.gpu)] if pair
+                       else torch.zeros(shp, device=self.gpu))
+        return out
+
+    def forward(self, item, prev_super_states, prev_states_lstm):
+        net = self.statenetphasedrecurrent
+        predictions_dict, super_state_dict, states_lstm_dict = {}, {}, {}
+        if prev_super_states is None:
+            B, _, H, W = item['image'].shape
+            states = self.init_states(B, H, W)
+        else:
+            states = [_to_nhwc(s) for s in prev_super_states]
+        K, baseline, lc = self.every_x_rgb_frame, self.baseline, self.loss_composition
+
+        def lstm_in(d):       # states_lstm dicts cross the boundary NCHW-shaped too
+            return None if d is None else {'encoders': [_to_nhwc(s) for s in d['encoders']],
+                                           'state_comb': [_to_nhwc(s) for s in d['state_comb']]}
+
+        def emit(key, pred, ss, sl):
+            predictions_dict[key] = pred
+            views = [_to_nchw(s) for s in ss]
+            super_state_dict[key] = views
+            comb = []
+            for s_in, v, c in zip(ss, views, sl['state_comb']):
+                comb.append(v if c is s_in else _to_nchw(c))         # GRU mode: state_comb[i] IS super_state[i]
+            states_lstm_dict[key] = {'encoders': [_to_nchw(s) for s in sl['encoders']], 'state_comb': comb}
+
+        events_as_image = baseline == "ergb0" or (baseline == "e" and lc == "image")
+        last = None
+        if not bool(baseline) or events_as_image:
+            if events_as_image:
+                loop_range, last = K - 1, lstm_in(prev_states_lstm['image'])
+            else:
+                loop_range, last = K, lstm_in(prev_states_lstm['events{}'.format(K - 1)])
+            for k in range(loop_range):
+                x = ops.pack_input(item['events{}'.format(k)], self.gpu)
+                if baseline == "ergb0" or baseline == 'e':
+                    ss, sl = net.forward_images(x, states, last)
+                else:
+                    ss, sl = net.forward_events(x, states, last)
+                emit('events{}'.format(k), net.forward_decoder(ss), ss, sl)
+                states, last = ss, sl
+
+        x = ops.pack_input(item['image'], self.gpu)
+        if not bool(baseline) or baseline == "rgb" or (baseline == "e" and lc != "image"):
+            last = lstm_in(prev_states_lstm['image'])
+        ss, sl = net.forward_images(x, states, last)
+        emit('image', net.forward_decoder(ss), ss, sl)
+        return predictions_dict, super_state_dict, states_lstm_dict

@@ -1,0 +1,120 @@
+"""StateNetPhasedRecurrent on HIP kernels — same sub-module names, construction order (=> identical seeded
+initialisation) and forward contract as RAM_Net/model/statenet.py:120-315.  Activations are NHWC internally.
+
+Combinations that raise inside the reference itself are refused at construction (DESIGN.md "out of scope"):
+state_combination 'sum'/'conv' (tuple-unpack of a tensor, statenet.py:230-233), skip_type != 'sum' for the
+recurrent net (decoder 0 gets no skip, statenet.py:107 vs :302).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .submodules import ConvLayer, UpsampleConvLayer, TransposedConvLayer, RecurrentConvLayer, Recurrent2ConvLayer, \
+    ResidualBlock
+
+
+class StateNetPhasedRecurrent(nn.Module):
+    def __init__(self, num_input_channels_rgb, num_input_channels_events, num_output_channels=1, skip_type='sum',
+                 state_combination='sum', activation='sigmoid', num_encoders=4, base_num_channels=32,
+                 num_residual_blocks=2, norm=None, use_upsample_conv=True, recurrent_block_type='convlstm',
+                 baseline=False):
+        super().__init__()
+        if skip_type not in ('sum', 'concat', 'no_skip', None):
+            raise KeyError('Could not identify skip_type, please add "skip_type":'
+                           ' "sum", "concat" or "no_skip" to config["model"]')
+        if state_combination not in ('sum', 'conv', 'convlstm', 'convgru'):
+            raise KeyError('Could not identify state_combination, please add "state_combination":'
+                           ' "sum", "conv", "convlstm" or "convgru" to config["model"]')
+        if skip_type != 'sum':
+            raise NotImplementedError("recurrent net: only skip_type 'sum' runs in the reference (statenet.py:107 vs :302)")
+        if state_combination not in ('convlstm', 'convgru'):
+            raise NotImplementedError("state_combination %r raises in the reference (statenet.py:230-233)" % state_combination)
+        assert activation == 'sigmoid' and num_output_channels == 1
+        assert recurrent_block_type in ('conv', 'convlstm')
+        self.skip_type, self.state_combination = skip_type, state_combination
+        self.recurrent_block_type, self.norm, self.baseline = recurrent_block_type, norm, baseline
+        self.num_encoders, self.base_num_channels = num_encoders, base_num_channels
+        self.num_residual_blocks = num_residual_blocks
+        self.max_num_channels = base_num_channels * pow(2, num_encoders)
+        if use_upsample_conv:
+            print('Using UpsampleConvLayer (slow, but no checkerboard artefacts)')
+            Up = UpsampleConvLayer
+        else:
+            print('Using TransposedConvLayer (fast, with checkerboard artefacts)')
+            Up = TransposedConvLayer
+        enc_in = [base_num_channels * pow(2, i) for i in range(num_encoders)]
+        enc_out = [base_num_channels * pow(2, i + 1) for i in range(num_encoders)]
+
+        # --- construction order mirrors statenet.py:139-202 (RNG stream => same seeded weights)
+        self.head_rgb = ConvLayer(num_input_channels_rgb, base_num_channels, kernel_size=5, stride=1, padding=2)
+        self.encoders_rgb = nn.ModuleList()
+        if not bool(baseline):
+            self.head_events = ConvLayer(num_input_channels_events, base_num_channels, kernel_size=5, stride=1, padding=2)
+            self.encoders_events = nn.ModuleList()
+            self.state_combination_events = nn.ModuleList()
+        self.state_combination_images = nn.ModuleList()
+        for cin, cout in zip(enc_in, enc_out):
+            if recurrent_block_type == 'convlstm':
+                mk = lambda: Recurrent2ConvLayer(cin, cout, kernel_size=5, stride=2, padding=2, norm=norm,  # noqa: E731
+                                                 recurrent_block_type='convlstm')
+            else:
+                mk = lambda: ConvLayer(cin, cout, kernel_size=5, stride=2, padding=2, norm=norm)  # noqa: E731
+            self.encoders_rgb.append(mk())
+            if not bool(baseline):
+                self.encoders_events.append(mk())
+                self.state_combination_events.append(RecurrentConvLayer(cout, cout, recurrent_block_type=state_combination))
+            self.state_combination_images.append(RecurrentConvLayer(cout, cout, recurrent_block_type=state_combination))
+        self.resblocks = nn.ModuleList([ResidualBlock(self.max_num_channels, self.max_num_channels, norm=norm)
+                                        for _ in range(num_residual_blocks)])
+        self.decoders = nn.ModuleList([Up(c, c // 2, kernel_size=5, padding=2, norm=norm) for c in reversed(enc_out)])
+        self.pred = ConvLayer(base_num_channels, num_output_channels, 1, activation=None, norm=norm)
+
+    # ---------------------------------------------------------------------------------------------- encoders
+    def _encode(self, x, head, encoders, combs, prev_super_state, prev_states_lstm, feed_state_forward):
+        n = self.num_encoders
+        x = head(x)
+        if prev_states_lstm is None:
+            prev_states_lstm = {'encoders': [None] * n, 'state_comb': [None] * n}
+        super_states, states_lstm = [], {'encoders': [], 'state_comb': []}
+        for i, encoder in enumerate(encoders):
+            if self.recurrent_block_type == 'conv':
+                x, enc_state = encoder(x), None
+            else:
+                x, enc_state = encoder(x, prev_states_lstm['encoders'][i])
+            if not feed_state_forward:
+                # RAM-Net: the shared state is updated; the ENCODER feature x feeds the next scale (statenet.py:215-237)
+                if self.state_combination == 'convlstm':
+                    _, super_state = combs[i](x, prev_super_state[i])       # h and c both from the shared state
+                else:
+                    _, super_state = combs[i](x, prev_super_state[i])
+                state_comb = super_state
+                super_states.append(super_state)
+            else:
+                # baselines: the recurrent OUTPUT feeds the next encoder (statenet.py:276-283)
+                if self.state_combination == 'convlstm':
+                    x, state_comb = combs[i](x, prev_states_lstm['state_comb'][i])
+                else:
+                    x, state_comb = combs[i](x, prev_super_state[i])
+                super_states.append(x)
+            states_lstm['encoders'].append(enc_state)
+            states_lstm['state_comb'].append(state_comb)
+        return super_states, states_lstm
+
+    def forward_events(self, x, prev_super_state, prev_states_lstm, times=None):
+        return self._encode(x, self.head_events, self.encoders_events, self.state_combination_events,
+                            prev_super_state, prev_states_lstm, False)
+
+    def forward_images(self, x, prev_super_state, prev_states_lstm, times=None):
+        return self._encode(x, self.head_rgb, self.encoders_rgb, self.state_combination_images,
+                            prev_super_state, prev_states_lstm, bool(self.baseline))
+
+    # ---------------------------------------------------------------------------------------------- decoder
+    def forward_decoder(self, super_states):
+        pair = (not bool(self.baseline)) and self.state_combination == 'convlstm'
+        pick = (lambda s: s[0]) if pair else (lambda s: s)
+        x = pick(super_states[-1])
+        for rb in self.resblocks:
+            x = rb(x)
+        for i, dec in enumerate(self.decoders):
+            x = dec(x) if i == 0 else dec(x, pick(super_states[self.num_encoders - i - 1]))   # no skip into decoder 0
+        return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

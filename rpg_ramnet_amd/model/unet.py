@@ -1,0 +1,46 @@
+"""Non-recurrent UNet (ERGB2Depth baseline) on HIP kernels; names/order as RAM_Net/model/unet.py:87-130."""
+import torch.nn as nn
+
+from .. import ops
+from .submodules import ConvLayer, UpsampleConvLayer, TransposedConvLayer, ResidualBlock
+
+
+class UNet(nn.Module):
+    def __init__(self, num_input_channels, num_output_channels=1, skip_type='sum', activation='sigmoid',
+                 num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None, use_upsample_conv=True):
+        super().__init__()
+        if skip_type not in ('sum', 'concat', 'no_skip', None):
+            raise KeyError('Could not identify skip_type, please add "skip_type":'
+                           ' "sum", "concat" or "no_skip" to config["model"]')
+        if skip_type != 'sum':
+            raise NotImplementedError("UNet on the HIP path: skip_type 'sum' only (the shipped config)")
+        assert activation == 'sigmoid' and num_output_channels == 1
+        self.num_encoders = num_encoders
+        if use_upsample_conv:
+            print('Using UpsampleConvLayer (slow, but no checkerboard artefacts)')
+            Up = UpsampleConvLayer
+        else:
+            print('Using TransposedConvLayer (fast, with checkerboard artefacts)')
+            Up = TransposedConvLayer
+        max_c = base_num_channels * pow(2, num_encoders)
+        enc_in = [base_num_channels * pow(2, i) for i in range(num_encoders)]
+        enc_out = [base_num_channels * pow(2, i + 1) for i in range(num_encoders)]
+        self.head = ConvLayer(num_input_channels, base_num_channels, kernel_size=5, stride=1, padding=2)
+        self.encoders = nn.ModuleList([ConvLayer(i, o, kernel_size=5, stride=2, padding=2, norm=norm)
+                                       for i, o in zip(enc_in, enc_out)])
+        self.resblocks = nn.ModuleList([ResidualBlock(max_c, max_c, norm=norm) for _ in range(num_residual_blocks)])
+        self.decoders = nn.ModuleList([Up(c, c // 2, kernel_size=5, padding=2, norm=norm) for c in reversed(enc_out)])
+        self.pred = ConvLayer(base_num_channels, num_output_channels, 1, activation=None, norm=norm)
+
+    def forward(self, x):
+        x = self.head(x)
+        head, blocks = x, []
+        for enc in self.encoders:
+            x = enc(x)
+            blocks.append(x)
+        for rb in self.resblocks:
+            x = rb(x)
+        for i, dec in enumerate(self.decoders):
+            x = dec(x, blocks[self.num_encoders - i - 1])           # every decoder gets its skip (unet.py:126-127)
+        x = ops.Add.apply(x, head)                                   # head skip (unet.py:129)
+        return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

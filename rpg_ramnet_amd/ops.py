@@ -1,0 +1,449 @@
+"""Autograd operators of the RAM-Net hot path; every forward AND backward is a HIP kernel launch
+through the C ABI (include/ramnet_hip.h).  torch supplies device memory, streams and the autograd graph.
+
+Activations are NHWC tensors [B, H, W, C] (fp32).  Weight gradients are accumulated by the weight-gradient
+kernel into per-layer [tap][Cin][Cout] workspaces over ALL time steps of a BPTT backward pass and folded into
+``param.grad`` (OIHW) once, by a callback queued on the autograd engine (the reference gets the same sums from
+autograd's per-use accumulation, lstm_trainer.py:450).
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _hip as H
+
+_NULL = None
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, off=0):
+    return None if t is None else C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def dense(t):
+    """NHWC tensor usable by the kernels as (ptr, ld): unit channel stride, 16-byte aligned pixels."""
+    if t is None:
+        return None
+    B, Hh, W, Cc = t.shape
+    s = t.stride()
+    ok = (s[3] == 1 or Cc == 1) and s[2] % 4 == 0 and s[1] == W * s[2] and s[0] == Hh * s[1] and t.data_ptr() % 16 == 0
+    if ok and t.dtype == torch.float32:
+        return t
+    return t.contiguous().float()
+
+
+def ld(t):
+    return t.stride(2)
+
+
+# ------------------------------------------------------------------------------------------------ tap lists
+class Taps:
+    """(dy, dx, weight-slice) triples of one launch, pre-converted to ctypes arrays."""
+    _cache = {}
+
+    def __init__(self, triples):
+        self.n = len(triples)
+        assert 1 <= self.n <= 25
+        self.dy = (C.c_int8 * 25)(*[t[0] for t in triples])
+        self.dx = (C.c_int8 * 25)(*[t[1] for t in triples])
+        self.wt = (C.c_uint8 * 25)(*[t[2] for t in triples])
+
+    @classmethod
+    def get(cls, kind, k, pad, py=0, px=0):
+        key = (kind, k, pad, py, px)
+        if key not in cls._cache:
+            if kind == "conv":        # forward taps: in(o*s + kh - pad)
+                tr = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
+            elif kind == "dgrad1":    # backward-data of a stride-1 conv: dy(o + pad - kh)
+                tr = [(pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k)]
+            elif kind == "dgrad2":    # backward-data of a stride-2 conv, output parity class (py, px)
+                tr = [((py + pad - kh) // 2, (px + pad - kw) // 2, kh * k + kw)
+                      for kh in range(k) for kw in range(k)
+                      if (py + pad - kh) % 2 == 0 and (px + pad - kw) % 2 == 0]
+            else:
+                raise KeyError(kind)
+            cls._cache[key] = cls(tr)
+        return cls._cache[key]
+
+
+def conv_launch(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
+                C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
+                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0):
+    B = x0.shape[0]
+    d = H.ConvDesc()
+    d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
+    d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
+    d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
+    d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
+    d.ntaps, d.stride = taps.n, stride
+    d.dy, d.dx, d.wtap = taps.dy, taps.dx, taps.wt
+    d.w, d.bias = _p(w), _p(bias)
+    d.Cout = Cout
+    d.HoF, d.WoF = out.shape[1], out.shape[2]
+    d.Ho, d.Wo = (d.HoF if Ho is None else Ho), (d.WoF if Wo is None else Wo)
+    d.osy, d.osx, d.ooy, d.oox = os
+    d.epi, d.beta = epi, beta
+    d.e0, d.e1 = _p(e0), _p(e1)
+    d.lde0, d.lde1 = (ld(e0) if e0 is not None else 0), (ld(e1) if e1 is not None else 0)
+    d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
+    d.ldo, d.ldo1, d.ldo2 = ld(out), (ld(o1) if o1 is not None else 0), (ld(o2) if o2 is not None else 0)
+    H.check(H.lib().ramnet_conv_launch(C.byref(d), _st()), "ramnet_conv_launch")
+
+
+def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
+                 C1=0, Hin=None, Win=None, gmask=None, dbias=None):
+    d = H.WgradDesc()
+    d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
+    d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
+    d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
+    d.B, d.Hin, d.Win = x0.shape[0], (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
+    d.ntaps, d.stride = taps.n, stride
+    d.dy, d.dx = taps.dy, taps.dx
+    d.dout, d.gmask = _p(dout), _p(gmask)
+    d.ldg, d.ldgm = ld(dout), (ld(gmask) if gmask is not None else 0)
+    d.Cout, d.Ho, d.Wo = Cout, dout.shape[1], dout.shape[2]
+    d.dw, d.dbias = _p(dw), _p(dbias)
+    H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
+
+
+# ------------------------------------------------------------------------------------------------ parameters
+class _Engine:
+    """Per-backward-pass bookkeeping: fold weight-gradient workspaces into .grad when the engine finishes."""
+    dirty = []
+    queued = False
+
+    @classmethod
+    def mark(cls, cp):
+        if not cp._dirty:
+            cp._dirty = True
+            cls.dirty.append(cp)
+        if not cls.queued:
+            cls.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+
+    @classmethod
+    def flush(cls):
+        for cp in cls.dirty:
+            cp.finalize()
+        cls.dirty, cls.queued = [], False
+
+
+def ensure_grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class ConvParam:
+    """Kernel-side state of one convolution: packed weights (forward / backward-data layouts, re-packed when the
+    nn.Parameter version changes) and the weight/bias gradient workspaces.  ``weights`` may hold several OIHW
+    parameters that are fused along O into one launch (ConvGRU update|reset gates)."""
+
+    def __init__(self, weights, biases, gates=1):
+        self.weights, self.biases, self.gates = list(weights), list(biases), gates
+        w0 = self.weights[0]
+        self.Cout = sum(w.shape[0] for w in self.weights)
+        self.Cin, self.k = w0.shape[1], w0.shape[2]
+        self.CinWs = (self.Cin + 3) // 4 * 4
+        self._fwd = self._bwd = self._bias = self._ws = self._bws = None
+        self._vf = self._vb = self._vbias = None
+        self._dirty = False
+
+    def _versions(self, ts):
+        return tuple((t._version, t.data_ptr()) for t in ts)
+
+    def _cat_w(self):
+        w = self.weights[0] if len(self.weights) == 1 else torch.cat([w.detach() for w in self.weights], 0)
+        return w.detach().contiguous()
+
+    def _pack(self, transposed):
+        n = H.lib().ramnet_packed_weight_elems(self.Cout, self.Cin, self.k, self.k, transposed, self.gates if not transposed else 1)
+        w = self._cat_w()
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+        H.check(H.lib().ramnet_pack_weight(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, transposed,
+                                           self.gates if not transposed else 1, _st()), "ramnet_pack_weight")
+        return out
+
+    def fwd(self):
+        v = self._versions(self.weights)
+        if self._fwd is None or v != self._vf:
+            self._fwd, self._vf = self._pack(0), v
+        return self._fwd
+
+    def bwd(self):
+        v = self._versions(self.weights)
+        if self._bwd is None or v != self._vb:
+            self._bwd, self._vb = self._pack(1), v
+        return self._bwd
+
+    def bias(self):
+        if len(self.biases) == 1:
+            return self.biases[0].detach()
+        v = self._versions(self.biases)
+        if self._bias is None or v != self._vbias:
+            self._bias, self._vbias = torch.cat([b.detach() for b in self.biases]).contiguous(), v
+        return self._bias
+
+    def grad_ws(self):
+        """([tap][CinWs][Cout] weight-gradient workspace, [Cout] bias-gradient workspace), zero at pass start."""
+        if self._ws is None:
+            dev = self.weights[0].device
+            self._ws = torch.zeros(self.k * self.k * self.CinWs * self.Cout, device=dev)
+            self._bws = torch.zeros(self.Cout, device=dev)
+        _Engine.mark(self)
+        return self._ws, self._bws
+
+    def finalize(self):
+        off = 0
+        for w, b in zip(self.weights, self.biases):
+            n = w.shape[0]
+            g = ensure_grad(w)
+            H.check(H.lib().ramnet_unpack_wgrad(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off,
+                                                self.k, self.k, _st()), "ramnet_unpack_wgrad")
+            ensure_grad(b).add_(self._bws[off:off + n])
+            off += n
+        self._ws.zero_()
+        self._bws.zero_()
+        self._dirty = False
+
+
+# ------------------------------------------------------------------------------------------------ operators
+def pack_input(x, device):
+    """Model input NCHW (any device) -> NHWC with channels zero-padded to a multiple of 4 (model.py:177,200)."""
+    x = x.to(device=device, dtype=torch.float32).contiguous()
+    B, Cc, Hh, W = x.shape
+    cp = (Cc + 3) // 4 * 4
+    out = torch.empty(B, Hh, W, cp, device=device)
+    H.check(H.lib().ramnet_nchw_to_nhwc_pad(_p(x), _p(out), B, Cc, Hh, W, cp, _st()), "ramnet_nchw_to_nhwc_pad")
+    return out
+
+
+class ConvAct(Function):
+    """ConvLayer / UpsampleConvLayer (submodules.py:8-35, 69-97): [bilinear x2 of (x [+ skip])] -> KxK conv -> bias -> [ReLU]."""
+
+    @staticmethod
+    def forward(ctx, x, skip, w, b, cp, stride, relu, up):
+        x, skip = dense(x), dense(skip)
+        B, Hh, W, _ = x.shape
+        k, pad = cp.k, cp.k // 2
+        Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
+        Ho, Wo = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
+        y = torch.empty(B, Ho, Wo, cp.Cout, device=x.device)
+        mode = (H.IN_UP2X_SKIP if skip is not None else H.IN_UP2X) if up else H.IN_PLAIN
+        conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
+                    Hin=Hin, Win=Win, bias=cp.bias(), epi=H.EPI_RELU if relu else H.EPI_LINEAR)
+        ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode = cp, stride, relu, up, mode
+        ctx.save_for_backward(x, skip, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, skip, y = ctx.saved_tensors
+        cp, stride, relu, up, mode = ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode
+        dy = dense(dy)
+        B, Hh, W, _ = x.shape
+        k, pad = cp.k, cp.k // 2
+        Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
+        ws, bws = cp.grad_ws()
+        wgrad_launch(x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
+                     Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
+        dx = dskip = None
+        if ctx.needs_input_grad[0] or (skip is not None and ctx.needs_input_grad[1]):
+            gin = torch.empty(B, Hin, Win, cp.Cin, device=x.device)
+            gmode = H.IN_RELUMASK if relu else H.IN_PLAIN
+            if stride == 1:
+                conv_launch(dy, Taps.get("dgrad1", k, pad), cp.bwd(), gin, cp.Cin, xm=y if relu else None, in_mode=gmode)
+            else:
+                for py in range(2):
+                    for px in range(2):
+                        conv_launch(dy, Taps.get("dgrad2", k, pad, py, px), cp.bwd(), gin, cp.Cin,
+                                    xm=y if relu else None, in_mode=gmode,
+                                    Ho=(Hin - py + 1) // 2, Wo=(Win - px + 1) // 2, os=(2, 2, py, px))
+            if up:
+                dx = torch.empty(B, Hh, W, cp.Cin, device=x.device)
+                H.check(H.lib().ramnet_upsample2x_bwd(_p(gin), _p(dx), B, Hh, W, cp.Cin, _st()), "ramnet_upsample2x_bwd")
+            else:
+                dx = gin
+            dskip = dx if skip is not None else None
+        return dx, dskip, None, None, None, None, None, None
+
+
+class ResConv(Function):
+    """Second half of ResidualBlock (submodules.py:205-214): relu(conv3x3(t) + b + residual)."""
+
+    @staticmethod
+    def forward(ctx, t, res, w, b, cp):
+        t, res = dense(t), dense(res)
+        y = torch.empty_like(res, memory_format=torch.contiguous_format)
+        conv_launch(t, Taps.get("conv", 3, 1), cp.fwd(), y, cp.Cout, bias=cp.bias(), epi=H.EPI_RES_RELU, e0=res)
+        ctx.cp = cp
+        ctx.save_for_backward(t, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, y = ctx.saved_tensors
+        cp = ctx.cp
+        dy = dense(dy)
+        dpre = torch.empty_like(y)
+        H.check(H.lib().ramnet_relu_bwd(_p(dy.contiguous()), _p(y), _p(dpre), y.numel(), _st()), "ramnet_relu_bwd")
+        ws, bws = cp.grad_ws()
+        wgrad_launch(t, Taps.get("conv", 3, 1), dpre, ws, cp.Cout, dbias=bws)
+        dt = torch.empty_like(t, memory_format=torch.contiguous_format)
+        conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dt, cp.Cin)
+        return dt, dpre, None, None, None
+
+
+class GRUCell(Function):
+    """ConvGRU (submodules.py:436-454) as two fused launches: [u|r] = sigmoid(W_ur*[x,h]) and
+    h' = h(1-u) + tanh(W_o*[x, h.r]) u (concat, h.r, tanh and the blend never touch HBM separately)."""
+
+    @staticmethod
+    def forward(ctx, x, h, wu, bu, wr, br, wo, bo, cp_ur, cp_o):
+        x, h = dense(x), dense(h)
+        B, Hh, W, Cc = x.shape
+        taps = Taps.get("conv", 3, 1)
+        ur = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
+        conv_launch(x, taps, cp_ur.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp_ur.bias(), epi=H.EPI_SIGMOID)
+        hn = torch.empty(B, Hh, W, Cc, device=x.device)
+        need = any(ctx.needs_input_grad)
+        o = torch.empty_like(hn) if need else None
+        conv_launch(x, taps, cp_o.fwd(), hn, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, bias=cp_o.bias(),
+                    epi=H.EPI_GRU_BLEND, e0=ur, e1=h, o1=o)
+        ctx.cps = (cp_ur, cp_o)
+        if need:
+            ctx.save_for_backward(x, h, ur, o)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        x, h, ur, o = ctx.saved_tensors
+        cp_ur, cp_o = ctx.cps
+        B, Hh, W, Cc = x.shape
+        npix = B * Hh * W
+        dhn = dense(dhn).contiguous()
+        L = H.lib()
+        dpo = torch.empty_like(o)
+        dpur = torch.empty_like(ur)
+        dhd = torch.empty_like(o)
+        H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_a")
+        taps, tapsd = Taps.get("conv", 3, 1), Taps.get("dgrad1", 3, 1)
+        ws, bws = cp_o.grad_ws()
+        wgrad_launch(x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
+        dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)       # [dx | dh]
+        conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
+        H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
+        ws, bws = cp_ur.grad_ws()
+        wgrad_launch(x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
+        conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)
+        return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None
+
+
+class LSTMCell(Function):
+    """ConvLSTM (submodules.py:318-358): one launch; the gate non-linearities and the cell update are the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, w, b, cp):
+        x, h, c = dense(x), dense(h), dense(c)
+        B, Hh, W, Cc = x.shape
+        hn = torch.empty(B, Hh, W, Cc, device=x.device)
+        cn = torch.empty_like(hn)
+        need = any(ctx.needs_input_grad)
+        gates = torch.empty(B, Hh, W, 4 * Cc, device=x.device) if need else None
+        conv_launch(x, Taps.get("conv", 3, 1), cp.fwd(), hn, Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp.bias(),
+                    epi=H.EPI_LSTM, e1=c, o1=cn, o2=gates)
+        ctx.cp = cp
+        if need:
+            ctx.save_for_backward(x, h, c, cn, gates)
+        return hn, cn
+
+    @staticmethod
+    def backward(ctx, dhn, dcn):
+        x, h, c, cn, gates = ctx.saved_tensors
+        cp = ctx.cp
+        B, Hh, W, Cc = x.shape
+        npix = B * Hh * W
+        dhn = None if dhn is None else dense(dhn).contiguous()
+        dcn = None if dcn is None else dense(dcn).contiguous()
+        dpre = torch.empty_like(gates)
+        dc = torch.empty_like(cn)
+        H.check(H.lib().ramnet_lstm_bwd(_p(gates), _p(c), _p(cn), _p(dhn), _p(dcn), _p(dpre), _p(dc), npix, Cc, _st()), "lstm_bwd")
+        ws, bws = cp.grad_ws()
+        wgrad_launch(x, Taps.get("conv", 3, 1), dpre, ws, 4 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
+        dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
+        conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dxh, 2 * Cc)
+        return dxh[..., :Cc], dxh[..., Cc:], dc, None, None, None
+
+
+class PredSigmoid(Function):
+    """pred = sigmoid(conv1x1(x) + b) (statenet.py:116-117, 313); returns NCHW [B,1,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = dense(x)
+        B, Hh, W, Cc = x.shape
+        y = torch.empty(B, 1, Hh, W, device=x.device)
+        H.check(H.lib().ramnet_pred_sigmoid_fwd(_p(x), ld(x), Cc, _p(w.detach()), _p(b.detach()), _p(y), B * Hh * W, _st()), "pred_fwd")
+        ctx.save_for_backward(x, w, b, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, y = ctx.saved_tensors
+        B, Hh, W, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, Hh, W, Cc, device=x.device) if ctx.needs_input_grad[0] else None
+        H.check(H.lib().ramnet_pred_sigmoid_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), _p(dx), Cc,
+                                                _p(ensure_grad(w)), _p(ensure_grad(b)), B * Hh * W, _st()), "pred_bwd")
+        return dx, None, None
+
+
+class SILoss(Function):
+    """scale_invariant_loss (model/loss.py:6-9): w * (mean(d^2) - lambda * mean(d)^2) over non-NaN d."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, n_lambda):
+        pred, target = pred.contiguous(), target.contiguous()
+        stats = torch.empty(3, device=pred.device, dtype=torch.float64)
+        loss = torch.empty((), device=pred.device)
+        H.check(H.lib().ramnet_si_loss_fwd(_p(pred), _p(target), pred.numel(), weight, n_lambda, _p(stats), _p(loss), _st()), "si_fwd")
+        ctx.save_for_backward(pred, target, stats)
+        ctx.wl = (weight, n_lambda)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(pred)
+        H.check(H.lib().ramnet_si_loss_bwd(_p(pred), _p(target), pred.numel(), ctx.wl[0], ctx.wl[1], _p(stats), _p(g), _p(d), _st()), "si_bwd")
+        return d, None, None, None
+
+
+def nhwc_add(a, b):
+    """a + b on NHWC tensors (UNet head skip, unet.py:129)."""
+    a, b = dense(a).contiguous(), dense(b).contiguous()
+    y = torch.empty_like(a)
+    H.check(H.lib().ramnet_add(_p(a), _p(b), _p(y), a.numel(), _st()), "ramnet_add")
+    return y
+
+
+def scale_invariant_loss(y_input, y_target, weight=1.0, n_lambda=1.0):
+    """Drop-in for model.loss.scale_invariant_loss (model/loss.py:6-9) on device tensors."""
+    return SILoss.apply(y_input, y_target.to(y_input.device), float(weight), float(n_lambda))
+
+
+class Add(Function):
+    """Skip sum x1 + x2 (unet.py:14-15) as a HIP kernel; gradient fans out unchanged."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return nhwc_add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy

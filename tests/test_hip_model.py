@@ -1,0 +1,139 @@
+"""GPU: whole-network parity of the HIP path against (a) golden vectors produced by the reference itself and
+(b) the CPU oracle on the same seeded inputs, including BPTT gradients through the trainer's loss assembly."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ramnet_ref
+from recipe import make_item
+from util import assert_close, build_hip_model, load_golden, ref_cfg
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3     # north star: <= 1e-3 relative fp32 against the reference forward
+
+
+def check_weights(model, z):
+    """Seeded init (torch.manual_seed(0)) must reproduce the reference's weights (checksums in the fixture)."""
+    for k, v in model.state_dict().items():
+        got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+        np.testing.assert_allclose(got, z["wsum." + k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def run_fixture(tag, arch="ERGB2DepthRecurrent"):
+    cfg, z = ref_cfg("net_%s.npz" % tag)
+    model = build_hip_model(arch, cfg).eval()
+    check_weights(model, z)
+    seed, B, H, W, n_ev, c_ev, c_img, calls = [int(v) for v in z["recipe"]]
+    rng = np.random.default_rng(seed)
+    prev_super, prev_lstm = None, ramnet_ref.empty_states_lstm(cfg["every_x_rgb_frame"])
+    worst = 0.0
+    with torch.no_grad():
+        for c in range(calls):
+            item = make_item(rng, B, H, W, n_ev, c_ev, c_img)
+            preds, supers, lstms = model(item, prev_super, prev_lstm)
+            assert list(preds.keys()) == [k[len("pred%d." % c):] for k in z.files if k.startswith("pred%d." % c)]
+            for k, v in preds.items():
+                assert v.shape == z["pred%d.%s" % (c, k)].shape
+                assert_close(v.cpu().numpy(), z["pred%d.%s" % (c, k)], TOL, "%s call %d pred %s" % (tag, c, k))
+            for name in [f for f in z.files if f.startswith("super%d.image." % c)]:
+                parts = name.split(".")
+                s = supers["image"][int(parts[2])]
+                s = s[{"h": 0, "c": 1}[parts[3]]] if len(parts) == 4 else s
+                assert s.shape == z[name].shape
+                assert_close(s.cpu().numpy(), z[name], TOL, "%s call %d %s" % (tag, c, name))
+            prev_super, prev_lstm = supers["image"], lstms
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["seeded_ramnet", "seeded_ramnet_lstm", "seeded_base_rgb"])
+def test_reference_golden_forward(tag):
+    run_fixture(tag)
+
+
+def test_reference_golden_unet():
+    run_fixture("seeded_unet", "ERGB2Depth")
+
+
+def test_baseline_config0_256x256():
+    """BASELINE.json configs[0]: single 256x256 frame + 1 event grid through ERGB2DepthRecurrent."""
+    run_fixture("config1_256")
+
+
+def test_state_contract():
+    """Return structure of model.py:193-219: dict keys in order, state_comb[i] is super_state[i], no in-place update."""
+    cfg, z = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    rng = np.random.default_rng(0)
+    K = cfg["every_x_rgb_frame"]
+    item = make_item(rng, 1, 32, 48, K, 5, 1)
+    with torch.no_grad():
+        p1, s1, l1 = model(item, None, ramnet_ref.empty_states_lstm(K))
+        keep = [t.clone() for t in s1["image"]]
+        p2, s2, l2 = model(item, s1["image"], l1)
+    assert list(p1.keys()) == ["events%d" % k for k in range(K)] + ["image"]
+    for key in p1:
+        assert p1[key].shape == (1, 1, 32, 48)
+        assert len(s1[key]) == 3 and s1[key][0].shape == (1, 64, 16, 24)
+        assert l1[key]["encoders"] == [None, None, None]
+        assert all(a is b for a, b in zip(l1[key]["state_comb"], s1[key]))
+    for a, b in zip(keep, s1["image"]):
+        assert torch.equal(a, b), "previous state was modified in place"
+
+
+def test_bptt_gradients_vs_reference_fixture():
+    """2-package BPTT with SI loss on ['image','events1'] (20 % NaN targets): parameter gradients vs the
+    reference's own LSTMTrainer.forward_pass_sequence + backward (fixture grads_seeded_ramnet.npz)."""
+    from rpg_ramnet_amd.trainer import sequence_loss
+    z = load_golden("grads_seeded_ramnet.npz")
+    cfg = json.loads(str(z["config"]))
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    check_weights(model, z)
+    L = int(z["L"])
+    seq = []
+    for l in range(L):
+        pre = "in%d." % l
+        seq.append({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)})
+    total, reported = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+    np.testing.assert_allclose(float(reported), float(z["reported_loss"]), rtol=1e-4)
+    model.zero_grad()
+    total.backward()
+    for k, p in model.named_parameters():
+        g = p.grad.cpu()
+        if "g." + k in z.files:
+            assert_close(g.numpy(), z["g." + k], 2e-3, "grad " + k)
+        else:
+            ref_norm = float(z["gnorm." + k][0])
+            np.testing.assert_allclose(float(g.double().norm()), ref_norm, rtol=2e-3, err_msg=k)
+            assert_close(g.flatten()[::997].numpy(), z["gsample." + k], 2e-3, "grad sample " + k)
+
+
+@pytest.mark.parametrize("mode", ["gru", "lstm", "enc_lstm", "base_e"])
+def test_bptt_gradients_vs_oracle(mode):
+    """Same seeded model + inputs through the HIP path and the CPU oracle: loss, predictions and all gradients."""
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
+    if mode == "lstm":
+        cfg["state_combination"] = "convlstm"
+    if mode == "enc_lstm":
+        cfg["recurrent_block_type"] = "convlstm"
+    if mode == "base_e":
+        cfg.update(baseline="e", loss_composition="image", state_combination="convlstm", num_bins_rgb=5, every_x_rgb_frame=3)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(3)
+    B, H, W, L = 2, 16, 32, 2
+    K = cfg["every_x_rgb_frame"]
+    n_ev = K - 1 if mode == "base_e" else K
+    seq = [make_item(rng, B, H, W, n_ev, 5, cfg["num_bins_rgb"], True, 0.2) for _ in range(L)]
+    lc = cfg["loss_composition"]
+    total, _ = sequence_loss(model, seq, lc, [1, 1])
+    model.zero_grad()
+    total.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ref_total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
+    ref_total.backward()
+    np.testing.assert_allclose(float(total), float(ref_total.detach()), rtol=1e-4)
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k)

@@ -1,0 +1,192 @@
+"""GPU: every fused HIP operator (forward, backward-data, backward-weights) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, ramnet_ref, voxel_ref
+from util import assert_close, load_golden, nchw, nhwc
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4   # exact-fp32 MFMA vs PyTorch CPU; summation order differs
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def run_pair(module, oracle_fn, inputs, seed=0):
+    """module: rpg_ramnet_amd layer (NHWC, cuda); oracle_fn(sd, *nchw_cpu_inputs) -> tensor or tuple."""
+    module = module.to(dev())
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in module.state_dict().items()}
+    cpu_in = [None if t is None else t.clone().requires_grad_(True) for t in inputs]
+    gpu_in = [None if t is None else nhwc(t).to(dev()).requires_grad_(True) for t in inputs]
+    ref = oracle_fn(sd, *cpu_in)
+    got = module(*gpu_in)
+    ref = ref if isinstance(ref, tuple) else (ref,)
+    got = got if isinstance(got, tuple) else (got,)
+    g = torch.Generator().manual_seed(seed)
+    loss_ref_, loss_got = 0, 0
+    for r, o in zip(ref, got):
+        o_nchw = o if o.shape == r.shape else o.permute(0, 3, 1, 2)
+        assert_close(o_nchw.detach().cpu().numpy(), r.detach().numpy(), TOL, "forward")
+        wgt = torch.randn(r.shape, generator=g)
+        loss_ref_ = loss_ref_ + (r * wgt).sum()
+        loss_got = loss_got + (o_nchw * wgt.to(dev())).sum()
+    loss_ref_.backward()
+    loss_got.backward()
+    for i, (c, gi) in enumerate(zip(cpu_in, gpu_in)):
+        if c is not None and c.grad is not None:
+            assert gi.grad is not None, "missing input grad %d" % i
+            assert_close(nchw(gi.grad).cpu().numpy(), c.grad.numpy(), TOL, "grad input %d" % i)
+    for k, p in module.named_parameters():
+        assert p.grad is not None, "missing grad for " + k
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), TOL, "grad " + k)
+
+
+SHAPES = [(2, 16, 32), (1, 8, 16), (3, 9, 37), (2, 24, 20)]
+
+
+@pytest.mark.parametrize("B,H,W", SHAPES)
+@pytest.mark.parametrize("cin,cout,stride", [(32, 64, 1), (32, 64, 2), (64, 32, 1), (8, 32, 1), (128, 128, 2), (4, 32, 1)])
+def test_conv_layer(B, H, W, cin, cout, stride):
+    from rpg_ramnet_amd.model.submodules import ConvLayer
+    torch.manual_seed(1)
+    m = ConvLayer(cin, cout, 5, stride, 2)
+    x = torch.randn(B, cin, H, W)
+    run_pair(m, lambda sd, a: torch.relu(torch.nn.functional.conv2d(a, sd["conv2d.weight"], sd["conv2d.bias"], stride, 2)), [x])
+
+
+@pytest.mark.parametrize("cin", [1, 5, 6])
+def test_head_conv_padded_input(cin):
+    """Model inputs: NCHW with 1/5/6 channels -> NHWC zero-padded to 4/8 -> 5x5 conv (no input gradient)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvLayer
+    torch.manual_seed(2)
+    m = ConvLayer(cin, 32, 5, 1, 2).to(dev())
+    x = torch.randn(2, cin, 20, 28)
+    y = m(ops.pack_input(x, dev()))
+    w, b = m.conv2d.weight.detach().cpu().requires_grad_(True), m.conv2d.bias.detach().cpu().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, 1, 2))
+    assert_close(nchw(y).detach().cpu().numpy(), ref.detach().numpy(), TOL, "head forward")
+    wgt = torch.randn(ref.shape)
+    (ref * wgt).sum().backward()
+    (nchw(y) * wgt.to(dev())).sum().backward()
+    assert_close(m.conv2d.weight.grad.cpu().numpy(), w.grad.numpy(), TOL, "head dW")
+    assert_close(m.conv2d.bias.grad.cpu().numpy(), b.grad.numpy(), TOL, "head db")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 16), (1, 5, 11), (2, 16, 24)])
+@pytest.mark.parametrize("cin,cout,skip", [(64, 32, True), (64, 32, False), (256, 128, True)])
+def test_upsample_conv(B, H, W, cin, cout, skip):
+    from rpg_ramnet_amd.model.submodules import UpsampleConvLayer
+    torch.manual_seed(3)
+    m = UpsampleConvLayer(cin, cout, 5, padding=2)
+    x, s = torch.randn(B, cin, H, W), (torch.randn(B, cin, H, W) if skip else None)
+
+    def oracle(sd, a, sk=None):
+        return ramnet_ref.upsample_conv_layer({"L." + k: v for k, v in sd.items()}, "L", a if sk is None else a + sk)
+
+    run_pair(m, oracle, [x, s] if skip else [x])
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
+def test_residual_block(B, H, W, C):
+    from rpg_ramnet_amd.model.submodules import ResidualBlock
+    torch.manual_seed(4)
+    m = ResidualBlock(C, C)
+    run_pair(m, lambda sd, a: ramnet_ref.residual_block({"L." + k: v for k, v in sd.items()}, "L", a),
+             [torch.randn(B, C, H, W)])
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256), (1, 16, 32, 128)])
+def test_conv_gru(B, H, W, C):
+    from rpg_ramnet_amd.model.submodules import ConvGRU
+    torch.manual_seed(5)
+    m = ConvGRU(C, C, 3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)     # non-zero biases (the reference initialises them to 0)
+    run_pair(m, lambda sd, a, h: ramnet_ref.conv_gru({"L." + k: v for k, v in sd.items()}, "L", a, h),
+             [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W))])
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
+def test_conv_lstm(B, H, W, C):
+    from rpg_ramnet_amd.model.submodules import ConvLSTM
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.L = ConvLSTM(C, C, 3)
+
+        def forward(self, x, h, c):
+            return self.L(x, (h, c))
+
+    torch.manual_seed(6)
+    m = Wrap()
+    run_pair(m, lambda sd, a, h, c: ramnet_ref.conv_lstm(sd, "L", a, (h, c)),
+             [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W)), torch.randn(B, C, H, W)])
+
+
+def test_pred_sigmoid():
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(7)
+    x = torch.randn(2, 32, 12, 20)
+    w, b = (torch.randn(1, 32, 1, 1) * 0.2), torch.randn(1) * 0.1
+    xg = nhwc(x).to(dev()).requires_grad_(True)
+    wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.PredSigmoid.apply(xg, wg, bg)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.sigmoid(torch.nn.functional.conv2d(xc, wc, bc))
+    assert_close(y.detach().cpu().numpy(), ref.detach().numpy(), TOL, "pred")
+    wgt = torch.randn(ref.shape)
+    (ref * wgt).sum().backward()
+    (y * wgt.to(dev())).sum().backward()
+    assert_close(nchw(xg.grad).cpu().numpy(), xc.grad.numpy(), TOL, "pred dx")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "pred dw")
+    assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "pred db")
+
+
+def test_si_loss_golden_and_grad():
+    from rpg_ramnet_amd import ops
+    z = load_golden("loss_metrics.npz")
+    for i in range(3):
+        p = torch.from_numpy(z["si%d.pred" % i]).to(dev()).requires_grad_(True)
+        t = torch.from_numpy(z["si%d.target" % i]).to(dev())
+        l = ops.scale_invariant_loss(p, t, 1.0, 1.0)
+        np.testing.assert_allclose(float(l), float(z["si%d.loss" % i]), rtol=1e-5)
+        (3.0 * l).backward()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), 3.0 * z["si%d.grad" % i], rtol=1e-4, atol=1e-9)
+        l2 = ops.scale_invariant_loss(p.detach(), t, 0.5, 0.85)
+        np.testing.assert_allclose(float(l2), float(z["si%d.loss_w05_l085" % i]), rtol=1e-5)
+
+
+VOX = ["rand", "rand10", "onebin", "single", "same_t", "corners", "int_ts_pm1"]
+
+
+@pytest.mark.parametrize("name", VOX)
+def test_voxel_grid_golden(name):
+    from rpg_ramnet_amd import voxel
+    z = load_golden("voxel.npz")
+    ev = z["%s.events" % name]
+    bins, W, H = [int(v) for v in z["%s.dims" % name]]
+    il, vl, okl, ir, vr, okr = voxel_ref.voxel_votes(ev, bins, W, H)
+    gl, gr = voxel.voxel_indices(torch.from_numpy(ev).to(dev()), bins, W, H)
+    assert np.array_equal(gl.cpu().numpy(), np.where(okl, il, -1)), "left indices must be bit-exact"
+    assert np.array_equal(gr.cpu().numpy(), np.where(okr, ir, -1)), "right indices must be bit-exact"
+    g = voxel.events_to_voxel_grid(torch.from_numpy(ev).to(dev()), bins, W, H).cpu().numpy()
+    ref = z["%s.grid_torch" % name]
+    assert np.array_equal(g != 0, ref != 0) or np.abs(g - ref).max() < 1e-5
+    np.testing.assert_allclose(g, ref, atol=1e-5)        # same votes; atomic accumulation order differs
+    if name == "rand":
+        n = voxel.normalize_nonzero(torch.from_numpy(ref).to(dev())).cpu().numpy()
+        np.testing.assert_allclose(n, z["rand.normalized"], rtol=1e-4, atol=1e-5)
+
+
+def test_voxel_empty_and_zero_grid():
+    from rpg_ramnet_amd import voxel
+    g = voxel.events_to_voxel_grid(torch.zeros(0, 4, dtype=torch.float64, device=dev()), 5, 16, 12)
+    assert g.shape == (5, 12, 16) and float(g.abs().sum()) == 0.0
+    z = voxel.normalize_nonzero(torch.zeros(2, 4, 4, device=dev()))
+    assert float(z.abs().sum()) == 0.0
