@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RAM-Net training step on MI355X (BASELINE.json configs[1]/[2]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer step over a batch of B=8 sequences of L=8 data packages per GPU (each package = 5 event
+voxel grids of 5 bins + 1 gray frame at 256x344, the reference's centre crop of 346x260 — the raw size does not run
+through the reference network): forward through ERGB2DepthRecurrent, scale-invariant loss on
+['image','events4'], BPTT backward, gradient all-reduce over RCCL (N>1), Adam.  Metric: depth samples/s, one sample
+= one data package of one batch element; value = N*B*L*K / max-over-ranks(time).
+Inputs are synthetic (device-generated event lists -> HIP voxel scatter-add -> nonzero normalisation; U[0,1) frames;
+log-depth targets) and resident in HBM before the timed region.  Weights: seeded random init (no checkpoints offline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RELEASED = dict(num_bins_rgb=1, num_bins_events=5, skip_type="sum", recurrent_block_type="conv",
+                state_combination="convgru", spatial_resolution=[112, 112], num_encoders=3, base_num_channels=32,
+                num_residual_blocks=2, use_upsample_conv=True, norm="none")
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--seq-len", type=int, default=8)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=344)
+    ap.add_argument("--events-per-grid", type=int, default=200000)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--state", choices=["convgru", "convlstm"], default="convgru")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
+    """SURVEY section 8d recipe, generated on device; returns a list of L item dicts (NCHW device tensors)."""
+    from rpg_ramnet_amd import voxel
+    dev = model.gpu
+    g = torch.Generator(device=dev).manual_seed(seed)
+    seq = []
+    for _ in range(L):
+        item = {}
+        for k in range(K):
+            grids = []
+            for _b in range(B):
+                ev = torch.empty(n_events, 4, device=dev, dtype=torch.float64)
+                ev[:, 0] = torch.sort(torch.rand(n_events, device=dev, generator=g, dtype=torch.float64) * 0.05)[0]
+                ev[:, 1] = torch.randint(0, W, (n_events,), device=dev, generator=g).double()
+                ev[:, 2] = torch.randint(0, H, (n_events,), device=dev, generator=g).double()
+                ev[:, 3] = torch.randint(0, 2, (n_events,), device=dev, generator=g).double()
+                grids.append(voxel.normalize_nonzero(voxel.events_to_voxel_grid(ev, bins, W, H)))
+            item["events%d" % k] = torch.stack(grids)
+        item["image"] = torch.rand(B, 1, H, W, device=dev, generator=g)
+        for key in ("image", "events%d" % (K - 1)):
+            u = torch.rand(B, 1, H, W, device=dev, generator=g) * 0.98 + 0.02
+            item["depth_" + key] = torch.clamp(1.0 + torch.log(u) / 3.70378, 0.0, 1.0)
+        seq.append(item)
+    return seq
+
+
+class KernelTimer:
+    """HIP-event timing of every MFMA launch on the launch stream, keyed by kernel symbol."""
+
+    def __init__(self):
+        self.rec = []
+        self.on = False
+
+    def install(self):
+        from rpg_ramnet_amd import ops
+        timer = self
+        conv0, wgrad0 = ops.conv_launch, ops.wgrad_launch
+
+        def variant(Cout, epi):
+            from rpg_ramnet_amd import _hip as Hh
+            if epi == Hh.EPI_LSTM:
+                return "conv_igemm_kernel<128,128,4,1>"
+            cp = (Cout + 31) // 32 * 32
+            return "conv_igemm_kernel<128,%d,%s>" % ((128, "2,2") if cp % 128 == 0 else (64, "2,2") if cp % 64 == 0 else (32, "4,1"))
+
+        def conv(x0, taps, w, out, Cout, **kw):
+            if not timer.on:
+                return conv0(x0, taps, w, out, Cout, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            conv0(x0, taps, w, out, Cout, **kw)
+            e.record()
+            cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
+            Ho, Wo = kw.get("Ho") or out.shape[1], kw.get("Wo") or out.shape[2]
+            nout = Cout * (4 if kw.get("epi") == 5 else 1)
+            timer.rec.append((variant(Cout, kw.get("epi", 0)), s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * nout))
+
+        def wgrad(x0, taps, dout, dw, Cout, **kw):
+            if not timer.on:
+                return wgrad0(x0, taps, dout, dw, Cout, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            wgrad0(x0, taps, dout, dw, Cout, **kw)
+            e.record()
+            cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
+            per = (taps.n + 1) // 2
+            name = "conv_wgrad_kernel<%d>" % (1 if per <= 1 else 5 if per <= 5 else 13)
+            timer.rec.append((name, s, e, 2.0 * dout.shape[0] * dout.shape[1] * dout.shape[2] * taps.n * cin * Cout))
+
+        ops.conv_launch, ops.wgrad_launch = conv, wgrad
+
+    def summary(self):
+        agg = {}
+        for name, s, e, fl in self.rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += fl
+        return agg
+
+
+def cpu_baseline(cfg, H, W, K, args):
+    """The oracle (CPU restatement, fixture-pinned to the reference) timed on this box's host cores on a bounded
+    sample of the same workload: one training step (fwd + SI loss + BPTT bwd) of B=1, L=1 at the bench resolution."""
+    from oracle import ramnet_ref
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from recipe import make_item
+    from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent
+    torch.manual_seed(0)
+    m = ERGB2DepthRecurrent(cfg)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(0)
+    cores = torch.get_num_threads()
+    B, L = 1, 1
+    seq = [make_item(rng, B, H, W, K, cfg["num_bins_events"], 1, True, 0.0) for _ in range(L)]
+    lc = cfg["loss_composition"]
+    t0 = time.time()
+    if args.mode == "train":
+        total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
+        total.backward()
+    else:
+        with torch.no_grad():
+            ramnet_ref.forward_recurrent(sd, cfg, seq[0], None, ramnet_ref.empty_states_lstm(K))
+    dt = time.time() - t0
+    return {"value": B * L / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%s step, B=%d L=%d K=%d %dx%d fp32 torch-CPU oracle, %.1f s" % (args.mode, B, L, K, H, W, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent
+    from rpg_ramnet_amd.parallel import FlatGradReducer
+    from rpg_ramnet_amd.trainer import sequence_loss, empty_states_lstm
+
+    K, bins, B, L, H, W = 5, 5, args.batch, args.seq_len, args.height, args.width
+    cfg = dict(RELEASED, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
+               state_combination=args.state)
+    torch.manual_seed(0)                       # identical initial weights on every rank (train.py:203)
+    model = ERGB2DepthRecurrent(cfg)
+    model = model.to(model.gpu)
+    seq = synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=1000 + rank)
+    timer = KernelTimer()
+    if not args.no_kernel_timing:
+        timer.install()
+
+    if args.mode == "train":
+        model.train()
+        reducer = FlatGradReducer(model)
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=0)
+
+        def step():
+            reducer.zero()
+            total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+            total.backward()
+            reducer.all_reduce()
+            reducer.wait()
+            opt.step()
+            return total
+    else:
+        model.eval()
+
+        def step():
+            prev_super, prev_lstm = None, empty_states_lstm(K)
+            with torch.no_grad():
+                for item in seq:
+                    preds, supers, prev_lstm = model(item, prev_super, prev_lstm)
+                    prev_super = supers["image"]
+            return preds["image"].mean()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = step()
+    fence()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=model.gpu, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(last)
+    assert np.isfinite(loss_val), "non-finite loss"
+
+    if rank == 0:
+        samples = world * B * L * args.steps
+        out = {"metric": "depth samples/sec (346x260 cropped to %dx%d, 5-bin grids, K=5 grids + 1 frame per sample; %s)"
+                         % (H, W, "training step" if args.mode == "train" else "inference"),
+               "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "EventScape-shaped 346x260 -> %dx%d crop, 5 event bins, K=5, batch %d/GPU, seq-len %d, "
+                                      "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam"
+                                      % (H, W, B, L, args.mode, args.state),
+                          "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
+               "final_loss": loss_val}
+        agg = timer.summary()
+        if agg:
+            dom = max(agg.items(), key=lambda kv: kv[1][1])
+            name, (n, secs, flops) = dom
+            ach = flops / secs / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                               "algorithmic_gflop_per_launch": flops / n / 1e9}
+            out["kernels"] = {k: {"launches": v[0], "ms": 1e3 * v[1], "tflops": v[2] / v[1] / 1e12} for k, v in agg.items()}
+            out["mfma_time_fraction"] = sum(v[1] for v in agg.values()) / dt
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, H, W, K, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

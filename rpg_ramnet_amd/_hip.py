@@ -87,6 +87,12 @@ def lib():
             raise HipLibraryMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). rpg_ramnet_amd has no CPU fallback." % LIB_PATH)
+        # bind to the SAME HIP runtime torch uses (torch ships its own libamdhip64.so.7): load torch's copy first so
+        # that our DT_NEEDED entry resolves to it instead of a second runtime with no initialised device
+        import torch
+        rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)

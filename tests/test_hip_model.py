@@ -99,10 +99,11 @@ def test_bptt_gradients_vs_reference_fixture():
     np.testing.assert_allclose(float(reported), float(z["reported_loss"]), rtol=1e-4)
     model.zero_grad()
     total.backward()
+    gmax = max(float(p.grad.abs().max()) for p in model.parameters())
     for k, p in model.named_parameters():
         g = p.grad.cpu()
         if "g." + k in z.files:
-            assert_close(g.numpy(), z["g." + k], 2e-3, "grad " + k)
+            assert_close(g.numpy(), z["g." + k], 2e-3, "grad " + k, floor=1e-4 * gmax)
         else:
             ref_norm = float(z["gnorm." + k][0])
             np.testing.assert_allclose(float(g.double().norm()), ref_norm, rtol=2e-3, err_msg=k)
@@ -133,7 +134,8 @@ def test_bptt_gradients_vs_oracle(mode):
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     ref_total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
     ref_total.backward()
-    np.testing.assert_allclose(float(total), float(ref_total.detach()), rtol=1e-4)
+    np.testing.assert_allclose(float(total.detach()), float(ref_total.detach()), rtol=1e-4)
+    gmax = max(float(v.grad.abs().max()) for v in sd.values())
     for k, p in model.named_parameters():
         assert p.grad is not None, k
-        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k)
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-4 * gmax)

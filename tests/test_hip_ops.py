@@ -155,7 +155,7 @@ def test_si_loss_golden_and_grad():
         p = torch.from_numpy(z["si%d.pred" % i]).to(dev()).requires_grad_(True)
         t = torch.from_numpy(z["si%d.target" % i]).to(dev())
         l = ops.scale_invariant_loss(p, t, 1.0, 1.0)
-        np.testing.assert_allclose(float(l), float(z["si%d.loss" % i]), rtol=1e-5)
+        np.testing.assert_allclose(float(l.detach()), float(z["si%d.loss" % i]), rtol=1e-5)
         (3.0 * l).backward()
         np.testing.assert_allclose(p.grad.cpu().numpy(), 3.0 * z["si%d.grad" % i], rtol=1e-4, atol=1e-9)
         l2 = ops.scale_invariant_loss(p.detach(), t, 0.5, 0.85)

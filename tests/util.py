@@ -18,8 +18,11 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def assert_close(a, b, tol, what=""):
-    e = rel_err(a, b)
+def assert_close(a, b, tol, what="", floor=0.0):
+    """floor: absolute scale below which a reference magnitude is treated as cancellation noise (e.g. the SI-loss
+    gradient of a bias is a sum that cancels to ~0); pass a fraction of the largest gradient in the model."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    e = float(np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-30))
     assert e <= tol, "%s: rel err %.3e > %.1e (max|ref| %.3e)" % (what, e, tol, float(np.abs(np.asarray(b)).max()))
 
 
