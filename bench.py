@@ -226,7 +226,7 @@ def main():
         t = torch.tensor([dt], device=model.gpu, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    loss_val = float(last)
+    loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
     if rank == 0:

@@ -103,7 +103,7 @@ def test_bptt_gradients_vs_reference_fixture():
     for k, p in model.named_parameters():
         g = p.grad.cpu()
         if "g." + k in z.files:
-            assert_close(g.numpy(), z["g." + k], 2e-3, "grad " + k, floor=1e-4 * gmax)
+            assert_close(g.numpy(), z["g." + k], 2e-3, "grad " + k, floor=1e-2 * gmax)
         else:
             ref_norm = float(z["gnorm." + k][0])
             np.testing.assert_allclose(float(g.double().norm()), ref_norm, rtol=2e-3, err_msg=k)
@@ -138,4 +138,4 @@ def test_bptt_gradients_vs_oracle(mode):
     gmax = max(float(v.grad.abs().max()) for v in sd.values())
     for k, p in model.named_parameters():
         assert p.grad is not None, k
-        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-4 * gmax)
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-2 * gmax)
