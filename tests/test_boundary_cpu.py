@@ -1,0 +1,183 @@
+"""CPU (no GPU): the drop-in boundary — C ABI exports, module API, config behaviour, state_dict layout, host logic."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from util import load_golden, ref_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rpg_ramnet_amd import _hip
+    hdr = open(os.path.join(ROOT, "include", "ramnet_hip.h")).read()
+    declared = set(re.findall(r"\b(ramnet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    assert declared == set(_hip.EXPORTS), "ctypes table and header disagree: %s" % (declared ^ set(_hip.EXPORTS))
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ramnet_abi_version.restype = ctypes.c_int
+    assert lib.ramnet_abi_version() == 1
+
+
+def test_desc_struct_layout_matches_header_field_order():
+    from rpg_ramnet_amd import _hip
+    hdr = open(os.path.join(ROOT, "include", "ramnet_hip.h")).read()
+    for cname, cls in (("ramnet_conv_desc", _hip.ConvDesc), ("ramnet_wgrad_desc", _hip.WgradDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(float|int|int8_t|uint8_t)\s+", "", decl)
+            names += [re.sub(r"[\*\s]|\[\d+\]", "", n) for n in decl.split(",")]
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from rpg_ramnet_amd import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/librpg_ramnet_hip.so")
+    with pytest.raises(_hip.HipLibraryMissing):
+        _hip.lib()
+
+
+@pytest.mark.parametrize("tag,arch", [("seeded_ramnet", "ERGB2DepthRecurrent"), ("seeded_ramnet_lstm", "ERGB2DepthRecurrent"),
+                                      ("seeded_base_rgb", "ERGB2DepthRecurrent"), ("seeded_unet", "ERGB2Depth")])
+def test_state_dict_layout_and_seeded_init_match_reference(tag, arch):
+    """Keys/shapes equal the reference's checkpoint layout and torch.manual_seed(0) gives the reference's weights."""
+    from rpg_ramnet_amd.model import model as mm
+    cfg, z = ref_cfg("net_%s.npz" % tag)
+    torch.manual_seed(0)
+    m = getattr(mm, arch)(cfg)
+    ref_keys = [k[5:] for k in z.files if k.startswith("wsum.")]
+    assert list(m.state_dict().keys()) == ref_keys
+    for k, v in m.state_dict().items():
+        got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+        np.testing.assert_allclose(got, z["wsum." + k], rtol=1e-6, atol=1e-9, err_msg=k)
+    assert isinstance(m, torch.nn.Module) and hasattr(m, "config") and hasattr(m, "logger")
+    m.summary()
+
+
+def test_explicit_weight_fixture_loads_strict():
+    """A reference state_dict (narrow model) loads with strict=True."""
+    from rpg_ramnet_amd.model import model as mm
+    z = load_golden("net_small_gru.npz")
+    cfg = json.loads(str(z["config"]))
+    m = mm.ERGB2DepthRecurrent(cfg)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    m.load_state_dict(sd, strict=True)
+
+
+def test_constructor_contract_errors():
+    from rpg_ramnet_amd.model import model as mm
+    base = dict(num_bins_rgb=1, num_bins_events=5, gpu=0, state_combination="convgru", num_encoders=3)
+    with pytest.raises(AssertionError):
+        mm.ERGB2DepthRecurrent({"num_bins_events": 5, "gpu": 0})
+    with pytest.raises(KeyError):
+        mm.ERGB2DepthRecurrent({k: v for k, v in base.items() if k != "gpu"})        # model.py:77
+    with pytest.raises(KeyError):
+        mm.ERGB2DepthRecurrent(dict(base, skip_type="bogus"))                         # statenet.py:57-59
+    with pytest.raises(KeyError):
+        mm.ERGB2DepthRecurrent(dict(base, state_combination="bogus"))                 # statenet.py:69-71
+    with pytest.raises(NotImplementedError):
+        mm.ERGB2DepthRecurrent(dict(base, norm="BN"))
+    m = mm.ERGB2DepthRecurrent(dict(base, spatial_resolution=[112, 112]))              # extra keys ignored
+    assert m.num_residual_blocks == 2 and m.base_num_channels == 32 and m.every_x_rgb_frame == 1
+    assert m.recurrent_block_type == "convlstm" and m.use_upsample_conv is True       # reference defaults
+
+
+def test_tap_lists_reproduce_conv_and_transposed_conv():
+    """Host logic: the tap lists fed to the kernels, evaluated in numpy, equal F.conv2d / its input gradient."""
+    from rpg_ramnet_amd.ops import Taps
+    rng = np.random.default_rng(0)
+
+    def taps(t):
+        return [(t.dy[i], t.dx[i], t.wt[i]) for i in range(t.n)]
+
+    for k, stride in [(5, 1), (3, 1), (5, 2)]:
+        pad = k // 2
+        H, W = 9, 11
+        x = rng.standard_normal((H, W))
+        w = rng.standard_normal((k, k))
+        xt = torch.from_numpy(x)[None, None].requires_grad_(True)
+        y = torch.nn.functional.conv2d(xt, torch.from_numpy(w)[None, None], None, stride, pad)
+        Ho, Wo = y.shape[2:]
+        mine = np.zeros((Ho, Wo))
+        for dy, dx, wt in taps(Taps.get("conv", k, pad)):
+            for a in range(Ho):
+                for b in range(Wo):
+                    iy, ix = a * stride + dy, b * stride + dx
+                    if 0 <= iy < H and 0 <= ix < W:
+                        mine[a, b] += x[iy, ix] * w.flat[wt]
+        np.testing.assert_allclose(mine, y[0, 0].detach().numpy(), atol=1e-12)
+        g = rng.standard_normal((Ho, Wo))
+        y.backward(torch.from_numpy(g)[None, None])
+        dx_ref = xt.grad[0, 0].numpy()
+        dxm = np.zeros((H, W))
+        classes = [(0, 0)] if stride == 1 else [(0, 0), (0, 1), (1, 0), (1, 1)]
+        for py, px in classes:
+            tl = Taps.get("dgrad1", k, pad) if stride == 1 else Taps.get("dgrad2", k, pad, py, px)
+            for a in range((H - py + stride - 1) // stride):
+                for b in range((W - px + stride - 1) // stride):
+                    s = 0.0
+                    for dy, dx, wt in taps(tl):
+                        iy, ix = a + dy, b + dx
+                        if 0 <= iy < Ho and 0 <= ix < Wo:
+                            s += g[iy, ix] * w.flat[wt]
+                    dxm[a * stride + py, b * stride + px] = s
+        np.testing.assert_allclose(dxm, dx_ref, atol=1e-12)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rpg_ramnet_amd.parallel import FlatGradReducer, shard_indices
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
+    red = FlatGradReducer(net, num_buckets=2)
+    red.zero()
+    data = torch.arange(8 * 3 * 6 * 6, dtype=torch.float32).reshape(8, 3, 6, 6) / 100.0
+    mine = shard_indices(8, rank, world)
+    net(data[mine]).square().mean().backward()
+    assert all(p.grad.data_ptr() == red.views[p].data_ptr() for p in net.parameters())   # grads landed in the flat buffer
+    red.all_reduce()
+    red.wait()
+    q.put((rank, mine, red.flat.clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_average_gloo_world2():
+    """N>1 path on CPU (gloo, world_size 2): bucketed flat all-reduce == mean of the per-rank gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-6)
+    # reference: single process, mean of the two shard gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 2, 1))
+    data = torch.arange(8 * 3 * 6 * 6, dtype=torch.float32).reshape(8, 3, 6, 6) / 100.0
+    grads = []
+    for idx in ([0, 2, 4, 6], [1, 3, 5, 7]):
+        net.zero_grad()
+        net(data[idx]).square().mean().backward()
+        grads.append(torch.cat([p.grad.flatten() for p in reversed(list(net.parameters()))]))
+    np.testing.assert_allclose(res[0][2], ((grads[0] + grads[1]) / 2).numpy(), rtol=1e-5, atol=1e-8)
