@@ -42,12 +42,13 @@ __global__ void si_finalize_kernel(const double *stats, float weight, float lamb
 
 __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight, float lambda,
                               const double *__restrict__ stats, const float *__restrict__ gscale, float *__restrict__ dpred) {
-    const double cnt = stats[2];
-    const float inv_n = (float)(1.0 / cnt), mean = (float)(stats[0] / cnt);
-    const float g = (gscale ? *gscale : 1.0f) * weight;
+    // d - lambda*mean is formed in double: rounding the mean to fp32 would add the SAME offset to every pixel, and
+    // gradients that are sums over pixels of this map (e.g. the last bias) cancel to ~0 and would keep only that offset.
+    const double cnt = stats[2], mean = stats[0] / cnt;
+    const double s2 = 2.0 * (double)((gscale ? *gscale : 1.0f) * weight) / cnt;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float d = pred[i] - target[i];
-        dpred[i] = (d == d) ? g * (2.0f * d * inv_n - 2.0f * lambda * mean * inv_n) : 0.f;
+        dpred[i] = (d == d) ? (float)(s2 * ((double)d - (double)lambda * mean)) : 0.f;
     }
 }
 
