@@ -86,12 +86,22 @@ class KernelTimer:
         timer = self
         conv0, wgrad0 = ops.conv_launch, ops.wgrad_launch
 
-        def variant(Cout, epi):
+        def variant(Cout, epi, B, Ho, Wo):
+            """Mirror of the tile-configuration choice in ramnet_conv_launch (csrc/conv_igemm.hip)."""
             from rpg_ramnet_amd import _hip as Hh
             if epi == Hh.EPI_LSTM:
-                return "conv_igemm_kernel<128,128,4,1>"
+                return "conv_igemm_kernel<128,128,4,1,1>"
             cp = (Cout + 31) // 32 * 32
-            return "conv_igemm_kernel<128,%d,%s>" % ((128, "2,2") if cp % 128 == 0 else (64, "2,2") if cp % 64 == 0 else (32, "4,1"))
+            bm, bn = 128, (128 if cp % 128 == 0 else 64 if cp % 64 == 0 else 32)
+
+            def blocks(m, n):
+                return -(-Wo // 16) * -(-Ho // (m // 16)) * B * (cp // n)
+            if bn >= 64:
+                if blocks(bm, bn) < 768:
+                    bm = 64
+                if blocks(bm, bn) < 768 and bn == 128:
+                    bn = 64
+            return "conv_igemm_kernel<%d,%d,%s,1>" % (bm, bn, "4,1" if bn == 32 else "2,2")
 
         def conv(x0, taps, w, out, Cout, **kw):
             if not timer.on:
@@ -103,7 +113,8 @@ class KernelTimer:
             cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
             Ho, Wo = kw.get("Ho") or out.shape[1], kw.get("Wo") or out.shape[2]
             nout = Cout * (4 if kw.get("epi") == 5 else 1)
-            timer.rec.append((variant(Cout, kw.get("epi", 0)), s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * nout))
+            timer.rec.append((variant(Cout, kw.get("epi", 0), x0.shape[0], Ho, Wo), s, e,
+                              2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * nout))
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:
@@ -113,8 +124,14 @@ class KernelTimer:
             wgrad0(x0, taps, dout, dw, Cout, **kw)
             e.record()
             cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
-            per = (taps.n + 1) // 2
-            name = "conv_wgrad_kernel<%d>" % (1 if per <= 1 else 5 if per <= 5 else 13)
+            tpm = 1 if cin > 16 else 8 if cin <= 4 else 4 if cin <= 8 else 2      # mirror of ramnet_wgrad_launch
+            ntt = -(-taps.n // tpm)
+            if Cout <= 32 or taps.n > 9:
+                per = -(-ntt // 4)
+                name = "conv_wgrad_kernel<%d,1>" % (1 if per <= 1 else 3 if per <= 3 else 7)
+            else:
+                per = -(-ntt // 2)
+                name = "conv_wgrad_kernel<%d,2>" % (1 if per <= 1 else 5 if per <= 5 else 13)
             timer.rec.append((name, s, e, 2.0 * dout.shape[0] * dout.shape[1] * dout.shape[2] * taps.n * cin * Cout))
 
         ops.conv_launch, ops.wgrad_launch = conv, wgrad

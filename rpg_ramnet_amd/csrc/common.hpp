@@ -95,6 +95,59 @@ __device__ __forceinline__ float4 load_in4(const InSrc &s, int b, int iy, int ix
     return v;
 }
 
+// ---- batched, branch-free patch staging ---------------------------------------------------------------------
+// Stages PH x PW pixels x (4*QPP) channels starting at channel c0 into LDS rows of LDX floats.  Slots are handled in
+// batches of NB: all global loads of a batch are issued before the first LDS store, so a thread exposes ONE memory
+// latency per batch instead of one per float4 (the naive loop serialises on every load).  Out-of-image pixels and
+// channels >= Cin read a safe address and are zeroed by a select (no divergent branches around the loads).
+template <int QPP, int LDX, int NB, int NT>
+__device__ __forceinline__ void stage_patch(float *__restrict__ patch, const InSrc &s, int b, int iy0, int ix0, int c0,
+                                            int PH, int PW, int tid) {
+    const int nslots = PH * PW * QPP;
+    if (s.mode == RAMNET_IN_UP2X || s.mode == RAMNET_IN_UP2X_SKIP) {   // 4-8 loads per slot already in flight
+        for (int sl = tid; sl < nslots; sl += NT) {
+            const int pix = sl / QPP, qd = sl - pix * QPP;
+            const int py = pix / PW, px = pix - py * PW;
+            st4(patch + pix * LDX + qd * 4, load_in4(s, b, iy0 + py, ix0 + px, c0 + qd * 4));
+        }
+        return;
+    }
+    const bool two = s.mode == RAMNET_IN_CAT_MUL || s.mode == RAMNET_IN_RELUMASK;
+    for (int base = tid; base < nslots; base += NB * NT) {
+        float4 v[NB], m[NB];
+        int dst[NB];
+        bool ok[NB], hasm[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sl = base + i * NT;
+            const int pix = sl / QPP, qd = sl - pix * QPP;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px, c = c0 + qd * 4;
+            ok[i] = sl < nslots && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win && c < s.Cin;
+            dst[i] = sl < nslots ? pix * LDX + qd * 4 : -1;
+            const size_t gp = ((size_t)b * s.Hin + iy) * s.Win + ix;
+            const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c >= s.C0;
+            const float *p0 = second ? s.x1 + gp * s.ld1 + (c - s.C0) : s.x0 + gp * s.ld0 + c;
+            hasm[i] = two && (s.mode == RAMNET_IN_RELUMASK || second);
+            const float *p1 = s.mode == RAMNET_IN_RELUMASK ? s.xm + gp * s.ldm + c : s.xm + gp * s.ldm + (c - s.C0);
+            v[i] = ld4(ok[i] ? p0 : s.x0);
+            if (two) m[i] = ld4(ok[i] && hasm[i] ? p1 : s.x0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            float4 r = v[i];
+            if (two && hasm[i]) {
+                if (s.mode == RAMNET_IN_RELUMASK)
+                    r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
+                else
+                    r = f4mul(r, m[i]);
+            }
+            if (!ok[i]) r = f4zero();
+            if (dst[i] >= 0) st4(patch + dst[i], r);
+        }
+    }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return cdiv(a, b) * b; }
 

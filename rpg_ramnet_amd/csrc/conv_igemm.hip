@@ -11,6 +11,7 @@
 // instead of once per tap) and whose B operand is a [BN][16] weight tile streamed through a
 // double-buffered LDS ring (global loads of tap t+1 are in flight under the MFMAs of tap t).
 // Fused epilogues: bias/ReLU/sigmoid, residual add, GRU blend, full LSTM cell.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace ramnet {
@@ -25,14 +26,14 @@ struct ConvDerived {
     unsigned woff[25];               // per-tap weight slice offset / CK (in 16-float rows)
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int G>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvDerived q) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TH = BM / TWID;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;                    // [PH*PW][LDP]
-    float *wsm = smem + q.patch_floats;     // [2][BN][LDP]
+    float *wsm = smem + q.patch_floats;     // [2][G][BN][LDP]: G taps per barrier
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,63 +66,72 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
-    // ---- weight tile ring: [BN][16] floats per (chunk, tap), contiguous in global memory
+    // ---- weight tile ring: [BN][16] floats per (chunk, tap), contiguous in global memory; G taps share one barrier
     constexpr int WF4 = BN * CK / 4;
     constexpr int WPT = (WF4 + 255) / 256;
-    float4 wreg[WPT];
-    auto load_w = [&](int chunk, int t) {
-        const float *src = p.w + ((size_t)q.woff[t] + ((size_t)chunk * q.CoutPad + n0)) * CK;
+    float4 wreg[G][WPT];
+    const int ntaps = p.ntaps, ngroups = (ntaps + G - 1) / G;
+    auto load_w = [&](int chunk, int grp) {
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int f = tid + i * 256;
-            if (WF4 % 256 == 0 || f < WF4) wreg[i] = ld4(src + (size_t)f * 4);
+        for (int j = 0; j < G; ++j) {
+            const int t = grp * G + j;
+            if (t < ntaps) {
+                const float *src = p.w + ((size_t)q.woff[t] + ((size_t)chunk * q.CoutPad + n0)) * CK;
+#pragma unroll
+                for (int i = 0; i < WPT; ++i) {
+                    const int f = tid + i * 256;
+                    if (WF4 % 256 == 0 || f < WF4) wreg[j][i] = ld4(src + (size_t)f * 4);
+                }
+            }
         }
     };
     auto store_w = [&](int buf) {
-        float *dst = wsm + buf * (BN * LDP);
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int f = tid + i * 256;
-            if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[i]);
+        for (int j = 0; j < G; ++j) {
+            float *dst = wsm + (buf * G + j) * (BN * LDP);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int f = tid + i * 256;
+                if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[j][i]);
+            }
         }
     };
 
-    const int ntaps = p.ntaps;
     load_w(0, 0);
     int buf = 0;
-    const int nslots = q.PH * q.PW * (CK / 4);
     for (int chunk = 0; chunk < q.nchunks; ++chunk) {
         __syncthreads();   // every wave is done reading the previous chunk's patch
         const int c0 = chunk * CK;
-        for (int s = tid; s < nslots; s += 256) {
-            const int pix = s >> 2, qd = s & 3;
-            const int py = pix / q.PW, px = pix - py * q.PW;
-            st4(patch + pix * LDP + qd * 4, load_in4(q.src, b, iy0 + py, ix0 + px, c0 + qd * 4));
-        }
-        for (int t = 0; t < ntaps; ++t) {
+        stage_patch<CK / 4, LDP, 4, 256>(patch, q.src, b, iy0, ix0, c0, q.PH, q.PW, tid);
+        for (int grp = 0; grp < ngroups; ++grp) {
             store_w(buf);
-            __syncthreads();   // patch + weight tile visible; the other ring slot is free again
-            if (t + 1 < ntaps) load_w(chunk, t + 1);
+            __syncthreads();   // patch + weight tiles visible; the other ring slot is free again
+            if (grp + 1 < ngroups) load_w(chunk, grp + 1);
             else if (chunk + 1 < q.nchunks) load_w(chunk + 1, 0);
-            const float *pa = patch + q.toff[t];
-            const float *wb = wsm + buf * (BN * LDP);
 #pragma unroll
-            for (int k8 = 0; k8 < CK / 8; ++k8) {
-                float4 a[TM], bb[TN];
+            for (int j = 0; j < G; ++j) {
+                const int t = grp * G + j;
+                if (t >= ntaps) break;
+                const float *pa = patch + q.toff[t];
+                const float *wb = wsm + (buf * G + j) * (BN * LDP);
 #pragma unroll
-                for (int ms = 0; ms < TM; ++ms) a[ms] = ld4(pa + aBase[ms] + k8 * 8);
+                for (int k8 = 0; k8 < CK / 8; ++k8) {
+                    float4 a[TM], bb[TN];
 #pragma unroll
-                for (int ns = 0; ns < TN; ++ns) bb[ns] = ld4(wb + bBase[ns] + k8 * 8);
-                // lanes 0-31 feed channels k8*8+j, lanes 32-63 channels k8*8+4+j: 4 MFMAs cover 8 channels
+                    for (int ms = 0; ms < TM; ++ms) a[ms] = ld4(pa + aBase[ms] + k8 * 8);
 #pragma unroll
-                for (int ms = 0; ms < TM; ++ms)
+                    for (int ns = 0; ns < TN; ++ns) bb[ns] = ld4(wb + bBase[ns] + k8 * 8);
+                    // lanes 0-31 feed channels k8*8+j, lanes 32-63 channels k8*8+4+j: 4 MFMAs cover 8 channels
 #pragma unroll
-                    for (int ns = 0; ns < TN; ++ns) {
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].x, bb[ns].x, acc[ms][ns], 0, 0, 0);
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].y, bb[ns].y, acc[ms][ns], 0, 0, 0);
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].z, bb[ns].z, acc[ms][ns], 0, 0, 0);
-                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].w, bb[ns].w, acc[ms][ns], 0, 0, 0);
-                    }
+                    for (int ms = 0; ms < TM; ++ms)
+#pragma unroll
+                        for (int ns = 0; ns < TN; ++ns) {
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].x, bb[ns].x, acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].y, bb[ns].y, acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].z, bb[ns].z, acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].w, bb[ns].w, acc[ms][ns], 0, 0, 0);
+                        }
+                }
             }
             buf ^= 1;
         }
@@ -184,10 +194,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
-    const size_t lds = ((size_t)q.patch_floats + 2 * BN * LDP) * sizeof(float);
+template <int BM, int BN, int WM, int WN, int G>
+static int launch_g(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, G>;
+    const size_t lds = ((size_t)q.patch_floats + 2 * G * BN * LDP) * sizeof(float);
     static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation (monotone)
     if (lds > lds_set) {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -201,6 +211,16 @@ static int launch_cfg(const ramnet_conv_desc &d, const ConvDerived &q, hipStream
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();
     return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
+    // taps per barrier.  Measured on MI355X (profiles/r01_b_tuning_notes.md): G=1 93 TF/s, G=2 84, G=3 75 summed over the
+    // forward layers — the extra weight-ring LDS of G>1 costs a co-resident workgroup, which hides more latency than
+    // the saved barriers.  G=2 stays available for experiments.
+    static const char *e = getenv("RAMNET_CONV_G");
+    if (e && atoi(e) == 2) return launch_g<BM, BN, WM, WN, 2>(d, q, st);
+    return launch_g<BM, BN, WM, WN, 1>(d, q, st);
 }
 
 }  // namespace ramnet
@@ -236,7 +256,17 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
         dymin = d.dy[t] < dymin ? d.dy[t] : dymin, dymax = d.dy[t] > dymax ? d.dy[t] : dymax;
         dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin, dxmax = d.dx[t] > dxmax ? d.dx[t] : dxmax;
     }
-    constexpr int TH = 8;   // BM = 128 in every configuration below
+    // ---- tile configuration.  Low-resolution layers (32x43 .. 64x86 pixels) give few 128-pixel tiles: a grid that does
+    // not cover the 256 CUs ~3x over leaves CUs idle in the last round (tile quantisation), so shrink the tile there.
+    const int lstm = d.epi == RAMNET_EPI_LSTM;
+    int BM = 128, BN = lstm ? 128 : (q.CoutPad % 128 == 0 ? 128 : q.CoutPad % 64 == 0 ? 64 : 32);
+    auto blocks = [&](int bm, int bn) { return (long)cdiv(d.Wo, TWID) * cdiv(d.Ho, bm / TWID) * d.B * (q.CoutPad / bn); };
+    if (!lstm && BN >= 64) {
+        const long want = 768;
+        if (blocks(BM, BN) < want) BM = 64;
+        if (blocks(BM, BN) < want && BN == 128) BN = 64;
+    }
+    const int TH = BM / TWID;
     q.dymin = dymin, q.dxmin = dxmin;
     q.PH = (TH - 1) * d.stride + (dymax - dymin) + 1;
     q.PW = (TWID - 1) * d.stride + (dxmax - dxmin) + 1;
@@ -247,8 +277,10 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
         q.woff[t] = (unsigned)d.wtap[t] * (unsigned)q.nchunks * (unsigned)q.CoutPad;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d.epi == RAMNET_EPI_LSTM) return launch_cfg<128, 128, 4, 1>(d, q, st);
-    if (q.CoutPad % 128 == 0) return launch_cfg<128, 128, 2, 2>(d, q, st);
-    if (q.CoutPad % 64 == 0) return launch_cfg<128, 64, 2, 2>(d, q, st);
+    if (lstm) return launch_cfg<128, 128, 4, 1>(d, q, st);
+    if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 2>(d, q, st);
+    if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2>(d, q, st);
+    if (BM == 64 && BN == 128) return launch_cfg<64, 128, 2, 2>(d, q, st);
+    if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2>(d, q, st);
     return launch_cfg<128, 32, 4, 1>(d, q, st);
 }

@@ -10,44 +10,53 @@
 // over the 4 waves (wave w: N-half w&1, taps (w>>1), (w>>1)+2, ...) and stay in registers for the
 // whole pixel range of the workgroup; partial sums of the pixel splits meet in a [tap][Cin][Cout]
 // fp32 workspace through coalesced atomic adds.  The bias gradient (column sums of g) rides along.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace ramnet {
 
 constexpr int WTH = 8;          // pixel tile = 8 x 16
-constexpr int WBN = 64;         // output channels per workgroup
 
 struct WgradDerived {
     InSrc src;
     int PH, PW, dymin, dxmin;
     int tiles_x, tiles_y, ntiles;   // pixel tiles per image / total
+    int tpm, ntt;                   // taps per 32-row accumulator tile (Cin < 32 packs several taps), number of tap tiles
     int toff[25];
 };
 
-template <int MAXT>
+// MAXT: accumulator tiles per wave; NSUB: 32-wide output-channel sub-tiles per workgroup (WBN = 32*NSUB).
+// Accumulator tile (jt, ns): rows = (tap jt*tpm + row/cinp, channel row%cinp), cols = output channel ns*32 + col.
+// Wave w owns ns = w % NSUB and tap tiles w/NSUB, w/NSUB + 4/NSUB, ...; waves with fewer real tiles run the same MAXT
+// MFMAs on a valid dummy address (they would wait at the barrier anyway) so the K loop has no branches.
+template <int MAXT, int NSUB>
 __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_desc p, const WgradDerived q) {
+    constexpr int WBN = 32 * NSUB, TSTEP = 4 / NSUB, GQ = WBN / 4;   // GQ: channel quads per gradient-tile pixel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;                         // [PH*PW][32]
-    float *gsm = smem + q.PH * q.PW * WCK;       // [128][64]
+    float *gsm = smem + q.PH * q.PW * WCK;       // [128][WBN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
-    const int ns = wave & 1, tap0 = wave >> 1;
-    const int ntw = (p.ntaps - tap0 + 1) / 2;    // taps owned by this wave: tap0, tap0+2, ...
+    const int ns = wave % NSUB, tap0 = wave / NSUB;
+    const int ntw = (q.ntt - tap0 + TSTEP - 1) / TSTEP;
     const int c0 = blockIdx.y * WCK, n0 = blockIdx.z * WBN;
+    const int cinp = 32 / q.tpm, sub = l31 / cinp, cl = l31 - sub * cinp;
 
     f32x16 acc[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    int toffw[MAXT];
+    int toffw[MAXT];                             // per-lane LDS offset of this lane's (tap, channel) row
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) toffw[j] = j < ntw ? q.toff[tap0 + 2 * j] : 0;
+    for (int j = 0; j < MAXT; ++j) {
+        const int tap = (tap0 + TSTEP * j) * q.tpm + sub;
+        toffw[j] = (j < ntw && tap < p.ntaps) ? q.toff[tap] + cl : cl;
+    }
 
-    float4 bsum = f4zero();                      // bias gradient partial: fixed channel quad (tid & 15)
+    float4 bsum = f4zero();                      // bias gradient partial: fixed channel quad (tid % GQ)
     const bool do_bias = p.dbias != nullptr && blockIdx.y == 0;
-    const int nslots = q.PH * q.PW * (WCK / 4);
 
     for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
         int tt = tile;
@@ -58,70 +67,72 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
         const int oy0 = ty_i * WTH, ox0 = tx_i * TWID;
         const int iy0 = oy0 * p.stride + q.dymin, ix0 = ox0 * p.stride + q.dxmin;
         __syncthreads();
-        for (int s = tid; s < nslots; s += 256) {
-            const int pix = s >> 3, qd = s & 7;
-            const int py = pix / q.PW, px = pix - py * q.PW;
-            st4(patch + pix * WCK + qd * 4, load_in4(q.src, b, iy0 + py, ix0 + px, c0 + qd * 4));
-        }
+        {   // gradient tile: 128 pixels x GQ channel quads, all loads (x2 with mask) in flight at once
+            constexpr int NG = 128 * GQ / 256;
+            float4 g[NG], y[NG];
+            bool ok[NG];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {            // 128 pixels x 16 channel quads
-            const int s = tid + i * 256;
-            const int m = s >> 4, qd = s & 15;
-            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
-            float4 g = f4zero();
-            if (oy < p.Ho && ox < p.Wo && n < p.Cout) {
+            for (int i = 0; i < NG; ++i) {
+                const int s = tid + i * 256;
+                const int m = s / GQ, qd = s % GQ;
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
+                ok[i] = oy < p.Ho && ox < p.Wo && n < p.Cout;
                 const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
-                g = ld4(p.dout + pix * p.ldg + n);
-                if (p.gmask) {
-                    const float4 y = ld4(p.gmask + pix * p.ldgm + n);
-                    g = make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
-                }
+                g[i] = ld4(ok[i] ? p.dout + pix * p.ldg + n : p.dout);
+                if (p.gmask) y[i] = ld4(ok[i] ? p.gmask + pix * p.ldgm + n : p.gmask);
             }
-            st4(gsm + m * WBN + qd * 4, g);
-            bsum = f4add(bsum, g);
+            stage_patch<WCK / 4, WCK, 4, 256>(patch, q.src, b, iy0, ix0, c0, q.PH, q.PW, tid);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int s = tid + i * 256;
+                float4 r = g[i];
+                if (p.gmask) r = make_float4(y[i].x > 0.f ? r.x : 0.f, y[i].y > 0.f ? r.y : 0.f, y[i].z > 0.f ? r.z : 0.f, y[i].w > 0.f ? r.w : 0.f);
+                if (!ok[i]) r = f4zero();
+                st4(gsm + (s / GQ) * WBN + (s % GQ) * 4, r);
+                bsum = f4add(bsum, r);
+            }
         }
         __syncthreads();
 #pragma unroll 4
         for (int i = 0; i < 64; ++i) {           // K step = 2 pixels (lanes 0-31: pixel 2i, lanes 32-63: pixel 2i+1)
             const int m = 2 * i + kk;
             const float bv = gsm[m * WBN + ns * 32 + l31];
-            const float *pa = patch + (((m >> 4) * p.stride) * q.PW + (m & 15) * p.stride) * WCK + l31;
+            const float *pa = patch + (((m >> 4) * p.stride) * q.PW + (m & 15) * p.stride) * WCK;
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j)
-                if (j < ntw) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[toffw[j]], bv, acc[j], 0, 0, 0);
+            for (int j = 0; j < MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[toffw[j]], bv, acc[j], 0, 0, 0);
         }
     }
 
-    // D[row = input channel][col = output channel] -> ws[(tap*Cin + c)*Cout + n]
+    // D[row = (tap, input channel)][col = output channel] -> ws[(tap*Cin + c)*Cout + n]
     const int Cin = q.src.Cin;
     const int n = n0 + ns * 32 + l31;
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
         if (j >= ntw) continue;
-        const int t = tap0 + 2 * j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)t * Cin + c) * p.Cout + n, acc[j][r]);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int t = (tap0 + TSTEP * j) * q.tpm + row / cinp, c = c0 + row % cinp;
+            if (t < p.ntaps && c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)t * Cin + c) * p.Cout + n, acc[j][r]);
         }
     }
     if (do_bias) {
         __syncthreads();
-        float *red = smem;                        // [16][64]
-        st4(red + (tid >> 4) * WBN + (tid & 15) * 4, bsum);
+        float *red = smem;                        // [256 / GQ][WBN]
+        st4(red + (tid / GQ) * WBN + (tid % GQ) * 4, bsum);
         __syncthreads();
         if (tid < WBN) {
             float s = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) s += red[g * WBN + tid];
+            for (int g = 0; g < 256 / GQ; ++g) s += red[g * WBN + tid];
             if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, s);
         }
     }
 }
 
-template <int MAXT>
+template <int MAXT, int NSUB>
 static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipStream_t st) {
-    auto kern = conv_wgrad_kernel<MAXT>;
+    auto kern = conv_wgrad_kernel<MAXT, NSUB>;
+    constexpr int WBN = 32 * NSUB;
     size_t lds = ((size_t)q.PH * q.PW * WCK + 128 * WBN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -133,7 +144,9 @@ static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipSt
         return RAMNET_E_UNSUPPORTED;
     }
     const int gy = cdiv(q.src.Cin, WCK), gz = cdiv(d.Cout, WBN);
-    int splits = cdiv(1024, gy * gz);             // ~4 workgroups per CU worth of parallelism
+    // one resident wave of workgroups (256 CUs x blocks/CU the register budget admits): fewer pixel splits = fewer
+    // atomic partial-sum merges, and every CU still gets an equal share
+    int splits = (MAXT >= 13 ? 256 : 512) / (gy * gz);
     if (splits > q.ntiles) splits = q.ntiles;
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(kern, dim3(splits, gy, gz), dim3(256), lds, st, d, q);
@@ -175,8 +188,22 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
     q.ntiles = q.tiles_x * q.tiles_y * d.B;
     for (int t = 0; t < d.ntaps; ++t) q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * WCK;
     hipStream_t st = (hipStream_t)stream;
-    const int per_wave = (d.ntaps + 1) / 2;       // wave 0/1 own ceil(ntaps/2) taps
-    if (per_wave <= 1) return launch_wgrad<1>(d, q, st);
-    if (per_wave <= 5) return launch_wgrad<5>(d, q, st);
-    return launch_wgrad<13>(d, q, st);
+    // Cin < 32: several taps share one 32-row accumulator tile (head convs: 5 or 1 input channels)
+    q.tpm = 1;
+    if (q.src.Cin <= 16) q.tpm = q.src.Cin <= 4 ? 8 : q.src.Cin <= 8 ? 4 : 2;
+    q.ntt = cdiv(d.ntaps, q.tpm);
+    static const char *force = getenv("RAMNET_WGRAD_NSUB");
+    // measured (profiles/r01_*layers*): 5x5 layers run 1.5x faster with WBN = 32 (7 tiles/wave, 2 workgroups/CU) than with
+    // WBN = 64 (13 tiles/wave, 1 workgroup/CU); 3x3 layers prefer WBN = 64 (5 tiles/wave)
+    const bool narrow = d.Cout <= 32 || d.ntaps > 9 || (force && force[0] == '1');
+    if (narrow) {                                   // WBN = 32: tap tiles spread over 4 waves
+        const int per_wave = cdiv(q.ntt, 4);
+        if (per_wave <= 1) return launch_wgrad<1, 1>(d, q, st);
+        if (per_wave <= 3) return launch_wgrad<3, 1>(d, q, st);
+        return launch_wgrad<7, 1>(d, q, st);
+    }
+    const int per_wave = cdiv(q.ntt, 2);            // WBN = 64: tap tiles spread over 2 wave pairs
+    if (per_wave <= 1) return launch_wgrad<1, 2>(d, q, st);
+    if (per_wave <= 5) return launch_wgrad<5, 2>(d, q, st);
+    return launch_wgrad<13, 2>(d, q, st);
 }
