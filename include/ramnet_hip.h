@@ -130,6 +130,8 @@ int ramnet_gru_bwd_b(const float *dxhr, const float *ur, const float *h, float *
  * dgates_pre [npix,4C], dc_prev.                                                                   */
 int ramnet_lstm_bwd(const float *gates, const float *cprev, const float *cnew, const float *dhn,
                     const float *dcn, float *dpre, float *dcprev, size_t npix, int C, void *stream);
+/* db[C] += sum_pixels dy * (mask > 0): bias gradient of the transposed-conv decoder (submodules.py:38-66). */
+int ramnet_bias_grad(const float *dy, const float *mask, float *db, size_t npix, int C, void *stream);
 /* y = a + b (gradient fan-in) */
 int ramnet_add(const float *a, const float *b, float *y, size_t n, void *stream);
 

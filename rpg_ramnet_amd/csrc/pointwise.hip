@@ -92,6 +92,28 @@ __global__ void add_kernel(const float *__restrict__ a, const float *__restrict_
     for (size_t i = n4 * 4 + i0; i < n; i += stride) y[i] = a[i] + b[i];
 }
 
+// db[c] += sum_pixels dy[pix][c] * (mask[pix][c] > 0)   (bias gradient of a layer whose wgrad launch cannot carry it)
+__global__ void bias_grad_kernel(const float *__restrict__ dy, const float *__restrict__ mask, float *__restrict__ db,
+                                 size_t npix, int C) {
+    const int C4 = C / 4, q = threadIdx.x % C4, rows = blockDim.x / C4, r0 = threadIdx.x / C4;
+    float4 s = f4zero();
+    if (r0 < rows)
+        for (size_t pix = blockIdx.x * (size_t)rows + r0; pix < npix; pix += (size_t)gridDim.x * rows) {
+            float4 g = ld4(dy + pix * C + q * 4);
+            if (mask) {
+                const float4 m = ld4(mask + pix * C + q * 4);
+                g = make_float4(m.x > 0.f ? g.x : 0.f, m.y > 0.f ? g.y : 0.f, m.z > 0.f ? g.z : 0.f, m.w > 0.f ? g.w : 0.f);
+            }
+            s = f4add(s, g);
+        }
+    if (r0 < rows) {
+        atomicAdd(db + q * 4 + 0, s.x);
+        atomicAdd(db + q * 4 + 1, s.y);
+        atomicAdd(db + q * 4 + 2, s.z);
+        atomicAdd(db + q * 4 + 3, s.w);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ prediction head
 // 8 lanes per pixel, each owns channel quads q, q+8, ...; butterfly over the 8 lanes.
 __global__ void pred_sigmoid_fwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
@@ -322,6 +344,13 @@ extern "C" int ramnet_unpack_wgrad(const float *ws, float *grad, int Cout, int C
 extern "C" int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *stream) {
     RAMNET_CHECK_ARG(dy && y && dx);
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_bias_grad(const float *dy, const float *mask, float *db, size_t npix, int C, void *stream) {
+    RAMNET_CHECK_ARG(dy && db && C > 0 && C % 4 == 0 && C <= 1024);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, dy, mask, db, npix, C);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

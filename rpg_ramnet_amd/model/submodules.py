@@ -58,11 +58,19 @@ class UpsampleConvLayer(nn.Module, _Lazy):
         return ops.ConvAct.apply(x, skip, self.conv2d.weight, self.conv2d.bias, self.cp(), 1, True, True)
 
 
-class TransposedConvLayer(nn.Module):
-    def __init__(self, *a, **k):
+class TransposedConvLayer(nn.Module, _Lazy):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
         super().__init__()
-        raise NotImplementedError("use_upsample_conv=False (TransposedConvLayer): not on the HIP path yet; "
-                                  "every shipped config uses the upsample-conv decoder")
+        _check_norm(norm)
+        assert kernel_size == 5 and padding == 2 and activation == 'relu'
+        self.transposed_conv2d = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=2, padding=padding,
+                                                    output_padding=1, bias=True)
+
+    def forward(self, x, skip=None):
+        if skip is not None:
+            x = ops.Add.apply(x, skip)
+        t = self.transposed_conv2d
+        return ops.TConvAct.apply(x, t.weight, t.bias, self._cp("t", [t.weight], [t.bias]))
 
 
 class ResidualBlock(nn.Module, _Lazy):

@@ -204,7 +204,8 @@ class ConvParam:
             g = ensure_grad(w)
             H.check(H.lib().ramnet_unpack_wgrad(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off,
                                                 self.k, self.k, _st()), "ramnet_unpack_wgrad")
-            ensure_grad(b).add_(self._bws[off:off + n])
+            if b.shape[0] == n:                        # (transposed conv: bias has Cout_t entries, handled by its op)
+                ensure_grad(b).add_(self._bws[off:off + n])
             off += n
         self._ws.zero_()
         self._bws.zero_()
@@ -270,6 +271,44 @@ class ConvAct(Function):
                 dx = gin
             dskip = dx if skip is not None else None
         return dx, dskip, None, None, None, None, None, None
+
+
+class TConvAct(Function):
+    """TransposedConvLayer (submodules.py:38-66): ConvTranspose2d k5 s2 p2 output_padding 1 -> bias -> ReLU.
+    The ConvTranspose weight [Cin, Cout, 5, 5] IS the OIHW weight of the stride-2 conv whose backward-data this op
+    computes, so forward = 4 sub-pixel launches of the backward-data form, backward-data = a plain stride-2 conv."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cp):
+        x = dense(x)
+        B, Hh, W, _ = x.shape
+        Ct = cp.Cin                                    # ConvParam sees (O=Cin_t, I=Cout_t): produced channels = cp.Cin
+        y = torch.empty(B, 2 * Hh, 2 * W, Ct, device=x.device)
+        for py in range(2):
+            for px in range(2):
+                conv_launch(x, Taps.get("dgrad2", 5, 2, py, px), cp.bwd(), y, Ct, bias=cp.bias(), epi=H.EPI_RELU,
+                            Ho=Hh, Wo=W, os=(2, 2, py, px))
+        ctx.cp = cp
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        cp = ctx.cp
+        dy = dense(dy)
+        B, Hh, W, Cx = x.shape
+        taps = Taps.get("conv", 5, 2)
+        ws, _ = cp.grad_ws()
+        # weight gradient of the stride-2 conv (input = masked dy, output gradient = x); bias gradient = sum of masked dy
+        wgrad_launch(dy, taps, x, ws, Cx, stride=2, xm=y, in_mode=H.IN_RELUMASK)
+        dyc = dy.contiguous()
+        H.check(H.lib().ramnet_bias_grad(_p(dyc), _p(y), _p(ensure_grad(cp.biases[0])), B * 4 * Hh * W, cp.Cin, _st()), "bias_grad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, Hh, W, Cx, device=x.device)
+            conv_launch(dy, taps, cp.fwd(), dx, Cx, stride=2, xm=y, in_mode=H.IN_RELUMASK)
+        return dx, None, None, None
 
 
 class ResConv(Function):

@@ -24,7 +24,11 @@ def check_weights(model, z):
 def run_fixture(tag, arch="ERGB2DepthRecurrent"):
     cfg, z = ref_cfg("net_%s.npz" % tag)
     model = build_hip_model(arch, cfg).eval()
-    check_weights(model, z)
+    if any(k.startswith("w.") for k in z.files):      # explicit reference weights (narrow variants)
+        sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+        model.load_state_dict(sd, strict=True)
+    else:
+        check_weights(model, z)
     seed, B, H, W, n_ev, c_ev, c_img, calls = [int(v) for v in z["recipe"]]
     rng = np.random.default_rng(seed)
     prev_super, prev_lstm = None, ramnet_ref.empty_states_lstm(cfg["every_x_rgb_frame"])
@@ -50,6 +54,18 @@ def run_fixture(tag, arch="ERGB2DepthRecurrent"):
 @pytest.mark.parametrize("tag", ["seeded_ramnet", "seeded_ramnet_lstm", "seeded_base_rgb"])
 def test_reference_golden_forward(tag):
     run_fixture(tag)
+
+
+@pytest.mark.parametrize("tag", ["small_gru", "small_lstm", "small_gru_enclstm", "small_tconv", "small_base_rgb",
+                                 "small_base_e", "small_base_ergb0"])
+def test_reference_golden_explicit_weights(tag):
+    """Narrow (base_num_channels=4) variants with the reference's own weights stored in the fixture: every wiring
+    mode of ERGB2DepthRecurrent incl. ConvLSTM encoders, the transposed-conv decoder and the three baselines."""
+    run_fixture(tag)
+
+
+def test_reference_golden_unet_explicit_weights():
+    run_fixture("small_unet", "ERGB2Depth")
 
 
 def test_reference_golden_unet():

@@ -89,6 +89,20 @@ def test_upsample_conv(B, H, W, cin, cout, skip):
     run_pair(m, oracle, [x, s] if skip else [x])
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 8, 16), (1, 5, 11)])
+@pytest.mark.parametrize("cin,cout,skip", [(64, 32, True), (32, 16, False)])
+def test_transposed_conv(B, H, W, cin, cout, skip):
+    from rpg_ramnet_amd.model.submodules import TransposedConvLayer
+    torch.manual_seed(8)
+    m = TransposedConvLayer(cin, cout, 5, padding=2)
+    x, s = torch.randn(B, cin, H, W), (torch.randn(B, cin, H, W) if skip else None)
+
+    def oracle(sd, a, sk=None):
+        return ramnet_ref.transposed_conv_layer({"L." + k: v for k, v in sd.items()}, "L", a if sk is None else a + sk)
+
+    run_pair(m, oracle, [x, s] if skip else [x])
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_residual_block(B, H, W, C):
     from rpg_ramnet_amd.model.submodules import ResidualBlock
