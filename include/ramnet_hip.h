@@ -34,6 +34,13 @@ enum ramnet_in_mode {
     RAMNET_IN_RELUMASK = 5   /* x0 * (xm > 0)                  backward through a ReLU             */
 };
 
+/* ---- arithmetic of the MFMA contraction ----------------------------------------------------------
+ * F32:    v_mfma_f32_32x32x2_f32, bit-exact fp32 (157 TFLOP/s peak).
+ * BF16X3: every fp32 operand x is split on the fly into bf16 hi + lo (hi+lo = x to ~2^-17) and a*b is evaluated as
+ *         hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error ~1e-5 per
+ *         product (vs 4e-3 for plain bf16), 3 MFMAs at 16x the fp32 rate.  Inputs/outputs stay fp32 in HBM.    */
+enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
+
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {
     RAMNET_EPI_LINEAR = 0,    /* acc + bias                                                      */
@@ -68,6 +75,7 @@ typedef struct ramnet_conv_desc {
     int lde0, lde1;
     float *out, *o1, *o2;
     int ldo, ldo1, ldo2;
+    int precision;                  /* RAMNET_PREC_F32 (exact fp32 MFMA) or RAMNET_PREC_BF16X3 (w packed with split=1) */
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
@@ -94,6 +102,10 @@ int ramnet_abi_version(void);
 int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream);
 /* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
 size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
+/* Same for the BF16X3 layout [tap][chunk32][hi|lo][n][32 bf16] (result in floats = bytes/4).       */
+size_t ramnet_packed_weight_elems_split(int Cout, int Cin, int KH, int KW, int transposed, int gates);
+int ramnet_pack_weight_split(const float *w_oihw, float *wp, int Cout, int Cin, int KH, int KW,
+                             int transposed, int gates, void *stream);
 /* OIHW -> kernel layout [tap][chunk][n][16].  transposed=1 packs the backward-data operator
  * (reduce over O, produce I).  gates=4 interleaves ConvLSTM gate blocks so that one wave owns
  * i,f,o,g of a channel (forward only).  CinValid rows beyond Cin are zero (padded inputs).        */

@@ -10,6 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "librpg_ramnet_hip.so")
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK = range(6)
+PREC_F32, PREC_BF16X3 = 0, 1
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
 
 _fp = C.c_void_p
@@ -30,6 +31,7 @@ class ConvDesc(C.Structure):
         ("e0", _fp), ("e1", _fp), ("lde0", C.c_int), ("lde1", C.c_int),
         ("out", _fp), ("o1", _fp), ("o2", _fp),
         ("ldo", C.c_int), ("ldo1", C.c_int), ("ldo2", C.c_int),
+        ("precision", C.c_int),
     ]
 
 
@@ -53,6 +55,8 @@ _SIGS = {
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_packed_weight_elems_split": (C.c_size_t, [C.c_int] * 6),
+    "ramnet_pack_weight_split": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),

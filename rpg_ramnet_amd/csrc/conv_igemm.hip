@@ -23,17 +23,23 @@ struct ConvDerived {
     int patch_floats;                // PH*PW*LDP (multiple of 4)
     int tiles_x, tiles_y;
     int toff[25];                    // per-tap patch offset (floats)
-    unsigned woff[25];               // per-tap weight slice offset / CK (in 16-float rows)
+    unsigned woff[25];               // per-tap weight slice offset in 64-byte rows
 };
 
-template <int BM, int BN, int WM, int WN, int G>
+// SPLIT = false: exact fp32 (v_mfma_f32_32x32x2_f32), 16 channels per chunk.
+// SPLIT = true : BF16X3 — operands split into bf16 hi/lo planes while staging, 3 x v_mfma_f32_32x32x16_bf16 per
+//                16-channel slab (hi*hi + hi*lo + lo*hi), 32 channels per chunk.  LDS rows are 80 bytes in both modes
+//                (16 fp32 + pad | 32 bf16 + pad), so tile geometry, tap offsets and fragment addresses are shared.
+template <int BM, int BN, int WM, int WN, bool SPLIT>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvDerived q) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TH = BM / TWID;
+    constexpr int CKC = SPLIT ? 32 : 16;           // input channels per chunk
+    constexpr int NPL = SPLIT ? 2 : 1;             // LDS planes (hi, lo)
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                    // [PH*PW][LDP]
-    float *wsm = smem + q.patch_floats;     // [2][G][BN][LDP]: G taps per barrier
+    float *patch = smem;                            // [NPL][PH*PW][LDP]
+    float *wsm = smem + NPL * q.patch_floats;       // [2][NPL][BN][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,33 +72,30 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
-    // ---- weight tile ring: [BN][16] floats per (chunk, tap), contiguous in global memory; G taps share one barrier
-    constexpr int WF4 = BN * CK / 4;
+    // ---- weight tile ring: per (chunk, tap) NPL planes of [BN] rows x 64 bytes, each plane contiguous in global memory
+    constexpr int WF4 = BN * 4;                     // 16-byte units per plane
     constexpr int WPT = (WF4 + 255) / 256;
-    float4 wreg[G][WPT];
-    const int ntaps = p.ntaps, ngroups = (ntaps + G - 1) / G;
-    auto load_w = [&](int chunk, int grp) {
+    float4 wreg[NPL][WPT];
+    const int ntaps = p.ntaps;
+    auto load_w = [&](int chunk, int t) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            const int t = grp * G + j;
-            if (t < ntaps) {
-                const float *src = p.w + ((size_t)q.woff[t] + ((size_t)chunk * q.CoutPad + n0)) * CK;
+        for (int pl = 0; pl < NPL; ++pl) {
+            const float *src = p.w + ((size_t)q.woff[t] + ((size_t)(chunk * NPL + pl) * q.CoutPad + n0)) * 16;
 #pragma unroll
-                for (int i = 0; i < WPT; ++i) {
-                    const int f = tid + i * 256;
-                    if (WF4 % 256 == 0 || f < WF4) wreg[j][i] = ld4(src + (size_t)f * 4);
-                }
+            for (int i = 0; i < WPT; ++i) {
+                const int f = tid + i * 256;
+                if (WF4 % 256 == 0 || f < WF4) wreg[pl][i] = ld4(src + (size_t)f * 4);
             }
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-            float *dst = wsm + (buf * G + j) * (BN * LDP);
+        for (int pl = 0; pl < NPL; ++pl) {
+            float *dst = wsm + (buf * NPL + pl) * (BN * LDP);
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const int f = tid + i * 256;
-                if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[j][i]);
+                if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[pl][i]);
             }
         }
     };
@@ -101,21 +104,17 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     int buf = 0;
     for (int chunk = 0; chunk < q.nchunks; ++chunk) {
         __syncthreads();   // every wave is done reading the previous chunk's patch
-        const int c0 = chunk * CK;
-        stage_patch<CK / 4, LDP, 4, 256>(patch, q.src, b, iy0, ix0, c0, q.PH, q.PW, tid);
-        for (int grp = 0; grp < ngroups; ++grp) {
+        stage_patch<CKC / 4, LDP, 4, 256, SPLIT>(patch, q.src, b, iy0, ix0, chunk * CKC, q.PH, q.PW, tid, q.patch_floats);
+        for (int t = 0; t < ntaps; ++t) {
             store_w(buf);
-            __syncthreads();   // patch + weight tiles visible; the other ring slot is free again
-            if (grp + 1 < ngroups) load_w(chunk, grp + 1);
+            __syncthreads();   // patch + weight tile visible; the other ring slot is free again
+            if (t + 1 < ntaps) load_w(chunk, t + 1);
             else if (chunk + 1 < q.nchunks) load_w(chunk + 1, 0);
+            const float *pa = patch + q.toff[t];
+            const float *wb = wsm + buf * NPL * (BN * LDP);
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const int t = grp * G + j;
-                if (t >= ntaps) break;
-                const float *pa = patch + q.toff[t];
-                const float *wb = wsm + (buf * G + j) * (BN * LDP);
-#pragma unroll
-                for (int k8 = 0; k8 < CK / 8; ++k8) {
+            for (int k8 = 0; k8 < 2; ++k8) {
+                if constexpr (!SPLIT) {
                     float4 a[TM], bb[TN];
 #pragma unroll
                     for (int ms = 0; ms < TM; ++ms) a[ms] = ld4(pa + aBase[ms] + k8 * 8);
@@ -130,6 +129,27 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
                             acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].y, bb[ns].y, acc[ms][ns], 0, 0, 0);
                             acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].z, bb[ns].z, acc[ms][ns], 0, 0, 0);
                             acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].w, bb[ns].w, acc[ms][ns], 0, 0, 0);
+                        }
+                } else {
+                    // one K=16 slab: lanes 0-31 hold channels 16*k8 .. +7, lanes 32-63 channels 16*k8+8 .. +15 (16 B each)
+                    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                    for (int ms = 0; ms < TM; ++ms) {
+                        ah[ms] = __builtin_bit_cast(bf16x8, ld4(pa + aBase[ms] + k8 * 8));
+                        al[ms] = __builtin_bit_cast(bf16x8, ld4(pa + q.patch_floats + aBase[ms] + k8 * 8));
+                    }
+#pragma unroll
+                    for (int ns = 0; ns < TN; ++ns) {
+                        bh[ns] = __builtin_bit_cast(bf16x8, ld4(wb + bBase[ns] + k8 * 8));
+                        bl[ns] = __builtin_bit_cast(bf16x8, ld4(wb + BN * LDP + bBase[ns] + k8 * 8));
+                    }
+#pragma unroll
+                    for (int ms = 0; ms < TM; ++ms)
+#pragma unroll
+                        for (int ns = 0; ns < TN; ++ns) {
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ms], bl[ns], acc[ms][ns], 0, 0, 0);
+                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ms], bh[ns], acc[ms][ns], 0, 0, 0);
                         }
                 }
             }
@@ -194,11 +214,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int G>
-static int launch_g(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, G>;
-    const size_t lds = ((size_t)q.patch_floats + 2 * G * BN * LDP) * sizeof(float);
-    static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation (monotone)
+template <int BM, int BN, int WM, int WN, bool SPLIT>
+static int launch_p(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, SPLIT>;
+    constexpr int NPL = SPLIT ? 2 : 1;
+    const size_t lds = ((size_t)NPL * q.patch_floats + 2 * NPL * BN * LDP) * sizeof(float);
+    static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation
     if (lds > lds_set) {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_set = 160 * 1024;
@@ -215,12 +236,8 @@ static int launch_g(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
-    // taps per barrier.  Measured on MI355X (profiles/r01_b_tuning_notes.md): G=1 93 TF/s, G=2 84, G=3 75 summed over the
-    // forward layers — the extra weight-ring LDS of G>1 costs a co-resident workgroup, which hides more latency than
-    // the saved barriers.  G=2 stays available for experiments.
-    static const char *e = getenv("RAMNET_CONV_G");
-    if (e && atoi(e) == 2) return launch_g<BM, BN, WM, WN, 2>(d, q, st);
-    return launch_g<BM, BN, WM, WN, 1>(d, q, st);
+    if (d.precision == RAMNET_PREC_BF16X3) return launch_p<BM, BN, WM, WN, true>(d, q, st);
+    return launch_p<BM, BN, WM, WN, false>(d, q, st);
 }
 
 }  // namespace ramnet
@@ -249,7 +266,9 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
     q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
-    q.nchunks = cdiv(q.src.Cin, CK);
+    const int split = d.precision == RAMNET_PREC_BF16X3;
+    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 || split);
+    q.nchunks = cdiv(q.src.Cin, split ? 32 : CK);
     q.CoutPad = d.epi == RAMNET_EPI_LSTM ? 4 * roundup(d.Cout, 32) : roundup(d.Cout, 32);
     int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
     for (int t = 0; t < d.ntaps; ++t) {
@@ -274,7 +293,7 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
     q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, TH);
     for (int t = 0; t < d.ntaps; ++t) {
         q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * LDP;
-        q.woff[t] = (unsigned)d.wtap[t] * (unsigned)q.nchunks * (unsigned)q.CoutPad;
+        q.woff[t] = (unsigned)d.wtap[t] * (unsigned)q.nchunks * (unsigned)(split ? 2 : 1) * (unsigned)q.CoutPad;
     }
     hipStream_t st = (hipStream_t)stream;
     if (lstm) return launch_cfg<128, 128, 4, 1>(d, q, st);

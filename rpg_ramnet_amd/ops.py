@@ -15,6 +15,22 @@ from . import _hip as H
 
 _NULL = None
 
+# Arithmetic of the forward / backward-data contraction: "f32" (exact fp32 MFMA, the parity path) or "bf16x3" (operands
+# split into bf16 hi+lo on the fly, hi*hi + hi*lo + lo*hi on the bf16 MFMA; ~1e-5 relative error per product).
+# Backward-weights always runs exact fp32.  Selected with set_precision() or the RAMNET_PRECISION environment variable.
+import os as _os
+
+_PRECISION = {"f32": H.PREC_F32, "bf16x3": H.PREC_BF16X3}[_os.environ.get("RAMNET_PRECISION", "f32")]
+
+
+def set_precision(name):
+    global _PRECISION
+    _PRECISION = {"f32": H.PREC_F32, "bf16x3": H.PREC_BF16X3}[name]
+
+
+def get_precision():
+    return "bf16x3" if _PRECISION == H.PREC_BF16X3 else "f32"
+
 
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -91,6 +107,7 @@ def conv_launch(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0,
     d.lde0, d.lde1 = (ld(e0) if e0 is not None else 0), (ld(e1) if e1 is not None else 0)
     d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
     d.ldo, d.ldo1, d.ldo2 = ld(out), (ld(o1) if o1 is not None else 0), (ld(o2) if o2 is not None else 0)
+    d.precision = _PRECISION
     H.check(H.lib().ramnet_conv_launch(C.byref(d), _st()), "ramnet_conv_launch")
 
 
@@ -161,21 +178,24 @@ class ConvParam:
         return w.detach().contiguous()
 
     def _pack(self, transposed):
-        n = H.lib().ramnet_packed_weight_elems(self.Cout, self.Cin, self.k, self.k, transposed, self.gates if not transposed else 1)
+        L, g = H.lib(), (self.gates if not transposed else 1)
+        split = _PRECISION == H.PREC_BF16X3
+        sizer, packer = (L.ramnet_packed_weight_elems_split, L.ramnet_pack_weight_split) if split else \
+                        (L.ramnet_packed_weight_elems, L.ramnet_pack_weight)
+        n = sizer(self.Cout, self.Cin, self.k, self.k, transposed, g)
         w = self._cat_w()
         out = torch.empty(n, device=w.device, dtype=torch.float32)
-        H.check(H.lib().ramnet_pack_weight(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, transposed,
-                                           self.gates if not transposed else 1, _st()), "ramnet_pack_weight")
+        H.check(packer(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, transposed, g, _st()), "ramnet_pack_weight")
         return out
 
     def fwd(self):
-        v = self._versions(self.weights)
+        v = (self._versions(self.weights), _PRECISION)
         if self._fwd is None or v != self._vf:
             self._fwd, self._vf = self._pack(0), v
         return self._fwd
 
     def bwd(self):
-        v = self._versions(self.weights)
+        v = (self._versions(self.weights), _PRECISION)
         if self._bwd is None or v != self._vb:
             self._bwd, self._vb = self._pack(1), v
         return self._bwd
