@@ -93,13 +93,32 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
             }
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < 64; ++i) {           // K step = 2 pixels (lanes 0-31: pixel 2i, lanes 32-63: pixel 2i+1)
-            const int m = 2 * i + kk;
-            const float bv = gsm[m * WBN + ns * 32 + l31];
-            const float *pa = patch + (((m >> 4) * p.stride) * q.PW + (m & 15) * p.stride) * WCK;
+        {   // K step = 2 pixels (lanes 0-31: pixel 2i, lanes 32-63: pixel 2i+1).  Two-stage operand pipeline pinned with
+            // sched_barrier: the LDS reads of step i+1 are issued BEFORE the MFMAs of step i (left alone, hipcc sinks the
+            // reads next to their use and every step eats a full LDS latency whenever the wave is alone on its SIMD).
+            float a0[MAXT], a1[MAXT], b0, b1;
+            auto fetch = [&](int i, float (&a)[MAXT], float &bv) {
+                const int m = 2 * i + kk;
+                bv = gsm[m * WBN + ns * 32 + l31];
+                const float *pa = patch + (((m >> 4) * p.stride) * q.PW + (m & 15) * p.stride) * WCK;
 #pragma unroll
-            for (int j = 0; j < MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[toffw[j]], bv, acc[j], 0, 0, 0);
+                for (int j = 0; j < MAXT; ++j) a[j] = pa[toffw[j]];
+            };
+            auto mma = [&](const float (&a)[MAXT], float bv) {
+#pragma unroll
+                for (int j = 0; j < MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv, acc[j], 0, 0, 0);
+            };
+            fetch(0, a0, b0);
+            for (int i = 0; i < 64; i += 2) {
+                fetch(i + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(i + 2 < 64 ? i + 2 : i, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 

@@ -127,11 +127,44 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
 
 
+# ------------------------------------------------------------------------------------------------ side stream
+# Backward-weights only feeds the gradient workspaces, never the backward-data chain, so it runs on a second HIP stream:
+# the hardware co-schedules its workgroups with the backward-data kernel of the main stream and fills the CUs that tile
+# quantisation / barrier stalls of one kernel leave idle.  Ordering: side waits for an event recorded on the main stream
+# (its inputs are ready), the end-of-backward fold waits for the side stream; inputs are record_stream()'ed so the
+# caching allocator does not recycle them while the side stream still reads them.
+_SIDE = {}
+_USE_SIDE = _os.environ.get("RAMNET_WGRAD_STREAM", "1") != "0"
+
+
+def _side_stream(dev):
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def wgrad_side(tensors, *args, **kw):
+    """wgrad_launch on the side stream (or inline when disabled)."""
+    if not _USE_SIDE:
+        return wgrad_launch(*args, **kw)
+    dev = args[0].device
+    side = _side_stream(dev)
+    side.wait_event(torch.cuda.current_stream().record_event())
+    with torch.cuda.stream(side):
+        wgrad_launch(*args, **kw)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    _Engine.side_used = dev
+
+
 # ------------------------------------------------------------------------------------------------ parameters
 class _Engine:
     """Per-backward-pass bookkeeping: fold weight-gradient workspaces into .grad when the engine finishes."""
     dirty = []
     queued = False
+    side_used = None
 
     @classmethod
     def mark(cls, cp):
@@ -144,6 +177,9 @@ class _Engine:
 
     @classmethod
     def flush(cls):
+        if cls.side_used is not None:      # all weight-gradient launches of this pass are done before the fold
+            torch.cuda.current_stream().wait_event(_side_stream(cls.side_used).record_event())
+            cls.side_used = None
         for cp in cls.dirty:
             cp.finalize()
         cls.dirty, cls.queued = [], False
@@ -270,8 +306,8 @@ class ConvAct(Function):
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
         ws, bws = cp.grad_ws()
-        wgrad_launch(x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
-                     Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
+        wgrad_side([x, skip, dy, y], x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
+                   Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
         dx = dskip = None
         if ctx.needs_input_grad[0] or (skip is not None and ctx.needs_input_grad[1]):
             gin = torch.empty(B, Hin, Win, cp.Cin, device=x.device)
@@ -351,7 +387,7 @@ class ResConv(Function):
         dpre = torch.empty_like(y)
         H.check(H.lib().ramnet_relu_bwd(_p(dy.contiguous()), _p(y), _p(dpre), y.numel(), _st()), "ramnet_relu_bwd")
         ws, bws = cp.grad_ws()
-        wgrad_launch(t, Taps.get("conv", 3, 1), dpre, ws, cp.Cout, dbias=bws)
+        wgrad_side([t, dpre], t, Taps.get("conv", 3, 1), dpre, ws, cp.Cout, dbias=bws)
         dt = torch.empty_like(t, memory_format=torch.contiguous_format)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dt, cp.Cin)
         return dt, dpre, None, None, None
@@ -392,12 +428,12 @@ class GRUCell(Function):
         H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_a")
         taps, tapsd = Taps.get("conv", 3, 1), Taps.get("dgrad1", 3, 1)
         ws, bws = cp_o.grad_ws()
-        wgrad_launch(x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
+        wgrad_side([x, h, ur, dpo], x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)       # [dx | dh]
         conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
         H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
         ws, bws = cp_ur.grad_ws()
-        wgrad_launch(x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
+        wgrad_side([x, h, dpur], x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)
         return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None
 
@@ -432,7 +468,7 @@ class LSTMCell(Function):
         dc = torch.empty_like(cn)
         H.check(H.lib().ramnet_lstm_bwd(_p(gates), _p(c), _p(cn), _p(dhn), _p(dcn), _p(dpre), _p(dc), npix, Cc, _st()), "lstm_bwd")
         ws, bws = cp.grad_ws()
-        wgrad_launch(x, Taps.get("conv", 3, 1), dpre, ws, 4 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
+        wgrad_side([x, h, dpre], x, Taps.get("conv", 3, 1), dpre, ws, 4 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dxh, 2 * Cc)
         return dxh[..., :Cc], dxh[..., Cc:], dc, None, None, None
