@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--state", choices=["convgru", "convlstm"], default="convgru")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="timed region with backward-weights on a side stream (faster; per-kernel timings then overlap)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) overlap / bf16x3 measurements")
     return ap.parse_args()
 
 
@@ -80,6 +84,7 @@ class KernelTimer:
     def __init__(self):
         self.rec = []
         self.on = False
+        self.only = None        # when set: bracket only launches of this kernel symbol (keeps the timed region unperturbed)
 
     def install(self):
         from rpg_ramnet_amd import ops
@@ -106,23 +111,21 @@ class KernelTimer:
         def conv(x0, taps, w, out, Cout, **kw):
             if not timer.on:
                 return conv0(x0, taps, w, out, Cout, **kw)
+            Ho, Wo = kw.get("Ho") or out.shape[1], kw.get("Wo") or out.shape[2]
+            name = variant(Cout, kw.get("epi", 0), x0.shape[0], Ho, Wo)
+            if timer.only is not None and name != timer.only:
+                return conv0(x0, taps, w, out, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             conv0(x0, taps, w, out, Cout, **kw)
             e.record()
             cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
-            Ho, Wo = kw.get("Ho") or out.shape[1], kw.get("Wo") or out.shape[2]
             nout = Cout * (4 if kw.get("epi") == 5 else 1)
-            timer.rec.append((variant(Cout, kw.get("epi", 0), x0.shape[0], Ho, Wo), s, e,
-                              2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * nout))
+            timer.rec.append((name, s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * nout))
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:
                 return wgrad0(x0, taps, dout, dw, Cout, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            wgrad0(x0, taps, dout, dw, Cout, **kw)
-            e.record()
             cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
             tpm = 1 if cin > 16 else 8 if cin <= 4 else 4 if cin <= 8 else 2      # mirror of ramnet_wgrad_launch
             ntt = -(-taps.n // tpm)
@@ -131,7 +134,13 @@ class KernelTimer:
                 name = "conv_wgrad_kernel<%d,1>" % (1 if per <= 1 else 3 if per <= 3 else 7)
             else:
                 per = -(-ntt // 2)
-                name = "conv_wgrad_kernel<%d,2>" % (1 if per <= 1 else 5 if per <= 5 else 13)
+                name = "conv_wgrad_kernel<%d,2>" % (1 if per <= 1 else 5)
+            if timer.only is not None and name != timer.only:
+                return wgrad0(x0, taps, dout, dw, Cout, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            wgrad0(x0, taps, dout, dw, Cout, **kw)
+            e.record()
             timer.rec.append((name, s, e, 2.0 * dout.shape[0] * dout.shape[1] * dout.shape[2] * taps.n * cin * Cout))
 
         ops.conv_launch, ops.wgrad_launch = conv, wgrad
@@ -187,6 +196,9 @@ def main():
     from rpg_ramnet_amd.parallel import FlatGradReducer
     from rpg_ramnet_amd.trainer import sequence_loss, empty_states_lstm
 
+    from rpg_ramnet_amd import ops
+    ops.set_precision(args.precision)
+    ops.set_wgrad_overlap(args.overlap_wgrad)
     K, bins, B, L, H, W = 5, 5, args.batch, args.seq_len, args.height, args.width
     cfg = dict(RELEASED, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)
@@ -228,11 +240,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up steps bracket EVERY MFMA launch with HIP events (per-kernel table + choice of the dominant symbol); in the
+    # timed region only the dominant symbol's launches are bracketed: ~7000 event pairs per step cost 3-4 % of the step.
     last = None
+    timer.on = not args.no_kernel_timing
     for _ in range(args.warmup):
         last = step()
     fence()
-    timer.on = True
+    warm = timer.summary()
+    timer.rec = []
+    if warm:
+        timer.only = max(warm.items(), key=lambda kv: kv[1][1])[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
@@ -246,29 +264,66 @@ def main():
     loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
+    # ---- extras (outside the timed region that defines `value`): the same step with (a) backward-weights overlapped on a
+    # side stream, (b) the bf16x3 split-operand contraction for forward/backward-data.  2 steps each, 1 warm-up.
+    extras = {}
+    if not args.no_extras and args.mode == "train" and world == 1:
+        def measure(n=2):
+            step()
+            fence()
+            t = time.perf_counter()
+            for _ in range(n):
+                lv = step()
+            fence()
+            e = (time.perf_counter() - t) / n
+            return {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach())}
+        if not args.overlap_wgrad:
+            ops.set_wgrad_overlap(True)
+            extras["overlap_wgrad"] = measure()
+            ops.set_wgrad_overlap(False)
+        if args.precision == "f32":
+            ops.set_precision("bf16x3")
+            extras["bf16x3_fwd_dgrad"] = dict(measure(), note="forward parity <= 1e-3 vs reference goldens is tested in "
+                                              "tests/test_hip_model.py[bf16x3]; backward-weights stays fp32")
+            ops.set_precision("f32")
+
     if rank == 0:
         samples = world * B * L * args.steps
         out = {"metric": "depth samples/sec (346x260 cropped to %dx%d, 5-bin grids, K=5 grids + 1 frame per sample; %s)"
                          % (H, W, "training step" if args.mode == "train" else "inference"),
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32" if args.precision == "f32" else "bf16x3(fwd,dgrad)+f32(wgrad)", "data": "synthetic",
                "config": {"workload": "EventScape-shaped 346x260 -> %dx%d crop, 5 event bins, K=5, batch %d/GPU, seq-len %d, "
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam"
                                       % (H, W, B, L, args.mode, args.state),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
                "final_loss": loss_val}
+        if extras:
+            out["extras"] = extras
         agg = timer.summary()
         if agg:
             dom = max(agg.items(), key=lambda kv: kv[1][1])
             name, (n, secs, flops) = dom
             ach = flops / secs / 1e12
+            traffic = None
+            try:    # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+                key = name.replace(",1>", ",f32>") if name.startswith("conv_igemm") else name
+                ent = pmc.get(key)
+                if ent:
+                    traffic = sum(v["hbm_bytes_per_launch"] for v in ent.values()) / len(ent)
+            except (OSError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01_pmc_*; "
+                                               "gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
                                "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9}
-            out["kernels"] = {k: {"launches": v[0], "ms": 1e3 * v[1], "tflops": v[2] / v[1] / 1e12} for k, v in agg.items()}
-            out["mfma_time_fraction"] = sum(v[1] for v in agg.values()) / dt
+            src = warm if warm else agg
+            out["kernels_warmup_steps"] = {k: {"launches": v[0], "ms": 1e3 * v[1], "tflops": v[2] / v[1] / 1e12}
+                                           for k, v in src.items()}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, H, W, K, args)
         print(json.dumps(out))

@@ -134,7 +134,14 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
 # (its inputs are ready), the end-of-backward fold waits for the side stream; inputs are record_stream()'ed so the
 # caching allocator does not recycle them while the side stream still reads them.
 _SIDE = {}
-_USE_SIDE = _os.environ.get("RAMNET_WGRAD_STREAM", "1") != "0"
+_USE_SIDE = _os.environ.get("RAMNET_WGRAD_STREAM", "0") == "1"
+
+
+def set_wgrad_overlap(on):
+    """Run backward-weights kernels on a side stream, co-scheduled with the backward-data chain (+4-6 % step rate on
+    MI355X; per-kernel timings then include co-scheduled time, so profiling runs keep it off)."""
+    global _USE_SIDE
+    _USE_SIDE = bool(on)
 
 
 def _side_stream(dev):
