@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=344)
     ap.add_argument("--events-per-grid", type=int, default=200000)
+    ap.add_argument("--bins", type=int, default=5, help="event voxel-grid bins (configs[4] uses 10)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU functional tests)")
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--state", choices=["convgru", "convlstm"], default="convgru")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,7 +169,7 @@ def cpu_baseline(cfg, H, W, K, args):
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     rng = np.random.default_rng(0)
     cores = torch.get_num_threads()
-    B, L = 1, 1
+    B, L = 2, 2                                   # ~10-30 s of CPU work on the GPU box's host cores
     seq = [make_item(rng, B, H, W, K, cfg["num_bins_events"], 1, True, 0.0) for _ in range(L)]
     lc = cfg["loss_composition"]
     t0 = time.time()
@@ -189,8 +191,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("RAMNET_BENCH_SINGLE_DEVICE") == "1":     # functional test of the N>1 path on a 1-GPU box
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent
     from rpg_ramnet_amd.parallel import FlatGradReducer
@@ -199,8 +206,8 @@ def main():
     from rpg_ramnet_amd import ops
     ops.set_precision(args.precision)
     ops.set_wgrad_overlap(args.overlap_wgrad)
-    K, bins, B, L, H, W = 5, 5, args.batch, args.seq_len, args.height, args.width
-    cfg = dict(RELEASED, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
+    K, bins, B, L, H, W = 5, args.bins, args.batch, args.seq_len, args.height, args.width
+    cfg = dict(RELEASED, num_bins_events=bins, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)
     torch.manual_seed(0)                       # identical initial weights on every rank (train.py:203)
     model = ERGB2DepthRecurrent(cfg)

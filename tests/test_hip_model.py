@@ -167,3 +167,24 @@ def test_bptt_gradients_vs_oracle(mode):
     for k, p in model.named_parameters():
         assert p.grad is not None, k
         assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-2 * gmax)
+
+
+def test_bench_two_ranks_share_one_gpu_gloo(tmp_path):
+    """The N>1 path of bench.py end to end on a 1-GPU box: 2 ranks (gloo, both on cuda:0), tiny problem.  Checks the
+    launch contract (torch.distributed.run env), the flat-bucket gradient all-reduce on CUDA tensors and the JSON line."""
+    import json as js
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RAMNET_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--backend", "gloo", "--height", "32", "--width", "48", "--batch", "2", "--seq-len", "2",
+           "--events-per-grid", "2000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = js.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
