@@ -155,6 +155,14 @@ int ramnet_si_loss_fwd(const float *pred, const float *target, size_t n, float w
 int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float weight, float lambda,
                        const double *stats, const float *gscale, float *dpred, void *stream);
 
+/* ---- multi-scale gradient loss: model/loss.py:22-70 (kornia Sobel restated; PARITY UNPINNED) -------
+ * ws / dws: float workspaces of ramnet_msg_workspace_elems() elements; stats: 2*num_scales doubles.          */
+size_t ramnet_msg_workspace_elems(int B, int H, int W, int num_scales);
+int ramnet_msg_loss_fwd(const float *pred, const float *target, int B, int H, int W, int num_scales, float *ws,
+                        double *stats, float *loss, void *stream);
+int ramnet_msg_loss_bwd(const float *ws, const double *stats, const float *gscale, int B, int H, int W, int num_scales,
+                        float *dws, float *dpred, void *stream);
+
 /* ---- event -> voxel grid: utils/event_tensor_utils.py:120-187, :52-66 ----------------------- */
 /* events: [N,4] float64 rows (t,x,y,p) sorted by t, on device.  grid [bins,H,W] fp32 is zeroed here. */
 int ramnet_voxelize(const double *events, size_t n_events, int bins, int W, int H, float *grid, void *stream);

@@ -52,6 +52,138 @@ __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------- multi-scale gradient loss
+// MultiScaleGradient (model/loss.py:22-70): diff = pred - target; for k = 1,2,4,8: P = AvgPool2d(k,k)(diff);
+// g = kornia spatial_gradient(P) (Sobel/8, replicate padding) ; loss_k = sum|g| over non-NaN / count * B * 2; mean over k.
+// PARITY UNPINNED (kornia 0.4.0 absent): follows the restatement in oracle/loss_ref.py.
+struct MsgScale { size_t off; int h, w, k; };
+struct MsgArgs { MsgScale sc[4]; int ns, B, H, W; };
+
+__global__ void msg_pool_kernel(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ ws, MsgArgs a) {
+    for (int s = 0; s < a.ns; ++s) {
+        const MsgScale sc = a.sc[s];
+        const size_t n = (size_t)a.B * sc.h * sc.w;
+        const float inv = 1.0f / (float)(sc.k * sc.k);
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+            const int x = (int)(i % sc.w);
+            const size_t j = i / sc.w;
+            const int y = (int)(j % sc.h), b = (int)(j / sc.h);
+            float acc = 0.f;
+            for (int dy = 0; dy < sc.k; ++dy)
+                for (int dx = 0; dx < sc.k; ++dx) {
+                    const size_t p = ((size_t)b * a.H + (y * sc.k + dy)) * a.W + (x * sc.k + dx);
+                    acc += pred[p] - target[p];          // NaN targets propagate, exactly like avg_pool2d
+                }
+            ws[sc.off + i] = acc * inv;
+        }
+    }
+}
+
+__device__ __forceinline__ void msg_sobel(const float *__restrict__ P, int h, int w, int y, int x, float &gx, float &gy) {
+    const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1, xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+    const float a = P[ym * w + xm], b = P[ym * w + x], c = P[ym * w + xp];
+    const float d = P[y * w + xm], e = P[y * w + x], f = P[y * w + xp];
+    const float g = P[yp * w + xm], hh = P[yp * w + x], i = P[yp * w + xp];
+    // the reference convolves with the full 3x3 kernel: a NaN anywhere in the window (even under a zero tap: 0*NaN)
+    // makes BOTH components NaN
+    const float nanprop = 0.f * (a + b + c + d + e + f + g + hh + i);
+    gx = (-a + c - 2.f * d + 2.f * f - g + i) * 0.125f + nanprop;
+    gy = (-a - 2.f * b - c + g + 2.f * hh + i) * 0.125f + nanprop;
+}
+
+__global__ void msg_stats_kernel(const float *__restrict__ ws, MsgArgs a, double *stats) {
+    for (int s = 0; s < a.ns; ++s) {
+        const MsgScale sc = a.sc[s];
+        const size_t n = (size_t)a.B * sc.h * sc.w;
+        double sum = 0.0, cnt = 0.0;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+            const int x = (int)(i % sc.w);
+            const size_t j = i / sc.w;
+            const int y = (int)(j % sc.h), b = (int)(j / sc.h);
+            float gx, gy;
+            msg_sobel(ws + sc.off + (size_t)b * sc.h * sc.w, sc.h, sc.w, y, x, gx, gy);
+            if (gx == gx) sum += fabsf(gx), cnt += 1.0;
+            if (gy == gy) sum += fabsf(gy), cnt += 1.0;
+        }
+        __shared__ double red[2][4];
+        sum = wave_sum(sum), cnt = wave_sum(cnt);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) red[0][wave] = sum, red[1][wave] = cnt;
+        __syncthreads();
+        if (threadIdx.x < 2) atomicAdd(stats + 2 * s + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+__global__ void msg_finalize_kernel(const double *stats, int ns, int B, float *loss) {
+    double t = 0.0;
+    for (int s = 0; s < ns; ++s) t += stats[2 * s] / stats[2 * s + 1] * (double)B * 2.0;
+    *loss = (float)(t / ns);
+}
+
+// d loss / d P_s scattered through the transposed Sobel stencil (replicate padding = clamped scatter targets)
+__global__ void msg_bwd_scatter_kernel(const float *__restrict__ ws, float *__restrict__ dws, MsgArgs a, const double *__restrict__ stats,
+                                       const float *__restrict__ gscale) {
+    const float up = gscale ? *gscale : 1.0f;
+    for (int s = 0; s < a.ns; ++s) {
+        const MsgScale sc = a.sc[s];
+        const size_t n = (size_t)a.B * sc.h * sc.w;
+        const float coef = up * (float)((double)a.B * 2.0 / stats[2 * s + 1] / a.ns) * 0.125f;
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+            const int x = (int)(i % sc.w);
+            const size_t j = i / sc.w;
+            const int y = (int)(j % sc.h), b = (int)(j / sc.h);
+            const size_t base = sc.off + (size_t)b * sc.h * sc.w;
+            float gx, gy;
+            msg_sobel(ws + base, sc.h, sc.w, y, x, gx, gy);
+            const float sx = gx == gx ? (gx > 0.f ? coef : gx < 0.f ? -coef : 0.f) : 0.f;
+            const float sy = gy == gy ? (gy > 0.f ? coef : gy < 0.f ? -coef : 0.f) : 0.f;
+            if (sx == 0.f && sy == 0.f) continue;
+            const int h = sc.h, w = sc.w;
+            const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1, xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+            float *D = dws + base;
+            atomicAdd(D + ym * w + xm, -sx - sy);
+            atomicAdd(D + ym * w + x, -2.f * sy);
+            atomicAdd(D + ym * w + xp, sx - sy);
+            atomicAdd(D + y * w + xm, -2.f * sx);
+            atomicAdd(D + y * w + xp, 2.f * sx);
+            atomicAdd(D + yp * w + xm, -sx + sy);
+            atomicAdd(D + yp * w + x, 2.f * sy);
+            atomicAdd(D + yp * w + xp, sx + sy);
+        }
+    }
+}
+
+// dpred[b,Y,X] = sum_s dP_s[b, Y/k, X/k] / k^2 (transposed average pooling, gathered)
+__global__ void msg_bwd_gather_kernel(const float *__restrict__ dws, MsgArgs a, float *__restrict__ dpred) {
+    const size_t n = (size_t)a.B * a.H * a.W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % a.W);
+        const size_t j = i / a.W;
+        const int Y = (int)(j % a.H), b = (int)(j / a.H);
+        float g = 0.f;
+        for (int s = 0; s < a.ns; ++s) {
+            const MsgScale sc = a.sc[s];
+            const int y = Y / sc.k, x = X / sc.k;
+            if (y < sc.h && x < sc.w) g += dws[sc.off + ((size_t)b * sc.h + y) * sc.w + x] / (float)(sc.k * sc.k);
+        }
+        dpred[i] = g;
+    }
+}
+
+static int msg_args(int B, int H, int W, int ns, MsgArgs &a, size_t &total) {
+    if (ns < 1 || ns > 4) return 1;
+    a.ns = ns, a.B = B, a.H = H, a.W = W;
+    total = 0;
+    for (int s = 0; s < ns; ++s) {
+        const int k = 1 << s;
+        a.sc[s].k = k, a.sc[s].h = H / k, a.sc[s].w = W / k, a.sc[s].off = total;
+        if (a.sc[s].h < 1 || a.sc[s].w < 1) return 1;
+        total += (size_t)B * a.sc[s].h * a.sc[s].w;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------- voxel grid
 // Index arithmetic restated from events_to_voxel_grid_pytorch (utils/event_tensor_utils.py:152-180):
 // float64 normalised time, floor, float32 votes pol*(1-dt) / pol*dt, `0 <= ti < bins` guards.
@@ -139,6 +271,41 @@ extern "C" int ramnet_si_loss_bwd(const float *pred, const float *target, size_t
                                   const float *gscale, float *dpred, void *stream) {
     RAMNET_CHECK_ARG(pred && target && stats && dpred && n > 0);
     hipLaunchKernelGGL(si_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, weight, lambda, stats, gscale, dpred);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t ramnet_msg_workspace_elems(int B, int H, int W, int num_scales) {
+    MsgArgs a;
+    size_t total = 0;
+    return msg_args(B, H, W, num_scales, a, total) ? 0 : total;
+}
+
+extern "C" int ramnet_msg_loss_fwd(const float *pred, const float *target, int B, int H, int W, int num_scales, float *ws,
+                                   double *stats, float *loss, void *stream) {
+    RAMNET_CHECK_ARG(pred && target && ws && stats && loss && B > 0);
+    MsgArgs a;
+    size_t total;
+    RAMNET_CHECK_ARG(msg_args(B, H, W, num_scales, a, total) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    RAMNET_HIP(hipMemsetAsync(stats, 0, 2 * num_scales * sizeof(double), st));
+    hipLaunchKernelGGL(msg_pool_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, pred, target, ws, a);
+    hipLaunchKernelGGL(msg_stats_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, ws, a, stats);
+    hipLaunchKernelGGL(msg_finalize_kernel, dim3(1), dim3(1), 0, st, stats, num_scales, B, loss);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_msg_loss_bwd(const float *ws, const double *stats, const float *gscale, int B, int H, int W, int num_scales,
+                                   float *dws, float *dpred, void *stream) {
+    RAMNET_CHECK_ARG(ws && stats && dws && dpred && B > 0);
+    MsgArgs a;
+    size_t total;
+    RAMNET_CHECK_ARG(msg_args(B, H, W, num_scales, a, total) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    RAMNET_HIP(hipMemsetAsync(dws, 0, total * sizeof(float), st));
+    hipLaunchKernelGGL(msg_bwd_scatter_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, ws, dws, a, stats, gscale);
+    hipLaunchKernelGGL(msg_bwd_gather_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, dws, a, dpred);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -111,6 +111,26 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                        else torch.zeros(shp, device=self.gpu))
         return out
 
+    def update_events(self, events, states, lstm_state=None):
+        """Asynchronous primitive (irregular schedules, BASELINE configs[3]): fold ONE event voxel grid [B,Ce,H,W] into the
+        shared multi-scale state.  `states`: list returned by init_states()/a previous update (NHWC buffers or the
+        NCHW-shaped views forward() returns).  Returns (new_states, lstm_state); nothing is modified in place.
+        Equivalent to one iteration of the k-loop of model.py:176-195 without the decode."""
+        assert not bool(self.baseline), "baselines have no event branch (model.py:181-185)"
+        st = [s if (torch.is_tensor(s) and s.shape[-1] == self.base_num_channels * 2 ** (i + 1) and s.dim() == 4 and
+                    s.is_contiguous()) else _to_nhwc(s) for i, s in enumerate(states)]
+        return self.statenetphasedrecurrent.forward_events(ops.pack_input(events, self.gpu), st, lstm_state)
+
+    def update_image(self, image, states, lstm_state=None):
+        """Fold ONE frame [B,Cr,H,W] into the shared state (model.py:196-213 without the decode)."""
+        st = [s if (torch.is_tensor(s) and s.shape[-1] == self.base_num_channels * 2 ** (i + 1) and s.dim() == 4 and
+                    s.is_contiguous()) else _to_nhwc(s) for i, s in enumerate(states)]
+        return self.statenetphasedrecurrent.forward_images(ops.pack_input(image, self.gpu), st, lstm_state)
+
+    def decode(self, states):
+        """Depth prediction [B,1,H,W] in [0,1] from the current state (statenet.py:290-315)."""
+        return self.statenetphasedrecurrent.forward_decoder(states)
+
     def forward(self, item, prev_super_states, prev_states_lstm):
         net = self.statenetphasedrecurrent
         predictions_dict, super_state_dict, states_lstm_dict = {}, {}, {}

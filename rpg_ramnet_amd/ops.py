@@ -526,6 +526,40 @@ class SILoss(Function):
         return d, None, None, None
 
 
+class MSGLoss(Function):
+    """multi_scale_grad_loss (model/loss.py:22-70): 4 average-pool scales x Sobel gradient, NaN-masked L1.
+    The Sobel arithmetic lives in kornia 0.4.0 (absent here): parity is pinned to the restatement in the oracle only."""
+
+    @staticmethod
+    def forward(ctx, pred, target, num_scales):
+        pred, target = pred.contiguous(), target.contiguous()
+        B, _, Hh, W = pred.shape
+        L = H.lib()
+        n = L.ramnet_msg_workspace_elems(B, Hh, W, num_scales)
+        ws = torch.empty(n, device=pred.device)
+        stats = torch.empty(2 * num_scales, device=pred.device, dtype=torch.float64)
+        loss = torch.empty((), device=pred.device)
+        H.check(L.ramnet_msg_loss_fwd(_p(pred), _p(target), B, Hh, W, num_scales, _p(ws), _p(stats), _p(loss), _st()), "msg_fwd")
+        ctx.save_for_backward(ws, stats)
+        ctx.dims = (B, Hh, W, num_scales)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ws, stats = ctx.saved_tensors
+        B, Hh, W, ns = ctx.dims
+        g = g.contiguous().float()
+        dws = torch.empty_like(ws)
+        d = torch.empty(B, 1, Hh, W, device=ws.device)
+        H.check(H.lib().ramnet_msg_loss_bwd(_p(ws), _p(stats), _p(g), B, Hh, W, ns, _p(dws), _p(d), _st()), "msg_bwd")
+        return d, None, None
+
+
+def multi_scale_grad_loss(prediction, target, num_scales=4):
+    """Drop-in for model.loss.multi_scale_grad_loss (non-preview branch) on device tensors."""
+    return MSGLoss.apply(prediction, target.to(prediction.device), int(num_scales))
+
+
 def nhwc_add(a, b):
     """a + b on NHWC tensors (UNet head skip, unet.py:129)."""
     a, b = dense(a).contiguous(), dense(b).contiguous()

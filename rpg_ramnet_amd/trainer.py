@@ -19,10 +19,13 @@ def empty_states_lstm(K):
     return d
 
 
-def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=None):
+def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=None, grad_loss_weight=None):
     """BPTT over the L packages of `sequence` (list of item dicts with 'depth_<key>' targets).
+    grad_loss_weight: weight of the multi-scale gradient loss (config['grad_loss']['weight'], 0.25 in the released
+    recipe; lstm_trainer.py:162-168, :197-199) or None for the SI loss alone.
     Returns (loss to call .backward() on, loss value the reference would report)."""
     loss_params = loss_params or {"weight": 1.0, "n_lambda": 1.0}
+    gterms = []
     L = len(sequence)
     assert L > 0
     K = model.every_x_rgb_frame
@@ -35,8 +38,12 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
                 w = loss_weights[loss_composition.index(key)]
                 target = item['depth_' + key].to(model.gpu)
                 terms.append(w * ops.scale_invariant_loss(value, target, **loss_params))
+                if grad_loss_weight is not None:
+                    gterms.append(w * ops.multi_scale_grad_loss(value, target))
                 if key not in keys_seen:
                     keys_seen.append(key)
         prev_super, prev_lstm = supers['image'], lstms
     total = torch.stack(terms).sum() / float(L)
+    if grad_loss_weight is not None:
+        total = total + grad_loss_weight * torch.stack(gterms).sum() / float(L)
     return total, total.detach() * len(keys_seen)

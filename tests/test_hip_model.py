@@ -188,3 +188,30 @@ def test_bench_two_ranks_share_one_gpu_gloo(tmp_path):
     out = js.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
+def test_irregular_asynchronous_schedule_matches_oracle():
+    """BASELINE configs[3]-style streaming: batch 1, persistent state, an IRREGULAR number of event grids between frames,
+    driven through the primitive API (update_events / update_image / decode) vs the oracle's encoder/decoder calls."""
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ncfg = ramnet_ref.normalize_config(cfg)
+    rng = np.random.default_rng(11)
+    H, W = 32, 48
+    states = model.init_states(1, H, W)
+    ref_states = [torch.zeros(1, 64 * 2 ** i, H >> (i + 1), W >> (i + 1)) for i in range(3)]
+    schedule = [3, 0, 7, 1, 2]              # event grids before each frame
+    with torch.no_grad():
+        for n_ev in schedule:
+            for _ in range(n_ev):
+                ev = torch.from_numpy(rng.standard_normal((1, 5, H, W)).astype(np.float32))
+                states, _ = model.update_events(ev, states)
+                ref_states, _ = ramnet_ref._encode(sd, ncfg, "events", ev, ref_states, None)
+                assert_close(model.decode(states).cpu().numpy(), ramnet_ref._decode(sd, ncfg, ref_states).numpy(), TOL, "event decode")
+            img = torch.from_numpy(rng.random((1, 1, H, W)).astype(np.float32))
+            states, _ = model.update_image(img, states)
+            ref_states, _ = ramnet_ref._encode(sd, ncfg, "rgb", img, ref_states, None)
+            assert_close(model.decode(states).cpu().numpy(), ramnet_ref._decode(sd, ncfg, ref_states).numpy(), TOL, "frame decode")
+    for s, r in zip(states, ref_states):
+        assert_close(s.permute(0, 3, 1, 2).cpu().numpy(), r.numpy(), TOL, "final state")

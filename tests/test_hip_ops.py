@@ -204,3 +204,22 @@ def test_voxel_empty_and_zero_grid():
     assert g.shape == (5, 12, 16) and float(g.abs().sum()) == 0.0
     z = voxel.normalize_nonzero(torch.zeros(2, 4, 4, device=dev()))
     assert float(z.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,nan_frac", [(2, 32, 48, 0.0), (3, 24, 40, 0.2), (1, 16, 16, 0.5)])
+def test_multi_scale_grad_loss_vs_oracle(B, H, W, nan_frac):
+    """Next-row component.  PARITY UNPINNED against kornia itself; checked against the oracle restatement
+    (value and gradient through torch autograd in float64)."""
+    from rpg_ramnet_amd import ops
+    rng = np.random.default_rng(5)
+    p = rng.random((B, 1, H, W)).astype(np.float32)
+    t = rng.random((B, 1, H, W)).astype(np.float32)
+    t[rng.random(t.shape) < nan_frac] = np.nan
+    pg = torch.from_numpy(p).to(dev()).requires_grad_(True)
+    l = ops.multi_scale_grad_loss(pg, torch.from_numpy(t).to(dev()))
+    (2.5 * l).backward()
+    pc = torch.from_numpy(p).double().requires_grad_(True)
+    lr = loss_ref.multi_scale_grad_loss(pc, torch.from_numpy(t).double())
+    (2.5 * lr).backward()
+    np.testing.assert_allclose(float(l.detach()), float(lr.detach()), rtol=2e-5)
+    assert_close(pg.grad.cpu().numpy(), pc.grad.numpy(), 1e-4, "msg grad")
