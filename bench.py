@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--events-per-grid", type=int, default=200000)
     ap.add_argument("--bins", type=int, default=5, help="event voxel-grid bins (configs[4] uses 10)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU functional tests)")
-    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--mode", choices=["train", "infer", "stream"], default="train",
+                    help="train: configs[1]/[2] step; infer: forward over the same sequences; stream: configs[3]-style batch-1 "
+                         "asynchronous inference, irregular number of event grids per frame, persistent state")
     ap.add_argument("--state", choices=["convgru", "convlstm"], default="convgru")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -230,6 +232,23 @@ def main():
             reducer.wait()
             opt.step()
             return total
+    elif args.mode == "stream":
+        model.eval()
+        rs = np.random.default_rng(7)
+        sched = [int(v) for v in rs.integers(1, 9, size=L)]        # event grids before each frame, drawn from {1..8}
+        stream_state = {"s": model.init_states(B, H, W)}
+
+        def step():
+            st = stream_state["s"]                                 # state persists ACROSS steps (one long stream)
+            with torch.no_grad():
+                for l, item in enumerate(seq):
+                    for k in range(sched[l]):
+                        st, _ = model.update_events(item["events%d" % (k % K)], st)
+                        pred = model.decode(st)
+                    st, _ = model.update_image(item["image"], st)
+                    pred = model.decode(st)
+            stream_state["s"] = st
+            return pred.mean()
     else:
         model.eval()
 
@@ -296,8 +315,10 @@ def main():
 
     if rank == 0:
         samples = world * B * L * args.steps
+        if args.mode == "stream":
+            updates = world * B * (sum(sched) + L) * args.steps
         out = {"metric": "depth samples/sec (346x260 cropped to %dx%d, 5-bin grids, K=5 grids + 1 frame per sample; %s)"
-                         % (H, W, "training step" if args.mode == "train" else "inference"),
+                         % (H, W, {"train": "training step", "infer": "inference", "stream": "asynchronous streaming inference"}[args.mode]),
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.precision == "f32" else "bf16x3(fwd,dgrad)+f32(wgrad)", "data": "synthetic",
@@ -306,6 +327,10 @@ def main():
                                       % (H, W, B, L, args.mode, args.state),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
                "final_loss": loss_val}
+        if args.mode == "stream":
+            out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
+                             "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "
+                             "state + decode one depth map; samples/s counts frames"}
         if extras:
             out["extras"] = extras
         agg = timer.summary()
