@@ -147,7 +147,32 @@ class KernelTimer:
             e.record()
             timer.rec.append((name, s, e, 2.0 * dout.shape[0] * dout.shape[1] * dout.shape[2] * taps.n * cin * Cout))
 
-        ops.conv_launch, ops.wgrad_launch = conv, wgrad
+        multi0 = ops.conv_launch_multi
+
+        def multi(x0, w, out, Cout, classes, **kw):
+            if not timer.on:
+                return multi0(x0, w, out, Cout, classes, **kw)
+            tiles = sum(-(-Wo // 16) * -(-Ho // 8) for _, Ho, Wo, _ in classes) * x0.shape[0]
+            cp = (Cout + 31) // 32 * 32
+            bm, bn = 128, (128 if cp % 128 == 0 else 64 if cp % 64 == 0 else 32)
+            if bn >= 64:
+                if tiles * (cp // bn) < 768:
+                    bm = 64
+                    tiles = sum(-(-Wo // 16) * -(-Ho // 4) for _, Ho, Wo, _ in classes) * x0.shape[0]
+                if tiles * (cp // bn) < 768 and bn == 128:
+                    bn = 64
+            name = "conv_igemm_kernel<%d,%d,%s,1>" % (bm, bn, "4,1" if bn == 32 else "2,2")
+            if timer.only is not None and name != timer.only:
+                return multi0(x0, w, out, Cout, classes, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            multi0(x0, w, out, Cout, classes, **kw)
+            e.record()
+            cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
+            fl = sum(2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * Cout for taps, Ho, Wo, _ in classes)
+            timer.rec.append((name, s, e, fl))
+
+        ops.conv_launch, ops.wgrad_launch, ops.conv_launch_multi = conv, wgrad, multi
 
     def summary(self):
         agg = {}

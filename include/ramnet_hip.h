@@ -118,6 +118,9 @@ int ramnet_unpack_wgrad(const float *ws, float *grad_oihw, int Cout, int Cin, in
 
 /* ---- the two MFMA kernels ----------------------------------------------------------------------- */
 int ramnet_conv_launch(const ramnet_conv_desc *d, void *stream);    /* forward and backward-data   */
+/* n <= 4 descriptors that differ only in tap list and output sub-grid (ntaps, dy, dx, wtap, Ho, Wo, ooy, oox): the four
+ * output-parity classes of a stride-2 backward-data / transposed convolution, executed as ONE launch.            */
+int ramnet_conv_launch_multi(const ramnet_conv_desc *descs, int n, void *stream);
 int ramnet_wgrad_launch(const ramnet_wgrad_desc *d, void *stream);  /* backward-weights (+bias)    */
 
 /* ---- HBM-bound point-wise / reduction kernels ------------------------------------------------- */

@@ -59,6 +59,7 @@ _SIGS = {
     "ramnet_pack_weight_split": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "ramnet_conv_launch_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _fp]),
     "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),
     "ramnet_pred_sigmoid_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_pred_sigmoid_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),

@@ -16,22 +16,33 @@
 
 namespace ramnet {
 
-struct ConvDerived {
+struct ConvCommon {
     InSrc src;
     int nchunks, CoutPad;            // weight geometry
+    int patch_floats;                // LDS floats reserved per patch plane (max over the launch's classes, multiple of 4)
+    int nclass;
+};
+
+// One output class of a launch: a plain convolution has one; the backward-data of a stride-2 layer (and the forward of
+// the transposed-conv decoder) has four — one per output parity — folded into ONE launch (blockIdx.z) so that the
+// quarter-size sub-problems fill the chip together instead of as four short, badly quantised launches.
+struct ConvClass {
+    int ntaps, Ho, Wo, ooy, oox;
     int PH, PW, dymin, dxmin;        // LDS patch geometry
-    int patch_floats;                // PH*PW*LDP (multiple of 4)
     int tiles_x, tiles_y;
     int toff[25];                    // per-tap patch offset (floats)
     unsigned woff[25];               // per-tap weight slice offset in 64-byte rows
 };
+struct ConvClasses { ConvClass c[4]; };
 
 // SPLIT = false: exact fp32 (v_mfma_f32_32x32x2_f32), 16 channels per chunk.
 // SPLIT = true : BF16X3 — operands split into bf16 hi/lo planes while staging, 3 x v_mfma_f32_32x32x16_bf16 per
 //                16-channel slab (hi*hi + hi*lo + lo*hi), 32 channels per chunk.  LDS rows are 80 bytes in both modes
 //                (16 fp32 + pad | 32 bf16 + pad), so tile geometry, tap offsets and fragment addresses are shared.
 template <int BM, int BN, int WM, int WN, bool SPLIT>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvDerived q) {
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvCommon qc, const ConvClasses qk) {
+    const ConvClass &q = qk.c[blockIdx.z];
+    if ((int)blockIdx.x >= q.tiles_x * q.tiles_y * p.B) return;      // classes of one launch may differ by a tile
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TH = BM / TWID;
     constexpr int CKC = SPLIT ? 32 : 16;           // input channels per chunk
@@ -39,7 +50,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;                            // [NPL][PH*PW][LDP]
-    float *wsm = smem + NPL * q.patch_floats;       // [2][NPL][BN][LDP]
+    float *wsm = smem + NPL * qc.patch_floats;      // [2][NPL][BN][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,11 +87,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     constexpr int WF4 = BN * 4;                     // 16-byte units per plane
     constexpr int WPT = (WF4 + 255) / 256;
     float4 wreg[NPL][WPT];
-    const int ntaps = p.ntaps;
+    const int ntaps = q.ntaps;
     auto load_w = [&](int chunk, int t) {
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-            const float *src = p.w + ((size_t)q.woff[t] + ((size_t)(chunk * NPL + pl) * q.CoutPad + n0)) * 16;
+            const float *src = p.w + ((size_t)q.woff[t] + ((size_t)(chunk * NPL + pl) * qc.CoutPad + n0)) * 16;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 const int f = tid + i * 256;
@@ -102,14 +113,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
 
     load_w(0, 0);
     int buf = 0;
-    for (int chunk = 0; chunk < q.nchunks; ++chunk) {
+    for (int chunk = 0; chunk < qc.nchunks; ++chunk) {
         __syncthreads();   // every wave is done reading the previous chunk's patch
-        stage_patch<CKC / 4, LDP, 4, 256, SPLIT>(patch, q.src, b, iy0, ix0, chunk * CKC, q.PH, q.PW, tid, q.patch_floats);
+        stage_patch<CKC / 4, LDP, 4, 256, SPLIT>(patch, qc.src, b, iy0, ix0, chunk * CKC, q.PH, q.PW, tid, qc.patch_floats);
         for (int t = 0; t < ntaps; ++t) {
             store_w(buf);
             __syncthreads();   // patch + weight tile visible; the other ring slot is free again
             if (t + 1 < ntaps) load_w(chunk, t + 1);
-            else if (chunk + 1 < q.nchunks) load_w(chunk + 1, 0);
+            else if (chunk + 1 < qc.nchunks) load_w(chunk + 1, 0);
             const float *pa = patch + q.toff[t];
             const float *wb = wsm + buf * NPL * (BN * LDP);
 #pragma unroll
@@ -136,7 +147,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
 #pragma unroll
                     for (int ms = 0; ms < TM; ++ms) {
                         ah[ms] = __builtin_bit_cast(bf16x8, ld4(pa + aBase[ms] + k8 * 8));
-                        al[ms] = __builtin_bit_cast(bf16x8, ld4(pa + q.patch_floats + aBase[ms] + k8 * 8));
+                        al[ms] = __builtin_bit_cast(bf16x8, ld4(pa + qc.patch_floats + aBase[ms] + k8 * 8));
                     }
 #pragma unroll
                     for (int ns = 0; ns < TN; ++ns) {
@@ -165,8 +176,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
         for (int r = 0; r < 16; ++r) {
             const int m = (wm * TM + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
+            if (oy >= q.Ho || ox >= q.Wo) continue;
+            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + q.ooy)) * p.WoF + (ox * p.osx + q.oox);
             if (epi == RAMNET_EPI_LSTM) {
                 if constexpr (TN == 4) {
                     // packed N order = (channel block of 32, gate, channel): ns is the gate (i, f, o, g)
@@ -215,10 +226,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
 }
 
 template <int BM, int BN, int WM, int WN, bool SPLIT>
-static int launch_p(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
+static int launch_p(const ramnet_conv_desc &d, const ConvCommon &qc, const ConvClasses &qk, int max_tiles, hipStream_t st) {
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, SPLIT>;
     constexpr int NPL = SPLIT ? 2 : 1;
-    const size_t lds = ((size_t)NPL * q.patch_floats + 2 * NPL * BN * LDP) * sizeof(float);
+    const size_t lds = ((size_t)NPL * qc.patch_floats + 2 * NPL * BN * LDP) * sizeof(float);
     static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation
     if (lds > lds_set) {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -228,25 +239,19 @@ static int launch_p(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t
         set_error("conv patch does not fit LDS (%zu bytes)", lds);
         return RAMNET_E_UNSUPPORTED;
     }
-    dim3 grid(q.tiles_x * q.tiles_y * d.B, q.CoutPad / BN);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, q);
+    dim3 grid(max_tiles * d.B, qc.CoutPad / BN, qc.nclass);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, qc, qk);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const ramnet_conv_desc &d, const ConvDerived &q, hipStream_t st) {
-    if (d.precision == RAMNET_PREC_BF16X3) return launch_p<BM, BN, WM, WN, true>(d, q, st);
-    return launch_p<BM, BN, WM, WN, false>(d, q, st);
+static int launch_cfg(const ramnet_conv_desc &d, const ConvCommon &qc, const ConvClasses &qk, int max_tiles, hipStream_t st) {
+    if (d.precision == RAMNET_PREC_BF16X3) return launch_p<BM, BN, WM, WN, true>(d, qc, qk, max_tiles, st);
+    return launch_p<BM, BN, WM, WN, false>(d, qc, qk, max_tiles, st);
 }
 
-}  // namespace ramnet
-
-using namespace ramnet;
-
-extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
-    RAMNET_CHECK_ARG(dp != nullptr);
-    const ramnet_conv_desc &d = *dp;
+static int check_desc(const ramnet_conv_desc &d) {
     RAMNET_CHECK_ARG(d.x0 && d.w && d.out);
     RAMNET_CHECK_ARG(d.ntaps >= 1 && d.ntaps <= 25 && (d.stride == 1 || d.stride == 2));
     RAMNET_CHECK_ARG(d.B > 0 && d.Ho > 0 && d.Wo > 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0);
@@ -260,46 +265,86 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
     if (d.epi == RAMNET_EPI_RES_RELU) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_GRU_BLEND) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
+    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 || d.precision == RAMNET_PREC_BF16X3);
+    return 0;
+}
 
-    ConvDerived q;
-    q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
-    q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
-    q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
-    q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
-    const int split = d.precision == RAMNET_PREC_BF16X3;
-    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 || split);
-    q.nchunks = cdiv(q.src.Cin, split ? 32 : CK);
-    q.CoutPad = d.epi == RAMNET_EPI_LSTM ? 4 * roundup(d.Cout, 32) : roundup(d.Cout, 32);
-    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
-    for (int t = 0; t < d.ntaps; ++t) {
-        dymin = d.dy[t] < dymin ? d.dy[t] : dymin, dymax = d.dy[t] > dymax ? d.dy[t] : dymax;
-        dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin, dxmax = d.dx[t] > dxmax ? d.dx[t] : dxmax;
+// n descriptors that differ ONLY in their tap lists and output sub-grid (Ho, Wo, ooy, oox) -> one launch
+static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
+    const ramnet_conv_desc &d = ds[0];
+    for (int i = 0; i < n; ++i) {
+        const int rc = check_desc(ds[i]);
+        if (rc) return rc;
+        RAMNET_CHECK_ARG(ds[i].x0 == d.x0 && ds[i].w == d.w && ds[i].out == d.out && ds[i].stride == d.stride &&
+                         ds[i].Cout == d.Cout && ds[i].epi == d.epi && ds[i].osy == d.osy && ds[i].osx == d.osx &&
+                         ds[i].B == d.B && ds[i].in_mode == d.in_mode && ds[i].precision == d.precision);
     }
+    const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
+    const int split = d.precision == RAMNET_PREC_BF16X3;
+    ConvCommon qc;
+    ConvClasses qk;
+    qc.src.x0 = d.x0, qc.src.x1 = d.x1, qc.src.xm = d.xm;
+    qc.src.ld0 = d.ld0, qc.src.ld1 = d.ld1, qc.src.ldm = d.ldm;
+    qc.src.C0 = d.C0, qc.src.Cin = d.C0 + (cat ? d.C1 : 0);
+    qc.src.mode = d.in_mode, qc.src.Hin = d.Hin, qc.src.Win = d.Win;
+    qc.nchunks = cdiv(qc.src.Cin, split ? 32 : CK);
+    qc.CoutPad = d.epi == RAMNET_EPI_LSTM ? 4 * roundup(d.Cout, 32) : roundup(d.Cout, 32);
+    qc.nclass = n;
     // ---- tile configuration.  Low-resolution layers (32x43 .. 64x86 pixels) give few 128-pixel tiles: a grid that does
     // not cover the 256 CUs ~3x over leaves CUs idle in the last round (tile quantisation), so shrink the tile there.
     const int lstm = d.epi == RAMNET_EPI_LSTM;
-    int BM = 128, BN = lstm ? 128 : (q.CoutPad % 128 == 0 ? 128 : q.CoutPad % 64 == 0 ? 64 : 32);
-    auto blocks = [&](int bm, int bn) { return (long)cdiv(d.Wo, TWID) * cdiv(d.Ho, bm / TWID) * d.B * (q.CoutPad / bn); };
+    int BM = 128, BN = lstm ? 128 : (qc.CoutPad % 128 == 0 ? 128 : qc.CoutPad % 64 == 0 ? 64 : 32);
+    auto blocks = [&](int bm, int bn) {
+        long t = 0;
+        for (int i = 0; i < n; ++i) t += (long)cdiv(ds[i].Wo, TWID) * cdiv(ds[i].Ho, bm / TWID);
+        return t * d.B * (qc.CoutPad / bn);
+    };
     if (!lstm && BN >= 64) {
         const long want = 768;
         if (blocks(BM, BN) < want) BM = 64;
         if (blocks(BM, BN) < want && BN == 128) BN = 64;
     }
     const int TH = BM / TWID;
-    q.dymin = dymin, q.dxmin = dxmin;
-    q.PH = (TH - 1) * d.stride + (dymax - dymin) + 1;
-    q.PW = (TWID - 1) * d.stride + (dxmax - dxmin) + 1;
-    q.patch_floats = q.PH * q.PW * LDP;
-    q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, TH);
-    for (int t = 0; t < d.ntaps; ++t) {
-        q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * LDP;
-        q.woff[t] = (unsigned)d.wtap[t] * (unsigned)q.nchunks * (unsigned)(split ? 2 : 1) * (unsigned)q.CoutPad;
+    int max_tiles = 0;
+    qc.patch_floats = 0;
+    for (int i = 0; i < n; ++i) {
+        const ramnet_conv_desc &e = ds[i];
+        ConvClass &q = qk.c[i];
+        int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127;
+        for (int t = 0; t < e.ntaps; ++t) {
+            dymin = e.dy[t] < dymin ? e.dy[t] : dymin, dymax = e.dy[t] > dymax ? e.dy[t] : dymax;
+            dxmin = e.dx[t] < dxmin ? e.dx[t] : dxmin, dxmax = e.dx[t] > dxmax ? e.dx[t] : dxmax;
+        }
+        q.ntaps = e.ntaps, q.Ho = e.Ho, q.Wo = e.Wo, q.ooy = e.ooy, q.oox = e.oox;
+        q.dymin = dymin, q.dxmin = dxmin;
+        q.PH = (TH - 1) * e.stride + (dymax - dymin) + 1;
+        q.PW = (TWID - 1) * e.stride + (dxmax - dxmin) + 1;
+        q.tiles_x = cdiv(e.Wo, TWID), q.tiles_y = cdiv(e.Ho, TH);
+        for (int t = 0; t < e.ntaps; ++t) {
+            q.toff[t] = ((e.dy[t] - dymin) * q.PW + (e.dx[t] - dxmin)) * LDP;
+            q.woff[t] = (unsigned)e.wtap[t] * (unsigned)qc.nchunks * (unsigned)(split ? 2 : 1) * (unsigned)qc.CoutPad;
+        }
+        if (q.PH * q.PW * LDP > qc.patch_floats) qc.patch_floats = q.PH * q.PW * LDP;
+        if (q.tiles_x * q.tiles_y > max_tiles) max_tiles = q.tiles_x * q.tiles_y;
     }
-    hipStream_t st = (hipStream_t)stream;
-    if (lstm) return launch_cfg<128, 128, 4, 1>(d, q, st);
-    if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 2>(d, q, st);
-    if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2>(d, q, st);
-    if (BM == 64 && BN == 128) return launch_cfg<64, 128, 2, 2>(d, q, st);
-    if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2>(d, q, st);
-    return launch_cfg<128, 32, 4, 1>(d, q, st);
+    if (lstm) return launch_cfg<128, 128, 4, 1>(d, qc, qk, max_tiles, st);
+    if (BM == 128 && BN == 128) return launch_cfg<128, 128, 2, 2>(d, qc, qk, max_tiles, st);
+    if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2>(d, qc, qk, max_tiles, st);
+    if (BM == 64 && BN == 128) return launch_cfg<64, 128, 2, 2>(d, qc, qk, max_tiles, st);
+    if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2>(d, qc, qk, max_tiles, st);
+    return launch_cfg<128, 32, 4, 1>(d, qc, qk, max_tiles, st);
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
+    RAMNET_CHECK_ARG(dp != nullptr);
+    return launch_classes(dp, 1, (hipStream_t)stream);
+}
+
+extern "C" int ramnet_conv_launch_multi(const ramnet_conv_desc *descs, int n, void *stream) {
+    RAMNET_CHECK_ARG(descs != nullptr && n >= 1 && n <= 4);
+    return launch_classes(descs, n, (hipStream_t)stream);
 }

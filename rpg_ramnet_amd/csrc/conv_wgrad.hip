@@ -15,11 +15,11 @@
 
 namespace ramnet {
 
-constexpr int WTH = 8;          // pixel tile = 8 x 16
 
 struct WgradDerived {
     InSrc src;
     int PH, PW, dymin, dxmin;
+    int TH;                         // pixel tile = TH x 16: 8, or 4 when two workgroups would not fit a CU's LDS (stride-2 5x5)
     int tiles_x, tiles_y, ntiles;   // pixel tiles per image / total
     int tpm, ntt;                   // taps per 32-row accumulator tile (Cin < 32 packs several taps), number of tap tiles
     int toff[25];
@@ -64,11 +64,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
         tt /= q.tiles_x;
         const int ty_i = tt % q.tiles_y;
         const int b = tt / q.tiles_y;
-        const int oy0 = ty_i * WTH, ox0 = tx_i * TWID;
+        const int oy0 = ty_i * q.TH, ox0 = tx_i * TWID;
         const int iy0 = oy0 * p.stride + q.dymin, ix0 = ox0 * p.stride + q.dxmin;
         __syncthreads();
         {   // gradient tile: 128 pixels x GQ channel quads, all loads (x2 with mask) in flight at once
             constexpr int NG = 128 * GQ / 256;
+            const int nsl = q.TH * TWID * GQ;
             float4 g[NG], y[NG];
             bool ok[NG];
 #pragma unroll
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
                 const int s = tid + i * 256;
                 const int m = s / GQ, qd = s % GQ;
                 const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
-                ok[i] = oy < p.Ho && ox < p.Wo && n < p.Cout;
+                ok[i] = s < nsl && oy < p.Ho && ox < p.Wo && n < p.Cout;
                 const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
                 g[i] = ld4(ok[i] ? p.dout + pix * p.ldg + n : p.dout);
                 if (p.gmask) y[i] = ld4(ok[i] ? p.gmask + pix * p.ldgm + n : p.gmask);
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
                 float4 r = g[i];
                 if (p.gmask) r = make_float4(y[i].x > 0.f ? r.x : 0.f, y[i].y > 0.f ? r.y : 0.f, y[i].z > 0.f ? r.z : 0.f, y[i].w > 0.f ? r.w : 0.f);
                 if (!ok[i]) r = f4zero();
-                st4(gsm + (s / GQ) * WBN + (s % GQ) * 4, r);
+                if (s < nsl) st4(gsm + (s / GQ) * WBN + (s % GQ) * 4, r);
                 bsum = f4add(bsum, r);
             }
         }
@@ -109,12 +110,13 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
                 for (int j = 0; j < MAXT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv, acc[j], 0, 0, 0);
             };
             fetch(0, a0, b0);
-            for (int i = 0; i < 64; i += 2) {
+            const int ksteps = q.TH * TWID / 2;
+            for (int i = 0; i < ksteps; i += 2) {
                 fetch(i + 1, a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
-                fetch(i + 2 < 64 ? i + 2 : i, a0, b0);
+                fetch(i + 2 < ksteps ? i + 2 : i, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(a1, b1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -152,7 +154,7 @@ template <int MAXT, int NSUB>
 static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipStream_t st) {
     auto kern = conv_wgrad_kernel<MAXT, NSUB>;
     constexpr int WBN = 32 * NSUB;
-    size_t lds = ((size_t)q.PH * q.PW * WCK + 128 * WBN) * sizeof(float);
+    size_t lds = ((size_t)q.PH * q.PW * WCK + q.TH * TWID * WBN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -201,9 +203,12 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
         dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin, dxmax = d.dx[t] > dxmax ? d.dx[t] : dxmax;
     }
     q.dymin = dymin, q.dxmin = dxmin;
-    q.PH = (WTH - 1) * d.stride + (dymax - dymin) + 1;
+    // two co-resident workgroups per CU hide each other's staging: halve the pixel tile when a full one needs > 80 KB
+    q.TH = 8;
+    if (((7 * d.stride + (dymax - dymin) + 1) * ((TWID - 1) * d.stride + (dxmax - dxmin) + 1) * WCK + 128 * 32) * 4 > 80 * 1024) q.TH = 4;
+    q.PH = (q.TH - 1) * d.stride + (dymax - dymin) + 1;
     q.PW = (TWID - 1) * d.stride + (dxmax - dxmin) + 1;
-    q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, WTH);
+    q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, q.TH);
     q.ntiles = q.tiles_x * q.tiles_y * d.B;
     for (int t = 0; t < d.ntaps; ++t) q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * WCK;
     hipStream_t st = (hipStream_t)stream;

@@ -86,7 +86,20 @@ class Taps:
         return cls._cache[key]
 
 
-def conv_launch(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
+def conv_launch(x0, taps, w, out, Cout, **kw):
+    d = _conv_desc(x0, taps, w, out, Cout, **kw)
+    H.check(H.lib().ramnet_conv_launch(C.byref(d), _st()), "ramnet_conv_launch")
+
+
+def conv_launch_multi(x0, w, out, Cout, classes, **kw):
+    """One launch for several output classes: `classes` = [(taps, Ho, Wo, (osy, osx, ooy, oox)), ...] (<= 4)."""
+    arr = (H.ConvDesc * len(classes))()
+    for i, (taps, Ho, Wo, os_) in enumerate(classes):
+        arr[i] = _conv_desc(x0, taps, w, out, Cout, Ho=Ho, Wo=Wo, os=os_, **kw)
+    H.check(H.lib().ramnet_conv_launch_multi(arr, len(classes), _st()), "ramnet_conv_launch_multi")
+
+
+def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
                 o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0):
     B = x0.shape[0]
@@ -108,7 +121,7 @@ def conv_launch(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0,
     d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
     d.ldo, d.ldo1, d.ldo2 = ld(out), (ld(o1) if o1 is not None else 0), (ld(o2) if o2 is not None else 0)
     d.precision = _PRECISION
-    H.check(H.lib().ramnet_conv_launch(C.byref(d), _st()), "ramnet_conv_launch")
+    return d
 
 
 def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
@@ -322,11 +335,9 @@ class ConvAct(Function):
             if stride == 1:
                 conv_launch(dy, Taps.get("dgrad1", k, pad), cp.bwd(), gin, cp.Cin, xm=y if relu else None, in_mode=gmode)
             else:
-                for py in range(2):
-                    for px in range(2):
-                        conv_launch(dy, Taps.get("dgrad2", k, pad, py, px), cp.bwd(), gin, cp.Cin,
-                                    xm=y if relu else None, in_mode=gmode,
-                                    Ho=(Hin - py + 1) // 2, Wo=(Win - px + 1) // 2, os=(2, 2, py, px))
+                conv_launch_multi(dy, cp.bwd(), gin, cp.Cin,
+                                  [(Taps.get("dgrad2", k, pad, py, px), (Hin - py + 1) // 2, (Win - px + 1) // 2, (2, 2, py, px))
+                                   for py in range(2) for px in range(2)], xm=y if relu else None, in_mode=gmode)
             if up:
                 dx = torch.empty(B, Hh, W, cp.Cin, device=x.device)
                 H.check(H.lib().ramnet_upsample2x_bwd(_p(gin), _p(dx), B, Hh, W, cp.Cin, _st()), "ramnet_upsample2x_bwd")
@@ -347,10 +358,8 @@ class TConvAct(Function):
         B, Hh, W, _ = x.shape
         Ct = cp.Cin                                    # ConvParam sees (O=Cin_t, I=Cout_t): produced channels = cp.Cin
         y = torch.empty(B, 2 * Hh, 2 * W, Ct, device=x.device)
-        for py in range(2):
-            for px in range(2):
-                conv_launch(x, Taps.get("dgrad2", 5, 2, py, px), cp.bwd(), y, Ct, bias=cp.bias(), epi=H.EPI_RELU,
-                            Ho=Hh, Wo=W, os=(2, 2, py, px))
+        conv_launch_multi(x, cp.bwd(), y, Ct, [(Taps.get("dgrad2", 5, 2, py, px), Hh, W, (2, 2, py, px))
+                                               for py in range(2) for px in range(2)], bias=cp.bias(), epi=H.EPI_RELU)
         ctx.cp = cp
         ctx.save_for_backward(x, y)
         return y

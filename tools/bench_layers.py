@@ -73,10 +73,9 @@ def main():
                 d = lambda: ops.conv_launch(dy, tapsd, cp.bwd(), dx, cin, xm=y, in_mode=H.IN_RELUMASK)  # noqa: E731
             else:
                 def d():
-                    for py in range(2):
-                        for px in range(2):
-                            ops.conv_launch(dy, ops.Taps.get("dgrad2", k, pad, py, px), cp.bwd(), dx, cin, xm=y, in_mode=H.IN_RELUMASK,
-                                            Ho=(Hin - py + 1) // 2, Wo=(Win - px + 1) // 2, os=(2, 2, py, px))
+                    ops.conv_launch_multi(dy, cp.bwd(), dx, cin,
+                                          [(ops.Taps.get("dgrad2", k, pad, py, px), (Hin - py + 1) // 2, (Win - px + 1) // 2, (2, 2, py, px))
+                                           for py in range(2) for px in range(2)], xm=y, in_mode=H.IN_RELUMASK)
             g = lambda: ops.wgrad_launch(x, taps, dy, ws, cout, stride=stride, gmask=y, dbias=bws)  # noqa: E731
         elif kind == "up":
             x = torch.randn(B, Hin // 2, Win // 2, cin, device=dev)
