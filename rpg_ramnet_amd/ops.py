@@ -305,6 +305,10 @@ class ConvAct(Function):
     @staticmethod
     def forward(ctx, x, skip, w, b, cp, stride, relu, up):
         x, skip = dense(x), dense(skip)
+        if skip is not None and skip.shape != x.shape:
+            raise RuntimeError("skip connection %s does not match the decoder feature map %s (NHWC)" % (tuple(skip.shape), tuple(x.shape)))
+        if x.shape[3] != (cp.Cin + 3) // 4 * 4:
+            raise RuntimeError("conv expects %d input channels, got %d" % (cp.Cin, x.shape[3]))
         B, Hh, W, _ = x.shape
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
@@ -389,6 +393,7 @@ class ResConv(Function):
     @staticmethod
     def forward(ctx, t, res, w, b, cp):
         t, res = dense(t), dense(res)
+        assert t.shape == res.shape
         y = torch.empty_like(res, memory_format=torch.contiguous_format)
         conv_launch(t, Taps.get("conv", 3, 1), cp.fwd(), y, cp.Cout, bias=cp.bias(), epi=H.EPI_RES_RELU, e0=res)
         ctx.cp = cp
@@ -416,6 +421,9 @@ class GRUCell(Function):
     @staticmethod
     def forward(ctx, x, h, wu, bu, wr, br, wo, bo, cp_ur, cp_o):
         x, h = dense(x), dense(h)
+        if x.shape != h.shape:       # the reference fails in torch.cat here (e.g. H, W not divisible by 2**num_encoders)
+            raise RuntimeError("Sizes of tensors must match except in dimension 1. Expected %s but got %s (input vs state; "
+                               "NHWC)" % (tuple(x.shape), tuple(h.shape)))
         B, Hh, W, Cc = x.shape
         taps = Taps.get("conv", 3, 1)
         ur = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
@@ -460,6 +468,9 @@ class LSTMCell(Function):
     @staticmethod
     def forward(ctx, x, h, c, w, b, cp):
         x, h, c = dense(x), dense(h), dense(c)
+        if x.shape != h.shape or x.shape != c.shape:
+            raise RuntimeError("Sizes of tensors must match except in dimension 1. Expected %s but got %s / %s (input vs "
+                               "hidden / cell state; NHWC)" % (tuple(x.shape), tuple(h.shape), tuple(c.shape)))
         B, Hh, W, Cc = x.shape
         hn = torch.empty(B, Hh, W, Cc, device=x.device)
         cn = torch.empty_like(hn)

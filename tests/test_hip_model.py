@@ -215,3 +215,17 @@ def test_irregular_asynchronous_schedule_matches_oracle():
             assert_close(model.decode(states).cpu().numpy(), ramnet_ref._decode(sd, ncfg, ref_states).numpy(), TOL, "frame decode")
     for s, r in zip(states, ref_states):
         assert_close(s.permute(0, 3, 1, 2).cpu().numpy(), r.numpy(), TOL, "final state")
+
+
+def test_raw_346x260_is_rejected_like_the_reference():
+    """346x260 does not run through the reference (state 32x43 vs feature 33x44 -> torch.cat RuntimeError, SURVEY section 0);
+    the HIP path must raise too instead of reading out of bounds."""
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    rng = np.random.default_rng(0)
+    item = make_item(rng, 1, 260, 346, cfg["every_x_rgb_frame"], 5, 1)
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        model(item, None, ramnet_ref.empty_states_lstm(cfg["every_x_rgb_frame"]))
+    bad = {"events0": torch.zeros(1, 3, 32, 48), "image": torch.zeros(1, 1, 32, 48)}       # wrong bin count
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        model(dict(bad, **{"events%d" % k: bad["events0"] for k in range(1, 5)}), None, ramnet_ref.empty_states_lstm(5))
