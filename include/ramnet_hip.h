@@ -158,6 +158,12 @@ int ramnet_si_loss_fwd(const float *pred, const float *target, size_t n, float w
 int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float weight, float lambda,
                        const double *stats, const float *gscale, float *dpred, void *stream);
 
+/* ---- depth post-processing + error sums: evaluation.py:74-96, :201-241; model/metric.py:8-33 --------------
+ * pred/target: normalised log depth.  out10 (zeroed here): n, sum abs-rel, sum sq-rel, sum sq err, sum log-err^2,
+ * sum log-err, sum abs err, count(delta < 1.25), (< 1.25^2), (< 1.25^3) over valid targets with metric depth <= cutoff. */
+int ramnet_depth_metrics(const float *pred, const float *target, size_t n, float clip_distance, float reg_factor,
+                         float cutoff, double *out10, void *stream);
+
 /* ---- multi-scale gradient loss: model/loss.py:22-70 (kornia Sobel restated; PARITY UNPINNED) -------
  * ws / dws: float workspaces of ramnet_msg_workspace_elems() elements; stats: 2*num_scales doubles.          */
 size_t ramnet_msg_workspace_elems(int B, int H, int W, int num_scales);

@@ -72,6 +72,7 @@ _SIGS = {
     "ramnet_bias_grad": (C.c_int, [_fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
     "ramnet_si_loss_fwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp]),
     "ramnet_si_loss_bwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp, _fp]),
+    "ramnet_depth_metrics": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "ramnet_msg_workspace_elems": (C.c_size_t, [C.c_int] * 4),
     "ramnet_msg_loss_fwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ramnet_msg_loss_bwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),

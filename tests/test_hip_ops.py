@@ -223,3 +223,26 @@ def test_multi_scale_grad_loss_vs_oracle(B, H, W, nan_frac):
     (2.5 * lr).backward()
     np.testing.assert_allclose(float(l.detach()), float(lr.detach()), rtol=2e-5)
     assert_close(pg.grad.cpu().numpy(), pc.grad.numpy(), 1e-4, "msg grad")
+
+
+def test_depth_metrics_vs_reference_golden():
+    """Next-row component: metric depth + Abs-Rel on device vs the reference's prepare_depth_data +
+    abs_rel_diff (golden), and vs the oracle for the remaining sums."""
+    from rpg_ramnet_amd import metrics
+    z = load_golden("loss_metrics.npz")
+    for clip, reg in [(80, 3.70378), (1000, 5.70378)]:
+        t_in, p_in = z["depth%d.target_in" % clip], z["depth%d.pred_in" % clip]
+        m = metrics.depth_metrics(torch.from_numpy(p_in).to(dev()), torch.from_numpy(t_in).to(dev()), float(clip), reg)
+        np.testing.assert_allclose(m["abs_rel_diff"], float(z["depth%d.abs_rel" % clip]), rtol=2e-5)
+        t, p = loss_ref.prepare_depth_data(t_in, p_in, float(clip), reg)
+        np.testing.assert_allclose(m["squ_rel_diff"], loss_ref.squ_rel_diff(p, t), rtol=2e-5)
+        np.testing.assert_allclose(m["rms_linear"], loss_ref.rms_linear(p, t), rtol=2e-5)
+        np.testing.assert_allclose(m["mean_error"], loss_ref.mean_error(p, t), rtol=2e-5)
+        assert m["n"] == t_in.size
+    tn = z["depth80.target_in"].copy()
+    tn[::3, ::2] = np.nan
+    m = metrics.depth_metrics(torch.from_numpy(z["depth80.pred_in"]).to(dev()), torch.from_numpy(tn).to(dev()), 80.0, 3.70378, cutoff=30.0)
+    t, p = loss_ref.prepare_depth_data(tn, z["depth80.pred_in"], 80.0, 3.70378)
+    ok = ~np.isnan(t) & (np.nan_to_num(t, nan=1e9) <= 30.0)
+    np.testing.assert_allclose(m["abs_rel_diff"], (np.abs(t[ok] - p[ok]) / (t[ok] + 1e-6)).mean(), rtol=2e-5)
+    assert m["n"] == int(ok.sum())
