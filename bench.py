@@ -110,6 +110,8 @@ class KernelTimer:
                     bm = 64
                 if blocks(bm, bn) < 768 and bn == 128:
                     bn = 64
+            if bn == 32 and -(-Wo // 16) * -(-Ho // 16) * B >= 1024:
+                bm = 256
             return "conv_igemm_kernel<%d,%d,%s,1>" % (bm, bn, "4,1" if bn == 32 else "2,2")
 
         def conv(x0, taps, w, out, Cout, **kw):
@@ -161,6 +163,8 @@ class KernelTimer:
                     tiles = sum(-(-Wo // 16) * -(-Ho // 4) for _, Ho, Wo, _ in classes) * x0.shape[0]
                 if tiles * (cp // bn) < 768 and bn == 128:
                     bn = 64
+            if bn == 32 and sum(-(-Wo // 16) * -(-Ho // 16) for _, Ho, Wo, _ in classes) * x0.shape[0] >= 1024:
+                bm = 256
             name = "conv_igemm_kernel<%d,%d,%s,1>" % (bm, bn, "4,1" if bn == 32 else "2,2")
             if timer.only is not None and name != timer.only:
                 return multi0(x0, w, out, Cout, classes, **kw)
@@ -379,6 +383,11 @@ def main():
                                "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9}
             src = warm if warm else agg
+            if warm and args.warmup > 0:      # overlap-proof view: all MFMA FLOP of a step over the step's wall time
+                step_flop = sum(v[2] for v in warm.values()) / args.warmup
+                out["step_mfma"] = {"algorithmic_tflop_per_step": step_flop / 1e12,
+                                    "achieved": step_flop / (dt / args.steps) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": step_flop / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS}
             out["kernels_warmup_steps"] = {k: {"launches": v[0], "ms": 1e3 * v[1], "tflops": v[2] / v[1] / 1e12}
                                            for k, v in src.items()}
         if not args.no_cpu_baseline and world == 1:

@@ -304,6 +304,9 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
         if (blocks(BM, BN) < want) BM = 64;
         if (blocks(BM, BN) < want && BN == 128) BN = 64;
     }
+    static const char *no256 = getenv("RAMNET_CONV_NO256");
+    if (!lstm && BN == 32 && blocks(256, 32) >= 1024 && !(no256 && no256[0] == '1'))
+        BM = 256;                    // 32-channel outputs: 16x16-pixel tiles, 2 accumulators per wave per tap
     const int TH = BM / TWID;
     int max_tiles = 0;
     qc.patch_floats = 0;
@@ -332,6 +335,7 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
     if (BM == 128 && BN == 64) return launch_cfg<128, 64, 2, 2>(d, qc, qk, max_tiles, st);
     if (BM == 64 && BN == 128) return launch_cfg<64, 128, 2, 2>(d, qc, qk, max_tiles, st);
     if (BM == 64 && BN == 64) return launch_cfg<64, 64, 2, 2>(d, qc, qk, max_tiles, st);
+    if (BM == 256) return launch_cfg<256, 32, 4, 1>(d, qc, qk, max_tiles, st);
     return launch_cfg<128, 32, 4, 1>(d, qc, qk, max_tiles, st);
 }
 
