@@ -18,8 +18,10 @@ def main(path):
     for key, v in sorted(per.items()):
         print("%-46s %9s %7s | " % key + " ".join("%14.4g" % (sum(v[c]) / max(1, len(v[c]))) for c in ctrs))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
-            mf = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / sum(v["GRBM_GUI_ACTIVE"]) / (256 * 4)
-            print("%-46s   MfmaUtil = %.1f %% of (GUI_ACTIVE x 1024 SIMDs)" % ("", 100 * mf))
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles are summed over all 1024 SIMDs
+            gui = sum(v["GRBM_GUI_ACTIVE"]) / 8.0
+            mf = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (gui * 256 * 4)
+            print("%-46s   MFMA pipe busy = %.1f %% of SIMD-cycles (GUI_ACTIVE/8 x 1024 SIMDs)" % ("", 100 * mf))
 
 
 if __name__ == "__main__":
