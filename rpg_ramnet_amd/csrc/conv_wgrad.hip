@@ -29,16 +29,21 @@ struct WgradDerived {
 // Accumulator tile (jt, ns): rows = (tap jt*tpm + row/cinp, channel row%cinp), cols = output channel ns*32 + col.
 // Wave w owns ns = w % NSUB and tap tiles w/NSUB, w/NSUB + 4/NSUB, ...; waves with fewer real tiles run the same MAXT
 // MFMAs on a valid dummy address (they would wait at the barrier anyway) so the K loop has no branches.
-template <int MAXT, int NSUB>
-__global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_desc p, const WgradDerived q) {
-    constexpr int WBN = 32 * NSUB, TSTEP = 4 / NSUB, GQ = WBN / 4;   // GQ: channel quads per gradient-tile pixel
+// CSUB = 2 (3x3 layers with >= 64 input channels): the workgroup owns 64 input x 64 output channels and wave w owns ALL taps
+// of quadrant (input half w>>1, output half w&1): 9 tiles per wave, perfectly balanced, and the gradient tile is staged
+// once per 64 input channels instead of once per 32.
+template <int MAXT, int NSUB, int CSUB = 1>
+__global__ void __launch_bounds__(256, CSUB == 2 ? 2 : 1) conv_wgrad_kernel(const ramnet_wgrad_desc p, const WgradDerived q) {
+    constexpr int WBN = 32 * NSUB, GQ = WBN / 4;   // GQ: channel quads per gradient-tile pixel
+    constexpr int WCK = 32 * CSUB;                 // input channels per workgroup (shadows the namespace default)
+    constexpr int TSTEP = CSUB == 2 ? 1 : 4 / NSUB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;                         // [PH*PW][32]
     float *gsm = smem + q.PH * q.PW * WCK;       // [128][WBN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
-    const int ns = wave % NSUB, tap0 = wave / NSUB;
+    const int ns = wave % NSUB, csub = CSUB == 2 ? wave / NSUB : 0, tap0 = CSUB == 2 ? 0 : wave / NSUB;
     const int ntw = (q.ntt - tap0 + TSTEP - 1) / TSTEP;
     const int c0 = blockIdx.y * WCK, n0 = blockIdx.z * WBN;
     const int cinp = 32 / q.tpm, sub = l31 / cinp, cl = l31 - sub * cinp;
@@ -52,7 +57,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
         const int tap = (tap0 + TSTEP * j) * q.tpm + sub;
-        toffw[j] = (j < ntw && tap < p.ntaps) ? q.toff[tap] + cl : cl;
+        toffw[j] = ((j < ntw && tap < p.ntaps) ? q.toff[tap] + cl : cl) + csub * 32;
     }
 
     float4 bsum = f4zero();                      // bias gradient partial: fixed channel quad (tid % GQ)
@@ -67,30 +72,33 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
         const int oy0 = ty_i * q.TH, ox0 = tx_i * TWID;
         const int iy0 = oy0 * p.stride + q.dymin, ix0 = ox0 * p.stride + q.dxmin;
         __syncthreads();
-        {   // gradient tile: 128 pixels x GQ channel quads, all loads (x2 with mask) in flight at once
+        {   // gradient tile: TH*16 pixels x GQ channel quads, 4 loads (x2 with mask) in flight per batch
             constexpr int NG = 128 * GQ / 256;
             const int nsl = q.TH * TWID * GQ;
-            float4 g[NG], y[NG];
-            bool ok[NG];
-#pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const int s = tid + i * 256;
-                const int m = s / GQ, qd = s % GQ;
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
-                ok[i] = s < nsl && oy < p.Ho && ox < p.Wo && n < p.Cout;
-                const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
-                g[i] = ld4(ok[i] ? p.dout + pix * p.ldg + n : p.dout);
-                if (p.gmask) y[i] = ld4(ok[i] ? p.gmask + pix * p.ldgm + n : p.gmask);
-            }
             stage_patch<WCK / 4, WCK, 4, 256>(patch, q.src, b, iy0, ix0, c0, q.PH, q.PW, tid);
 #pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const int s = tid + i * 256;
-                float4 r = g[i];
-                if (p.gmask) r = make_float4(y[i].x > 0.f ? r.x : 0.f, y[i].y > 0.f ? r.y : 0.f, y[i].z > 0.f ? r.z : 0.f, y[i].w > 0.f ? r.w : 0.f);
-                if (!ok[i]) r = f4zero();
-                if (s < nsl) st4(gsm + (s / GQ) * WBN + (s % GQ) * 4, r);
-                bsum = f4add(bsum, r);
+            for (int h = 0; h < NG; h += 4) {
+                float4 g[4], y[4];
+                bool ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = tid + (h + i) * 256;
+                    const int m = s / GQ, qd = s % GQ;
+                    const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
+                    ok[i] = s < nsl && oy < p.Ho && ox < p.Wo && n < p.Cout;
+                    const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+                    g[i] = ld4(ok[i] ? p.dout + pix * p.ldg + n : p.dout);
+                    if (p.gmask) y[i] = ld4(ok[i] ? p.gmask + pix * p.ldgm + n : p.gmask);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = tid + (h + i) * 256;
+                    float4 r = g[i];
+                    if (p.gmask) r = make_float4(y[i].x > 0.f ? r.x : 0.f, y[i].y > 0.f ? r.y : 0.f, y[i].z > 0.f ? r.z : 0.f, y[i].w > 0.f ? r.w : 0.f);
+                    if (!ok[i]) r = f4zero();
+                    if (s < nsl) st4(gsm + (s / GQ) * WBN + (s % GQ) * 4, r);
+                    bsum = f4add(bsum, r);
+                }
             }
         }
         __syncthreads();
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const int t = (tap0 + TSTEP * j) * q.tpm + row / cinp, c = c0 + row % cinp;
+            const int t = (tap0 + TSTEP * j) * q.tpm + row / cinp, c = c0 + csub * 32 + row % cinp;
             if (t < p.ntaps && c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)t * Cin + c) * p.Cout + n, acc[j][r]);
         }
     }
@@ -150,10 +158,10 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_kernel(const ramnet_wgrad_d
     }
 }
 
-template <int MAXT, int NSUB>
+template <int MAXT, int NSUB, int CSUB = 1>
 static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipStream_t st) {
-    auto kern = conv_wgrad_kernel<MAXT, NSUB>;
-    constexpr int WBN = 32 * NSUB;
+    auto kern = conv_wgrad_kernel<MAXT, NSUB, CSUB>;
+    constexpr int WBN = 32 * NSUB, WCK = 32 * CSUB;
     size_t lds = ((size_t)q.PH * q.PW * WCK + q.TH * TWID * WBN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -167,7 +175,7 @@ static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipSt
     const int gy = cdiv(q.src.Cin, WCK), gz = cdiv(d.Cout, WBN);
     // one resident wave of workgroups (256 CUs x blocks/CU the register budget admits): fewer pixel splits = fewer
     // atomic partial-sum merges, and every CU still gets an equal share
-    int splits = (MAXT >= 13 ? 256 : 512) / (gy * gz);
+    int splits = 512 / (gy * gz);
     if (splits > q.ntiles) splits = q.ntiles;
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(kern, dim3(splits, gy, gz), dim3(256), lds, st, d, q);
@@ -205,12 +213,17 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
     q.dymin = dymin, q.dxmin = dxmin;
     // two co-resident workgroups per CU hide each other's staging: halve the pixel tile when a full one needs > 80 KB
     q.TH = 8;
-    if (((7 * d.stride + (dymax - dymin) + 1) * ((TWID - 1) * d.stride + (dxmax - dxmin) + 1) * WCK + 128 * 32) * 4 > 80 * 1024) q.TH = 4;
+    // -> conv_wgrad_kernel<9,2,2>; needs >= 4 pixel tiles per workgroup to amortise its 9 x 64 x 64 atomic epilogue
+    const long tiles8 = (long)cdiv(d.Wo, TWID) * cdiv(d.Ho, 8) * d.B;
+    const bool wide = d.ntaps <= 9 && d.ntaps > 1 && q.src.Cin >= 64 && d.Cout > 32 &&
+                      tiles8 * cdiv(q.src.Cin, 64) * cdiv(d.Cout, 64) >= 2048;
+    const int wck = wide ? 64 : WCK;
+    if (((7 * d.stride + (dymax - dymin) + 1) * ((TWID - 1) * d.stride + (dxmax - dxmin) + 1) * wck + 128 * 32) * 4 > 80 * 1024) q.TH = 4;
     q.PH = (q.TH - 1) * d.stride + (dymax - dymin) + 1;
     q.PW = (TWID - 1) * d.stride + (dxmax - dxmin) + 1;
     q.tiles_x = cdiv(d.Wo, TWID), q.tiles_y = cdiv(d.Ho, q.TH);
     q.ntiles = q.tiles_x * q.tiles_y * d.B;
-    for (int t = 0; t < d.ntaps; ++t) q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * WCK;
+    for (int t = 0; t < d.ntaps; ++t) q.toff[t] = ((d.dy[t] - dymin) * q.PW + (d.dx[t] - dxmin)) * wck;
     hipStream_t st = (hipStream_t)stream;
     // Cin < 32: several taps share one 32-row accumulator tile (head convs: 5 or 1 input channels)
     q.tpm = 1;
@@ -226,6 +239,8 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
         if (per_wave <= 3) return launch_wgrad<3, 1>(d, q, st);
         return launch_wgrad<7, 1>(d, q, st);
     }
+    static const char *nowide = getenv("RAMNET_WGRAD_NOWIDE");
+    if (wide && !(nowide && nowide[0] == '1')) return launch_wgrad<9, 2, 2>(d, q, st);
     const int per_wave = cdiv(q.ntt, 2);            // WBN = 64: tap tiles spread over 2 wave pairs
     if (per_wave <= 1) return launch_wgrad<1, 2>(d, q, st);
     if (per_wave <= 5) return launch_wgrad<5, 2>(d, q, st);
