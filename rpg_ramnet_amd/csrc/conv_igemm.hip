@@ -300,7 +300,8 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
         return t * d.B * (qc.CoutPad / bn);
     };
     if (!lstm && BN >= 64) {
-        const long want = 768;
+        static const char *we = getenv("RAMNET_CONV_WANT");     // tuning knob: minimum workgroups before shrinking tiles
+        const long want = we ? atol(we) : 768;
         if (blocks(BM, BN) < want) BM = 64;
         if (blocks(BM, BN) < want && BN == 128) BN = 64;
     }
