@@ -13,6 +13,7 @@ Inputs are synthetic (device-generated event lists -> HIP voxel scatter-add -> n
 log-depth targets) and resident in HBM before the timed region.  Weights: seeded random init (no checkpoints offline).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -199,7 +200,8 @@ def cpu_baseline(cfg, H, W, K, args):
     from recipe import make_item
     from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent
     torch.manual_seed(0)
-    m = ERGB2DepthRecurrent(cfg)
+    with contextlib.redirect_stdout(sys.stderr):      # the constructor prints (like the reference's); stdout carries ONE JSON line
+        m = ERGB2DepthRecurrent(cfg)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     rng = np.random.default_rng(0)
     cores = torch.get_num_threads()
@@ -244,7 +246,8 @@ def main():
     cfg = dict(RELEASED, num_bins_events=bins, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)
     torch.manual_seed(0)                       # identical initial weights on every rank (train.py:203)
-    model = ERGB2DepthRecurrent(cfg)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = ERGB2DepthRecurrent(cfg)
     model = model.to(model.gpu)
     seq = synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=1000 + rank)
     timer = KernelTimer()
