@@ -21,6 +21,7 @@ struct ConvCommon {
     int nchunks, CoutPad;            // weight geometry
     int patch_floats;                // LDS floats reserved per patch plane (max over the launch's classes, multiple of 4)
     int nclass;
+    int xcd_swizzle;
 };
 
 // One output class of a launch: a plain convolution has one; the backward-data of a stride-2 layer (and the forward of
@@ -41,8 +42,18 @@ struct ConvClasses { ConvClass c[4]; };
 //                (16 fp32 + pad | 32 bf16 + pad), so tile geometry, tap offsets and fragment addresses are shared.
 template <int BM, int BN, int WM, int WN, bool SPLIT>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvCommon qc, const ConvClasses qk) {
-    const ConvClass &q = qk.c[blockIdx.z];
-    if ((int)blockIdx.x >= q.tiles_x * q.tiles_y * p.B) return;      // classes of one launch may differ by a tile
+    // XCD-aware tile order: the dispatcher deals consecutive (flattened) workgroup ids round-robin to the 8 XCDs, each with
+    // a private L2.  Remap the flattened id so that every XCD walks a CONTIGUOUS range of (class, channel tile, spatial
+    // tile): neighbouring spatial tiles then share their halo rows and their weight tile through ONE L2 instead of
+    // fetching them on 8.  Bijective for any grid size (q/r split); only speed depends on the placement assumption.
+    int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (qc.xcd_swizzle) {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z, xcd = flat & 7, qq = nwg >> 3, rr = nwg & 7;
+        flat = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (flat >> 3);
+    }
+    int bid = flat % gridDim.x;
+    const int by = (flat / gridDim.x) % gridDim.y, bz = flat / (gridDim.x * gridDim.y);
+    const ConvClass &q = qk.c[bz];
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TH = BM / TWID;
     constexpr int CKC = SPLIT ? 32 : 16;           // input channels per chunk
@@ -57,12 +68,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, kk = lane >> 5;
 
-    int bid = blockIdx.x;
+    if (bid >= q.tiles_x * q.tiles_y * p.B) return;                   // classes of one launch may differ by a tile
     const int tx_i = bid % q.tiles_x;
     bid /= q.tiles_x;
     const int ty_i = bid % q.tiles_y;
     const int b = bid / q.tiles_y;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = by * BN;
     const int oy0 = ty_i * TH, ox0 = tx_i * TWID;
     const int iy0 = oy0 * p.stride + q.dymin, ix0 = ox0 * p.stride + q.dxmin;
 
@@ -181,7 +192,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
             if (epi == RAMNET_EPI_LSTM) {
                 if constexpr (TN == 4) {
                     // packed N order = (channel block of 32, gate, channel): ns is the gate (i, f, o, g)
-                    const int C = p.Cout, ch = blockIdx.y * 32 + l31;
+                    const int C = p.Cout, ch = by * 32 + l31;
                     if (ch < C) {
                         const float gi = sigmoidf_(acc[ms][0][r] + p.bias[ch]);
                         const float gf = sigmoidf_(acc[ms][1][r] + p.bias[C + ch]);
@@ -290,6 +301,11 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
     qc.nchunks = cdiv(qc.src.Cin, split ? 32 : CK);
     qc.CoutPad = d.epi == RAMNET_EPI_LSTM ? 4 * roundup(d.Cout, 32) : roundup(d.Cout, 32);
     qc.nclass = n;
+    // measured on MI355X (profiles/r01_b_tuning_notes.md): forward 5.55 -> 5.50 ms, backward-data 5.40 -> 5.56 ms per pass,
+    // i.e. null within noise — these kernels are MFMA-bound and their operands sit in L2 / Infinity Cache either way.
+    // Kept as an opt-in knob (RAMNET_XCD_SWIZZLE=1) for HBM-bound shapes.
+    static const char *sw = getenv("RAMNET_XCD_SWIZZLE");
+    qc.xcd_swizzle = sw && sw[0] == '1';
     // ---- tile configuration.  Low-resolution layers (32x43 .. 64x86 pixels) give few 128-pixel tiles: a grid that does
     // not cover the 256 CUs ~3x over leaves CUs idle in the last round (tile quantisation), so shrink the tile there.
     const int lstm = d.epi == RAMNET_EPI_LSTM;
