@@ -1,0 +1,79 @@
+"""Checkpoint files in the reference's layout (RAM_Net/base/base_trainer.py:133-179):
+
+    {'arch', 'epoch', 'logger', 'state_dict', 'optimizer', 'monitor_best', 'config'}   ->  *.pth.tar
+
+so that checkpoints written here load in the reference's `test.py` / `--resume`, and the released checkpoints
+(`ramnet_sim.pth.tar`, README.md:59) load here.  Reference files pickle a `logger.logger.Logger` instance under
+'logger'; that module is not importable outside the reference tree, so loading installs a structural stand-in
+(same attribute: `entries`) for the duration of `torch.load`.
+"""
+import os
+import sys
+import types
+
+import torch
+
+
+class Logger:
+    """Same surface as RAM_Net/logger/logger.py:4-18 (dict of entries)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def add_entry(self, entry):
+        self.entries[len(self.entries) + 1] = entry
+
+    def __str__(self):
+        import json
+        return json.dumps(self.entries, sort_keys=True, indent=4)
+
+
+def checkpoint_name(save_dir, epoch, loss):
+    """base_trainer.py:151-152 naming."""
+    return os.path.join(save_dir, 'checkpoint-epoch{:03d}-loss-{:.4f}.pth.tar'.format(epoch, loss))
+
+
+def save_checkpoint(path, model, optimizer, epoch, config, monitor_best=float('inf'), logger=None):
+    state = {
+        'arch': type(model).__name__,
+        'epoch': epoch,
+        'logger': logger if logger is not None else Logger(),
+        'state_dict': model.state_dict(),
+        'optimizer': optimizer.state_dict() if optimizer is not None else None,
+        'monitor_best': monitor_best,
+        'config': config,
+    }
+    torch.save(state, path)
+    return path
+
+
+def load_checkpoint(path, map_location='cpu'):
+    """torch.load of a reference-layout checkpoint (needs weights_only=False: the file pickles Python objects)."""
+    injected = []
+    if 'logger' not in sys.modules:
+        pkg = types.ModuleType('logger')
+        sub = types.ModuleType('logger.logger')
+        sub.Logger = Logger
+        pkg.Logger = Logger
+        pkg.logger = sub
+        sys.modules['logger'], sys.modules['logger.logger'] = pkg, sub
+        injected = ['logger', 'logger.logger']
+    try:
+        return torch.load(path, map_location=map_location, weights_only=False)
+    finally:
+        for m in injected:
+            sys.modules.pop(m, None)
+
+
+def resume(path, model, optimizer=None, map_location='cpu'):
+    """base_trainer.py:160-179: restore model (strict), optimizer, epoch, monitor_best.  Returns (start_epoch, ckpt)."""
+    ckpt = load_checkpoint(path, map_location)
+    model.load_state_dict(ckpt['state_dict'])
+    if optimizer is not None and ckpt.get('optimizer') is not None:
+        optimizer.load_state_dict(ckpt['optimizer'])
+        dev = next(model.parameters()).device
+        for st in optimizer.state.values():
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    st[k] = v.to(dev)
+    return ckpt['epoch'] + 1, ckpt
