@@ -138,13 +138,13 @@ class KernelTimer:
             ntt = -(-taps.n // tpm)
             if Cout <= 32 or taps.n > 9:
                 per = -(-ntt // 4)
-                name = "conv_wgrad_kernel<%d,1>" % (1 if per <= 1 else 3 if per <= 3 else 7)
+                name = "conv_wgrad_kernel<%d,1,1>" % (1 if per <= 1 else 3 if per <= 3 else 7)
             elif (taps.n > 1 and cin >= 64 and
                   -(-dout.shape[2] // 16) * -(-dout.shape[1] // 8) * dout.shape[0] * -(-cin // 64) * -(-Cout // 64) >= 2048):
                 name = "conv_wgrad_kernel<9,2,2>"
             else:
                 per = -(-ntt // 2)
-                name = "conv_wgrad_kernel<%d,2>" % (1 if per <= 1 else 5)
+                name = "conv_wgrad_kernel<%d,2,1>" % (1 if per <= 1 else 5)
             if timer.only is not None and name != timer.only:
                 return wgrad0(x0, taps, dout, dw, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
