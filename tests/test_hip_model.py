@@ -229,3 +229,32 @@ def test_raw_346x260_is_rejected_like_the_reference():
     bad = {"events0": torch.zeros(1, 3, 32, 48), "image": torch.zeros(1, 1, 32, 48)}       # wrong bin count
     with torch.no_grad(), pytest.raises(RuntimeError):
         model(dict(bad, **{"events%d" % k: bad["events0"] for k in range(1, 5)}), None, ramnet_ref.empty_states_lstm(5))
+
+
+def test_training_trajectory_matches_oracle():
+    """End to end: 6 Adam steps (lr 1e-4) on one fixed batch through the HIP path and through the CPU oracle with
+    torch autograd — identical seeded weights and data.  The loss trajectories must coincide and fall."""
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(0)
+    seq = [make_item(rng, 2, 32, 48, 2, 5, 1, True, 0.0) for _ in range(2)]
+    for item in seq:       # learnable targets: a smooth function of the frame
+        tgt = 0.25 + 0.5 * torch.nn.functional.avg_pool2d(item["image"], 5, 1, 2)
+        item["depth_image"], item["depth_events1"] = tgt, tgt.clone()
+    og, oc = torch.optim.Adam(model.parameters(), lr=1e-4), torch.optim.Adam(list(sd.values()), lr=1e-4)
+    hip, ora = [], []
+    for _ in range(6):
+        og.zero_grad()
+        lg, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+        lg.backward()
+        og.step()
+        oc.zero_grad()
+        lc, _ = ramnet_ref.sequence_loss(sd, cfg, seq, cfg["loss_composition"], [1, 1])
+        lc.backward()
+        oc.step()
+        hip.append(float(lg.detach()))
+        ora.append(float(lc.detach()))
+    np.testing.assert_allclose(hip, ora, rtol=2e-4)
+    assert hip[-1] < 0.8 * hip[0], hip
