@@ -222,3 +222,24 @@ def test_checkpoint_layout_round_trip_and_reference_pickle(tmp_path):
     c2 = ck.load_checkpoint(str(tmp_path / "ref.pth.tar"))
     assert c2["logger"].entries[1]["loss"] == 0.5
     mm.ERGB2DepthRecurrent(cfg).load_state_dict(c2["state_dict"], strict=True)
+
+
+def test_cabi_argument_errors_and_host_only_entry_points():
+    """Error behaviour of the C ABI without a GPU: bad arguments are rejected before any HIP call, with a message;
+    size helpers are pure host functions."""
+    from rpg_ramnet_amd import _hip
+    L = _hip.lib()
+    assert L.ramnet_conv_launch(None, None) == 10001 and b"bad argument" in L.ramnet_last_error()
+    assert L.ramnet_wgrad_launch(None, None) == 10001
+    d = _hip.ConvDesc()                      # all-zero descriptor: null pointers
+    assert L.ramnet_conv_launch(ctypes.byref(d), None) == 10001
+    assert L.ramnet_si_loss_fwd(None, None, 0, 1.0, 1.0, None, None, None) == 10001
+    assert L.ramnet_voxelize(None, 10, 0, 4, 4, None, None) == 10001
+    # packed sizes: [tap][chunk16][Cout_pad32][16] / split: [tap][chunk32][2][Cout_pad32][32] bf16 (in floats)
+    assert L.ramnet_packed_weight_elems(64, 32, 5, 5, 0, 1) == 25 * 2 * 64 * 16
+    assert L.ramnet_packed_weight_elems(64, 32, 5, 5, 1, 1) == 25 * 4 * 32 * 16          # transposed: reduce over O=64
+    assert L.ramnet_packed_weight_elems(256, 128, 3, 3, 0, 4) == 9 * 8 * 256 * 16         # LSTM gates: 4 x pad32(64)
+    assert L.ramnet_packed_weight_elems(32, 5, 5, 5, 0, 1) == 25 * 1 * 32 * 16            # 5 input channels -> one chunk
+    assert L.ramnet_packed_weight_elems_split(64, 32, 5, 5, 0, 1) == 25 * 1 * 2 * 64 * 32 // 2
+    assert L.ramnet_msg_workspace_elems(2, 32, 48, 4) == 2 * (32 * 48 + 16 * 24 + 8 * 12 + 4 * 6)
+    assert L.ramnet_msg_workspace_elems(2, 4, 4, 4) == 0                                   # 8x pooling of a 4x4 map
