@@ -361,7 +361,7 @@ def main():
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam"
                                       % (H, W, B, L, args.mode, args.state),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
-               "final_loss": loss_val}
+               "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
         if args.mode == "stream":
             out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
                              "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "
