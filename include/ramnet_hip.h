@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 1
+#define RAMNET_ABI_VERSION 2
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -40,6 +40,8 @@ enum ramnet_in_mode {
  *         hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error ~1e-5 per
  *         product (vs 4e-3 for plain bf16), 3 MFMAs at 16x the fp32 rate.  Inputs/outputs stay fp32 in HBM.    */
 enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
+/* RAMNET_ALGO_WINOGRAD: F(2x2,3x3), fp32; only the dense 3x3 stride-1 tap list, w from ramnet_pack_weight_wino() */
+enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1 };
 
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {
@@ -76,6 +78,7 @@ typedef struct ramnet_conv_desc {
     float *out, *o1, *o2;
     int ldo, ldo1, ldo2;
     int precision;                  /* RAMNET_PREC_F32 (exact fp32 MFMA) or RAMNET_PREC_BF16X3 (w packed with split=1) */
+    int algo;                       /* RAMNET_ALGO_DIRECT or RAMNET_ALGO_WINOGRAD (F32 only)                     */
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
@@ -106,6 +109,10 @@ size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transpo
 size_t ramnet_packed_weight_elems_split(int Cout, int Cin, int KH, int KW, int transposed, int gates);
 int ramnet_pack_weight_split(const float *w_oihw, float *wp, int Cout, int Cin, int KH, int KW,
                              int transposed, int gates, void *stream);
+/* Winograd F(2x2,3x3) weights U = G g G^T of a 3x3 conv, layout [Cin/8][Cout/64][16][64][8] (padded with zeros).
+ * transposed=1 packs the backward-data operator (flipped taps, reduce over O).                      */
+size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed);
+int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, void *stream);
 /* OIHW -> kernel layout [tap][chunk][n][16].  transposed=1 packs the backward-data operator
  * (reduce over O, produce I).  gates=4 interleaves ConvLSTM gate blocks so that one wave owns
  * i,f,o,g of a channel (forward only).  CinValid rows beyond Cin are zero (padded inputs).        */

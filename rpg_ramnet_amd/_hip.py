@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_PKG, "librpg_ramnet_hip.so")
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK = range(6)
 PREC_F32, PREC_BF16X3 = 0, 1
+ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
 
 _fp = C.c_void_p
@@ -32,6 +33,7 @@ class ConvDesc(C.Structure):
         ("out", _fp), ("o1", _fp), ("o2", _fp),
         ("ldo", C.c_int), ("ldo1", C.c_int), ("ldo2", C.c_int),
         ("precision", C.c_int),
+        ("algo", C.c_int),
     ]
 
 
@@ -57,6 +59,8 @@ _SIGS = {
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_split": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight_split": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 3),
+    "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ramnet_conv_launch_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _fp]),
@@ -107,7 +111,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 1:
+        if l.ramnet_abi_version() != 2:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

@@ -15,6 +15,7 @@ constexpr int TWID = 16;      // output tile width in pixels (tile = TH x 16)
 constexpr int WCK = 32;       // input channels per block of the weight-gradient kernel
 
 void set_error(const char *fmt, ...);
+int launch_wino(const ramnet_conv_desc &d, hipStream_t st);   // conv_wino.hip
 
 #define RAMNET_CHECK_ARG(cond)                                                        \
     do {                                                                              \
@@ -181,6 +182,56 @@ __device__ __forceinline__ void stage_patch(float *__restrict__ patch, const InS
         }
     }
 }
+
+// The same staging split in two halves so that the global loads of the NEXT chunk can be kept in flight (in registers)
+// under the MFMAs of the current one: load() issues them, store() applies mask / product / zero padding and writes LDS.
+// (PLAIN / CAT / CAT_MUL / RELUMASK sources; the upsampling loaders are not needed by the 3x3 layers that use it.)
+template <int QPP, int NB, int NT>
+struct PatchRegs {
+    float4 v[NB], m[NB];
+    unsigned okmask, mmask;
+
+    __device__ __forceinline__ void load(const InSrc &s, int b, int iy0, int ix0, int c0, int PH, int PW, int tid) {
+        const int nslots = PH * PW * QPP;
+        const bool two = s.mode == RAMNET_IN_CAT_MUL || s.mode == RAMNET_IN_RELUMASK;
+        okmask = 0, mmask = 0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sl = tid + i * NT;
+            const int pix = sl / QPP, qd = sl - pix * QPP;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px, c = c0 + qd * 4;
+            const bool ok = sl < nslots && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win && c < s.Cin;
+            const size_t gp = ((size_t)b * s.Hin + iy) * s.Win + ix;
+            const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c >= s.C0;
+            const float *p0 = second ? s.x1 + gp * s.ld1 + (c - s.C0) : s.x0 + gp * s.ld0 + c;
+            const bool hm = two && (s.mode == RAMNET_IN_RELUMASK || second);
+            const float *p1 = s.mode == RAMNET_IN_RELUMASK ? s.xm + gp * s.ldm + c : s.xm + gp * s.ldm + (c - s.C0);
+            v[i] = ld4(ok ? p0 : s.x0);
+            m[i] = two ? ld4(ok && hm ? p1 : s.x0) : f4zero();
+            okmask |= (ok ? 1u : 0u) << i;
+            mmask |= (hm ? 1u : 0u) << i;
+        }
+    }
+
+    template <int LDX>
+    __device__ __forceinline__ void store(float *__restrict__ patch, const InSrc &s, int PH, int PW, int tid) const {
+        const int nslots = PH * PW * QPP;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sl = tid + i * NT;
+            float4 r = v[i];
+            if ((mmask >> i) & 1u) {
+                if (s.mode == RAMNET_IN_RELUMASK)
+                    r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
+                else
+                    r = f4mul(r, m[i]);
+            }
+            if (!((okmask >> i) & 1u)) r = f4zero();
+            if (sl < nslots) st4(patch + (sl / QPP) * LDX + (sl % QPP) * 4, r);
+        }
+    }
+};
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int roundup(int a, int b) { return cdiv(a, b) * b; }

@@ -13,6 +13,7 @@
 // Fused epilogues: bias/ReLU/sigmoid, residual add, GRU blend, full LSTM cell.
 #include <stdlib.h>
 #include "common.hpp"
+#include "conv_epilogue.hpp"
 
 namespace ramnet {
 
@@ -214,23 +215,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
             for (int ns = 0; ns < TN; ++ns) {
                 const int n = n0 + (wn * TN + ns) * 32 + l31;
                 if (n >= p.Cout) continue;
-                float v = acc[ms][ns][r] + (p.bias ? p.bias[n] : 0.f);
-                if (epi == RAMNET_EPI_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (epi == RAMNET_EPI_SIGMOID) {
-                    v = sigmoidf_(v);
-                } else if (epi == RAMNET_EPI_RES_RELU) {
-                    v = fmaxf(v + p.e0[pix * p.lde0 + n], 0.f);
-                } else if (epi == RAMNET_EPI_GRU_BLEND) {
-                    const float o = tanhf(v);
-                    const float u = p.e0[pix * p.lde0 + n];
-                    const float h = p.e1 ? p.e1[pix * p.lde1 + n] : 0.f;
-                    if (p.o1) p.o1[pix * p.ldo1 + n] = o;
-                    v = h * (1.0f - u) + o * u;
-                } else if (p.beta != 0.f) {
-                    v += p.beta * p.out[pix * p.ldo + n];
-                }
-                p.out[pix * p.ldo + n] = v;
+                epilogue_store(p, epi, pix, n, acc[ms][ns][r]);
             }
         }
     }
@@ -362,6 +347,11 @@ using namespace ramnet;
 
 extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
     RAMNET_CHECK_ARG(dp != nullptr);
+    if (dp->algo == RAMNET_ALGO_WINOGRAD) {
+        const int rc = check_desc(*dp);
+        return rc ? rc : launch_wino(*dp, (hipStream_t)stream);
+    }
+    RAMNET_CHECK_ARG(dp->algo == RAMNET_ALGO_DIRECT);
     return launch_classes(dp, 1, (hipStream_t)stream);
 }
 

@@ -32,6 +32,21 @@ def get_precision():
     return "bf16x3" if _PRECISION == H.PREC_BF16X3 else "f32"
 
 
+# 3x3 stride-1 layers (ConvGRU gates / candidate, residual blocks) run Winograd F(2x2,3x3) in fp32 — 2.25x fewer
+# multiplies, rounding error ~1e-6 relative (tests/test_hip_ops.py) — unless switched off (RAMNET_WINOGRAD=0).
+_WINOGRAD = _os.environ.get("RAMNET_WINOGRAD", "1") == "1"
+_WINO_MIN_CIN = int(_os.environ.get("RAMNET_WINOGRAD_MIN_CIN", "32"))
+
+
+def set_winograd(on):
+    global _WINOGRAD
+    _WINOGRAD = bool(on)
+
+
+def get_winograd():
+    return _WINOGRAD
+
+
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -67,6 +82,7 @@ class Taps:
         self.dy = (C.c_int8 * 25)(*[t[0] for t in triples])
         self.dx = (C.c_int8 * 25)(*[t[1] for t in triples])
         self.wt = (C.c_uint8 * 25)(*[t[2] for t in triples])
+        self.wino = False
 
     @classmethod
     def get(cls, kind, k, pad, py=0, px=0):
@@ -83,6 +99,7 @@ class Taps:
             else:
                 raise KeyError(kind)
             cls._cache[key] = cls(tr)
+            cls._cache[key].wino = kind in ("conv", "dgrad1") and k == 3 and pad == 1   # dense padded 3x3 window
         return cls._cache[key]
 
 
@@ -94,6 +111,8 @@ def conv_launch(x0, taps, w, out, Cout, **kw):
 def conv_launch_multi(x0, w, out, Cout, classes, **kw):
     """One launch for several output classes: `classes` = [(taps, Ho, Wo, (osy, osx, ooy, oox)), ...] (<= 4)."""
     arr = (H.ConvDesc * len(classes))()
+    if isinstance(w, PackRef):
+        w = w.cp.pack(w.transposed, False)
     for i, (taps, Ho, Wo, os_) in enumerate(classes):
         arr[i] = _conv_desc(x0, taps, w, out, Cout, Ho=Ho, Wo=Wo, os=os_, **kw)
     H.check(H.lib().ramnet_conv_launch_multi(arr, len(classes), _st()), "ramnet_conv_launch_multi")
@@ -107,6 +126,12 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
     d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
+    d.algo = H.ALGO_DIRECT
+    if isinstance(w, PackRef):
+        wino = (_WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1 and w.cp.gates == 1
+                and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP) and d.C0 + C1 >= _WINO_MIN_CIN)
+        d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
+        w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
     d.ntaps, d.stride = taps.n, stride
     d.dy, d.dx, d.wtap = taps.dy, taps.dx, taps.wt
@@ -211,6 +236,14 @@ def ensure_grad(p):
     return p.grad
 
 
+class PackRef:
+    """Handle on the packed weights of a ConvParam; the launch picks the layout (direct / Winograd) that fits it."""
+    __slots__ = ("cp", "transposed")
+
+    def __init__(self, cp, transposed):
+        self.cp, self.transposed = cp, transposed
+
+
 class ConvParam:
     """Kernel-side state of one convolution: packed weights (forward / backward-data layouts, re-packed when the
     nn.Parameter version changes) and the weight/bias gradient workspaces.  ``weights`` may hold several OIHW
@@ -222,8 +255,9 @@ class ConvParam:
         self.Cout = sum(w.shape[0] for w in self.weights)
         self.Cin, self.k = w0.shape[1], w0.shape[2]
         self.CinWs = (self.Cin + 3) // 4 * 4
-        self._fwd = self._bwd = self._bias = self._ws = self._bws = None
-        self._vf = self._vb = self._vbias = None
+        self._bias = self._ws = self._bws = None
+        self._vbias = None
+        self._packs = {}
         self._dirty = False
 
     def _versions(self, ts):
@@ -233,28 +267,36 @@ class ConvParam:
         w = self.weights[0] if len(self.weights) == 1 else torch.cat([w.detach() for w in self.weights], 0)
         return w.detach().contiguous()
 
-    def _pack(self, transposed):
+    def _pack(self, transposed, wino):
         L, g = H.lib(), (self.gates if not transposed else 1)
+        w = self._cat_w()
+        if wino:
+            n = L.ramnet_packed_weight_elems_wino(self.Cout, self.Cin, transposed)
+            out = torch.empty(n, device=w.device, dtype=torch.float32)
+            H.check(L.ramnet_pack_weight_wino(_p(w), _p(out), self.Cout, self.Cin, transposed, _st()), "ramnet_pack_weight_wino")
+            return out
         split = _PRECISION == H.PREC_BF16X3
         sizer, packer = (L.ramnet_packed_weight_elems_split, L.ramnet_pack_weight_split) if split else \
                         (L.ramnet_packed_weight_elems, L.ramnet_pack_weight)
         n = sizer(self.Cout, self.Cin, self.k, self.k, transposed, g)
-        w = self._cat_w()
         out = torch.empty(n, device=w.device, dtype=torch.float32)
         H.check(packer(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, transposed, g, _st()), "ramnet_pack_weight")
         return out
 
-    def fwd(self):
+    def pack(self, transposed, wino=False):
+        """Packed weights for the forward (transposed=0) / backward-data (1) launch, re-packed when a parameter changes."""
         v = (self._versions(self.weights), _PRECISION)
-        if self._fwd is None or v != self._vf:
-            self._fwd, self._vf = self._pack(0), v
-        return self._fwd
+        key = (transposed, bool(wino))
+        hit = self._packs.get(key)
+        if hit is None or hit[0] != v:
+            hit = self._packs[key] = (v, self._pack(transposed, bool(wino)))
+        return hit[1]
+
+    def fwd(self):
+        return PackRef(self, 0)
 
     def bwd(self):
-        v = (self._versions(self.weights), _PRECISION)
-        if self._bwd is None or v != self._vb:
-            self._bwd, self._vb = self._pack(1), v
-        return self._bwd
+        return PackRef(self, 1)
 
     def bias(self):
         if len(self.biases) == 1:

@@ -103,8 +103,61 @@ def test_transposed_conv(B, H, W, cin, cout, skip):
     run_pair(m, oracle, [x, s] if skip else [x])
 
 
+@pytest.fixture(params=["winograd", "direct"])
+def algo3x3(request):
+    """3x3 stride-1 layers: Winograd F(2x2,3x3) (default) and the direct implicit GEMM, both against the oracle."""
+    from rpg_ramnet_amd import ops
+    old = ops.get_winograd()
+    ops.set_winograd(request.param == "winograd")
+    yield request.param
+    ops.set_winograd(old)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
+def test_winograd_conv3x3_raw(B, H, W, cin, cout):
+    """Winograd forward and backward-data launches (all loader / epilogue combinations the 3x3 layers use) against
+    float64 F.conv2d and against the direct kernel; channel counts that are not multiples of the 8 / 64 blocking."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops, _hip as Hh
+    torch.manual_seed(11)
+    w = torch.randn(cout, cin, 3, 3) * 0.1
+    b = torch.randn(cout) * 0.1
+    cp = ops.ConvParam([torch.nn.Parameter(w.to(dev()))], [torch.nn.Parameter(b.to(dev()))])
+    x = torch.randn(B, cin, H, W)
+    xg = nhwc(x).to(dev()).contiguous()
+    res = torch.randn(B, cout, H, W)
+    resg = nhwc(res).to(dev()).contiguous()
+    taps, tapsd = ops.Taps.get("conv", 3, 1), ops.Taps.get("dgrad1", 3, 1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    outs = {}
+    for on in (True, False):
+        ops.set_winograd(on)
+        try:
+            y = torch.full((B, H, W, cout), float("nan"), device=dev())
+            ops.conv_launch(xg, taps, cp.fwd(), y, cout, bias=cp.bias(), epi=Hh.EPI_RES_RELU, e0=resg)
+            dx = torch.full((B, H, W, cin), float("nan"), device=dev())
+            ops.conv_launch(y, tapsd, cp.bwd(), dx, cin, xm=resg, in_mode=Hh.IN_RELUMASK)
+            acc = xg.clone()
+            ops.conv_launch(y, tapsd, cp.bwd(), acc, cin, beta=1.0)
+        finally:
+            ops.set_winograd(True)
+        outs[on] = (y, dx, acc)
+    yref = torch.relu(ref + res.double())
+    dy = torch.where(res > 0, yref, torch.zeros_like(yref))                     # the RELUMASK loader of the backward pass
+    dxref = F.conv_transpose2d(dy, w.double(), None, 1, 1)
+    accref = x.double() + F.conv_transpose2d(yref, w.double(), None, 1, 1)
+    for on in (True, False):
+        y, dx, acc = outs[on]
+        assert_close(nchw(y).cpu().numpy(), yref.numpy(), TOL, "forward winograd=%s" % on)
+        assert_close(nchw(dx).cpu().numpy(), dxref.numpy(), TOL, "dgrad winograd=%s" % on)
+        assert_close(nchw(acc).cpu().numpy(), accref.numpy(), TOL, "dgrad beta winograd=%s" % on)
+    # rounding of F(2x2,3x3) in fp32 stays within a few ulp of the direct kernel
+    assert_close(outs[True][0].cpu().numpy(), outs[False][0].cpu().numpy(), 2e-5, "winograd vs direct")
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
-def test_residual_block(B, H, W, C):
+def test_residual_block(B, H, W, C, algo3x3):
     from rpg_ramnet_amd.model.submodules import ResidualBlock
     torch.manual_seed(4)
     m = ResidualBlock(C, C)
@@ -113,7 +166,7 @@ def test_residual_block(B, H, W, C):
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256), (1, 16, 32, 128)])
-def test_conv_gru(B, H, W, C):
+def test_conv_gru(B, H, W, C, algo3x3):
     from rpg_ramnet_amd.model.submodules import ConvGRU
     torch.manual_seed(5)
     m = ConvGRU(C, C, 3)
