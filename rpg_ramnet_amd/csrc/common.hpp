@@ -214,6 +214,38 @@ struct PatchRegs {
         }
     }
 
+    // value of slot i after mask / product / zero padding
+    __device__ __forceinline__ float4 value(const InSrc &s, int i) const {
+        float4 r = v[i];
+        if ((mmask >> i) & 1u) {
+            if (s.mode == RAMNET_IN_RELUMASK)
+                r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
+            else
+                r = f4mul(r, m[i]);
+        }
+        if (!((okmask >> i) & 1u)) r = f4zero();
+        return r;
+    }
+
+    // channel-pair planes: patch[pair][row][ROWF] (2 floats per pixel), planes PS floats apart — the layout whose
+    // b64 reads by (tile, channel pair) lanes are bank-conflict free (conv_wino.hip)
+    template <int ROWF, int PS>
+    __device__ __forceinline__ void store_planes(float *__restrict__ patch, const InSrc &s, int PH, int PW, int tid) const {
+        const int nslots = PH * PW * QPP;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sl = tid + i * NT;
+            const float4 r = value(s, i);
+            const int pix = sl / QPP, qd = sl - pix * QPP;
+            const int py = pix / PW, px = pix - py * PW;
+            if (sl < nslots) {
+                float *d = patch + (2 * qd) * PS + py * ROWF + px * 2;
+                *reinterpret_cast<float2 *>(d) = make_float2(r.x, r.y);
+                *reinterpret_cast<float2 *>(d + PS) = make_float2(r.z, r.w);
+            }
+        }
+    }
+
     template <int LDX>
     __device__ __forceinline__ void store(float *__restrict__ patch, const InSrc &s, int PH, int PW, int tid) const {
         const int nslots = PH * PW * QPP;

@@ -5,13 +5,13 @@
 //
 // A workgroup (4 waves) owns 8 x 16 output pixels = 4 x 8 Winograd tiles and 64 output channels.  For every chunk of 8
 // input channels it stages the 10 x 18 input patch once (same fused loaders as the direct kernel: concatenation, the
-// GRU's h*r product, the ReLU mask of the backward pass), transforms it to V[16 positions][32 tiles][8] in LDS, copies
-// the pre-transformed weights U[16][64][8] (packed by ramnet_pack_weight_wino, LDS image = global image) and runs the 16
-// independent [32 tiles x 8] x [8 x 64] products.  Each wave keeps ALL 16 positions of its 16 tiles x 32 channels in
-// registers (16 x 2 accumulators of the 16x16 MFMA = 128 VGPRs), so the output transform A^T M A is register-local and
-// the fused epilogues (bias / ReLU / sigmoid / residual / GRU blend) run straight from it.
-// Global loads run one chunk ahead in registers; LDS fills and the input transform of chunk i+1 are issued under the
-// MFMAs of chunk i (two barriers per chunk, see the pipeline comment in the kernel).
+// GRU's h*r product, the ReLU mask of the backward pass) and transforms it to V[16 positions][32 tiles][8] in LDS — the
+// transformed INPUT is what the four waves share.  A weight tile is consumed by exactly one wave, so the waves split the
+// 64 channels (16 each) and load their B operand U[pos][16 channels][8] from global memory (L2-resident, 1 KB coalesced
+// per wave-load) directly in the lane layout of the MFMA, one chunk ahead, into a register ring: no weight traffic
+// through LDS.  Each wave keeps ALL 16 positions of its 32 tiles x 16 channels in registers (16 x 2 accumulators of the
+// 16x16 MFMA = 128 VGPRs), so the output transform A^T M A is register-local and the fused epilogues (bias / ReLU /
+// sigmoid / residual / GRU blend) run straight from it.  One barrier per chunk (V and the patch are double-buffered).
 #include <stdlib.h>
 #include "common.hpp"
 #include "conv_epilogue.hpp"
@@ -24,7 +24,7 @@ constexpr int WK = 8;                         // input channels per chunk
 constexpr int WBN = 64;                       // output channels per workgroup
 constexpr int WTH = 8, WTW = 16;              // output pixels per workgroup (4 x 8 tiles of 2 x 2)
 constexpr int WPH = WTH + 2, WPW = WTW + 2;   // input patch
-constexpr int WU_FLOATS = 16 * WBN * WK;      // 32 KB
+constexpr int WU_FLOATS = 16 * WBN * WK;      // weights of one (chunk, 64-channel block): 32 KB
 constexpr int WV_FLOATS = 16 * 32 * WK;       // 16 KB
 constexpr int WP_FLOATS = WPH * WPW * WK;     // 5.6 KB
 
@@ -37,15 +37,81 @@ struct WinoParams {
 
 __device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
+#ifdef WINO_TRACE   // tools/wino_trace.hip: per-wave timestamps at the phase boundaries of the main loop
+__device__ unsigned long long *g_wino_trace;
+#define WINO_STAMP(slot)                                                                                     \
+    do {                                                                                                     \
+        if (lane == 0 && chunk < 32)                                                                         \
+            g_wino_trace[(((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 32 + chunk) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define WINO_STAMP(slot)
+#endif
+
+// Patch prefetcher of the Winograd kernel.  Everything that does not depend on the chunk (pixel offsets of the thread's
+// two slots in each source tensor, in-image flags) is computed once; per chunk the source selection of the concatenated
+// input is wave-uniform (C0 % 8 == 0 is required), so a load is a scalar base plus a per-thread 32-bit offset and the
+// whole prefetch costs a dozen vector instructions — the main loop has no cycles to spare next to its 32-cycle MFMAs.
+struct WinoPatch {
+    float4 v[2], m[2];
+    unsigned off0[2], off1[2], offm[2];   // float offsets of (pixel, quad) in x0 / x1 / xm
+    int cmax[2];                          // channels c0 < cmax are valid for the slot (-1: outside the image / no slot)
+    int ldst[2];                          // LDS float offset of the slot, or -1
+
+    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = tid + i * 256;
+            const int pix = sl >> 1, qd = sl & 1;
+            const int py = pix / WPW, px = pix - py * WPW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool slot = sl < WPH * WPW * 2;
+            const bool in = slot && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
+            const unsigned gp = in ? (unsigned)((b * s.Hin + iy) * s.Win + ix) : 0u;
+            off0[i] = gp * s.ld0 + qd * 4, off1[i] = gp * s.ld1 + qd * 4, offm[i] = gp * s.ldm + qd * 4;
+            cmax[i] = in ? s.Cin - qd * 4 : -1;
+            ldst[i] = slot ? sl * 4 : -1;
+        }
+    }
+    // issue the global loads of slot i for the 8 channels starting at c0 (wave-uniform)
+    __device__ __forceinline__ void load_slot(const InSrc &s, int c0, int i) {
+        const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;     // uniform
+        const float *base = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
+        const bool hasm = s.mode == RAMNET_IN_RELUMASK || (s.mode == RAMNET_IN_CAT_MUL && second);      // uniform
+        const float *mbase = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
+        const bool ok = c0 < cmax[i];
+        const unsigned o = ok ? (second ? off1[i] : off0[i]) : 0u;
+        v[i] = ld4((ok ? base : s.x0) + o);
+        if (hasm) m[i] = ld4((ok ? mbase : s.x0) + (ok ? offm[i] : 0u));
+    }
+    __device__ __forceinline__ void load(const InSrc &s, int c0) { load_slot(s, c0, 0), load_slot(s, c0, 1); }
+    // registers of slot i (loaded for channel c0) -> LDS patch [pixel][8]
+    __device__ __forceinline__ void store_slot(float *__restrict__ patch, const InSrc &s, int c0, int i) const {
+        const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;
+        const bool hasm = s.mode == RAMNET_IN_RELUMASK || (s.mode == RAMNET_IN_CAT_MUL && second);
+        float4 r = v[i];
+        if (hasm) {
+            if (s.mode == RAMNET_IN_RELUMASK)
+                r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
+            else
+                r = f4mul(r, m[i]);
+        }
+        if (!(c0 < cmax[i])) r = f4zero();
+        if (ldst[i] >= 0) st4(patch + ldst[i], r);
+    }
+    __device__ __forceinline__ void store(float *__restrict__ patch, const InSrc &s, int c0) const { store_slot(patch, s, c0, 0), store_slot(patch, s, c0, 1); }
+};
+
+// Pipeline, ONE barrier per chunk:
+//   during the MFMAs of chunk i:  patch(i+1) [LDS, stored during chunk i-1] -> V[(i+1)&1];  registers -> patch(i+2);
+//                                 global loads of patch(i+3) and of U(i+1).
 __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_desc p, const WinoParams q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *U = smem;                  // [16][64][8]  (row n: channel c at c ^ 4*((n>>3)&1))
-    float *V = U + WU_FLOATS;         // [2][16][32][8]  (row t: same swizzle), double-buffered
-    float *patch = V + 2 * WV_FLOATS; // [10][18][8]
+    float *V = smem;                      // [2][16][32][8]
+    float *patch = V + 2 * WV_FLOATS;     // [2][10][18][8]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, ks = lane >> 4;
 
     int bid = blockIdx.x;
@@ -57,10 +123,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
     const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
     const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
 
-    // MFMA operand addresses: lane supplies row (l&15), k-slot (l>>4) = channels 2*ks, 2*ks+1 of the chunk
     const int swz = 4 * ((l15 >> 3) & 1);
-    const int aoff = (wm * 16 + l15) * WK + ((ks * 2) ^ swz);
-    const int boff = (wn * 32 + l15) * WK + ((ks * 2) ^ swz);
+    const int aoff = l15 * WK + ((ks * 2) ^ swz);                       // A fragment 0; fragment 1 is 16 rows further
+    // weights: [chunk][block64][position pair 8][n 64][k-slot 4][2 positions][2 channels] -> one 16-byte load per pair
+    const float *wsrc = p.w + (size_t)blockIdx.y * WU_FLOATS + (wave * 16 + l15) * 16 + ks * 4;
+    const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -68,100 +135,114 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
 #pragma unroll
         for (int f = 0; f < 2; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // input-transform role of this thread: row i of B^T d B for (tile, channel quad)
-    const int ti = wave;                                 // 0..3 (wave-uniform)
+    const int ti = wave;
     const int tq = tid & 1, tt = (tid >> 1) & 31;
     const int tty = tt >> 3, ttx = tt & 7;
-    const int ra = ti == 0 ? 0 : (ti == 2 ? 2 : 1);     // rows combined: i0: d0-d2, i1: d1+d2, i2: d2-d1, i3: d1-d3
+    const int ra = ti == 0 ? 0 : (ti == 2 ? 2 : 1);
     const int rb = ti == 0 ? 2 : (ti == 1 ? 2 : (ti == 2 ? 1 : 3));
     const float sb = ti == 1 ? 1.f : -1.f;
-    const float *pra = patch + ((2 * tty + ra) * WPW + 2 * ttx) * WK + tq * 4;
-    const float *prb = patch + ((2 * tty + rb) * WPW + 2 * ttx) * WK + tq * 4;
+    const int pra = ((2 * tty + ra) * WPW + 2 * ttx) * WK + tq * 4;
+    const int prb = ((2 * tty + rb) * WPW + 2 * ttx) * WK + tq * 4;
     const int vdst = (ti * 4) * (32 * WK) + tt * WK + ((tq ^ ((tt >> 3) & 1)) * 4);
 
-    PatchRegs<WK / 4, 2, 256> pr;
-    float4 ulo[4], uhi[4];                         // weights of positions 0-7 / 8-15 in flight
-    auto load_u = [&](float4 (&r)[4], int chunk, int half) {
-        const float *src = p.w + ((size_t)chunk * q.nblk + blockIdx.y) * WU_FLOATS + half * (WU_FLOATS / 2) + tid * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = ld4(src + i * 1024);
+    WinoPatch pr;
+    pr.init(q.src, b, iy0, ix0, tid);
+    float4 breg[8];                                 // weights of the current chunk (position pairs); refilled with chunk+1 once used
+    // input transform of (tile tt, channel quad tq), row `ti` of B^T d B, in pieces small enough to be issued between
+    // two MFMAs: 8 LDS reads -> te[c] = d[ra][c] +- d[rb][c] -> 4 column combinations -> 4 LDS writes
+    float4 tx[4], ty[4], te[4];
+    auto tr_read = [&](const float *pb, int c) { tx[c] = ld4(pb + pra + c * WK), ty[c] = ld4(pb + prb + c * WK); };
+    auto tr_row = [&](int c) { te[c] = make_float4(tx[c].x + sb * ty[c].x, tx[c].y + sb * ty[c].y, tx[c].z + sb * ty[c].z, tx[c].w + sb * ty[c].w); };
+    auto tr_col = [&](float *vbuf, int j) {
+        float4 r;
+        if (j == 0) r = make_float4(te[0].x - te[2].x, te[0].y - te[2].y, te[0].z - te[2].z, te[0].w - te[2].w);
+        if (j == 1) r = f4add(te[1], te[2]);
+        if (j == 2) r = make_float4(te[2].x - te[1].x, te[2].y - te[1].y, te[2].z - te[1].z, te[2].w - te[1].w);
+        if (j == 3) r = make_float4(te[1].x - te[3].x, te[1].y - te[3].y, te[1].z - te[3].z, te[1].w - te[3].w);
+        st4(vbuf + vdst + j * (32 * WK), r);
     };
-    auto store_u = [&](const float4 (&r)[4], int half) {
+    auto transform = [&](const float *pb, float *vbuf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st4(U + half * (WU_FLOATS / 2) + tid * 4 + i * 1024, r[i]);
-    };
-    auto transform = [&](float *vbuf) {            // patch -> row `ti` of B^T d B of (tile tt, channel quad tq)
-        float4 e[4];
+        for (int c = 0; c < 4; ++c) tr_read(pb, c);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 x = ld4(pra + c * WK), y = ld4(prb + c * WK);
-            e[c] = make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w);
-        }
-        const float4 v0 = make_float4(e[0].x - e[2].x, e[0].y - e[2].y, e[0].z - e[2].z, e[0].w - e[2].w);
-        const float4 v1 = f4add(e[1], e[2]);
-        const float4 v2 = make_float4(e[2].x - e[1].x, e[2].y - e[1].y, e[2].z - e[1].z, e[2].w - e[1].w);
-        const float4 v3 = make_float4(e[1].x - e[3].x, e[1].y - e[3].y, e[1].z - e[3].z, e[1].w - e[3].w);
-        st4(vbuf + vdst, v0);
-        st4(vbuf + vdst + 32 * WK, v1);
-        st4(vbuf + vdst + 2 * 32 * WK, v2);
-        st4(vbuf + vdst + 3 * 32 * WK, v3);
-    };
-    auto mma = [&](const float *vbuf, int pos0) {  // 8 of the 16 positions
+        for (int c = 0; c < 4; ++c) tr_row(c);
 #pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int pos = pos0 + pp;
-            const float2 a = ld2(vbuf + pos * (32 * WK) + aoff);
-            const float2 b0 = ld2(U + pos * (WBN * WK) + boff);
-            const float2 b1 = ld2(U + pos * (WBN * WK) + boff + 16 * WK);
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[pos][0], 0, 0, 0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[pos][1], 0, 0, 0);
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[pos][0], 0, 0, 0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[pos][1], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) tr_col(vbuf, j);
     };
 
-    // Two-phase software pipeline, two barriers per chunk, every LDS fill under the MFMAs of the other half:
-    //   phase 1 (positions 0-7 of chunk i):  U_hi(i) and patch(i+1) are written   (their readers finished at barrier X)
-    //   phase 2 (positions 8-15 of chunk i): patch(i+1) -> V[(i+1)&1], U_lo(i+1) written  (readers finished at barrier Y)
-    // Global loads are issued one full iteration before the registers are stored to LDS.
     const int nch = q.nchunks;
-    pr.load(q.src, b, iy0, ix0, 0, WPH, WPW, tid);
-    load_u(ulo, 0, 0);
-    load_u(uhi, 0, 1);
-    pr.store<WK>(patch, q.src, WPH, WPW, tid);
+    // prologue: patch(0) -> V[0];  patch(1) -> LDS;  patch(2) and U(0) in registers
+    const int clast = (nch - 1) * WK;
+    { const int chunk = 0; WINO_STAMP(2); }
+    pr.load(q.src, 0);
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) breg[pp] = ld4(wsrc + pp * 1024);
+    pr.store(patch, q.src, 0);
+    pr.load(q.src, min(WK, clast));
     __syncthreads();
-    transform(V);
-    store_u(ulo, 0);
-    if (nch > 1) {
-        pr.load(q.src, b, iy0, ix0, WK, WPH, WPW, tid);
-        load_u(ulo, 1, 0);
-    }
-    __syncthreads();                               // barrier X_0
+    transform(patch, V);
+    pr.store(patch + WP_FLOATS, q.src, min(WK, clast));
+    pr.load(q.src, min(2 * WK, clast));
+    __syncthreads();
+    // The loop body is branch-free (loads past the last chunk are clamped to it; the fills they feed go to buffers nobody
+    // reads any more) and hand-interleaved: a 16x16x4 MFMA occupies the matrix pipe for 32 cycles and the wave issues in
+    // order, so work placed behind a GROUP of MFMAs only overlaps the last one.  Each MFMA is therefore followed by its
+    // own small slice of the side work: weight reload, A-operand fetch, and pieces s0/s1 of transform / patch traffic.
     for (int chunk = 0; chunk < nch; ++chunk) {
         const float *vcur = V + (chunk & 1) * WV_FLOATS;
         float *vnext = V + ((chunk + 1) & 1) * WV_FLOATS;
-        store_u(uhi, 1);
-        if (chunk + 1 < nch) {
-            pr.store<WK>(patch, q.src, WPH, WPW, tid);
-            load_u(uhi, chunk + 1, 1);
-            if (chunk + 2 < nch) pr.load(q.src, b, iy0, ix0, (chunk + 2) * WK, WPH, WPW, tid);
+        const float *pnext = patch + ((chunk + 1) & 1) * WP_FLOATS;     // holds patch(i+1)
+        float *pfree = patch + (chunk & 1) * WP_FLOATS;                 // patch(i): transformed long ago -> patch(i+2)
+        const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
+        const int c2 = min((chunk + 2) * WK, clast), c3 = min((chunk + 3) * WK, clast);
+        WINO_STAMP(0);
+        float2 aq[4][2];                            // A operands, ring over positions (filled two positions ahead)
+        aq[0][0] = ld2(vcur + aoff), aq[0][1] = ld2(vcur + aoff + 16 * WK);
+        aq[1][0] = ld2(vcur + 32 * WK + aoff), aq[1][1] = ld2(vcur + 32 * WK + aoff + 16 * WK);
+        auto side = [&](int pos, int sub) {         // (pos, sub) are compile-time constants after unrolling
+            const int k = pos * 2 + sub;
+            if (k < 4) tr_read(pnext, k);
+            else if (k < 8) tr_row(k - 4);
+            else if (k < 12) tr_col(vnext, k - 8);
+            else if (k < 14) pr.store_slot(pfree, q.src, c2, k - 12);
+            else if (k < 16) pr.load_slot(q.src, c3, k - 14);
+        };
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            const float2 bb = (pos & 1) ? make_float2(breg[pos >> 1].z, breg[pos >> 1].w) : make_float2(breg[pos >> 1].x, breg[pos >> 1].y);
+            const float2 a0 = aq[pos & 3][0], a1 = aq[pos & 3][1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bb.x, acc[pos][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pos >= 2 && !(pos & 1)) breg[(pos >> 1) - 1] = ld4(wnext + ((pos >> 1) - 1) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bb.x, acc[pos][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pos + 2 < 16) {
+                aq[(pos + 2) & 3][0] = ld2(vcur + (pos + 2) * (32 * WK) + aoff);
+                aq[(pos + 2) & 3][1] = ld2(vcur + (pos + 2) * (32 * WK) + aoff + 16 * WK);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bb.y, acc[pos][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            side(pos, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bb.y, acc[pos][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            side(pos, 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        mma(vcur, 0);
-        __syncthreads();                           // barrier Y: U_hi(i), patch(i+1) visible; U_lo(i) free
-        if (chunk + 1 < nch) {
-            transform(vnext);
-            store_u(ulo, 0);
-            if (chunk + 2 < nch) load_u(ulo, chunk + 2, 0);
-        }
-        mma(vcur, 8);
-        __syncthreads();                           // barrier X: V(i+1), U_lo(i+1) visible; U_hi(i), V(i), patch free
+        breg[7] = ld4(wnext + 7 * 1024);
+        WINO_STAMP(1);
+        __syncthreads();                           // V(i+1), patch(i+2) visible; V(i), patch(i+1) free
     }
 
+    { const int chunk = 31; WINO_STAMP(2); }
     // ---- output transform + epilogue.  D of the 16x16 MFMA: col = lane&15 (channel), row = 4*(lane>>4) + r (tile)
     const int epi = p.epi;
+    const int n = n0 + wave * 16 + l15;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        const int n = n0 + wn * 32 + f * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float t[4][2];
@@ -177,7 +258,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
                 y[0][c] = t[0][c] + t[1][c] + t[2][c];
                 y[1][c] = t[1][c] - t[2][c] - t[3][c];
             }
-            const int tile = wm * 16 + 4 * ks + r;
+            const int tile = f * 16 + 4 * ks + r;
             const int ty = tile >> 3, tx = tile & 7;
             if (n >= p.Cout) continue;
 #pragma unroll
@@ -191,21 +272,23 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
                 }
         }
     }
+    { const int chunk = 31; WINO_STAMP(3); }
 }
 
-// OIHW 3x3 -> U = G g G^T in the kernel's LDS image [chunk8][block64][pos 16][64][8 swizzled]; evaluated in double.
+// OIHW 3x3 -> U = G g G^T in the lane order of the kernel's B operand (see wsrc above); evaluated in double.
 __global__ void pack_weight_wino_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
                                         int R, int N, int nchunks, int nblk, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cphys = (int)(i % WK);
-        size_t j = i / WK;
+        // i = ((((chunk * nblk + nb) * 8 + pp) * 64 + n) * 4 + ks) * 4 + (pos & 1) * 2 + (c & 1),  c = 2 * ks + (c & 1)
+        const int cl = (int)(i & 1), p1 = (int)((i >> 1) & 1), ksl = (int)((i >> 2) & 3);
+        size_t j = i >> 4;
         const int n = (int)(j % WBN);
         j /= WBN;
-        const int pos = (int)(j % 16);
-        j /= 16;
+        const int pos = (int)(j % 8) * 2 + p1;
+        j /= 8;
         const int nb = (int)(j % nblk);
         const int chunk = (int)(j / nblk);
-        const int c = cphys ^ (4 * ((n >> 3) & 1));
+        const int c = 2 * ksl + cl;
         const int r = chunk * WK + c, no = nb * WBN + n;
         float v = 0.f;
         if (r < R && no < N) {
@@ -235,6 +318,7 @@ static void wino_geometry(int Cout, int Cin, int transposed, int &R, int &N, int
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && d.precision == RAMNET_PREC_F32 && d.epi != RAMNET_EPI_LSTM);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
+    if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
     // the taps must be the dense 3x3 window; which weight slice each one reads is baked into the Winograd pack
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
@@ -257,12 +341,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
     q.dy0 = dymin, q.dx0 = dxmin;
-    const size_t lds = (size_t)(WU_FLOATS + 2 * WV_FLOATS + WP_FLOATS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     dim3 grid(q.tiles_x * q.tiles_y * d.B, q.nblk);
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();

@@ -129,7 +129,8 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.algo = H.ALGO_DIRECT
     if isinstance(w, PackRef):
         wino = (_WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1 and w.cp.gates == 1
-                and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP) and d.C0 + C1 >= _WINO_MIN_CIN)
+                and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP) and d.C0 + C1 >= _WINO_MIN_CIN
+                and (C1 == 0 or d.C0 % 8 == 0))
         d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
         w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
