@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 2
+#define RAMNET_ABI_VERSION 3
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -93,8 +93,10 @@ typedef struct ramnet_wgrad_desc {
     const float *dout, *gmask;      /* gradient wrt the layer's pre-activation output (+ ReLU mask)  */
     int ldg, ldgm;
     int Cout, Ho, Wo;
-    float *dw;                      /* [ntaps][Cin][Cout] accumulation workspace                    */
+    float *dw;                      /* [ntaps][Cin][Cout] accumulation workspace ([16][Cin][Cout] for WINOGRAD) */
     float *dbias;                   /* [Cout] or NULL                                               */
+    int algo;                       /* RAMNET_ALGO_DIRECT, or RAMNET_ALGO_WINOGRAD: dense 3x3 stride-1 taps in kh*3+kw order; dw then
+                                     * accumulates the transformed-domain gradient dU, folded by ramnet_unpack_wgrad_wino() */
 } ramnet_wgrad_desc;
 
 const char *ramnet_last_error(void);
@@ -122,6 +124,10 @@ int ramnet_pack_weight(const float *w_oihw, float *wp, int Cout, int Cin, int KH
  * (CoutWs/n_off: fused launches such as the GRU's update|reset gates share one workspace.)        */
 int ramnet_unpack_wgrad(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
                         int KH, int KW, void *stream);
+
+/* Winograd backward-weights workspace [16][CinWs][CoutWs] (dU) -> OIHW 3x3: grad += G^T dU G.                 */
+int ramnet_unpack_wgrad_wino(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
+                             void *stream);
 
 /* ---- the two MFMA kernels ----------------------------------------------------------------------- */
 int ramnet_conv_launch(const ramnet_conv_desc *d, void *stream);    /* forward and backward-data   */

@@ -48,6 +48,7 @@ class WgradDesc(C.Structure):
         ("dout", _fp), ("gmask", _fp), ("ldg", C.c_int), ("ldgm", C.c_int),
         ("Cout", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("dw", _fp), ("dbias", _fp),
+        ("algo", C.c_int),
     ]
 
 
@@ -62,6 +63,7 @@ _SIGS = {
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 3),
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
+    "ramnet_unpack_wgrad_wino": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ramnet_conv_launch_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _fp]),
     "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),
@@ -111,7 +113,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 2:
+        if l.ramnet_abi_version() != 3:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

@@ -200,6 +200,8 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
     if (d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK) RAMNET_CHECK_ARG(d.xm && d.ldm % 4 == 0);
     if (d.in_mode == RAMNET_IN_UP2X_SKIP) RAMNET_CHECK_ARG(d.x1 && d.ld1 % 4 == 0);
     if (d.gmask) RAMNET_CHECK_ARG(d.ldgm % 4 == 0);
+    if (d.algo == RAMNET_ALGO_WINOGRAD) return launch_wgrad_wino(d, (hipStream_t)stream);
+    RAMNET_CHECK_ARG(d.algo == RAMNET_ALGO_DIRECT);
 
     WgradDerived q;
     q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;

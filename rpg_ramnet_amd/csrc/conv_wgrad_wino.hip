@@ -1,0 +1,299 @@
+// Winograd F(2x2, 3x3) backward-weights for gfx950 (MI355X): the 3x3 stride-1 layers of the RAM-Net path (ConvGRU gates /
+// candidate, residual blocks), exact-fp32 arithmetic on v_mfma_f32_32x32x2_f32.
+//
+//   y = A^T [ (G g G^T) .* (B^T d B) ] A   =>   dU_p[ci][co] = sum_tiles V_p[tile][ci] * Z_p[tile][co],   V = B^T d B,
+//   Z = A dy A^T (the 2x2 output-gradient tile spread to 4x4),   dg = G^T dU G  (ramnet_unpack_wgrad_wino).
+//
+// 16 independent GEMMs, M = input channel, N = output channel, K = Winograd tiles: 16 MACs per tile and channel pair
+// instead of the 36 of the direct form (2.25x fewer MFMAs).  A workgroup owns 32 input x 64 output channels and walks
+// batches of 8 tiles (one 2 x 16 pixel strip of the output).  Per batch it stages the raw 4 x 18 input patch (same fused
+// loaders as everywhere: concatenation, h*r, ReLU mask) and the 2 x 16 gradient strip, transforms both into LDS with the
+// tile index innermost — V[16][32][8], Z[16][64][8], so that one 16-byte LDS read feeds four K = 2 MFMAs — and wave
+// (position half, channel half) accumulates 8 positions x (32 x 32) in registers (128 VGPRs) over its whole tile range.
+// Partial sums of the tile splits meet in a [16][Cin][Cout] fp32 workspace through coalesced atomic adds; the bias
+// gradient (sum of dy) rides along.  Raw data of batch i+1 is written to LDS, and batch i+2 is requested from memory,
+// between the MFMAs of batch i.
+#include <stdlib.h>
+#include "common.hpp"
+
+namespace ramnet {
+
+constexpr int GW_CI = 32, GW_CO = 64;          // channels per workgroup
+constexpr int GW_T = 8;                        // tiles per batch (2 x 16 output pixels)
+constexpr int GW_LDX = 36, GW_LDY = 68;        // padded raw-patch rows (floats): (2 pixels) * LD == 8 (mod 64) -> conflict-free
+constexpr int GW_XPIX = 4 * 18, GW_YPIX = 2 * 16;
+constexpr int GW_V = 16 * GW_CI * GW_T;        // 4096 floats
+constexpr int GW_Z = 16 * GW_CO * GW_T;        // 8192 floats
+constexpr int GW_XP = GW_XPIX * GW_LDX;        // 2592
+constexpr int GW_YP = GW_YPIX * GW_LDY;        // 2176
+
+struct WgradWinoParams {
+    InSrc src;
+    int bx_n, ty_n, nbatch;     // batches per row, tile rows per image, total
+    int dy0, dx0;               // offset of the first filter tap
+};
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *V = smem;              // [16][32][8]
+    float *Z = V + GW_V;          // [16][64][8]
+    float *Xp = Z + GW_Z;         // [4][18][36]
+    float *Yp = Xp + GW_XP;       // [2][16][68]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int ch = wave & 1, ph = wave >> 1;            // output-channel half, position half
+    const int c0 = blockIdx.y * GW_CI, n0 = blockIdx.z * GW_CO;
+    const InSrc &s = q.src;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- raw-data prefetch registers
+    float4 xr[3], xm[3], yr[2], ym[2];
+    unsigned xok = 0, yok = 0;
+    const bool two = s.mode == RAMNET_IN_CAT_MUL || s.mode == RAMNET_IN_RELUMASK;
+    auto load_raw = [&](int batch) {
+        int tt = batch;
+        const int bx = tt % q.bx_n;
+        tt /= q.bx_n;
+        const int ty = tt % q.ty_n;
+        const int b = tt / q.ty_n;
+        const int iy0 = 2 * ty + q.dy0, ix0 = 16 * bx + q.dx0;
+        xok = 0, yok = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int sl = tid + i * 256;
+            const int qd = sl & 7, pix = sl >> 3;
+            const int py = pix / 18, px = pix - py * 18;
+            const int iy = iy0 + py, ix = ix0 + px, c = c0 + qd * 4;
+            const bool ok = sl < GW_XPIX * 8 && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win && c < s.Cin;
+            const size_t gp = ((size_t)b * s.Hin + iy) * s.Win + ix;
+            const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c >= s.C0;
+            const float *p0 = second ? s.x1 + gp * s.ld1 + (c - s.C0) : s.x0 + gp * s.ld0 + c;
+            const bool hm = two && (s.mode == RAMNET_IN_RELUMASK || second);
+            const float *p1 = s.mode == RAMNET_IN_RELUMASK ? s.xm + gp * s.ldm + c : s.xm + gp * s.ldm + (c - s.C0);
+            xr[i] = ld4(ok ? p0 : s.x0);
+            xm[i] = two ? ld4(ok && hm ? p1 : s.x0) : f4zero();
+            xok |= (ok ? 1u : 0u) << i;
+            xok |= (hm ? 1u : 0u) << (8 + i);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = tid + i * 256;
+            const int qd = sl & 15, pix = sl >> 4;
+            const int oy = 2 * ty + (pix >> 4), ox = 16 * bx + (pix & 15), n = n0 + qd * 4;
+            const bool ok = oy < p.Ho && ox < p.Wo && n < p.Cout;
+            const size_t gp = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+            yr[i] = ld4(ok ? p.dout + gp * p.ldg + n : p.dout);
+            if (p.gmask) ym[i] = ld4(ok ? p.gmask + gp * p.ldgm + n : p.gmask);
+            yok |= (ok ? 1u : 0u) << i;
+        }
+    };
+    float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
+    auto store_x = [&](int i) {
+        const int sl = tid + i * 256;
+        float4 r = xr[i];
+        if ((xok >> (8 + i)) & 1u) {
+            if (s.mode == RAMNET_IN_RELUMASK)
+                r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
+            else
+                r = f4mul(r, xm[i]);
+        }
+        if (!((xok >> i) & 1u)) r = f4zero();
+        if (sl < GW_XPIX * 8) st4(Xp + (sl >> 3) * GW_LDX + (sl & 7) * 4, r);
+    };
+    auto store_y = [&](int i) {
+        const int sl = tid + i * 256;
+        float4 r = yr[i];
+        if (p.gmask) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
+        if (!((yok >> i) & 1u)) r = f4zero();
+        st4(Yp + (sl >> 4) * GW_LDY + (sl & 15) * 4, r);
+        bsum = f4add(bsum, r);
+    };
+
+    // ---- transforms: thread = (tile tid&7, channel tid>>3 [+32 for the second Z item])
+    const int tt8 = tid & 7, tc = tid >> 3;
+    auto transform = [&]() {
+        {   // V = B^T d B of the 4x4 input window of (tile, input channel)
+            float d[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[r][c] = Xp[(r * 18 + 2 * tt8 + c) * GW_LDX + tc];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float e0 = d[0][c] - d[2][c], e1 = d[1][c] + d[2][c], e2 = d[2][c] - d[1][c], e3 = d[1][c] - d[3][c];
+                d[0][c] = e0, d[1][c] = e1, d[2][c] = e2, d[3][c] = e3;
+            }
+            float *dst = V + tc * GW_T + tt8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[(i * 4 + 0) * (GW_CI * GW_T)] = d[i][0] - d[i][2];
+                dst[(i * 4 + 1) * (GW_CI * GW_T)] = d[i][1] + d[i][2];
+                dst[(i * 4 + 2) * (GW_CI * GW_T)] = d[i][2] - d[i][1];
+                dst[(i * 4 + 3) * (GW_CI * GW_T)] = d[i][1] - d[i][3];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {   // Z = A dy A^T of the 2x2 gradient tile of (tile, output channel)
+            const int co = tc + 32 * k;
+            const float g00 = Yp[(2 * tt8) * GW_LDY + co], g01 = Yp[(2 * tt8 + 1) * GW_LDY + co];
+            const float g10 = Yp[(16 + 2 * tt8) * GW_LDY + co], g11 = Yp[(16 + 2 * tt8 + 1) * GW_LDY + co];
+            // rows of A dy: (g0*, g0* + g1*, g0* - g1*, -g1*)
+            const float w[4][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g00 - g10, g01 - g11}, {-g10, -g11}};
+            float *dst = Z + co * GW_T + tt8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[(i * 4 + 0) * (GW_CO * GW_T)] = w[i][0];
+                dst[(i * 4 + 1) * (GW_CO * GW_T)] = w[i][0] + w[i][1];
+                dst[(i * 4 + 2) * (GW_CO * GW_T)] = w[i][0] - w[i][1];
+                dst[(i * 4 + 3) * (GW_CO * GW_T)] = -w[i][1];
+            }
+        }
+    };
+
+    const int aoff = (ph * 8 * GW_CI + l31) * GW_T + kk * 4;
+    const int boff = (ph * 8 * GW_CO + ch * 32 + l31) * GW_T + kk * 4;
+
+    // ---- pipeline: batch list of this workgroup = blockIdx.x, +gridDim.x, ...
+    int batch = blockIdx.x;
+    const int step = gridDim.x;
+    if (batch < q.nbatch) {
+        load_raw(batch);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) store_x(i);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) store_y(i);
+        if (batch + step < q.nbatch) load_raw(batch + step);
+        __syncthreads();
+        transform();
+        __syncthreads();
+    }
+    for (; batch < q.nbatch; batch += step) {
+        const bool more = batch + step < q.nbatch, more2 = batch + 2 * step < q.nbatch;
+        float4 a = ld4(V + aoff), bv = ld4(Z + boff);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            float4 an, bn;
+            if (pp + 1 < 8) an = ld4(V + aoff + (pp + 1) * (GW_CI * GW_T)), bn = ld4(Z + boff + (pp + 1) * (GW_CO * GW_T));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[pp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // raw data of the next batch -> LDS (its readers, transform(i), finished before the last barrier)
+            if (more) {
+                if (pp < 3) store_x(pp);
+                else if (pp < 5) store_y(pp - 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[pp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp + 1 < 8) a = an, bv = bn;
+        }
+        if (more2) load_raw(batch + 2 * step);
+        __syncthreads();                 // V, Z free; raw patch of the next batch visible
+        if (more) transform();
+        __syncthreads();                 // V, Z of the next batch visible; raw patch free
+    }
+
+    // D[row = input channel][col = output channel] of position ph*8 + pp -> ws[(pos*Cin + c)*Cout + n]
+    const int Cin = s.Cin;
+    const int n = n0 + ch * 32 + l31;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)(ph * 8 + pp) * Cin + c) * p.Cout + n, acc[pp][r]);
+        }
+    }
+    if (p.dbias != nullptr && blockIdx.y == 0) {
+        __syncthreads();
+        float *red = smem;                        // [16][64]
+        st4(red + (tid >> 4) * GW_CO + (tid & 15) * 4, bsum);
+        __syncthreads();
+        if (tid < GW_CO) {
+            float t = 0.f;
+            for (int g = 0; g < 16; ++g) t += red[g * GW_CO + tid];
+            if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, t);
+        }
+    }
+}
+
+// ws [16][CinWs][CoutWs] (dU) -> grad OIHW [Cout][Cin][3][3] (+=): dg = G^T dU G
+__global__ void unpack_wgrad_wino_kernel(const float *__restrict__ ws, float *__restrict__ g, int Cout, int Cin, int CinWs, int CoutWs,
+                                         int n_off, size_t total) {
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin), n = (int)(i / Cin);
+        float u[4][4];
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) u[a][b] = ws[((size_t)(a * 4 + b) * CinWs + c) * CoutWs + n_off + n];
+        for (int ka = 0; ka < 3; ++ka)
+            for (int kb = 0; kb < 3; ++kb) {
+                float sum = 0.f;
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) sum += G[a][ka] * u[a][b] * G[b][kb];
+                g[((size_t)n * Cin + c) * 9 + ka * 3 + kb] += sum;
+            }
+    }
+}
+
+int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
+    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1);
+    RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
+    RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win);
+    int dymin = 127, dxmin = 127;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        dymin = d.dy[t] < dymin ? d.dy[t] : dymin;
+        dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin;
+    }
+    for (int t = 0; t < 9; ++t) {   // the workspace rows follow the forward tap order (kh*3 + kw): require exactly that list
+        RAMNET_CHECK_ARG(d.dy[t] - dymin == t / 3 && d.dx[t] - dxmin == t % 3);
+        seen |= 1u << t;
+    }
+    RAMNET_CHECK_ARG(seen == 0x1ffu);
+    const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
+    WgradWinoParams q;
+    q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
+    q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
+    q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
+    q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
+    q.nbatch = q.bx_n * q.ty_n * d.B;
+    q.dy0 = dymin, q.dx0 = dxmin;
+    const size_t lds = (size_t)(GW_V + GW_Z + GW_XP + GW_YP) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int gy = cdiv(q.src.Cin, GW_CI), gz = cdiv(d.Cout, GW_CO);
+    static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
+    int splits = (se ? atoi(se) : 512) / (gy * gz);
+    if (splits > q.nbatch) splits = q.nbatch;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3(splits, gy, gz), dim3(256), lds, st, d, q);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_unpack_wgrad_wino(const float *ws, float *grad, int Cout, int Cin, int CinWs, int CoutWs, int n_off, void *stream) {
+    RAMNET_CHECK_ARG(ws && grad && Cout > 0 && Cin > 0 && CinWs >= Cin && n_off >= 0 && CoutWs >= n_off + Cout);
+    const size_t total = (size_t)Cout * Cin;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(unpack_wgrad_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, grad, Cout, Cin, CinWs, CoutWs, n_off, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}

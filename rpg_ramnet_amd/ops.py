@@ -163,6 +163,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     d.ldg, d.ldgm = ld(dout), (ld(gmask) if gmask is not None else 0)
     d.Cout, d.Ho, d.Wo = Cout, dout.shape[1], dout.shape[2]
     d.dw, d.dbias = _p(dw), _p(dbias)
+    d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
 
 
@@ -307,12 +308,18 @@ class ConvParam:
             self._bias, self._vbias = torch.cat([b.detach() for b in self.biases]).contiguous(), v
         return self._bias
 
-    def grad_ws(self):
-        """([tap][CinWs][Cout] weight-gradient workspace, [Cout] bias-gradient workspace), zero at pass start."""
+    def grad_ws(self, wino_ok=False):
+        """([tap][CinWs][Cout] weight-gradient workspace, [Cout] bias-gradient workspace), zero at pass start.
+        wino_ok: the caller's launch is a plain 3x3 stride-1 convolution (no upsampling loader), i.e. eligible for the
+        Winograd backward-weights kernel, whose workspace holds the transformed-domain gradient [16][CinWs][Cout]."""
         if self._ws is None:
             dev = self.weights[0].device
-            self._ws = torch.zeros(self.k * self.k * self.CinWs * self.Cout, device=dev)
+            slots = 16 if self.k == 3 else self.k * self.k       # 3x3: room for the Winograd-domain gradient dU
+            self._ws = torch.zeros(slots * self.CinWs * self.Cout, device=dev)
             self._bws = torch.zeros(self.Cout, device=dev)
+        if not self._dirty:     # one algorithm per backward pass: every launch of the pass accumulates into the same layout
+            self._ws.wino = bool(wino_ok and _WINOGRAD and _PRECISION == H.PREC_F32 and self.k == 3
+                                 and self.CinWs >= _WINO_MIN_CIN)
         _Engine.mark(self)
         return self._ws, self._bws
 
@@ -321,8 +328,12 @@ class ConvParam:
         for w, b in zip(self.weights, self.biases):
             n = w.shape[0]
             g = ensure_grad(w)
-            H.check(H.lib().ramnet_unpack_wgrad(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off,
-                                                self.k, self.k, _st()), "ramnet_unpack_wgrad")
+            if getattr(self._ws, "wino", False):
+                H.check(H.lib().ramnet_unpack_wgrad_wino(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
+                        "ramnet_unpack_wgrad_wino")
+            else:
+                H.check(H.lib().ramnet_unpack_wgrad(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off,
+                                                    self.k, self.k, _st()), "ramnet_unpack_wgrad")
             if b.shape[0] == n:                        # (transposed conv: bias has Cout_t entries, handled by its op)
                 ensure_grad(b).add_(self._bws[off:off + n])
             off += n
@@ -372,7 +383,7 @@ class ConvAct(Function):
         B, Hh, W, _ = x.shape
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
-        ws, bws = cp.grad_ws()
+        ws, bws = cp.grad_ws(wino_ok=(stride == 1 and k == 3 and pad == 1 and mode == H.IN_PLAIN))
         wgrad_side([x, skip, dy, y], x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
                    Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
         dx = dskip = None
@@ -450,7 +461,7 @@ class ResConv(Function):
         dy = dense(dy)
         dpre = torch.empty_like(y)
         H.check(H.lib().ramnet_relu_bwd(_p(dy.contiguous()), _p(y), _p(dpre), y.numel(), _st()), "ramnet_relu_bwd")
-        ws, bws = cp.grad_ws()
+        ws, bws = cp.grad_ws(wino_ok=True)
         wgrad_side([t, dpre], t, Taps.get("conv", 3, 1), dpre, ws, cp.Cout, dbias=bws)
         dt = torch.empty_like(t, memory_format=torch.contiguous_format)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dt, cp.Cin)
@@ -494,12 +505,12 @@ class GRUCell(Function):
         dhd = torch.empty_like(o)
         H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_a")
         taps, tapsd = Taps.get("conv", 3, 1), Taps.get("dgrad1", 3, 1)
-        ws, bws = cp_o.grad_ws()
+        ws, bws = cp_o.grad_ws(wino_ok=True)
         wgrad_side([x, h, ur, dpo], x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)       # [dx | dh]
         conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
         H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
-        ws, bws = cp_ur.grad_ws()
+        ws, bws = cp_ur.grad_ws(wino_ok=True)
         wgrad_side([x, h, dpur], x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)
         return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None
@@ -537,7 +548,7 @@ class LSTMCell(Function):
         dpre = torch.empty_like(gates)
         dc = torch.empty_like(cn)
         H.check(H.lib().ramnet_lstm_bwd(_p(gates), _p(c), _p(cn), _p(dhn), _p(dcn), _p(dpre), _p(dc), npix, Cc, _st()), "lstm_bwd")
-        ws, bws = cp.grad_ws()
+        ws, bws = cp.grad_ws(wino_ok=True)
         wgrad_side([x, h, dpre], x, Taps.get("conv", 3, 1), dpre, ws, 4 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dxh, 2 * Cc)

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import loss_ref, ramnet_ref, voxel_ref
+from rpg_ramnet_amd import _hip as Hh
 from util import assert_close, load_golden, nchw, nhwc
 
 pytestmark = pytest.mark.gpu
@@ -154,6 +155,38 @@ def test_winograd_conv3x3_raw(B, H, W, cin, cout):
         assert_close(nchw(acc).cpu().numpy(), accref.numpy(), TOL, "dgrad beta winograd=%s" % on)
     # rounding of F(2x2,3x3) in fp32 stays within a few ulp of the direct kernel
     assert_close(outs[True][0].cpu().numpy(), outs[False][0].cpu().numpy(), 2e-5, "winograd vs direct")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (3, 32, 48)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
+def test_winograd_wgrad_raw(B, H, W, cin, cout):
+    """Winograd backward-weights (+bias, + ReLU mask on the gradient) against float64 autograd and the direct kernel."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(12)
+    x = torch.randn(B, cin, H, W)
+    dy = torch.randn(B, cout, H, W)
+    y = torch.randn(B, cout, H, W)                     # forward output whose sign is the ReLU mask
+    g = torch.where(y > 0, dy, torch.zeros_like(dy)).double()
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, bias, 1, 1) * g).sum().backward()
+    xg, dyg, yg = (nhwc(t).to(dev()).contiguous() for t in (x, dy, y))
+    taps = ops.Taps.get("conv", 3, 1)
+    for wino in (True, False):
+        ws = torch.zeros(16 * cin * cout, device=dev())
+        ws.wino = wino
+        bws = torch.zeros(cout, device=dev())
+        for _ in range(2):                              # accumulates over launches (BPTT time steps)
+            ops.wgrad_launch(xg, taps, dyg, ws, cout, gmask=yg, dbias=bws)
+        grad = torch.zeros(cout, cin, 3, 3, device=dev())
+        L = Hh.lib()
+        if wino:
+            Hh.check(L.ramnet_unpack_wgrad_wino(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, ops._st()), "unpack")
+        else:
+            Hh.check(L.ramnet_unpack_wgrad(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, 3, 3, ops._st()), "unpack")
+        assert_close(grad.cpu().numpy(), 2 * w.grad.numpy(), TOL, "dW winograd=%s" % wino)
+        assert_close(bws.cpu().numpy(), 2 * bias.grad.numpy(), TOL, "db winograd=%s" % wino)
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])

@@ -61,7 +61,8 @@ def main():
         cp = ops.ConvParam([wp], [bp], gates=4 if kind == "lstm" else 1)
         taps, tapsd = ops.Taps.get("conv", k, pad), ops.Taps.get("dgrad1", k, pad)
         gfl = 2.0 * B * Ho * Wo * k * k * cin * cout / 1e9
-        ws = torch.zeros(k * k * cin_p * cout, device=dev)
+        ws = torch.zeros((16 if k == 3 else k * k) * cin_p * cout, device=dev)
+        ws.wino = k == 3 and stride == 1 and kind != "up" and ops.get_winograd()      # Winograd backward-weights workspace
         bws = torch.zeros(cout, device=dev)
         if kind == "conv":
             x = torch.randn(B, Hin, Win, cin_p, device=dev)
