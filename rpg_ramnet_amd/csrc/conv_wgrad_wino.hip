@@ -27,12 +27,27 @@ constexpr int GW_Z = 16 * GW_CO * GW_T;        // 8192 floats
 constexpr int GW_XP = GW_XPIX * GW_LDX;        // 2592
 constexpr int GW_YP = GW_YPIX * GW_LDY;        // 2176
 
+#ifdef WW_TRACE   // tools/wgrad_wino_trace.hip: per-wave timestamps at the phase boundaries of the batch loop
+__device__ unsigned long long *g_ww_trace;
+#define WW_STAMP(slot)                                                                                                   \
+    do {                                                                                                                 \
+        if (lane == 0 && nb_done < 32)                                                                                   \
+            g_ww_trace[((((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 32 + nb_done) * 4 + (slot)] = \
+                __builtin_amdgcn_s_memtime();                                                                            \
+    } while (0)
+#else
+#define WW_STAMP(slot)
+#endif
+
 struct WgradWinoParams {
     InSrc src;
     int bx_n, ty_n, nbatch;     // batches per row, tile rows per image, total
     int dy0, dx0;               // offset of the first filter tap
+    int stagger;                // s_sleep units (64 clocks) by which every second co-resident workgroup starts late
 };
 
+// XM: the input loader has a second operand for this workgroup's channels (h*r product / ReLU mask); GM: ReLU mask on dy.
+template <bool XM, bool GM>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *V = smem;              // [16][32][8]
@@ -52,52 +67,75 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // ---- raw-data prefetch registers
+    // ---- raw-data prefetch.  Slot geometry is per-thread constant; per batch only a wave-uniform base pointer moves.
+    // (The concatenated input switches tensors at C0, a multiple of 32: uniform for the workgroup's 32 channels.)
     float4 xr[3], xm[3], yr[2], ym[2];
     unsigned xok = 0, yok = 0;
-    const bool two = s.mode == RAMNET_IN_CAT_MUL || s.mode == RAMNET_IN_RELUMASK;
-    auto load_raw = [&](int batch) {
+    const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;
+    const bool use_m = XM && (s.mode == RAMNET_IN_RELUMASK || second);      // wave-uniform: the h*r product only touches the h half
+    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
+    const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
+    const int ldS = second ? s.ld1 : s.ld0;
+    int xpy[3], xpx[3], xoff[3], xmoff[3], ypx[2], yoff[2], ymoff[2];
+    const int safe_x = (-q.dy0 * s.Win - q.dx0) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;   // the strip's own first pixel: always readable
+    bool xslot[3], yslot[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int sl = tid + i * 256, qd = sl & 7, pix = sl >> 3;
+        xpy[i] = pix / 18, xpx[i] = pix - xpy[i] * 18;
+        xslot[i] = sl < GW_XPIX * 8 && c0 + qd * 4 < s.Cin;
+        xoff[i] = (xpy[i] * s.Win + xpx[i]) * ldS + qd * 4;
+        xmoff[i] = (xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sl = tid + i * 256, qd = sl & 15, pix = sl >> 4;
+        ypx[i] = pix & 15;
+        yslot[i] = n0 + qd * 4 < p.Cout;
+        yoff[i] = ((pix >> 4) * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4;
+        ymoff[i] = ((pix >> 4) * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4;
+    }
+    int lb_ty = 0, lb_bx = 0;                     // batch being loaded (wave-uniform)
+    const float *lb_x = nullptr, *lb_m = nullptr, *lb_g = nullptr, *lb_gm = nullptr;
+    auto load_begin = [&](int batch) {
         int tt = batch;
-        const int bx = tt % q.bx_n;
+        lb_bx = tt % q.bx_n;
         tt /= q.bx_n;
-        const int ty = tt % q.ty_n;
+        lb_ty = tt % q.ty_n;
         const int b = tt / q.ty_n;
-        const int iy0 = 2 * ty + q.dy0, ix0 = 16 * bx + q.dx0;
+        const long pix = ((long)b * p.Ho + 2 * lb_ty) * p.Wo + 16 * lb_bx;
+        const long corner = pix + (long)q.dy0 * s.Win + q.dx0;           // patch corner (may lie "before" the image)
+        lb_x = xsrc + corner * ldS;
+        if (use_m) lb_m = msrc + corner * s.ldm;
+        lb_g = p.dout + pix * p.ldg;
+        if (GM) lb_gm = p.gmask + pix * p.ldgm;
         xok = 0, yok = 0;
+    };
+    auto load_x = [&](int i) {
+        const int iy = 2 * lb_ty + q.dy0 + xpy[i], ix = 16 * lb_bx + q.dx0 + xpx[i];
+        const bool ok = xslot[i] && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
+        xr[i] = ld4(lb_x + (ok ? xoff[i] : safe_x));
+        if (use_m) xm[i] = ld4(lb_m + (ok ? xmoff[i] : safe_m));
+        xok |= (ok ? 1u : 0u) << i;
+    };
+    auto load_y = [&](int i) {
+        const bool ok = yslot[i] && 2 * lb_ty + i < p.Ho && 16 * lb_bx + ypx[i] < p.Wo;     // slot i = output row i of the strip
+        yr[i] = ld4(lb_g + (ok ? yoff[i] : 0));
+        if (GM) ym[i] = ld4(lb_gm + (ok ? ymoff[i] : 0));
+        yok |= (ok ? 1u : 0u) << i;
+    };
+    auto load_raw = [&](int batch) {
+        load_begin(batch);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int sl = tid + i * 256;
-            const int qd = sl & 7, pix = sl >> 3;
-            const int py = pix / 18, px = pix - py * 18;
-            const int iy = iy0 + py, ix = ix0 + px, c = c0 + qd * 4;
-            const bool ok = sl < GW_XPIX * 8 && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win && c < s.Cin;
-            const size_t gp = ((size_t)b * s.Hin + iy) * s.Win + ix;
-            const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c >= s.C0;
-            const float *p0 = second ? s.x1 + gp * s.ld1 + (c - s.C0) : s.x0 + gp * s.ld0 + c;
-            const bool hm = two && (s.mode == RAMNET_IN_RELUMASK || second);
-            const float *p1 = s.mode == RAMNET_IN_RELUMASK ? s.xm + gp * s.ldm + c : s.xm + gp * s.ldm + (c - s.C0);
-            xr[i] = ld4(ok ? p0 : s.x0);
-            xm[i] = two ? ld4(ok && hm ? p1 : s.x0) : f4zero();
-            xok |= (ok ? 1u : 0u) << i;
-            xok |= (hm ? 1u : 0u) << (8 + i);
-        }
+        for (int i = 0; i < 3; ++i) load_x(i);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int sl = tid + i * 256;
-            const int qd = sl & 15, pix = sl >> 4;
-            const int oy = 2 * ty + (pix >> 4), ox = 16 * bx + (pix & 15), n = n0 + qd * 4;
-            const bool ok = oy < p.Ho && ox < p.Wo && n < p.Cout;
-            const size_t gp = ((size_t)b * p.Ho + oy) * p.Wo + ox;
-            yr[i] = ld4(ok ? p.dout + gp * p.ldg + n : p.dout);
-            if (p.gmask) ym[i] = ld4(ok ? p.gmask + gp * p.ldgm + n : p.gmask);
-            yok |= (ok ? 1u : 0u) << i;
-        }
+        for (int i = 0; i < 2; ++i) load_y(i);
     };
     float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
     auto store_x = [&](int i) {
         const int sl = tid + i * 256;
         float4 r = xr[i];
-        if ((xok >> (8 + i)) & 1u) {
+        if (use_m) {
             if (s.mode == RAMNET_IN_RELUMASK)
                 r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
             else
@@ -106,13 +144,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
         if (!((xok >> i) & 1u)) r = f4zero();
         if (sl < GW_XPIX * 8) st4(Xp + (sl >> 3) * GW_LDX + (sl & 7) * 4, r);
     };
+    bool count_bias = true;                       // false for the clamped re-store of the last batch
     auto store_y = [&](int i) {
         const int sl = tid + i * 256;
         float4 r = yr[i];
-        if (p.gmask) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
+        if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
         if (!((yok >> i) & 1u)) r = f4zero();
         st4(Yp + (sl >> 4) * GW_LDY + (sl & 15) * 4, r);
-        bsum = f4add(bsum, r);
+        if (count_bias) bsum = f4add(bsum, r);
     };
 
     // ---- transforms: thread = (tile tid&7, channel tid>>3 [+32 for the second Z item])
@@ -159,46 +198,67 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
     const int aoff = (ph * 8 * GW_CI + l31) * GW_T + kk * 4;
     const int boff = (ph * 8 * GW_CO + ch * 32 + l31) * GW_T + kk * 4;
 
-    // ---- pipeline: batch list of this workgroup = blockIdx.x, +gridDim.x, ...
-    int batch = blockIdx.x;
+    // Two workgroups share a CU and run the identical instruction stream: started together they stay in lockstep — both in
+    // their MFMA phase (sharing the pipe), then both in their transform phase (pipe idle).  The workgroup whose waves sit in
+    // an odd hardware wave slot therefore starts half a period late, so that one's transform runs under the other's MFMAs.
+    if (q.stagger > 0) {
+        const unsigned hw_wave = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
+        const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int mode = q.stagger >> 8;
+        const bool late = mode == 0 ? (hw_wave & 1) : mode == 1 ? (flat & 1) : mode == 2 ? ((flat >> 8) & 1) : mode == 3 ? ((flat >> 3) & 1) : ((flat >> 1) & 1);
+        if (late)
+            for (int i = 0; i < (q.stagger & 255); ++i) __builtin_amdgcn_s_sleep(8);               // 8 x 64 clocks
+    }
+    // ---- pipeline: batch list of this workgroup = blockIdx.x, +gridDim.x, ...  The loop body is branch-free: past the end the
+    // "next" batch is clamped to the last one (re-staged into buffers nobody reads; its bias contribution is not re-counted).
     const int step = gridDim.x;
+    int batch = blockIdx.x;
     if (batch < q.nbatch) {
+        const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
         load_raw(batch);
 #pragma unroll
         for (int i = 0; i < 3; ++i) store_x(i);
 #pragma unroll
         for (int i = 0; i < 2; ++i) store_y(i);
-        if (batch + step < q.nbatch) load_raw(batch + step);
+        load_raw(min(batch + step, last));
         __syncthreads();
         transform();
         __syncthreads();
-    }
-    for (; batch < q.nbatch; batch += step) {
-        const bool more = batch + step < q.nbatch, more2 = batch + 2 * step < q.nbatch;
-        float4 a = ld4(V + aoff), bv = ld4(Z + boff);
+        int nb_done = 0;
+        for (; batch <= last; batch += step, ++nb_done) {
+            count_bias = batch + step <= last;
+            WW_STAMP(0);
+            const int b2 = min(batch + 2 * step, last);
+            float4 a = ld4(V + aoff), bv = ld4(Z + boff);
 #pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            float4 an, bn;
-            if (pp + 1 < 8) an = ld4(V + aoff + (pp + 1) * (GW_CI * GW_T)), bn = ld4(Z + boff + (pp + 1) * (GW_CO * GW_T));
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[pp], 0, 0, 0);
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[pp], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // raw data of the next batch -> LDS (its readers, transform(i), finished before the last barrier)
-            if (more) {
+            for (int pp = 0; pp < 8; ++pp) {
+                float4 an, bn;
+                if (pp + 1 < 8) an = ld4(V + aoff + (pp + 1) * (GW_CI * GW_T)), bn = ld4(Z + boff + (pp + 1) * (GW_CO * GW_T));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[pp], 0, 0, 0);
+                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[pp], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // raw data of the next batch -> LDS (its readers, transform(i), finished before the last barrier), then the
+                // loads of the batch after it into the registers just stored
                 if (pp < 3) store_x(pp);
                 else if (pp < 5) store_y(pp - 3);
+                if (pp == 4) load_begin(b2);
+                if (pp == 5) load_x(0), load_x(1);
+                if (pp == 6) load_x(2), load_y(0);
+                if (pp == 7) load_y(1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[pp], 0, 0, 0);
+                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[pp], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp + 1 < 8) a = an, bv = bn;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[pp], 0, 0, 0);
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[pp], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pp + 1 < 8) a = an, bv = bn;
+            WW_STAMP(1);
+            __syncthreads();                 // V, Z free; raw patch of the next batch visible
+            WW_STAMP(2);
+            transform();
+            WW_STAMP(3);
+            __syncthreads();                 // V, Z of the next batch visible; raw patch free
         }
-        if (more2) load_raw(batch + 2 * step);
-        __syncthreads();                 // V, Z free; raw patch of the next batch visible
-        if (more) transform();
-        __syncthreads();                 // V, Z of the next batch visible; raw patch free
     }
 
     // D[row = input channel][col = output channel] of position ph*8 + pp -> ws[(pos*Cin + c)*Cout + n]
@@ -248,6 +308,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win);
+    if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % GW_CI == 0);   // a workgroup's 32 channels come from one tensor
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
     for (int t = 0; t < 9; ++t) {
@@ -268,18 +329,29 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
+    static const char *stg = getenv("RAMNET_WGRAD_STAGGER");
+    q.stagger = stg ? atoi(stg) : 0;
     const size_t lds = (size_t)(GW_V + GW_Z + GW_XP + GW_YP) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     const int gy = cdiv(q.src.Cin, GW_CI), gz = cdiv(d.Cout, GW_CO);
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
     int splits = (se ? atoi(se) : 512) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
-    hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3(splits, gy, gz), dim3(256), lds, st, d, q);
+    const dim3 grid(splits, gy, gz);
+    // the second loader operand exists for ALL workgroups (ReLU mask) or only for those on the h half (h*r): the kernel
+    // reads xm only when its own channels need it, so launch the XM variant whenever any workgroup might
+    const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
+    auto go = [&](auto kern) -> int {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, q);
+        return 0;
+    };
+    int rc;
+    if (xm && gm) rc = go(conv_wgrad_wino_kernel<true, true>);
+    else if (xm) rc = go(conv_wgrad_wino_kernel<true, false>);
+    else if (gm) rc = go(conv_wgrad_wino_kernel<false, true>);
+    else rc = go(conv_wgrad_wino_kernel<false, false>);
+    if (rc) return rc;
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

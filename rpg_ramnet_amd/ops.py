@@ -164,6 +164,8 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     d.Cout, d.Ho, d.Wo = Cout, dout.shape[1], dout.shape[2]
     d.dw, d.dbias = _p(dw), _p(dbias)
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
+    if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
+        raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
 
 
@@ -505,12 +507,12 @@ class GRUCell(Function):
         dhd = torch.empty_like(o)
         H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_a")
         taps, tapsd = Taps.get("conv", 3, 1), Taps.get("dgrad1", 3, 1)
-        ws, bws = cp_o.grad_ws(wino_ok=True)
+        ws, bws = cp_o.grad_ws(wino_ok=Cc % 32 == 0)
         wgrad_side([x, h, ur, dpo], x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)       # [dx | dh]
         conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
         H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
-        ws, bws = cp_ur.grad_ws(wino_ok=True)
+        ws, bws = cp_ur.grad_ws(wino_ok=Cc % 32 == 0)
         wgrad_side([x, h, dpur], x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)
         return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None
@@ -548,7 +550,7 @@ class LSTMCell(Function):
         dpre = torch.empty_like(gates)
         dc = torch.empty_like(cn)
         H.check(H.lib().ramnet_lstm_bwd(_p(gates), _p(c), _p(cn), _p(dhn), _p(dcn), _p(dpre), _p(dc), npix, Cc, _st()), "lstm_bwd")
-        ws, bws = cp.grad_ws(wino_ok=True)
+        ws, bws = cp.grad_ws(wino_ok=x.shape[3] % 32 == 0)
         wgrad_side([x, h, dpre], x, Taps.get("conv", 3, 1), dpre, ws, 4 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dxh, 2 * Cc)
