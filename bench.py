@@ -120,6 +120,9 @@ class KernelTimer:
                 return conv0(x0, taps, w, out, Cout, **kw)
             Ho, Wo = kw.get("Ho") or out.shape[1], kw.get("Wo") or out.shape[2]
             name = variant(Cout, kw.get("epi", 0), x0.shape[0], Ho, Wo)
+            if ops.uses_winograd(taps, w, kw.get("stride", 1), kw.get("epi", 0), kw.get("in_mode", 0),
+                                 kw.get("C0") or x0.shape[3], kw.get("C1", 0)):
+                name = "conv_wino_kernel"
             if timer.only is not None and name != timer.only:
                 return conv0(x0, taps, w, out, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -145,6 +148,9 @@ class KernelTimer:
             else:
                 per = -(-ntt // 2)
                 name = "conv_wgrad_kernel<%d,2,1>" % (1 if per <= 1 else 5)
+            if getattr(dw, "wino", False):         # Winograd backward-weights (template flags: loader operand, ReLU mask on dy)
+                from rpg_ramnet_amd import _hip as Hh
+                name = "conv_wgrad_wino_kernel<%d,%d>" % (kw.get("in_mode", 0) in (Hh.IN_RELUMASK, Hh.IN_CAT_MUL), kw.get("gmask") is not None)
             if timer.only is not None and name != timer.only:
                 return wgrad0(x0, taps, dout, dw, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

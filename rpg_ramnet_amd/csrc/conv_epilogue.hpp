@@ -25,4 +25,28 @@ __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int ep
     p.out[pix * p.ldo + n] = v;
 }
 
+// Four consecutive output channels n..n+3 of one pixel (all pointers 16-byte aligned, Cout % 4 == 0: checked on the host).
+__device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int epi, size_t pix, int n, float4 acc) {
+    float4 v = p.bias ? f4add(acc, ld4(p.bias + n)) : acc;
+    if (epi == RAMNET_EPI_RELU) {
+        v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    } else if (epi == RAMNET_EPI_SIGMOID) {
+        v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+    } else if (epi == RAMNET_EPI_RES_RELU) {
+        const float4 e = ld4(p.e0 + pix * p.lde0 + n);
+        v = make_float4(fmaxf(v.x + e.x, 0.f), fmaxf(v.y + e.y, 0.f), fmaxf(v.z + e.z, 0.f), fmaxf(v.w + e.w, 0.f));
+    } else if (epi == RAMNET_EPI_GRU_BLEND) {
+        const float4 o = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+        const float4 u = ld4(p.e0 + pix * p.lde0 + n);
+        const float4 h = p.e1 ? ld4(p.e1 + pix * p.lde1 + n) : f4zero();
+        if (p.o1) st4(p.o1 + pix * p.ldo1 + n, o);
+        v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
+                        h.w * (1.0f - u.w) + o.w * u.w);
+    } else if (p.beta != 0.f) {
+        const float4 old = ld4(p.out + pix * p.ldo + n);
+        v = make_float4(v.x + p.beta * old.x, v.y + p.beta * old.y, v.z + p.beta * old.z, v.w + p.beta * old.w);
+    }
+    st4(p.out + pix * p.ldo + n, v);
+}
+
 }  // namespace ramnet

@@ -33,6 +33,7 @@ struct WinoParams {
     int nchunks, nblk;      // Cin/8, CoutPad/64
     int tiles_x, tiles_y;
     int dy0, dx0;           // offset of the first filter tap (-1 for the padded 3x3)
+    int vec4;               // all epilogue operands allow 16-byte channel-quad accesses
 };
 
 __device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
@@ -241,6 +242,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
     // ---- output transform + epilogue.  D of the 16x16 MFMA: col = lane&15 (channel), row = 4*(lane>>4) + r (tile)
     const int epi = p.epi;
     const int n = n0 + wave * 16 + l15;
+    constexpr int OLD = WBN + 4;                      // row of the LDS output tile [128 pixels][64 channels + pad]
+    float *O = smem;                                  // reuses V / patch (the last barrier of the loop freed them)
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
 #pragma unroll
@@ -260,6 +263,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
             }
             const int tile = f * 16 + 4 * ks + r;
             const int ty = tile >> 3, tx = tile & 7;
+            if (q.vec4) {        // stage the tile in LDS so that the stores (and the epilogue operands) go out as 16-byte quads
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) O[((2 * ty + a) * WTW + 2 * tx + c) * OLD + wave * 16 + l15] = y[a][c];
+                continue;
+            }
             if (n >= p.Cout) continue;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -270,6 +280,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
                     const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
                     epilogue_store(p, epi, pix, n, y[a][c]);
                 }
+        }
+    }
+    if (q.vec4) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sl = tid + i * 256, pxl = sl >> 4, qd = sl & 15;
+            const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), nq = n0 + qd * 4;
+            if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
+            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
+            epilogue_store4(p, epi, pix, nq, ld4(O + pxl * OLD + qd * 4));
         }
     }
     { const int chunk = 31; WINO_STAMP(3); }
@@ -341,6 +362,9 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
     q.dy0 = dymin, q.dx0 = dxmin;
+    auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
+    q.vec4 = d.Cout % 4 == 0 && d.ldo % 4 == 0 && al16(d.out) && al16(d.bias) && (!d.o1 || (d.ldo1 % 4 == 0 && al16(d.o1))) &&
+             (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1)));
     const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     dim3 grid(q.tiles_x * q.tiles_y * d.B, q.nblk);
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);

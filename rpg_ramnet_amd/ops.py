@@ -118,6 +118,14 @@ def conv_launch_multi(x0, w, out, Cout, classes, **kw):
     H.check(H.lib().ramnet_conv_launch_multi(arr, len(classes), _st()), "ramnet_conv_launch_multi")
 
 
+def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
+    """Does this forward / backward-data launch run the Winograd F(2x2,3x3) kernel?  (3x3 stride-1 window, fp32, no LSTM
+    epilogue, no upsampling loader, >= 32 reduction channels, concatenation boundary on a chunk of 8.)"""
+    return bool(isinstance(w, PackRef) and _WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1
+                and w.cp.gates == 1 and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP)
+                and C0 + C1 >= _WINO_MIN_CIN and (C1 == 0 or C0 % 8 == 0))
+
+
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
                 o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0):
@@ -128,9 +136,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
     d.algo = H.ALGO_DIRECT
     if isinstance(w, PackRef):
-        wino = (_WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1 and w.cp.gates == 1
-                and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP) and d.C0 + C1 >= _WINO_MIN_CIN
-                and (C1 == 0 or d.C0 % 8 == 0))
+        wino = uses_winograd(taps, w, stride, epi, in_mode, d.C0, C1)
         d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
         w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
