@@ -381,19 +381,23 @@ def main():
             ach = flops / secs / 1e12
             traffic = None
             try:    # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-                key = name.replace(",1>", ",f32>") if name.startswith("conv_igemm") else name
-                ent = pmc.get(key)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic.json")))      # tools/pmc_traffic.py
+                ent = pmc.get(name.replace(",1>", ",0>") if name.startswith("conv_igemm") else name)
                 if ent:
-                    traffic = sum(v["hbm_bytes_per_launch"] for v in ent.values()) / len(ent)
-            except (OSError, ValueError):
+                    traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent.values()) /
+                               max(1, sum(v["launches"] for v in ent.values())))
+            except (OSError, ValueError, KeyError):
                 pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                               "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from profiles/r01_pmc_*; "
-                                               "gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
+                               "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB, launch-weighted over the kernel's grids, "
+                                               "from profiles/r01_g_pmc_*; gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
                                "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9}
+            if "wino" in name:   # Winograd F(2x2,3x3) executes 16/36 of the algorithmic multiplies on the MFMA pipe
+                out["roofline"]["mfma_flop_executed_frac_of_peak"] = ach / 2.25 / F32_MFMA_PEAK_TFLOPS
+                out["roofline"]["note"] = ("achieved/frac count the ALGORITHMIC FLOP of the convolution (2*B*H*W*9*Cin*Cout, SURVEY 8d) as the "
+                                           "contract asks; the kernel executes 1/2.25 of them (Winograd), see mfma_flop_executed_frac_of_peak")
             src = warm if warm else agg
             if warm and args.warmup > 0:      # overlap-proof view: all MFMA FLOP of a step over the step's wall time
                 step_flop = sum(v[2] for v in warm.values()) / args.warmup

@@ -115,19 +115,25 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, ks = lane >> 4;
 
-    int bid = blockIdx.x;
+    // XCD-aware order (1-D grid): consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Within
+    // an XCD the 64-channel blocks of ONE spatial tile are consecutive, so that the input patch they all read is fetched
+    // from HBM / Infinity Cache once and served to the others by that XCD's L2.
+    const int xslot = blockIdx.x >> 3;
+    const int nblk_i = xslot % q.nblk;
+    int bid = (xslot / q.nblk) * 8 + (blockIdx.x & 7);
+    if (bid >= q.tiles_x * q.tiles_y * p.B) return;
     const int tx_i = bid % q.tiles_x;
     bid /= q.tiles_x;
     const int ty_i = bid % q.tiles_y;
     const int b = bid / q.tiles_y;
-    const int n0 = blockIdx.y * WBN;
+    const int n0 = nblk_i * WBN;
     const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
     const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
 
     const int swz = 4 * ((l15 >> 3) & 1);
     const int aoff = l15 * WK + ((ks * 2) ^ swz);                       // A fragment 0; fragment 1 is 16 rows further
     // weights: [chunk][block64][position pair 8][n 64][k-slot 4][2 positions][2 channels] -> one 16-byte load per pair
-    const float *wsrc = p.w + (size_t)blockIdx.y * WU_FLOATS + (wave * 16 + l15) * 16 + ks * 4;
+    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + (wave * 16 + l15) * 16 + ks * 4;
     const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
 
     f32x4 acc[16][2];
@@ -366,7 +372,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.vec4 = d.Cout % 4 == 0 && d.ldo % 4 == 0 && al16(d.out) && al16(d.bias) && (!d.o1 || (d.ldo1 % 4 == 0 && al16(d.o1))) &&
              (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1)));
     const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
-    dim3 grid(q.tiles_x * q.tiles_y * d.B, q.nblk);
+    dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();
     return 0;
