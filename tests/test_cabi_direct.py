@@ -68,3 +68,52 @@ def test_loss_and_voxel_entry_points_raw():
     exp = np.zeros((3, 6, 8), np.float32)
     exp[0, 1, 1], exp[1, 3, 2], exp[2, 5, 7] = 1.0, -1.0, 1.0          # t -> bins 0, 1, 2 exactly (dt = 0)
     assert np.array_equal(grid.cpu().numpy(), exp)
+
+
+def test_winograd_conv_and_wgrad_through_raw_descriptors():
+    """RAMNET_ALGO_WINOGRAD end to end with raw pointers: pack U = G g G^T, forward launch, backward-weights launch into
+    the transformed-domain workspace, fold into OIHW; checked against float64 autograd."""
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(3)
+    B, H, W, Cin, Cout = 2, 14, 22, 64, 96
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.1
+    b = torch.randn(Cout, device=dev) * 0.1
+    wp = torch.empty(L.ramnet_packed_weight_elems_wino(Cout, Cin, 0), device=dev)
+    assert L.ramnet_pack_weight_wino(ptr(w), ptr(wp), Cout, Cin, 0, st) == 0
+    y = torch.empty(B, H, W, Cout, device=dev)
+    d = _hip.ConvDesc()
+    d.x0, d.ld0, d.C0, d.in_mode = ptr(x), Cin, Cin, _hip.IN_PLAIN
+    d.B, d.Hin, d.Win, d.stride, d.ntaps = B, H, W, 1, 9
+    for i in range(9):
+        d.dy[i], d.dx[i], d.wtap[i] = i // 3 - 1, i % 3 - 1, i
+    d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
+    d.Ho, d.Wo, d.HoF, d.WoF = H, W, H, W
+    d.osy, d.osx = 1, 1
+    d.epi, d.out, d.ldo, d.precision, d.algo = _hip.EPI_LINEAR, ptr(y), Cout, _hip.PREC_F32, _hip.ALGO_WINOGRAD
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    xr = x.permute(0, 3, 1, 2).cpu().double()
+    wr, br = w.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br, 1, 1)
+    assert float((y.permute(0, 3, 1, 2).cpu() - ref.detach()).abs().max() / ref.abs().max()) < 2e-4
+    # the Winograd kernel only serves the dense 3x3 stride-1 window
+    d.stride = 2
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+    # backward-weights
+    dy = torch.randn(B, H, W, Cout, device=dev)
+    (ref * dy.permute(0, 3, 1, 2).cpu().double()).sum().backward()
+    ws, dbias = torch.zeros(16 * Cin * Cout, device=dev), torch.zeros(Cout, device=dev)
+    g = _hip.WgradDesc()
+    g.x0, g.ld0, g.C0, g.in_mode = ptr(x), Cin, Cin, _hip.IN_PLAIN
+    g.B, g.Hin, g.Win, g.ntaps, g.stride = B, H, W, 9, 1
+    for i in range(9):
+        g.dy[i], g.dx[i] = i // 3 - 1, i % 3 - 1
+    g.dout, g.ldg, g.Cout, g.Ho, g.Wo = ptr(dy), Cout, Cout, H, W
+    g.dw, g.dbias, g.algo = ptr(ws), ptr(dbias), _hip.ALGO_WINOGRAD
+    assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
+    grad = torch.zeros(Cout, Cin, 3, 3, device=dev)
+    assert L.ramnet_unpack_wgrad_wino(ptr(ws), ptr(grad), Cout, Cin, Cin, Cout, 0, st) == 0
+    assert float((grad.cpu() - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-4
+    assert float((dbias.cpu() - br.grad).abs().max() / br.grad.abs().max()) < 2e-4

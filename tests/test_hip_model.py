@@ -135,6 +135,44 @@ def test_bptt_gradients_vs_reference_fixture():
             assert_close(g.flatten()[::997].numpy(), z["gsample." + k], 2e-3, "grad sample " + k)
 
 
+@pytest.fixture
+def wgrad_overlap():
+    from rpg_ramnet_amd import ops
+    ops.set_wgrad_overlap(True)
+    yield
+    ops.set_wgrad_overlap(False)
+
+
+def test_wgrad_side_stream_gradients(wgrad_overlap):
+    """Backward-weights on the side stream (bench.py's default schedule): same gradients as the float64 oracle, and the
+    same as the single-stream schedule up to the summation order of the atomics."""
+    test_bptt_gradients_vs_oracle("gru")
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=3, loss_composition=["image", "events2"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(5)
+    seq = [make_item(rng, 2, 32, 48, 3, 5, cfg["num_bins_rgb"], True, 0.1) for _ in range(3)]
+    grads = {}
+    for on in (True, False, True):
+        ops.set_wgrad_overlap(on)
+        model.zero_grad()
+        total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+        total.backward()
+        torch.cuda.synchronize()
+        g = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        gmax = max(float(v.abs().max()) for v in g.values())
+        if on in grads:     # run-to-run: only the order of the atomic partial sums differs (pred.bias cancels to ~1e-6: floor)
+            for k in g:
+                if k.endswith("pred.conv2d.bias"):      # a sum of ~1e5 terms that cancels to ~1e-6: pure summation-order noise
+                    continue
+                assert_close(g[k].cpu().numpy(), grads[on][k].cpu().numpy(), 1e-5, "repeat " + k, floor=1e-2 * gmax)
+        grads[on] = g
+    for k in grads[True]:
+        if not k.endswith("pred.conv2d.bias"):
+            assert_close(grads[True][k].cpu().numpy(), grads[False][k].cpu().numpy(), 1e-4, "side stream vs single " + k, floor=1e-2 * gmax)
+
+
 @pytest.mark.parametrize("mode", ["gru", "lstm", "enc_lstm", "base_e"])
 def test_bptt_gradients_vs_oracle(mode):
     """Same seeded model + inputs through the HIP path and the CPU oracle: loss, predictions and all gradients."""

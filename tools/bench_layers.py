@@ -46,6 +46,9 @@ def main():
         L.append(("dec%d" % i, "up", ci, co, 5, 1, Hh >> (2 - i), Ww >> (2 - i)))
     for i, c in enumerate([64, 128, 256]):
         L.append(("lstm%d" % i, "lstm", 2 * c, 4 * c, 3, 1, Hh >> (i + 1), Ww >> (i + 1)))
+    # the decoder convolutions on a MATERIALISED upsampled input (plain loader): what the fused bilinear loader costs
+    for i, (ci, co) in enumerate([(256, 128), (128, 64), (64, 32)]):
+        L.append(("dec%d_plain" % i, "conv", ci, co, 5, 1, Hh >> (2 - i), Ww >> (2 - i)))
     print("%-12s %8s | %8s %7s | %8s %7s | %8s %7s" % ("layer", "GFLOP", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
     tot = [0.0, 0.0, 0.0, 0.0]
     for name, kind, cin, cout, k, stride, Hin, Win in L:
