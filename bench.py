@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-overlap-wgrad", dest="overlap_wgrad", action="store_false",
                     help="run backward-weights on the main stream instead of co-scheduling it with backward-data on a side stream "
                          "(the default schedule; per-kernel durations then include co-scheduled time)")
+    ap.add_argument("--overlap-decoder", action="store_true",
+                    help="run the decoders on a second stream, concurrent with the next state update (ops.set_decoder_overlap)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) overlap / bf16x3 measurements")
     return ap.parse_args()
@@ -249,6 +251,7 @@ def main():
     from rpg_ramnet_amd import ops
     ops.set_precision(args.precision)
     ops.set_wgrad_overlap(args.overlap_wgrad)
+    ops.set_decoder_overlap(args.overlap_decoder)
     K, bins, B, L, H, W = 5, args.bins, args.batch, args.seq_len, args.height, args.width
     cfg = dict(RELEASED, num_bins_events=bins, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)

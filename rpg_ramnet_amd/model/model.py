@@ -154,6 +154,20 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                 comb.append(v if c is s_in else _to_nchw(c))         # GRU mode: state_comb[i] IS super_state[i]
             states_lstm_dict[key] = {'encoders': [_to_nchw(s) for s in sl['encoders']], 'state_comb': comb}
 
+        side = ops.decode_stream(self.gpu) if ops.decoder_overlap() else None
+
+        def decode(ss):
+            """Prediction from the state after this update; optionally on the decode stream, concurrent with the next update."""
+            if side is None:
+                return net.forward_decoder(ss)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                pred = net.forward_decoder(ss)
+            for t in ss:
+                for u in (t if isinstance(t, (list, tuple)) else (t,)):
+                    u.record_stream(side)
+            return pred
+
         events_as_image = baseline == "ergb0" or (baseline == "e" and lc == "image")
         last = None
         if not bool(baseline) or events_as_image:
@@ -167,12 +181,16 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                     ss, sl = net.forward_images(x, states, last)
                 else:
                     ss, sl = net.forward_events(x, states, last)
-                emit('events{}'.format(k), net.forward_decoder(ss), ss, sl)
+                emit('events{}'.format(k), decode(ss), ss, sl)
                 states, last = ss, sl
 
         x = ops.pack_input(item['image'], self.gpu)
         if not bool(baseline) or baseline == "rgb" or (baseline == "e" and lc != "image"):
             last = lstm_in(prev_states_lstm['image'])
         ss, sl = net.forward_images(x, states, last)
-        emit('image', net.forward_decoder(ss), ss, sl)
+        emit('image', decode(ss), ss, sl)
+        if side is not None:                       # predictions are consumed on the caller's stream
+            torch.cuda.current_stream().wait_stream(side)
+            for pred in predictions_dict.values():
+                pred.record_stream(torch.cuda.current_stream())
         return predictions_dict, super_state_dict, states_lstm_dict

@@ -122,7 +122,7 @@ def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
     """Does this forward / backward-data launch run the Winograd F(2x2,3x3) kernel?  (3x3 stride-1 window, fp32, no LSTM
     epilogue, no upsampling loader, >= 32 reduction channels, concatenation boundary on a chunk of 8.)"""
     return bool(isinstance(w, PackRef) and _WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1
-                and w.cp.gates == 1 and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP)
+                and (w.cp.gates == 1 or w.transposed) and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP)
                 and C0 + C1 >= _WINO_MIN_CIN and (C1 == 0 or C0 % 8 == 0))
 
 
@@ -192,6 +192,31 @@ def set_wgrad_overlap(on):
     _USE_SIDE = bool(on)
 
 
+# The decoder of update k (prediction for that measurement) and the state update k+1 both depend only on the state after
+# update k: with set_decoder_overlap(True) the model runs its decoders on a second stream, in forward and — because
+# autograd runs a node's backward on its forward stream — in backward, so the two kernel chains fill each other's tails.
+_DECODE = {}
+_USE_DECODE = _os.environ.get("RAMNET_DECODE_STREAM", "0") == "1"
+_DECODE_USED = set()
+
+
+def set_decoder_overlap(on):
+    global _USE_DECODE
+    _USE_DECODE = bool(on)
+
+
+def decoder_overlap():
+    return _USE_DECODE
+
+
+def decode_stream(dev):
+    st = _DECODE.get(dev)
+    if st is None:
+        st = _DECODE[dev] = torch.cuda.Stream(device=dev)
+    _DECODE_USED.add(dev)
+    return st
+
+
 def _side_stream(dev):
     st = _SIDE.get(dev)
     if st is None:
@@ -232,6 +257,8 @@ class _Engine:
 
     @classmethod
     def flush(cls):
+        for dev in _DECODE_USED:           # decoder backward (and its weight-gradient launches) ran on the decode stream
+            torch.cuda.current_stream(dev).wait_stream(_DECODE[dev])
         if cls.side_used is not None:      # all weight-gradient launches of this pass are done before the fold
             torch.cuda.current_stream().wait_event(_side_stream(cls.side_used).record_event())
             cls.side_used = None

@@ -173,6 +173,39 @@ def test_wgrad_side_stream_gradients(wgrad_overlap):
             assert_close(grads[True][k].cpu().numpy(), grads[False][k].cpu().numpy(), 1e-4, "side stream vs single " + k, floor=1e-2 * gmax)
 
 
+def test_decoder_stream_overlap_same_results():
+    """Decoders on a second stream (ops.set_decoder_overlap): identical predictions, gradients equal up to atomic order."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=3, loss_composition=["image", "events2"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(7)
+    seq = [make_item(rng, 2, 32, 48, 3, 5, cfg["num_bins_rgb"], True, 0.1) for _ in range(3)]
+    res = {}
+    try:
+        for on in (False, True, True):
+            ops.set_decoder_overlap(on)
+            ops.set_wgrad_overlap(on)
+            model.zero_grad()
+            with torch.no_grad():
+                preds, _, _ = model(seq[0], None, ramnet_ref.empty_states_lstm(cfg["every_x_rgb_frame"]))
+            total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+            total.backward()
+            torch.cuda.synchronize()
+            res[on] = ({k: v.clone() for k, v in preds.items()}, float(total.detach()),
+                       {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    finally:
+        ops.set_decoder_overlap(False)
+        ops.set_wgrad_overlap(False)
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert res[False][1] == res[True][1]
+    gmax = max(float(v.abs().max()) for v in res[False][2].values())
+    for k in res[False][2]:
+        if not k.endswith("pred.conv2d.bias"):
+            assert_close(res[True][2][k].cpu().numpy(), res[False][2][k].cpu().numpy(), 1e-4, "decode stream " + k, floor=1e-2 * gmax)
+
+
 @pytest.mark.parametrize("mode", ["gru", "lstm", "enc_lstm", "base_e"])
 def test_bptt_gradients_vs_oracle(mode):
     """Same seeded model + inputs through the HIP path and the CPU oracle: loss, predictions and all gradients."""
