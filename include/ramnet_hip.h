@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 3
+#define RAMNET_ABI_VERSION 4
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -111,10 +111,11 @@ size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transpo
 size_t ramnet_packed_weight_elems_split(int Cout, int Cin, int KH, int KW, int transposed, int gates);
 int ramnet_pack_weight_split(const float *w_oihw, float *wp, int Cout, int Cin, int KH, int KW,
                              int transposed, int gates, void *stream);
-/* Winograd F(2x2,3x3) weights U = G g G^T of a 3x3 conv, layout [Cin/8][Cout/64][16][64][8] (padded with zeros).
- * transposed=1 packs the backward-data operator (flipped taps, reduce over O).                      */
-size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed);
-int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, void *stream);
+/* Winograd F(2x2,3x3) weights U = G g G^T of a 3x3 conv in the lane order of the kernel's B operand
+ * ([Cin/8][Cout/64][8 position pairs][64][4][2][2], zero padded).  transposed=1 packs the backward-data operator
+ * (flipped taps, reduce over O); gates=4 (forward only) groups the ConvLSTM gates of 16 hidden channels per block.  */
+size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed, int gates);
+int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, int gates, void *stream);
 /* OIHW -> kernel layout [tap][chunk][n][16].  transposed=1 packs the backward-data operator
  * (reduce over O, produce I).  gates=4 interleaves ConvLSTM gate blocks so that one wave owns
  * i,f,o,g of a channel (forward only).  CinValid rows beyond Cin are zero (padded inputs).        */

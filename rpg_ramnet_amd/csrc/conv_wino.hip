@@ -288,7 +288,33 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
                 }
         }
     }
-    if (q.vec4) {
+    if (q.vec4 && epi == RAMNET_EPI_LSTM) {
+        // ConvLSTM cell (submodules.py:346-358): the block's 64 columns are 16 hidden channels x gates (i, f, o, g)
+        __syncthreads();
+        const int C = p.Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = tid + i * 256, pxl = sl >> 2, qd = sl & 3;
+            const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), chn = nblk_i * 16 + qd * 4;
+            if (oy >= p.Ho || ox >= p.Wo || chn >= C) continue;
+            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
+            const float *orow = O + pxl * OLD + qd * 4;
+            const float4 ai = f4add(ld4(orow), ld4(p.bias + chn)), af = f4add(ld4(orow + 16), ld4(p.bias + C + chn));
+            const float4 ao = f4add(ld4(orow + 32), ld4(p.bias + 2 * C + chn)), ag = f4add(ld4(orow + 48), ld4(p.bias + 3 * C + chn));
+            const float4 gi = make_float4(sigmoidf_(ai.x), sigmoidf_(ai.y), sigmoidf_(ai.z), sigmoidf_(ai.w));
+            const float4 gf = make_float4(sigmoidf_(af.x), sigmoidf_(af.y), sigmoidf_(af.z), sigmoidf_(af.w));
+            const float4 go = make_float4(sigmoidf_(ao.x), sigmoidf_(ao.y), sigmoidf_(ao.z), sigmoidf_(ao.w));
+            const float4 gc = make_float4(tanhf(ag.x), tanhf(ag.y), tanhf(ag.z), tanhf(ag.w));
+            const float4 cp = p.e1 ? ld4(p.e1 + pix * p.lde1 + chn) : f4zero();
+            const float4 cn = make_float4(gf.x * cp.x + gi.x * gc.x, gf.y * cp.y + gi.y * gc.y, gf.z * cp.z + gi.z * gc.z, gf.w * cp.w + gi.w * gc.w);
+            st4(p.out + pix * p.ldo + chn, make_float4(go.x * tanhf(cn.x), go.y * tanhf(cn.y), go.z * tanhf(cn.z), go.w * tanhf(cn.w)));
+            st4(p.o1 + pix * p.ldo1 + chn, cn);
+            if (p.o2) {
+                float *g = p.o2 + pix * p.ldo2 + chn;
+                st4(g, gi), st4(g + C, gf), st4(g + 2 * C, go), st4(g + 3 * C, gc);
+            }
+        }
+    } else if (q.vec4) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -304,7 +330,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
 
 // OIHW 3x3 -> U = G g G^T in the lane order of the kernel's B operand (see wsrc above); evaluated in double.
 __global__ void pack_weight_wino_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
-                                        int R, int N, int nchunks, int nblk, size_t total) {
+                                        int gates, int R, int N, int nchunks, int nblk, size_t total) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         // i = ((((chunk * nblk + nb) * 8 + pp) * 64 + n) * 4 + ks) * 4 + (pos & 1) * 2 + (c & 1),  c = 2 * ks + (c & 1)
         const int cl = (int)(i & 1), p1 = (int)((i >> 1) & 1), ksl = (int)((i >> 2) & 3);
@@ -316,9 +342,16 @@ __global__ void pack_weight_wino_kernel(const float *__restrict__ w, float *__re
         const int nb = (int)(j % nblk);
         const int chunk = (int)(j / nblk);
         const int c = 2 * ksl + cl;
-        const int r = chunk * WK + c, no = nb * WBN + n;
+        const int r = chunk * WK + c;
+        int no = nb * WBN + n;
+        bool ok = r < R && no < N;
+        if (gates > 1) {    // ConvLSTM: a 64-column block = 16 hidden channels x (i, f, o, g) -> the epilogue sees the four gates
+            const int C = N / gates, chn = nb * 16 + (n & 15);      // of a channel in one LDS row; original row = gate*C + channel
+            ok = r < R && chn < C;
+            no = (n >> 4) * C + chn;
+        }
         float v = 0.f;
-        if (r < R && no < N) {
+        if (ok) {
             double g[3][3];
             for (int a = 0; a < 3; ++a)
                 for (int bb = 0; bb < 3; ++bb)
@@ -335,15 +368,15 @@ __global__ void pack_weight_wino_kernel(const float *__restrict__ w, float *__re
     }
 }
 
-static void wino_geometry(int Cout, int Cin, int transposed, int &R, int &N, int &nchunks, int &nblk) {
+static void wino_geometry(int Cout, int Cin, int transposed, int gates, int &R, int &N, int &nchunks, int &nblk) {
     R = transposed ? Cout : Cin;
     N = transposed ? Cin : Cout;
     nchunks = cdiv(R, WK);
-    nblk = cdiv(N, WBN);
+    nblk = gates > 1 ? cdiv(N / gates, 16) : cdiv(N, WBN);
 }
 
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
-    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && d.precision == RAMNET_PREC_F32 && d.epi != RAMNET_EPI_LSTM);
+    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && d.precision == RAMNET_PREC_F32);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
     // the taps must be the dense 3x3 window; which weight slice each one reads is baked into the Winograd pack
@@ -365,12 +398,14 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
     q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
-    q.nchunks = cdiv(q.src.Cin, WK), q.nblk = cdiv(d.Cout, WBN);
+    q.nchunks = cdiv(q.src.Cin, WK), q.nblk = d.epi == RAMNET_EPI_LSTM ? cdiv(d.Cout, 16) : cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
     q.dy0 = dymin, q.dx0 = dxmin;
     auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
     q.vec4 = d.Cout % 4 == 0 && d.ldo % 4 == 0 && al16(d.out) && al16(d.bias) && (!d.o1 || (d.ldo1 % 4 == 0 && al16(d.o1))) &&
-             (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1)));
+             (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1))) &&
+             (!d.o2 || (d.ldo2 % 4 == 0 && al16(d.o2)));
+    if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(q.vec4);      // the cell epilogue works on channel quads of the staged tile
     const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);
@@ -382,21 +417,22 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
 
 using namespace ramnet;
 
-extern "C" size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed) {
+extern "C" size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed, int gates) {
     int R, N, nchunks, nblk;
-    wino_geometry(Cout, Cin, transposed, R, N, nchunks, nblk);
+    wino_geometry(Cout, Cin, transposed, gates, R, N, nchunks, nblk);
     return (size_t)nchunks * nblk * WU_FLOATS;
 }
 
-extern "C" int ramnet_pack_weight_wino(const float *w, float *wp, int Cout, int Cin, int transposed, void *stream) {
+extern "C" int ramnet_pack_weight_wino(const float *w, float *wp, int Cout, int Cin, int transposed, int gates, void *stream) {
     RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0);
+    RAMNET_CHECK_ARG(gates == 1 || (gates == 4 && !transposed && Cout % 4 == 0));
     int R, N, nchunks, nblk;
-    wino_geometry(Cout, Cin, transposed, R, N, nchunks, nblk);
+    wino_geometry(Cout, Cin, transposed, gates, R, N, nchunks, nblk);
     const size_t total = (size_t)nchunks * nblk * WU_FLOATS;
     size_t blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, transposed,
-                       R, N, nchunks, nblk, total);
+                       gates, R, N, nchunks, nblk, total);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

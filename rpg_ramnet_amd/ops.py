@@ -119,10 +119,12 @@ def conv_launch_multi(x0, w, out, Cout, classes, **kw):
 
 
 def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
-    """Does this forward / backward-data launch run the Winograd F(2x2,3x3) kernel?  (3x3 stride-1 window, fp32, no LSTM
-    epilogue, no upsampling loader, >= 32 reduction channels, concatenation boundary on a chunk of 8.)"""
+    """Does this forward / backward-data launch run the Winograd F(2x2,3x3) kernel?  (3x3 stride-1 window, fp32, no
+    upsampling loader, >= 32 reduction channels, concatenation boundary on a chunk of 8; the ConvLSTM cell epilogue
+    needs a hidden size that is a multiple of 4.)"""
     return bool(isinstance(w, PackRef) and _WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1
-                and (w.cp.gates == 1 or w.transposed) and epi != H.EPI_LSTM and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP)
+                and (w.cp.gates == 1 or w.transposed or (epi == H.EPI_LSTM and w.cp.Cout % 16 == 0))
+                and (epi != H.EPI_LSTM or w.cp.gates == 4) and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP)
                 and C0 + C1 >= _WINO_MIN_CIN and (C1 == 0 or C0 % 8 == 0))
 
 
@@ -308,9 +310,9 @@ class ConvParam:
         L, g = H.lib(), (self.gates if not transposed else 1)
         w = self._cat_w()
         if wino:
-            n = L.ramnet_packed_weight_elems_wino(self.Cout, self.Cin, transposed)
+            n = L.ramnet_packed_weight_elems_wino(self.Cout, self.Cin, transposed, g)
             out = torch.empty(n, device=w.device, dtype=torch.float32)
-            H.check(L.ramnet_pack_weight_wino(_p(w), _p(out), self.Cout, self.Cin, transposed, _st()), "ramnet_pack_weight_wino")
+            H.check(L.ramnet_pack_weight_wino(_p(w), _p(out), self.Cout, self.Cin, transposed, g, _st()), "ramnet_pack_weight_wino")
             return out
         split = _PRECISION == H.PREC_BF16X3
         sizer, packer = (L.ramnet_packed_weight_elems_split, L.ramnet_pack_weight_split) if split else \

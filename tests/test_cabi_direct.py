@@ -81,8 +81,8 @@ def test_winograd_conv_and_wgrad_through_raw_descriptors():
     x = torch.randn(B, H, W, Cin, device=dev)
     w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.1
     b = torch.randn(Cout, device=dev) * 0.1
-    wp = torch.empty(L.ramnet_packed_weight_elems_wino(Cout, Cin, 0), device=dev)
-    assert L.ramnet_pack_weight_wino(ptr(w), ptr(wp), Cout, Cin, 0, st) == 0
+    wp = torch.empty(L.ramnet_packed_weight_elems_wino(Cout, Cin, 0, 1), device=dev)
+    assert L.ramnet_pack_weight_wino(ptr(w), ptr(wp), Cout, Cin, 0, 1, st) == 0
     y = torch.empty(B, H, W, Cout, device=dev)
     d = _hip.ConvDesc()
     d.x0, d.ld0, d.C0, d.in_mode = ptr(x), Cin, Cin, _hip.IN_PLAIN
