@@ -53,8 +53,9 @@ def parse():
     ap.add_argument("--no-overlap-wgrad", dest="overlap_wgrad", action="store_false",
                     help="run backward-weights on the main stream instead of co-scheduling it with backward-data on a side stream "
                          "(the default schedule; per-kernel durations then include co-scheduled time)")
-    ap.add_argument("--overlap-decoder", action="store_true",
-                    help="run the decoders on a second stream, concurrent with the next state update (ops.set_decoder_overlap)")
+    ap.add_argument("--no-overlap-decoder", dest="overlap_decoder", action="store_false",
+                    help="run the decoders on the main stream instead of a second stream concurrent with the next state update "
+                         "(ops.set_decoder_overlap; default schedule)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) overlap / bf16x3 measurements")
     return ap.parse_args()
@@ -328,6 +329,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.on = False
+    agg_timed = timer.summary()          # dominant kernel over the timed region (the extras below reuse the timer)
+    timer.rec = []
     if world > 1:
         t = torch.tensor([dt], device=model.gpu, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,9 +351,24 @@ def main():
             fence()
             e = (time.perf_counter() - t) / n
             return {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach())}
-        ops.set_wgrad_overlap(not args.overlap_wgrad)          # the other schedule
-        extras["single_stream" if args.overlap_wgrad else "overlap_wgrad"] = measure()
+        single = not (args.overlap_wgrad or args.overlap_decoder)          # the other schedule: everything on one stream
+        ops.set_wgrad_overlap(single)
+        ops.set_decoder_overlap(single)
+        if not single and timer.only is not None:      # ... with the dominant kernel bracketed: its un-co-scheduled duration
+            timer.on, timer.rec = True, []
+        extras["multi_stream" if single else "single_stream"] = measure()
+        if timer.on:
+            timer.on = False
+            iso = timer.summary().get(timer.only)
+            timer.rec = []
+            if iso:
+                extras["single_stream"]["dominant_kernel"] = {
+                    "kernel": timer.only, "launches": iso[0], "avg_launch_ms": 1e3 * iso[1] / iso[0],
+                    "achieved": iso[2] / iso[1] / 1e12, "unit": "TFLOP/s", "frac": iso[2] / iso[1] / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                    "note": "same kernel with every launch on ONE stream: the timed region co-schedules three streams, so its "
+                            "per-kernel wall durations include time shared with other kernels"}
         ops.set_wgrad_overlap(args.overlap_wgrad)
+        ops.set_decoder_overlap(args.overlap_decoder)
         if args.precision == "f32":
             ops.set_precision("bf16x3")
             extras["bf16x3_fwd_dgrad"] = dict(measure(), note="forward parity <= 1e-3 vs reference goldens is tested in "
@@ -368,7 +386,8 @@ def main():
                "dtype": "f32" if args.precision == "f32" else "bf16x3(fwd,dgrad)+f32(wgrad)", "data": "synthetic",
                "config": {"workload": "EventScape-shaped 346x260 -> %dx%d crop, 5 event bins, K=5, batch %d/GPU, seq-len %d, "
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam, backward-weights %s"
-                                      % (H, W, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream"),
+                                      % (H, W, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream") +
+                                      (", decoders on a second stream" if args.overlap_decoder and args.mode == "train" else ""),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
                "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
         if args.mode == "stream":
@@ -377,7 +396,7 @@ def main():
                              "state + decode one depth map; samples/s counts frames"}
         if extras:
             out["extras"] = extras
-        agg = timer.summary()
+        agg = agg_timed
         if agg:
             dom = max(agg.items(), key=lambda kv: kv[1][1])
             name, (n, secs, flops) = dom
@@ -397,8 +416,15 @@ def main():
                                                "from profiles/r01_g_pmc_*; gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
                                "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9}
+            iso = extras.get("single_stream", {}).get("dominant_kernel")
+            if iso and iso["kernel"] == name:      # the same kernel without co-scheduled neighbours (single-stream extras pass)
+                out["roofline"].update({"isolated_achieved": iso["achieved"], "isolated_frac": iso["frac"],
+                                        "isolated_avg_launch_ms": iso["avg_launch_ms"],
+                                        "schedule_note": "the timed region runs three streams (main, decoders, backward-weights): achieved/frac use "
+                                                         "wall durations that include time shared with co-scheduled kernels; isolated_* = same "
+                                                         "kernel, same launches, one stream (extras.single_stream)"})
             if "wino" in name:   # Winograd F(2x2,3x3) executes 16/36 of the algorithmic multiplies on the MFMA pipe
-                out["roofline"]["mfma_flop_executed_frac_of_peak"] = ach / 2.25 / F32_MFMA_PEAK_TFLOPS
+                out["roofline"]["mfma_flop_executed_frac_of_peak"] = out["roofline"].get("isolated_achieved", ach) / 2.25 / F32_MFMA_PEAK_TFLOPS
                 out["roofline"]["note"] = ("achieved/frac count the ALGORITHMIC FLOP of the convolution (2*B*H*W*9*Cin*Cout, SURVEY 8d) as the "
                                            "contract asks; the kernel executes 1/2.25 of them (Winograd), see mfma_flop_executed_frac_of_peak")
             src = warm if warm else agg
