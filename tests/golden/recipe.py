@@ -29,3 +29,62 @@ def synth_events(rng, n, W, H, t0=0.0, t1=0.05):
     return ev
 
 
+
+
+def make_dataset_dir(root, n_seq=2, n_frames=14, H=20, W=28, bins=5, seed=0):
+    """A tiny EventScape-shaped directory tree (SURVEY 8f-4 file patterns): per sequence events/voxels/*_{idx:04d}_voxel.npy
+    + timestamps.txt, depth/data/*_{idx:04d}_depth.npy + timestamps.txt, rgb/data/*_{idx:04d}_image.png.  Seeded, so the
+    golden generator and the tests build byte-identical trees."""
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    for s in range(n_seq):
+        base = os.path.join(root, "Town%02d_sequence_%d" % (s + 1, s))
+        ev, dp, im = (os.path.join(base, p) for p in ("events/voxels", "depth/data", "rgb/data"))
+        for d in (ev, dp, im):
+            os.makedirs(d, exist_ok=True)
+        n = n_frames + 2 * s
+        stamps = 12.5 + s + 0.04 * np.arange(n)
+        table = np.stack([np.arange(n, dtype=np.float64), stamps], 1)
+        np.savetxt(os.path.join(ev, "timestamps.txt"), table, fmt="%.6f")
+        np.savetxt(os.path.join(dp, "timestamps.txt"), table, fmt="%.6f")
+        for i in range(n):
+            vox = rng.standard_normal((bins, H, W)).astype(np.float32)
+            vox[rng.random((bins, H, W)) < 0.7] = 0.0                     # sparse, like event grids
+            if i == 3:
+                vox[:] = 0.0                                              # an empty grid: normalisation must leave it alone
+            np.save(os.path.join(ev, "05_%03d_%04d_voxel.npy" % (s, i)), vox)
+            depth = (rng.random((H, W)) ** 3 * 1500.0).astype(np.float32)  # metres, some beyond clip_distance = 1000
+            depth[rng.random((H, W)) < 0.05] = np.nan
+            np.save(os.path.join(dp, "05_%03d_%04d_depth.npy" % (s, i)), depth)
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            Image.fromarray(rgb).save(os.path.join(im, "05_%03d_%04d_image.png" % (s, i)))
+    return root
+
+
+FOLDERS = dict(event_folder="events/voxels", depth_folder="depth/data", frame_folder="rgb/data")
+# (name, sequence index in sorted(os.listdir), item index, RNG seed, transform spec, dataset kwargs)
+DATASET_CASES = [
+    ("ramnet_center", 0, 0, 1, ("center", 16), dict(sequence_length=2, step_size=1, every_x_rgb_frame=3, clip_distance=1000.0,
+                                                    reg_factor=5.70378, loss_composition=["image", "events2"])),
+    ("ramnet_center_i2", 0, 2, 2, ("center", 16), dict(sequence_length=2, step_size=1, every_x_rgb_frame=3, clip_distance=1000.0,
+                                                       reg_factor=5.70378, loss_composition=["image", "events2"])),
+    ("ramnet_train_aug", 1, 1, 3, ("train", 16), dict(sequence_length=3, step_size=2, every_x_rgb_frame=2, clip_distance=1000.0,
+                                                      reg_factor=5.70378, loss_composition=["image", "events1"])),
+    ("ramnet_nocrop_scale", 0, 1, 4, None, dict(sequence_length=2, step_size=1, every_x_rgb_frame=2, clip_distance=80.0,
+                                                reg_factor=3.70378, scale_factor=0.5, normalize=False)),
+    ("baseline_rgb", 0, 1, 5, ("center", 16), dict(sequence_length=2, step_size=1, every_x_rgb_frame=3, clip_distance=1000.0,
+                                                   baseline="rgb", loss_composition="image")),
+    ("baseline_e", 0, 1, 6, ("center", 16), dict(sequence_length=2, step_size=1, every_x_rgb_frame=3, clip_distance=1000.0,
+                                                 baseline="e", loss_composition="image")),
+    ("baseline_ergb0", 0, 0, 7, ("center", 16), dict(sequence_length=3, step_size=1, every_x_rgb_frame=3, clip_distance=1000.0,
+                                                     baseline="ergb0", loss_composition="image")),
+    ("time_window", 1, 0, 8, ("center", 16), dict(sequence_length=2, step_size=1, every_x_rgb_frame=2, clip_distance=1000.0,
+                                                  start_time=0.1, stop_time=0.45)),
+]
+
+
+def flatten_sequence(prefix, seq, out):
+    for l, package in enumerate(seq):
+        for k, v in package.items():
+            out["%s/%d/%s" % (prefix, l, k)] = v.numpy() if v is not None else np.zeros(0, np.float32)

@@ -1,6 +1,7 @@
 """GPU: whole-network parity of the HIP path against (a) golden vectors produced by the reference itself and
 (b) the CPU oracle on the same seeded inputs, including BPTT gradients through the trainer's loss assembly."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -329,3 +330,27 @@ def test_training_trajectory_matches_oracle():
         ora.append(float(lc.detach()))
     np.testing.assert_allclose(hip, ora, rtol=2e-4)
     assert hip[-1] < 0.8 * hip[0], hip
+
+
+def test_training_step_from_a_dataset_directory(tmp_path):
+    """Disk -> rpg_ramnet_amd.data (EventScape file layout) -> DataLoader collation -> HIP model -> SI loss -> backward:
+    the synthetic benchmark's input side replaced by the real loader."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from recipe import FOLDERS, make_dataset_dir
+    from torch.utils.data import DataLoader
+    from rpg_ramnet_amd import data as D
+    from rpg_ramnet_amd.trainer import sequence_loss
+    root = make_dataset_dir(str(tmp_path), n_seq=2, n_frames=16, H=40, W=56)
+    ds = D.concatenate_subfolders(root, "SequenceSynchronizedFramesEventsDataset", sequence_length=2, step_size=2,
+                                  transform=D.Compose([D.RandomRotationFlip(0.0, 0.5, 0.0), D.RandomCrop(32)]),
+                                  clip_distance=1000.0, every_x_rgb_frame=3, reg_factor=5.70378,
+                                  loss_composition=["image", "events2"], **FOLDERS)
+    batch = next(iter(DataLoader(ds, batch_size=2, shuffle=False)))          # list of L dicts of [B,C,H,W] tensors
+    assert len(batch) == 2 and batch[0]["events0"].shape == (2, 5, 32, 32) and batch[0]["image"].shape == (2, 1, 32, 32)
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=3, loss_composition=["image", "events2"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    total, reported = sequence_loss(model, batch, cfg["loss_composition"], [1, 1])
+    total.backward()
+    assert np.isfinite(float(total)) and float(reported) > 0
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
