@@ -43,7 +43,6 @@ struct WgradWinoParams {
     InSrc src;
     int bx_n, ty_n, nbatch;     // batches per row, tile rows per image, total
     int dy0, dx0;               // offset of the first filter tap
-    int stagger;                // s_sleep units (64 clocks) by which every second co-resident workgroup starts late
 };
 
 // XM: the input loader has a second operand for this workgroup's channels (h*r product / ReLU mask); GM: ReLU mask on dy.
@@ -198,17 +197,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
     const int aoff = (ph * 8 * GW_CI + l31) * GW_T + kk * 4;
     const int boff = (ph * 8 * GW_CO + ch * 32 + l31) * GW_T + kk * 4;
 
-    // Two workgroups share a CU and run the identical instruction stream: started together they stay in lockstep — both in
-    // their MFMA phase (sharing the pipe), then both in their transform phase (pipe idle).  The workgroup whose waves sit in
-    // an odd hardware wave slot therefore starts half a period late, so that one's transform runs under the other's MFMAs.
-    if (q.stagger > 0) {
-        const unsigned hw_wave = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
-        const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int mode = q.stagger >> 8;
-        const bool late = mode == 0 ? (hw_wave & 1) : mode == 1 ? (flat & 1) : mode == 2 ? ((flat >> 8) & 1) : mode == 3 ? ((flat >> 3) & 1) : ((flat >> 1) & 1);
-        if (late)
-            for (int i = 0; i < (q.stagger & 255); ++i) __builtin_amdgcn_s_sleep(8);               // 8 x 64 clocks
-    }
     // ---- pipeline: batch list of this workgroup = blockIdx.x, +gridDim.x, ...  The loop body is branch-free: past the end the
     // "next" batch is clamped to the last one (re-staged into buffers nobody reads; its bias contribution is not re-counted).
     const int step = gridDim.x;
@@ -329,8 +317,6 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
-    static const char *stg = getenv("RAMNET_WGRAD_STAGGER");
-    q.stagger = stg ? atoi(stg) : 0;
     const size_t lds = (size_t)(GW_V + GW_Z + GW_XP + GW_YP) * sizeof(float);
     const int gy = cdiv(q.src.Cin, GW_CI), gz = cdiv(d.Cout, GW_CO);
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
