@@ -38,6 +38,9 @@ struct WinoParams {
 
 __device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
+#ifndef WINO_ABLATE   // timing experiments only (tools/wino_trace.hip): 1 = no weight reloads, 2 = no transform / patch traffic,
+#define WINO_ABLATE 0  // 4 = no A-operand fetches, 8 = no barrier; results are then wrong by construction
+#endif
 #ifdef WINO_TRACE   // tools/wino_trace.hip: per-wave timestamps at the phase boundaries of the main loop
 __device__ unsigned long long *g_wino_trace;
 #define WINO_STAMP(slot)                                                                                     \
@@ -221,27 +224,37 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
             __builtin_amdgcn_sched_barrier(0);
             acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bb.x, acc[pos][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#if !(WINO_ABLATE & 1)
             if (pos >= 2 && !(pos & 1)) breg[(pos >> 1) - 1] = ld4(wnext + ((pos >> 1) - 1) * 1024);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bb.x, acc[pos][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (pos + 2 < 16) {
+            if (pos + 2 < 16 && !(WINO_ABLATE & 4)) {
                 aq[(pos + 2) & 3][0] = ld2(vcur + (pos + 2) * (32 * WK) + aoff);
                 aq[(pos + 2) & 3][1] = ld2(vcur + (pos + 2) * (32 * WK) + aoff + 16 * WK);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bb.y, acc[pos][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#if !(WINO_ABLATE & 2)
             side(pos, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bb.y, acc[pos][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#if !(WINO_ABLATE & 2)
             side(pos, 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#if !(WINO_ABLATE & 1)
         breg[7] = ld4(wnext + 7 * 1024);
+#endif
         WINO_STAMP(1);
+#if !(WINO_ABLATE & 8)
         __syncthreads();                           // V(i+1), patch(i+2) visible; V(i), patch(i+1) free
+#endif
     }
 
     { const int chunk = 31; WINO_STAMP(2); }

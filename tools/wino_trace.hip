@@ -13,7 +13,7 @@ int main() {
     const int B = 8, H = 64, W = 86, Cin = 256, Cout = 256;
     float *x, *y, *w;
     const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * H * W * Cout;
-    const size_t nw = ramnet_packed_weight_elems_wino(Cout, Cin, 0);
+    const size_t nw = ramnet_packed_weight_elems_wino(Cout, Cin, 0, 1);
     hipMalloc(&x, nx * 4), hipMalloc(&y, ny * 4), hipMalloc(&w, nw * 4);
     hipMemset(x, 0, nx * 4), hipMemset(w, 0, nw * 4);
     const int nblocks = B * ((H + 7) / 8) * ((W + 15) / 16) * (Cout / 64);
