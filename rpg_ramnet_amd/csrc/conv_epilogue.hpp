@@ -5,8 +5,24 @@
 namespace ramnet {
 
 // value `acc` of output channel n at flattened output pixel `pix` -> bias, activation / residual / GRU blend, store.
-__device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int epi, size_t pix, int n, float acc) {
+// addold: this pixel accumulates beta*out_old into the pre-activation (LINEAR / RELU).  frame == 0: every pixel.  frame > 0
+// (folded upsample-conv): only the top / bottom `frame` rows of the full output; the left / right `frame` columns instead add
+// the side buffer e0 [B][HoF][2*frame][lde0] (columns 0..frame-1 = left edge, frame..2*frame-1 = right edge) — see epilogue_side().
+__device__ __forceinline__ bool epilogue_addold(const ramnet_conv_desc &p, int oyF, int oxF) {
+    if (p.beta == 0.f) return false;
+    return p.frame == 0 || oyF < p.frame || oyF >= p.HoF - p.frame;
+}
+
+__device__ __forceinline__ float epilogue_side(const ramnet_conv_desc &p, int epi, int b, int oyF, int oxF, int n) {
+    if (p.frame == 0 || p.e0 == nullptr || (epi != RAMNET_EPI_RELU && epi != RAMNET_EPI_LINEAR)) return 0.f;
+    if (oxF >= p.frame && oxF < p.WoF - p.frame) return 0.f;
+    const int col = oxF < p.frame ? oxF : oxF - p.WoF + 2 * p.frame;
+    return p.e0[(((size_t)b * p.HoF + oyF) * (2 * p.frame) + col) * p.lde0 + n];
+}
+
+__device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int epi, size_t pix, int n, float acc, bool addold) {
     float v = acc + (p.bias ? p.bias[n] : 0.f);
+    if (addold && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR)) v += p.beta * p.out[pix * p.ldo + n];
     if (epi == RAMNET_EPI_RELU) {
         v = fmaxf(v, 0.f);
     } else if (epi == RAMNET_EPI_SIGMOID) {
@@ -19,15 +35,17 @@ __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int ep
         const float h = p.e1 ? p.e1[pix * p.lde1 + n] : 0.f;
         if (p.o1) p.o1[pix * p.ldo1 + n] = o;
         v = h * (1.0f - u) + o * u;
-    } else if (p.beta != 0.f) {
-        v += p.beta * p.out[pix * p.ldo + n];
     }
     p.out[pix * p.ldo + n] = v;
 }
 
 // Four consecutive output channels n..n+3 of one pixel (all pointers 16-byte aligned, Cout % 4 == 0: checked on the host).
-__device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int epi, size_t pix, int n, float4 acc) {
+__device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int epi, size_t pix, int n, float4 acc, bool addold) {
     float4 v = p.bias ? f4add(acc, ld4(p.bias + n)) : acc;
+    if (addold && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR)) {
+        const float4 old = ld4(p.out + pix * p.ldo + n);
+        v = make_float4(v.x + p.beta * old.x, v.y + p.beta * old.y, v.z + p.beta * old.z, v.w + p.beta * old.w);
+    }
     if (epi == RAMNET_EPI_RELU) {
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     } else if (epi == RAMNET_EPI_SIGMOID) {
@@ -42,9 +60,6 @@ __device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int e
         if (p.o1) st4(p.o1 + pix * p.ldo1 + n, o);
         v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
                         h.w * (1.0f - u.w) + o.w * u.w);
-    } else if (p.beta != 0.f) {
-        const float4 old = ld4(p.out + pix * p.ldo + n);
-        v = make_float4(v.x + p.beta * old.x, v.y + p.beta * old.y, v.z + p.beta * old.z, v.w + p.beta * old.w);
     }
     st4(p.out + pix * p.ldo + n, v);
 }

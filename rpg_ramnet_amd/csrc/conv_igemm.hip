@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             if (oy >= q.Ho || ox >= q.Wo) continue;
             const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + q.ooy)) * p.WoF + (ox * p.osx + q.oox);
+            const bool addold = epilogue_addold(p, oy * p.osy + q.ooy, ox * p.osx + q.oox);
             if (epi == RAMNET_EPI_LSTM) {
                 if constexpr (TN == 4) {
                     // packed N order = (channel block of 32, gate, channel): ns is the gate (i, f, o, g)
@@ -215,7 +216,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
             for (int ns = 0; ns < TN; ++ns) {
                 const int n = n0 + (wn * TN + ns) * 32 + l31;
                 if (n >= p.Cout) continue;
-                epilogue_store(p, epi, pix, n, acc[ms][ns][r]);
+                epilogue_store(p, epi, pix, n, acc[ms][ns][r] + epilogue_side(p, epi, b, oy * p.osy + q.ooy, ox * p.osx + q.oox, n), addold);
             }
         }
     }
@@ -262,6 +263,7 @@ static int check_desc(const ramnet_conv_desc &d) {
     if (d.epi == RAMNET_EPI_GRU_BLEND) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
     RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 || d.precision == RAMNET_PREC_BF16X3);
+    RAMNET_CHECK_ARG(d.frame >= 0);
     return 0;
 }
 

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
                     const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + c;
                     if (oy >= p.Ho || ox >= p.Wo) continue;
                     const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
-                    epilogue_store(p, epi, pix, n, y[a][c]);
+                    epilogue_store(p, epi, pix, n, y[a][c], epilogue_addold(p, oy * p.osy + p.ooy, ox * p.osx + p.oox));
                 }
         }
     }
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
             const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), nq = n0 + qd * 4;
             if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
             const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
-            epilogue_store4(p, epi, pix, nq, ld4(O + pxl * OLD + qd * 4));
+            epilogue_store4(p, epi, pix, nq, ld4(O + pxl * OLD + qd * 4), epilogue_addold(p, oy * p.osy + p.ooy, ox * p.osx + p.oox));
         }
     }
     { const int chunk = 31; WINO_STAMP(3); }

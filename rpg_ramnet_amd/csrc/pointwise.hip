@@ -244,6 +244,69 @@ __global__ void upsample2x_bwd_kernel(const float *__restrict__ dup, float *__re
     }
 }
 
+// ---- folded upsample-conv helpers ---------------------------------------------------------------------------------
+// replicate-padded sum: out[b][i+2][j+2] = (x + skip)[clamp i][clamp j]
+__global__ void pad2_sum_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ out, int B, int H, int W, int C) {
+    const int C4 = C / 4, Hp = H + 4, Wp = W + 4;
+    const size_t total = (size_t)B * Hp * Wp * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        size_t j = i / C4;
+        const int xx = (int)(j % Wp);
+        j /= Wp;
+        const int yy = (int)(j % Hp), b = (int)(j / Hp);
+        const int sy = min(max(yy - 2, 0), H - 1), sx = min(max(xx - 2, 0), W - 1);
+        const size_t src = (((size_t)b * H + sy) * W + sx) * C + c;
+        float4 v = ld4(x + src);
+        if (skip) v = f4add(v, ld4(skip + src));
+        st4(out + i * 4, v);
+    }
+}
+
+// u(r, c) = bilinear x2 upsample of (x + skip) at high-res pixel (r, c) INSIDE the image (F.interpolate, align_corners=False)
+__device__ __forceinline__ float4 up2x_at(const float *__restrict__ x, const float *__restrict__ skip, int b, int H, int W, int C,
+                                          int r, int c, int ch) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    up2x_coord(r, H, y0, y1, ly);
+    up2x_coord(c, W, x0, x1, lx);
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const size_t r0 = ((size_t)b * H + y0) * W, r1 = ((size_t)b * H + y1) * W;
+    float4 v00 = ld4(x + (r0 + x0) * C + ch), v01 = ld4(x + (r0 + x1) * C + ch);
+    float4 v10 = ld4(x + (r1 + x0) * C + ch), v11 = ld4(x + (r1 + x1) * C + ch);
+    if (skip) {
+        v00 = f4add(v00, ld4(skip + (r0 + x0) * C + ch)), v01 = f4add(v01, ld4(skip + (r0 + x1) * C + ch));
+        v10 = f4add(v10, ld4(skip + (r1 + x0) * C + ch)), v11 = f4add(v11, ld4(skip + (r1 + x1) * C + ch));
+    }
+    const float4 top = f4add(f4scale(v00, hx), f4scale(v01, lx)), bot = f4add(f4scale(v10, hx), f4scale(v11, lx));
+    return f4add(f4scale(top, hy), f4scale(bot, ly));
+}
+
+// Three-pixel-wide band of ring(r, c) = u(clamp r, clamp c) outside the 2H x 2W image and 0 inside:
+// side 0: rows -2, -1, 0 x cols -2 .. 2W+1;  1: rows 2H-1, 2H, 2H+1;  2: rows 0 .. 2H-1 x cols -2, -1, 0;  3: cols 2W-1, 2W, 2W+1.
+// (The in-image row / column of each band is the zero row the restricted tap lists of the band launches run into.)
+__global__ void up2x_ring_band_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ band, int B, int H,
+                                      int W, int C, int side) {
+    const int C4 = C / 4, H2 = 2 * H, W2 = 2 * W;
+    const int bh = side < 2 ? 3 : H2, bw = side < 2 ? W2 + 4 : 3;
+    const int r0 = side == 0 ? -2 : side == 1 ? H2 - 1 : 0, c0 = side < 2 ? -2 : side == 2 ? -2 : W2 - 1;
+    const size_t total = (size_t)B * bh * bw * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C4) * 4;
+        size_t j = i / C4;
+        const int cc = (int)(j % bw);
+        j /= bw;
+        const int rr = (int)(j % bh), b = (int)(j / bh);
+        const int r = r0 + rr, c = c0 + cc;
+        // top / bottom bands carry every tap whose ROW is outside (any column); left / right the taps whose row is inside and
+        // whose COLUMN is outside: together each removed tap exactly once
+        const bool on = side < 2 ? (r < 0 || r >= H2) : (c < 0 || c >= W2);
+        float4 v = f4zero();
+        if (on) v = up2x_at(x, skip, b, H, W, C, min(max(r, 0), H2 - 1), min(max(c, 0), W2 - 1), ch);
+        st4(band + i * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ GRU / LSTM backward maps
 // ur = [u | r] (2C per pixel).  dpur = [dpu | dpr].
 __global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__restrict__ ur, const float *__restrict__ o,
@@ -351,7 +414,7 @@ extern "C" size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, 
 }
 
 extern "C" int ramnet_pack_weight(const float *w, float *wp, int Cout, int Cin, int KH, int KW, int transposed, int gates, void *stream) {
-    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 25);
+    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 64);      // (64 = the folded upsample-conv: 4 parities x 16 taps)
     RAMNET_CHECK_ARG(gates == 1 || (gates == 4 && !transposed && Cout % 4 == 0));
     int R, N, nchunks, NPad;
     pack_geometry(Cout, Cin, transposed, gates, R, N, nchunks, NPad);
@@ -432,6 +495,21 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
 extern "C" int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream) {
     RAMNET_CHECK_ARG(dup && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dup, dx, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pad2_sum(const float *x, const float *skip, float *out, int B, int H, int W, int C, void *stream) {
+    RAMNET_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    hipLaunchKernelGGL(pad2_sum_kernel, dim3(grid_for((size_t)B * (H + 4) * (W + 4) * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, skip, out, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_up2x_ring_band(const float *x, const float *skip, float *band, int B, int H, int W, int C, int side, void *stream) {
+    RAMNET_CHECK_ARG(x && band && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && side >= 0 && side < 4);
+    const size_t n = (size_t)B * (side < 2 ? 3 * (2 * W + 4) : 2 * H * 3) * (C / 4);
+    hipLaunchKernelGGL(up2x_ring_band_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, band, B, H, W, C, side);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

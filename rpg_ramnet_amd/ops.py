@@ -47,6 +47,22 @@ def get_winograd():
     return _WINOGRAD
 
 
+# UpsampleConvLayer forward as four 4x4 parity convolutions of the low-resolution input (16 instead of 25 MACs per output,
+# no interpolation in the loader).  Opt-in (RAMNET_FOLD_UPSAMPLE=1 / set_fold_upsample(True)): the
+# folded launch itself is 1.5-1.6x faster than the direct kernel, but the four border-band launches are latency-bound
+# (30-90 us each, not overlapped across streams), so the whole op only wins on maps of >= 256 x 344 output pixels today.
+_FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "0") == "1"
+
+
+def set_fold_upsample(on):
+    global _FOLD_UP
+    _FOLD_UP = bool(on)
+
+
+def get_fold_upsample():
+    return _FOLD_UP
+
+
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -96,6 +112,18 @@ class Taps:
                 tr = [((py + pad - kh) // 2, (px + pad - kw) // 2, kh * k + kw)
                       for kh in range(k) for kw in range(k)
                       if (py + pad - kh) % 2 == 0 and (px + pad - kw) % 2 == 0]
+            elif kind == "valid":     # un-padded window: in(o + kh)
+                tr = [(kh, kw, kh * k + kw) for kh in range(k) for kw in range(k)]
+            elif kind == "band_rows_lo":     # border bands of the folded upsample-conv: the taps whose ROW falls above the image,
+                tr = [(kh, kw, kh * k + kw) for kh in (0, 1) for kw in range(k)]                     # on a 3-row band (rows -2,-1,0)
+            elif kind == "band_rows_hi":     # ... below it (band rows 2H-1, 2H, 2H+1)
+                tr = [(kh - 3, kw, kh * k + kw) for kh in (3, 4) for kw in range(k)]
+            elif kind == "band_cols_lo":     # ... whose COLUMN falls left of it while the row is inside (zero rows by padding)
+                tr = [(kh - pad, kw, kh * k + kw) for kh in range(k) for kw in (0, 1)]
+            elif kind == "band_cols_hi":
+                tr = [(kh - pad, kw - 3, kh * k + kw) for kh in range(k) for kw in (3, 4)]
+            elif kind == "fold":      # parity class (py, px) of the folded upsample-conv on the replicate-padded (by 2) low-res
+                tr = [(py + ty, px + tx, (py * 2 + px) * 16 + ty * 4 + tx) for ty in range(4) for tx in range(4)]   # input
             else:
                 raise KeyError(kind)
             cls._cache[key] = cls(tr)
@@ -130,7 +158,7 @@ def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
 
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
-                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0):
+                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0):
     B = x0.shape[0]
     d = H.ConvDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
@@ -149,7 +177,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.HoF, d.WoF = out.shape[1], out.shape[2]
     d.Ho, d.Wo = (d.HoF if Ho is None else Ho), (d.WoF if Wo is None else Wo)
     d.osy, d.osx, d.ooy, d.oox = os
-    d.epi, d.beta = epi, beta
+    d.epi, d.beta, d.frame = epi, beta, frame
     d.e0, d.e1 = _p(e0), _p(e1)
     d.lde0, d.lde1 = (ld(e0) if e0 is not None else 0), (ld(e1) if e1 is not None else 0)
     d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
@@ -216,6 +244,16 @@ def decode_stream(dev):
     if st is None:
         st = _DECODE[dev] = torch.cuda.Stream(device=dev)
     _DECODE_USED.add(dev)
+    return st
+
+
+_BAND = {}
+
+
+def _band_stream(dev, i):
+    st = _BAND.get((dev, i))
+    if st is None:
+        st = _BAND[(dev, i)] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -334,6 +372,38 @@ class ConvParam:
     def fwd(self):
         return PackRef(self, 0)
 
+    # -- folded upsample-conv (5x5 after bilinear x2): effective 4x4 kernels of the four output parities ------------------
+    # high-res row 2i + p + k - 2 (k = 0..4) is 0.25 / 0.75 of two low-res rows; A[p][t][k] = weight of low-res row
+    # i + p - 2 + t (t = 0..3) in tap k.
+    _FOLD_A = ([[.25, 0, 0, 0, 0], [.75, .75, .25, 0, 0], [0, .25, .75, .75, .25], [0, 0, 0, .25, .75]],
+               [[.75, .25, 0, 0, 0], [.25, .75, .75, .25, 0], [0, 0, .25, .75, .75], [0, 0, 0, 0, .25]])
+
+    def pack_fold(self):
+        """[64 = (py, px, ty, tx)] tap slices W4 = A_py w A_px^T in the direct kernel's layout (float64 accumulation)."""
+        v = (self._versions(self.weights), "fold")
+        hit = self._packs.get("fold")
+        if hit is None or hit[0] != v:
+            w = self._cat_w().double()
+            A = torch.tensor(self._FOLD_A, dtype=torch.float64, device=w.device)           # [p][t][k]
+            w4 = torch.einsum("ptk,qsl,oikl->oipqts", A, A, w).reshape(self.Cout, self.Cin, 8, 8).float().contiguous()
+            L = H.lib()
+            out = torch.empty(L.ramnet_packed_weight_elems(self.Cout, self.Cin, 8, 8, 0, 1), device=w.device)
+            H.check(L.ramnet_pack_weight(_p(w4), _p(out), self.Cout, self.Cin, 8, 8, 0, 1, _st()), "ramnet_pack_weight")
+            hit = self._packs["fold"] = (v, out)
+        return hit[1]
+
+    def pack_neg(self):
+        """Direct-kernel pack of -w: the border-band launches subtract what the folded kernels over-count at the image edge."""
+        v = (self._versions(self.weights), "neg")
+        hit = self._packs.get("neg")
+        if hit is None or hit[0] != v:
+            w = (-self._cat_w()).contiguous()
+            L = H.lib()
+            out = torch.empty(L.ramnet_packed_weight_elems(self.Cout, self.Cin, self.k, self.k, 0, 1), device=w.device)
+            H.check(L.ramnet_pack_weight(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, 0, 1, _st()), "ramnet_pack_weight")
+            hit = self._packs["neg"] = (v, out)
+        return hit[1]
+
     def bwd(self):
         return PackRef(self, 1)
 
@@ -390,6 +460,48 @@ def pack_input(x, device):
     return out
 
 
+def _folded_upsample_conv(x, skip, cp, y, epi):
+    """y = act(conv5x5_zero_padded(up2x(x + skip)) + b) without ever forming the upsampled image:
+    (1) the 2-pixel frame of y receives MINUS the contribution of the taps that the zero padding removes — four thin "valid"
+        launches of the direct kernel on bands of the replicate-extended upsample (which is what step 2 implicitly uses);
+    (2) ONE multi-class launch: each output parity is a 4x4 convolution of the replicate-padded low-res sum, 16 taps instead
+        of 25, plain loads; its epilogue adds the frame written by (1) before bias / activation."""
+    L = H.lib()
+    B, Hh, W, Cc = x.shape
+    dev = x.device
+    xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
+    H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
+    neg = cp.pack_neg()
+    H2, W2 = 2 * Hh, 2 * W
+    # (band shape, tap list, target, output rows x cols, output origin): only the taps the zero padding removes.  Row bands write
+    # the top / bottom two rows of y itself; column bands a side buffer [B][2H][4][Cout] (left | right), because the corner
+    # pixels receive both and the four launches run concurrently.
+    side_buf = torch.empty(B, H2, 4, cp.Cout, device=dev)
+    plan = [((3, W2 + 4), "band_rows_lo", y, (2, W2), (0, 0)), ((3, W2 + 4), "band_rows_hi", y, (2, W2), (H2 - 2, 0)),
+            ((H2, 3), "band_cols_lo", side_buf, (H2, 2), (0, 0)), ((H2, 3), "band_cols_hi", side_buf, (H2, 2), (0, 2))]
+    main = torch.cuda.current_stream()
+    bands = []
+    for side, ((bh, bw), _, _, _, _) in enumerate(plan):
+        band = torch.empty(B, bh, bw, Cc, device=dev)
+        H.check(L.ramnet_up2x_ring_band(_p(x), _p(skip), _p(band), B, Hh, W, Cc, side, _st()), "ramnet_up2x_ring_band")
+        bands.append(band)
+    # the four band launches are short serial chains on a handful of workgroups: run them side by side
+    ready = main.record_event()
+    for side, (_, kind, target, (Ho, Wo), (oy, ox)) in enumerate(plan):
+        st = _band_stream(dev, side)
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            conv_launch(bands[side], Taps.get(kind, 5, 2), neg, target, cp.Cout, Ho=Ho, Wo=Wo, os=(1, 1, oy, ox), epi=H.EPI_LINEAR)
+        bands[side].record_stream(st)
+        main.wait_event(st.record_event())
+    for st_i in range(4):
+        side_buf.record_stream(_band_stream(dev, st_i))
+        y.record_stream(_band_stream(dev, st_i))
+    conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
+                      [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)],
+                      bias=cp.bias(), epi=epi, beta=1.0, frame=2, e0=side_buf)
+
+
 class ConvAct(Function):
     """ConvLayer / UpsampleConvLayer (submodules.py:8-35, 69-97): [bilinear x2 of (x [+ skip])] -> KxK conv -> bias -> [ReLU]."""
 
@@ -406,8 +518,12 @@ class ConvAct(Function):
         Ho, Wo = (Hin + 2 * pad - k) // stride + 1, (Win + 2 * pad - k) // stride + 1
         y = torch.empty(B, Ho, Wo, cp.Cout, device=x.device)
         mode = (H.IN_UP2X_SKIP if skip is not None else H.IN_UP2X) if up else H.IN_PLAIN
-        conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
-                    Hin=Hin, Win=Win, bias=cp.bias(), epi=H.EPI_RELU if relu else H.EPI_LINEAR)
+        epi = H.EPI_RELU if relu else H.EPI_LINEAR
+        if up and k == 5 and stride == 1 and _FOLD_UP and _PRECISION == H.PREC_F32 and Hh >= 4 and W >= 4:
+            _folded_upsample_conv(x, skip, cp, y, epi)
+        else:
+            conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
+                        Hin=Hin, Win=Win, bias=cp.bias(), epi=epi)
         ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode = cp, stride, relu, up, mode
         ctx.save_for_backward(x, skip, y)
         return y

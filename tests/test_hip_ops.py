@@ -76,9 +76,20 @@ def test_head_conv_padded_input(cin):
     assert_close(m.conv2d.bias.grad.cpu().numpy(), b.grad.numpy(), TOL, "head db")
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 8, 16), (1, 5, 11), (2, 16, 24)])
+@pytest.fixture(params=["folded", "direct"])
+def upsample_algo(request):
+    """UpsampleConvLayer forward: four 4x4 parity convolutions of the low-res input (default) and the direct 5x5 kernel with the
+    bilinear loader, both against the oracle."""
+    from rpg_ramnet_amd import ops
+    old = ops.get_fold_upsample()
+    ops.set_fold_upsample(request.param == "folded")
+    yield request.param
+    ops.set_fold_upsample(old)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 16), (1, 5, 11), (2, 16, 24), (1, 4, 4), (1, 32, 43)])
 @pytest.mark.parametrize("cin,cout,skip", [(64, 32, True), (64, 32, False), (256, 128, True)])
-def test_upsample_conv(B, H, W, cin, cout, skip):
+def test_upsample_conv(B, H, W, cin, cout, skip, upsample_algo):
     from rpg_ramnet_amd.model.submodules import UpsampleConvLayer
     torch.manual_seed(3)
     m = UpsampleConvLayer(cin, cout, 5, padding=2)

@@ -87,7 +87,10 @@ def main():
             y = torch.empty(B, Hin, Win, cout, device=dev)
             dy = torch.randn_like(y)
             dx = torch.empty(B, Hin, Win, cin, device=dev)
-            f = lambda: ops.conv_launch(x, taps, cp.fwd(), y, cout, x1=s, in_mode=H.IN_UP2X_SKIP, Hin=Hin, Win=Win, bias=b, epi=H.EPI_RELU)  # noqa: E731
+            if ops.get_fold_upsample():     # four 4x4 parity convolutions of the low-res sum + border bands (ops._folded_upsample_conv)
+                f = lambda: ops._folded_upsample_conv(x, s, cp, y, H.EPI_RELU)  # noqa: E731
+            else:
+                f = lambda: ops.conv_launch(x, taps, cp.fwd(), y, cout, x1=s, in_mode=H.IN_UP2X_SKIP, Hin=Hin, Win=Win, bias=b, epi=H.EPI_RELU)  # noqa: E731
             d = lambda: ops.conv_launch(dy, tapsd, cp.bwd(), dx, cin, xm=y, in_mode=H.IN_RELUMASK)  # noqa: E731
             g = lambda: ops.wgrad_launch(x, taps, dy, ws, cout, x1=s, in_mode=H.IN_UP2X_SKIP, Hin=Hin, Win=Win, gmask=y, dbias=bws)  # noqa: E731
         else:
