@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 5
+#define RAMNET_ABI_VERSION 6
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -79,9 +79,9 @@ typedef struct ramnet_conv_desc {
     int ldo, ldo1, ldo2;
     int precision;                  /* RAMNET_PREC_F32 (exact fp32 MFMA) or RAMNET_PREC_BF16X3 (w packed with split=1) */
     int algo;                       /* RAMNET_ALGO_DIRECT or RAMNET_ALGO_WINOGRAD (F32 only)                     */
-    int frame;                      /* 0: beta*out_old is added (before the activation; LINEAR and RELU) at every pixel.
-                                     * > 0 (folded upsample-conv): only in the top / bottom `frame` rows of the FULL output,
-                                     * and the left / right `frame` columns add e0 [B][HoF][2*frame][lde0] instead      */
+    int frame;                      /* > 0 (folded upsample-conv, LINEAR / RELU epilogues): border corrections are added to the
+                                     * pre-activation of the outermost `frame` (= 2) rows / columns of the FULL output:
+                                     * rows from e1 [2 sides][B][WoF][lde1 = frame*Cout], columns from e0 [2][B][HoF][lde0]  */
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
@@ -152,10 +152,10 @@ int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *
 /* Folded upsample-conv (UpsampleConvLayer forward as four 4x4 parity convolutions of the LOW-resolution input):
  * out[b][i+2][j+2][c] = (x + skip)[clamp(i)][clamp(j)] for i in [-2, H+1], j in [-2, W+1]  (skip may be NULL).       */
 int ramnet_pad2_sum(const float *x, const float *skip, float *out, int B, int H, int W, int C, void *stream);
-/* One 3-pixel band of ring = (replicate extension of up2x(x + skip)) outside the 2H x 2W image, 0 inside:
- * side 0 top [B][3][2W+4][C] (rows -2..0), 1 bottom (rows 2H-1..2H+1), 2 left [B][2H][3][C] (cols -2..0; rows outside the image
- * belong to the top / bottom bands), 3 right (cols 2W-1..2W+1).                                                        */
-int ramnet_up2x_ring_band(const float *x, const float *skip, float *band, int B, int H, int W, int C, int side, void *stream);
+/* Border lines of u = up2x(x + skip) unrolled along the 5 filter taps, the A operands of the border-correction GEMMs:
+ * rows [2][B*2W][5][C] (top / bottom image row, columns clamped), cols [2][B*2H][5][C] (left / right image column, rows outside
+ * the image zero).                                                                                                      */
+int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, float *cols, int B, int H, int W, int C, void *stream);
 /* Adjoint of the bilinear x2 upsample: dup [B,2H,2W,C] -> dx [B,H,W,C] (backward of submodules.py:88). */
 int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream);
 /* ConvGRU backward, point-wise parts (derivation in DESIGN.md):

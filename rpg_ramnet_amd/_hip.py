@@ -64,7 +64,7 @@ _SIGS = {
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 4),
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_pad2_sum": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
-    "ramnet_up2x_ring_band": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_up2x_border_im2col": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
     "ramnet_unpack_wgrad_wino": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
@@ -116,7 +116,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 5:
+        if l.ramnet_abi_version() != 6:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

@@ -5,19 +5,24 @@
 namespace ramnet {
 
 // value `acc` of output channel n at flattened output pixel `pix` -> bias, activation / residual / GRU blend, store.
-// addold: this pixel accumulates beta*out_old into the pre-activation (LINEAR / RELU).  frame == 0: every pixel.  frame > 0
-// (folded upsample-conv): only the top / bottom `frame` rows of the full output; the left / right `frame` columns instead add
-// the side buffer e0 [B][HoF][2*frame][lde0] (columns 0..frame-1 = left edge, frame..2*frame-1 = right edge) — see epilogue_side().
-__device__ __forceinline__ bool epilogue_addold(const ramnet_conv_desc &p, int oyF, int oxF) {
-    if (p.beta == 0.f) return false;
-    return p.frame == 0 || oyF < p.frame || oyF >= p.HoF - p.frame;
-}
+// addold: this pixel accumulates beta*out_old into the pre-activation (LINEAR / RELU)
+__device__ __forceinline__ bool epilogue_addold(const ramnet_conv_desc &p, int oyF, int oxF) { return p.beta != 0.f; }
 
+// Border corrections of the folded upsample-conv (ramnet_conv_desc.frame > 0): the outermost `frame` rows add
+// e1[side][b][oxF][slot*Cout + n] (side 0 top / 1 bottom, slot = distance into the band), the outermost columns
+// e0[side][b][oyF][slot*Cout + n] (left / right); corner pixels get both.
 __device__ __forceinline__ float epilogue_side(const ramnet_conv_desc &p, int epi, int b, int oyF, int oxF, int n) {
-    if (p.frame == 0 || p.e0 == nullptr || (epi != RAMNET_EPI_RELU && epi != RAMNET_EPI_LINEAR)) return 0.f;
-    if (oxF >= p.frame && oxF < p.WoF - p.frame) return 0.f;
-    const int col = oxF < p.frame ? oxF : oxF - p.WoF + 2 * p.frame;
-    return p.e0[(((size_t)b * p.HoF + oyF) * (2 * p.frame) + col) * p.lde0 + n];
+    if (p.frame == 0 || (epi != RAMNET_EPI_RELU && epi != RAMNET_EPI_LINEAR)) return 0.f;
+    float v = 0.f;
+    if (oyF < p.frame || oyF >= p.HoF - p.frame) {
+        const int side = oyF < p.frame ? 0 : 1, slot = side ? oyF - (p.HoF - p.frame) : oyF;
+        v += p.e1[(((size_t)side * p.B + b) * p.WoF + oxF) * p.lde1 + slot * p.Cout + n];
+    }
+    if (oxF < p.frame || oxF >= p.WoF - p.frame) {
+        const int side = oxF < p.frame ? 0 : 1, slot = side ? oxF - (p.WoF - p.frame) : oxF;
+        v += p.e0[(((size_t)side * p.B + b) * p.HoF + oyF) * p.lde0 + slot * p.Cout + n];
+    }
+    return v;
 }
 
 __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int epi, size_t pix, int n, float acc, bool addold) {

@@ -264,6 +264,7 @@ static int check_desc(const ramnet_conv_desc &d) {
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
     RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 || d.precision == RAMNET_PREC_BF16X3);
     RAMNET_CHECK_ARG(d.frame >= 0);
+    if (d.frame > 0) RAMNET_CHECK_ARG(d.e0 && d.e1 && (d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR));
     return 0;
 }
 

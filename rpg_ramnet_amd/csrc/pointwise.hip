@@ -282,28 +282,32 @@ __device__ __forceinline__ float4 up2x_at(const float *__restrict__ x, const flo
     return f4add(f4scale(top, hy), f4scale(bot, ly));
 }
 
-// Three-pixel-wide band of ring(r, c) = u(clamp r, clamp c) outside the 2H x 2W image and 0 inside:
-// side 0: rows -2, -1, 0 x cols -2 .. 2W+1;  1: rows 2H-1, 2H, 2H+1;  2: rows 0 .. 2H-1 x cols -2, -1, 0;  3: cols 2W-1, 2W, 2W+1.
-// (The in-image row / column of each band is the zero row the restricted tap lists of the band launches run into.)
-__global__ void up2x_ring_band_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ band, int B, int H,
-                                      int W, int C, int side) {
+// Border lines of u = up2x(x + skip), unrolled along the 5 taps (im2col) for the border-correction GEMMs of the folded
+// upsample-conv:  rows [2 sides][B*2W][5][C]: side 0/1 = top/bottom image row, entry (o_x, kx) = u[row][clamp(o_x + kx - 2)];
+//                 cols [2 sides][B*2H][5][C]: side 0/1 = left/right image column, entry (o_y, ky) = u[o_y + ky - 2][col], 0 outside.
+__global__ void up2x_border_im2col_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ rows,
+                                          float *__restrict__ cols, int B, int H, int W, int C) {
     const int C4 = C / 4, H2 = 2 * H, W2 = 2 * W;
-    const int bh = side < 2 ? 3 : H2, bw = side < 2 ? W2 + 4 : 3;
-    const int r0 = side == 0 ? -2 : side == 1 ? H2 - 1 : 0, c0 = side < 2 ? -2 : side == 2 ? -2 : W2 - 1;
-    const size_t total = (size_t)B * bh * bw * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % C4) * 4;
-        size_t j = i / C4;
-        const int cc = (int)(j % bw);
-        j /= bw;
-        const int rr = (int)(j % bh), b = (int)(j / bh);
-        const int r = r0 + rr, c = c0 + cc;
-        // top / bottom bands carry every tap whose ROW is outside (any column); left / right the taps whose row is inside and
-        // whose COLUMN is outside: together each removed tap exactly once
-        const bool on = side < 2 ? (r < 0 || r >= H2) : (c < 0 || c >= W2);
+    const size_t nrows = (size_t)2 * B * W2 * 5 * C4, ncols = (size_t)2 * B * H2 * 5 * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nrows + ncols; i += (size_t)gridDim.x * blockDim.x) {
+        const bool isrow = i < nrows;
+        size_t j = isrow ? i : i - nrows;
+        const int ch = (int)(j % C4) * 4;
+        j /= C4;
+        const int k = (int)(j % 5);
+        j /= 5;
+        const int L = isrow ? W2 : H2;
+        const int o = (int)(j % L);
+        j /= L;
+        const int b = (int)(j % B), side = (int)(j / B);
         float4 v = f4zero();
-        if (on) v = up2x_at(x, skip, b, H, W, C, min(max(r, 0), H2 - 1), min(max(c, 0), W2 - 1), ch);
-        st4(band + i * 4, v);
+        if (isrow) {
+            v = up2x_at(x, skip, b, H, W, C, side ? H2 - 1 : 0, min(max(o + k - 2, 0), W2 - 1), ch);
+        } else {
+            const int r = o + k - 2;
+            if (r >= 0 && r < H2) v = up2x_at(x, skip, b, H, W, C, r, side ? W2 - 1 : 0, ch);
+        }
+        st4((isrow ? rows : cols) + (isrow ? i : i - nrows) * 4, v);
     }
 }
 
@@ -506,10 +510,10 @@ extern "C" int ramnet_pad2_sum(const float *x, const float *skip, float *out, in
     return 0;
 }
 
-extern "C" int ramnet_up2x_ring_band(const float *x, const float *skip, float *band, int B, int H, int W, int C, int side, void *stream) {
-    RAMNET_CHECK_ARG(x && band && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && side >= 0 && side < 4);
-    const size_t n = (size_t)B * (side < 2 ? 3 * (2 * W + 4) : 2 * H * 3) * (C / 4);
-    hipLaunchKernelGGL(up2x_ring_band_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, band, B, H, W, C, side);
+extern "C" int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, float *cols, int B, int H, int W, int C, void *stream) {
+    RAMNET_CHECK_ARG(x && rows && cols && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
+    hipLaunchKernelGGL(up2x_border_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, rows, cols, B, H, W, C);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

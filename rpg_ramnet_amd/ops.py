@@ -48,10 +48,9 @@ def get_winograd():
 
 
 # UpsampleConvLayer forward as four 4x4 parity convolutions of the low-resolution input (16 instead of 25 MACs per output,
-# no interpolation in the loader).  Opt-in (RAMNET_FOLD_UPSAMPLE=1 / set_fold_upsample(True)): the
-# folded launch itself is 1.5-1.6x faster than the direct kernel, but the four border-band launches are latency-bound
-# (30-90 us each, not overlapped across streams), so the whole op only wins on maps of >= 256 x 344 output pixels today.
-_FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "0") == "1"
+# no interpolation in the loader) plus small border-correction GEMMs.  RAMNET_FOLD_UPSAMPLE=0 /
+# set_fold_upsample(False) keeps the direct 5x5 kernel with the bilinear loader.
+_FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
 
 
 def set_fold_upsample(on):
@@ -112,16 +111,6 @@ class Taps:
                 tr = [((py + pad - kh) // 2, (px + pad - kw) // 2, kh * k + kw)
                       for kh in range(k) for kw in range(k)
                       if (py + pad - kh) % 2 == 0 and (px + pad - kw) % 2 == 0]
-            elif kind == "valid":     # un-padded window: in(o + kh)
-                tr = [(kh, kw, kh * k + kw) for kh in range(k) for kw in range(k)]
-            elif kind == "band_rows_lo":     # border bands of the folded upsample-conv: the taps whose ROW falls above the image,
-                tr = [(kh, kw, kh * k + kw) for kh in (0, 1) for kw in range(k)]                     # on a 3-row band (rows -2,-1,0)
-            elif kind == "band_rows_hi":     # ... below it (band rows 2H-1, 2H, 2H+1)
-                tr = [(kh - 3, kw, kh * k + kw) for kh in (3, 4) for kw in range(k)]
-            elif kind == "band_cols_lo":     # ... whose COLUMN falls left of it while the row is inside (zero rows by padding)
-                tr = [(kh - pad, kw, kh * k + kw) for kh in range(k) for kw in (0, 1)]
-            elif kind == "band_cols_hi":
-                tr = [(kh - pad, kw - 3, kh * k + kw) for kh in range(k) for kw in (3, 4)]
             elif kind == "fold":      # parity class (py, px) of the folded upsample-conv on the replicate-padded (by 2) low-res
                 tr = [(py + ty, px + tx, (py * 2 + px) * 16 + ty * 4 + tx) for ty in range(4) for tx in range(4)]   # input
             else:
@@ -244,16 +233,6 @@ def decode_stream(dev):
     if st is None:
         st = _DECODE[dev] = torch.cuda.Stream(device=dev)
     _DECODE_USED.add(dev)
-    return st
-
-
-_BAND = {}
-
-
-def _band_stream(dev, i):
-    st = _BAND.get((dev, i))
-    if st is None:
-        st = _BAND[(dev, i)] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -392,16 +371,24 @@ class ConvParam:
             hit = self._packs["fold"] = (v, out)
         return hit[1]
 
-    def pack_neg(self):
-        """Direct-kernel pack of -w: the border-band launches subtract what the folded kernels over-count at the image edge."""
-        v = (self._versions(self.weights), "neg")
-        hit = self._packs.get("neg")
+    def border_weights(self):
+        """(Wrows [2][5*Cin][2*Cout], Wcols [2][5*Cin][2*Cout]): MINUS the sums of the taps that the zero padding of the 5x5 conv
+        removes at the image border — rows: side 0 = top (slot 0: output row 0 loses ky in {0,1}, slot 1: row 1 loses ky = 0),
+        side 1 = bottom (rows 2H-2 / 2H-1 lose ky = 4 / ky in {3,4}), K index = (kx, ci); columns likewise with ky <-> kx."""
+        v = (self._versions(self.weights), "border")
+        hit = self._packs.get("border")
         if hit is None or hit[0] != v:
-            w = (-self._cat_w()).contiguous()
-            L = H.lib()
-            out = torch.empty(L.ramnet_packed_weight_elems(self.Cout, self.Cin, self.k, self.k, 0, 1), device=w.device)
-            H.check(L.ramnet_pack_weight(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, 0, 1, _st()), "ramnet_pack_weight")
-            hit = self._packs["neg"] = (v, out)
+            w = self._cat_w()                                              # [co][ci][ky][kx]
+            lost = [[(0, 1), (0,)], [(4,), (3, 4)]]                        # [side][slot] -> tap indices outside the image
+
+            def mats(wk):                                                  # wk[co][ci][a][b]: `a` is the lost direction
+                out = []
+                for side in range(2):
+                    slots = [-sum(wk[:, :, a, :] for a in lost[side][slot]) for slot in range(2)]      # [co][ci][b]
+                    m = torch.stack(slots, 0).permute(3, 2, 0, 1)          # [b][ci][slot][co]
+                    out.append(m.reshape(5 * self.Cin, 2 * self.Cout))
+                return torch.stack(out, 0).contiguous()
+            hit = self._packs["border"] = (v, (mats(w), mats(w.transpose(2, 3))))
         return hit[1]
 
     def bwd(self):
@@ -462,44 +449,28 @@ def pack_input(x, device):
 
 def _folded_upsample_conv(x, skip, cp, y, epi):
     """y = act(conv5x5_zero_padded(up2x(x + skip)) + b) without ever forming the upsampled image:
-    (1) the 2-pixel frame of y receives MINUS the contribution of the taps that the zero padding removes — four thin "valid"
-        launches of the direct kernel on bands of the replicate-extended upsample (which is what step 2 implicitly uses);
-    (2) ONE multi-class launch: each output parity is a 4x4 convolution of the replicate-padded low-res sum, 16 taps instead
-        of 25, plain loads; its epilogue adds the frame written by (1) before bias / activation."""
+    (1) ONE multi-class launch: each output parity is a 4x4 convolution of the replicate-padded low-res sum — 16 taps instead
+        of 25, plain loads — which equals the 5x5 convolution of the REPLICATE-extended upsample;
+    (2) the true layer zero-pads instead, so the outermost two rows / columns lose the taps that fall outside: those taps see a
+        constant line (the clamped border row / column of the upsample), i.e. four small plain GEMMs
+        [border pixels x 5*Cin] x [5*Cin x 2*Cout] (rocBLAS through torch.bmm; 1-3 % of the layer's FLOP), whose results the
+        epilogue of (1) adds to the pre-activation of the frame pixels (ramnet_conv_desc.frame)."""
     L = H.lib()
     B, Hh, W, Cc = x.shape
     dev = x.device
+    if Cc != cp.Cin:
+        raise RuntimeError("folded upsample-conv needs un-padded input channels")
+    H2, W2 = 2 * Hh, 2 * W
     xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
     H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
-    neg = cp.pack_neg()
-    H2, W2 = 2 * Hh, 2 * W
-    # (band shape, tap list, target, output rows x cols, output origin): only the taps the zero padding removes.  Row bands write
-    # the top / bottom two rows of y itself; column bands a side buffer [B][2H][4][Cout] (left | right), because the corner
-    # pixels receive both and the four launches run concurrently.
-    side_buf = torch.empty(B, H2, 4, cp.Cout, device=dev)
-    plan = [((3, W2 + 4), "band_rows_lo", y, (2, W2), (0, 0)), ((3, W2 + 4), "band_rows_hi", y, (2, W2), (H2 - 2, 0)),
-            ((H2, 3), "band_cols_lo", side_buf, (H2, 2), (0, 0)), ((H2, 3), "band_cols_hi", side_buf, (H2, 2), (0, 2))]
-    main = torch.cuda.current_stream()
-    bands = []
-    for side, ((bh, bw), _, _, _, _) in enumerate(plan):
-        band = torch.empty(B, bh, bw, Cc, device=dev)
-        H.check(L.ramnet_up2x_ring_band(_p(x), _p(skip), _p(band), B, Hh, W, Cc, side, _st()), "ramnet_up2x_ring_band")
-        bands.append(band)
-    # the four band launches are short serial chains on a handful of workgroups: run them side by side
-    ready = main.record_event()
-    for side, (_, kind, target, (Ho, Wo), (oy, ox)) in enumerate(plan):
-        st = _band_stream(dev, side)
-        st.wait_event(ready)
-        with torch.cuda.stream(st):
-            conv_launch(bands[side], Taps.get(kind, 5, 2), neg, target, cp.Cout, Ho=Ho, Wo=Wo, os=(1, 1, oy, ox), epi=H.EPI_LINEAR)
-        bands[side].record_stream(st)
-        main.wait_event(st.record_event())
-    for st_i in range(4):
-        side_buf.record_stream(_band_stream(dev, st_i))
-        y.record_stream(_band_stream(dev, st_i))
+    a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
+    a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+    H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
+    w_rows, w_cols = cp.border_weights()
+    g_rows, g_cols = torch.bmm(a_rows, w_rows), torch.bmm(a_cols, w_cols)         # [2][B*2W][2*Cout], [2][B*2H][2*Cout]
+    desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
-                      [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)],
-                      bias=cp.bias(), epi=epi, beta=1.0, frame=2, e0=side_buf)
+                      [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)], **desc_kw)
 
 
 class ConvAct(Function):
