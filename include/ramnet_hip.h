@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 6
+#define RAMNET_ABI_VERSION 7
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -100,6 +100,8 @@ typedef struct ramnet_wgrad_desc {
     float *dbias;                   /* [Cout] or NULL                                               */
     int algo;                       /* RAMNET_ALGO_DIRECT, or RAMNET_ALGO_WINOGRAD: dense 3x3 stride-1 taps in kh*3+kw order; dw then
                                      * accumulates the transformed-domain gradient dU, folded by ramnet_unpack_wgrad_wino() */
+    int gsy, gsx, goy, gox;         /* dout / gmask are read at pixel (oy*gsy + goy, ox*gsx + gox) of a [B, HoG, WoG] tensor      */
+    int HoG, WoG;                   /* (all 0 = dense [B, Ho, Wo]; DIRECT only): one output parity of the folded upsample-conv  */
 } ramnet_wgrad_desc;
 
 const char *ramnet_last_error(void);
@@ -156,6 +158,9 @@ int ramnet_pad2_sum(const float *x, const float *skip, float *out, int B, int H,
  * rows [2][B*2W][5][C] (top / bottom image row, columns clamped), cols [2][B*2H][5][C] (left / right image column, rows outside
  * the image zero).                                                                                                      */
 int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, float *cols, int B, int H, int W, int C, void *stream);
+/* Outermost two rows / columns of dy (* (mask > 0) when mask != NULL) of a [B, H2, W2, C] tensor, in the layout of the
+ * border-correction GEMMs of the folded upsample-conv: rows [2][B*W2][2][C], cols [2][B*H2][2][C].                       */
+int ramnet_frame_gather(const float *dy, const float *mask, float *rows, float *cols, int B, int H2, int W2, int C, void *stream);
 /* Adjoint of the bilinear x2 upsample: dup [B,2H,2W,C] -> dx [B,H,W,C] (backward of submodules.py:88). */
 int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream);
 /* ConvGRU backward, point-wise parts (derivation in DESIGN.md):

@@ -50,6 +50,7 @@ class WgradDesc(C.Structure):
         ("Cout", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
         ("dw", _fp), ("dbias", _fp),
         ("algo", C.c_int),
+        ("gsy", C.c_int), ("gsx", C.c_int), ("goy", C.c_int), ("gox", C.c_int), ("HoG", C.c_int), ("WoG", C.c_int),
     ]
 
 
@@ -65,6 +66,7 @@ _SIGS = {
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_pad2_sum": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_up2x_border_im2col": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_frame_gather": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
     "ramnet_unpack_wgrad_wino": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
@@ -116,7 +118,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 6:
+        if l.ramnet_abi_version() != 7:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

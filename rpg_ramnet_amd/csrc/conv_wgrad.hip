@@ -23,6 +23,7 @@ struct WgradDerived {
     int tiles_x, tiles_y, ntiles;   // pixel tiles per image / total
     int tpm, ntt;                   // taps per 32-row accumulator tile (Cin < 32 packs several taps), number of tap tiles
     int toff[25];
+    int gsy, gsx, goy, gox, HoG, WoG;   // addressing of dout / gmask (ramnet_wgrad_desc)
 };
 
 // MAXT: accumulator tiles per wave; NSUB: 32-wide output-channel sub-tiles per workgroup (WBN = 32*NSUB).
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(256, CSUB == 2 ? 2 : 1) conv_wgrad_kernel(cons
                     const int m = s / GQ, qd = s % GQ;
                     const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15), n = n0 + qd * 4;
                     ok[i] = s < nsl && oy < p.Ho && ox < p.Wo && n < p.Cout;
-                    const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
+                    const size_t pix = ((size_t)b * q.HoG + (oy * q.gsy + q.goy)) * q.WoG + (ox * q.gsx + q.gox);
                     g[i] = ld4(ok[i] ? p.dout + pix * p.ldg + n : p.dout);
                     if (p.gmask) y[i] = ld4(ok[i] ? p.gmask + pix * p.ldgm + n : p.gmask);
                 }
@@ -200,6 +201,9 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
     if (d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK) RAMNET_CHECK_ARG(d.xm && d.ldm % 4 == 0);
     if (d.in_mode == RAMNET_IN_UP2X_SKIP) RAMNET_CHECK_ARG(d.x1 && d.ld1 % 4 == 0);
     if (d.gmask) RAMNET_CHECK_ARG(d.ldgm % 4 == 0);
+    const bool gdense = d.gsy == 0 && d.gsx == 0 && d.goy == 0 && d.gox == 0 && d.HoG == 0 && d.WoG == 0;
+    if (!gdense) RAMNET_CHECK_ARG(d.gsy >= 1 && d.gsx >= 1 && d.goy >= 0 && d.gox >= 0 && (d.Ho - 1) * d.gsy + d.goy < d.HoG &&
+                                  (d.Wo - 1) * d.gsx + d.gox < d.WoG && d.algo == RAMNET_ALGO_DIRECT);
     if (d.algo == RAMNET_ALGO_WINOGRAD) return launch_wgrad_wino(d, (hipStream_t)stream);
     RAMNET_CHECK_ARG(d.algo == RAMNET_ALGO_DIRECT);
 
@@ -214,6 +218,8 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
         dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin, dxmax = d.dx[t] > dxmax ? d.dx[t] : dxmax;
     }
     q.dymin = dymin, q.dxmin = dxmin;
+    q.gsy = gdense ? 1 : d.gsy, q.gsx = gdense ? 1 : d.gsx, q.goy = d.goy, q.gox = d.gox;
+    q.HoG = gdense ? d.Ho : d.HoG, q.WoG = gdense ? d.Wo : d.WoG;
     // two co-resident workgroups per CU hide each other's staging: halve the pixel tile when a full one needs > 80 KB
     q.TH = 8;
     // -> conv_wgrad_kernel<9,2,2>; needs >= 4 pixel tiles per workgroup to amortise its 9 x 64 x 64 atomic epilogue
@@ -240,6 +246,7 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
         const int per_wave = cdiv(q.ntt, 4);
         if (per_wave <= 1) return launch_wgrad<1, 1>(d, q, st);
         if (per_wave <= 3) return launch_wgrad<3, 1>(d, q, st);
+        if (per_wave <= 4) return launch_wgrad<4, 1>(d, q, st);     // 16 taps: one parity of the folded upsample-conv
         return launch_wgrad<7, 1>(d, q, st);
     }
     static const char *nowide = getenv("RAMNET_WGRAD_NOWIDE");

@@ -311,6 +311,35 @@ __global__ void up2x_border_im2col_kernel(const float *__restrict__ x, const flo
     }
 }
 
+// Outermost two rows / columns of the (ReLU-masked) output gradient in the layout of the border-correction GEMMs:
+// rows [2 sides][B*W2][2 slots][C], cols [2 sides][B*H2][2 slots][C]  (side 0 = top / left, slot = distance into the band).
+__global__ void frame_gather_kernel(const float *__restrict__ dy, const float *__restrict__ mask, float *__restrict__ rows,
+                                    float *__restrict__ cols, int B, int H2, int W2, int C) {
+    const int C4 = C / 4;
+    const size_t nrows = (size_t)2 * B * W2 * 2 * C4, ncols = (size_t)2 * B * H2 * 2 * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nrows + ncols; i += (size_t)gridDim.x * blockDim.x) {
+        const bool isrow = i < nrows;
+        size_t j = isrow ? i : i - nrows;
+        const int ch = (int)(j % C4) * 4;
+        j /= C4;
+        const int slot = (int)(j % 2);
+        j /= 2;
+        const int L = isrow ? W2 : H2;
+        const int o = (int)(j % L);
+        j /= L;
+        const int b = (int)(j % B), side = (int)(j / B);
+        const int edge = side ? (isrow ? H2 : W2) - 2 + slot : slot;
+        const int oy = isrow ? edge : o, ox = isrow ? o : edge;
+        const size_t src = (((size_t)b * H2 + oy) * W2 + ox) * C + ch;
+        float4 v = ld4(dy + src);
+        if (mask) {
+            const float4 m = ld4(mask + src);
+            v = make_float4(m.x > 0.f ? v.x : 0.f, m.y > 0.f ? v.y : 0.f, m.z > 0.f ? v.z : 0.f, m.w > 0.f ? v.w : 0.f);
+        }
+        st4((isrow ? rows : cols) + (isrow ? i : i - nrows) * 4, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ GRU / LSTM backward maps
 // ur = [u | r] (2C per pixel).  dpur = [dpu | dpr].
 __global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__restrict__ ur, const float *__restrict__ o,
@@ -514,6 +543,14 @@ extern "C" int ramnet_up2x_border_im2col(const float *x, const float *skip, floa
     RAMNET_CHECK_ARG(x && rows && cols && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
     const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
     hipLaunchKernelGGL(up2x_border_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, rows, cols, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_frame_gather(const float *dy, const float *mask, float *rows, float *cols, int B, int H2, int W2, int C, void *stream) {
+    RAMNET_CHECK_ARG(dy && rows && cols && B > 0 && H2 >= 4 && W2 >= 4 && C > 0 && C % 4 == 0);
+    const size_t n = (size_t)2 * B * (W2 + H2) * 2 * (C / 4);
+    hipLaunchKernelGGL(frame_gather_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, mask, rows, cols, B, H2, W2, C);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -176,7 +176,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
 
 
 def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
-                 C1=0, Hin=None, Win=None, gmask=None, dbias=None):
+                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0):
     d = H.WgradDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
@@ -186,8 +186,10 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     d.dy, d.dx = taps.dy, taps.dx
     d.dout, d.gmask = _p(dout), _p(gmask)
     d.ldg, d.ldgm = ld(dout), (ld(gmask) if gmask is not None else 0)
-    d.Cout, d.Ho, d.Wo = Cout, dout.shape[1], dout.shape[2]
-    d.dw, d.dbias = _p(dw), _p(dbias)
+    d.Cout, d.Ho, d.Wo = Cout, (dout.shape[1] if Ho is None else Ho), (dout.shape[2] if Wo is None else Wo)
+    d.dw, d.dbias = _p(dw, dw_off), _p(dbias)
+    if gview is not None:      # dout / gmask addressed as (oy*gsy + goy, ox*gsx + gox) of [B, HoG, WoG]
+        d.gsy, d.gsx, d.goy, d.gox, d.HoG, d.WoG = gview
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
     if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
@@ -271,8 +273,11 @@ class _Engine:
             cp._dirty = True
             cls.dirty.append(cp)
         if not cls.queued:
-            cls.queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+                cls.queued = True
+            except RuntimeError:        # not inside a backward pass (kernel benchmarks): the caller folds with _Engine.flush()
+                pass
 
     @classmethod
     def flush(cls):
@@ -312,6 +317,8 @@ class ConvParam:
         self.Cin, self.k = w0.shape[1], w0.shape[2]
         self.CinWs = (self.Cin + 3) // 4 * 4
         self._bias = self._ws = self._bws = None
+        self._ws_fold = None             # (dW4 [64][CinWs][Cout], dWrows, dWcols) of the folded upsample-conv backward-weights
+        self._fold_used = self._ws_used = False
         self._vbias = None
         self._packs = {}
         self._dirty = False
@@ -415,9 +422,51 @@ class ConvParam:
             self._ws.wino = bool(wino_ok and _WINOGRAD and _PRECISION == H.PREC_F32 and self.k == 3
                                  and self.CinWs >= _WINO_MIN_CIN)
         _Engine.mark(self)
+        self._ws_used = True
         return self._ws, self._bws
 
+    def grad_ws_fold(self):
+        """Workspaces of the folded upsample-conv backward-weights: dW4 [64 = (py,px,ty,tx)][CinWs][Cout] of the four parity
+        convolutions, the gradients of the two border-GEMM weight stacks, and the shared bias workspace."""
+        assert len(self.weights) == 1 and self.k == 5
+        dev = self.weights[0].device
+        if self._bws is None:
+            self._bws = torch.zeros(self.Cout, device=dev)
+        if self._ws_fold is None:
+            self._ws_fold = (torch.zeros(64 * self.CinWs * self.Cout, device=dev),
+                             torch.zeros(2, 5 * self.Cin, 2 * self.Cout, device=dev),
+                             torch.zeros(2, 5 * self.Cin, 2 * self.Cout, device=dev))
+        _Engine.mark(self)
+        self._fold_used = True
+        return self._ws_fold + (self._bws,)
+
+    def _finalize_fold(self):
+        """dW5 = sum_parities A_py^T dW4 A_px  -  (border GEMM gradients routed back to the taps they summed)."""
+        w4, wr, wc = self._ws_fold
+        g = ensure_grad(self.weights[0])
+        A = torch.tensor(self._FOLD_A, dtype=torch.float32, device=g.device)                        # [p][t][k]
+        d4 = w4.view(2, 2, 4, 4, self.CinWs, self.Cout)[:, :, :, :, :self.Cin]
+        g.add_(torch.einsum("ptk,qsl,pqtsio->oikl", A, A, d4))
+        lost = [[(0, 1), (0,)], [(4,), (3, 4)]]
+        r = wr.view(2, 5, self.Cin, 2, self.Cout)          # [side][kx][ci][slot][co]
+        c = wc.view(2, 5, self.Cin, 2, self.Cout)          # [side][ky][ci][slot][co]
+        for side in range(2):
+            for slot in range(2):
+                for a in lost[side][slot]:
+                    g[:, :, a, :].sub_(r[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][kx]
+                    g[:, :, :, a].sub_(c[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][ky]
+        w4.zero_(), wr.zero_(), wc.zero_()
+        self._fold_used = False
+
     def finalize(self):
+        if self._fold_used:
+            self._finalize_fold()
+        if not self._ws_used:
+            if self.biases[0].shape[0] == self.Cout:
+                ensure_grad(self.biases[0]).add_(self._bws)
+            self._bws.zero_()
+            self._dirty = False
+            return
         off = 0
         for w, b in zip(self.weights, self.biases):
             n = w.shape[0]
@@ -433,7 +482,7 @@ class ConvParam:
             off += n
         self._ws.zero_()
         self._bws.zero_()
-        self._dirty = False
+        self._dirty = self._ws_used = False
 
 
 # ------------------------------------------------------------------------------------------------ operators
@@ -473,6 +522,37 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
                       [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)], **desc_kw)
 
 
+def _fold_eligible(x, cp, k, stride, up):
+    return bool(up and k == 5 and stride == 1 and _FOLD_UP and _PRECISION == H.PREC_F32 and x.shape[1] >= 4 and x.shape[2] >= 4
+                and x.shape[3] == cp.Cin)
+
+
+def _folded_upsample_wgrad(x, skip, dy, y, cp):
+    """Backward-weights of the folded upsample-conv: each output parity is a 16-tap convolution of pad2(x + skip), so its weight
+    gradient is a 16-tap backward-weights launch on (pad2(x + skip), the parity sub-grid of dy [* ReLU mask]) — 64 instead of
+    100 tap-pixels per low-res pixel, plain loads — and the border GEMMs contribute A^T dy_frame; ConvParam._finalize_fold maps
+    both back to the 5x5 weights when the autograd engine finishes."""
+    L = H.lib()
+    B, Hh, W, Cc = x.shape
+    H2, W2 = 2 * Hh, 2 * W
+    dev = x.device
+    w4, wr, wc, bws = cp.grad_ws_fold()
+    xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
+    H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
+    for py in range(2):
+        for px in range(2):
+            wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, py, px), dy, w4, cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
+                       gview=(2, 2, py, px, H2, W2), dw_off=(py * 2 + px) * 16 * cp.CinWs * cp.Cout)
+    a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
+    a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+    H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
+    g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
+    g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
+    H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
+    wr.baddbmm_(a_rows.transpose(1, 2), g_rows)
+    wc.baddbmm_(a_cols.transpose(1, 2), g_cols)
+
+
 class ConvAct(Function):
     """ConvLayer / UpsampleConvLayer (submodules.py:8-35, 69-97): [bilinear x2 of (x [+ skip])] -> KxK conv -> bias -> [ReLU]."""
 
@@ -490,7 +570,7 @@ class ConvAct(Function):
         y = torch.empty(B, Ho, Wo, cp.Cout, device=x.device)
         mode = (H.IN_UP2X_SKIP if skip is not None else H.IN_UP2X) if up else H.IN_PLAIN
         epi = H.EPI_RELU if relu else H.EPI_LINEAR
-        if up and k == 5 and stride == 1 and _FOLD_UP and _PRECISION == H.PREC_F32 and Hh >= 4 and W >= 4:
+        if _fold_eligible(x, cp, k, stride, up):
             _folded_upsample_conv(x, skip, cp, y, epi)
         else:
             conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
@@ -507,9 +587,12 @@ class ConvAct(Function):
         B, Hh, W, _ = x.shape
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
-        ws, bws = cp.grad_ws(wino_ok=(stride == 1 and k == 3 and pad == 1 and mode == H.IN_PLAIN))
-        wgrad_side([x, skip, dy, y], x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
-                   Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
+        if _fold_eligible(x, cp, k, stride, up):
+            _folded_upsample_wgrad(x, skip, dy, y if relu else None, cp)
+        else:
+            ws, bws = cp.grad_ws(wino_ok=(stride == 1 and k == 3 and pad == 1 and mode == H.IN_PLAIN))
+            wgrad_side([x, skip, dy, y], x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
+                       Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
         dx = dskip = None
         if ctx.needs_input_grad[0] or (skip is not None and ctx.needs_input_grad[1]):
             gin = torch.empty(B, Hin, Win, cp.Cin, device=x.device)
