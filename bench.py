@@ -135,7 +135,7 @@ class KernelTimer:
             e.record()
             cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
             nout = Cout * (4 if kw.get("epi") == 5 else 1)
-            timer.rec.append((name, s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * nout))
+            timer.rec.append((name, s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout))
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:
@@ -145,7 +145,7 @@ class KernelTimer:
             ntt = -(-taps.n // tpm)
             if Cout <= 32 or taps.n > 9:
                 per = -(-ntt // 4)
-                name = "conv_wgrad_kernel<%d,1,1>" % (1 if per <= 1 else 3 if per <= 3 else 7)
+                name = "conv_wgrad_kernel<%d,1,1>" % (1 if per <= 1 else 3 if per <= 3 else 4 if per <= 4 else 7)
             elif (taps.n > 1 and cin >= 64 and
                   -(-dout.shape[2] // 16) * -(-dout.shape[1] // 8) * dout.shape[0] * -(-cin // 64) * -(-Cout // 64) >= 2048):
                 name = "conv_wgrad_kernel<9,2,2>"
@@ -161,7 +161,8 @@ class KernelTimer:
             s.record()
             wgrad0(x0, taps, dout, dw, Cout, **kw)
             e.record()
-            timer.rec.append((name, s, e, 2.0 * dout.shape[0] * dout.shape[1] * dout.shape[2] * taps.n * cin * Cout))
+            ho, wo = kw.get("Ho") or dout.shape[1], kw.get("Wo") or dout.shape[2]       # (parity sub-grid of the folded upsample-conv)
+            timer.rec.append((name, s, e, 2.0 * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout))
 
         multi0 = ops.conv_launch_multi
 
@@ -187,7 +188,7 @@ class KernelTimer:
             multi0(x0, w, out, Cout, classes, **kw)
             e.record()
             cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
-            fl = sum(2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * Cout for taps, Ho, Wo, _ in classes)
+            fl = sum(2.0 * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * Cout for taps, Ho, Wo, _ in classes)
             timer.rec.append((name, s, e, fl))
 
         ops.conv_launch, ops.wgrad_launch, ops.conv_launch_multi = conv, wgrad, multi
@@ -403,7 +404,7 @@ def main():
             ach = flops / secs / 1e12
             traffic = None
             try:    # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic.json")))      # tools/pmc_traffic.py
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_i_pmc_hbm_traffic.json")))      # tools/pmc_traffic.py
                 ent = pmc.get(name.replace(",1>", ",0>") if name.startswith("conv_igemm") else name)
                 if ent:
                     traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent.values()) /
@@ -413,7 +414,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB, launch-weighted over the kernel's grids, "
-                                               "from profiles/r01_h_pmc_*; gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
+                                               "from profiles/r01_i_pmc_*; gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
                                "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9}
             iso = extras.get("single_stream", {}).get("dominant_kernel")

@@ -98,6 +98,7 @@ class Taps:
         self.dx = (C.c_int8 * 25)(*[t[1] for t in triples])
         self.wt = (C.c_uint8 * 25)(*[t[2] for t in triples])
         self.wino = False
+        self.flop_taps = self.n          # taps of the convolution this launch stands for (algorithmic FLOP accounting)
 
     @classmethod
     def get(cls, kind, k, pad, py=0, px=0):
@@ -117,6 +118,8 @@ class Taps:
                 raise KeyError(kind)
             cls._cache[key] = cls(tr)
             cls._cache[key].wino = kind in ("conv", "dgrad1") and k == 3 and pad == 1   # dense padded 3x3 window
+            if kind == "fold":          # one output parity of a 5x5 convolution after the x2 upsample
+                cls._cache[key].flop_taps = 25
         return cls._cache[key]
 
 
