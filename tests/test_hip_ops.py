@@ -101,6 +101,31 @@ def test_upsample_conv(B, H, W, cin, cout, skip, upsample_algo):
     run_pair(m, oracle, [x, s] if skip else [x])
 
 
+def test_upsample_conv_without_activation(upsample_algo):
+    """The op also serves a linear upsample-conv (no ReLU): folded frame corrections and gradients without a mask."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(4)
+    B, H, W, cin, cout = 2, 6, 9, 32, 48
+    w = torch.nn.Parameter((torch.randn(cout, cin, 5, 5) * 0.05).to(dev()))
+    b = torch.nn.Parameter((torch.randn(cout) * 0.1).to(dev()))
+    cp = ops.ConvParam([w], [b])
+    x, s = torch.randn(B, cin, H, W), torch.randn(B, cin, H, W)
+    xg, sg = nhwc(x).to(dev()).requires_grad_(True), nhwc(s).to(dev()).requires_grad_(True)
+    y = ops.ConvAct.apply(xg, sg, w, b, cp, 1, False, True)
+    xr, sr = x.double().requires_grad_(True), s.double().requires_grad_(True)
+    wr, br = w.detach().cpu().double().requires_grad_(True), b.detach().cpu().double().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xr + sr, scale_factor=2, mode="bilinear", align_corners=False), wr, br, 1, 2)
+    assert_close(nchw(y).detach().cpu().numpy(), ref.detach().numpy(), TOL, "linear upsample-conv forward")
+    g = torch.randn(ref.shape)
+    (ref * g.double()).sum().backward()
+    (nchw(y) * g.to(dev())).sum().backward()
+    assert_close(w.grad.cpu().numpy(), wr.grad.numpy(), TOL, "dW")
+    assert_close(b.grad.cpu().numpy(), br.grad.numpy(), TOL, "db")
+    assert_close(nchw(xg.grad).cpu().numpy(), xr.grad.numpy(), TOL, "dx")
+    assert_close(nchw(sg.grad).cpu().numpy(), sr.grad.numpy(), TOL, "dskip")
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 8, 16), (1, 5, 11)])
 @pytest.mark.parametrize("cin,cout,skip", [(64, 32, True), (32, 16, False)])
 def test_transposed_conv(B, H, W, cin, cout, skip):
