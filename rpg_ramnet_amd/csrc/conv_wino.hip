@@ -1,5 +1,6 @@
 // Winograd F(2x2, 3x3) convolution for gfx950 (MI355X): forward and backward-data of the 3x3 stride-1 layers of the
-// RAM-Net path (ConvGRU gates / candidate, residual blocks), exact-fp32 arithmetic on v_mfma_f32_16x16x4_f32.
+// RAM-Net path — ConvGRU gates / candidate (submodules.py:447-452), ConvLSTM gates + cell (submodules.py:346-358), residual
+// blocks (submodules.py:200-215) — exact-fp32 arithmetic on v_mfma_f32_16x16x4_f32.
 //
 //   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A         (Lavin & Gray 2016; 2.25x fewer multiplies than direct)
 //
@@ -7,11 +8,13 @@
 // input channels it stages the 10 x 18 input patch once (same fused loaders as the direct kernel: concatenation, the
 // GRU's h*r product, the ReLU mask of the backward pass) and transforms it to V[16 positions][32 tiles][8] in LDS — the
 // transformed INPUT is what the four waves share.  A weight tile is consumed by exactly one wave, so the waves split the
-// 64 channels (16 each) and load their B operand U[pos][16 channels][8] from global memory (L2-resident, 1 KB coalesced
-// per wave-load) directly in the lane layout of the MFMA, one chunk ahead, into a register ring: no weight traffic
-// through LDS.  Each wave keeps ALL 16 positions of its 32 tiles x 16 channels in registers (16 x 2 accumulators of the
-// 16x16 MFMA = 128 VGPRs), so the output transform A^T M A is register-local and the fused epilogues (bias / ReLU /
-// sigmoid / residual / GRU blend) run straight from it.  One barrier per chunk (V and the patch are double-buffered).
+// 64 channels (16 each) and load their B operand from global memory (L2-resident; packed so that one 16-byte lane load
+// holds two positions, 1 KB coalesced per wave-load) directly in the lane layout of the MFMA, one chunk ahead, into a
+// register ring: no weight traffic through LDS.  Each wave keeps ALL 16 positions of its 32 tiles x 16 channels in
+// registers (16 x 2 accumulators of the 16x16 MFMA = 128 VGPRs), so the output transform A^T M A is register-local; the
+// result tile is then staged through the (free) LDS so that the fused epilogues (bias / ReLU / sigmoid / residual / GRU
+// blend / ConvLSTM cell) and their operands go out as 16-byte channel quads.  One barrier per chunk (V and the patch are
+// double-buffered); XCD-aware workgroup order.  Design log: profiles/r01_g_winograd_notes.md.
 #include <stdlib.h>
 #include "common.hpp"
 #include "conv_epilogue.hpp"
