@@ -300,6 +300,34 @@ def ensure_grad(p):
     return p.grad
 
 
+# ---- folded upsample-conv: weight algebra (pure torch, device-agnostic; tests/test_boundary_cpu.py checks it against F.conv2d)
+# high-res row 2i + p + k - 2 (k = 0..4) of the x2 bilinear upsample is a 0.25 / 0.75 blend of two low-res rows;
+# FOLD_A[p][t][k] = weight of low-res row i + p - 2 + t (t = 0..3) in tap k of output parity p.
+FOLD_A = ([[.25, 0, 0, 0, 0], [.75, .75, .25, 0, 0], [0, .25, .75, .75, .25], [0, 0, 0, .25, .75]],
+          [[.75, .25, 0, 0, 0], [.25, .75, .75, .25, 0], [0, 0, .25, .75, .75], [0, 0, 0, 0, .25]])
+FOLD_LOST = [[(0, 1), (0,)], [(4,), (3, 4)]]    # [side: near / far edge][slot: distance into the band] -> taps outside the image
+
+
+def fold_weights(w):
+    """OIHW 5x5 -> [O][I][py][px][ty][tx]: the 4x4 filter of every output parity, W4 = A_py w A_px^T (float64)."""
+    A = torch.tensor(FOLD_A, dtype=torch.float64, device=w.device)
+    return torch.einsum("ptk,qsl,oikl->oipqts", A, A, w.double())
+
+
+def border_matrices(w):
+    """(Wrows, Wcols), each [2 sides][5*Cin][2*Cout]: MINUS the sums of the taps the zero padding removes at the image border.
+    Rows: K index = (kx, ci), N index = (slot, co), lost direction ky; columns the same with ky <-> kx."""
+    Cout, Cin = w.shape[0], w.shape[1]
+
+    def mats(wk):                                                          # wk[co][ci][a][b]: `a` is the lost direction
+        out = []
+        for side in range(2):
+            slots = [-sum(wk[:, :, a, :] for a in FOLD_LOST[side][slot]) for slot in range(2)]          # [co][ci][b]
+            out.append(torch.stack(slots, 0).permute(3, 2, 0, 1).reshape(5 * Cin, 2 * Cout))              # [b][ci][slot][co]
+        return torch.stack(out, 0).contiguous()
+    return mats(w), mats(w.transpose(2, 3))
+
+
 class PackRef:
     """Handle on the packed weights of a ConvParam; the launch picks the layout (direct / Winograd) that fits it."""
     __slots__ = ("cp", "transposed")
@@ -361,44 +389,27 @@ class ConvParam:
     def fwd(self):
         return PackRef(self, 0)
 
-    # -- folded upsample-conv (5x5 after bilinear x2): effective 4x4 kernels of the four output parities ------------------
-    # high-res row 2i + p + k - 2 (k = 0..4) is 0.25 / 0.75 of two low-res rows; A[p][t][k] = weight of low-res row
-    # i + p - 2 + t (t = 0..3) in tap k.
-    _FOLD_A = ([[.25, 0, 0, 0, 0], [.75, .75, .25, 0, 0], [0, .25, .75, .75, .25], [0, 0, 0, .25, .75]],
-               [[.75, .25, 0, 0, 0], [.25, .75, .75, .25, 0], [0, 0, .25, .75, .75], [0, 0, 0, 0, .25]])
+    # -- folded upsample-conv (5x5 after bilinear x2): effective 4x4 kernels of the four output parities + border matrices
+    _FOLD_A = FOLD_A
 
     def pack_fold(self):
-        """[64 = (py, px, ty, tx)] tap slices W4 = A_py w A_px^T in the direct kernel's layout (float64 accumulation)."""
+        """[64 = (py, px, ty, tx)] tap slices of fold_weights() in the direct kernel's layout."""
         v = (self._versions(self.weights), "fold")
         hit = self._packs.get("fold")
         if hit is None or hit[0] != v:
-            w = self._cat_w().double()
-            A = torch.tensor(self._FOLD_A, dtype=torch.float64, device=w.device)           # [p][t][k]
-            w4 = torch.einsum("ptk,qsl,oikl->oipqts", A, A, w).reshape(self.Cout, self.Cin, 8, 8).float().contiguous()
+            w4 = fold_weights(self._cat_w()).reshape(self.Cout, self.Cin, 8, 8).float().contiguous()
             L = H.lib()
-            out = torch.empty(L.ramnet_packed_weight_elems(self.Cout, self.Cin, 8, 8, 0, 1), device=w.device)
+            out = torch.empty(L.ramnet_packed_weight_elems(self.Cout, self.Cin, 8, 8, 0, 1), device=w4.device)
             H.check(L.ramnet_pack_weight(_p(w4), _p(out), self.Cout, self.Cin, 8, 8, 0, 1, _st()), "ramnet_pack_weight")
             hit = self._packs["fold"] = (v, out)
         return hit[1]
 
     def border_weights(self):
-        """(Wrows [2][5*Cin][2*Cout], Wcols [2][5*Cin][2*Cout]): MINUS the sums of the taps that the zero padding of the 5x5 conv
-        removes at the image border — rows: side 0 = top (slot 0: output row 0 loses ky in {0,1}, slot 1: row 1 loses ky = 0),
-        side 1 = bottom (rows 2H-2 / 2H-1 lose ky = 4 / ky in {3,4}), K index = (kx, ci); columns likewise with ky <-> kx."""
+        """border_matrices() of the current weights, cached per parameter version."""
         v = (self._versions(self.weights), "border")
         hit = self._packs.get("border")
         if hit is None or hit[0] != v:
-            w = self._cat_w()                                              # [co][ci][ky][kx]
-            lost = [[(0, 1), (0,)], [(4,), (3, 4)]]                        # [side][slot] -> tap indices outside the image
-
-            def mats(wk):                                                  # wk[co][ci][a][b]: `a` is the lost direction
-                out = []
-                for side in range(2):
-                    slots = [-sum(wk[:, :, a, :] for a in lost[side][slot]) for slot in range(2)]      # [co][ci][b]
-                    m = torch.stack(slots, 0).permute(3, 2, 0, 1)          # [b][ci][slot][co]
-                    out.append(m.reshape(5 * self.Cin, 2 * self.Cout))
-                return torch.stack(out, 0).contiguous()
-            hit = self._packs["border"] = (v, (mats(w), mats(w.transpose(2, 3))))
+            hit = self._packs["border"] = (v, border_matrices(self._cat_w()))
         return hit[1]
 
     def bwd(self):
@@ -450,7 +461,7 @@ class ConvParam:
         A = torch.tensor(self._FOLD_A, dtype=torch.float32, device=g.device)                        # [p][t][k]
         d4 = w4.view(2, 2, 4, 4, self.CinWs, self.Cout)[:, :, :, :, :self.Cin]
         g.add_(torch.einsum("ptk,qsl,pqtsio->oikl", A, A, d4))
-        lost = [[(0, 1), (0,)], [(4,), (3, 4)]]
+        lost = FOLD_LOST
         r = wr.view(2, 5, self.Cin, 2, self.Cout)          # [side][kx][ci][slot][co]
         c = wc.view(2, 5, self.Cin, 2, self.Cout)          # [side][ky][ci][slot][co]
         for side in range(2):

@@ -243,3 +243,44 @@ def test_cabi_argument_errors_and_host_only_entry_points():
     assert L.ramnet_packed_weight_elems_split(64, 32, 5, 5, 0, 1) == 25 * 1 * 2 * 64 * 32 // 2
     assert L.ramnet_msg_workspace_elems(2, 32, 48, 4) == 2 * (32 * 48 + 16 * 24 + 8 * 12 + 4 * 6)
     assert L.ramnet_msg_workspace_elems(2, 4, 4, 4) == 0                                   # 8x pooling of a 4x4 map
+
+
+def test_folded_upsample_conv_algebra_cpu():
+    """conv5x5_zero_padded(bilinear_x2(x)) == four 4x4 parity convolutions of the replicate-padded input (ops.fold_weights)
+    + the border GEMMs (ops.border_matrices): the factorisation the HIP path runs, checked in float64 with torch ops only."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(0)
+    B, Cin, Cout, H, W = 2, 3, 5, 6, 7
+    x = torch.randn(B, Cin, H, W, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64)
+    u = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    ref = F.conv2d(u, w, None, 1, 2)
+    w4 = ops.fold_weights(w)                                          # [O][I][py][px][ty][tx]
+    xp = F.pad(x, (2, 2, 2, 2), mode="replicate")
+    y = torch.zeros_like(ref)
+    for py in range(2):
+        for px in range(2):
+            full = F.conv2d(xp, w4[:, :, py, px])                     # valid 4x4 conv: (H+1) x (W+1) positions
+            y[:, :, py::2, px::2] = full[:, :, py:py + H, px:px + W]   # tap t reads padded row i + py + t
+    H2, W2 = 2 * H, 2 * W
+    assert torch.allclose(y[:, :, 2:H2 - 2, 2:W2 - 2], ref[:, :, 2:H2 - 2, 2:W2 - 2], atol=1e-12)          # interior: exact as is
+    wr, wc = ops.border_matrices(w)
+    idx = torch.arange(W2)
+    for side, row in enumerate((0, H2 - 1)):                          # rows: A[(b, ox)][(kx, ci)] = u[row][clamp(ox + kx - 2)]
+        A = torch.stack([u[:, :, row, (idx + kx - 2).clamp(0, W2 - 1)] for kx in range(5)], 1)              # [B][5][Cin][W2]
+        G = (A.permute(0, 3, 1, 2).reshape(B * W2, 5 * Cin) @ wr[side]).view(B, W2, 2, Cout)
+        for slot in range(2):
+            y[:, :, (H2 - 2 + slot) if side else slot, :] += G[:, :, slot].permute(0, 2, 1)
+    idy = torch.arange(H2)
+    for side, col in enumerate((0, W2 - 1)):                          # columns: rows outside the image contribute nothing
+        cols = []
+        for ky in range(5):
+            r = idy + ky - 2
+            v = u[:, :, r.clamp(0, H2 - 1), col] * ((r >= 0) & (r < H2)).to(u.dtype)
+            cols.append(v)
+        A = torch.stack(cols, 1)                                      # [B][5][Cin][H2]
+        G = (A.permute(0, 3, 1, 2).reshape(B * H2, 5 * Cin) @ wc[side]).view(B, H2, 2, Cout)
+        for slot in range(2):
+            y[:, :, :, (W2 - 2 + slot) if side else slot] += G[:, :, slot].permute(0, 2, 1)
+    assert torch.allclose(y, ref, atol=1e-12), float((y - ref).abs().max())
