@@ -284,3 +284,35 @@ def test_folded_upsample_conv_algebra_cpu():
         for slot in range(2):
             y[:, :, :, (W2 - 2 + slot) if side else slot] += G[:, :, slot].permute(0, 2, 1)
     assert torch.allclose(y, ref, atol=1e-12), float((y - ref).abs().max())
+
+
+def test_winograd_f2x2_3x3_algebra_cpu():
+    """The transforms hard-wired in csrc/conv_wino.hip / conv_wgrad_wino.hip, in float64 torch: forward
+    Y = A^T[(G g G^T) .* (B^T d B)]A per 4x4 input tile, and backward-weights dg = G^T [sum_tiles (B^T d B) .* (A dy A^T)] G,
+    against F.conv2d and its autograd."""
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    Cin, Cout, H, W = 3, 4, 6, 8
+    x = torch.randn(1, Cin, H, W, dtype=torch.float64)
+    g = torch.randn(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(x, g, None, 1, 1)
+    dy = torch.randn_like(ref)
+    (ref * dy).sum().backward()
+    xp = F.pad(x, (1, 1, 1, 1))
+    U = torch.einsum("ia,ocab,jb->ocij", G, g.detach(), G)                               # [co][ci][4][4]
+    y = torch.zeros_like(ref)
+    dU = torch.zeros_like(U)
+    for ty in range(H // 2):
+        for tx in range(W // 2):
+            d = xp[0, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]                           # [ci][4][4]
+            V = torch.einsum("ia,cab,jb->cij", Bt, d, Bt)
+            M = torch.einsum("ocij,cij->oij", U, V)
+            y[0, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = torch.einsum("ai,oij,bj->oab", At, M, At)
+            Z = torch.einsum("ia,oab,jb->oij", At.t(), dy[0, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2], At.t())
+            dU += torch.einsum("cij,oij->ocij", V, Z)
+    assert torch.allclose(y, ref, atol=1e-12)
+    dg = torch.einsum("ia,ocij,jb->ocab", G, dU, G)                                      # G^T dU G
+    assert torch.allclose(dg, g.grad, atol=1e-12)
