@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 7
+#define RAMNET_ABI_VERSION 8
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -161,6 +161,9 @@ int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, fl
 /* Outermost two rows / columns of dy (* (mask > 0) when mask != NULL) of a [B, H2, W2, C] tensor, in the layout of the
  * border-correction GEMMs of the folded upsample-conv: rows [2][B*W2][2][C], cols [2][B*H2][2][C].                       */
 int ramnet_frame_gather(const float *dy, const float *mask, float *rows, float *cols, int B, int H2, int W2, int C, void *stream);
+/* Space-to-depth by 2: [B,H,W,C] -> [B,H/2,W/2,4C], channel (a*2 + c)*C + ch = pixel parity (a, c); inverse=1: the way back.
+ * A stride-2 5x5 convolution of x is a stride-1 3x3 convolution of it (9 taps x 4C channels, 11 of the 36 slices zero).   */
+int ramnet_space_to_depth2(const float *x, float *out, int B, int H, int W, int C, int inverse, void *stream);
 /* Adjoint of the bilinear x2 upsample: dup [B,2H,2W,C] -> dx [B,H,W,C] (backward of submodules.py:88). */
 int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream);
 /* ConvGRU backward, point-wise parts (derivation in DESIGN.md):

@@ -340,6 +340,26 @@ __global__ void frame_gather_kernel(const float *__restrict__ dy, const float *_
     }
 }
 
+// ---- space-to-depth (stride-2 5x5 convolution as a 3x3 stride-1 convolution over the four input parities) ----------
+// out[b][i][j][(a*2 + c)*C + ch] = x[b][2i + a][2j + c][ch];  inverse = the same map read backwards.
+__global__ void space_to_depth2_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int Ho, int Wo, int C, int inverse) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)B * Ho * Wo * 4 * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % C4) * 4;
+        size_t j = i / C4;
+        const int par = (int)(j % 4);
+        j /= 4;
+        const int xx = (int)(j % Wo);
+        j /= Wo;
+        const int yy = (int)(j % Ho), b = (int)(j / Ho);
+        const size_t deep = i * 4;                                                        // [b][yy][xx][par][ch]
+        const size_t flat = ((((size_t)b * 2 * Ho + 2 * yy + (par >> 1)) * 2 * Wo) + 2 * xx + (par & 1)) * C + ch;
+        if (inverse) st4(out + flat, ld4(x + deep));
+        else st4(out + deep, ld4(x + flat));
+    }
+}
+
 // ------------------------------------------------------------------------------------------ GRU / LSTM backward maps
 // ur = [u | r] (2C per pixel).  dpur = [dpu | dpr].
 __global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__restrict__ ur, const float *__restrict__ o,
@@ -551,6 +571,14 @@ extern "C" int ramnet_frame_gather(const float *dy, const float *mask, float *ro
     RAMNET_CHECK_ARG(dy && rows && cols && B > 0 && H2 >= 4 && W2 >= 4 && C > 0 && C % 4 == 0);
     const size_t n = (size_t)2 * B * (W2 + H2) * 2 * (C / 4);
     hipLaunchKernelGGL(frame_gather_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, mask, rows, cols, B, H2, W2, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_space_to_depth2(const float *x, float *out, int B, int H, int W, int C, int inverse, void *stream) {
+    RAMNET_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0);
+    hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, out, B, H / 2,
+                       W / 2, C, inverse);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -328,6 +328,32 @@ def border_matrices(w):
     return mats(w), mats(w.transpose(2, 3))
 
 
+# ---- stride-2 5x5 convolution == stride-1 3x3 convolution of the space-to-depth input (4*Cin channels): tap ky of the 5x5
+# filter reads input row 2i + ky - 2 = 2(i + dy) + a with (dy, a) = S2D_TAP[ky]; the slice (dy = 1, a = 1) does not exist (zero).
+S2D_TAP = [(-1, 0), (-1, 1), (0, 0), (0, 1), (1, 0)]
+
+
+def s2d_weights(w):
+    """OIHW [O][I][5][5] -> [O][4*I][3][3] with input channel (a*2 + b)*I + i (pure torch; tests/test_boundary_cpu.py)."""
+    O, I = w.shape[0], w.shape[1]
+    out = w.new_zeros(O, 4, I, 3, 3)
+    for ky, (dy, a) in enumerate(S2D_TAP):
+        for kx, (dx, b) in enumerate(S2D_TAP):
+            out[:, a * 2 + b, :, dy + 1, dx + 1] = w[:, :, ky, kx]
+    return out.reshape(O, 4 * I, 3, 3)
+
+
+def s2d_weights_adjoint(g3, I):
+    """Gradient w.r.t. the [O][4*I][3][3] weights -> gradient w.r.t. the 5x5 weights (reads the 25 populated slices)."""
+    O = g3.shape[0]
+    g3 = g3.view(O, 4, I, 3, 3)
+    out = g3.new_zeros(O, I, 5, 5)
+    for ky, (dy, a) in enumerate(S2D_TAP):
+        for kx, (dx, b) in enumerate(S2D_TAP):
+            out[:, :, ky, kx] = g3[:, a * 2 + b, :, dy + 1, dx + 1]
+    return out
+
+
 class PackRef:
     """Handle on the packed weights of a ConvParam; the launch picks the layout (direct / Winograd) that fits it."""
     __slots__ = ("cp", "transposed")
@@ -415,6 +441,12 @@ class ConvParam:
     def bwd(self):
         return PackRef(self, 1)
 
+    def s2d(self):
+        """3x3 view over the space-to-depth input of this 5x5 stride-2 convolution (S2DConvParam), created once."""
+        if getattr(self, "_s2d", None) is None:
+            self._s2d = S2DConvParam(self)
+        return self._s2d
+
     def bias(self):
         if len(self.biases) == 1:
             return self.biases[0].detach()
@@ -499,6 +531,42 @@ class ConvParam:
         self._dirty = self._ws_used = False
 
 
+class S2DConvParam(ConvParam):
+    """The 3x3 / 4*Cin view of a stride-2 5x5 convolution (s2d_weights): gives that layer the Winograd kernels for forward,
+    backward-data and backward-weights.  Packs follow the parent's parameter versions; the weight gradient accumulates in the
+    Winograd-domain workspace of THIS object and is mapped back into the parent's 5x5 `.grad` when the engine finishes."""
+
+    def __init__(self, parent):
+        assert len(parent.weights) == 1 and parent.k == 5 and parent.gates == 1
+        self.parent = parent
+        self.weights, self.biases, self.gates = parent.weights, parent.biases, 1
+        self.Cout, self.Cin, self.k = parent.Cout, 4 * parent.Cin, 3
+        self.CinWs = self.Cin
+        self._bias = self._ws = self._bws = None
+        self._vbias = None
+        self._ws_fold = None
+        self._fold_used = self._ws_used = False
+        self._packs = {}
+        self._dirty = False
+
+    def _cat_w(self):
+        return s2d_weights(self.parent.weights[0].detach()).contiguous()
+
+    def finalize(self):
+        w, b = self.parent.weights[0], self.parent.biases[0]
+        g3 = torch.zeros(self.Cout, self.Cin, 3, 3, device=w.device)
+        L = H.lib()
+        if getattr(self._ws, "wino", False):
+            H.check(L.ramnet_unpack_wgrad_wino(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino")
+        else:
+            H.check(L.ramnet_unpack_wgrad(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, 3, 3, _st()), "ramnet_unpack_wgrad")
+        ensure_grad(w).add_(s2d_weights_adjoint(g3, self.parent.Cin))
+        ensure_grad(b).add_(self._bws)
+        self._ws.zero_()
+        self._bws.zero_()
+        self._dirty = self._ws_used = False
+
+
 # ------------------------------------------------------------------------------------------------ operators
 def pack_input(x, device):
     """Model input NCHW (any device) -> NHWC with channels zero-padded to a multiple of 4 (model.py:177,200)."""
@@ -534,6 +602,35 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
                       [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)], **desc_kw)
+
+
+# Stride-2 5x5 layers (the encoders) as 3x3 stride-1 convolutions of the space-to-depth input on the Winograd kernels
+# (DESIGN 3.1d).  RAMNET_S2D=0 / set_space_to_depth(False) keeps the direct stride-2 kernels.
+_S2D = _os.environ.get("RAMNET_S2D", "1") == "1"
+
+
+def set_space_to_depth(on):
+    global _S2D
+    _S2D = bool(on)
+
+
+def get_space_to_depth():
+    return _S2D
+
+
+def _s2d_eligible(x, cp, k, stride, up):
+    return bool(_S2D and _WINOGRAD and _PRECISION == H.PREC_F32 and stride == 2 and k == 5 and not up and x.shape[1] % 2 == 0
+                and x.shape[2] % 2 == 0 and x.shape[3] == cp.Cin and cp.Cin % 8 == 0 and cp.gates == 1 and len(cp.weights) == 1)
+
+
+def _space_to_depth(x, inverse=False):
+    """[B,H,W,C] -> [B,H/2,W/2,4C] (channel = pixel parity major), or back."""
+    B, Hh, W, Cc = x.shape
+    out = torch.empty((B, 2 * Hh, 2 * W, Cc // 4) if inverse else (B, Hh // 2, W // 2, 4 * Cc), device=x.device)
+    full = out if inverse else x
+    H.check(H.lib().ramnet_space_to_depth2(_p(x), _p(out), B, full.shape[1], full.shape[2], full.shape[3], int(inverse), _st()),
+            "ramnet_space_to_depth2")
+    return out
 
 
 def _fold_eligible(x, cp, k, stride, up):
@@ -584,7 +681,11 @@ class ConvAct(Function):
         y = torch.empty(B, Ho, Wo, cp.Cout, device=x.device)
         mode = (H.IN_UP2X_SKIP if skip is not None else H.IN_UP2X) if up else H.IN_PLAIN
         epi = H.EPI_RELU if relu else H.EPI_LINEAR
-        if _fold_eligible(x, cp, k, stride, up):
+        ctx.s2d = _s2d_eligible(x, cp, k, stride, up)
+        if ctx.s2d:         # 5x5 stride 2 == 3x3 stride 1 over the four input parities: Winograd kernels
+            x = _space_to_depth(x)
+            conv_launch(x, Taps.get("conv", 3, 1), cp.s2d().fwd(), y, cp.Cout, bias=cp.bias(), epi=epi)
+        elif _fold_eligible(x, cp, k, stride, up):
             _folded_upsample_conv(x, skip, cp, y, epi)
         else:
             conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
@@ -598,6 +699,17 @@ class ConvAct(Function):
         x, skip, y = ctx.saved_tensors
         cp, stride, relu, up, mode = ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode
         dy = dense(dy)
+        if ctx.s2d:         # x is the space-to-depth input saved by forward
+            sp = cp.s2d()
+            ws, bws = sp.grad_ws(wino_ok=True)
+            wgrad_side([x, dy, y], x, Taps.get("conv", 3, 1), dy, ws, cp.Cout, gmask=y if relu else None, dbias=bws)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                gs = torch.empty_like(x)
+                conv_launch(dy, Taps.get("dgrad1", 3, 1), sp.bwd(), gs, sp.Cin, xm=y if relu else None,
+                            in_mode=H.IN_RELUMASK if relu else H.IN_PLAIN)
+                dx = _space_to_depth(gs, inverse=True)
+            return dx, None, None, None, None, None, None, None
         B, Hh, W, _ = x.shape
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)

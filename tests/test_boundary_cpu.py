@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ramnet_abi_version.restype = ctypes.c_int
-    assert lib.ramnet_abi_version() == 7
+    assert lib.ramnet_abi_version() == 8
 
 
 def test_desc_struct_layout_matches_header_field_order():
@@ -316,3 +316,24 @@ def test_winograd_f2x2_3x3_algebra_cpu():
     assert torch.allclose(y, ref, atol=1e-12)
     dg = torch.einsum("ia,ocij,jb->ocab", G, dU, G)                                      # G^T dU G
     assert torch.allclose(dg, g.grad, atol=1e-12)
+
+
+def test_space_to_depth_weight_maps_cpu():
+    """conv5x5 stride 2 == conv3x3 stride 1 of the space-to-depth input with ops.s2d_weights; its adjoint routes the gradient
+    of the 3x3 / 4*Cin weights back to the 5x5 ones (what S2DConvParam.finalize does)."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(2)
+    B, Cin, Cout, H, W = 2, 3, 4, 8, 10
+    x = torch.randn(B, Cin, H, W, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(x, w, None, 2, 2)
+    xs = F.pixel_unshuffle(x, 2).view(B, Cin, 4, H // 2, W // 2).permute(0, 2, 1, 3, 4).reshape(B, 4 * Cin, H // 2, W // 2)
+    w3 = ops.s2d_weights(w.detach()).requires_grad_(True)
+    y = F.conv2d(xs, w3, None, 1, 1)
+    assert torch.allclose(y, ref, atol=1e-12)
+    assert int((ops.s2d_weights(torch.ones(1, 1, 5, 5)) != 0).sum()) == 25          # 25 of the 36 slices are populated
+    g = torch.randn_like(ref)
+    (ref * g).sum().backward()
+    (y * g).sum().backward()
+    assert torch.allclose(ops.s2d_weights_adjoint(w3.grad, Cin), w.grad, atol=1e-12)
