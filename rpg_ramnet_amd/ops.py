@@ -104,9 +104,9 @@ class Taps:
     def get(cls, kind, k, pad, py=0, px=0):
         key = (kind, k, pad, py, px)
         if key not in cls._cache:
-            if kind == "conv":        # forward taps: in(o*s + kh - pad)
+            if kind in ("conv", "conv_s2d"):        # forward taps: in(o*s + kh - pad)
                 tr = [(kh - pad, kw - pad, kh * k + kw) for kh in range(k) for kw in range(k)]
-            elif kind == "dgrad1":    # backward-data of a stride-1 conv: dy(o + pad - kh)
+            elif kind in ("dgrad1", "dgrad1_s2d"):  # backward-data of a stride-1 conv: dy(o + pad - kh)
                 tr = [(pad - kh, pad - kw, kh * k + kw) for kh in range(k) for kw in range(k)]
             elif kind == "dgrad2":    # backward-data of a stride-2 conv, output parity class (py, px)
                 tr = [((py + pad - kh) // 2, (px + pad - kw) // 2, kh * k + kw)
@@ -117,7 +117,9 @@ class Taps:
             else:
                 raise KeyError(kind)
             cls._cache[key] = cls(tr)
-            cls._cache[key].wino = kind in ("conv", "dgrad1") and k == 3 and pad == 1   # dense padded 3x3 window
+            cls._cache[key].wino = kind in ("conv", "dgrad1", "conv_s2d", "dgrad1_s2d") and k == 3 and pad == 1   # dense padded 3x3
+            if kind.endswith("_s2d"):     # 3x3 over 4*Cin space-to-depth channels standing for a 5x5 stride-2 layer over Cin
+                cls._cache[key].flop_taps = 25.0 / 4.0
             if kind == "fold":          # one output parity of a 5x5 convolution after the x2 upsample
                 cls._cache[key].flop_taps = 25
         return cls._cache[key]
@@ -684,7 +686,7 @@ class ConvAct(Function):
         ctx.s2d = _s2d_eligible(x, cp, k, stride, up)
         if ctx.s2d:         # 5x5 stride 2 == 3x3 stride 1 over the four input parities: Winograd kernels
             x = _space_to_depth(x)
-            conv_launch(x, Taps.get("conv", 3, 1), cp.s2d().fwd(), y, cp.Cout, bias=cp.bias(), epi=epi)
+            conv_launch(x, Taps.get("conv_s2d", 3, 1), cp.s2d().fwd(), y, cp.Cout, bias=cp.bias(), epi=epi)
         elif _fold_eligible(x, cp, k, stride, up):
             _folded_upsample_conv(x, skip, cp, y, epi)
         else:
@@ -702,11 +704,11 @@ class ConvAct(Function):
         if ctx.s2d:         # x is the space-to-depth input saved by forward
             sp = cp.s2d()
             ws, bws = sp.grad_ws(wino_ok=True)
-            wgrad_side([x, dy, y], x, Taps.get("conv", 3, 1), dy, ws, cp.Cout, gmask=y if relu else None, dbias=bws)
+            wgrad_side([x, dy, y], x, Taps.get("conv_s2d", 3, 1), dy, ws, cp.Cout, gmask=y if relu else None, dbias=bws)
             dx = None
             if ctx.needs_input_grad[0]:
                 gs = torch.empty_like(x)
-                conv_launch(dy, Taps.get("dgrad1", 3, 1), sp.bwd(), gs, sp.Cin, xm=y if relu else None,
+                conv_launch(dy, Taps.get("dgrad1_s2d", 3, 1), sp.bwd(), gs, sp.Cin, xm=y if relu else None,
                             in_mode=H.IN_RELUMASK if relu else H.IN_PLAIN)
                 dx = _space_to_depth(gs, inverse=True)
             return dx, None, None, None, None, None, None, None
