@@ -18,21 +18,35 @@
 
 namespace ramnet {
 
-constexpr int GW_CI = 32, GW_CO = 64;          // channels per workgroup
+constexpr int GW_CO = 64;                      // output channels per workgroup
 constexpr int GW_T = 8;                        // tiles per batch (2 x 16 output pixels)
-constexpr int GW_LDX = 36, GW_LDY = 68;        // padded raw-patch rows (floats): (2 pixels) * LD == 8 (mod 64) -> conflict-free
+constexpr int GW_LDY = 68;                     // padded raw-patch rows (floats): (2 pixels) * LD == 8 (mod 64) -> conflict-free
 constexpr int GW_XPIX = 4 * 18, GW_YPIX = 2 * 16;
-constexpr int GW_V = 16 * GW_CI * GW_T;        // 4096 floats
 constexpr int GW_Z = 16 * GW_CO * GW_T;        // 8192 floats
-constexpr int GW_XP = GW_XPIX * GW_LDX;        // 2592
 constexpr int GW_YP = GW_YPIX * GW_LDY;        // 2176
+
+// Geometry of the two workgroup shapes: CIB = 32 input channels (4 waves, two workgroups per CU) or 64 (8 waves, one per CU;
+// the transform and barrier phases are then shared by twice the MFMA work).
+template <int CIB>
+struct GwGeom {
+    static constexpr int NT = CIB * 8;             // threads: one (tile, input channel) transform item each
+    static constexpr int XQ = CIB / 4;             // channel quads per raw input pixel
+    static constexpr int LDX = CIB + 4;            // 36 / 68: (2 pixels) * LD == 8 (mod 64)
+    static constexpr int XSLOTS = GW_XPIX * XQ;
+    static constexpr int NXS = (XSLOTS + NT - 1) / NT;     // 3 for both shapes
+    static constexpr int NYS = GW_YPIX * 16 / NT;          // 2 / 1
+    static constexpr int NZ = GW_CO * GW_T / NT;           // gradient transform items per thread: 2 / 1
+    static constexpr int V = 16 * CIB * GW_T;
+    static constexpr int XP = GW_XPIX * LDX;
+    static constexpr size_t lds = (size_t)(V + GW_Z + XP + GW_YP) * sizeof(float);
+};
 
 #ifdef WW_TRACE   // tools/wgrad_wino_trace.hip: per-wave timestamps at the phase boundaries of the batch loop
 __device__ unsigned long long *g_ww_trace;
 #define WW_STAMP(slot)                                                                                                   \
     do {                                                                                                                 \
         if (lane == 0 && nb_done < 32)                                                                                   \
-            g_ww_trace[((((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 32 + nb_done) * 4 + (slot)] = \
+            g_ww_trace[((((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (G::NT / 64) + wave) * 32 + nb_done) * 4 + (slot)] = \
                 __builtin_amdgcn_s_memtime();                                                                            \
     } while (0)
 #else
@@ -46,17 +60,19 @@ struct WgradWinoParams {
 };
 
 // XM: the input loader has a second operand for this workgroup's channels (h*r product / ReLU mask); GM: ReLU mask on dy.
-template <bool XM, bool GM>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
+template <bool XM, bool GM, int CIB>
+__global__ void __launch_bounds__(CIB * 8, CIB == 32 ? 2 : 1) conv_wgrad_wino_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
+    using G = GwGeom<CIB>;
+    constexpr int NT = G::NT, XQ = G::XQ, GW_CI = CIB, GW_LDX = G::LDX, NXS = G::NXS, NYS = G::NYS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *V = smem;              // [16][32][8]
-    float *Z = V + GW_V;          // [16][64][8]
-    float *Xp = Z + GW_Z;         // [4][18][36]
-    float *Yp = Xp + GW_XP;       // [2][16][68]
+    float *V = smem;              // [16][CIB][8]
+    float *Z = V + G::V;          // [16][64][8]
+    float *Xp = Z + GW_Z;         // [4][18][LDX]
+    float *Yp = Xp + G::XP;       // [2][16][68]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
-    const int ch = wave & 1, ph = wave >> 1;            // output-channel half, position half
+    const int ch = wave & 1, ph = (wave >> 1) & 1, cih = wave >> 2;   // output-channel half, position half, input-channel half (8 waves)
     const int c0 = blockIdx.y * GW_CI, n0 = blockIdx.z * GW_CO;
     const InSrc &s = q.src;
 
@@ -68,31 +84,31 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
 
     // ---- raw-data prefetch.  Slot geometry is per-thread constant; per batch only a wave-uniform base pointer moves.
     // (The concatenated input switches tensors at C0, a multiple of 32: uniform for the workgroup's 32 channels.)
-    float4 xr[3], xm[3], yr[2], ym[2];
+    float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
     unsigned xok = 0, yok = 0;
     const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;
     const bool use_m = XM && (s.mode == RAMNET_IN_RELUMASK || second);      // wave-uniform: the h*r product only touches the h half
     const float *xsrc = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
     const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
     const int ldS = second ? s.ld1 : s.ld0;
-    int xpy[3], xpx[3], xoff[3], xmoff[3], ypx[2], yoff[2], ymoff[2];
+    int xpy[NXS], xpx[NXS], xoff[NXS], xmoff[NXS], ypx[NYS], ypy[NYS], yoff[NYS], ymoff[NYS];
     const int safe_x = (-q.dy0 * s.Win - q.dx0) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;   // the strip's own first pixel: always readable
-    bool xslot[3], yslot[2];
+    bool xslot[NXS], yslot[NYS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int sl = tid + i * 256, qd = sl & 7, pix = sl >> 3;
+    for (int i = 0; i < NXS; ++i) {
+        const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
         xpy[i] = pix / 18, xpx[i] = pix - xpy[i] * 18;
-        xslot[i] = sl < GW_XPIX * 8 && c0 + qd * 4 < s.Cin;
+        xslot[i] = sl < G::XSLOTS && c0 + qd * 4 < s.Cin;
         xoff[i] = (xpy[i] * s.Win + xpx[i]) * ldS + qd * 4;
         xmoff[i] = (xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int sl = tid + i * 256, qd = sl & 15, pix = sl >> 4;
-        ypx[i] = pix & 15;
+    for (int i = 0; i < NYS; ++i) {
+        const int sl = tid + i * NT, qd = sl & 15, pix = sl >> 4;
+        ypx[i] = pix & 15, ypy[i] = pix >> 4;
         yslot[i] = n0 + qd * 4 < p.Cout;
-        yoff[i] = ((pix >> 4) * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4;
-        ymoff[i] = ((pix >> 4) * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4;
+        yoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4;
+        ymoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4;
     }
     int lb_ty = 0, lb_bx = 0;                     // batch being loaded (wave-uniform)
     const float *lb_x = nullptr, *lb_m = nullptr, *lb_g = nullptr, *lb_gm = nullptr;
@@ -118,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
         xok |= (ok ? 1u : 0u) << i;
     };
     auto load_y = [&](int i) {
-        const bool ok = yslot[i] && 2 * lb_ty + i < p.Ho && 16 * lb_bx + ypx[i] < p.Wo;     // slot i = output row i of the strip
+        const bool ok = yslot[i] && 2 * lb_ty + ypy[i] < p.Ho && 16 * lb_bx + ypx[i] < p.Wo;
         yr[i] = ld4(lb_g + (ok ? yoff[i] : 0));
         if (GM) ym[i] = ld4(lb_gm + (ok ? ymoff[i] : 0));
         yok |= (ok ? 1u : 0u) << i;
@@ -126,13 +142,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
     auto load_raw = [&](int batch) {
         load_begin(batch);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) load_x(i);
+        for (int i = 0; i < NXS; ++i) load_x(i);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) load_y(i);
+        for (int i = 0; i < NYS; ++i) load_y(i);
     };
     float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
     auto store_x = [&](int i) {
-        const int sl = tid + i * 256;
+        const int sl = tid + i * NT;
         float4 r = xr[i];
         if (use_m) {
             if (s.mode == RAMNET_IN_RELUMASK)
@@ -141,11 +157,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
                 r = f4mul(r, xm[i]);
         }
         if (!((xok >> i) & 1u)) r = f4zero();
-        if (sl < GW_XPIX * 8) st4(Xp + (sl >> 3) * GW_LDX + (sl & 7) * 4, r);
+        if (sl < G::XSLOTS) st4(Xp + (sl / XQ) * GW_LDX + (sl % XQ) * 4, r);
     };
     bool count_bias = true;                       // false for the clamped re-store of the last batch
     auto store_y = [&](int i) {
-        const int sl = tid + i * 256;
+        const int sl = tid + i * NT;
         float4 r = yr[i];
         if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
         if (!((yok >> i) & 1u)) r = f4zero();
@@ -153,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
         if (count_bias) bsum = f4add(bsum, r);
     };
 
-    // ---- transforms: thread = (tile tid&7, channel tid>>3 [+32 for the second Z item])
+    // ---- transforms: thread = (tile tid&7, channel tid>>3 [+32 for the second Z item of the 4-wave shape])
     const int tt8 = tid & 7, tc = tid >> 3;
     auto transform = [&]() {
         {   // V = B^T d B of the 4x4 input window of (tile, input channel)
@@ -177,8 +193,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
             }
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {   // Z = A dy A^T of the 2x2 gradient tile of (tile, output channel)
-            const int co = tc + 32 * k;
+        for (int k = 0; k < G::NZ; ++k) {   // Z = A dy A^T of the 2x2 gradient tile of (tile, output channel)
+            const int co = tc + CIB * k;
             const float g00 = Yp[(2 * tt8) * GW_LDY + co], g01 = Yp[(2 * tt8 + 1) * GW_LDY + co];
             const float g10 = Yp[(16 + 2 * tt8) * GW_LDY + co], g11 = Yp[(16 + 2 * tt8 + 1) * GW_LDY + co];
             // rows of A dy: (g0*, g0* + g1*, g0* - g1*, -g1*)
@@ -194,7 +210,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
         }
     };
 
-    const int aoff = (ph * 8 * GW_CI + l31) * GW_T + kk * 4;
+    const int aoff = (ph * 8 * GW_CI + cih * 32 + l31) * GW_T + kk * 4;
     const int boff = (ph * 8 * GW_CO + ch * 32 + l31) * GW_T + kk * 4;
 
     // ---- pipeline: batch list of this workgroup = blockIdx.x, +gridDim.x, ...  The loop body is branch-free: past the end the
@@ -205,9 +221,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
         const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
         load_raw(batch);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) store_x(i);
+        for (int i = 0; i < NXS; ++i) store_x(i);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) store_y(i);
+        for (int i = 0; i < NYS; ++i) store_y(i);
         load_raw(min(batch + step, last));
         __syncthreads();
         transform();
@@ -229,11 +245,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
                 // raw data of the next batch -> LDS (its readers, transform(i), finished before the last barrier), then the
                 // loads of the batch after it into the registers just stored
                 if (pp < 3) store_x(pp);
-                else if (pp < 5) store_y(pp - 3);
+                else if (pp - 3 < NYS) store_y(pp - 3);
                 if (pp == 4) load_begin(b2);
                 if (pp == 5) load_x(0), load_x(1);
                 if (pp == 6) load_x(2), load_y(0);
-                if (pp == 7) load_y(1);
+                if (pp == 7 && NYS > 1) load_y(NYS - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[pp], 0, 0, 0);
                 acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[pp], 0, 0, 0);
@@ -256,18 +272,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_kernel(const ramnet_wg
     for (int pp = 0; pp < 8; ++pp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int c = c0 + cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
             if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)(ph * 8 + pp) * Cin + c) * p.Cout + n, acc[pp][r]);
         }
     }
     if (p.dbias != nullptr && blockIdx.y == 0) {
         __syncthreads();
-        float *red = smem;                        // [16][64]
+        float *red = smem;                        // [NT/16][64]
         st4(red + (tid >> 4) * GW_CO + (tid & 15) * 4, bsum);
         __syncthreads();
         if (tid < GW_CO) {
             float t = 0.f;
-            for (int g = 0; g < 16; ++g) t += red[g * GW_CO + tid];
+            for (int g = 0; g < NT / 16; ++g) t += red[g * GW_CO + tid];
             if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, t);
         }
     }
@@ -296,7 +312,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win);
-    if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % GW_CI == 0);   // a workgroup's 32 channels come from one tensor
+    if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % 32 == 0);   // a workgroup's channels come from one tensor
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
     for (int t = 0; t < 9; ++t) {
@@ -317,10 +333,15 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
-    const size_t lds = (size_t)(GW_V + GW_Z + GW_XP + GW_YP) * sizeof(float);
-    const int gy = cdiv(q.src.Cin, GW_CI), gz = cdiv(d.Cout, GW_CO);
+    // 8-wave workgroups (64 x 64 channels) when both channel counts fill them and the concatenation boundary allows
+    static const char *w8 = getenv("RAMNET_WGRAD_WINO8");
+    const int w8m = w8 ? atoi(w8) : 1;   // 0: never, 1: whenever the shape allows, 2: only single-tensor inputs, 3: only concatenated
+    const bool wide = w8m != 0 && q.src.Cin % 64 == 0 && d.Cout >= 64 && (!cat || d.C0 % 64 == 0) && (w8m != 2 || !cat) && (w8m != 3 || cat);
+    const int cib = wide ? 64 : 32;
+    const size_t lds = wide ? GwGeom<64>::lds : GwGeom<32>::lds;
+    const int gy = cdiv(q.src.Cin, cib), gz = cdiv(d.Cout, GW_CO);
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
-    int splits = (se ? atoi(se) : 512) / (gy * gz);
+    int splits = (se ? atoi(se) : (wide ? 256 : 512)) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
     const dim3 grid(splits, gy, gz);
@@ -329,14 +350,21 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
     auto go = [&](auto kern) -> int {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, q);
+        hipLaunchKernelGGL(kern, grid, dim3(cib * 8), lds, st, d, q);
         return 0;
     };
     int rc;
-    if (xm && gm) rc = go(conv_wgrad_wino_kernel<true, true>);
-    else if (xm) rc = go(conv_wgrad_wino_kernel<true, false>);
-    else if (gm) rc = go(conv_wgrad_wino_kernel<false, true>);
-    else rc = go(conv_wgrad_wino_kernel<false, false>);
+    if (wide) {
+        if (xm && gm) rc = go(conv_wgrad_wino_kernel<true, true, 64>);
+        else if (xm) rc = go(conv_wgrad_wino_kernel<true, false, 64>);
+        else if (gm) rc = go(conv_wgrad_wino_kernel<false, true, 64>);
+        else rc = go(conv_wgrad_wino_kernel<false, false, 64>);
+    } else {
+        if (xm && gm) rc = go(conv_wgrad_wino_kernel<true, true, 32>);
+        else if (xm) rc = go(conv_wgrad_wino_kernel<true, false, 32>);
+        else if (gm) rc = go(conv_wgrad_wino_kernel<false, true, 32>);
+        else rc = go(conv_wgrad_wino_kernel<false, false, 32>);
+    }
     if (rc) return rc;
     RAMNET_LAUNCH_CHECK();
     return 0;
