@@ -133,14 +133,14 @@ class KernelTimer:
             s.record()
             conv0(x0, taps, w, out, Cout, **kw)
             e.record()
-            cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
+            cin = ((kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)) * (4 if kw.get("in_mode", 0) == 6 else 1)   # IN_S2D: 4 parities
             nout = Cout * (4 if kw.get("epi") == 5 else 1)
             timer.rec.append((name, s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout))
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:
                 return wgrad0(x0, taps, dout, dw, Cout, **kw)
-            cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
+            cin = ((kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)) * (4 if kw.get("in_mode", 0) == 6 else 1)
             tpm = 1 if cin > 16 else 8 if cin <= 4 else 4 if cin <= 8 else 2      # mirror of ramnet_wgrad_launch
             ntt = -(-taps.n // tpm)
             if Cout <= 32 or taps.n > 9:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 8
+#define RAMNET_ABI_VERSION 9
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -31,7 +31,11 @@ enum ramnet_in_mode {
     RAMNET_IN_CAT_MUL = 2,   /* cat(x0[C0], x1[C1] * xm[C1])   ConvGRU candidate submodules.py:450  */
     RAMNET_IN_UP2X = 3,      /* bilinear x2 (align_corners=False) of x0          submodules.py:88   */
     RAMNET_IN_UP2X_SKIP = 4, /* bilinear x2 of (x0 + x1)       decoder skip sum  statenet.py:305-308 */
-    RAMNET_IN_RELUMASK = 5   /* x0 * (xm > 0)                  backward through a ReLU             */
+    RAMNET_IN_RELUMASK = 5,  /* x0 * (xm > 0)                  backward through a ReLU             */
+    RAMNET_IN_S2D = 6        /* space-to-depth view of x0 [B][2*Hin][2*Win][C0]: logical channel (a*2+c)*C0 + ch of pixel
+                              * (i, j) = x0(2i+a, 2j+c, ch), Cin = 4*C0 — the stride-2 5x5 encoders (submodules.py:22-48) as
+                              * 3x3 stride-1 convolutions without materialising the view.  WINOGRAD launches only; C0 a power
+                              * of two >= 8                                                       */
 };
 
 /* ---- arithmetic of the MFMA contraction ----------------------------------------------------------
@@ -82,6 +86,9 @@ typedef struct ramnet_conv_desc {
     int frame;                      /* > 0 (folded upsample-conv, LINEAR / RELU epilogues): border corrections are added to the
                                      * pre-activation of the outermost `frame` (= 2) rows / columns of the FULL output:
                                      * rows from e1 [2 sides][B][WoF][lde1 = frame*Cout], columns from e0 [2][B][HoF][lde0]  */
+    int out_s2d;                    /* C > 0 (WINOGRAD, LINEAR epilogue, no bias, beta = 0): the Cout = 4*C output channels are the
+                                     * space-to-depth view of out [B][HoF = 2*Ho][WoF = 2*Wo][C]: channel (a*2+c)*C + ch of pixel (i, j)
+                                     * is stored at out(2i+a, 2j+c, ch) — backward-data of the encoders.  C a power of two >= 8  */
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)

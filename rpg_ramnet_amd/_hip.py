@@ -9,7 +9,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet_hip.so")     # (override: A/B builds)
 
-IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK = range(6)
+IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D = range(7)
 PREC_F32, PREC_BF16X3 = 0, 1
 ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("precision", C.c_int),
         ("algo", C.c_int),
         ("frame", C.c_int),
+        ("out_s2d", C.c_int),
     ]
 
 
@@ -119,7 +120,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 8:
+        if l.ramnet_abi_version() != 9:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

@@ -354,11 +354,12 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
         const int rc = check_desc(*dp);
         return rc ? rc : launch_wino(*dp, (hipStream_t)stream);
     }
-    RAMNET_CHECK_ARG(dp->algo == RAMNET_ALGO_DIRECT);
+    RAMNET_CHECK_ARG(dp->algo == RAMNET_ALGO_DIRECT && dp->in_mode != RAMNET_IN_S2D && dp->out_s2d == 0);   // fused space-to-depth: Winograd kernels only
     return launch_classes(dp, 1, (hipStream_t)stream);
 }
 
 extern "C" int ramnet_conv_launch_multi(const ramnet_conv_desc *descs, int n, void *stream) {
     RAMNET_CHECK_ARG(descs != nullptr && n >= 1 && n <= 4);
+    for (int i = 0; i < n; ++i) RAMNET_CHECK_ARG(descs[i].in_mode != RAMNET_IN_S2D && descs[i].out_s2d == 0);
     return launch_classes(descs, n, (hipStream_t)stream);
 }

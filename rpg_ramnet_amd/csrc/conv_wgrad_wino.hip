@@ -86,20 +86,25 @@ __global__ void __launch_bounds__(CIB * 8, CIB == 32 ? 2 : 1) conv_wgrad_wino_ke
     // (The concatenated input switches tensors at C0, a multiple of 32: uniform for the workgroup's 32 channels.)
     float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
     unsigned xok = 0, yok = 0;
-    const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;
+    const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
     const bool use_m = XM && (s.mode == RAMNET_IN_RELUMASK || second);      // wave-uniform: the h*r product only touches the h half
-    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
+    // space-to-depth view (RAMNET_IN_S2D, ld1 = log2(C0)): the workgroup's channels lie in ONE parity group (a, c); logical
+    // pixel (i, j) is full-resolution pixel (2i + a, 2j + c): pixel strides double, the group moves the base pointer
+    const bool s2d = s.mode == RAMNET_IN_S2D;
+    const int sgrp = s2d ? c0 >> s.ld1 : 0;
+    const int rowS = s2d ? 4 * s.Win : s.Win, colS = s2d ? 2 : 1;          // logical row / column step in source pixels
+    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s2d ? s.x0 + ((sgrp >> 1) * 2 * s.Win + (sgrp & 1)) * s.ld0 + (c0 - (sgrp << s.ld1)) : s.x0 + c0;
     const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
     const int ldS = second ? s.ld1 : s.ld0;
     int xpy[NXS], xpx[NXS], xoff[NXS], xmoff[NXS], ypx[NYS], ypy[NYS], yoff[NYS], ymoff[NYS];
-    const int safe_x = (-q.dy0 * s.Win - q.dx0) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;   // the strip's own first pixel: always readable
+    const int safe_x = (-q.dy0 * rowS - q.dx0 * colS) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;   // the strip's own first pixel: always readable
     bool xslot[NXS], yslot[NYS];
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
         const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
         xpy[i] = pix / 18, xpx[i] = pix - xpy[i] * 18;
         xslot[i] = sl < G::XSLOTS && c0 + qd * 4 < s.Cin;
-        xoff[i] = (xpy[i] * s.Win + xpx[i]) * ldS + qd * 4;
+        xoff[i] = (xpy[i] * rowS + xpx[i] * colS) * ldS + qd * 4;
         xmoff[i] = (xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4;
     }
 #pragma unroll
@@ -120,7 +125,8 @@ __global__ void __launch_bounds__(CIB * 8, CIB == 32 ? 2 : 1) conv_wgrad_wino_ke
         const int b = tt / q.ty_n;
         const long pix = ((long)b * p.Ho + 2 * lb_ty) * p.Wo + 16 * lb_bx;
         const long corner = pix + (long)q.dy0 * s.Win + q.dx0;           // patch corner (may lie "before" the image)
-        lb_x = xsrc + corner * ldS;
+        const long corner_src = s2d ? ((long)b * p.Ho + 2 * lb_ty + q.dy0) * rowS + (16 * lb_bx + q.dx0) * colS : corner;
+        lb_x = xsrc + corner_src * ldS;
         if (use_m) lb_m = msrc + corner * s.ldm;
         lb_g = p.dout + pix * p.ldg;
         if (GM) lb_gm = p.gmask + pix * p.ldgm;
@@ -313,6 +319,8 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win);
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % 32 == 0);   // a workgroup's channels come from one tensor
+    auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
+    if (d.in_mode == RAMNET_IN_S2D) RAMNET_CHECK_ARG(d.C0 >= 32 && log2_exact(d.C0) > 0);                 // ... or one parity group
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
     for (int t = 0; t < 9; ++t) {
@@ -330,13 +338,14 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
     q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    if (d.in_mode == RAMNET_IN_S2D) q.src.Cin = 4 * d.C0, q.src.ld1 = log2_exact(d.C0);
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
     // 8-wave workgroups (64 x 64 channels) when both channel counts fill them and the concatenation boundary allows
     static const char *w8 = getenv("RAMNET_WGRAD_WINO8");
     const int w8m = w8 ? atoi(w8) : 1;   // 0: never, 1: whenever the shape allows, 2: only single-tensor inputs, 3: only concatenated
-    const bool wide = w8m != 0 && q.src.Cin % 64 == 0 && d.Cout >= 64 && (!cat || d.C0 % 64 == 0) && (w8m != 2 || !cat) && (w8m != 3 || cat);
+    const bool wide = w8m != 0 && q.src.Cin % 64 == 0 && d.Cout >= 64 && ((!cat && d.in_mode != RAMNET_IN_S2D) || d.C0 % 64 == 0) && (w8m != 2 || !cat) && (w8m != 3 || cat);
     const int cib = wide ? 64 : 32;
     const size_t lds = wide ? GwGeom<64>::lds : GwGeom<32>::lds;
     const int gy = cdiv(q.src.Cin, cib), gz = cdiv(d.Cout, GW_CO);

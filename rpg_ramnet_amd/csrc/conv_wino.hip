@@ -37,6 +37,7 @@ struct WinoParams {
     int tiles_x, tiles_y;
     int dy0, dx0;           // offset of the first filter tap (-1 for the padded 3x3)
     int vec4;               // all epilogue operands allow 16-byte channel-quad accesses
+    int s2d_shift;          // log2(out_s2d) or 0
 };
 
 __device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
@@ -74,7 +75,10 @@ struct WinoPatch {
             const int iy = iy0 + py, ix = ix0 + px;
             const bool slot = sl < WPH * WPW * 2;
             const bool in = slot && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
-            const unsigned gp = in ? (unsigned)((b * s.Hin + iy) * s.Win + ix) : 0u;
+            // space-to-depth view: logical pixel (iy, ix) starts at full-resolution pixel (2iy, 2ix); the parity group of a
+            // chunk only moves the (wave-uniform) base pointer, see load_slot
+            const unsigned gp = !in ? 0u : s.mode == RAMNET_IN_S2D ? (unsigned)((b * 2 * s.Hin + 2 * iy) * 2 * s.Win + 2 * ix)
+                                                                   : (unsigned)((b * s.Hin + iy) * s.Win + ix);
             off0[i] = gp * s.ld0 + qd * 4, off1[i] = gp * s.ld1 + qd * 4, offm[i] = gp * s.ldm + qd * 4;
             cmax[i] = in ? s.Cin - qd * 4 : -1;
             ldst[i] = slot ? sl * 4 : -1;
@@ -82,8 +86,13 @@ struct WinoPatch {
     }
     // issue the global loads of slot i for the 8 channels starting at c0 (wave-uniform)
     __device__ __forceinline__ void load_slot(const InSrc &s, int c0, int i) {
-        const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;     // uniform
+        const bool cat = s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL;
+        const bool second = cat && c0 >= s.C0;     // uniform
         const float *base = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
+        if (s.mode == RAMNET_IN_S2D) {              // ld1 = log2(C0): parity group g = (a*2 + c) of the chunk -> pixel (2i+a, 2j+c)
+            const int g = c0 >> s.ld1;
+            base = s.x0 + ((g >> 1) * 2 * s.Win + (g & 1)) * s.ld0 + (c0 - (g << s.ld1));
+        }
         const bool hasm = s.mode == RAMNET_IN_RELUMASK || (s.mode == RAMNET_IN_CAT_MUL && second);      // uniform
         const float *mbase = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
         const bool ok = c0 < cmax[i];
@@ -94,7 +103,7 @@ struct WinoPatch {
     __device__ __forceinline__ void load(const InSrc &s, int c0) { load_slot(s, c0, 0), load_slot(s, c0, 1); }
     // registers of slot i (loaded for channel c0) -> LDS patch [pixel][8]
     __device__ __forceinline__ void store_slot(float *__restrict__ patch, const InSrc &s, int c0, int i) const {
-        const bool second = s.mode != RAMNET_IN_PLAIN && s.mode != RAMNET_IN_RELUMASK && c0 >= s.C0;
+        const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
         const bool hasm = s.mode == RAMNET_IN_RELUMASK || (s.mode == RAMNET_IN_CAT_MUL && second);
         float4 r = v[i];
         if (hasm) {
@@ -337,6 +346,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
             const int sl = tid + i * 256, pxl = sl >> 4, qd = sl & 15;
             const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), nq = n0 + qd * 4;
             if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
+            if (q.s2d_shift) {      // out_s2d: the quad's parity group picks the full-resolution pixel (LINEAR, no bias: checked on the host)
+                const int g = nq >> q.s2d_shift;
+                const size_t pix = ((size_t)b * p.HoF + 2 * oy + (g >> 1)) * p.WoF + 2 * ox + (g & 1);
+                st4(p.out + pix * p.ldo + (nq - (g << q.s2d_shift)), ld4(O + pxl * OLD + qd * 4));
+                continue;
+            }
             const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
             epilogue_store4(p, epi, pix, nq, ld4(O + pxl * OLD + qd * 4), epilogue_addold(p, oy * p.osy + p.ooy, ox * p.osx + p.oox));
         }
@@ -395,6 +410,8 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && d.precision == RAMNET_PREC_F32);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
+    auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
+    if (d.in_mode == RAMNET_IN_S2D) RAMNET_CHECK_ARG(d.C0 >= WK && log2_exact(d.C0) > 0);                 // a chunk lies in one parity group
     // the taps must be the dense 3x3 window; which weight slice each one reads is baked into the Winograd pack
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
@@ -414,6 +431,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
     q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    if (d.in_mode == RAMNET_IN_S2D) q.src.Cin = 4 * d.C0, q.src.ld1 = log2_exact(d.C0);
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = d.epi == RAMNET_EPI_LSTM ? cdiv(d.Cout, 16) : cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
     q.dy0 = dymin, q.dx0 = dxmin;
@@ -422,6 +440,12 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
              (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1))) &&
              (!d.o2 || (d.ldo2 % 4 == 0 && al16(d.o2)));
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(q.vec4);      // the cell epilogue works on channel quads of the staged tile
+    q.s2d_shift = 0;
+    if (d.out_s2d) {
+        RAMNET_CHECK_ARG(d.out_s2d >= 8 && log2_exact(d.out_s2d) > 0 && d.Cout == 4 * d.out_s2d && q.vec4 && d.epi == RAMNET_EPI_LINEAR &&
+                         !d.bias && d.beta == 0.f && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
+        q.s2d_shift = log2_exact(d.out_s2d);
+    }
     const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);

@@ -152,7 +152,7 @@ def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
 
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
-                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0):
+                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0):
     B = x0.shape[0]
     d = H.ConvDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
@@ -171,7 +171,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.HoF, d.WoF = out.shape[1], out.shape[2]
     d.Ho, d.Wo = (d.HoF if Ho is None else Ho), (d.WoF if Wo is None else Wo)
     d.osy, d.osx, d.ooy, d.oox = os
-    d.epi, d.beta, d.frame = epi, beta, frame
+    d.epi, d.beta, d.frame, d.out_s2d = epi, beta, frame, out_s2d
     d.e0, d.e1 = _p(e0), _p(e1)
     d.lde0, d.lde1 = (ld(e0) if e0 is not None else 0), (ld(e1) if e1 is not None else 0)
     d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
@@ -238,7 +238,7 @@ def decoder_overlap():
 def decode_stream(dev):
     st = _DECODE.get(dev)
     if st is None:
-        st = _DECODE[dev] = torch.cuda.Stream(device=dev)
+        st = _DECODE[dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("RAMNET_DECODE_PRIORITY", "0")))
     _DECODE_USED.add(dev)
     return st
 
@@ -246,7 +246,7 @@ def decode_stream(dev):
 def _side_stream(dev):
     st = _SIDE.get(dev)
     if st is None:
-        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("RAMNET_WGRAD_PRIORITY", "0")))
     return st
 
 
@@ -625,6 +625,20 @@ def _s2d_eligible(x, cp, k, stride, up):
                 and x.shape[2] % 2 == 0 and x.shape[3] == cp.Cin and cp.Cin % 8 == 0 and cp.gates == 1 and len(cp.weights) == 1)
 
 
+# The space-to-depth view is read / written in place by the Winograd kernels (RAMNET_IN_S2D loader, out_s2d epilogue) when
+# the channel count is a power of two >= 32; RAMNET_S2D_FUSED=0 materialises it with ramnet_space_to_depth2 instead.
+_S2D_FUSED = _os.environ.get("RAMNET_S2D_FUSED", "1") == "1"
+
+
+def set_space_to_depth_fused(on):
+    global _S2D_FUSED
+    _S2D_FUSED = bool(on)
+
+
+def _s2d_fused(C):
+    return bool(_S2D_FUSED and C >= 32 and C & (C - 1) == 0)
+
+
 def _space_to_depth(x, inverse=False):
     """[B,H,W,C] -> [B,H/2,W/2,4C] (channel = pixel parity major), or back."""
     B, Hh, W, Cc = x.shape
@@ -684,7 +698,11 @@ class ConvAct(Function):
         mode = (H.IN_UP2X_SKIP if skip is not None else H.IN_UP2X) if up else H.IN_PLAIN
         epi = H.EPI_RELU if relu else H.EPI_LINEAR
         ctx.s2d = _s2d_eligible(x, cp, k, stride, up)
-        if ctx.s2d:         # 5x5 stride 2 == 3x3 stride 1 over the four input parities: Winograd kernels
+        ctx.s2d_fused = ctx.s2d and _s2d_fused(x.shape[3])
+        if ctx.s2d_fused:   # ... reading the four parities straight from x
+            conv_launch(x, Taps.get("conv_s2d", 3, 1), cp.s2d().fwd(), y, cp.Cout, in_mode=H.IN_S2D, Hin=Hh // 2, Win=W // 2,
+                        bias=cp.bias(), epi=epi)
+        elif ctx.s2d:       # 5x5 stride 2 == 3x3 stride 1 over the four input parities: Winograd kernels
             x = _space_to_depth(x)
             conv_launch(x, Taps.get("conv_s2d", 3, 1), cp.s2d().fwd(), y, cp.Cout, bias=cp.bias(), epi=epi)
         elif _fold_eligible(x, cp, k, stride, up):
@@ -701,6 +719,18 @@ class ConvAct(Function):
         x, skip, y = ctx.saved_tensors
         cp, stride, relu, up, mode = ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode
         dy = dense(dy)
+        if ctx.s2d_fused:   # x is the full-resolution input; the kernels address its space-to-depth view
+            sp = cp.s2d()
+            ws, bws = sp.grad_ws(wino_ok=True)
+            Hl, Wl = x.shape[1] // 2, x.shape[2] // 2
+            wgrad_side([x, dy, y], x, Taps.get("conv_s2d", 3, 1), dy, ws, cp.Cout, in_mode=H.IN_S2D, Hin=Hl, Win=Wl,
+                       gmask=y if relu else None, dbias=bws)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                conv_launch(dy, Taps.get("dgrad1_s2d", 3, 1), sp.bwd(), dx, sp.Cin, xm=y if relu else None,
+                            in_mode=H.IN_RELUMASK if relu else H.IN_PLAIN, Ho=Hl, Wo=Wl, out_s2d=x.shape[3])
+            return dx, None, None, None, None, None, None, None
         if ctx.s2d:         # x is the space-to-depth input saved by forward
             sp = cp.s2d()
             ws, bws = sp.grad_ws(wino_ok=True)

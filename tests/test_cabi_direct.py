@@ -117,3 +117,81 @@ def test_winograd_conv_and_wgrad_through_raw_descriptors():
     assert L.ramnet_unpack_wgrad_wino(ptr(ws), ptr(grad), Cout, Cin, Cin, Cout, 0, st) == 0
     assert float((grad.cpu() - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-4
     assert float((dbias.cpu() - br.grad).abs().max() / br.grad.abs().max()) < 2e-4
+
+
+def test_space_to_depth_view_through_raw_descriptors():
+    """RAMNET_IN_S2D / out_s2d: the Winograd kernels read and write the space-to-depth view of a full-resolution NHWC
+    tensor in place; checked against the materialised view (ramnet_space_to_depth2) fed to the same kernels and against
+    torch.  (ramnet_hip.h: ramnet_in_mode, ramnet_conv_desc.out_s2d.)"""
+    L, st = _hip.lib(), None
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, H, W, Cc, Cout = 2, 12, 20, 32, 64           # logical 3x3 layer: [B, 6, 10, 128] -> [B, 6, 10, 64]
+    Hl, Wl, Cin = H // 2, W // 2, 4 * Cc
+    x = torch.randn(B, H, W, Cc, device=dev)
+    deep = torch.empty(B, Hl, Wl, Cin, device=dev)
+    assert L.ramnet_space_to_depth2(ptr(x), ptr(deep), B, H, W, Cc, 0, st) == 0
+    ref_deep = x.view(B, Hl, 2, Wl, 2, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, Hl, Wl, Cin)
+    assert torch.equal(deep, ref_deep)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.1
+    wp = torch.empty(L.ramnet_packed_weight_elems_wino(Cout, Cin, 0, 1), device=dev)
+    assert L.ramnet_pack_weight_wino(ptr(w), ptr(wp), Cout, Cin, 0, 1, st) == 0
+
+    def conv_desc(src, ld, c0, mode, out, cout, wpk):
+        d = _hip.ConvDesc()
+        d.x0, d.ld0, d.C0, d.in_mode = ptr(src), ld, c0, mode
+        d.B, d.Hin, d.Win, d.stride, d.ntaps = B, Hl, Wl, 1, 9
+        for i in range(9):
+            d.dy[i], d.dx[i], d.wtap[i] = i // 3 - 1, i % 3 - 1, i
+        d.w, d.Cout = ptr(wpk), cout
+        d.Ho, d.Wo, d.HoF, d.WoF = Hl, Wl, out.shape[1], out.shape[2]
+        d.osy, d.osx = 1, 1
+        d.epi, d.out, d.ldo, d.precision, d.algo = _hip.EPI_LINEAR, ptr(out), out.shape[3], _hip.PREC_F32, _hip.ALGO_WINOGRAD
+        return d
+
+    # forward: in-place view == materialised view, bit for bit (same kernel, same operands)
+    y_view, y_deep = torch.empty(B, Hl, Wl, Cout, device=dev), torch.empty(B, Hl, Wl, Cout, device=dev)
+    d = conv_desc(x, Cc, Cc, _hip.IN_S2D, y_view, Cout, wp)
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    d = conv_desc(deep, Cin, Cin, _hip.IN_PLAIN, y_deep, Cout, wp)
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    assert torch.equal(y_view, y_deep)
+    ref = torch.nn.functional.conv2d(ref_deep.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), None, 1, 1)
+    assert float((y_view.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max()) < 2e-4
+    # the direct kernel does not know the view
+    d = conv_desc(x, Cc, Cc, _hip.IN_S2D, y_view, Cout, wp)
+    d.algo = _hip.ALGO_DIRECT
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+
+    # backward-data: 4*Cc logical output channels stored at their full-resolution pixels
+    dy = torch.randn(B, Hl, Wl, Cout, device=dev)
+    wt = torch.empty(L.ramnet_packed_weight_elems_wino(Cout, Cin, 1, 1), device=dev)
+    assert L.ramnet_pack_weight_wino(ptr(w), ptr(wt), Cout, Cin, 1, 1, st) == 0
+    dx_view, dx_deep = torch.empty(B, H, W, Cc, device=dev), torch.empty(B, Hl, Wl, Cin, device=dev)
+    d = conv_desc(dy, Cout, Cout, _hip.IN_PLAIN, dx_view, Cin, wt)
+    d.out_s2d = Cc
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    d = conv_desc(dy, Cout, Cout, _hip.IN_PLAIN, dx_deep, Cin, wt)
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    back = torch.empty(B, H, W, Cc, device=dev)
+    assert L.ramnet_space_to_depth2(ptr(dx_deep), ptr(back), B, H, W, Cc, 1, st) == 0
+    assert torch.equal(dx_view, back)
+    d = conv_desc(dy, Cout, Cout, _hip.IN_PLAIN, dx_view, Cin, wt)
+    d.out_s2d, d.epi = Cc, _hip.EPI_RELU                     # only the plain store knows the view
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+
+    # backward-weights: same workspace from the view as from the materialised tensor (atomic order aside)
+    def wgrad(src, ld, c0, mode):
+        ws = torch.zeros(16 * Cin * Cout, device=dev)
+        g = _hip.WgradDesc()
+        g.x0, g.ld0, g.C0, g.in_mode = ptr(src), ld, c0, mode
+        g.B, g.Hin, g.Win, g.ntaps, g.stride = B, Hl, Wl, 9, 1
+        for i in range(9):
+            g.dy[i], g.dx[i] = i // 3 - 1, i % 3 - 1
+        g.dout, g.ldg, g.Cout, g.Ho, g.Wo = ptr(dy), Cout, Cout, Hl, Wl
+        g.dw, g.algo = ptr(ws), _hip.ALGO_WINOGRAD
+        assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
+        return ws
+    a, b = wgrad(x, Cc, Cc, _hip.IN_S2D), wgrad(deep, Cin, Cin, _hip.IN_PLAIN)
+    torch.cuda.synchronize()
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-5

@@ -47,18 +47,21 @@ def run_pair(module, oracle_fn, inputs, seed=0):
 SHAPES = [(2, 16, 32), (1, 8, 16), (3, 9, 37), (2, 24, 20)]
 
 
-@pytest.fixture(params=["s2d", "direct"])
+@pytest.fixture(params=["s2d", "s2d_materialised", "direct"])
 def stride2_algo(request):
-    """5x5 stride-2 layers: 3x3 Winograd over the space-to-depth input (default) and the direct stride-2 kernels."""
+    """5x5 stride-2 layers: 3x3 Winograd over the space-to-depth view read in place (default; channel counts that are not a
+    power of two >= 32 materialise it), over the materialised view, and the direct stride-2 kernels."""
     from rpg_ramnet_amd import ops
-    old = ops.get_space_to_depth()
-    ops.set_space_to_depth(request.param == "s2d")
+    old, oldf = ops.get_space_to_depth(), ops._S2D_FUSED
+    ops.set_space_to_depth(request.param != "direct")
+    ops.set_space_to_depth_fused(request.param == "s2d")
     yield request.param
     ops.set_space_to_depth(old)
+    ops.set_space_to_depth_fused(oldf)
 
 
 @pytest.mark.parametrize("B,H,W", SHAPES)
-@pytest.mark.parametrize("cin,cout,stride", [(32, 64, 1), (32, 64, 2), (64, 32, 1), (8, 32, 1), (128, 128, 2), (4, 32, 1), (8, 16, 2)])
+@pytest.mark.parametrize("cin,cout,stride", [(32, 64, 1), (32, 64, 2), (64, 32, 1), (8, 32, 1), (128, 128, 2), (4, 32, 1), (8, 16, 2), (64, 96, 2)])
 def test_conv_layer(B, H, W, cin, cout, stride, stride2_algo):
     from rpg_ramnet_amd.model.submodules import ConvLayer
     torch.manual_seed(1)
