@@ -127,6 +127,8 @@ class KernelTimer:
             if ops.uses_winograd(taps, w, kw.get("stride", 1), kw.get("epi", 0), kw.get("in_mode", 0),
                                  kw.get("C0") or x0.shape[3], kw.get("C1", 0)):
                 name = "conv_wino_kernel"
+            if ops.uses_head(taps, w, kw.get("stride", 1), kw.get("epi", 0), kw.get("in_mode", 0)):
+                name = "conv_head_fwd_kernel"
             if timer.only is not None and name != timer.only:
                 return conv0(x0, taps, w, out, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -155,6 +157,9 @@ class KernelTimer:
             if getattr(dw, "wino", False):         # Winograd backward-weights (template flags: loader operand, ReLU mask on dy)
                 from rpg_ramnet_amd import _hip as Hh
                 name = "conv_wgrad_wino_kernel<%d,%d>" % (kw.get("in_mode", 0) in (Hh.IN_RELUMASK, Hh.IN_CAT_MUL), kw.get("gmask") is not None)
+            if getattr(dw, "head_cin", 0) and ops.get_head_kernel() and taps.head and kw.get("stride", 1) == 1 and kw.get("in_mode", 0) == 0 \
+                    and kw.get("gview") is None:
+                name = "conv_head_wgrad_kernel"
             if timer.only is not None and name != timer.only:
                 return wgrad0(x0, taps, dout, dw, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

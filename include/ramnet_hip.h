@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 9
+#define RAMNET_ABI_VERSION 10
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -45,7 +45,9 @@ enum ramnet_in_mode {
  *         product (vs 4e-3 for plain bf16), 3 MFMAs at 16x the fp32 rate.  Inputs/outputs stay fp32 in HBM.    */
 enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
 /* RAMNET_ALGO_WINOGRAD: F(2x2,3x3), fp32; only the dense 3x3 stride-1 tap list, w from ramnet_pack_weight_wino() */
-enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1 };
+/* RAMNET_ALGO_HEAD: the 5x5 stride-1 head layers with 1, 3 or 5 real input channels and <= 32 outputs (statenet.py:160-175):
+ * dense (tap, channel) reduction, weights from ramnet_pack_weight_head() held in registers; fp32 */
+enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2 };
 
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {
@@ -82,13 +84,14 @@ typedef struct ramnet_conv_desc {
     float *out, *o1, *o2;
     int ldo, ldo1, ldo2;
     int precision;                  /* RAMNET_PREC_F32 (exact fp32 MFMA) or RAMNET_PREC_BF16X3 (w packed with split=1) */
-    int algo;                       /* RAMNET_ALGO_DIRECT or RAMNET_ALGO_WINOGRAD (F32 only)                     */
+    int algo;                       /* RAMNET_ALGO_DIRECT, RAMNET_ALGO_WINOGRAD or RAMNET_ALGO_HEAD (the latter two F32 only)   */
     int frame;                      /* > 0 (folded upsample-conv, LINEAR / RELU epilogues): border corrections are added to the
                                      * pre-activation of the outermost `frame` (= 2) rows / columns of the FULL output:
                                      * rows from e1 [2 sides][B][WoF][lde1 = frame*Cout], columns from e0 [2][B][HoF][lde0]  */
     int out_s2d;                    /* C > 0 (WINOGRAD, LINEAR epilogue, no bias, beta = 0): the Cout = 4*C output channels are the
                                      * space-to-depth view of out [B][HoF = 2*Ho][WoF = 2*Wo][C]: channel (a*2+c)*C + ch of pixel (i, j)
                                      * is stored at out(2i+a, 2j+c, ch) — backward-data of the encoders.  C a power of two >= 8  */
+    int head_cin;                   /* RAMNET_ALGO_HEAD: real input channels (1, 3 or 5) among the C0 padded ones of x0       */
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
@@ -109,6 +112,8 @@ typedef struct ramnet_wgrad_desc {
                                      * accumulates the transformed-domain gradient dU, folded by ramnet_unpack_wgrad_wino() */
     int gsy, gsx, goy, gox;         /* dout / gmask are read at pixel (oy*gsy + goy, ox*gsx + gox) of a [B, HoG, WoG] tensor      */
     int HoG, WoG;                   /* (all 0 = dense [B, Ho, Wo]; DIRECT only): one output parity of the folded upsample-conv  */
+    int head_cin;                   /* RAMNET_ALGO_HEAD (dense 5x5 stride-1 taps, Cout <= 32): real input channels (1, 3 or 5); dw keeps
+                                     * the DIRECT layout [25][C0][Cout]                                                          */
 } ramnet_wgrad_desc;
 
 const char *ramnet_last_error(void);
@@ -128,6 +133,11 @@ int ramnet_pack_weight_split(const float *w_oihw, float *wp, int Cout, int Cin, 
  * (flipped taps, reduce over O); gates=4 (forward only) groups the ConvLSTM gates of 16 hidden channels per block.  */
 size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed, int gates);
 int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, int gates, void *stream);
+/* Head layers (RAMNET_ALGO_HEAD): OIHW [Cout<=32][Cin][5][5] -> [25*Cin rounded up to even][32], row = tap*Cin + channel.
+ * ramnet_head_supported: does the head kernel serve this channel pair (Cin in {1,3,5}, Cout <= 32)?              */
+size_t ramnet_packed_weight_elems_head(int Cin);
+int ramnet_head_supported(int Cin, int Cout);
+int ramnet_pack_weight_head(const float *w_oihw, float *wp, int Cout, int Cin, void *stream);
 /* OIHW -> kernel layout [tap][chunk][n][16].  transposed=1 packs the backward-data operator
  * (reduce over O, produce I).  gates=4 interleaves ConvLSTM gate blocks so that one wave owns
  * i,f,o,g of a channel (forward only).  CinValid rows beyond Cin are zero (padded inputs).        */

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D = range(7)
 PREC_F32, PREC_BF16X3 = 0, 1
-ALGO_DIRECT, ALGO_WINOGRAD = 0, 1
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD = 0, 1, 2
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
 
 _fp = C.c_void_p
@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("algo", C.c_int),
         ("frame", C.c_int),
         ("out_s2d", C.c_int),
+        ("head_cin", C.c_int),
     ]
 
 
@@ -52,6 +53,7 @@ class WgradDesc(C.Structure):
         ("dw", _fp), ("dbias", _fp),
         ("algo", C.c_int),
         ("gsy", C.c_int), ("gsx", C.c_int), ("goy", C.c_int), ("gox", C.c_int), ("HoG", C.c_int), ("WoG", C.c_int),
+        ("head_cin", C.c_int),
     ]
 
 
@@ -65,6 +67,9 @@ _SIGS = {
     "ramnet_pack_weight_split": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 4),
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
+    "ramnet_head_supported": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_pack_weight_head": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "ramnet_pad2_sum": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_up2x_border_im2col": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_space_to_depth2": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -120,7 +125,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 9:
+        if l.ramnet_abi_version() != 10:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

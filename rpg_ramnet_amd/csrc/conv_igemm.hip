@@ -354,6 +354,10 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
         const int rc = check_desc(*dp);
         return rc ? rc : launch_wino(*dp, (hipStream_t)stream);
     }
+    if (dp->algo == RAMNET_ALGO_HEAD) {
+        const int rc = check_desc(*dp);
+        return rc ? rc : launch_head(*dp, (hipStream_t)stream);
+    }
     RAMNET_CHECK_ARG(dp->algo == RAMNET_ALGO_DIRECT && dp->in_mode != RAMNET_IN_S2D && dp->out_s2d == 0);   // fused space-to-depth: Winograd kernels only
     return launch_classes(dp, 1, (hipStream_t)stream);
 }

@@ -98,6 +98,7 @@ class Taps:
         self.dx = (C.c_int8 * 25)(*[t[1] for t in triples])
         self.wt = (C.c_uint8 * 25)(*[t[2] for t in triples])
         self.wino = False
+        self.head = False                # dense padded 5x5 forward window (head kernel eligible)
         self.flop_taps = self.n          # taps of the convolution this launch stands for (algorithmic FLOP accounting)
 
     @classmethod
@@ -118,6 +119,7 @@ class Taps:
                 raise KeyError(kind)
             cls._cache[key] = cls(tr)
             cls._cache[key].wino = kind in ("conv", "dgrad1", "conv_s2d", "dgrad1_s2d") and k == 3 and pad == 1   # dense padded 3x3
+            cls._cache[key].head = kind == "conv" and k == 5 and pad == 2
             if kind.endswith("_s2d"):     # 3x3 over 4*Cin space-to-depth channels standing for a 5x5 stride-2 layer over Cin
                 cls._cache[key].flop_taps = 25.0 / 4.0
             if kind == "fold":          # one output parity of a 5x5 convolution after the x2 upsample
@@ -150,6 +152,28 @@ def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
                 and C0 + C1 >= _WINO_MIN_CIN and (C1 == 0 or C0 % 8 == 0))
 
 
+# The two 5x5 head layers (1 / 5 real input channels -> 32 maps at full resolution) on their own kernel:
+# dense (tap, channel) reduction with the weights in registers.  RAMNET_HEAD_KERNEL=0 / set_head_kernel(False): generic kernel.
+_HEAD = _os.environ.get("RAMNET_HEAD_KERNEL", "1") == "1"
+
+
+def set_head_kernel(on):
+    global _HEAD
+    _HEAD = bool(on)
+
+
+def get_head_kernel():
+    return _HEAD
+
+
+def uses_head(taps, w, stride, epi, in_mode):
+    """Does this forward launch run the head kernel?  (dense 5x5 stride-1 window, fp32, plain input, 1/3/5 real input
+    channels, <= 32 outputs, bias + optional ReLU only.)"""
+    return bool(isinstance(w, PackRef) and _HEAD and _PRECISION == H.PREC_F32 and taps.head and stride == 1 and not w.transposed
+                and w.cp.gates == 1 and len(w.cp.weights) == 1 and in_mode == H.IN_PLAIN and epi in (H.EPI_LINEAR, H.EPI_RELU)
+                and H.lib().ramnet_head_supported(w.cp.Cin, w.cp.Cout))
+
+
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
                 o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0):
@@ -159,7 +183,10 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
     d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
     d.algo = H.ALGO_DIRECT
-    if isinstance(w, PackRef):
+    if isinstance(w, PackRef) and beta == 0.0 and frame == 0 and os == (1, 1, 0, 0) and uses_head(taps, w, stride, epi, in_mode):
+        d.algo, d.head_cin = H.ALGO_HEAD, w.cp.Cin
+        w = w.cp.pack(0, "head")
+    elif isinstance(w, PackRef):
         wino = uses_winograd(taps, w, stride, epi, in_mode, d.C0, C1)
         d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
         w = w.cp.pack(w.transposed, wino)
@@ -196,6 +223,9 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     if gview is not None:      # dout / gmask addressed as (oy*gsy + goy, ox*gsx + gox) of [B, HoG, WoG]
         d.gsy, d.gsx, d.goy, d.gox, d.HoG, d.WoG = gview
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
+    hc = getattr(dw, "head_cin", 0)
+    if hc and _HEAD and _PRECISION == H.PREC_F32 and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
+        d.algo, d.head_cin = H.ALGO_HEAD, hc
     if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
@@ -392,6 +422,10 @@ class ConvParam:
     def _pack(self, transposed, wino):
         L, g = H.lib(), (self.gates if not transposed else 1)
         w = self._cat_w()
+        if wino == "head":
+            out = torch.empty(L.ramnet_packed_weight_elems_head(self.Cin), device=w.device, dtype=torch.float32)
+            H.check(L.ramnet_pack_weight_head(_p(w), _p(out), self.Cout, self.Cin, _st()), "ramnet_pack_weight_head")
+            return out
         if wino:
             n = L.ramnet_packed_weight_elems_wino(self.Cout, self.Cin, transposed, g)
             out = torch.empty(n, device=w.device, dtype=torch.float32)
@@ -408,10 +442,11 @@ class ConvParam:
     def pack(self, transposed, wino=False):
         """Packed weights for the forward (transposed=0) / backward-data (1) launch, re-packed when a parameter changes."""
         v = (self._versions(self.weights), _PRECISION)
-        key = (transposed, bool(wino))
+        wino = wino if wino == "head" else bool(wino)
+        key = (transposed, wino)
         hit = self._packs.get(key)
         if hit is None or hit[0] != v:
-            hit = self._packs[key] = (v, self._pack(transposed, bool(wino)))
+            hit = self._packs[key] = (v, self._pack(transposed, wino))
         return hit[1]
 
     def fwd(self):
@@ -469,6 +504,9 @@ class ConvParam:
         if not self._dirty:     # one algorithm per backward pass: every launch of the pass accumulates into the same layout
             self._ws.wino = bool(wino_ok and _WINOGRAD and _PRECISION == H.PREC_F32 and self.k == 3
                                  and self.CinWs >= _WINO_MIN_CIN)
+            # head layers: the launch may run the head kernel (same [tap][CinWs][Cout] layout as the direct kernel)
+            self._ws.head_cin = self.Cin if (self.k == 5 and self.gates == 1 and len(self.weights) == 1
+                                             and H.lib().ramnet_head_supported(self.Cin, self.Cout)) else 0
         _Engine.mark(self)
         self._ws_used = True
         return self._ws, self._bws

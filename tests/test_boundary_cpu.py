@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.ramnet_abi_version.restype = ctypes.c_int
-    assert lib.ramnet_abi_version() == 9
+    assert lib.ramnet_abi_version() == 10
 
 
 def test_desc_struct_layout_matches_header_field_order():

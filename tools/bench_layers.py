@@ -66,6 +66,7 @@ def main():
         gfl = 2.0 * B * Ho * Wo * k * k * cin * cout / 1e9
         ws = torch.zeros((16 if k == 3 else k * k) * cin_p * cout, device=dev)
         ws.wino = k == 3 and stride == 1 and kind != "up" and ops.get_winograd()      # Winograd backward-weights workspace
+        ws.head_cin = cin if (kind == "conv" and k == 5 and stride == 1 and H.lib().ramnet_head_supported(cin, cout)) else 0
         bws = torch.zeros(cout, device=dev)
         if kind == "conv":
             x = torch.randn(B, Hin, Win, cin_p, device=dev)
