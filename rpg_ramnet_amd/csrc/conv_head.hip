@@ -17,26 +17,29 @@
 
 namespace ramnet {
 
-constexpr int HT_H = 16, HT_W = 32;                 // output pixels per workgroup (4 waves x 4 rows x 32)
-constexpr int HP_H = HT_H + 4, HP_W = HT_W + 4;     // input patch
+constexpr int HT_W = 32;                            // output pixels per workgroup: TH rows (TH/4 per wave) x 32
+constexpr int HP_W = HT_W + 4;                      // input patch width
 constexpr int HP_LD = HP_W + 1;                     // padded patch row (floats)
-constexpr int HP_PLANE = HP_H * HP_LD;              // one channel plane: 740 floats
+constexpr int HF_H = 16, HG_H = 8;                  // tile height of the forward / backward-weights kernel
 
-template <int CR>
+template <int CR, int TH>
 struct HeadGeom {
     static constexpr int KT = 25 * CR;              // dense reduction length
     static constexpr int NS = (KT + 1) / 2;         // MFMA steps (K = 2 each)
+    static constexpr int PLANE = (TH + 4) * HP_LD;  // one channel plane of the input patch
     // LDS offset of reduction index k inside the planar patch, relative to the output pixel's own position
     static constexpr int koff(int k) {
-        return k >= KT ? 0 : (k % CR) * HP_PLANE + ((k / CR) / 5) * HP_LD + (k / CR) % 5;
+        return k >= KT ? 0 : (k % CR) * PLANE + ((k / CR) / 5) * HP_LD + (k / CR) % 5;
     }
 };
 
-// stage the (HP_H x HP_W) input patch of the tile at (b, oy0, ox0) as CR channel planes; zero outside the image
-template <int CR>
+// stage the (TH+4 x HP_W) input patch of the tile at (b, oy0, ox0) as CR channel planes; zero outside the image
+template <int CR, int TH>
 __device__ __forceinline__ void head_stage_patch(float *__restrict__ P, const float *__restrict__ x, int ld, int b, int oy0, int ox0, int H,
                                                  int W, int tid) {
-    for (int i = tid; i < HP_H * HP_W; i += 256) {
+    constexpr int HP_PLANE = HeadGeom<CR, TH>::PLANE;
+#pragma unroll
+    for (int i = tid; i < (TH + 4) * HP_W; i += 256) {
         const int py = i / HP_W, px = i - py * HP_W;
         const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -64,8 +67,9 @@ struct HeadFwdParams {
 
 template <int CR>
 __global__ void __launch_bounds__(256, 2) conv_head_fwd_kernel(const HeadFwdParams p) {
-    using G = HeadGeom<CR>;
-    __shared__ float P[CR * HP_PLANE];
+    using G = HeadGeom<CR, HF_H>;
+    constexpr int HT_H = HF_H;
+    __shared__ float P[CR * G::PLANE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(256, 2) conv_head_fwd_kernel(const HeadFwdPara
 #pragma unroll
     for (int s = 0; s < G::NS; ++s) wreg[s] = p.wp[(2 * s + h) * 32 + n];
 
-    head_stage_patch<CR>(P, p.x, p.ld, b, oy0, ox0, p.H, p.W, tid);
+    head_stage_patch<CR, HF_H>(P, p.x, p.ld, b, oy0, ox0, p.H, p.W, tid);
     __syncthreads();
 
     f32x16 acc[4];
@@ -124,15 +128,16 @@ struct HeadWgradParams {
     int ld, ldg, ldgm, B, H, W, Cin, Cout, tiles_x, tiles_y, ntiles;
 };
 
-constexpr int HG_LD = 32;                           // gradient tile [512 pixels][32 channels]
+constexpr int HG_LD = 32;                           // gradient tile [HG_H * 32 pixels][32 channels]
 
 template <int CR>
 __global__ void __launch_bounds__(256, 2) conv_head_wgrad_kernel(const HeadWgradParams p) {
-    using G = HeadGeom<CR>;
+    using G = HeadGeom<CR, HG_H>;
+    constexpr int HT_H = HG_H, HP_PLANE = G::PLANE, WR = HG_H / 4;     // WR rows of 32 pixels per wave
     constexpr int MT = (G::KT + 31) / 32;           // 32-row blocks of the (tap, channel) index
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *P = smem;                                // [CR][HP_H][HP_LD]
-    float *Gt = smem + ((CR * HP_PLANE + 3) & ~3);  // [HT_H * HT_W][32]
+    float *P = smem;                                // [CR][HG_H + 4][HP_LD]
+    float *Gt = smem + ((CR * HP_PLANE + 3) & ~3);  // [HG_H * 32][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -142,15 +147,15 @@ __global__ void __launch_bounds__(256, 2) conv_head_wgrad_kernel(const HeadWgrad
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // A row m = (tap, channel) mt*32 + l31 at pixel 2j + h of the wave's 4 x 32 strip; B row = the same pixel, column l31
+    // A row m = (tap, channel) mt*32 + l31 at pixel 2j + h of the wave's WR x 32 strip; B row = the same pixel, column l31
     int aoff[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = t * 32 + l31;
         const int tap = m / CR, c = m - tap * CR;
-        aoff[t] = (m < G::KT ? c * HP_PLANE + (tap / 5) * HP_LD + tap % 5 : 0) + wave * 4 * HP_LD + h;
+        aoff[t] = (m < G::KT ? c * HP_PLANE + (tap / 5) * HP_LD + tap % 5 : 0) + wave * WR * HP_LD + h;
     }
-    const int boff = (wave * 128 + h) * HG_LD + l31;
+    const int boff = (wave * WR * 32 + h) * HG_LD + l31;
     float4 bsum = f4zero();                         // bias gradient partial of channel quad (tid & 7)
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -160,9 +165,9 @@ __global__ void __launch_bounds__(256, 2) conv_head_wgrad_kernel(const HeadWgrad
         const int ty = bid % p.tiles_y, b = bid / p.tiles_y;
         const int oy0 = ty * HT_H, ox0 = tx * HT_W;
         __syncthreads();                            // the previous tile's readers are done
-        head_stage_patch<CR>(P, p.x, p.ld, b, oy0, ox0, p.H, p.W, tid);
-#pragma unroll 4
-        for (int i = 0; i < HT_H * HT_W * 8 / 256; ++i) {      // gradient tile: 512 pixels x 8 channel quads
+        head_stage_patch<CR, HG_H>(P, p.x, p.ld, b, oy0, ox0, p.H, p.W, tid);
+#pragma unroll
+        for (int i = 0; i < HT_H * HT_W * 8 / 256; ++i) {      // gradient tile: pixels x 8 channel quads
             const int sl = tid + i * 256, pix = sl >> 3, qd = sl & 7;
             const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
             float4 r = f4zero();
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) conv_head_wgrad_kernel(const HeadWgrad
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {              // 128 pixels of the wave, two per MFMA
+        for (int j = 0; j < WR * 16; ++j) {         // the wave's pixels, two per MFMA
             const int po = ((2 * j) >> 5) * HP_LD + ((2 * j) & 31);
             const float bv = Gt[boff + 2 * j * HG_LD];
             float a[MT];
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) conv_head_wgrad_kernel(const HeadWgrad
 
     // fold the four waves' partials in LDS, then one atomic per element into ws[tap][Cin][Cout]
     __syncthreads();
-    float *red = smem;                              // [MT*32][32]
+    float *red = smem;                              // [MT*32][32]  (red + bred = 5120 floats fit below the gradient tile's end)
     for (int i = tid; i < MT * 32 * 32; i += 256) red[i] = 0.f;
     float *bred = smem + MT * 1024;                 // [32][32], behind red
     __syncthreads();
@@ -223,12 +228,12 @@ int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st) {
     HeadWgradParams q;
     q.x = d.x0, q.g = d.dout, q.gm = d.gmask, q.dw = d.dw, q.dbias = d.dbias;
     q.ld = d.ld0, q.ldg = d.ldg, q.ldgm = d.ldgm, q.B = d.B, q.H = d.Hin, q.W = d.Win, q.Cin = d.C0, q.Cout = d.Cout;
-    q.tiles_x = cdiv(d.Wo, HT_W), q.tiles_y = cdiv(d.Ho, HT_H), q.ntiles = q.tiles_x * q.tiles_y * d.B;
+    q.tiles_x = cdiv(d.Wo, HT_W), q.tiles_y = cdiv(d.Ho, HG_H), q.ntiles = q.tiles_x * q.tiles_y * d.B;
     static const char *se = getenv("RAMNET_HEAD_WGRAD_BLOCKS");
     int blocks = se ? atoi(se) : 512;
     if (blocks > q.ntiles) blocks = q.ntiles;
     auto go = [&](auto kern, int cr) -> int {
-        const size_t lds = (size_t)(((cr * HP_PLANE + 3) & ~3) + HT_H * HT_W * HG_LD) * sizeof(float);
+        const size_t lds = (size_t)(((cr * (HG_H + 4) * HP_LD + 3) & ~3) + HG_H * HT_W * HG_LD) * sizeof(float);
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, q);
         return 0;
@@ -261,7 +266,7 @@ int launch_head(const ramnet_conv_desc &d, hipStream_t st) {
     HeadFwdParams q;
     q.x = d.x0, q.wp = d.w, q.bias = d.bias, q.out = d.out;
     q.ld = d.ld0, q.ldo = d.ldo, q.B = d.B, q.H = d.Hin, q.W = d.Win, q.Cout = d.Cout, q.relu = d.epi == RAMNET_EPI_RELU;
-    q.tiles_x = cdiv(d.Wo, HT_W), q.tiles_y = cdiv(d.Ho, HT_H);
+    q.tiles_x = cdiv(d.Wo, HT_W), q.tiles_y = cdiv(d.Ho, HF_H);
     const dim3 grid(q.tiles_x * q.tiles_y * d.B);
     if (d.head_cin == 1) hipLaunchKernelGGL(conv_head_fwd_kernel<1>, grid, dim3(256), 0, st, q);
     else if (d.head_cin == 3) hipLaunchKernelGGL(conv_head_fwd_kernel<3>, grid, dim3(256), 0, st, q);

@@ -195,3 +195,55 @@ def test_space_to_depth_view_through_raw_descriptors():
     a, b = wgrad(x, Cc, Cc, _hip.IN_S2D), wgrad(deep, Cin, Cin, _hip.IN_PLAIN)
     torch.cuda.synchronize()
     assert float((a - b).abs().max() / b.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cpad", [(5, 8), (1, 4), (3, 4)])
+def test_head_layer_through_raw_descriptors(cin, cpad):
+    """RAMNET_ALGO_HEAD: the 5x5 head layers (statenet.py:160-175) forward and backward-weights with raw descriptors,
+    against torch in float64 and against the generic kernel's workspace layout."""
+    L, st = _hip.lib(), None
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    B, H, W, Cout = 2, 21, 45, 32
+    x = torch.zeros(B, H, W, cpad, device=dev)
+    x[..., :cin] = torch.randn(B, H, W, cin, device=dev)
+    w = torch.randn(Cout, cin, 5, 5, device=dev) * 0.2
+    b = torch.randn(Cout, device=dev) * 0.1
+    assert L.ramnet_head_supported(cin, Cout) == 1 and L.ramnet_head_supported(2, Cout) == 0 and L.ramnet_head_supported(cin, 64) == 0
+    wp = torch.empty(L.ramnet_packed_weight_elems_head(cin), device=dev)
+    assert L.ramnet_pack_weight_head(ptr(w), ptr(wp), Cout, cin, st) == 0
+    y = torch.empty(B, H, W, Cout, device=dev)
+    d = _hip.ConvDesc()
+    d.x0, d.ld0, d.C0, d.in_mode = ptr(x), cpad, cpad, _hip.IN_PLAIN
+    d.B, d.Hin, d.Win, d.stride, d.ntaps = B, H, W, 1, 25
+    for i in range(25):
+        d.dy[i], d.dx[i], d.wtap[i] = i // 5 - 2, i % 5 - 2, i
+    d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
+    d.Ho, d.Wo, d.HoF, d.WoF = H, W, H, W
+    d.osy, d.osx = 1, 1
+    d.epi, d.out, d.ldo, d.precision, d.algo, d.head_cin = _hip.EPI_RELU, ptr(y), Cout, _hip.PREC_F32, _hip.ALGO_HEAD, cin
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    xr = x[..., :cin].permute(0, 3, 1, 2).cpu().double()
+    wr, br = w.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.conv2d(xr, wr, br, 1, 2))
+    assert float((y.permute(0, 3, 1, 2).cpu() - ref.detach()).abs().max() / ref.abs().max()) < 1e-5
+    d.stride = 2                                    # only the dense stride-1 window
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+    d.stride, d.head_cin = 1, 2                     # unsupported channel count
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+
+    dy = torch.randn(B, H, W, Cout, device=dev)
+    (ref * dy.permute(0, 3, 1, 2).cpu().double()).sum().backward()
+    ws, dbias = torch.zeros(25 * cpad * Cout, device=dev), torch.zeros(Cout, device=dev)
+    g = _hip.WgradDesc()
+    g.x0, g.ld0, g.C0, g.in_mode = ptr(x), cpad, cpad, _hip.IN_PLAIN
+    g.B, g.Hin, g.Win, g.ntaps, g.stride = B, H, W, 25, 1
+    for i in range(25):
+        g.dy[i], g.dx[i] = i // 5 - 2, i % 5 - 2
+    g.dout, g.ldg, g.gmask, g.ldgm, g.Cout, g.Ho, g.Wo = ptr(dy), Cout, ptr(y), Cout, Cout, H, W
+    g.dw, g.dbias, g.algo, g.head_cin = ptr(ws), ptr(dbias), _hip.ALGO_HEAD, cin
+    assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
+    grad = torch.zeros(Cout, cin, 5, 5, device=dev)
+    assert L.ramnet_unpack_wgrad(ptr(ws), ptr(grad), Cout, cin, cpad, Cout, 0, 5, 5, st) == 0      # same layout as the generic kernel
+    assert float((grad.cpu() - wr.grad).abs().max() / wr.grad.abs().max()) < 1e-4
+    assert float((dbias.cpu() - br.grad).abs().max() / br.grad.abs().max()) < 1e-4
