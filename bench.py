@@ -129,6 +129,9 @@ class KernelTimer:
                 name = "conv_wino_kernel"
             if ops.uses_head(taps, w, kw.get("stride", 1), kw.get("epi", 0), kw.get("in_mode", 0)):
                 name = "conv_head_fwd_kernel"
+            nclass = 1
+            if kw.get("wino24"):        # one launch = the four output parities of a folded decoder layer
+                name, nclass = "conv_wino24_kernel", 4
             if timer.only is not None and name != timer.only:
                 return conv0(x0, taps, w, out, Cout, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -137,7 +140,7 @@ class KernelTimer:
             e.record()
             cin = ((kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)) * (4 if kw.get("in_mode", 0) == 6 else 1)   # IN_S2D: 4 parities
             nout = Cout * (4 if kw.get("epi") == 5 else 1)
-            timer.rec.append((name, s, e, 2.0 * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout))
+            timer.rec.append((name, s, e, 2.0 * nclass * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout))
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:

@@ -47,7 +47,14 @@ enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
 /* RAMNET_ALGO_WINOGRAD: F(2x2,3x3), fp32; only the dense 3x3 stride-1 tap list, w from ramnet_pack_weight_wino() */
 /* RAMNET_ALGO_HEAD: the 5x5 stride-1 head layers with 1, 3 or 5 real input channels and <= 32 outputs (statenet.py:160-175):
  * dense (tap, channel) reduction, weights from ramnet_pack_weight_head() held in registers; fp32 */
-enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2 };
+/* RAMNET_ALGO_WINOGRAD24: all four output parities of the folded upsample-conv (decoders, statenet.py:305-308) as Winograd
+ * F(2x2,4x4) convolutions of the replicate-padded low-res input: x0 = [B][Hin = H+4][Win = W+4][C0] (ramnet_pad2_sum),
+ * Ho, Wo = H, W (one parity grid), out = [B][HoF = 2H][WoF = 2W][Cout]; C0 % 16 == 0, Cout % 64 == 0; bias, LINEAR / RELU and
+ * `frame` as for the direct launch.  w = U[class = py*2+px][C0/16][Cout/64][25 positions][4][64][4] floats with
+ * U[cls][pos = a*5+b][k][n] = sum_{t,s} G[a][t] W4[n][k][py][px][t][s] G[b][s] (W4 = the 4x4 parity filters, G below) stored at
+ * ((((cls*(C0/16) + k/16)*(Cout/64) + n/64)*25 + pos)*4 + (n%64)/16)*256 + (((k%16)/4)*16 + n%16)*4 + k%4.
+ * G = [1/2 0 0 0; -1/2 -1/2 -1/2 -1/2; -1/6 1/6 -1/6 1/6; 1/6 1/3 2/3 4/3; 0 0 0 1] (Toom-Cook points 0, 1, -1, 2, inf).  */
+enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3 };
 
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D = range(7)
 PREC_F32, PREC_BF16X3 = 0, 1
-ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD = 0, 1, 2
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24 = 0, 1, 2, 3
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
 
 _fp = C.c_void_p

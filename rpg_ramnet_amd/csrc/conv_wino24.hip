@@ -1,0 +1,187 @@
+// Winograd F(2x2, 4x4) for the folded upsample-conv of the decoders (statenet.py:305-308, submodules.py:69-97) on gfx950.
+//
+// conv5x5(bilinear_x2(x + skip)) is, per output parity (py, px), a 4x4 stride-1 convolution of the replicate-padded low-res
+// sum.  Each of those four convolutions is evaluated here as
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A,     5x5 input tile -> 2x2 outputs, 25 instead of 64 multiplies
+// (Toom-Cook points 0, 1, -1, 2, inf), i.e. 6.25 multiplies per output and input channel instead of 16 (25 for the plain 5x5).
+//
+// Workgroup = 8 waves: 32 tiles (8 x 4 tiles = 16 x 8 pixels of one parity grid) x 64 output channels.  Per chunk of 16
+// input channels every thread loads the 5x5 window of ONE (tile, channel) straight from global memory (the padded input needs
+// no bounds logic), transforms it in registers and writes the 25 values to V[25][32 tiles][16] in LDS (double-buffered, one
+// barrier per chunk).  Wave (tile half, channel quarter) accumulates all 25 positions of its 16 tiles x 16 channels on
+// v_mfma_f32_16x16x4_f32 (100 accumulator VGPRs): A = one 16-byte LDS read per position (swizzled, conflict-free), B = one
+// 16-byte global (L2) read per position from weights packed in exactly that lane order.  Loads and the transform of chunk
+// i+1 are issued between the MFMAs of chunk i.  The output transform is register-local; bias / ReLU and the border
+// corrections of the folded layer (ramnet_conv_desc.frame) are applied by the shared epilogue.
+#include "common.hpp"
+#include "conv_epilogue.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ramnet {
+
+constexpr int W24_K = 16;                         // input channels per chunk
+constexpr int W24_TY = 8, W24_TX = 4;             // tiles per workgroup (2x2 outputs each)
+constexpr int W24_V = 25 * 32 * W24_K;            // floats per V buffer (51.2 KB)
+constexpr int W24_U = 25 * 4 * 256;               // packed weights of one (class, chunk, 64-channel block): 25.6K floats
+
+struct Wino24Params {
+    const float *x;          // replicate-padded low-res input [B][Hp][Wp][Cin]
+    const float *wp;         // [4 classes][Cin/16][Cout/64][25][4][64 lanes][4]
+    int Hp, Wp, ldx, nchunks, nblk, tiles_x, tiles_y, Hc, Wc;
+};
+
+__global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_desc p, const Wino24Params q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *V = smem;                               // [2][25][32][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, ks = lane >> 4;
+    const int th = wave & 1, cq = wave >> 1;       // tile half, output-channel quarter
+
+    // blockIdx.x = ((tile block * nblk + channel block) * 4 + class): the four parities of a tile block read the same input
+    int bid = blockIdx.x;
+    const int cls = bid & 3;
+    bid >>= 2;
+    const int nb = bid % q.nblk;
+    bid /= q.nblk;
+    const int tbx = bid % q.tiles_x;
+    bid /= q.tiles_x;
+    const int tby = bid % q.tiles_y, b = bid / q.tiles_y;
+    const int py = cls >> 1, px = cls & 1;
+    const int n0 = nb * 64;
+
+    // ---- input transform item of this thread: (tile tid>>4, channel tid&15)
+    const int it = tid >> 4, ik = tid & 15;
+    // window rows / columns past the padded input only feed outputs past the grid: clamp them one by one
+    const int iy0 = 2 * (tby * W24_TY + (it >> 2)) + py, ix0 = 2 * (tbx * W24_TX + (it & 3)) + px;
+    int rowo[5], colo[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) rowo[r] = min(iy0 + r, q.Hp - 1) * q.Wp * q.ldx, colo[r] = min(ix0 + r, q.Wp - 1) * q.ldx;
+    const float *xsrc = q.x + (size_t)b * q.Hp * q.Wp * q.ldx + ik;
+    const int vdst = it * W24_K + (((ik >> 2) ^ ((it >> 2) & 3)) << 2) + (ik & 3);
+    float raw[25];
+    auto load_raw = [&](int chunk) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) raw[r * 5 + c] = xsrc[rowo[r] + colo[c] + chunk * W24_K];
+    };
+    // B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
+    auto tr_col = [&](int c) {
+        const float d0 = raw[c], d1 = raw[5 + c], d2 = raw[10 + c], d3 = raw[15 + c], d4 = raw[20 + c];
+        raw[c] = 2.f * (d0 - d2) - d1 + d3;
+        raw[5 + c] = d3 - d2 - 2.f * d1;
+        raw[10 + c] = 2.f * d1 - 3.f * d2 + d3;
+        raw[15 + c] = d3 - d1;
+        raw[20 + c] = 2.f * (d1 - d3) - d2 + d4;
+    };
+    auto tr_row = [&](float *vbuf, int i) {
+        const float d0 = raw[i * 5], d1 = raw[i * 5 + 1], d2 = raw[i * 5 + 2], d3 = raw[i * 5 + 3], d4 = raw[i * 5 + 4];
+        float *dst = vbuf + (i * 5) * (32 * W24_K) + vdst;
+        dst[0 * 32 * W24_K] = 2.f * (d0 - d2) - d1 + d3;
+        dst[1 * 32 * W24_K] = d3 - d2 - 2.f * d1;
+        dst[2 * 32 * W24_K] = 2.f * d1 - 3.f * d2 + d3;
+        dst[3 * 32 * W24_K] = d3 - d1;
+        dst[4 * 32 * W24_K] = 2.f * (d1 - d3) - d2 + d4;
+    };
+
+    // ---- MFMA operands
+    const int tile = th * 16 + l15;
+    const int aoff = tile * W24_K + ((ks ^ ((tile >> 2) & 3)) << 2);
+    const float *wsrc = q.wp + ((size_t)(cls * q.nchunks) * q.nblk + nb) * W24_U + cq * 256 + lane * 4;
+    const size_t wchunk = (size_t)q.nblk * W24_U;
+
+    f32x4 acc[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nch = q.nchunks;
+    load_raw(0);
+    float4 bq[5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = ld4(wsrc + i * 1024);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) tr_col(c);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tr_row(V, i);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const float *vb = V + (chunk & 1) * W24_V;
+        float *vn = V + ((chunk + 1) & 1) * W24_V;
+        const int cnext = min(chunk + 1, nch - 1);            // past the end: re-stage the last chunk into the unused buffer
+        const float *wcur = wsrc + chunk * wchunk, *wnext = wsrc + cnext * wchunk;
+        load_raw(cnext);
+        float4 a = ld4(vb + aoff);
+#pragma unroll
+        for (int pos = 0; pos < 25; ++pos) {
+            float4 an;
+            if (pos + 1 < 25) an = ld4(vb + (pos + 1) * (32 * W24_K) + aoff);
+            bq[(pos + 4) % 5] = pos + 4 < 25 ? ld4(wcur + (pos + 4) * 1024) : ld4(wnext + (pos + 4 - 25) * 1024);
+            const float4 bv = bq[pos % 5];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc[pos], 0, 0, 0);
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc[pos], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pos >= 10 && pos < 15) tr_col(pos - 10);
+            if (pos >= 15 && pos < 20) tr_row(vn, pos - 15);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv.z, acc[pos], 0, 0, 0);
+            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv.w, acc[pos], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pos + 1 < 25) a = an;
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue
+    const int n = n0 + cq * 16 + l15;
+    if (n >= p.Cout) return;
+    const int epi = p.epi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s[2][5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const float m0 = acc[j][r], m1 = acc[5 + j][r], m2 = acc[10 + j][r], m3 = acc[15 + j][r], m4 = acc[20 + j][r];
+            s[0][j] = m0 + m1 + m2 + m3;
+            s[1][j] = m1 - m2 + 2.f * m3 + m4;
+        }
+        const int t = th * 16 + 4 * ks + r;
+        const int oy0 = 2 * (tby * W24_TY + (t >> 2)), ox0 = 2 * (tbx * W24_TX + (t & 3));
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const float y0 = s[a2][0] + s[a2][1] + s[a2][2] + s[a2][3];
+            const float y1 = s[a2][1] - s[a2][2] + 2.f * s[a2][3] + s[a2][4];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int oy = oy0 + a2, ox = ox0 + c2;
+                if (oy >= q.Hc || ox >= q.Wc) continue;
+                const int oyF = 2 * oy + py, oxF = 2 * ox + px;
+                const size_t pix = ((size_t)b * p.HoF + oyF) * p.WoF + oxF;
+                epilogue_store(p, epi, pix, n, (c2 ? y1 : y0) + epilogue_side(p, epi, b, oyF, oxF, n), false);
+            }
+        }
+    }
+}
+
+int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
+    // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
+    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
+    RAMNET_CHECK_ARG(d.C0 % W24_K == 0 && d.Cout % 64 == 0 && d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
+    RAMNET_CHECK_ARG((d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR) && d.beta == 0.f && d.out_s2d == 0 && d.Ho >= 2 && d.Wo >= 2);
+    Wino24Params q;
+    q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
+    q.nchunks = d.C0 / W24_K, q.nblk = d.Cout / 64;
+    q.Hc = d.Ho, q.Wc = d.Wo;
+    q.tiles_x = cdiv(d.Wo, 2 * W24_TX), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
+    const size_t lds = (size_t)2 * W24_V * sizeof(float);
+    RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
+    hipLaunchKernelGGL(conv_wino24_kernel, grid, dim3(512), lds, st, d, q);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ramnet

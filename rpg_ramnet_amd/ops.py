@@ -53,6 +53,15 @@ def get_winograd():
 _FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
 
 
+_FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
+
+
+def set_fold_winograd(on):
+    """Folded upsample-conv forward on the Winograd F(2x2,4x4) kernel (needs Cin % 16 == 0, Cout % 64 == 0) or the direct one."""
+    global _FOLD_WINO
+    _FOLD_WINO = bool(on)
+
+
 def set_fold_upsample(on):
     global _FOLD_UP
     _FOLD_UP = bool(on)
@@ -176,7 +185,7 @@ def uses_head(taps, w, stride, epi, in_mode):
 
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
-                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0):
+                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0, wino24=False):
     B = x0.shape[0]
     d = H.ConvDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
@@ -204,6 +213,8 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
     d.ldo, d.ldo1, d.ldo2 = ld(out), (ld(o1) if o1 is not None else 0), (ld(o2) if o2 is not None else 0)
     d.precision = _PRECISION
+    if wino24:          # w = ConvParam.pack_fold_wino(): all four parities in one Winograd F(2x2,4x4) launch
+        d.algo = H.ALGO_WINOGRAD24
     return d
 
 
@@ -340,6 +351,26 @@ FOLD_A = ([[.25, 0, 0, 0, 0], [.75, .75, .25, 0, 0], [0, .25, .75, .75, .25], [0
 FOLD_LOST = [[(0, 1), (0,)], [(4,), (3, 4)]]    # [side: near / far edge][slot: distance into the band] -> taps outside the image
 
 
+# Winograd F(2x2,4x4) of the four parity filters (csrc/conv_wino24.hip; Toom-Cook points 0, 1, -1, 2, inf)
+W24_G = [[0.5, 0, 0, 0], [-0.5, -0.5, -0.5, -0.5], [-1 / 6, 1 / 6, -1 / 6, 1 / 6], [1 / 6, 1 / 3, 2 / 3, 4 / 3], [0, 0, 0, 1]]
+W24_BT = [[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]]
+W24_AT = [[1, 1, 1, 1, 0], [0, 1, -1, 2, 1]]
+
+
+def fold_weights_wino(w):
+    """OIHW 5x5 -> U[class = py*2+px][pos = a*5+b][Cin][Cout] = G W4 G^T of the four 4x4 parity filters (float64)."""
+    G = torch.tensor(W24_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum("at,bs,oipqts->pqabio", G, G, fold_weights(w))
+    return u.reshape(4, 25, w.shape[1], w.shape[0])
+
+
+def pack_fold_wino(w):
+    """fold_weights_wino() in the lane order of conv_wino24_kernel's B operand (layout: include/ramnet_hip.h)."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    u = fold_weights_wino(w).float().view(4, 25, Cin // 16, 4, 4, Cout // 64, 4, 16)      # cls pos chunk ks j nb cq l15
+    return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)                          # cls chunk nb pos cq ks l15 j
+
+
 def fold_weights(w):
     """OIHW 5x5 -> [O][I][py][px][ty][tx]: the 4x4 filter of every output parity, W4 = A_py w A_px^T (float64)."""
     A = torch.tensor(FOLD_A, dtype=torch.float64, device=w.device)
@@ -465,6 +496,14 @@ class ConvParam:
             out = torch.empty(L.ramnet_packed_weight_elems(self.Cout, self.Cin, 8, 8, 0, 1), device=w4.device)
             H.check(L.ramnet_pack_weight(_p(w4), _p(out), self.Cout, self.Cin, 8, 8, 0, 1, _st()), "ramnet_pack_weight")
             hit = self._packs["fold"] = (v, out)
+        return hit[1]
+
+    def pack_fold_wino(self):
+        """Winograd-domain weights of the folded upsample-conv (conv_wino24_kernel), cached per parameter version."""
+        v = (self._versions(self.weights), "fold24")
+        hit = self._packs.get("fold24")
+        if hit is None or hit[0] != v:
+            hit = self._packs["fold24"] = (v, pack_fold_wino(self._cat_w()))
         return hit[1]
 
     def border_weights(self):
@@ -640,6 +679,9 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     w_rows, w_cols = cp.border_weights()
     g_rows, g_cols = torch.bmm(a_rows, w_rows), torch.bmm(a_cols, w_cols)         # [2][B*2W][2*Cout], [2][B*2H][2*Cout]
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
+    if _FOLD_WINO and Cc % 16 == 0 and cp.Cout % 64 == 0:      # Winograd F(2x2,4x4) over the four parities
+        conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
+        return
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
                       [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)], **desc_kw)
 

@@ -337,3 +337,42 @@ def test_space_to_depth_weight_maps_cpu():
     (ref * g).sum().backward()
     (y * g).sum().backward()
     assert torch.allclose(ops.s2d_weights_adjoint(w3.grad, Cin), w.grad, atol=1e-12)
+
+
+def test_winograd_f2x2_4x4_algebra_cpu():
+    """The matrices of csrc/conv_wino24.hip / ops.fold_weights_wino: Y = A^T[(G g G^T) .* (B^T d B)]A equals the 4x4 stride-1
+    correlation of every parity class of the folded upsample-conv, and the four classes together equal the 5x5 convolution of the
+    bilinear upsample away from the border."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(0)
+    Cin, Cout, Hh, W = 3, 2, 6, 8
+    w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64)
+    x = torch.randn(1, Cin, Hh, W, dtype=torch.float64)
+    xpad = F.pad(x, (2, 2, 2, 2), mode="replicate")
+    U = ops.fold_weights_wino(w)                                   # [4][25][Cin][Cout]
+    BT = torch.tensor(ops.W24_BT, dtype=torch.float64)
+    AT = torch.tensor(ops.W24_AT, dtype=torch.float64)
+    W4 = ops.fold_weights(w)                                       # [O][I][py][px][4][4]
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    ref = F.conv2d(up, w, None, 1, 2)
+    y = torch.zeros(1, Cout, 2 * Hh, 2 * W, dtype=torch.float64)
+    for py in range(2):
+        for px in range(2):
+            cls = py * 2 + px
+            direct = F.conv2d(xpad[:, :, py:py + Hh + 3, px:px + W + 3], W4[:, :, py, px])          # [1][Cout][Hh][W]
+            for ty in range(Hh // 2):
+                for tx in range(W // 2):
+                    d = xpad[0, :, 2 * ty + py:2 * ty + py + 5, 2 * tx + px:2 * tx + px + 5]        # [Cin][5][5]
+                    v = torch.einsum("ar,crs,bs->cab", BT, d, BT).reshape(Cin, 25)
+                    m = torch.einsum("cp,pco->po", v, U[cls]).reshape(5, 5, Cout)
+                    out = torch.einsum("ai,ijo,bj->oab", AT, m, AT)                               # [Cout][2][2]
+                    assert torch.allclose(out, direct[0, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2], atol=1e-10)
+                    y[0, :, 4 * ty + py:4 * ty + py + 4:2, 4 * tx + px:4 * tx + px + 4:2] = out
+    assert torch.allclose(y[:, :, 2:-2, 2:-2], ref[:, :, 2:-2, 2:-2], atol=1e-10)
+    # packed layout: element (cls, pos, k, n) sits where include/ramnet_hip.h says
+    w2 = torch.randn(64, 32, 5, 5)
+    packed, U2 = ops.pack_fold_wino(w2), ops.fold_weights_wino(w2).float()
+    for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 31, 63), (2, 7, 21, 37), (1, 13, 6, 50)]:
+        idx = ((((cls * 2 + k // 16) * 1 + n // 64) * 25 + pos) * 4 + (n % 64) // 16) * 256 + (((k % 16) // 4) * 16 + n % 16) * 4 + k % 4
+        assert packed[idx] == U2[cls, pos, k, n]
