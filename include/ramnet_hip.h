@@ -49,10 +49,11 @@ enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
  * dense (tap, channel) reduction, weights from ramnet_pack_weight_head() held in registers; fp32 */
 /* RAMNET_ALGO_WINOGRAD24: all four output parities of the folded upsample-conv (decoders, statenet.py:305-308) as Winograd
  * F(2x2,4x4) convolutions of the replicate-padded low-res input: x0 = [B][Hin = H+4][Win = W+4][C0] (ramnet_pad2_sum),
- * Ho, Wo = H, W (one parity grid), out = [B][HoF = 2H][WoF = 2W][Cout]; C0 % 16 == 0, Cout % 64 == 0; bias, LINEAR / RELU and
- * `frame` as for the direct launch.  w = U[class = py*2+px][C0/16][Cout/64][25 positions][4][64][4] floats with
+ * Ho, Wo = H, W (one parity grid), out = [B][HoF = 2H][WoF = 2W][Cout]; C0 % 8 == 0, Cout % 32 == 0; bias, LINEAR / RELU and
+ * `frame` as for the direct launch.  With (KC, NCQ) = (16, 4) when Cout % 64 == 0 and C0 % 16 == 0, else (8, 2):
+ * w = U[class = py*2+px][C0/KC][Cout/(16*NCQ)][25 positions][NCQ][64][KC/4] floats with
  * U[cls][pos = a*5+b][k][n] = sum_{t,s} G[a][t] W4[n][k][py][px][t][s] G[b][s] (W4 = the 4x4 parity filters, G below) stored at
- * ((((cls*(C0/16) + k/16)*(Cout/64) + n/64)*25 + pos)*4 + (n%64)/16)*256 + (((k%16)/4)*16 + n%16)*4 + k%4.
+ * ((((cls*(C0/KC) + k/KC)*(Cout/(16*NCQ)) + n/(16*NCQ))*25 + pos)*NCQ + (n%(16*NCQ))/16)*16*KC + (((k%KC)/(KC/4))*16 + n%16)*(KC/4) + k%(KC/4).
  * G = [1/2 0 0 0; -1/2 -1/2 -1/2 -1/2; -1/6 1/6 -1/6 1/6; 1/6 1/3 2/3 4/3; 0 0 0 1] (Toom-Cook points 0, 1, -1, 2, inf).  */
 enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3 };
 

@@ -5,7 +5,8 @@
 //     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A,     5x5 input tile -> 2x2 outputs, 25 instead of 64 multiplies
 // (Toom-Cook points 0, 1, -1, 2, inf), i.e. 6.25 multiplies per output and input channel instead of 16 (25 for the plain 5x5).
 //
-// Workgroup = 8 waves: 32 tiles (8 x 4 tiles = 16 x 8 pixels of one parity grid) x 64 output channels.  Per chunk of 16
+// Workgroup = 8 waves: 32 tiles (8 x 4 tiles = 16 x 8 pixels of one parity grid) x 64 output channels (NCQ = 4; for 32-channel
+// layers NCQ = 2: 64 tiles x 32 channels, chunks of 8 input channels, 8-byte operand reads).  Per chunk of 16
 // input channels every thread loads the 5x5 window of ONE (tile, channel) straight from global memory (the padded input needs
 // no bounds logic), transforms it in registers and writes the 25 values to V[25][32 tiles][16] in LDS (double-buffered, one
 // barrier per chunk).  Wave (tile half, channel quarter) accumulates all 25 positions of its 16 tiles x 16 channels on
@@ -20,10 +21,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace ramnet {
 
-constexpr int W24_K = 16;                         // input channels per chunk
-constexpr int W24_TY = 8, W24_TX = 4;             // tiles per workgroup (2x2 outputs each)
-constexpr int W24_V = 25 * 32 * W24_K;            // floats per V buffer (51.2 KB)
-constexpr int W24_U = 25 * 4 * 256;               // packed weights of one (class, chunk, 64-channel block): 25.6K floats
+constexpr int W24_TY = 8;                         // tile rows per workgroup (2x2 outputs each)
+constexpr int W24_PS = 512;                       // floats per position in V: tiles x chunk channels (32 x 16 or 64 x 8)
+constexpr int W24_V = 25 * W24_PS;                // floats per V buffer (51.2 KB)
+
+__device__ __forceinline__ float2 ld2f(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
 struct Wino24Params {
     const float *x;          // replicate-padded low-res input [B][Hp][Wp][Cin]
@@ -31,13 +33,19 @@ struct Wino24Params {
     int Hp, Wp, ldx, nchunks, nblk, tiles_x, tiles_y, Hc, Wc;
 };
 
+// NCQ = 16-channel groups of output channels per workgroup: 4 (32 tiles, chunks of 16) or 2 (64 tiles, chunks of 8)
+template <int NCQ>
 __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_desc p, const Wino24Params q) {
+    constexpr int W24_K = NCQ == 4 ? 16 : 8;          // input channels per chunk
+    constexpr int W24_TX = NCQ == 4 ? 4 : 8;          // tile columns per workgroup
+    constexpr int VEC = W24_K / 4;                    // floats per lane and operand read (k = VEC*ks + j)
+    constexpr int W24_U = 25 * NCQ * 64 * VEC;        // packed weights of one (class, chunk, channel block)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *V = smem;                               // [2][25][32][16]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, ks = lane >> 4;
-    const int th = wave & 1, cq = wave >> 1;       // tile half, output-channel quarter
+    const int th = NCQ == 4 ? wave & 1 : wave & 3, cq = NCQ == 4 ? wave >> 1 : wave >> 2;       // 16-tile group, 16-channel group
 
     // blockIdx.x = ((tile block * nblk + channel block) * 4 + class): the four parities of a tile block read the same input
     int bid = blockIdx.x;
@@ -49,17 +57,18 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     bid /= q.tiles_x;
     const int tby = bid % q.tiles_y, b = bid / q.tiles_y;
     const int py = cls >> 1, px = cls & 1;
-    const int n0 = nb * 64;
+    const int n0 = nb * 16 * NCQ;
 
-    // ---- input transform item of this thread: (tile tid>>4, channel tid&15)
-    const int it = tid >> 4, ik = tid & 15;
+    // ---- input transform item of this thread: (tile, channel of the chunk)
+    const int it = tid / W24_K, ik = tid % W24_K;
     // window rows / columns past the padded input only feed outputs past the grid: clamp them one by one
-    const int iy0 = 2 * (tby * W24_TY + (it >> 2)) + py, ix0 = 2 * (tbx * W24_TX + (it & 3)) + px;
+    const int iy0 = 2 * (tby * W24_TY + it / W24_TX) + py, ix0 = 2 * (tbx * W24_TX + it % W24_TX) + px;
     int rowo[5], colo[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) rowo[r] = min(iy0 + r, q.Hp - 1) * q.Wp * q.ldx, colo[r] = min(ix0 + r, q.Wp - 1) * q.ldx;
     const float *xsrc = q.x + (size_t)b * q.Hp * q.Wp * q.ldx + ik;
-    const int vdst = it * W24_K + (((ik >> 2) ^ ((it >> 2) & 3)) << 2) + (ik & 3);
+    // operand reads are VEC floats per lane; the XOR swizzle spreads the 16 tiles of a read over all banks
+    const int vdst = NCQ == 4 ? it * 16 + (((ik >> 2) ^ ((it >> 2) & 3)) << 2) + (ik & 3) : it * 8 + (((ik >> 1) ^ ((it >> 3) & 1)) << 1) + (ik & 1);
     float raw[25];
     auto load_raw = [&](int chunk) {
 #pragma unroll
@@ -78,18 +87,24 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     };
     auto tr_row = [&](float *vbuf, int i) {
         const float d0 = raw[i * 5], d1 = raw[i * 5 + 1], d2 = raw[i * 5 + 2], d3 = raw[i * 5 + 3], d4 = raw[i * 5 + 4];
-        float *dst = vbuf + (i * 5) * (32 * W24_K) + vdst;
-        dst[0 * 32 * W24_K] = 2.f * (d0 - d2) - d1 + d3;
-        dst[1 * 32 * W24_K] = d3 - d2 - 2.f * d1;
-        dst[2 * 32 * W24_K] = 2.f * d1 - 3.f * d2 + d3;
-        dst[3 * 32 * W24_K] = d3 - d1;
-        dst[4 * 32 * W24_K] = 2.f * (d1 - d3) - d2 + d4;
+        float *dst = vbuf + (i * 5) * W24_PS + vdst;
+        dst[0 * W24_PS] = 2.f * (d0 - d2) - d1 + d3;
+        dst[1 * W24_PS] = d3 - d2 - 2.f * d1;
+        dst[2 * W24_PS] = 2.f * d1 - 3.f * d2 + d3;
+        dst[3 * W24_PS] = d3 - d1;
+        dst[4 * W24_PS] = 2.f * (d1 - d3) - d2 + d4;
     };
 
     // ---- MFMA operands
     const int tile = th * 16 + l15;
-    const int aoff = tile * W24_K + ((ks ^ ((tile >> 2) & 3)) << 2);
-    const float *wsrc = q.wp + ((size_t)(cls * q.nchunks) * q.nblk + nb) * W24_U + cq * 256 + lane * 4;
+    const int aoff = NCQ == 4 ? tile * 16 + ((ks ^ ((tile >> 2) & 3)) << 2) : tile * 8 + ((ks ^ ((tile >> 3) & 1)) << 1);
+    constexpr int WPOS = NCQ * 64 * VEC;              // packed floats per position
+    const float *wsrc = q.wp + ((size_t)(cls * q.nchunks) * q.nblk + nb) * W24_U + cq * (64 * VEC) + lane * VEC;
+    auto ldv = [&](const float *ptr) {                // VEC floats -> float4 (upper half unused for VEC = 2)
+        if (VEC == 4) return ld4(ptr);
+        const float2 t = ld2f(ptr);
+        return make_float4(t.x, t.y, 0.f, 0.f);
+    };
     const size_t wchunk = (size_t)q.nblk * W24_U;
 
     f32x4 acc[25];
@@ -100,7 +115,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     load_raw(0);
     float4 bq[5];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = ld4(wsrc + i * 1024);
+    for (int i = 0; i < 4; ++i) bq[i] = ldv(wsrc + i * WPOS);
 #pragma unroll
     for (int c = 0; c < 5; ++c) tr_col(c);
 #pragma unroll
@@ -113,12 +128,12 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
         const int cnext = min(chunk + 1, nch - 1);            // past the end: re-stage the last chunk into the unused buffer
         const float *wcur = wsrc + chunk * wchunk, *wnext = wsrc + cnext * wchunk;
         load_raw(cnext);
-        float4 a = ld4(vb + aoff);
+        float4 a = ldv(vb + aoff);
 #pragma unroll
         for (int pos = 0; pos < 25; ++pos) {
             float4 an;
-            if (pos + 1 < 25) an = ld4(vb + (pos + 1) * (32 * W24_K) + aoff);
-            bq[(pos + 4) % 5] = pos + 4 < 25 ? ld4(wcur + (pos + 4) * 1024) : ld4(wnext + (pos + 4 - 25) * 1024);
+            if (pos + 1 < 25) an = ldv(vb + (pos + 1) * W24_PS + aoff);
+            bq[(pos + 4) % 5] = pos + 4 < 25 ? ldv(wcur + (pos + 4) * WPOS) : ldv(wnext + (pos + 4 - 25) * WPOS);
             const float4 bv = bq[pos % 5];
             __builtin_amdgcn_sched_barrier(0);
             acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc[pos], 0, 0, 0);
@@ -127,8 +142,10 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             if (pos >= 10 && pos < 15) tr_col(pos - 10);
             if (pos >= 15 && pos < 20) tr_row(vn, pos - 15);
             __builtin_amdgcn_sched_barrier(0);
-            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv.z, acc[pos], 0, 0, 0);
-            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv.w, acc[pos], 0, 0, 0);
+            if (VEC == 4) {
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv.z, acc[pos], 0, 0, 0);
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv.w, acc[pos], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (pos + 1 < 25) a = an;
         }
@@ -149,7 +166,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             s[1][j] = m1 - m2 + 2.f * m3 + m4;
         }
         const int t = th * 16 + 4 * ks + r;
-        const int oy0 = 2 * (tby * W24_TY + (t >> 2)), ox0 = 2 * (tbx * W24_TX + (t & 3));
+        const int oy0 = 2 * (tby * W24_TY + t / W24_TX), ox0 = 2 * (tbx * W24_TX + t % W24_TX);
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
             const float y0 = s[a2][0] + s[a2][1] + s[a2][2] + s[a2][3];
@@ -169,17 +186,23 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
     RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
-    RAMNET_CHECK_ARG(d.C0 % W24_K == 0 && d.Cout % 64 == 0 && d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
+    const bool wide = d.Cout % 64 == 0 && d.C0 % 16 == 0;      // 64-channel workgroups, chunks of 16; else 32 channels, chunks of 8
+    RAMNET_CHECK_ARG(d.C0 % 8 == 0 && d.Cout % 32 == 0 && d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
     RAMNET_CHECK_ARG((d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR) && d.beta == 0.f && d.out_s2d == 0 && d.Ho >= 2 && d.Wo >= 2);
     Wino24Params q;
     q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
-    q.nchunks = d.C0 / W24_K, q.nblk = d.Cout / 64;
+    q.nchunks = d.C0 / (wide ? 16 : 8), q.nblk = d.Cout / (wide ? 64 : 32);
     q.Hc = d.Ho, q.Wc = d.Wo;
-    q.tiles_x = cdiv(d.Wo, 2 * W24_TX), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
+    q.tiles_x = cdiv(d.Wo, 2 * (wide ? 4 : 8)), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
-    RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
-    hipLaunchKernelGGL(conv_wino24_kernel, grid, dim3(512), lds, st, d, q);
+    if (wide) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(conv_wino24_kernel<4>, grid, dim3(512), lds, st, d, q);
+    } else {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(conv_wino24_kernel<2>, grid, dim3(512), lds, st, d, q);
+    }
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -54,10 +54,11 @@ _FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
 
 
 _FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
+_FOLD_WINO_MIN_COUT = int(_os.environ.get("RAMNET_FOLD_WINOGRAD_MIN_COUT", "32"))
 
 
 def set_fold_winograd(on):
-    """Folded upsample-conv forward on the Winograd F(2x2,4x4) kernel (needs Cin % 16 == 0, Cout % 64 == 0) or the direct one."""
+    """Folded upsample-conv forward on the Winograd F(2x2,4x4) kernel (needs Cin % 8 == 0, Cout % 32 == 0) or the direct one."""
     global _FOLD_WINO
     _FOLD_WINO = bool(on)
 
@@ -367,8 +368,9 @@ def fold_weights_wino(w):
 def pack_fold_wino(w):
     """fold_weights_wino() in the lane order of conv_wino24_kernel's B operand (layout: include/ramnet_hip.h)."""
     Cout, Cin = w.shape[0], w.shape[1]
-    u = fold_weights_wino(w).float().view(4, 25, Cin // 16, 4, 4, Cout // 64, 4, 16)      # cls pos chunk ks j nb cq l15
-    return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)                          # cls chunk nb pos cq ks l15 j
+    kc, ncq = (16, 4) if (Cout % 64 == 0 and Cin % 16 == 0) else (8, 2)     # chunk size, 16-channel groups per workgroup
+    u = fold_weights_wino(w).float().view(4, 25, Cin // kc, 4, kc // 4, Cout // (16 * ncq), ncq, 16)      # cls pos chunk ks j nb cq l15
+    return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)                                       # cls chunk nb pos cq ks l15 j
 
 
 def fold_weights(w):
@@ -679,7 +681,7 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     w_rows, w_cols = cp.border_weights()
     g_rows, g_cols = torch.bmm(a_rows, w_rows), torch.bmm(a_cols, w_cols)         # [2][B*2W][2*Cout], [2][B*2H][2*Cout]
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
-    if _FOLD_WINO and Cc % 16 == 0 and cp.Cout % 64 == 0:      # Winograd F(2x2,4x4) over the four parities
+    if _FOLD_WINO and Cc % 8 == 0 and cp.Cout % 32 == 0 and cp.Cout >= _FOLD_WINO_MIN_COUT:   # Winograd F(2x2,4x4) over the four parities
         conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
         return
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
