@@ -49,7 +49,7 @@ enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
  * dense (tap, channel) reduction, weights from ramnet_pack_weight_head() held in registers; fp32 */
 /* RAMNET_ALGO_WINOGRAD24: all four output parities of the folded upsample-conv (decoders, statenet.py:305-308) as Winograd
  * F(2x2,4x4) convolutions of the replicate-padded low-res input: x0 = [B][Hin = H+4][Win = W+4][C0] (ramnet_pad2_sum),
- * Ho, Wo = H, W (one parity grid), out = [B][HoF = 2H][WoF = 2W][Cout]; C0 % 8 == 0, Cout % 32 == 0; bias, LINEAR / RELU and
+ * Ho, Wo = H, W (one parity grid), out = [B][HoF = 2H][WoF = 2W][Cout]; C0 % 16 == 0 (an even number of chunks), Cout % 32 == 0; bias, LINEAR / RELU and
  * `frame` as for the direct launch.  With (KC, NCQ) = (16, 4) when Cout % 64 == 0 and C0 % 16 == 0, else (8, 2):
  * w = U[class = py*2+px][C0/KC][Cout/(16*NCQ)][25 positions][NCQ][64][KC/4] floats with
  * U[cls][pos = a*5+b][k][n] = sum_{t,s} G[a][t] W4[n][k][py][px][t][s] G[b][s] (W4 = the 4x4 parity filters, G below) stored at

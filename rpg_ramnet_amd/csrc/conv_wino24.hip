@@ -27,6 +27,16 @@ constexpr int W24_V = 25 * W24_PS;                // floats per V buffer (51.2 K
 
 __device__ __forceinline__ float2 ld2f(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
+#ifdef W24_TRACE   // tools/wino24_trace.hip: per-wave timestamps (s_memtime, 100 MHz): [block][wave][16 chunks][6 slots] + 4 kernel slots
+__device__ unsigned long long *g_w24_trace;
+#define W24_STAMP(chunk_, slot)                                                                                          \
+    do {                                                                                                                 \
+        if (lane == 0 && (chunk_) < 16) g_w24_trace[(((size_t)blockIdx.x * 8 + wave) * 17 + (chunk_)) * 6 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define W24_STAMP(chunk_, slot)
+#endif
+
 struct Wino24Params {
     const float *x;          // replicate-padded low-res input [B][Hp][Wp][Cin]
     const float *wp;         // [4 classes][Cin/16][Cout/64][25][4][64 lanes][4]
@@ -112,45 +122,85 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     for (int i = 0; i < 25; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nch = q.nchunks;
+    W24_STAMP(16, 0);
     load_raw(0);
-    float4 bq[5];
+    // Weight ring: 10 slots, prefetch distance 9 positions.  Vector loads return in order, so a weight load issued after the
+    // 25 window loads of a chunk can only be consumed once those have landed: the ring is deep enough to give them ~9 positions
+    // (~1 us) of MFMA work, and the chunk loop is unrolled by two so that the slot of a position is a compile-time constant.
+    constexpr int RING = 10, DIST = 8;
+    float4 bq[RING];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = ldv(wsrc + i * WPOS);
+    for (int i = 0; i < DIST; ++i) bq[i] = ldv(wsrc + i * WPOS);
 #pragma unroll
     for (int c = 0; c < 5; ++c) tr_col(c);
 #pragma unroll
     for (int i = 0; i < 5; ++i) tr_row(V, i);
     __syncthreads();
 
-    for (int chunk = 0; chunk < nch; ++chunk) {
-        const float *vb = V + (chunk & 1) * W24_V;
-        float *vn = V + ((chunk + 1) & 1) * W24_V;
-        const int cnext = min(chunk + 1, nch - 1);            // past the end: re-stage the last chunk into the unused buffer
-        const float *wcur = wsrc + chunk * wchunk, *wnext = wsrc + cnext * wchunk;
-        load_raw(cnext);
-        float4 a = ldv(vb + aoff);
+    W24_STAMP(16, 1);
+    for (int chunk0 = 0; chunk0 < nch; chunk0 += 2) {             // nch is even (checked on the host)
 #pragma unroll
-        for (int pos = 0; pos < 25; ++pos) {
-            float4 an;
-            if (pos + 1 < 25) an = ldv(vb + (pos + 1) * W24_PS + aoff);
-            bq[(pos + 4) % 5] = pos + 4 < 25 ? ldv(wcur + (pos + 4) * WPOS) : ldv(wnext + (pos + 4 - 25) * WPOS);
-            const float4 bv = bq[pos % 5];
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv.x, acc[pos], 0, 0, 0);
-            acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv.y, acc[pos], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pos >= 10 && pos < 15) tr_col(pos - 10);
-            if (pos >= 15 && pos < 20) tr_row(vn, pos - 15);
-            __builtin_amdgcn_sched_barrier(0);
-            if (VEC == 4) {
-                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv.z, acc[pos], 0, 0, 0);
-                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv.w, acc[pos], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+            const int chunk = chunk0 + half;
+            const float *vb = V + half * W24_V;
+            float *vn = V + (half ^ 1) * W24_V;
+            const int cnext = min(chunk + 1, nch - 1);            // past the end: re-stage the last chunk into the unused buffer
+            const float *wcur = wsrc + chunk * wchunk, *wnext = wsrc + cnext * wchunk;
+            W24_STAMP(chunk, 0);
+#if !defined(W24_ABLATE) || !(W24_ABLATE & 1)      // timing experiments (tools/wino24_trace.hip): 1 = no window loads, 2 = no weight loads
+            load_raw(cnext);
+#endif
+            // positions go in pairs (two independent accumulator chains: a 16x16x4 MFMA can be issued every 32 cycles but its
+            // result is only available to a dependent one after 40); the last position runs alone
+            float4 a0 = ldv(vb + aoff), a1 = ldv(vb + W24_PS + aoff);
+#pragma unroll
+            for (int pp = 0; pp < 13; ++pp) {
+                const int pos = 2 * pp, g = half * 25 + pos;
+                const bool two = pos + 1 < 25;
+                float4 an0, an1;
+                if (pos + 2 < 25) an0 = ldv(vb + (pos + 2) * W24_PS + aoff);
+                if (pos + 3 < 25) an1 = ldv(vb + (pos + 3) * W24_PS + aoff);
+#if !defined(W24_ABLATE) || !(W24_ABLATE & 2)
+                bq[(g + DIST) % RING] = pos + DIST < 25 ? ldv(wcur + (pos + DIST) * WPOS) : ldv(wnext + (pos + DIST - 25) * WPOS);
+                if (two) bq[(g + 1 + DIST) % RING] = pos + 1 + DIST < 25 ? ldv(wcur + (pos + 1 + DIST) * WPOS) : ldv(wnext + (pos + 1 + DIST - 25) * WPOS);
+#endif
+                const float4 b0 = bq[g % RING], b1 = bq[(g + 1) % RING];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[pos], 0, 0, 0);
+                if (two) acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[pos + 1], 0, 0, 0);
+                acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[pos], 0, 0, 0);
+                if (two) acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[pos + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp == 6) W24_STAMP(chunk, 1);
+                if (pp == 6) tr_col(0), tr_col(1);
+                if (pp == 7) tr_col(2);
+                if (pp == 8) tr_col(4);
+                if (pp == 9) tr_row(vn, 0);
+                if (pp == 10) tr_row(vn, 2);
+                if (pp == 11) tr_row(vn, 4);
+                if (pp == 8) W24_STAMP(chunk, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (VEC == 4) {
+                    acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[pos], 0, 0, 0);
+                    if (two) acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[pos + 1], 0, 0, 0);
+                    acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[pos], 0, 0, 0);
+                    if (two) acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[pos + 1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp == 7) tr_col(3);
+                if (pp == 9) tr_row(vn, 1);
+                if (pp == 10) tr_row(vn, 3);
+                if (pp == 11) W24_STAMP(chunk, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pos + 2 < 25) a0 = an0;
+                if (pos + 3 < 25) a1 = an1;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (pos + 1 < 25) a = an;
+            W24_STAMP(chunk, 4);
+            __syncthreads();
+            W24_STAMP(chunk, 5);
         }
-        __syncthreads();
     }
+    W24_STAMP(16, 2);
 
     // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue
     const int n = n0 + cq * 16 + l15;
@@ -181,12 +231,14 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             }
         }
     }
+    W24_STAMP(16, 3);
 }
 
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
     RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
     const bool wide = d.Cout % 64 == 0 && d.C0 % 16 == 0;      // 64-channel workgroups, chunks of 16; else 32 channels, chunks of 8
+    RAMNET_CHECK_ARG(d.C0 % (wide ? 32 : 16) == 0);            // an even number of chunks (the chunk loop is unrolled by two)
     RAMNET_CHECK_ARG(d.C0 % 8 == 0 && d.Cout % 32 == 0 && d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
     RAMNET_CHECK_ARG((d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR) && d.beta == 0.f && d.out_s2d == 0 && d.Ho >= 2 && d.Wo >= 2);
     Wino24Params q;

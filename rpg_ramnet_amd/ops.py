@@ -57,8 +57,15 @@ _FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
 _FOLD_WINO_MIN_COUT = int(_os.environ.get("RAMNET_FOLD_WINOGRAD_MIN_COUT", "32"))
 
 
+def _fold_wino_ok(Cin, Cout):
+    """conv_wino24_kernel shapes: 64-channel workgroups with chunks of 16, else 32-channel ones with chunks of 8; an even
+    number of chunks."""
+    kc = 16 if (Cout % 64 == 0 and Cin % 16 == 0) else 8
+    return Cout % 32 == 0 and Cout >= _FOLD_WINO_MIN_COUT and Cin % (2 * kc) == 0
+
+
 def set_fold_winograd(on):
-    """Folded upsample-conv forward on the Winograd F(2x2,4x4) kernel (needs Cin % 8 == 0, Cout % 32 == 0) or the direct one."""
+    """Folded upsample-conv forward on the Winograd F(2x2,4x4) kernel (shapes: _fold_wino_ok) or the direct one."""
     global _FOLD_WINO
     _FOLD_WINO = bool(on)
 
@@ -681,7 +688,7 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     w_rows, w_cols = cp.border_weights()
     g_rows, g_cols = torch.bmm(a_rows, w_rows), torch.bmm(a_cols, w_cols)         # [2][B*2W][2*Cout], [2][B*2H][2*Cout]
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
-    if _FOLD_WINO and Cc % 8 == 0 and cp.Cout % 32 == 0 and cp.Cout >= _FOLD_WINO_MIN_COUT:   # Winograd F(2x2,4x4) over the four parities
+    if _FOLD_WINO and _fold_wino_ok(Cc, cp.Cout):   # Winograd F(2x2,4x4) over the four parities
         conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
         return
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
