@@ -27,6 +27,15 @@ constexpr int W24_V = 25 * W24_PS;                // floats per V buffer (51.2 K
 
 __device__ __forceinline__ float2 ld2f(const float *p) { return *reinterpret_cast<const float2 *>(p); }
 
+// Buffer resource over [p, p + bytes): loads then take a 32-bit per-lane byte offset plus a scalar one, so the window and
+// weight streams of the main loop need no 64-bit address arithmetic.  The pointer goes through readfirstlane so that the
+// compiler knows the descriptor is wave-uniform (cdna_hip_programming.md, buffer addressing).
+__device__ __forceinline__ auto make_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
+}
+
 #ifdef W24_TRACE   // tools/wino24_trace.hip: per-wave timestamps (s_memtime, 100 MHz): [block][wave][16 chunks][6 slots] + 4 kernel slots
 __device__ unsigned long long *g_w24_trace;
 #define W24_STAMP(chunk_, slot)                                                                                          \
@@ -41,6 +50,7 @@ struct Wino24Params {
     const float *x;          // replicate-padded low-res input [B][Hp][Wp][Cin]
     const float *wp;         // [4 classes][Cin/16][Cout/64][25][4][64 lanes][4]
     int Hp, Wp, ldx, nchunks, nblk, tiles_x, tiles_y, Hc, Wc;
+    unsigned xbytes, wbytes;  // extents of x and wp (buffer addressing: both below 4 GB)
 };
 
 // NCQ = 16-channel groups of output channels per workgroup: 4 (32 tiles, chunks of 16) or 2 (64 tiles, chunks of 8)
@@ -73,18 +83,22 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     const int it = tid / W24_K, ik = tid % W24_K;
     // window rows / columns past the padded input only feed outputs past the grid: clamp them one by one
     const int iy0 = 2 * (tby * W24_TY + it / W24_TX) + py, ix0 = 2 * (tbx * W24_TX + it % W24_TX) + px;
-    int rowo[5], colo[5];
+    // byte offsets: lane part (image + row, column + channel: one add per load) + scalar part (chunk)
+    unsigned rowo[5], colo[5];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) rowo[r] = min(iy0 + r, q.Hp - 1) * q.Wp * q.ldx, colo[r] = min(ix0 + r, q.Wp - 1) * q.ldx;
-    const float *xsrc = q.x + (size_t)b * q.Hp * q.Wp * q.ldx + ik;
+    for (int r = 0; r < 5; ++r)
+        rowo[r] = 4u * (unsigned)((b * q.Hp + min(iy0 + r, q.Hp - 1)) * q.Wp * q.ldx), colo[r] = 4u * (unsigned)(min(ix0 + r, q.Wp - 1) * q.ldx + ik);
+    const auto xrs = make_rsrc(q.x, q.xbytes);
     // operand reads are VEC floats per lane; the XOR swizzle spreads the 16 tiles of a read over all banks
     const int vdst = NCQ == 4 ? it * 16 + (((ik >> 2) ^ ((it >> 2) & 3)) << 2) + (ik & 3) : it * 8 + (((ik >> 1) ^ ((it >> 3) & 1)) << 1) + (ik & 1);
     float raw[25];
     auto load_raw = [&](int chunk) {
+        const int soff = chunk * (W24_K * 4);           // uniform
 #pragma unroll
         for (int r = 0; r < 5; ++r)
 #pragma unroll
-            for (int c = 0; c < 5; ++c) raw[r * 5 + c] = xsrc[rowo[r] + colo[c] + chunk * W24_K];
+            for (int c = 0; c < 5; ++c)
+                raw[r * 5 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(rowo[r] + colo[c]), soff, 0));
     };
     // B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
     auto tr_col = [&](int c) {
@@ -109,13 +123,23 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     const int tile = th * 16 + l15;
     const int aoff = NCQ == 4 ? tile * 16 + ((ks ^ ((tile >> 2) & 3)) << 2) : tile * 8 + ((ks ^ ((tile >> 3) & 1)) << 1);
     constexpr int WPOS = NCQ * 64 * VEC;              // packed floats per position
-    const float *wsrc = q.wp + ((size_t)(cls * q.nchunks) * q.nblk + nb) * W24_U + cq * (64 * VEC) + lane * VEC;
+    const auto wrs = make_rsrc(q.wp, q.wbytes);
+    const int wsrc = (((cls * q.nchunks) * q.nblk + nb) * W24_U + cq * (64 * VEC)) * 4;     // uniform byte offset; lane part below
+    const int wlane = lane * VEC * 4;
     auto ldv = [&](const float *ptr) {                // VEC floats -> float4 (upper half unused for VEC = 2)
         if (VEC == 4) return ld4(ptr);
         const float2 t = ld2f(ptr);
         return make_float4(t.x, t.y, 0.f, 0.f);
     };
-    const size_t wchunk = (size_t)q.nblk * W24_U;
+    auto ldw = [&](int soff) {                       // weights: scalar byte offset + lane offset
+        if constexpr (VEC == 4) {
+            return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, soff, 0));
+        } else {
+            const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(wrs, wlane, soff, 0));
+            return make_float4(t.x, t.y, 0.f, 0.f);
+        }
+    };
+    const int wchunk = q.nblk * W24_U * 4;
 
     f32x4 acc[25];
 #pragma unroll
@@ -130,11 +154,12 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     constexpr int RING = 10, DIST = 8;
     float4 bq[RING];
 #pragma unroll
-    for (int i = 0; i < DIST; ++i) bq[i] = ldv(wsrc + i * WPOS);
+    for (int i = 0; i < DIST; ++i) bq[i] = ldw(wsrc + i * (WPOS * 4));
 #pragma unroll
     for (int c = 0; c < 5; ++c) tr_col(c);
 #pragma unroll
     for (int i = 0; i < 5; ++i) tr_row(V, i);
+    load_raw(min(1, nch - 1));
     __syncthreads();
 
     W24_STAMP(16, 1);
@@ -144,25 +169,26 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             const int chunk = chunk0 + half;
             const float *vb = V + half * W24_V;
             float *vn = V + (half ^ 1) * W24_V;
-            const int cnext = min(chunk + 1, nch - 1);            // past the end: re-stage the last chunk into the unused buffer
-            const float *wcur = wsrc + chunk * wchunk, *wnext = wsrc + cnext * wchunk;
+            // The window of chunk+1 is already in registers (loaded at the end of the previous phase: a weight load issued
+            // after it can only be consumed once it has landed, and there it has a barrier and four position pairs to do so);
+            // it is transformed into the other V buffer during this phase and the window of chunk+2 requested right after.
+            const int cnext = min(chunk + 1, nch - 1), cnext2 = min(chunk + 2, nch - 1);     // past the end: re-stage the last chunk
+            const int wcur = wsrc + chunk * wchunk, wnext = wsrc + cnext * wchunk;
             W24_STAMP(chunk, 0);
-#if !defined(W24_ABLATE) || !(W24_ABLATE & 1)      // timing experiments (tools/wino24_trace.hip): 1 = no window loads, 2 = no weight loads
-            load_raw(cnext);
-#endif
             // positions go in pairs (two independent accumulator chains: a 16x16x4 MFMA can be issued every 32 cycles but its
             // result is only available to a dependent one after 40); the last position runs alone
-            float4 a0 = ldv(vb + aoff), a1 = ldv(vb + W24_PS + aoff);
+            float4 aq[2][2];                                   // A operands of the current / next pair (ping-pong, no copies)
+            aq[0][0] = ldv(vb + aoff), aq[0][1] = ldv(vb + W24_PS + aoff);
 #pragma unroll
             for (int pp = 0; pp < 13; ++pp) {
                 const int pos = 2 * pp, g = half * 25 + pos;
                 const bool two = pos + 1 < 25;
-                float4 an0, an1;
-                if (pos + 2 < 25) an0 = ldv(vb + (pos + 2) * W24_PS + aoff);
-                if (pos + 3 < 25) an1 = ldv(vb + (pos + 3) * W24_PS + aoff);
+                if (pos + 2 < 25) aq[(pp + 1) & 1][0] = ldv(vb + (pos + 2) * W24_PS + aoff);
+                if (pos + 3 < 25) aq[(pp + 1) & 1][1] = ldv(vb + (pos + 3) * W24_PS + aoff);
+                const float4 a0 = aq[pp & 1][0], a1 = aq[pp & 1][1];
 #if !defined(W24_ABLATE) || !(W24_ABLATE & 2)
-                bq[(g + DIST) % RING] = pos + DIST < 25 ? ldv(wcur + (pos + DIST) * WPOS) : ldv(wnext + (pos + DIST - 25) * WPOS);
-                if (two) bq[(g + 1 + DIST) % RING] = pos + 1 + DIST < 25 ? ldv(wcur + (pos + 1 + DIST) * WPOS) : ldv(wnext + (pos + 1 + DIST - 25) * WPOS);
+                bq[(g + DIST) % RING] = pos + DIST < 25 ? ldw(wcur + (pos + DIST) * (WPOS * 4)) : ldw(wnext + (pos + DIST - 25) * (WPOS * 4));
+                if (two) bq[(g + 1 + DIST) % RING] = pos + 1 + DIST < 25 ? ldw(wcur + (pos + 1 + DIST) * (WPOS * 4)) : ldw(wnext + (pos + 1 + DIST - 25) * (WPOS * 4));
 #endif
                 const float4 b0 = bq[g % RING], b1 = bq[(g + 1) % RING];
                 __builtin_amdgcn_sched_barrier(0);
@@ -192,8 +218,9 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
                 if (pp == 10) tr_row(vn, 3);
                 if (pp == 11) W24_STAMP(chunk, 3);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pos + 2 < 25) a0 = an0;
-                if (pos + 3 < 25) a1 = an1;
+#if !defined(W24_ABLATE) || !(W24_ABLATE & 1)      // timing experiments (tools/wino24_trace.hip): 1 = no window loads, 2 = no weight loads
+                if (pp == 11) load_raw(cnext2);
+#endif
             }
             W24_STAMP(chunk, 4);
             __syncthreads();
@@ -245,6 +272,9 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
     q.nchunks = d.C0 / (wide ? 16 : 8), q.nblk = d.Cout / (wide ? 64 : 32);
     q.Hc = d.Ho, q.Wc = d.Wo;
+    const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
+    RAMNET_CHECK_ARG(xb < 0xffffffffull && wb < 0x7fffffffull);
+    q.xbytes = (unsigned)xb, q.wbytes = (unsigned)wb;
     q.tiles_x = cdiv(d.Wo, 2 * (wide ? 4 : 8)), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
