@@ -160,6 +160,9 @@ class KernelTimer:
             if getattr(dw, "wino", False):         # Winograd backward-weights (template flags: loader operand, ReLU mask on dy)
                 from rpg_ramnet_amd import _hip as Hh
                 name = "conv_wgrad_wino_kernel<%d,%d>" % (kw.get("in_mode", 0) in (Hh.IN_RELUMASK, Hh.IN_CAT_MUL), kw.get("gmask") is not None)
+            nclass = 1
+            if kw.get("wino24"):
+                name, nclass = "conv_wgrad_wino24_kernel", 4
             if getattr(dw, "head_cin", 0) and ops.get_head_kernel() and taps.head and kw.get("stride", 1) == 1 and kw.get("in_mode", 0) == 0 \
                     and kw.get("gview") is None:
                 name = "conv_head_wgrad_kernel"
@@ -170,7 +173,7 @@ class KernelTimer:
             wgrad0(x0, taps, dout, dw, Cout, **kw)
             e.record()
             ho, wo = kw.get("Ho") or dout.shape[1], kw.get("Wo") or dout.shape[2]       # (parity sub-grid of the folded upsample-conv)
-            timer.rec.append((name, s, e, 2.0 * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout))
+            timer.rec.append((name, s, e, 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout))
 
         multi0 = ops.conv_launch_multi
 

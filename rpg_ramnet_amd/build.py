@@ -5,7 +5,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "conv_head.hip", "conv_wino24.hip", "pointwise.hip", "loss_voxel.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "conv_head.hip", "conv_wino24.hip", "conv_wgrad_wino24.hip", "pointwise.hip", "loss_voxel.hip"]
 LIB = os.path.join(PKG, "librpg_ramnet_hip.so")
 
 

@@ -18,6 +18,7 @@ void set_error(const char *fmt, ...);
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st);   // conv_wino.hip
 int launch_head(const ramnet_conv_desc &d, hipStream_t st);   // conv_head.hip
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st); // conv_wino24.hip
+int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino24.hip
 int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st);
 int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino.hip
 

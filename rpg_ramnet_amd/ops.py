@@ -55,6 +55,14 @@ _FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
 
 _FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
 _FOLD_WINO_MIN_COUT = int(_os.environ.get("RAMNET_FOLD_WINOGRAD_MIN_COUT", "32"))
+_FOLD_WINO_WGRAD = _os.environ.get("RAMNET_FOLD_WINOGRAD_WGRAD", "1") == "1"
+
+
+def set_fold_winograd_wgrad(on):
+    """Folded upsample-conv backward-weights in the Winograd F(2x2,4x4) domain (Cin % 32 == 0, Cout % 64 == 0) or as four direct
+    16-tap parity launches."""
+    global _FOLD_WINO_WGRAD
+    _FOLD_WINO_WGRAD = bool(on)
 
 
 def _fold_wino_ok(Cin, Cout):
@@ -227,7 +235,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
 
 
 def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
-                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0):
+                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0, wino24=False):
     d = H.WgradDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
@@ -242,6 +250,8 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     if gview is not None:      # dout / gmask addressed as (oy*gsy + goy, ox*gsx + gox) of [B, HoG, WoG]
         d.gsy, d.gsx, d.goy, d.gox, d.HoG, d.WoG = gview
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
+    if wino24:          # folded upsample-conv in the Winograd F(2x2,4x4) domain: dw = [4][25][C0][Cout]
+        d.algo = H.ALGO_WINOGRAD24
     hc = getattr(dw, "head_cin", 0)
     if hc and _HEAD and _PRECISION == H.PREC_F32 and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
         d.algo, d.head_cin = H.ALGO_HEAD, hc
@@ -574,12 +584,24 @@ class ConvParam:
         self._fold_used = True
         return self._ws_fold + (self._bws,)
 
+    def grad_ws_fold24(self):
+        """dU [4 parity classes][25 positions][Cin][Cout]: Winograd-domain gradient of the four 4x4 parity filters."""
+        if getattr(self, "_ws_fold24", None) is None:
+            self._ws_fold24 = torch.zeros(4 * 25 * self.CinWs * self.Cout, device=self.weights[0].device)
+        self._fold24_used = True
+        return self._ws_fold24
+
     def _finalize_fold(self):
         """dW5 = sum_parities A_py^T dW4 A_px  -  (border GEMM gradients routed back to the taps they summed)."""
         w4, wr, wc = self._ws_fold
         g = ensure_grad(self.weights[0])
         A = torch.tensor(self._FOLD_A, dtype=torch.float32, device=g.device)                        # [p][t][k]
         d4 = w4.view(2, 2, 4, 4, self.CinWs, self.Cout)[:, :, :, :, :self.Cin]
+        if getattr(self, "_fold24_used", False):        # dW4 += G^T dU G
+            G = torch.tensor(W24_G, dtype=torch.float32, device=g.device)
+            d4 = d4 + torch.einsum("at,bs,pqabio->pqtsio", G, G, self._ws_fold24.view(2, 2, 5, 5, self.CinWs, self.Cout))
+            self._ws_fold24.zero_()
+            self._fold24_used = False
         g.add_(torch.einsum("ptk,qsl,pqtsio->oikl", A, A, d4))
         lost = FOLD_LOST
         r = wr.view(2, 5, self.Cin, 2, self.Cout)          # [side][kx][ci][slot][co]
@@ -755,10 +777,15 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp):
     w4, wr, wc, bws = cp.grad_ws_fold()
     xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
     H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
-    for py in range(2):
-        for px in range(2):
-            wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, py, px), dy, w4, cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
-                       gview=(2, 2, py, px, H2, W2), dw_off=(py * 2 + px) * 16 * cp.CinWs * cp.Cout)
+    if _FOLD_WINO_WGRAD and _PRECISION == H.PREC_F32 and Cc % 32 == 0 and cp.Cout % 64 == 0 and Cc == cp.CinWs:
+        # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
+        wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, 0, 0), dy, cp.grad_ws_fold24(), cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
+                   gview=(0, 0, 0, 0, H2, W2), wino24=True)
+    else:
+        for py in range(2):
+            for px in range(2):
+                wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, py, px), dy, w4, cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
+                           gview=(2, 2, py, px, H2, W2), dw_off=(py * 2 + px) * 16 * cp.CinWs * cp.Cout)
     a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
     a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
     H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")

@@ -100,12 +100,14 @@ def upsample_algo(request):
     the channel counts allow (default) or on the direct kernel — and the direct 5x5 kernel with the bilinear loader, all against
     the oracle."""
     from rpg_ramnet_amd import ops
-    old, oldw = ops.get_fold_upsample(), ops._FOLD_WINO
+    old, oldw, oldg = ops.get_fold_upsample(), ops._FOLD_WINO, ops._FOLD_WINO_WGRAD
     ops.set_fold_upsample(request.param != "direct")
     ops.set_fold_winograd(request.param == "folded")
+    ops.set_fold_winograd_wgrad(request.param == "folded")
     yield request.param
     ops.set_fold_upsample(old)
     ops.set_fold_winograd(oldw)
+    ops.set_fold_winograd_wgrad(oldg)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 8, 16), (1, 5, 11), (2, 16, 24), (1, 4, 4), (1, 32, 43)])
