@@ -120,7 +120,7 @@ typedef struct ramnet_wgrad_desc {
                                      * accumulates the transformed-domain gradient dU, folded by ramnet_unpack_wgrad_wino();
                                      * or RAMNET_ALGO_WINOGRAD24 (folded upsample-conv): x0 = [B][Hin = Ho+4][Win = Wo+4][C0] as for the
                                      * forward launch, dout / gmask = the full-resolution [B][HoG = 2*Ho][WoG = 2*Wo][Cout] tensors,
-                                     * dw = dU [4 classes][25 positions][C0][Cout] (dW4 = G^T dU G per class), C0 % 32 == 0     */
+                                     * dw = dU [4 classes][25 positions][C0][Cout] (dW4 = G^T dU G per class); C0 % 32 == 0 and Cout % 64 == 0, or C0 % 64 == 0 and Cout % 32 == 0 */
     int gsy, gsx, goy, gox;         /* dout / gmask are read at pixel (oy*gsy + goy, ox*gsx + gox) of a [B, HoG, WoG] tensor      */
     int HoG, WoG;                   /* (all 0 = dense [B, Ho, Wo]; DIRECT only): one output parity of the folded upsample-conv  */
     int head_cin;                   /* RAMNET_ALGO_HEAD (dense 5x5 stride-1 taps, Cout <= 32): real input channels (1, 3 or 5); dw keeps

@@ -17,9 +17,7 @@
 namespace ramnet {
 
 constexpr int G24_T = 8;                          // tiles per batch
-constexpr int G24_CI = 32, G24_CO = 64;           // channels per workgroup
-constexpr int G24_V = 25 * G24_T * G24_CI;        // 6400 floats
-constexpr int G24_Z = 25 * G24_T * G24_CO;        // 12800 floats
+// channels per workgroup: 32 input x 64 output, or (WCI, for 32-output-channel layers) 64 input x 32 output
 
 struct Wgrad24Params {
     const float *x, *g, *gm;
@@ -27,22 +25,24 @@ struct Wgrad24Params {
     int ldx, ldg, ldgm, Hp, Wp, H2, W2, Hc, Wc, Cin, Cout, tiles_x, tiles_y, ntiles, nbatch, ncob;
 };
 
-template <bool GM>
+template <bool GM, bool WCI>
 __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24Params p) {
+    constexpr int G24_CI = WCI ? 64 : 32, G24_CO = WCI ? 32 : 64;
+    constexpr int G24_V = 25 * G24_T * G24_CI, G24_Z = 25 * G24_T * G24_CO;      // 6400 / 12800 floats (or swapped)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *V = smem;                   // [2][25][8][32]
-    float *Z = smem + 2 * G24_V;       // [2][25][8][64]
+    float *V = smem;                   // [2][25][8][CI]
+    float *Z = smem + 2 * G24_V;       // [2][25][8][CO]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
-    const int pg = wave >> 1, ch = wave & 1;                  // position group, output-channel half
+    const int pg = wave >> 1, ch = wave & 1;                  // position group, half of the wider channel dimension
     const int p0 = pg == 0 ? 0 : 1 + 6 * pg;                  // positions p0 .. p0 + (pg == 0 ? 7 : 6) - 1
     const int cls = blockIdx.z / p.ncob, cob = blockIdx.z % p.ncob;
     const int py = cls >> 1, px = cls & 1;
     const int c0 = blockIdx.y * G24_CI, n0 = cob * G24_CO;
-    const bool vrole = wave < 4;                               // threads 0..255 also own an input item
-    const int vt = (tid >> 5) & 7, vc = tid & 31;              // input item: (tile of the batch, input channel)
-    const int zt = tid >> 6, zc = tid & 63;                    // gradient item: (tile, output channel)
+    const bool vrole = WCI || wave < 4, zrole = !WCI || wave < 4;      // the narrower operand has 256 items per batch, the wider 512
+    const int vt = (tid / G24_CI) & 7, vc = tid % G24_CI;      // input item: (tile of the batch, input channel)
+    const int zt = (tid / G24_CO) & 7, zc = tid % G24_CO;      // gradient item: (tile, output channel)
 
     f32x16 acc[7];
 #pragma unroll
@@ -134,10 +134,12 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
     if (batch < p.nbatch) {
         const int last = batch + ((p.nbatch - 1 - batch) / step) * step;
         // prologue: batch -> buffer 0; raw data of the next batch in registers
-        load_z(batch, true);
+        if (zrole) load_z(batch, true);
         if (vrole) load_v(batch);
+        if (zrole) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) z_row(Z, i);
+            for (int i = 0; i < 5; ++i) z_row(Z, i);
+        }
         if (vrole) {
             v_cols();
 #pragma unroll
@@ -145,11 +147,11 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
         }
         {
             const bool more = batch + step <= last;
-            load_z(min(batch + step, last), more);
+            if (zrole) load_z(min(batch + step, last), more);
             if (vrole) load_v(min(batch + step, last));
         }
         __syncthreads();
-        const int aoff = (kk * 4) * G24_CI + l31, boff = (kk * 4) * G24_CO + ch * 32 + l31;
+        const int aoff = (kk * 4) * G24_CI + (WCI ? ch * 32 : 0) + l31, boff = (kk * 4) * G24_CO + (WCI ? 0 : ch * 32) + l31;
         int buf = 0;
         for (; batch <= last; batch += step, buf ^= 1) {
             const float *vb = V + buf * G24_V, *zb = Z + buf * G24_Z;
@@ -168,13 +170,13 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[q], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     // raw data of the next batch (in registers) -> the other LDS buffer; then the loads of the batch after it
-                    if (q == 0) z_row(zn, 0), z_row(zn, 1), z_row(zn, 2);
-                    if (q == 1) z_row(zn, 3), z_row(zn, 4);
+                    if (q == 0 && zrole) z_row(zn, 0), z_row(zn, 1), z_row(zn, 2);
+                    if (q == 1 && zrole) z_row(zn, 3), z_row(zn, 4);
                     if (q == 2 && vrole) v_cols();
                     if (q == 3 && vrole) v_row(vn, 0), v_row(vn, 1), v_row(vn, 2);
                     if (q == 4 && vrole) v_row(vn, 3), v_row(vn, 4);
                     if (q == 4) {
-                        load_z(b2, more2);
+                        if (zrole) load_z(b2, more2);
                         if (vrole) load_v(b2);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -188,21 +190,21 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
     }
 
     // D[row = input channel][col = output channel] of position p0 + q -> dw[((cls*25 + pos)*Cin + c)*Cout + n]
-    const int n = n0 + ch * 32 + l31;
+    const int n = n0 + (WCI ? 0 : ch * 32) + l31;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
         if (q < 6 || pg == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                const int c = c0 + (WCI ? ch * 32 : 0) + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 if (c < p.Cin && n < p.Cout) atomicAdd(p.dw + (((size_t)cls * 25 + p0 + q) * p.Cin + c) * p.Cout + n, acc[q][r]);
             }
         }
     }
     if (p.dbias != nullptr && blockIdx.y == 0) {
         __syncthreads();
-        float *red = smem;                        // [8][64]
-        red[zt * G24_CO + zc] = bsum;
+        float *red = smem;                        // [8][CO]
+        if (zrole) red[zt * G24_CO + zc] = bsum;
         __syncthreads();
         if (tid < G24_CO) {
             float t = 0.f;
@@ -214,7 +216,9 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
 
 int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st) {
     // x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; dout / gmask = [B][HoG = 2H][WoG = 2W][Cout]; Ho, Wo = H, W
-    RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN && d.stride == 1 && d.C0 % G24_CI == 0);
+    const bool wci = d.Cout % 64 != 0;           // 32-output-channel layers: 64 x 32 channels per workgroup
+    const int G24_CI = wci ? 64 : 32, G24_CO = wci ? 32 : 64;
+    RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN && d.stride == 1 && d.C0 % G24_CI == 0 && d.Cout % 32 == 0);
     RAMNET_CHECK_ARG(d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoG == 2 * d.Ho && d.WoG == 2 * d.Wo && d.Ho >= 2 && d.Wo >= 2);
     Wgrad24Params q;
     q.x = d.x0, q.g = d.dout, q.gm = d.gmask, q.dw = d.dw, q.dbias = d.dbias;
@@ -227,14 +231,15 @@ int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st) {
     int splits = (se ? atoi(se) : 256) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
-    const size_t lds = (size_t)(2 * G24_V + 2 * G24_Z) * sizeof(float);
+    const size_t lds = (size_t)2 * 25 * G24_T * (32 + 64) * sizeof(float);
     const dim3 grid(splits, gy, gz);
     auto go = [&](auto kern) -> int {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, q);
         return 0;
     };
-    const int rc = d.gmask ? go(conv_wgrad_wino24_kernel<true>) : go(conv_wgrad_wino24_kernel<false>);
+    const int rc = wci ? (d.gmask ? go(conv_wgrad_wino24_kernel<true, true>) : go(conv_wgrad_wino24_kernel<false, true>))
+                       : (d.gmask ? go(conv_wgrad_wino24_kernel<true, false>) : go(conv_wgrad_wino24_kernel<false, false>));
     if (rc) return rc;
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -59,8 +59,8 @@ _FOLD_WINO_WGRAD = _os.environ.get("RAMNET_FOLD_WINOGRAD_WGRAD", "1") == "1"
 
 
 def set_fold_winograd_wgrad(on):
-    """Folded upsample-conv backward-weights in the Winograd F(2x2,4x4) domain (Cin % 32 == 0, Cout % 64 == 0) or as four direct
-    16-tap parity launches."""
+    """Folded upsample-conv backward-weights in the Winograd F(2x2,4x4) domain (32 x 64 or 64 x 32 channel workgroups) or as four
+    direct 16-tap parity launches."""
     global _FOLD_WINO_WGRAD
     _FOLD_WINO_WGRAD = bool(on)
 
@@ -777,7 +777,8 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp):
     w4, wr, wc, bws = cp.grad_ws_fold()
     xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
     H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
-    if _FOLD_WINO_WGRAD and _PRECISION == H.PREC_F32 and Cc % 32 == 0 and cp.Cout % 64 == 0 and Cc == cp.CinWs:
+    if _FOLD_WINO_WGRAD and _PRECISION == H.PREC_F32 and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
+                                                                             (Cc % 64 == 0 and cp.Cout % 32 == 0)):
         # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
         wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, 0, 0), dy, cp.grad_ws_fold24(), cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
                    gview=(0, 0, 0, 0, H2, W2), wino24=True)
