@@ -56,6 +56,7 @@ _FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
 _FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
 _FOLD_WINO_MIN_COUT = int(_os.environ.get("RAMNET_FOLD_WINOGRAD_MIN_COUT", "32"))
 _FOLD_WINO_WGRAD = _os.environ.get("RAMNET_FOLD_WINOGRAD_WGRAD", "1") == "1"
+_SAVE_XPAD = _os.environ.get("RAMNET_SAVE_XPAD", "0") == "1"      # keep pad2(x + skip) of a folded decoder layer for its backward (+2 GB, no measurable gain: off)
 
 
 def set_fold_winograd_wgrad(on):
@@ -712,9 +713,10 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     if _FOLD_WINO and _fold_wino_ok(Cc, cp.Cout):   # Winograd F(2x2,4x4) over the four parities
         conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
-        return
+        return xpad
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
                       [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)], **desc_kw)
+    return xpad
 
 
 # Stride-2 5x5 layers (the encoders) as 3x3 stride-1 convolutions of the space-to-depth input on the Winograd kernels
@@ -765,7 +767,7 @@ def _fold_eligible(x, cp, k, stride, up):
                 and x.shape[3] == cp.Cin)
 
 
-def _folded_upsample_wgrad(x, skip, dy, y, cp):
+def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     """Backward-weights of the folded upsample-conv: each output parity is a 16-tap convolution of pad2(x + skip), so its weight
     gradient is a 16-tap backward-weights launch on (pad2(x + skip), the parity sub-grid of dy [* ReLU mask]) — 64 instead of
     100 tap-pixels per low-res pixel, plain loads — and the border GEMMs contribute A^T dy_frame; ConvParam._finalize_fold maps
@@ -775,8 +777,9 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp):
     H2, W2 = 2 * Hh, 2 * W
     dev = x.device
     w4, wr, wc, bws = cp.grad_ws_fold()
-    xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
-    H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
+    if xpad is None:            # not kept by forward (RAMNET_SAVE_XPAD=0): recompute pad2(x + skip)
+        xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
+        H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
     if _FOLD_WINO_WGRAD and _PRECISION == H.PREC_F32 and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
                                                                              (Cc % 64 == 0 and cp.Cout % 32 == 0)):
         # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
@@ -814,6 +817,7 @@ class ConvAct(Function):
         y = torch.empty(B, Ho, Wo, cp.Cout, device=x.device)
         mode = (H.IN_UP2X_SKIP if skip is not None else H.IN_UP2X) if up else H.IN_PLAIN
         epi = H.EPI_RELU if relu else H.EPI_LINEAR
+        xpad = None
         ctx.s2d = _s2d_eligible(x, cp, k, stride, up)
         ctx.s2d_fused = ctx.s2d and _s2d_fused(x.shape[3])
         if ctx.s2d_fused:   # ... reading the four parities straight from x
@@ -823,17 +827,17 @@ class ConvAct(Function):
             x = _space_to_depth(x)
             conv_launch(x, Taps.get("conv_s2d", 3, 1), cp.s2d().fwd(), y, cp.Cout, bias=cp.bias(), epi=epi)
         elif _fold_eligible(x, cp, k, stride, up):
-            _folded_upsample_conv(x, skip, cp, y, epi)
+            xpad = _folded_upsample_conv(x, skip, cp, y, epi)      # pad2(x + skip): kept for backward-weights
         else:
             conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
                         Hin=Hin, Win=Win, bias=cp.bias(), epi=epi)
         ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode = cp, stride, relu, up, mode
-        ctx.save_for_backward(x, skip, y)
+        ctx.save_for_backward(x, skip, y, xpad if _SAVE_XPAD else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, skip, y = ctx.saved_tensors
+        x, skip, y, xpad = ctx.saved_tensors
         cp, stride, relu, up, mode = ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode
         dy = dense(dy)
         if ctx.s2d_fused:   # x is the full-resolution input; the kernels address its space-to-depth view
@@ -863,7 +867,7 @@ class ConvAct(Function):
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
         if _fold_eligible(x, cp, k, stride, up):
-            _folded_upsample_wgrad(x, skip, dy, y if relu else None, cp)
+            _folded_upsample_wgrad(x, skip, dy, y if relu else None, cp, xpad)
         else:
             ws, bws = cp.grad_ws(wino_ok=(stride == 1 and k == 3 and pad == 1 and mode == H.IN_PLAIN))
             wgrad_side([x, skip, dy, y], x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
