@@ -144,6 +144,13 @@ int ramnet_pack_weight_split(const float *w_oihw, float *wp, int Cout, int Cin, 
  * (flipped taps, reduce over O); gates=4 (forward only) groups the ConvLSTM gates of 16 hidden channels per block.  */
 size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed, int gates);
 int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, int gates, void *stream);
+/* Folded upsample-conv (RAMNET_ALGO_WINOGRAD24): OIHW 5x5 weights of an UpsampleConvLayer (submodules.py:69-97) -> Winograd-domain
+ * weights of the four 4x4 parity filters in the kernel's layout (see ramnet_algo above); 100*Cout*Cin floats.
+ * ramnet_fold_wino_supported: Cout % 32 == 0 and an even number of input-channel chunks (Cin % 32 == 0, or Cin % 16 == 0 with
+ * 32-channel workgroups).                                                                                     */
+int ramnet_fold_wino_supported(int Cout, int Cin);
+size_t ramnet_packed_weight_elems_fold_wino(int Cout, int Cin);
+int ramnet_pack_weight_fold_wino(const float *w_oihw, float *wp, int Cout, int Cin, void *stream);
 /* Head layers (RAMNET_ALGO_HEAD): OIHW [Cout<=32][Cin][5][5] -> [25*Cin rounded up to even][32], row = tap*Cin + channel.
  * ramnet_head_supported: does the head kernel serve this channel pair (Cin in {1,3,5}, Cout <= 32)?              */
 size_t ramnet_packed_weight_elems_head(int Cin);

@@ -70,6 +70,9 @@ _SIGS = {
     "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
     "ramnet_head_supported": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_pack_weight_head": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    "ramnet_fold_wino_supported": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_packed_weight_elems_fold_wino": (C.c_size_t, [C.c_int, C.c_int]),
+    "ramnet_pack_weight_fold_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "ramnet_pad2_sum": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_up2x_border_im2col": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_space_to_depth2": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -261,6 +261,51 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     W24_STAMP(16, 3);
 }
 
+// OIHW 5x5 weights of an UpsampleConvLayer -> U = G W4 G^T of the four 4x4 parity filters W4 = A_py w A_px^T (the bilinear x2
+// upsample folded into the filter) in the lane order of the kernel's B operand; evaluated in double.
+__global__ void pack_weight_fold_wino_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int kc, int ncq,
+                                             size_t total) {
+    const double FA[2][4][5] = {{{.25, 0, 0, 0, 0}, {.75, .75, .25, 0, 0}, {0, .25, .75, .75, .25}, {0, 0, 0, .25, .75}},
+                                {{.75, .25, 0, 0, 0}, {.25, .75, .75, .25, 0}, {0, 0, .25, .75, .75}, {0, 0, 0, 0, .25}}};
+    const double G[5][4] = {{0.5, 0, 0, 0}, {-0.5, -0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3, 4.0 / 3}, {0, 0, 0, 1}};
+    const int vec = kc / 4, nblk = Cout / (16 * ncq), nch = Cin / kc;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i = ((((cls*nch + chunk)*nblk + nb)*25 + pos)*ncq + cq)*64*vec + (ks*16 + l15)*vec + j
+        size_t r = i;
+        const int j = (int)(r % vec);
+        r /= vec;
+        const int l15 = (int)(r % 16);
+        r /= 16;
+        const int ks = (int)(r % 4);
+        r /= 4;
+        const int cq = (int)(r % ncq);
+        r /= ncq;
+        const int pos = (int)(r % 25);
+        r /= 25;
+        const int nb = (int)(r % nblk);
+        r /= nblk;
+        const int chunk = (int)(r % nch), cls = (int)(r / nch);
+        const int k = chunk * kc + ks * vec + j, n = (nb * ncq + cq) * 16 + l15;
+        const int py = cls >> 1, px = cls & 1, a = pos / 5, b = pos % 5;
+        // U[a][b] = sum_{t,s} G[a][t] G[b][s] sum_{kh,kw} FA[py][t][kh] FA[px][s][kw] w[n][k][kh][kw]
+        double ga[5], gb[5];                        // rows of G^T... combined with the fold: ga[kh] = sum_t G[a][t] FA[py][t][kh]
+        for (int kh = 0; kh < 5; ++kh) {
+            ga[kh] = 0, gb[kh] = 0;
+            for (int t = 0; t < 4; ++t) ga[kh] += G[a][t] * FA[py][t][kh], gb[kh] += G[b][t] * FA[px][t][kh];
+        }
+        double u = 0;
+        const float *wk = w + ((size_t)n * Cin + k) * 25;
+        for (int kh = 0; kh < 5; ++kh)
+            for (int kw = 0; kw < 5; ++kw) u += ga[kh] * gb[kw] * (double)wk[kh * 5 + kw];
+        wp[i] = (float)u;
+    }
+}
+
+static bool fold_wino_geometry(int Cout, int Cin, int &kc, int &ncq) {
+    kc = (Cout % 64 == 0 && Cin % 16 == 0) ? 16 : 8, ncq = kc == 16 ? 4 : 2;
+    return Cout % 32 == 0 && Cin % (2 * kc) == 0;
+}
+
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
     RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
@@ -290,3 +335,23 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
 }
 
 }  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_fold_wino_supported(int Cout, int Cin) {
+    int kc, ncq;
+    return fold_wino_geometry(Cout, Cin, kc, ncq) ? 1 : 0;
+}
+
+extern "C" size_t ramnet_packed_weight_elems_fold_wino(int Cout, int Cin) { return (size_t)100 * Cout * Cin; }
+
+extern "C" int ramnet_pack_weight_fold_wino(const float *w, float *wp, int Cout, int Cin, void *stream) {
+    int kc, ncq;
+    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && fold_wino_geometry(Cout, Cin, kc, ncq));
+    const size_t total = (size_t)100 * Cout * Cin;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weight_fold_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, kc, ncq, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}

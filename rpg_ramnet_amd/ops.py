@@ -523,7 +523,10 @@ class ConvParam:
         v = (self._versions(self.weights), "fold24")
         hit = self._packs.get("fold24")
         if hit is None or hit[0] != v:
-            hit = self._packs["fold24"] = (v, pack_fold_wino(self._cat_w()))
+            L, w = H.lib(), self._cat_w()
+            out = torch.empty(L.ramnet_packed_weight_elems_fold_wino(self.Cout, self.Cin), device=w.device, dtype=torch.float32)
+            H.check(L.ramnet_pack_weight_fold_wino(_p(w), _p(out), self.Cout, self.Cin, _st()), "ramnet_pack_weight_fold_wino")
+            hit = self._packs["fold24"] = (v, out)
         return hit[1]
 
     def border_weights(self):

@@ -247,3 +247,63 @@ def test_head_layer_through_raw_descriptors(cin, cpad):
     assert L.ramnet_unpack_wgrad(ptr(ws), ptr(grad), Cout, cin, cpad, Cout, 0, 5, 5, st) == 0      # same layout as the generic kernel
     assert float((grad.cpu() - wr.grad).abs().max() / wr.grad.abs().max()) < 1e-4
     assert float((dbias.cpu() - br.grad).abs().max() / br.grad.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("Cin,Cout", [(64, 64), (64, 32)])
+def test_folded_upsample_conv_winograd_through_raw_descriptors(Cin, Cout):
+    """RAMNET_ALGO_WINOGRAD24 with raw descriptors: forward of conv5x5(bilinear_x2(x)) away from the border (the border
+    corrections are a separate GEMM, `frame`), and the Winograd-domain backward-weights, against torch in float64; the C pack
+    function against the documented layout (ops.pack_fold_wino)."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    L, st = _hip.lib(), None
+    dev = torch.device("cuda:0")
+    torch.manual_seed(13)
+    B, H, W = 2, 9, 14
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, Cin, 5, 5, device=dev) * 0.1
+    b = torch.randn(Cout, device=dev) * 0.1
+    assert L.ramnet_fold_wino_supported(Cout, Cin) == 1 and L.ramnet_fold_wino_supported(48, Cin) == 0
+    wp = torch.empty(L.ramnet_packed_weight_elems_fold_wino(Cout, Cin), device=dev)
+    assert L.ramnet_pack_weight_fold_wino(ptr(w), ptr(wp), Cout, Cin, st) == 0
+    assert float((wp - ops.pack_fold_wino(w)).abs().max()) < 1e-6
+    xpad = torch.empty(B, H + 4, W + 4, Cin, device=dev)
+    assert L.ramnet_pad2_sum(ptr(x), None, ptr(xpad), B, H, W, Cin, st) == 0
+    y = torch.zeros(B, 2 * H, 2 * W, Cout, device=dev)
+    d = _hip.ConvDesc()
+    d.x0, d.ld0, d.C0, d.in_mode = ptr(xpad), Cin, Cin, _hip.IN_PLAIN
+    d.B, d.Hin, d.Win, d.stride, d.ntaps = B, H + 4, W + 4, 1, 16
+    d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
+    d.Ho, d.Wo, d.HoF, d.WoF = H, W, 2 * H, 2 * W
+    d.osy, d.osx = 1, 1
+    d.epi, d.out, d.ldo, d.precision, d.algo = _hip.EPI_LINEAR, ptr(y), Cout, _hip.PREC_F32, _hip.ALGO_WINOGRAD24
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    xr = x.permute(0, 3, 1, 2).cpu().double()
+    wr, br = w.cpu().double(), b.cpu().double()
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False), wr, br, 1, 2)
+    got = y.permute(0, 3, 1, 2).cpu().double()
+    assert float((got - ref)[:, :, 2:-2, 2:-2].abs().max() / ref.abs().max()) < 2e-5          # the frame needs the border GEMMs
+    d.Cout = 48                                                                                # unsupported channel count
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+
+    # backward-weights: dU -> dW4 = G^T dU G must equal the gradient of the four 4x4 parity filters
+    dy = torch.randn(B, 2 * H, 2 * W, Cout, device=dev)
+    ws, dbias = torch.zeros(4 * 25 * Cin * Cout, device=dev), torch.zeros(Cout, device=dev)
+    g = _hip.WgradDesc()
+    g.x0, g.ld0, g.C0, g.in_mode = ptr(xpad), Cin, Cin, _hip.IN_PLAIN
+    g.B, g.Hin, g.Win, g.ntaps, g.stride = B, H + 4, W + 4, 16, 1
+    g.dout, g.ldg, g.Cout, g.Ho, g.Wo, g.HoG, g.WoG = ptr(dy), Cout, Cout, H, W, 2 * H, 2 * W
+    g.dw, g.dbias, g.algo = ptr(ws), ptr(dbias), _hip.ALGO_WINOGRAD24
+    assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
+    G = torch.tensor(ops.W24_G, dtype=torch.float64)
+    d4 = torch.einsum("at,bs,pqabio->pqtsio", G, G, ws.view(2, 2, 5, 5, Cin, Cout).cpu().double())
+    xp = xpad.permute(0, 3, 1, 2).cpu().double()
+    dyr = dy.permute(0, 3, 1, 2).cpu().double()
+    for py in range(2):
+        for px in range(2):
+            w4 = torch.zeros(Cout, Cin, 4, 4, dtype=torch.float64, requires_grad=True)
+            out = F.conv2d(xp[:, :, py:py + H + 3, px:px + W + 3], w4)                         # [B][Cout][H][W]
+            (out * dyr[:, :, py::2, px::2]).sum().backward()
+            got4 = d4[py, px].permute(3, 2, 0, 1)                                              # [co][ci][t][s]
+            assert float((got4 - w4.grad).abs().max() / w4.grad.abs().max()) < 2e-5
+    assert float((dbias.cpu().double() - dyr.sum((0, 2, 3))).abs().max() / dyr.sum((0, 2, 3)).abs().max()) < 2e-5
