@@ -32,10 +32,14 @@ enum ramnet_in_mode {
     RAMNET_IN_UP2X = 3,      /* bilinear x2 (align_corners=False) of x0          submodules.py:88   */
     RAMNET_IN_UP2X_SKIP = 4, /* bilinear x2 of (x0 + x1)       decoder skip sum  statenet.py:305-308 */
     RAMNET_IN_RELUMASK = 5,  /* x0 * (xm > 0)                  backward through a ReLU             */
-    RAMNET_IN_S2D = 6        /* space-to-depth view of x0 [B][2*Hin][2*Win][C0]: logical channel (a*2+c)*C0 + ch of pixel
+    RAMNET_IN_S2D = 6,       /* space-to-depth view of x0 [B][2*Hin][2*Win][C0]: logical channel (a*2+c)*C0 + ch of pixel
                               * (i, j) = x0(2i+a, 2j+c, ch), Cin = 4*C0 — the stride-2 5x5 encoders (submodules.py:22-48) as
                               * 3x3 stride-1 convolutions without materialising the view.  WINOGRAD launches only; C0 a power
                               * of two >= 8                                                       */
+    RAMNET_IN_PARITY4 = 7    /* RAMNET_ALGO_WINOGRAD24 only: backward-data of the folded upsample-conv.  x0 = dy * mask
+                              * [B][Hin = 2H][Win = 2W][C0]; its four parity sub-grids are the reduction blocks (4*C0 channels,
+                              * zero outside); out = gradient of the replicate-padded low-res tensor [B][Ho = H+4][Wo = W+4][Cout],
+                              * w = Winograd weights of the flipped parity filters; C0 % 16 == 0, Cout % 64 == 0                */
 };
 
 /* ---- arithmetic of the MFMA contraction ----------------------------------------------------------
@@ -193,6 +197,11 @@ int ramnet_pad2_sum(const float *x, const float *skip, float *out, int B, int H,
  * rows [2][B*2W][5][C] (top / bottom image row, columns clamped), cols [2][B*2H][5][C] (left / right image column, rows outside
  * the image zero).                                                                                                      */
 int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, float *cols, int B, int H, int W, int C, void *stream);
+/* Backward-data of the folded upsample-conv: adjoint of ramnet_pad2_sum (dx[B][H][W][C] = dxpad summed over the padded pixels that
+ * copy each pixel; also the skip gradient) and adjoint of ramnet_up2x_border_im2col (gradients of the unrolled border lines
+ * rows [2][B*2W][5][C] / cols [2][B*2H][5][C] scattered through the bilinear taps into dx, +=).                                */
+int ramnet_unpad2_fold(const float *dxpad, float *dx, int B, int H, int W, int C, void *stream);
+int ramnet_up2x_border_col2im(const float *rows, const float *cols, float *dx, int B, int H, int W, int C, void *stream);
 /* Outermost two rows / columns of dy (* (mask > 0) when mask != NULL) of a [B, H2, W2, C] tensor, in the layout of the
  * border-correction GEMMs of the folded upsample-conv: rows [2][B*W2][2][C], cols [2][B*H2][2][C].                       */
 int ramnet_frame_gather(const float *dy, const float *mask, float *rows, float *cols, int B, int H2, int W2, int C, void *stream);

@@ -9,7 +9,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet_hip.so")     # (override: A/B builds)
 
-IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D = range(7)
+IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D, IN_PARITY4 = range(8)
 PREC_F32, PREC_BF16X3 = 0, 1
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24 = 0, 1, 2, 3
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
@@ -73,6 +73,8 @@ _SIGS = {
     "ramnet_fold_wino_supported": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_packed_weight_elems_fold_wino": (C.c_size_t, [C.c_int, C.c_int]),
     "ramnet_pack_weight_fold_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    "ramnet_unpad2_fold": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_up2x_border_col2im": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_pad2_sum": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_up2x_border_im2col": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_space_to_depth2": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -50,11 +50,16 @@ struct Wino24Params {
     const float *x;          // replicate-padded low-res input [B][Hp][Wp][Cin]
     const float *wp;         // [4 classes][Cin/16][Cout/64][25][4][64 lanes][4]
     int Hp, Wp, ldx, nchunks, nblk, tiles_x, tiles_y, Hc, Wc;
+    int cpc;                  // backward-data (DG): chunks per parity class = Cout_fwd / chunk size
     unsigned xbytes, wbytes;  // extents of x and wp (buffer addressing: both below 4 GB)
 };
 
 // NCQ = 16-channel groups of output channels per workgroup: 4 (32 tiles, chunks of 16) or 2 (64 tiles, chunks of 8)
-template <int NCQ>
+// DG = backward-data of the folded layer (RAMNET_IN_PARITY4): the input is the full-resolution gradient [B][2*Hc][2*Wc][C]
+// (Hp, Wp = its extent), whose four parity sub-grids are the reduction blocks (class = chunk / cpc: window origin and pixel
+// stride 2, zero outside — a buffer load past the tensor returns 0); the output is the dense (Hc+4) x (Wc+4) grid of the padded
+// low-resolution tensor.
+template <int NCQ, bool DG>
 __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_desc p, const Wino24Params q) {
     constexpr int W24_K = NCQ == 4 ? 16 : 8;          // input channels per chunk
     constexpr int W24_TX = NCQ == 4 ? 4 : 8;          // tile columns per workgroup
@@ -69,8 +74,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
 
     // blockIdx.x = ((tile block * nblk + channel block) * 4 + class): the four parities of a tile block read the same input
     int bid = blockIdx.x;
-    const int cls = bid & 3;
-    bid >>= 2;
+    const int cls = DG ? 0 : bid & 3;
+    if (!DG) bid >>= 2;
     const int nb = bid % q.nblk;
     bid /= q.nblk;
     const int tbx = bid % q.tiles_x;
@@ -85,15 +90,34 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     const int iy0 = 2 * (tby * W24_TY + it / W24_TX) + py, ix0 = 2 * (tbx * W24_TX + it % W24_TX) + px;
     // byte offsets: lane part (image + row, column + channel: one add per load) + scalar part (chunk)
     unsigned rowo[5], colo[5];
+    int cur_cls = -1;
+    auto set_class = [&](int c) {                   // DG: window of parity class c = (c >> 1, c & 1); invalid -> offset past the tensor
+        cur_cls = c;
+        const int cy = c >> 1, cx = c & 1;
+        const int u0 = 2 * (tby * W24_TY + it / W24_TX), v0 = 2 * (tbx * W24_TX + it % W24_TX);
 #pragma unroll
-    for (int r = 0; r < 5; ++r)
-        rowo[r] = 4u * (unsigned)((b * q.Hp + min(iy0 + r, q.Hp - 1)) * q.Wp * q.ldx), colo[r] = 4u * (unsigned)(min(ix0 + r, q.Wp - 1) * q.ldx + ik);
+        for (int r = 0; r < 5; ++r) {
+            const int i = u0 - cy - 3 + r, j = v0 - cx - 3 + r;           // class-grid row / column
+            rowo[r] = (unsigned)i < (unsigned)q.Hc ? 4u * (unsigned)((b * q.Hp + 2 * i + cy) * q.Wp * q.ldx) : 0x40000000u;
+            colo[r] = (unsigned)j < (unsigned)q.Wc ? 4u * (unsigned)((2 * j + cx) * q.ldx + ik) : 0x40000000u;
+        }
+    };
+    if (!DG) {
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+            rowo[r] = 4u * (unsigned)((b * q.Hp + min(iy0 + r, q.Hp - 1)) * q.Wp * q.ldx), colo[r] = 4u * (unsigned)(min(ix0 + r, q.Wp - 1) * q.ldx + ik);
+    }
     const auto xrs = make_rsrc(q.x, q.xbytes);
     // operand reads are VEC floats per lane; the XOR swizzle spreads the 16 tiles of a read over all banks
     const int vdst = NCQ == 4 ? it * 16 + (((ik >> 2) ^ ((it >> 2) & 3)) << 2) + (ik & 3) : it * 8 + (((ik >> 1) ^ ((it >> 3) & 1)) << 1) + (ik & 1);
     float raw[25];
     auto load_raw = [&](int chunk) {
-        const int soff = chunk * (W24_K * 4);           // uniform
+        int soff = chunk * (W24_K * 4);                 // uniform
+        if (DG) {
+            const int c = chunk / q.cpc;
+            if (c != cur_cls) set_class(c);
+            soff = (chunk - c * q.cpc) * (W24_K * 4);
+        }
 #pragma unroll
         for (int r = 0; r < 5; ++r)
 #pragma unroll
@@ -251,6 +275,10 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int oy = oy0 + a2, ox = ox0 + c2;
+                if (DG) {                           // dense output grid, plain store
+                    if (oy < p.Ho && ox < p.Wo) p.out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.ldo + n] = c2 ? y1 : y0;
+                    continue;
+                }
                 if (oy >= q.Hc || ox >= q.Wc) continue;
                 const int oyF = 2 * oy + py, oxF = 2 * ox + px;
                 const size_t pix = ((size_t)b * p.HoF + oyF) * p.WoF + oxF;
@@ -306,7 +334,31 @@ static bool fold_wino_geometry(int Cout, int Cin, int &kc, int &ncq) {
     return Cout % 32 == 0 && Cin % (2 * kc) == 0;
 }
 
+// Backward-data of the folded layer: x0 = g = dy * mask [B][Hin = 2H][Win = 2W][C0 = Cout_fwd], out = gradient of the padded
+// low-res tensor [B][Ho = H+4][Wo = W+4][Cout = Cin_fwd]; w = Winograd weights of the flipped parity filters over 4*C0 reduction
+// channels (ops.pack_fold_wino_dgrad).
+static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
+    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.stride == 1 && d.C0 % 16 == 0 && d.Cout % 64 == 0);
+    RAMNET_CHECK_ARG(d.Hin % 2 == 0 && d.Win % 2 == 0 && d.Ho == d.Hin / 2 + 4 && d.Wo == d.Win / 2 + 4 && d.HoF == d.Ho && d.WoF == d.Wo);
+    RAMNET_CHECK_ARG(d.epi == RAMNET_EPI_LINEAR && !d.bias && d.beta == 0.f && d.frame == 0 && d.out_s2d == 0);
+    Wino24Params q;
+    q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
+    q.cpc = d.C0 / 16, q.nchunks = 4 * q.cpc, q.nblk = d.Cout / 64;
+    q.Hc = d.Hin / 2, q.Wc = d.Win / 2;
+    const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
+    RAMNET_CHECK_ARG(xb < 0x40000000ull && wb < 0x7fffffffull);          // invalid window elements use offsets >= 2^30
+    q.xbytes = (unsigned)xb, q.wbytes = (unsigned)wb;
+    q.tiles_x = cdiv(d.Wo, 2 * 4), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
+    const size_t lds = (size_t)2 * W24_V * sizeof(float);
+    const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk));
+    RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((conv_wino24_kernel<4, true>), grid, dim3(512), lds, st, d, q);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
+    if (d.in_mode == RAMNET_IN_PARITY4) return launch_wino24_dgrad(d, st);
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
     RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
     const bool wide = d.Cout % 64 == 0 && d.C0 % 16 == 0;      // 64-channel workgroups, chunks of 16; else 32 channels, chunks of 8
@@ -316,7 +368,7 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     Wino24Params q;
     q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
     q.nchunks = d.C0 / (wide ? 16 : 8), q.nblk = d.Cout / (wide ? 64 : 32);
-    q.Hc = d.Ho, q.Wc = d.Wo;
+    q.Hc = d.Ho, q.Wc = d.Wo, q.cpc = 1;
     const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
     RAMNET_CHECK_ARG(xb < 0xffffffffull && wb < 0x7fffffffull);
     q.xbytes = (unsigned)xb, q.wbytes = (unsigned)wb;
@@ -324,11 +376,11 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
     if (wide) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(conv_wino24_kernel<4>, grid, dim3(512), lds, st, d, q);
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<4, false>), grid, dim3(512), lds, st, d, q);
     } else {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL(conv_wino24_kernel<2>, grid, dim3(512), lds, st, d, q);
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<2, false>), grid, dim3(512), lds, st, d, q);
     }
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -311,6 +311,69 @@ __global__ void up2x_border_im2col_kernel(const float *__restrict__ x, const flo
     }
 }
 
+// Adjoint of the replicate padding by 2 (ramnet_pad2_sum): dx[b][i][j] = sum of dxpad over the padded pixels that copy (i, j) —
+// the pixel itself and, on the image border, the ring pixels clamped onto it.
+__global__ void unpad2_fold_kernel(const float *__restrict__ dxpad, float *__restrict__ dx, int B, int H, int W, int C) {
+    const int C4 = C / 4, Wp = W + 4;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % C4) * 4;
+        size_t j = idx / C4;
+        const int x = (int)(j % W);
+        j /= W;
+        const int y = (int)(j % H), b = (int)(j / H);
+        const int y0 = y == 0 ? 0 : y + 2, y1 = y == H - 1 ? H + 3 : y + 2;
+        const int x0 = x == 0 ? 0 : x + 2, x1 = x == W - 1 ? W + 3 : x + 2;
+        float4 acc = f4zero();
+        for (int r = y0; r <= y1; ++r)
+            for (int c = x0; c <= x1; ++c) acc = f4add(acc, ld4(dxpad + (((size_t)b * (H + 4) + r) * Wp + c) * C + ch));
+        st4(dx + idx * 4, acc);
+    }
+}
+
+// Adjoint of up2x_border_im2col: the gradients of the unrolled border lines are scattered (atomically) through the bilinear
+// taps of their source pixel into dx [B][H][W][C] (+=).
+__device__ __forceinline__ void up2x_at_adjoint(float *__restrict__ dx, int b, int H, int W, int C, int r, int c, int ch, float4 d) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    up2x_coord(r, H, y0, y1, ly);
+    up2x_coord(c, W, x0, x1, lx);
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const size_t r0 = ((size_t)b * H + y0) * W, r1 = ((size_t)b * H + y1) * W;
+    const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+    const size_t offs[4] = {(r0 + x0) * C + ch, (r0 + x1) * C + ch, (r1 + x0) * C + ch, (r1 + x1) * C + ch};
+    for (int t = 0; t < 4; ++t) {
+        if (wts[t] == 0.f) continue;
+        float *q = dx + offs[t];
+        atomicAdd(q, wts[t] * d.x), atomicAdd(q + 1, wts[t] * d.y), atomicAdd(q + 2, wts[t] * d.z), atomicAdd(q + 3, wts[t] * d.w);
+    }
+}
+
+__global__ void up2x_border_col2im_kernel(const float *__restrict__ rows, const float *__restrict__ cols, float *__restrict__ dx, int B,
+                                          int H, int W, int C) {
+    const int C4 = C / 4, H2 = 2 * H, W2 = 2 * W;
+    const size_t nrows = (size_t)2 * B * W2 * 5 * C4, ncols = (size_t)2 * B * H2 * 5 * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nrows + ncols; i += (size_t)gridDim.x * blockDim.x) {
+        const bool isrow = i < nrows;
+        size_t j = isrow ? i : i - nrows;
+        const int ch = (int)(j % C4) * 4;
+        j /= C4;
+        const int k = (int)(j % 5);
+        j /= 5;
+        const int L = isrow ? W2 : H2;
+        const int o = (int)(j % L);
+        j /= L;
+        const int b = (int)(j % B), side = (int)(j / B);
+        const float4 d = ld4((isrow ? rows : cols) + (isrow ? i : i - nrows) * 4);
+        if (isrow) {
+            up2x_at_adjoint(dx, b, H, W, C, side ? H2 - 1 : 0, min(max(o + k - 2, 0), W2 - 1), ch, d);
+        } else {
+            const int r = o + k - 2;
+            if (r >= 0 && r < H2) up2x_at_adjoint(dx, b, H, W, C, r, side ? W2 - 1 : 0, ch, d);
+        }
+    }
+}
+
 // Outermost two rows / columns of the (ReLU-masked) output gradient in the layout of the border-correction GEMMs:
 // rows [2 sides][B*W2][2 slots][C], cols [2 sides][B*H2][2 slots][C]  (side 0 = top / left, slot = distance into the band).
 __global__ void frame_gather_kernel(const float *__restrict__ dy, const float *__restrict__ mask, float *__restrict__ rows,
@@ -563,6 +626,21 @@ extern "C" int ramnet_up2x_border_im2col(const float *x, const float *skip, floa
     RAMNET_CHECK_ARG(x && rows && cols && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
     const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
     hipLaunchKernelGGL(up2x_border_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, rows, cols, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_unpad2_fold(const float *dxpad, float *dx, int B, int H, int W, int C, void *stream) {
+    RAMNET_CHECK_ARG(dxpad && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    hipLaunchKernelGGL(unpad2_fold_kernel, dim3(grid_for((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dxpad, dx, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_up2x_border_col2im(const float *rows, const float *cols, float *dx, int B, int H, int W, int C, void *stream) {
+    RAMNET_CHECK_ARG(rows && cols && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
+    const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
+    hipLaunchKernelGGL(up2x_border_col2im_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rows, cols, dx, B, H, W, C);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

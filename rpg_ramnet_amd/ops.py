@@ -391,6 +391,16 @@ def pack_fold_wino(w):
     return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)                                       # cls chunk nb pos cq ks l15 j
 
 
+def pack_fold_wino_dgrad(w):
+    """Backward-data of the folded layer on conv_wino24_kernel (RAMNET_IN_PARITY4): Winograd weights of the FLIPPED parity filters
+    with the roles of the channels swapped — reduce over (parity class, output channel), produce input channels."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    G = torch.tensor(W24_G, dtype=torch.float64, device=w.device)
+    u = torch.einsum("at,bs,ncpqts->abpqnc", G, G, fold_weights(w).flip(4, 5)).reshape(1, 25, 4 * Cout, Cin).float()
+    u = u.view(1, 25, 4 * Cout // 16, 4, 4, Cin // 64, 4, 16)                   # cls pos chunk ks j nb cq l15
+    return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)
+
+
 def fold_weights(w):
     """OIHW 5x5 -> [O][I][py][px][ty][tx]: the 4x4 filter of every output parity, W4 = A_py w A_px^T (float64)."""
     A = torch.tensor(FOLD_A, dtype=torch.float64, device=w.device)
@@ -527,6 +537,13 @@ class ConvParam:
             out = torch.empty(L.ramnet_packed_weight_elems_fold_wino(self.Cout, self.Cin), device=w.device, dtype=torch.float32)
             H.check(L.ramnet_pack_weight_fold_wino(_p(w), _p(out), self.Cout, self.Cin, _st()), "ramnet_pack_weight_fold_wino")
             hit = self._packs["fold24"] = (v, out)
+        return hit[1]
+
+    def pack_fold_wino_dgrad(self):
+        v = (self._versions(self.weights), "fold24d")
+        hit = self._packs.get("fold24d")
+        if hit is None or hit[0] != v:
+            hit = self._packs["fold24d"] = (v, pack_fold_wino_dgrad(self._cat_w()))
         return hit[1]
 
     def border_weights(self):
@@ -803,6 +820,44 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     wc.baddbmm_(a_cols.transpose(1, 2), g_cols)
 
 
+# Backward-data of the folded upsample-conv: the adjoint of (four parity convolutions of the replicate-padded input + border GEMMs),
+# i.e. conv_wino24_kernel over the parity sub-grids of dy * mask with the flipped filters -> gradient of the padded tensor ->
+# replicate-padding adjoint, plus the border GEMMs' adjoint scattered through the bilinear taps.  RAMNET_FOLD_DGRAD=0: direct 5x5 kernel on the full-resolution grid + bilinear adjoint.
+_FOLD_DGRAD = _os.environ.get("RAMNET_FOLD_DGRAD", "1") == "1"
+
+
+def set_fold_dgrad(on):
+    global _FOLD_DGRAD
+    _FOLD_DGRAD = bool(on)
+
+
+def _fold_dgrad_ok(B, H2, W2, cp):
+    return bool(_FOLD_DGRAD and _FOLD_UP and _PRECISION == H.PREC_F32 and cp.Cout % 16 == 0 and cp.Cin % 64 == 0
+                and B * H2 * W2 * cp.Cout * 4 < 2 ** 30)
+
+
+def _folded_upsample_dgrad(x, dy, y, cp):
+    L = H.lib()
+    B, Hh, W, Cc = x.shape
+    H2, W2 = 2 * Hh, 2 * W
+    dev = x.device
+    g = dy
+    if y is not None:
+        g = torch.empty_like(dy)
+        H.check(L.ramnet_relu_bwd(_p(dy), _p(y), _p(g), dy.numel(), _st()), "ramnet_relu_bwd")
+    dxpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
+    conv_launch(g, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino_dgrad(), dxpad, Cc, in_mode=H.IN_PARITY4, wino24=True)
+    dx = torch.empty(B, Hh, W, Cc, device=dev)
+    H.check(L.ramnet_unpad2_fold(_p(dxpad), _p(dx), B, Hh, W, Cc, _st()), "ramnet_unpad2_fold")
+    g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
+    g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
+    H.check(L.ramnet_frame_gather(_p(g), None, _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
+    w_rows, w_cols = cp.border_weights()                                         # [2][5*Cin][2*Cout]
+    d_rows, d_cols = torch.bmm(g_rows, w_rows.transpose(1, 2)), torch.bmm(g_cols, w_cols.transpose(1, 2))
+    H.check(L.ramnet_up2x_border_col2im(_p(d_rows), _p(d_cols), _p(dx), B, Hh, W, Cc, _st()), "ramnet_up2x_border_col2im")
+    return dx
+
+
 class ConvAct(Function):
     """ConvLayer / UpsampleConvLayer (submodules.py:8-35, 69-97): [bilinear x2 of (x [+ skip])] -> KxK conv -> bias -> [ReLU]."""
 
@@ -876,6 +931,10 @@ class ConvAct(Function):
             wgrad_side([x, skip, dy, y], x, Taps.get("conv", k, pad), dy, ws, cp.Cout, stride=stride, x1=skip, in_mode=mode,
                        Hin=Hin, Win=Win, gmask=y if relu else None, dbias=bws)
         dx = dskip = None
+        if (ctx.needs_input_grad[0] or (skip is not None and ctx.needs_input_grad[1])) and _fold_eligible(x, cp, k, stride, up) \
+                and _fold_dgrad_ok(B, Hin, Win, cp):
+            dx = _folded_upsample_dgrad(x, dy, y if relu else None, cp)
+            return dx, (dx if skip is not None else None), None, None, None, None, None, None
         if ctx.needs_input_grad[0] or (skip is not None and ctx.needs_input_grad[1]):
             gin = torch.empty(B, Hin, Win, cp.Cin, device=x.device)
             gmode = H.IN_RELUMASK if relu else H.IN_PLAIN

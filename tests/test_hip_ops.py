@@ -94,17 +94,19 @@ def test_head_conv_padded_input(cin):
     assert_close(m.conv2d.bias.grad.cpu().numpy(), b.grad.numpy(), TOL, "head db")
 
 
-@pytest.fixture(params=["folded", "folded_direct", "direct"])
+@pytest.fixture(params=["folded", "folded_dgrad", "folded_direct", "direct"])
 def upsample_algo(request):
     """UpsampleConvLayer forward: four 4x4 parity convolutions of the low-res input — on the Winograd F(2x2,4x4) kernel where
     the channel counts allow (default) or on the direct kernel — and the direct 5x5 kernel with the bilinear loader, all against
     the oracle."""
     from rpg_ramnet_amd import ops
-    old, oldw, oldg = ops.get_fold_upsample(), ops._FOLD_WINO, ops._FOLD_WINO_WGRAD
+    old, oldw, oldg, oldd = ops.get_fold_upsample(), ops._FOLD_WINO, ops._FOLD_WINO_WGRAD, ops._FOLD_DGRAD
     ops.set_fold_upsample(request.param != "direct")
-    ops.set_fold_winograd(request.param == "folded")
-    ops.set_fold_winograd_wgrad(request.param == "folded")
+    ops.set_fold_winograd(request.param in ("folded", "folded_dgrad"))
+    ops.set_fold_winograd_wgrad(request.param in ("folded", "folded_dgrad"))
+    ops.set_fold_dgrad(request.param == "folded_dgrad")           # backward-data through the folded operator's adjoint
     yield request.param
+    ops.set_fold_dgrad(oldd)
     ops.set_fold_upsample(old)
     ops.set_fold_winograd(oldw)
     ops.set_fold_winograd_wgrad(oldg)
