@@ -199,7 +199,7 @@ int ramnet_pad2_sum(const float *x, const float *skip, float *out, int B, int H,
 int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, float *cols, int B, int H, int W, int C, void *stream);
 /* Backward-data of the folded upsample-conv: adjoint of ramnet_pad2_sum (dx[B][H][W][C] = dxpad summed over the padded pixels that
  * copy each pixel; also the skip gradient) and adjoint of ramnet_up2x_border_im2col (gradients of the unrolled border lines
- * rows [2][B*2W][5][C] / cols [2][B*2H][5][C] scattered through the bilinear taps into dx, +=).                                */
+ * rows [2][B*2W][5][C] / cols [2][B*2H][5][C] gathered by the border pixels of dx through their bilinear weights, +=).                                */
 int ramnet_unpad2_fold(const float *dxpad, float *dx, int B, int H, int W, int C, void *stream);
 int ramnet_up2x_border_col2im(const float *rows, const float *cols, float *dx, int B, int H, int W, int C, void *stream);
 /* Outermost two rows / columns of dy (* (mask > 0) when mask != NULL) of a [B, H2, W2, C] tensor, in the layout of the

@@ -331,46 +331,46 @@ __global__ void unpad2_fold_kernel(const float *__restrict__ dxpad, float *__res
     }
 }
 
-// Adjoint of up2x_border_im2col: the gradients of the unrolled border lines are scattered (atomically) through the bilinear
-// taps of their source pixel into dx [B][H][W][C] (+=).
-__device__ __forceinline__ void up2x_at_adjoint(float *__restrict__ dx, int b, int H, int W, int C, int r, int c, int ch, float4 d) {
-    int y0, y1, x0, x1;
-    float ly, lx;
-    up2x_coord(r, H, y0, y1, ly);
-    up2x_coord(c, W, x0, x1, lx);
-    const float hy = 1.0f - ly, hx = 1.0f - lx;
-    const size_t r0 = ((size_t)b * H + y0) * W, r1 = ((size_t)b * H + y1) * W;
-    const float wts[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
-    const size_t offs[4] = {(r0 + x0) * C + ch, (r0 + x1) * C + ch, (r1 + x0) * C + ch, (r1 + x1) * C + ch};
-    for (int t = 0; t < 4; ++t) {
-        if (wts[t] == 0.f) continue;
-        float *q = dx + offs[t];
-        atomicAdd(q, wts[t] * d.x), atomicAdd(q + 1, wts[t] * d.y), atomicAdd(q + 2, wts[t] * d.z), atomicAdd(q + 3, wts[t] * d.w);
-    }
-}
-
+// Adjoint of up2x_border_im2col as a gather: every border pixel of dx [B][H][W][C] collects (+=) the gradients of the unrolled
+// border lines whose bilinear source it is.  Line position cu of a side sums S[cu] = the entries (o, k) with clamp(o + k - 2)
+// = cu (rows: clamped like the forward) or o + k - 2 = cu (columns: zero outside); pixel j takes S[cu] * its bilinear weight for
+// the (at most four) positions cu = 2j-1 .. 2j+2.  `part` 0 = the two border rows, 1 = the two border columns (two launches:
+// the corner pixels belong to both).
 __global__ void up2x_border_col2im_kernel(const float *__restrict__ rows, const float *__restrict__ cols, float *__restrict__ dx, int B,
-                                          int H, int W, int C) {
+                                          int H, int W, int C, int part) {
     const int C4 = C / 4, H2 = 2 * H, W2 = 2 * W;
-    const size_t nrows = (size_t)2 * B * W2 * 5 * C4, ncols = (size_t)2 * B * H2 * 5 * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nrows + ncols; i += (size_t)gridDim.x * blockDim.x) {
-        const bool isrow = i < nrows;
-        size_t j = isrow ? i : i - nrows;
-        const int ch = (int)(j % C4) * 4;
-        j /= C4;
-        const int k = (int)(j % 5);
-        j /= 5;
-        const int L = isrow ? W2 : H2;
-        const int o = (int)(j % L);
-        j /= L;
-        const int b = (int)(j % B), side = (int)(j / B);
-        const float4 d = ld4((isrow ? rows : cols) + (isrow ? i : i - nrows) * 4);
-        if (isrow) {
-            up2x_at_adjoint(dx, b, H, W, C, side ? H2 - 1 : 0, min(max(o + k - 2, 0), W2 - 1), ch, d);
-        } else {
-            const int r = o + k - 2;
-            if (r >= 0 && r < H2) up2x_at_adjoint(dx, b, H, W, C, r, side ? W2 - 1 : 0, ch, d);
+    const int L = part ? H : W, L2 = 2 * L;                  // pixels / line positions along the border line
+    const float *src = part ? cols : rows;
+    const size_t total = (size_t)2 * B * L * C4;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % C4) * 4;
+        size_t t = idx / C4;
+        const int j = (int)(t % L);
+        t /= L;
+        const int b = (int)(t % B), side = (int)(t / B);
+        const float *line = src + ((size_t)(side * B + b) * L2) * 5 * C + ch;        // [L2][5][C]
+        float4 acc = f4zero();
+        for (int cu = max(2 * j - 1, 0); cu <= min(2 * j + 2, L2 - 1); ++cu) {
+            int p0, p1;
+            float l1;
+            up2x_coord(cu, L, p0, p1, l1);
+            const float wgt = (p0 == j ? 1.0f - l1 : 0.0f) + (p1 == j ? l1 : 0.0f);
+            if (wgt == 0.0f) continue;
+            float4 sum = f4zero();
+            for (int k = 0; k < 5; ++k) {
+                int olo = cu + 2 - k, ohi = olo;
+                if (!part) {                                  // rows: positions left of 0 / right of L2-1 are clamped onto them
+                    if (cu == 0) olo = 0;
+                    if (cu == L2 - 1) ohi = L2 - 1;
+                }
+                olo = max(olo, 0), ohi = min(ohi, L2 - 1);
+                for (int o = olo; o <= ohi; ++o) sum = f4add(sum, ld4(line + ((size_t)o * 5 + k) * C));
+            }
+            acc = f4add(acc, f4scale(sum, wgt));
         }
+        const int y = part ? j : (side ? H - 1 : 0), x = part ? (side ? W - 1 : 0) : j;
+        float *dst = dx + (((size_t)b * H + y) * W + x) * C + ch;
+        st4(dst, f4add(ld4(dst), acc));
     }
 }
 
@@ -639,8 +639,9 @@ extern "C" int ramnet_unpad2_fold(const float *dxpad, float *dx, int B, int H, i
 
 extern "C" int ramnet_up2x_border_col2im(const float *rows, const float *cols, float *dx, int B, int H, int W, int C, void *stream) {
     RAMNET_CHECK_ARG(rows && cols && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0);
-    const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
-    hipLaunchKernelGGL(up2x_border_col2im_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rows, cols, dx, B, H, W, C);
+    for (int part = 0; part < 2; ++part)
+        hipLaunchKernelGGL(up2x_border_col2im_kernel, dim3(grid_for((size_t)2 * B * (part ? H : W) * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                           rows, cols, dx, B, H, W, C, part);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
