@@ -93,6 +93,8 @@ def main():
             else:
                 f = lambda: ops.conv_launch(x, taps, cp.fwd(), y, cout, x1=s, in_mode=H.IN_UP2X_SKIP, Hin=Hin, Win=Win, bias=b, epi=H.EPI_RELU)  # noqa: E731
             d = lambda: ops.conv_launch(dy, tapsd, cp.bwd(), dx, cin, xm=y, in_mode=H.IN_RELUMASK)  # noqa: E731
+            if ops.get_fold_upsample() and ops._fold_dgrad_ok(B, Hin, Win, cp):     # adjoint of the folded operator (incl. un-pad fold, border adjoint)
+                d = lambda: ops._folded_upsample_dgrad(x, dy, y, cp)  # noqa: E731
             if ops.get_fold_upsample():
                 g = lambda: ops._folded_upsample_wgrad(x, s, dy, y, cp)  # noqa: E731
             else:
