@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace ramnet {
 
-constexpr int W24_TY = 8;                         // tile rows per workgroup (2x2 outputs each)
+// tiles per workgroup (2x2 outputs each): 8 x 4 or 4 x 8 (rows x columns, TXW = columns) for 32 tiles, 8 x 8 for 64
 constexpr int W24_PS = 512;                       // floats per position in V: tiles x chunk channels (32 x 16 or 64 x 8)
 constexpr int W24_V = 25 * W24_PS;                // floats per V buffer (51.2 KB)
 
@@ -59,10 +59,10 @@ struct Wino24Params {
 // (Hp, Wp = its extent), whose four parity sub-grids are the reduction blocks (class = chunk / cpc: window origin and pixel
 // stride 2, zero outside — a buffer load past the tensor returns 0); the output is the dense (Hc+4) x (Wc+4) grid of the padded
 // low-resolution tensor.
-template <int NCQ, bool DG>
+template <int NCQ, bool DG, int TXW>
 __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_desc p, const Wino24Params q) {
     constexpr int W24_K = NCQ == 4 ? 16 : 8;          // input channels per chunk
-    constexpr int W24_TX = NCQ == 4 ? 4 : 8;          // tile columns per workgroup
+    constexpr int W24_TX = TXW, W24_TY = (NCQ == 4 ? 32 : 64) / TXW;      // tile columns / rows per workgroup
     constexpr int VEC = W24_K / 4;                    // floats per lane and operand read (k = VEC*ks + j)
     constexpr int W24_U = 25 * NCQ * 64 * VEC;        // packed weights of one (class, chunk, channel block)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -348,11 +348,18 @@ static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
     const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
     RAMNET_CHECK_ARG(xb < 0x40000000ull && wb < 0x7fffffffull);          // invalid window elements use offsets >= 2^30
     q.xbytes = (unsigned)xb, q.wbytes = (unsigned)wb;
-    q.tiles_x = cdiv(d.Wo, 2 * 4), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
+    // 16 x 8 or 8 x 16 output pixels per workgroup: whichever covers the grid with fewer workgroups
+    const bool flat = cdiv(d.Wo, 16) * cdiv(d.Ho, 8) < cdiv(d.Wo, 8) * cdiv(d.Ho, 16);
+    q.tiles_x = cdiv(d.Wo, flat ? 16 : 8), q.tiles_y = cdiv(d.Ho, flat ? 8 : 16);
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk));
-    RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL((conv_wino24_kernel<4, true>), grid, dim3(512), lds, st, d, q);
+    if (flat) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<4, true, 8>), grid, dim3(512), lds, st, d, q);
+    } else {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<4, true, 4>), grid, dim3(512), lds, st, d, q);
+    }
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
@@ -372,15 +379,19 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
     RAMNET_CHECK_ARG(xb < 0xffffffffull && wb < 0x7fffffffull);
     q.xbytes = (unsigned)xb, q.wbytes = (unsigned)wb;
-    q.tiles_x = cdiv(d.Wo, 2 * (wide ? 4 : 8)), q.tiles_y = cdiv(d.Ho, 2 * W24_TY);
+    const bool flat = wide && cdiv(d.Wo, 16) * cdiv(d.Ho, 8) < cdiv(d.Wo, 8) * cdiv(d.Ho, 16);      // 8 x 16 instead of 16 x 8 pixels
+    q.tiles_x = cdiv(d.Wo, wide && !flat ? 8 : 16), q.tiles_y = cdiv(d.Ho, flat ? 8 : 16);
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
-    if (wide) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((conv_wino24_kernel<4, false>), grid, dim3(512), lds, st, d, q);
+    if (wide && flat) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<4, false, 8>), grid, dim3(512), lds, st, d, q);
+    } else if (wide) {
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<4, false, 4>), grid, dim3(512), lds, st, d, q);
     } else {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((conv_wino24_kernel<2, false>), grid, dim3(512), lds, st, d, q);
+        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<2, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((conv_wino24_kernel<2, false, 8>), grid, dim3(512), lds, st, d, q);
     }
     RAMNET_LAUNCH_CHECK();
     return 0;
