@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 10
+#define RAMNET_ABI_VERSION 11
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -42,12 +42,8 @@ enum ramnet_in_mode {
                               * w = Winograd weights of the flipped parity filters; C0 % 16 == 0, Cout % 64 == 0                */
 };
 
-/* ---- arithmetic of the MFMA contraction ----------------------------------------------------------
- * F32:    v_mfma_f32_32x32x2_f32, bit-exact fp32 (157 TFLOP/s peak).
- * BF16X3: every fp32 operand x is split on the fly into bf16 hi + lo (hi+lo = x to ~2^-17) and a*b is evaluated as
- *         hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error ~1e-5 per
- *         product (vs 4e-3 for plain bf16), 3 MFMAs at 16x the fp32 rate.  Inputs/outputs stay fp32 in HBM.    */
-enum ramnet_precision { RAMNET_PREC_F32 = 0, RAMNET_PREC_BF16X3 = 1 };
+/* ---- arithmetic of the MFMA contraction: exact fp32 on v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (bit-identical to
+ * an fmaf chain, 157 TFLOP/s peak).  There is no reduced-precision mode. */
 /* RAMNET_ALGO_WINOGRAD: F(2x2,3x3), fp32; only the dense 3x3 stride-1 tap list, w from ramnet_pack_weight_wino() */
 /* RAMNET_ALGO_HEAD: the 5x5 stride-1 head layers with 1, 3 or 5 real input channels and <= 32 outputs (statenet.py:160-175):
  * dense (tap, channel) reduction, weights from ramnet_pack_weight_head() held in registers; fp32 */
@@ -95,8 +91,7 @@ typedef struct ramnet_conv_desc {
     int lde0, lde1;
     float *out, *o1, *o2;
     int ldo, ldo1, ldo2;
-    int precision;                  /* RAMNET_PREC_F32 (exact fp32 MFMA) or RAMNET_PREC_BF16X3 (w packed with split=1) */
-    int algo;                       /* RAMNET_ALGO_DIRECT, RAMNET_ALGO_WINOGRAD or RAMNET_ALGO_HEAD (the latter two F32 only)   */
+    int algo;                       /* RAMNET_ALGO_DIRECT, RAMNET_ALGO_WINOGRAD or RAMNET_ALGO_HEAD    */
     int frame;                      /* > 0 (folded upsample-conv, LINEAR / RELU epilogues): border corrections are added to the
                                      * pre-activation of the outermost `frame` (= 2) rows / columns of the FULL output:
                                      * rows from e1 [2 sides][B][WoF][lde1 = frame*Cout], columns from e0 [2][B][HoF][lde0]  */
@@ -139,10 +134,6 @@ int ramnet_abi_version(void);
 int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream);
 /* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
 size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
-/* Same for the BF16X3 layout [tap][chunk32][hi|lo][n][32 bf16] (result in floats = bytes/4).       */
-size_t ramnet_packed_weight_elems_split(int Cout, int Cin, int KH, int KW, int transposed, int gates);
-int ramnet_pack_weight_split(const float *w_oihw, float *wp, int Cout, int Cin, int KH, int KW,
-                             int transposed, int gates, void *stream);
 /* Winograd F(2x2,3x3) weights U = G g G^T of a 3x3 conv in the lane order of the kernel's B operand
  * ([Cin/8][Cout/64][8 position pairs][64][4][2][2], zero padded).  transposed=1 packs the backward-data operator
  * (flipped taps, reduce over O); gates=4 (forward only) groups the ConvLSTM gates of 16 hidden channels per block.  */
@@ -235,10 +226,12 @@ int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float w
                        const double *stats, const float *gscale, float *dpred, void *stream);
 
 /* ---- depth post-processing + error sums: evaluation.py:74-96, :201-241; model/metric.py:8-33 --------------
- * pred/target: normalised log depth.  out10 (zeroed here): n, sum abs-rel, sum sq-rel, sum sq err, sum log-err^2,
- * sum log-err, sum abs err, count(delta < 1.25), (< 1.25^2), (< 1.25^3) over valid targets with metric depth <= cutoff. */
+ * pred/target: normalised log depth; mask = nan_to_num(metric target) < cutoff (evaluation.py:367).  out11 (zeroed here):
+ * n (non-NaN targets in the mask), n_mask, and over those n pixels: sum |d|/(t+1e-6), sum d^2/(t^2+1e-6), sum d^2,
+ * sum ld^2, sum |ld| (ld = log(t+1e-5) - log(p+1e-5)), sum |d|, count(ratio <= 1.25), (<= 1.25^2), (<= 1.25^3) with
+ * ratio = max(t/(p+1e-5), p/(t+1e-5)).                                                                          */
 int ramnet_depth_metrics(const float *pred, const float *target, size_t n, float clip_distance, float reg_factor,
-                         float cutoff, double *out10, void *stream);
+                         float cutoff, double *out11, void *stream);
 
 /* ---- multi-scale gradient loss: model/loss.py:22-70 (kornia Sobel restated; PARITY UNPINNED) -------
  * ws / dws: float workspaces of ramnet_msg_workspace_elems() elements; stats: 2*num_scales doubles.          */

@@ -10,7 +10,6 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet_hip.so")     # (override: A/B builds)
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D, IN_PARITY4 = range(8)
-PREC_F32, PREC_BF16X3 = 0, 1
 ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24 = 0, 1, 2, 3
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
 
@@ -32,7 +31,6 @@ class ConvDesc(C.Structure):
         ("e0", _fp), ("e1", _fp), ("lde0", C.c_int), ("lde1", C.c_int),
         ("out", _fp), ("o1", _fp), ("o2", _fp),
         ("ldo", C.c_int), ("ldo1", C.c_int), ("ldo2", C.c_int),
-        ("precision", C.c_int),
         ("algo", C.c_int),
         ("frame", C.c_int),
         ("out_s2d", C.c_int),
@@ -63,8 +61,6 @@ _SIGS = {
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
-    "ramnet_packed_weight_elems_split": (C.c_size_t, [C.c_int] * 6),
-    "ramnet_pack_weight_split": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 4),
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
@@ -130,7 +126,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 10:
+        if l.ramnet_abi_version() != 11:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib

@@ -1,39 +1,63 @@
-"""Build librpg_ramnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build librpg_ramnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every csrc/*.hip is compiled to its own object (in parallel, only when it or a header changed) and the objects are linked
+into one shared library with a plain C ABI (include/ramnet_hip.h) and no torch dependency."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["conv_igemm.hip", "conv_wino.hip", "conv_wgrad.hip", "conv_wgrad_wino.hip", "conv_head.hip", "conv_wino24.hip", "conv_wgrad_wino24.hip", "pointwise.hip", "loss_voxel.hip"]
+OBJ = os.path.join(PKG, "build")
+HEADER = os.path.join(PKG, "..", "include", "ramnet_hip.h")
 LIB = os.path.join(PKG, "librpg_ramnet_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "ramnet_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library (C ABI, no torch dependency)."""
-    if not force and not _stale():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [HEADER]
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(hipcc, src, obj, verbose):
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building %s" % LIB)
-    if verbose:
-        sys.stderr.write(r.stderr)
+    return src, r
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source and link the shared library; returns its path."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    hm = _headers_mtime()
+    jobs, objs = [], []
+    for f in sources():
+        src, obj = os.path.join(CSRC, f), os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+            jobs.append((src, obj))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for src, r in ex.map(lambda j: _compile(hipcc, j[0], j[1], verbose), jobs):
+                if r.returncode != 0:
+                    sys.stderr.write(r.stdout + r.stderr)
+                    raise RuntimeError("hipcc failed on %s" % src)
+                if verbose:
+                    sys.stderr.write(r.stderr)
+    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed linking %s" % LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose="-v" in sys.argv))
+    print(build(force="-f" in sys.argv, verbose="-v" in sys.argv))

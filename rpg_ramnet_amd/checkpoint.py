@@ -5,7 +5,9 @@
 so that checkpoints written here load in the reference's `test.py` / `--resume`, and the released checkpoints
 (`ramnet_sim.pth.tar`, README.md:59) load here.  Reference files pickle a `logger.logger.Logger` instance under
 'logger'; that module is not importable outside the reference tree, so loading installs a structural stand-in
-(same attribute: `entries`) for the duration of `torch.load`.
+(same attribute: `entries`) for the duration of `torch.load` — and `save_checkpoint` pickles its own logger under that
+same module path (`logger.logger.Logger`), so a file written here unpickles inside the reference tree with the reference's
+own class and WITHOUT `rpg_ramnet_amd` on `sys.path`.
 """
 import os
 import sys
@@ -28,6 +30,29 @@ class Logger:
         return json.dumps(self.entries, sort_keys=True, indent=4)
 
 
+Logger.__module__ = 'logger.logger'     # pickled under the reference's module path (RAM_Net/logger/logger.py)
+
+
+class _LoggerModules:
+    """Make `logger.logger.Logger` resolvable while pickling / unpickling outside the reference tree."""
+
+    def __enter__(self):
+        self.injected = []
+        if 'logger' not in sys.modules:
+            pkg = types.ModuleType('logger')
+            sub = types.ModuleType('logger.logger')
+            sub.Logger = Logger
+            pkg.Logger = Logger
+            pkg.logger = sub
+            sys.modules['logger'], sys.modules['logger.logger'] = pkg, sub
+            self.injected = ['logger', 'logger.logger']
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.injected:
+            sys.modules.pop(m, None)
+
+
 def checkpoint_name(save_dir, epoch, loss):
     """base_trainer.py:151-152 naming."""
     return os.path.join(save_dir, 'checkpoint-epoch{:03d}-loss-{:.4f}.pth.tar'.format(epoch, loss))
@@ -43,26 +68,15 @@ def save_checkpoint(path, model, optimizer, epoch, config, monitor_best=float('i
         'monitor_best': monitor_best,
         'config': config,
     }
-    torch.save(state, path)
+    with _LoggerModules():
+        torch.save(state, path)
     return path
 
 
 def load_checkpoint(path, map_location='cpu'):
     """torch.load of a reference-layout checkpoint (needs weights_only=False: the file pickles Python objects)."""
-    injected = []
-    if 'logger' not in sys.modules:
-        pkg = types.ModuleType('logger')
-        sub = types.ModuleType('logger.logger')
-        sub.Logger = Logger
-        pkg.Logger = Logger
-        pkg.logger = sub
-        sys.modules['logger'], sys.modules['logger.logger'] = pkg, sub
-        injected = ['logger', 'logger.logger']
-    try:
+    with _LoggerModules():
         return torch.load(path, map_location=map_location, weights_only=False)
-    finally:
-        for m in injected:
-            sys.modules.pop(m, None)
 
 
 def resume(path, model, optimizer=None, map_location='cpu'):

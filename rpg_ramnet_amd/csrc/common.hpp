@@ -101,54 +101,21 @@ __device__ __forceinline__ float4 load_in4(const InSrc &s, int b, int iy, int ix
     return v;
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// fp32 -> (hi, lo) bf16 pair with hi + lo = x to ~2^-17 relative: the "bf16x3" operand split.  a*b is then evaluated
-// as hi*hi + hi*lo + lo*hi on the bf16 MFMA (16x the fp32 MFMA rate, exact products, fp32 accumulate).
-__device__ __forceinline__ void split_bf16(float x, unsigned short &hi, unsigned short &lo) {
-    const __bf16 h = (__bf16)x;
-    const __bf16 l = (__bf16)(x - (float)h);
-    hi = __builtin_bit_cast(unsigned short, h);
-    lo = __builtin_bit_cast(unsigned short, l);
-}
-
-// store one float4 (4 consecutive channels) either as fp32 (SPLIT=false: 16 B at float offset `off`) or as 4+4 bf16 in
-// the hi / lo planes (SPLIT=true: 8 B each at byte offset `off` bytes, planes `plane` floats apart)
-template <bool SPLIT>
-__device__ __forceinline__ void store_patch4(float *patch, int off, int plane, float4 v) {
-    if constexpr (!SPLIT) {
-        st4(patch + off, v);
-    } else {
-        unsigned short h[4], l[4];
-        split_bf16(v.x, h[0], l[0]);
-        split_bf16(v.y, h[1], l[1]);
-        split_bf16(v.z, h[2], l[2]);
-        split_bf16(v.w, h[3], l[3]);
-        uint2 hv = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-        uint2 lv = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
-        char *b = reinterpret_cast<char *>(patch) + off;
-        *reinterpret_cast<uint2 *>(b) = hv;
-        *reinterpret_cast<uint2 *>(b + plane * 4) = lv;
-    }
-}
-
 // ---- batched, branch-free patch staging ---------------------------------------------------------------------
 // Stages PH x PW pixels x (4*QPP) channels starting at channel c0 into LDS rows of LDX floats.  Slots are handled in
 // batches of NB: all global loads of a batch are issued before the first LDS store, so a thread exposes ONE memory
 // latency per batch instead of one per float4 (the naive loop serialises on every load).  Out-of-image pixels and
 // channels >= Cin read a safe address and are zeroed by a select (no divergent branches around the loads).
-// SPLIT: LDS rows hold bf16 hi/lo planes (row = LDX floats = 4*LDX bytes; quad q of a pixel sits at byte q*8).
-template <int QPP, int LDX, int NB, int NT, bool SPLIT = false>
+template <int QPP, int LDX, int NB, int NT>
 __device__ __forceinline__ void stage_patch(float *__restrict__ patch, const InSrc &s, int b, int iy0, int ix0, int c0,
-                                            int PH, int PW, int tid, int plane = 0) {
-    constexpr int PXS = SPLIT ? LDX * 4 : LDX;     // per-pixel stride in `off` units (bytes if SPLIT, floats otherwise)
-    constexpr int QS = SPLIT ? 8 : 4;              // per-quad stride
+                                            int PH, int PW, int tid) {
+    constexpr int PXS = LDX, QS = 4;               // per-pixel / per-quad stride (floats)
     const int nslots = PH * PW * QPP;
     if (s.mode == RAMNET_IN_UP2X || s.mode == RAMNET_IN_UP2X_SKIP) {   // 4-8 loads per slot already in flight
         for (int sl = tid; sl < nslots; sl += NT) {
             const int pix = sl / QPP, qd = sl - pix * QPP;
             const int py = pix / PW, px = pix - py * PW;
-            store_patch4<SPLIT>(patch, pix * PXS + qd * QS, plane, load_in4(s, b, iy0 + py, ix0 + px, c0 + qd * 4));
+            st4(patch + pix * PXS + qd * QS, load_in4(s, b, iy0 + py, ix0 + px, c0 + qd * 4));
         }
         return;
     }
@@ -183,7 +150,7 @@ __device__ __forceinline__ void stage_patch(float *__restrict__ patch, const InS
                     r = f4mul(r, m[i]);
             }
             if (!ok[i]) r = f4zero();
-            if (dst[i] >= 0) store_patch4<SPLIT>(patch, dst[i], plane, r);
+            if (dst[i] >= 0) st4(patch + dst[i], r);
         }
     }
 }

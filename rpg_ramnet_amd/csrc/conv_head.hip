@@ -257,7 +257,7 @@ __global__ void pack_weight_head_kernel(const float *__restrict__ w, float *__re
 }
 
 int launch_head(const ramnet_conv_desc &d, hipStream_t st) {
-    RAMNET_CHECK_ARG(d.ntaps == 25 && d.stride == 1 && d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN);
+    RAMNET_CHECK_ARG(d.ntaps == 25 && d.stride == 1 && d.in_mode == RAMNET_IN_PLAIN);
     for (int t = 0; t < 25; ++t) RAMNET_CHECK_ARG(d.dy[t] == t / 5 - 2 && d.dx[t] == t % 5 - 2 && d.wtap[t] == t);   // dense padded 5x5
     RAMNET_CHECK_ARG(d.head_cin >= 1 && d.head_cin <= d.C0 && head_channels_ok(d.head_cin) && d.Cout <= 32);
     RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win && d.HoF == d.Ho && d.WoF == d.Wo && d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0);

@@ -37,11 +37,8 @@ struct ConvClass {
 };
 struct ConvClasses { ConvClass c[4]; };
 
-// SPLIT = false: exact fp32 (v_mfma_f32_32x32x2_f32), 16 channels per chunk.
-// SPLIT = true : BF16X3 — operands split into bf16 hi/lo planes while staging, 3 x v_mfma_f32_32x32x16_bf16 per
-//                16-channel slab (hi*hi + hi*lo + lo*hi), 32 channels per chunk.  LDS rows are 80 bytes in both modes
-//                (16 fp32 + pad | 32 bf16 + pad), so tile geometry, tap offsets and fragment addresses are shared.
-template <int BM, int BN, int WM, int WN, bool SPLIT>
+// Exact fp32 (v_mfma_f32_32x32x2_f32), 16 channels per chunk.
+template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc p, const ConvCommon qc, const ConvClasses qk) {
     // XCD-aware tile order: the dispatcher deals consecutive (flattened) workgroup ids round-robin to the 8 XCDs, each with
     // a private L2.  Remap the flattened id so that every XCD walks a CONTIGUOUS range of (class, channel tile, spatial
@@ -57,12 +54,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     const ConvClass &q = qk.c[bz];
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int TH = BM / TWID;
-    constexpr int CKC = SPLIT ? 32 : 16;           // input channels per chunk
-    constexpr int NPL = SPLIT ? 2 : 1;             // LDS planes (hi, lo)
+    constexpr int CKC = CK;                        // input channels per chunk
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *patch = smem;                            // [NPL][PH*PW][LDP]
-    float *wsm = smem + NPL * qc.patch_floats;      // [2][NPL][BN][LDP]
+    float *patch = smem;                            // [PH*PW][LDP]
+    float *wsm = smem + qc.patch_floats;            // [2][BN][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,31 +91,25 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.f;
 
-    // ---- weight tile ring: per (chunk, tap) NPL planes of [BN] rows x 64 bytes, each plane contiguous in global memory
-    constexpr int WF4 = BN * 4;                     // 16-byte units per plane
+    // ---- weight tile ring: per (chunk, tap) [BN] rows x 64 bytes, contiguous in global memory
+    constexpr int WF4 = BN * 4;                     // 16-byte units per tile
     constexpr int WPT = (WF4 + 255) / 256;
-    float4 wreg[NPL][WPT];
+    float4 wreg[WPT];
     const int ntaps = q.ntaps;
     auto load_w = [&](int chunk, int t) {
+        const float *src = p.w + ((size_t)q.woff[t] + ((size_t)chunk * qc.CoutPad + n0)) * 16;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            const float *src = p.w + ((size_t)q.woff[t] + ((size_t)(chunk * NPL + pl) * qc.CoutPad + n0)) * 16;
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) {
-                const int f = tid + i * 256;
-                if (WF4 % 256 == 0 || f < WF4) wreg[pl][i] = ld4(src + (size_t)f * 4);
-            }
+        for (int i = 0; i < WPT; ++i) {
+            const int f = tid + i * 256;
+            if (WF4 % 256 == 0 || f < WF4) wreg[i] = ld4(src + (size_t)f * 4);
         }
     };
     auto store_w = [&](int buf) {
+        float *dst = wsm + buf * (BN * LDP);
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            float *dst = wsm + (buf * NPL + pl) * (BN * LDP);
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) {
-                const int f = tid + i * 256;
-                if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[pl][i]);
-            }
+        for (int i = 0; i < WPT; ++i) {
+            const int f = tid + i * 256;
+            if (WF4 % 256 == 0 || f < WF4) st4(dst + (f >> 2) * LDP + (f & 3) * 4, wreg[i]);
         }
     };
 
@@ -127,54 +117,31 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     int buf = 0;
     for (int chunk = 0; chunk < qc.nchunks; ++chunk) {
         __syncthreads();   // every wave is done reading the previous chunk's patch
-        stage_patch<CKC / 4, LDP, 4, 256, SPLIT>(patch, qc.src, b, iy0, ix0, chunk * CKC, q.PH, q.PW, tid, qc.patch_floats);
+        stage_patch<CKC / 4, LDP, 4, 256>(patch, qc.src, b, iy0, ix0, chunk * CKC, q.PH, q.PW, tid);
         for (int t = 0; t < ntaps; ++t) {
             store_w(buf);
             __syncthreads();   // patch + weight tile visible; the other ring slot is free again
             if (t + 1 < ntaps) load_w(chunk, t + 1);
             else if (chunk + 1 < qc.nchunks) load_w(chunk + 1, 0);
             const float *pa = patch + q.toff[t];
-            const float *wb = wsm + buf * NPL * (BN * LDP);
+            const float *wb = wsm + buf * (BN * LDP);
 #pragma unroll
             for (int k8 = 0; k8 < 2; ++k8) {
-                if constexpr (!SPLIT) {
-                    float4 a[TM], bb[TN];
+                float4 a[TM], bb[TN];
 #pragma unroll
-                    for (int ms = 0; ms < TM; ++ms) a[ms] = ld4(pa + aBase[ms] + k8 * 8);
+                for (int ms = 0; ms < TM; ++ms) a[ms] = ld4(pa + aBase[ms] + k8 * 8);
 #pragma unroll
-                    for (int ns = 0; ns < TN; ++ns) bb[ns] = ld4(wb + bBase[ns] + k8 * 8);
-                    // lanes 0-31 feed channels k8*8+j, lanes 32-63 channels k8*8+4+j: 4 MFMAs cover 8 channels
+                for (int ns = 0; ns < TN; ++ns) bb[ns] = ld4(wb + bBase[ns] + k8 * 8);
+                // lanes 0-31 feed channels k8*8+j, lanes 32-63 channels k8*8+4+j: 4 MFMAs cover 8 channels
 #pragma unroll
-                    for (int ms = 0; ms < TM; ++ms)
-#pragma unroll
-                        for (int ns = 0; ns < TN; ++ns) {
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].x, bb[ns].x, acc[ms][ns], 0, 0, 0);
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].y, bb[ns].y, acc[ms][ns], 0, 0, 0);
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].z, bb[ns].z, acc[ms][ns], 0, 0, 0);
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].w, bb[ns].w, acc[ms][ns], 0, 0, 0);
-                        }
-                } else {
-                    // one K=16 slab: lanes 0-31 hold channels 16*k8 .. +7, lanes 32-63 channels 16*k8+8 .. +15 (16 B each)
-                    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                    for (int ms = 0; ms < TM; ++ms) {
-                        ah[ms] = __builtin_bit_cast(bf16x8, ld4(pa + aBase[ms] + k8 * 8));
-                        al[ms] = __builtin_bit_cast(bf16x8, ld4(pa + qc.patch_floats + aBase[ms] + k8 * 8));
-                    }
+                for (int ms = 0; ms < TM; ++ms)
 #pragma unroll
                     for (int ns = 0; ns < TN; ++ns) {
-                        bh[ns] = __builtin_bit_cast(bf16x8, ld4(wb + bBase[ns] + k8 * 8));
-                        bl[ns] = __builtin_bit_cast(bf16x8, ld4(wb + BN * LDP + bBase[ns] + k8 * 8));
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].x, bb[ns].x, acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].y, bb[ns].y, acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].z, bb[ns].z, acc[ms][ns], 0, 0, 0);
+                        acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ms].w, bb[ns].w, acc[ms][ns], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int ms = 0; ms < TM; ++ms)
-#pragma unroll
-                        for (int ns = 0; ns < TN; ++ns) {
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ms], bh[ns], acc[ms][ns], 0, 0, 0);
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ms], bl[ns], acc[ms][ns], 0, 0, 0);
-                            acc[ms][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ms], bh[ns], acc[ms][ns], 0, 0, 0);
-                        }
-                }
             }
             buf ^= 1;
         }
@@ -222,11 +189,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool SPLIT>
-static int launch_p(const ramnet_conv_desc &d, const ConvCommon &qc, const ConvClasses &qk, int max_tiles, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, SPLIT>;
-    constexpr int NPL = SPLIT ? 2 : 1;
-    const size_t lds = ((size_t)NPL * qc.patch_floats + 2 * NPL * BN * LDP) * sizeof(float);
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ramnet_conv_desc &d, const ConvCommon &qc, const ConvClasses &qk, int max_tiles, hipStream_t st) {
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN>;
+    const size_t lds = ((size_t)qc.patch_floats + 2 * BN * LDP) * sizeof(float);
     static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation
     if (lds > lds_set) {
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -240,12 +206,6 @@ static int launch_p(const ramnet_conv_desc &d, const ConvCommon &qc, const ConvC
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, qc, qk);
     RAMNET_LAUNCH_CHECK();
     return 0;
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const ramnet_conv_desc &d, const ConvCommon &qc, const ConvClasses &qk, int max_tiles, hipStream_t st) {
-    if (d.precision == RAMNET_PREC_BF16X3) return launch_p<BM, BN, WM, WN, true>(d, qc, qk, max_tiles, st);
-    return launch_p<BM, BN, WM, WN, false>(d, qc, qk, max_tiles, st);
 }
 
 static int check_desc(const ramnet_conv_desc &d) {
@@ -262,7 +222,6 @@ static int check_desc(const ramnet_conv_desc &d) {
     if (d.epi == RAMNET_EPI_RES_RELU) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_GRU_BLEND) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
-    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 || d.precision == RAMNET_PREC_BF16X3);
     RAMNET_CHECK_ARG(d.frame >= 0);
     if (d.frame > 0) RAMNET_CHECK_ARG(d.e0 && d.e1 && (d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR));
     return 0;
@@ -276,17 +235,16 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
         if (rc) return rc;
         RAMNET_CHECK_ARG(ds[i].x0 == d.x0 && ds[i].w == d.w && ds[i].out == d.out && ds[i].stride == d.stride &&
                          ds[i].Cout == d.Cout && ds[i].epi == d.epi && ds[i].osy == d.osy && ds[i].osx == d.osx &&
-                         ds[i].B == d.B && ds[i].in_mode == d.in_mode && ds[i].precision == d.precision);
+                         ds[i].B == d.B && ds[i].in_mode == d.in_mode);
     }
     const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
-    const int split = d.precision == RAMNET_PREC_BF16X3;
     ConvCommon qc;
     ConvClasses qk;
     qc.src.x0 = d.x0, qc.src.x1 = d.x1, qc.src.xm = d.xm;
     qc.src.ld0 = d.ld0, qc.src.ld1 = d.ld1, qc.src.ldm = d.ldm;
     qc.src.C0 = d.C0, qc.src.Cin = d.C0 + (cat ? d.C1 : 0);
     qc.src.mode = d.in_mode, qc.src.Hin = d.Hin, qc.src.Win = d.Win;
-    qc.nchunks = cdiv(qc.src.Cin, split ? 32 : CK);
+    qc.nchunks = cdiv(qc.src.Cin, CK);
     qc.CoutPad = d.epi == RAMNET_EPI_LSTM ? 4 * roundup(d.Cout, 32) : roundup(d.Cout, 32);
     qc.nclass = n;
     // measured on MI355X (profiles/r01_b_tuning_notes.md): forward 5.55 -> 5.50 ms, backward-data 5.40 -> 5.56 ms per pass,
@@ -330,7 +288,7 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
         q.tiles_x = cdiv(e.Wo, TWID), q.tiles_y = cdiv(e.Ho, TH);
         for (int t = 0; t < e.ntaps; ++t) {
             q.toff[t] = ((e.dy[t] - dymin) * q.PW + (e.dx[t] - dxmin)) * LDP;
-            q.woff[t] = (unsigned)e.wtap[t] * (unsigned)qc.nchunks * (unsigned)(split ? 2 : 1) * (unsigned)qc.CoutPad;
+            q.woff[t] = (unsigned)e.wtap[t] * (unsigned)qc.nchunks * (unsigned)qc.CoutPad;
         }
         if (q.PH * q.PW * LDP > qc.patch_floats) qc.patch_floats = q.PH * q.PW * LDP;
         if (q.tiles_x * q.tiles_y > max_tiles) max_tiles = q.tiles_x * q.tiles_y;

@@ -407,7 +407,7 @@ static void wino_geometry(int Cout, int Cin, int transposed, int gates, int &R, 
 }
 
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
-    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && d.precision == RAMNET_PREC_F32);
+    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
     auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };

@@ -338,7 +338,7 @@ static bool fold_wino_geometry(int Cout, int Cin, int &kc, int &ncq) {
 // low-res tensor [B][Ho = H+4][Wo = W+4][Cout = Cin_fwd]; w = Winograd weights of the flipped parity filters over 4*C0 reduction
 // channels (ops.pack_fold_wino_dgrad).
 static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
-    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.stride == 1 && d.C0 % 16 == 0 && d.Cout % 64 == 0);
+    RAMNET_CHECK_ARG(d.stride == 1 && d.C0 % 16 == 0 && d.Cout % 64 == 0);
     RAMNET_CHECK_ARG(d.Hin % 2 == 0 && d.Win % 2 == 0 && d.Ho == d.Hin / 2 + 4 && d.Wo == d.Win / 2 + 4 && d.HoF == d.Ho && d.WoF == d.Wo);
     RAMNET_CHECK_ARG(d.epi == RAMNET_EPI_LINEAR && !d.bias && d.beta == 0.f && d.frame == 0 && d.out_s2d == 0);
     Wino24Params q;
@@ -367,7 +367,7 @@ static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     if (d.in_mode == RAMNET_IN_PARITY4) return launch_wino24_dgrad(d, st);
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
-    RAMNET_CHECK_ARG(d.precision == RAMNET_PREC_F32 && d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
+    RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
     const bool wide = d.Cout % 64 == 0 && d.C0 % 16 == 0;      // 64-channel workgroups, chunks of 16; else 32 channels, chunks of 8
     RAMNET_CHECK_ARG(d.C0 % (wide ? 32 : 16) == 0);            // an even number of chunks (the chunk loop is unrolled by two)
     RAMNET_CHECK_ARG(d.C0 % 8 == 0 && d.Cout % 32 == 0 && d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);

@@ -59,29 +59,34 @@ __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__res
 // sum (log t - log p)^2, sum (log t - log p), sum |t-p|;  out[7..9] = count(max(t/p,p/t) < 1.25^k), k=1..3.
 __global__ void depth_metrics_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float clip,
                                      float reg, float cutoff, double *out) {
-    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // out: n (non-NaN pixels of the mask), n_mask, sum |d|/(t+1e-6), sum d^2/(t^2+1e-6), sum d^2, sum ld^2, sum |ld|, sum |d|,
+    // counts of ratio <= 1.25^k — operators and epsilons of evaluation.py:201-241 / metric.py:8-33
+    double acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float lo = expf(-reg) * clip;
+    const double eps = 1e-5;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float tn = target[i];
-        if (!(tn == tn)) continue;
+        const bool nan = !(tn == tn);
         const float t = expf(reg * (tn - 1.0f)) * clip;
-        if (t > cutoff) continue;
+        if (!nan && !(t < cutoff)) continue;          // mask: nan_to_num(target) < cutoff  (NaN -> 0: inside)
+        acc[1] += 1.0;
+        if (nan) continue;
         const float p = fminf(fmaxf(expf(reg * (pred[i] - 1.0f)) * clip, lo), clip);
-        const double d = (double)t - (double)p, ld = log((double)t) - log((double)p);
-        acc[0] += 1.0, acc[1] += fabs(d) / ((double)t + 1e-6), acc[2] += d * d / ((double)t * t + 1e-6), acc[3] += d * d;
-        acc[4] += ld * ld, acc[5] += ld, acc[6] += fabs(d);
-        const double r = fmax((double)t / p, (double)p / t);
-        acc[7] += r < 1.25, acc[8] += r < 1.5625, acc[9] += r < 1.953125;
+        const double d = (double)t - (double)p, ld = log((double)t + eps) - log((double)p + eps);
+        acc[0] += 1.0, acc[2] += fabs(d) / ((double)t + 1e-6), acc[3] += d * d / ((double)t * t + 1e-6), acc[4] += d * d;
+        acc[5] += ld * ld, acc[6] += fabs(ld), acc[7] += fabs(d);
+        const double r = fmax((double)t / ((double)p + eps), (double)p / ((double)t + eps));
+        acc[8] += r <= 1.25, acc[9] += r <= 1.5625, acc[10] += r <= 1.953125;
     }
-    __shared__ double red[10][4];
+    __shared__ double red[11][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
+    for (int k = 0; k < 11; ++k) {
         const double v = wave_sum(acc[k]);
         if (lane == 0) red[k][wave] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 10) atomicAdd(out + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 11) atomicAdd(out + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 // ---------------------------------------------------------------------------------------- multi-scale gradient loss
@@ -308,11 +313,11 @@ extern "C" int ramnet_si_loss_bwd(const float *pred, const float *target, size_t
 }
 
 extern "C" int ramnet_depth_metrics(const float *pred, const float *target, size_t n, float clip_distance, float reg_factor,
-                                    float cutoff, double *out10, void *stream) {
-    RAMNET_CHECK_ARG(pred && target && out10 && n > 0 && clip_distance > 0.f);
+                                    float cutoff, double *out11, void *stream) {
+    RAMNET_CHECK_ARG(pred && target && out11 && n > 0 && clip_distance > 0.f);
     hipStream_t st = (hipStream_t)stream;
-    RAMNET_HIP(hipMemsetAsync(out10, 0, 10 * sizeof(double), st));
-    hipLaunchKernelGGL(depth_metrics_kernel, dim3(grid_for(n)), dim3(256), 0, st, pred, target, n, clip_distance, reg_factor, cutoff, out10);
+    RAMNET_HIP(hipMemsetAsync(out11, 0, 11 * sizeof(double), st));
+    hipLaunchKernelGGL(depth_metrics_kernel, dim3(grid_for(n)), dim3(256), 0, st, pred, target, n, clip_distance, reg_factor, cutoff, out11);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -65,36 +65,6 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
     }
 }
 
-// OIHW -> [tap][chunk32][plane hi|lo][n][32] bf16 (the BF16X3 operand split of the weights, done once per optimizer step)
-__global__ void pack_weight_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ wp, int Cout, int Cin, int T,
-                                         int transposed, int gates, int R, int N, int nchunks, int NPad, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ck = (int)(i % 32);
-        size_t j = i / 32;
-        const int n = (int)(j % NPad);
-        j /= NPad;
-        const int chunk = (int)(j % nchunks);
-        const int t = (int)(j / nchunks);
-        const int r = chunk * 32 + ck;
-        int no = n;
-        bool ok = r < R;
-        if (gates > 1) {
-            const int C = N / gates, blk = n / (32 * gates), g = (n / 32) % gates, ch = blk * 32 + (n % 32);
-            ok = ok && ch < C;
-            no = g * C + ch;
-        } else {
-            ok = ok && n < N;
-        }
-        float v = 0.f;
-        if (ok) v = transposed ? w[((size_t)r * Cin + no) * T + t] : w[((size_t)no * Cin + r) * T + t];
-        unsigned short hi, lo;
-        split_bf16(v, hi, lo);
-        const size_t base = (((size_t)t * nchunks + chunk) * 2) * NPad * 32 + (size_t)n * 32 + ck;
-        wp[base] = hi;
-        wp[base + (size_t)NPad * 32] = lo;
-    }
-}
-
 // ws [T][CinWs][CoutWs] -> grad OIHW [Cout][Cin][T] (+=)
 __global__ void unpack_wgrad_kernel(const float *__restrict__ ws, float *__restrict__ g, int Cout, int Cin, int CinWs, int CoutWs,
                                     int n_off, int T, size_t total) {
@@ -537,25 +507,6 @@ extern "C" int ramnet_pack_weight(const float *w, float *wp, int Cout, int Cin, 
     const size_t total = (size_t)KH * KW * nchunks * NPad * CK;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, KH * KW,
                        transposed, gates, R, N, nchunks, NPad, total);
-    RAMNET_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" size_t ramnet_packed_weight_elems_split(int Cout, int Cin, int KH, int KW, int transposed, int gates) {
-    int R, N, nchunks, NPad;
-    pack_geometry(Cout, Cin, transposed, gates, R, N, nchunks, NPad);
-    return (size_t)KH * KW * cdiv(R, 32) * 2 * NPad * 32 / 2;      // bf16 elements / 2 = floats
-}
-
-extern "C" int ramnet_pack_weight_split(const float *w, float *wp, int Cout, int Cin, int KH, int KW, int transposed, int gates, void *stream) {
-    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && KH * KW <= 25);
-    RAMNET_CHECK_ARG(gates == 1 || (gates == 4 && !transposed && Cout % 4 == 0));
-    int R, N, nchunks, NPad;
-    pack_geometry(Cout, Cin, transposed, gates, R, N, nchunks, NPad);
-    nchunks = cdiv(R, 32);
-    const size_t total = (size_t)KH * KW * nchunks * NPad * 32;
-    hipLaunchKernelGGL(pack_weight_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<unsigned short *>(wp), Cout, Cin, KH * KW, transposed, gates, R, N, nchunks, NPad, total);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

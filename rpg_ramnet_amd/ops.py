@@ -7,6 +7,7 @@ kernel into per-layer [tap][Cin][Cout] workspaces over ALL time steps of a BPTT 
 autograd's per-use accumulation, lstm_trainer.py:450).
 """
 import ctypes as C
+import os as _os
 
 import torch
 from torch.autograd import Function
@@ -14,23 +15,6 @@ from torch.autograd import Function
 from . import _hip as H
 
 _NULL = None
-
-# Arithmetic of the forward / backward-data contraction: "f32" (exact fp32 MFMA, the parity path) or "bf16x3" (operands
-# split into bf16 hi+lo on the fly, hi*hi + hi*lo + lo*hi on the bf16 MFMA; ~1e-5 relative error per product).
-# Backward-weights always runs exact fp32.  Selected with set_precision() or the RAMNET_PRECISION environment variable.
-import os as _os
-
-_PRECISION = {"f32": H.PREC_F32, "bf16x3": H.PREC_BF16X3}[_os.environ.get("RAMNET_PRECISION", "f32")]
-
-
-def set_precision(name):
-    global _PRECISION
-    _PRECISION = {"f32": H.PREC_F32, "bf16x3": H.PREC_BF16X3}[name]
-
-
-def get_precision():
-    return "bf16x3" if _PRECISION == H.PREC_BF16X3 else "f32"
-
 
 # 3x3 stride-1 layers (ConvGRU gates / candidate, residual blocks) run Winograd F(2x2,3x3) in fp32 — 2.25x fewer
 # multiplies, rounding error ~1e-6 relative (tests/test_hip_ops.py) — unless switched off (RAMNET_WINOGRAD=0).
@@ -172,7 +156,7 @@ def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
     """Does this forward / backward-data launch run the Winograd F(2x2,3x3) kernel?  (3x3 stride-1 window, fp32, no
     upsampling loader, >= 32 reduction channels, concatenation boundary on a chunk of 8; the ConvLSTM cell epilogue
     needs a hidden size that is a multiple of 4.)"""
-    return bool(isinstance(w, PackRef) and _WINOGRAD and _PRECISION == H.PREC_F32 and taps.wino and stride == 1
+    return bool(isinstance(w, PackRef) and _WINOGRAD and taps.wino and stride == 1
                 and (w.cp.gates == 1 or w.transposed or (epi == H.EPI_LSTM and w.cp.Cout % 16 == 0))
                 and (epi != H.EPI_LSTM or w.cp.gates == 4) and in_mode not in (H.IN_UP2X, H.IN_UP2X_SKIP)
                 and C0 + C1 >= _WINO_MIN_CIN and (C1 == 0 or C0 % 8 == 0))
@@ -195,7 +179,7 @@ def get_head_kernel():
 def uses_head(taps, w, stride, epi, in_mode):
     """Does this forward launch run the head kernel?  (dense 5x5 stride-1 window, fp32, plain input, 1/3/5 real input
     channels, <= 32 outputs, bias + optional ReLU only.)"""
-    return bool(isinstance(w, PackRef) and _HEAD and _PRECISION == H.PREC_F32 and taps.head and stride == 1 and not w.transposed
+    return bool(isinstance(w, PackRef) and _HEAD and taps.head and stride == 1 and not w.transposed
                 and w.cp.gates == 1 and len(w.cp.weights) == 1 and in_mode == H.IN_PLAIN and epi in (H.EPI_LINEAR, H.EPI_RELU)
                 and H.lib().ramnet_head_supported(w.cp.Cin, w.cp.Cout))
 
@@ -229,7 +213,6 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.lde0, d.lde1 = (ld(e0) if e0 is not None else 0), (ld(e1) if e1 is not None else 0)
     d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
     d.ldo, d.ldo1, d.ldo2 = ld(out), (ld(o1) if o1 is not None else 0), (ld(o2) if o2 is not None else 0)
-    d.precision = _PRECISION
     if wino24:          # w = ConvParam.pack_fold_wino(): all four parities in one Winograd F(2x2,4x4) launch
         d.algo = H.ALGO_WINOGRAD24
     return d
@@ -254,7 +237,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     if wino24:          # folded upsample-conv in the Winograd F(2x2,4x4) domain: dw = [4][25][C0][Cout]
         d.algo = H.ALGO_WINOGRAD24
     hc = getattr(dw, "head_cin", 0)
-    if hc and _HEAD and _PRECISION == H.PREC_F32 and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
+    if hc and _HEAD and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
         d.algo, d.head_cin = H.ALGO_HEAD, hc
     if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
@@ -327,33 +310,54 @@ def wgrad_side(tensors, *args, **kw):
 
 # ------------------------------------------------------------------------------------------------ parameters
 class _Engine:
-    """Per-backward-pass bookkeeping: fold weight-gradient workspaces into .grad when the engine finishes."""
+    """Per-backward-pass bookkeeping: fold weight-gradient workspaces into .grad when the autograd engine finishes the pass.
+
+    Keyed on the engine's graph task: the first weight-gradient launch of a backward pass queues ONE end-of-pass callback
+    (flush).  The engine runs callbacks only when the pass completes; a pass that raises mid-way (OOM, a bad argument, a hook)
+    leaves workspaces partly filled, so the next pass — recognised by its new task id — first discards them (reset)."""
     dirty = []
-    queued = False
+    task = -1                # graph task whose callback is queued (-1: none / launches outside autograd, caller flushes)
     side_used = None
 
     @classmethod
+    def enter(cls):
+        tid = torch._C._current_graph_task_id()
+        if tid != cls.task:
+            if cls.dirty:            # leftovers of a pass that never reached its callback
+                cls.reset()
+            cls.task = tid
+            if tid != -1:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+
+    @classmethod
     def mark(cls, cp):
+        cls.enter()
         if not cp._dirty:
             cp._dirty = True
             cls.dirty.append(cp)
-        if not cls.queued:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
-                cls.queued = True
-            except RuntimeError:        # not inside a backward pass (kernel benchmarks): the caller folds with _Engine.flush()
-                pass
 
     @classmethod
-    def flush(cls):
+    def _join(cls):
         for dev in _DECODE_USED:           # decoder backward (and its weight-gradient launches) ran on the decode stream
             torch.cuda.current_stream(dev).wait_stream(_DECODE[dev])
         if cls.side_used is not None:      # all weight-gradient launches of this pass are done before the fold
             torch.cuda.current_stream().wait_event(_side_stream(cls.side_used).record_event())
             cls.side_used = None
-        for cp in cls.dirty:
+
+    @classmethod
+    def flush(cls):
+        cls._join()
+        dirty, cls.dirty, cls.task = cls.dirty, [], -1
+        for cp in dirty:
             cp.finalize()
-        cls.dirty, cls.queued = [], False
+
+    @classmethod
+    def reset(cls):
+        """Drop the partial weight-gradient sums of an aborted backward pass (nothing reaches .grad)."""
+        cls._join()
+        dirty, cls.dirty, cls.task = cls.dirty, [], -1
+        for cp in dirty:
+            cp.discard()
 
 
 def ensure_grad(p):
@@ -492,17 +496,14 @@ class ConvParam:
             out = torch.empty(n, device=w.device, dtype=torch.float32)
             H.check(L.ramnet_pack_weight_wino(_p(w), _p(out), self.Cout, self.Cin, transposed, g, _st()), "ramnet_pack_weight_wino")
             return out
-        split = _PRECISION == H.PREC_BF16X3
-        sizer, packer = (L.ramnet_packed_weight_elems_split, L.ramnet_pack_weight_split) if split else \
-                        (L.ramnet_packed_weight_elems, L.ramnet_pack_weight)
-        n = sizer(self.Cout, self.Cin, self.k, self.k, transposed, g)
+        n = L.ramnet_packed_weight_elems(self.Cout, self.Cin, self.k, self.k, transposed, g)
         out = torch.empty(n, device=w.device, dtype=torch.float32)
-        H.check(packer(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, transposed, g, _st()), "ramnet_pack_weight")
+        H.check(L.ramnet_pack_weight(_p(w), _p(out), self.Cout, self.Cin, self.k, self.k, transposed, g, _st()), "ramnet_pack_weight")
         return out
 
     def pack(self, transposed, wino=False):
         """Packed weights for the forward (transposed=0) / backward-data (1) launch, re-packed when a parameter changes."""
-        v = (self._versions(self.weights), _PRECISION)
+        v = self._versions(self.weights)
         wino = wino if wino == "head" else bool(wino)
         key = (transposed, wino)
         hit = self._packs.get(key)
@@ -580,8 +581,9 @@ class ConvParam:
             slots = 16 if self.k == 3 else self.k * self.k       # 3x3: room for the Winograd-domain gradient dU
             self._ws = torch.zeros(slots * self.CinWs * self.Cout, device=dev)
             self._bws = torch.zeros(self.Cout, device=dev)
+        _Engine.enter()         # (a new pass after an aborted one resets _dirty first)
         if not self._dirty:     # one algorithm per backward pass: every launch of the pass accumulates into the same layout
-            self._ws.wino = bool(wino_ok and _WINOGRAD and _PRECISION == H.PREC_F32 and self.k == 3
+            self._ws.wino = bool(wino_ok and _WINOGRAD and self.k == 3
                                  and self.CinWs >= _WINO_MIN_CIN)
             # head layers: the launch may run the head kernel (same [tap][CinWs][Cout] layout as the direct kernel)
             self._ws.head_cin = self.Cin if (self.k == 5 and self.gates == 1 and len(self.weights) == 1
@@ -634,6 +636,13 @@ class ConvParam:
                     g[:, :, :, a].sub_(c[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][ky]
         w4.zero_(), wr.zero_(), wc.zero_()
         self._fold_used = False
+
+    def discard(self):
+        """Zero every gradient workspace without folding it (aborted backward pass)."""
+        for t in (self._ws, self._bws, getattr(self, "_ws_fold24", None)) + tuple(self._ws_fold or ()):
+            if t is not None:
+                t.zero_()
+        self._dirty = self._ws_used = self._fold_used = self._fold24_used = False
 
     def finalize(self):
         if self._fold_used:
@@ -754,7 +763,7 @@ def get_space_to_depth():
 
 
 def _s2d_eligible(x, cp, k, stride, up):
-    return bool(_S2D and _WINOGRAD and _PRECISION == H.PREC_F32 and stride == 2 and k == 5 and not up and x.shape[1] % 2 == 0
+    return bool(_S2D and _WINOGRAD and stride == 2 and k == 5 and not up and x.shape[1] % 2 == 0
                 and x.shape[2] % 2 == 0 and x.shape[3] == cp.Cin and cp.Cin % 8 == 0 and cp.gates == 1 and len(cp.weights) == 1)
 
 
@@ -783,7 +792,7 @@ def _space_to_depth(x, inverse=False):
 
 
 def _fold_eligible(x, cp, k, stride, up):
-    return bool(up and k == 5 and stride == 1 and _FOLD_UP and _PRECISION == H.PREC_F32 and x.shape[1] >= 4 and x.shape[2] >= 4
+    return bool(up and k == 5 and stride == 1 and _FOLD_UP and x.shape[1] >= 4 and x.shape[2] >= 4
                 and x.shape[3] == cp.Cin)
 
 
@@ -800,7 +809,7 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     if xpad is None:            # not kept by forward (RAMNET_SAVE_XPAD=0): recompute pad2(x + skip)
         xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
         H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
-    if _FOLD_WINO_WGRAD and _PRECISION == H.PREC_F32 and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
+    if _FOLD_WINO_WGRAD and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
                                                                              (Cc % 64 == 0 and cp.Cout % 32 == 0)):
         # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
         wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, 0, 0), dy, cp.grad_ws_fold24(), cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
@@ -832,7 +841,7 @@ def set_fold_dgrad(on):
 
 
 def _fold_dgrad_ok(B, H2, W2, cp):
-    return bool(_FOLD_DGRAD and _FOLD_UP and _PRECISION == H.PREC_F32 and cp.Cout % 16 == 0 and cp.Cin % 64 == 0
+    return bool(_FOLD_DGRAD and _FOLD_UP and cp.Cout % 16 == 0 and cp.Cin % 64 == 0
                 and B * H2 * W2 * cp.Cout * 4 < 2 ** 30)
 
 
@@ -1006,14 +1015,18 @@ class ResConv(Function):
     def backward(ctx, dy):
         t, y = ctx.saved_tensors
         cp = ctx.cp
-        dy = dense(dy)
+        dy = dense(dy).contiguous()
         dpre = torch.empty_like(y)
-        H.check(H.lib().ramnet_relu_bwd(_p(dy.contiguous()), _p(y), _p(dpre), y.numel(), _st()), "ramnet_relu_bwd")
+        H.check(H.lib().ramnet_relu_bwd(_p(dy), _p(y), _p(dpre), y.numel(), _st()), "ramnet_relu_bwd")
         ws, bws = cp.grad_ws(wino_ok=True)
         wgrad_side([t, dpre], t, Taps.get("conv", 3, 1), dpre, ws, cp.Cout, dbias=bws)
         dt = torch.empty_like(t, memory_format=torch.contiguous_format)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dt, cp.Cin)
-        return dt, dpre, None, None, None
+        dres = dpre
+        if _USE_SIDE:       # autograd may accumulate IN PLACE into the tensor returned for the residual input while the side
+            dres = torch.empty_like(y)      # stream still reads dpre: hand it a buffer of its own
+            H.check(H.lib().ramnet_relu_bwd(_p(dy), _p(y), _p(dres), y.numel(), _st()), "ramnet_relu_bwd")
+        return dt, dres, None, None, None
 
 
 class GRUCell(Function):
@@ -1179,7 +1192,7 @@ class MSGLoss(Function):
 
 def multi_scale_grad_loss(prediction, target, num_scales=4):
     """Drop-in for model.loss.multi_scale_grad_loss (non-preview branch) on device tensors."""
-    return MSGLoss.apply(prediction, target.to(prediction.device), int(num_scales))
+    return MSGLoss.apply(prediction.float(), target.to(prediction.device).float(), int(num_scales))
 
 
 def nhwc_add(a, b):
@@ -1192,7 +1205,7 @@ def nhwc_add(a, b):
 
 def scale_invariant_loss(y_input, y_target, weight=1.0, n_lambda=1.0):
     """Drop-in for model.loss.scale_invariant_loss (model/loss.py:6-9) on device tensors."""
-    return SILoss.apply(y_input, y_target.to(y_input.device), float(weight), float(n_lambda))
+    return SILoss.apply(y_input.float(), y_target.to(y_input.device).float(), float(weight), float(n_lambda))
 
 
 class Add(Function):

@@ -3,9 +3,10 @@ gradients averaged with RCCL (torch.distributed backend "nccl" on ROCm) over xGM
 
 The reference is single-GPU (no collective anywhere); this module ADDS data parallelism.
 Design for xGMI (point-to-point links, per-link bound rings): all 68-77 gradient tensors live in ONE flat fp32 buffer
-(59.5 MB for RAM-Net) whose views are the parameters' ``.grad``; it is all-reduced in a few large buckets on a
-side HIP stream as soon as the backward pass has folded each bucket's weight-gradient workspaces, so the collective
-of bucket i overlaps the fold kernels of bucket i+1 and the host-side bookkeeping; Adam waits on an event.
+(59.5 MB for RAM-Net) whose views are the parameters' ``.grad``; it is all-reduced in a few large buckets on a side
+HIP stream.  Every weight is used at every time step of the BPTT pass, so no gradient is final before the pass ends
+and its fold (ops._Engine.flush) has run: all_reduce() is therefore called AFTER backward() returns and overlaps only
+host-side work (loss read-back, optimizer bookkeeping); Adam waits on the event recorded behind the last bucket.
 Loss semantics: each rank's loss is the mean over ITS batch (standard DDP); gradients are averaged over ranks.
 """
 import torch
@@ -56,6 +57,10 @@ class FlatGradReducer:
     def all_reduce(self):
         """Average gradients over ranks; asynchronous on the side stream (wait() before the optimizer)."""
         w = self.world
+        for p, v in self.views.items():     # e.g. optimizer.zero_grad(set_to_none=True) after zero(): autograd allocated a
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():      # fresh .grad outside the flat buffer
+                v.copy_(p.grad)
+                p.grad = v
         if w == 1:
             return
         if self.cuda:

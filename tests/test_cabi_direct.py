@@ -38,7 +38,7 @@ def test_conv_forward_through_raw_descriptor():
     d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
     d.Ho, d.Wo, d.HoF, d.WoF = H, W, H, W
     d.osy, d.osx, d.ooy, d.oox = 1, 1, 0, 0
-    d.epi, d.beta, d.out, d.ldo, d.precision = _hip.EPI_RELU, 0.0, ptr(y), Cout, _hip.PREC_F32
+    d.epi, d.beta, d.out, d.ldo = _hip.EPI_RELU, 0.0, ptr(y), Cout
     rc = L.ramnet_conv_launch(C.byref(d), st)
     assert rc == 0, L.ramnet_last_error()
     ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).cpu(), w.cpu(), b.cpu(), 1, 1))
@@ -92,7 +92,7 @@ def test_winograd_conv_and_wgrad_through_raw_descriptors():
     d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
     d.Ho, d.Wo, d.HoF, d.WoF = H, W, H, W
     d.osy, d.osx = 1, 1
-    d.epi, d.out, d.ldo, d.precision, d.algo = _hip.EPI_LINEAR, ptr(y), Cout, _hip.PREC_F32, _hip.ALGO_WINOGRAD
+    d.epi, d.out, d.ldo, d.algo = _hip.EPI_LINEAR, ptr(y), Cout, _hip.ALGO_WINOGRAD
     assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
     xr = x.permute(0, 3, 1, 2).cpu().double()
     wr, br = w.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
@@ -146,7 +146,7 @@ def test_space_to_depth_view_through_raw_descriptors():
         d.w, d.Cout = ptr(wpk), cout
         d.Ho, d.Wo, d.HoF, d.WoF = Hl, Wl, out.shape[1], out.shape[2]
         d.osy, d.osx = 1, 1
-        d.epi, d.out, d.ldo, d.precision, d.algo = _hip.EPI_LINEAR, ptr(out), out.shape[3], _hip.PREC_F32, _hip.ALGO_WINOGRAD
+        d.epi, d.out, d.ldo, d.algo = _hip.EPI_LINEAR, ptr(out), out.shape[3], _hip.ALGO_WINOGRAD
         return d
 
     # forward: in-place view == materialised view, bit for bit (same kernel, same operands)
@@ -221,7 +221,7 @@ def test_head_layer_through_raw_descriptors(cin, cpad):
     d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
     d.Ho, d.Wo, d.HoF, d.WoF = H, W, H, W
     d.osy, d.osx = 1, 1
-    d.epi, d.out, d.ldo, d.precision, d.algo, d.head_cin = _hip.EPI_RELU, ptr(y), Cout, _hip.PREC_F32, _hip.ALGO_HEAD, cin
+    d.epi, d.out, d.ldo, d.algo, d.head_cin = _hip.EPI_RELU, ptr(y), Cout, _hip.ALGO_HEAD, cin
     assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
     xr = x[..., :cin].permute(0, 3, 1, 2).cpu().double()
     wr, br = w.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
@@ -276,7 +276,7 @@ def test_folded_upsample_conv_winograd_through_raw_descriptors(Cin, Cout):
     d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
     d.Ho, d.Wo, d.HoF, d.WoF = H, W, 2 * H, 2 * W
     d.osy, d.osx = 1, 1
-    d.epi, d.out, d.ldo, d.precision, d.algo = _hip.EPI_LINEAR, ptr(y), Cout, _hip.PREC_F32, _hip.ALGO_WINOGRAD24
+    d.epi, d.out, d.ldo, d.algo = _hip.EPI_LINEAR, ptr(y), Cout, _hip.ALGO_WINOGRAD24
     assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
     xr = x.permute(0, 3, 1, 2).cpu().double()
     wr, br = w.cpu().double(), b.cpu().double()

@@ -15,15 +15,6 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3     # north star: <= 1e-3 relative fp32 against the reference forward
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
-def precision(request):
-    """Forward parity is checked for both contraction arithmetics (exact fp32 MFMA, and the bf16 hi/lo split)."""
-    from rpg_ramnet_amd import ops
-    ops.set_precision(request.param)
-    yield request.param
-    ops.set_precision("f32")
-
-
 def check_weights(model, z):
     """Seeded init (torch.manual_seed(0)) must reproduce the reference's weights (checksums in the fixture)."""
     for k, v in model.state_dict().items():
@@ -62,13 +53,13 @@ def run_fixture(tag, arch="ERGB2DepthRecurrent"):
 
 
 @pytest.mark.parametrize("tag", ["seeded_ramnet", "seeded_ramnet_lstm", "seeded_base_rgb"])
-def test_reference_golden_forward(tag, precision):
+def test_reference_golden_forward(tag):
     run_fixture(tag)
 
 
 @pytest.mark.parametrize("tag", ["small_gru", "small_lstm", "small_gru_enclstm", "small_tconv", "small_base_rgb",
                                  "small_base_e", "small_base_ergb0"])
-def test_reference_golden_explicit_weights(tag, precision):
+def test_reference_golden_explicit_weights(tag):
     """Narrow (base_num_channels=4) variants with the reference's own weights stored in the fixture: every wiring
     mode of ERGB2DepthRecurrent incl. ConvLSTM encoders, the transposed-conv decoder and the three baselines."""
     run_fixture(tag)
@@ -78,11 +69,11 @@ def test_reference_golden_unet_explicit_weights():
     run_fixture("small_unet", "ERGB2Depth")
 
 
-def test_reference_golden_unet(precision):
+def test_reference_golden_unet():
     run_fixture("seeded_unet", "ERGB2Depth")
 
 
-def test_baseline_config0_256x256(precision):
+def test_baseline_config0_256x256():
     """BASELINE.json configs[0]: single 256x256 frame + 1 event grid through ERGB2DepthRecurrent."""
     run_fixture("config1_256")
 

@@ -374,22 +374,40 @@ def test_multi_scale_grad_loss_vs_oracle(B, H, W, nan_frac):
 
 def test_depth_metrics_vs_reference_golden():
     """Next-row component: metric depth + Abs-Rel on device vs the reference's prepare_depth_data +
-    abs_rel_diff (golden), and vs the oracle for the remaining sums."""
+    abs_rel_diff (golden), and vs the oracle / a numpy restatement of evaluation.py:201-241 for the remaining sums."""
     from rpg_ramnet_amd import metrics
     z = load_golden("loss_metrics.npz")
+    eps = 1e-5
+
+    def reference_sums(t, p, mask):
+        """add_to_metrics (evaluation.py:211-238) on the masked pixels; NaN targets dropped where metric.py drops them."""
+        tm, pm = t[mask], p[mask]
+        ok = ~np.isnan(tm)
+        ratio = np.maximum(tm / (pm + eps), pm / (tm + eps))
+        ld = np.log(tm[ok] + eps) - np.log(pm[ok] + eps)
+        with np.errstate(invalid="ignore"):
+            out = {"threshold_delta_1.25": np.mean(ratio <= 1.25), "threshold_delta_1.25^2": np.mean(ratio <= 1.25 ** 2),
+                   "threshold_delta_1.25^3": np.mean(ratio <= 1.25 ** 3)}
+        out.update({"abs_rel_diff": loss_ref.abs_rel_diff(pm, tm), "squ_rel_diff": loss_ref.squ_rel_diff(pm, tm),
+                    "RMS_linear": loss_ref.rms_linear(pm, tm), "RMS_log": np.sqrt((ld ** 2).mean()),
+                    "SILog": loss_ref.scale_invariant_error(np.log(pm + eps), np.log(tm + eps)),
+                    "mean_depth_error": loss_ref.mean_error(pm, tm)})
+        return out, int(ok.sum())
+
     for clip, reg in [(80, 3.70378), (1000, 5.70378)]:
         t_in, p_in = z["depth%d.target_in" % clip], z["depth%d.pred_in" % clip]
         m = metrics.depth_metrics(torch.from_numpy(p_in).to(dev()), torch.from_numpy(t_in).to(dev()), float(clip), reg)
         np.testing.assert_allclose(m["abs_rel_diff"], float(z["depth%d.abs_rel" % clip]), rtol=2e-5)
         t, p = loss_ref.prepare_depth_data(t_in, p_in, float(clip), reg)
-        np.testing.assert_allclose(m["squ_rel_diff"], loss_ref.squ_rel_diff(p, t), rtol=2e-5)
-        np.testing.assert_allclose(m["rms_linear"], loss_ref.rms_linear(p, t), rtol=2e-5)
-        np.testing.assert_allclose(m["mean_error"], loss_ref.mean_error(p, t), rtol=2e-5)
-        assert m["n"] == t_in.size
+        want, n = reference_sums(t.astype(np.float64), p.astype(np.float64), np.ones(t.shape, bool))
+        assert m["n"] == n == t_in.size
+        for k, v in want.items():
+            np.testing.assert_allclose(m[k], v, rtol=5e-5, atol=1e-7, err_msg=k)
     tn = z["depth80.target_in"].copy()
     tn[::3, ::2] = np.nan
     m = metrics.depth_metrics(torch.from_numpy(z["depth80.pred_in"]).to(dev()), torch.from_numpy(tn).to(dev()), 80.0, 3.70378, cutoff=30.0)
     t, p = loss_ref.prepare_depth_data(tn, z["depth80.pred_in"], 80.0, 3.70378)
-    ok = ~np.isnan(t) & (np.nan_to_num(t, nan=1e9) <= 30.0)
-    np.testing.assert_allclose(m["abs_rel_diff"], (np.abs(t[ok] - p[ok]) / (t[ok] + 1e-6)).mean(), rtol=2e-5)
-    assert m["n"] == int(ok.sum())
+    want, n = reference_sums(t.astype(np.float64), p.astype(np.float64), np.nan_to_num(t) < 30.0)     # strict <, NaN -> inside
+    assert m["n"] == n
+    for k, v in want.items():
+        np.testing.assert_allclose(m[k], v, rtol=5e-5, atol=1e-7, err_msg=k)

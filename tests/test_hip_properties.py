@@ -91,24 +91,3 @@ def test_full_size_voxel_grid_checksums():
     nz = n[n != 0].double()
     assert abs(float(nz.mean())) < 1e-4 and abs(float(nz.std(unbiased=False)) - 1.0) < 1e-3
     assert torch.equal(n == 0, g == 0)
-
-
-def test_bf16x3_forward_operators_close_to_fp32():
-    """The split-operand contraction: forward of conv / upsample-conv / ConvGRU / ConvLSTM within 1e-4 of exact fp32."""
-    from rpg_ramnet_amd import ops
-    from rpg_ramnet_amd.model.submodules import ConvGRU, ConvLayer, ConvLSTM, UpsampleConvLayer
-    torch.manual_seed(3)
-    mods = [(ConvLayer(64, 128, 5, 2, 2), lambda m, x: m(x)), (UpsampleConvLayer(64, 32, 5, padding=2), lambda m, x: m(x, 0.5 * x)),
-            (ConvGRU(64, 64, 3), lambda m, x: m(x, torch.tanh(x))), (ConvLSTM(64, 64, 3), lambda m, x: m(x, (torch.tanh(x), x))[0])]
-    x = torch.randn(2, 24, 40, 64, device=dev())
-    try:
-        for m, f in mods:
-            m = m.to(dev())
-            with torch.no_grad():
-                ops.set_precision("f32")
-                y0 = f(m, x)
-                ops.set_precision("bf16x3")
-                y1 = f(m, x)
-            assert_close(y1.cpu().numpy(), y0.cpu().numpy(), 1e-4, type(m).__name__)
-    finally:
-        ops.set_precision("f32")
