@@ -11,9 +11,18 @@ through the reference network): forward through ERGB2DepthRecu
 = one data package of one batch element; value = N*B*L*K / max-over-ranks(time).
 Inputs are synthetic (device-generated event lists -> HIP voxel scatter-add -> nonzero normalisation; U[0,1) frames;
 log-depth targets) and resident in HBM before the timed region.  Weights: seeded random init (no checkpoints offline).
+
+Roofline accounting.  The convolutions are MFMA-bound.  Every MFMA launch is classified by the kernel the
+library reports (ramnet_last_kernel) and carries two FLOP counts: ALGORITHMIC (2*B*Ho*Wo*taps*Cin*Cout of the layer it
+stands for) and EXECUTED (what the MFMA pipe really multiplies: Winograd F(2x2,3x3) 16/36 of the 3x3 taps —
+16/25 for the stride-2 5x5 encoders run as 3x3 over the space-to-depth view —, F(2x2,4x4) 25/100 of a folded decoder).
+`roofline.achieved/frac` use the EXECUTED count (a fraction of the fp32 MFMA peak that cannot exceed 1);
+`roofline.algorithmic_achieved` is the layer-level rate.  `traffic` comes from the newest tracked
+profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes of this command, tools/pmc_traffic.py).
 """
 import argparse
 import contextlib
+import glob
 import json
 import os
 import sys
@@ -29,7 +38,8 @@ sys.path.insert(0, ROOT)
 RELEASED = dict(num_bins_rgb=1, num_bins_events=5, skip_type="sum", recurrent_block_type="conv",
                 state_combination="convgru", spatial_resolution=[112, 112], num_encoders=3, base_num_channels=32,
                 num_residual_blocks=2, use_upsample_conv=True, norm="none")
-F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+F32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32
+HBM_PEAK_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
 
 
 def parse():
@@ -56,29 +66,29 @@ def parse():
     ap.add_argument("--no-overlap-decoder", dest="overlap_decoder", action="store_false",
                     help="run the decoders on the main stream instead of a second stream concurrent with the next state update "
                          "(ops.set_decoder_overlap; default schedule)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) overlap / bf16x3 measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) single-stream measurements")
     return ap.parse_args()
 
 
 def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
-    """SURVEY section 8d recipe, generated on device; returns a list of L item dicts (NCHW device tensors)."""
+    """SURVEY section 8d recipe, generated on device; returns a list of L item dicts (NCHW device tensors).  The B x K event
+    lists of a package go through ONE batched scatter-add launch and one batched nonzero normalisation."""
     from rpg_ramnet_amd import voxel
     dev = model.gpu
     g = torch.Generator(device=dev).manual_seed(seed)
     seq = []
     for _ in range(L):
-        item = {}
+        item, lists = {}, []
+        for _k in range(K * B):
+            ev = torch.empty(n_events, 4, device=dev, dtype=torch.float64)
+            ev[:, 0] = torch.sort(torch.rand(n_events, device=dev, generator=g, dtype=torch.float64) * 0.05)[0]
+            ev[:, 1] = torch.randint(0, W, (n_events,), device=dev, generator=g).double()
+            ev[:, 2] = torch.randint(0, H, (n_events,), device=dev, generator=g).double()
+            ev[:, 3] = torch.randint(0, 2, (n_events,), device=dev, generator=g).double()
+            lists.append(ev)
+        grids = voxel.events_to_voxel_grids(lists, bins, W, H, dev, normalize=True).view(K, B, bins, H, W)
         for k in range(K):
-            grids = []
-            for _b in range(B):
-                ev = torch.empty(n_events, 4, device=dev, dtype=torch.float64)
-                ev[:, 0] = torch.sort(torch.rand(n_events, device=dev, generator=g, dtype=torch.float64) * 0.05)[0]
-                ev[:, 1] = torch.randint(0, W, (n_events,), device=dev, generator=g).double()
-                ev[:, 2] = torch.randint(0, H, (n_events,), device=dev, generator=g).double()
-                ev[:, 3] = torch.randint(0, 2, (n_events,), device=dev, generator=g).double()
-                grids.append(voxel.normalize_nonzero(voxel.events_to_voxel_grid(ev, bins, W, H)))
-            item["events%d" % k] = torch.stack(grids)
+            item["events%d" % k] = grids[k]
         item["image"] = torch.rand(B, 1, H, W, device=dev, generator=g)
         for key in ("image", "events%d" % (K - 1)):
             u = torch.rand(B, 1, H, W, device=dev, generator=g) * 0.98 + 0.02
@@ -87,136 +97,175 @@ def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
     return seq
 
 
+# ---------------------------------------------------------------------------------------------------------------- timing
+def winograd_factor(kernel):
+    """Multiplies the MFMA pipe executes per multiply of the tap list the launch was given: F(2x2,3x3) 16 per 36,
+    F(2x2,4x4) 25 per 64; direct kernels 1."""
+    if kernel.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel", "conv_gru_kernel")):
+        return 16.0 / 36.0
+    if kernel.startswith(("conv_wino24_kernel", "conv_wgrad_wino24_kernel")):
+        return 25.0 / 64.0
+    return 1.0
+
+
+# algorithmic HBM bytes of the HBM-bound library calls, from their C arguments (include/ramnet_hip.h; SURVEY 8d figures:
+# voxelizer 32 B/event + 2 atomic fp32 RMW (16 B) + grid zero-fill; SI loss 8 B/pixel; pred 4*(C+1) B/pixel)
+HBM_CALLS = {
+    "ramnet_voxelize": lambda a: 48.0 * a[1] + 4.0 * a[2] * a[3] * a[4],
+    "ramnet_voxelize_batch": lambda a: None,           # bytes filled in by the caller (needs the event count)
+    "ramnet_si_loss_fwd": lambda a: 8.0 * a[2],
+    "ramnet_si_loss_bwd": lambda a: 12.0 * a[2],
+    "ramnet_pred_sigmoid_fwd": lambda a: (4.0 * a[2] + 4.0) * a[6],
+    "ramnet_pred_sigmoid_bwd": lambda a: (8.0 * a[2] + 8.0) * a[10],
+    "ramnet_gru_bwd_a": lambda a: 28.0 * a[8] * a[7],
+    "ramnet_gru_bwd_b": lambda a: 24.0 * a[6] * a[5],
+    "ramnet_pad2_sum": lambda a: 4.0 * a[6] * a[3] * ((2 if a[1] else 1) * a[4] * a[5] + (a[4] + 4) * (a[5] + 4)),
+    "ramnet_relu_bwd": lambda a: 12.0 * a[3],
+    "ramnet_unpad2_fold": lambda a: 4.0 * a[5] * a[2] * (a[3] * a[4] + (a[3] + 4) * (a[4] + 4)),
+    "ramnet_nchw_to_nhwc_pad": lambda a: 4.0 * a[2] * a[4] * a[5] * (a[3] + a[6]),
+}
+
+
 class KernelTimer:
-    """HIP-event timing of every MFMA launch on the launch stream, keyed by kernel symbol."""
+    """HIP-event timing on the launch stream.  MFMA launches (ops.conv_launch / wgrad_launch / conv_launch_multi) are keyed by
+    the kernel symbol the library reports and carry algorithmic + executed FLOP; HBM-bound library calls (HBM_CALLS) are keyed
+    by their entry point and carry algorithmic bytes."""
 
     def __init__(self):
-        self.rec = []
+        self.rec = []           # (key, start, end, alg_flop, exec_flop, bytes, tag)
         self.on = False
         self.only = None        # when set: bracket only launches of this kernel symbol (keeps the timed region unperturbed)
+        self.hbm = False        # also bracket the HBM-bound calls (warm-up steps only)
+        self.names = {}         # launch signature -> kernel symbol
+
+    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None):
+        """sig: hashable launch signature -> kernel symbol, learnt while every launch is bracketed (warm-up); with `only` set,
+        launches whose signature maps to another symbol run un-bracketed.  tap_ratio = taps in the launch's list / taps of
+        the layer it stands for (16/25 folded decoder, 36/25 space-to-depth encoder, else 1)."""
+        if self.only is not None and self.names.get(sig, self.only) != self.only:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        name = self.names[sig] = name_of()
+        if self.only is not None and name != self.only:
+            return
+        self.rec.append((name, s, e, alg, alg * tap_ratio * winograd_factor(name), 0.0, tag))
 
     def install(self):
-        from rpg_ramnet_amd import ops
+        from rpg_ramnet_amd import ops, _hip as Hh
         timer = self
-        conv0, wgrad0 = ops.conv_launch, ops.wgrad_launch
+        conv0, wgrad0, multi0 = ops.conv_launch, ops.wgrad_launch, ops.conv_launch_multi
 
-        def variant(Cout, epi, B, Ho, Wo):
-            """Mirror of the tile-configuration choice in ramnet_conv_launch (csrc/conv_igemm.hip)."""
-            from rpg_ramnet_amd import _hip as Hh
-            if epi == Hh.EPI_LSTM:
-                return "conv_igemm_kernel<128,128,4,1,1>"
-            cp = (Cout + 31) // 32 * 32
-            bm, bn = 128, (128 if cp % 128 == 0 else 64 if cp % 64 == 0 else 32)
+        def last():
+            return Hh.lib().ramnet_last_kernel().decode()
 
-            def blocks(m, n):
-                return -(-Wo // 16) * -(-Ho // (m // 16)) * B * (cp // n)
-            if bn >= 64:
-                if blocks(bm, bn) < 768:
-                    bm = 64
-                if blocks(bm, bn) < 768 and bn == 128:
-                    bn = 64
-            if bn == 32 and -(-Wo // 16) * -(-Ho // 16) * B >= 1024:
-                bm = 256
-            return "conv_igemm_kernel<%d,%d,%s,1>" % (bm, bn, "4,1" if bn == 32 else "2,2")
+        def cin_of(x0, kw, w=None):
+            c = ((kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)) * (4 if kw.get("in_mode", 0) == Hh.IN_S2D else 1)
+            if isinstance(w, ops.PackRef) and not w.transposed:
+                c = min(c, w.cp.Cin)              # head layers: 1 / 5 / 10 real channels inside a padded quad
+            return c
+
+        def sig_of(kind, x0, taps, Cout, kw):
+            return (kind, tuple(x0.shape), id(taps), Cout) + tuple(kw.get(k) if not torch.is_tensor(kw.get(k)) else 1 for k in
+                                                                  ("stride", "in_mode", "C0", "C1", "epi", "Ho", "Wo", "wino24", "out_s2d", "beta", "frame", "gview"))
 
         def conv(x0, taps, w, out, Cout, **kw):
             if not timer.on:
                 return conv0(x0, taps, w, out, Cout, **kw)
             Ho, Wo = kw.get("Ho") or out.shape[1], kw.get("Wo") or out.shape[2]
-            name = variant(Cout, kw.get("epi", 0), x0.shape[0], Ho, Wo)
-            if ops.uses_winograd(taps, w, kw.get("stride", 1), kw.get("epi", 0), kw.get("in_mode", 0),
-                                 kw.get("C0") or x0.shape[3], kw.get("C1", 0)):
-                name = "conv_wino_kernel"
-            if ops.uses_head(taps, w, kw.get("stride", 1), kw.get("epi", 0), kw.get("in_mode", 0)):
-                name = "conv_head_fwd_kernel"
-            nclass = 1
-            if kw.get("wino24"):        # one launch = the four output parities of a folded decoder layer
-                name, nclass = "conv_wino24_kernel", 4
-            if timer.only is not None and name != timer.only:
-                return conv0(x0, taps, w, out, Cout, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            conv0(x0, taps, w, out, Cout, **kw)
-            e.record()
-            cin = ((kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)) * (4 if kw.get("in_mode", 0) == 6 else 1)   # IN_S2D: 4 parities
-            nout = Cout * (4 if kw.get("epi") == 5 else 1)
-            timer.rec.append((name, s, e, 2.0 * nclass * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout))
+            parity4 = kw.get("in_mode", 0) == Hh.IN_PARITY4
+            nclass = 4 if (kw.get("wino24") and not parity4) else 1
+            cin, nout = cin_of(x0, kw, w), Cout * (4 if kw.get("epi") == Hh.EPI_LSTM else 1)
+            ratio = taps.n / float(taps.flop_taps)
+            if parity4:     # decoder backward-data: stands for a 5x5 convolution over the full-resolution gradient; runs 16 taps
+                alg = 2.0 * x0.shape[0] * x0.shape[1] * x0.shape[2] * 25 * x0.shape[3] * Cout      # over 4*C0 channels on the
+                ratio = 16.0 * 4 * Ho * Wo / (25.0 * x0.shape[1] * x0.shape[2])                    # padded low-resolution grid
+            else:
+                alg = 2.0 * nclass * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout
+            tag = None
+            if kw.get("epi") in (Hh.EPI_SIGMOID, Hh.EPI_GRU_BLEND) and kw.get("in_mode", 0) in (Hh.IN_CAT, Hh.IN_CAT_MUL):
+                tag = "gru_fwd_C%d" % (kw.get("C1") or 0)
+            timer._bracket(lambda: conv0(x0, taps, w, out, Cout, **kw), last, sig_of("c", x0, taps, Cout, kw) + (isinstance(w, ops.PackRef),),
+                           alg, ratio, tag)
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:
                 return wgrad0(x0, taps, dout, dw, Cout, **kw)
-            cin = ((kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)) * (4 if kw.get("in_mode", 0) == 6 else 1)
-            tpm = 1 if cin > 16 else 8 if cin <= 4 else 4 if cin <= 8 else 2      # mirror of ramnet_wgrad_launch
-            ntt = -(-taps.n // tpm)
-            if Cout <= 32 or taps.n > 9:
-                per = -(-ntt // 4)
-                name = "conv_wgrad_kernel<%d,1,1>" % (1 if per <= 1 else 3 if per <= 3 else 4 if per <= 4 else 7)
-            elif (taps.n > 1 and cin >= 64 and
-                  -(-dout.shape[2] // 16) * -(-dout.shape[1] // 8) * dout.shape[0] * -(-cin // 64) * -(-Cout // 64) >= 2048):
-                name = "conv_wgrad_kernel<9,2,2>"
-            else:
-                per = -(-ntt // 2)
-                name = "conv_wgrad_kernel<%d,2,1>" % (1 if per <= 1 else 5)
-            if getattr(dw, "wino", False):         # Winograd backward-weights (template flags: loader operand, ReLU mask on dy)
-                from rpg_ramnet_amd import _hip as Hh
-                name = "conv_wgrad_wino_kernel<%d,%d>" % (kw.get("in_mode", 0) in (Hh.IN_RELUMASK, Hh.IN_CAT_MUL), kw.get("gmask") is not None)
-            nclass = 1
-            if kw.get("wino24"):
-                name, nclass = "conv_wgrad_wino24_kernel", 4
-            if getattr(dw, "head_cin", 0) and ops.get_head_kernel() and taps.head and kw.get("stride", 1) == 1 and kw.get("in_mode", 0) == 0 \
-                    and kw.get("gview") is None:
-                name = "conv_head_wgrad_kernel"
-            if timer.only is not None and name != timer.only:
-                return wgrad0(x0, taps, dout, dw, Cout, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            wgrad0(x0, taps, dout, dw, Cout, **kw)
-            e.record()
-            ho, wo = kw.get("Ho") or dout.shape[1], kw.get("Wo") or dout.shape[2]       # (parity sub-grid of the folded upsample-conv)
-            timer.rec.append((name, s, e, 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout))
-
-        multi0 = ops.conv_launch_multi
+            ho, wo = kw.get("Ho") or dout.shape[1], kw.get("Wo") or dout.shape[2]     # (parity sub-grid of a folded decoder)
+            nclass = 4 if kw.get("wino24") else 1
+            cin = getattr(dw, "head_cin", 0) or cin_of(x0, kw)
+            alg = 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout
+            timer._bracket(lambda: wgrad0(x0, taps, dout, dw, Cout, **kw), last,
+                           sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "head_cin", 0)),
+                           alg, taps.n / float(taps.flop_taps))
 
         def multi(x0, w, out, Cout, classes, **kw):
             if not timer.on:
                 return multi0(x0, w, out, Cout, classes, **kw)
-            tiles = sum(-(-Wo // 16) * -(-Ho // 8) for _, Ho, Wo, _ in classes) * x0.shape[0]
-            cp = (Cout + 31) // 32 * 32
-            bm, bn = 128, (128 if cp % 128 == 0 else 64 if cp % 64 == 0 else 32)
-            if bn >= 64:
-                if tiles * (cp // bn) < 768:
-                    bm = 64
-                    tiles = sum(-(-Wo // 16) * -(-Ho // 4) for _, Ho, Wo, _ in classes) * x0.shape[0]
-                if tiles * (cp // bn) < 768 and bn == 128:
-                    bn = 64
-            if bn == 32 and sum(-(-Wo // 16) * -(-Ho // 16) for _, Ho, Wo, _ in classes) * x0.shape[0] >= 1024:
-                bm = 256
-            name = "conv_igemm_kernel<%d,%d,%s,1>" % (bm, bn, "4,1" if bn == 32 else "2,2")
-            if timer.only is not None and name != timer.only:
-                return multi0(x0, w, out, Cout, classes, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            multi0(x0, w, out, Cout, classes, **kw)
-            e.record()
-            cin = (kw.get("C0") or x0.shape[3]) + kw.get("C1", 0)
-            fl = sum(2.0 * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * Cout for taps, Ho, Wo, _ in classes)
-            timer.rec.append((name, s, e, fl))
+            cin = cin_of(x0, kw)
+            alg = sum(2.0 * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * Cout for taps, Ho, Wo, _ in classes)
+            ex = sum(2.0 * x0.shape[0] * Ho * Wo * taps.n * cin * Cout for taps, Ho, Wo, _ in classes)
+            timer._bracket(lambda: multi0(x0, w, out, Cout, classes, **kw), last,
+                           sig_of("m", x0, classes[0][0], Cout, kw) + (len(classes), classes[0][1], classes[0][2]), alg, ex / alg)
 
         ops.conv_launch, ops.wgrad_launch, ops.conv_launch_multi = conv, wgrad, multi
 
-    def summary(self):
+        def tracer(name, fn, args):
+            f = HBM_CALLS.get(name)
+            if f is None or not (timer.on and timer.hbm):
+                return fn(*args)
+            vals = [getattr(a, "value", a) for a in args]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            timer.rec.append((name, s, e, 0.0, 0.0, f(vals) or 0.0, None))
+            return rc
+        self.tracer = tracer
+
+    def summary(self, by_tag=False):
         agg = {}
-        for name, s, e, fl in self.rec:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
+        for name, s, e, alg, ex, nbytes, tag in self.rec:
+            key = tag if by_tag else name
+            if key is None:
+                continue
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e) * 1e-3
-            a[2] += fl
+            a[2] += alg
+            a[3] += ex
+            a[4] += nbytes
         return agg
 
 
+def newest_pmc_traffic():
+    """The newest tracked PMC summary (tools/pmc_traffic.py): {kernel: {grid: {launches, hbm_bytes_per_launch}}}."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_hbm_traffic.json")))
+    if not files:
+        raise FileNotFoundError("no profiles/r*_pmc_hbm_traffic.json: run the rocprofv3 --pmc passes (tools/pmc_traffic.py) and commit it")
+    return os.path.basename(files[-1]), json.load(open(files[-1]))
+
+
+def traffic_of(pmc, name):
+    """Launch-weighted HBM bytes per launch of kernel symbol `name` (template arguments: rocprofv3 prints ", " separators)."""
+    want = name.replace(" ", "")
+    hit = None
+    for k, ent in pmc.items():
+        kk = k.replace(" ", "").replace("(bool)", "").replace("true", "1").replace("false", "0")
+        if kk == want or kk.split("<")[0] == want:
+            hit = ent if hit is None else {**hit, **{g + "'": v for g, v in ent.items()}}
+    if not hit:
+        return None
+    n = sum(v["launches"] for v in hit.values())
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit.values()) / max(1, n)
+
+
 def cpu_baseline(cfg, H, W, K, args):
-    """The oracle (CPU restatement, fixture-pinned to the reference) timed on this box's host cores on a bounded
-    sample of the same workload: one training step (fwd + SI loss + BPTT bwd) of B=1, L=1 at the bench resolution."""
+    """The oracle (CPU restatement, fixture-pinned to the reference) timed on this box's host cores on a bounded sample of the
+    same workload: one untimed warm-up step at B=1, L=1, then ONE full training step — forward, SI loss
+    on [image, events4], BPTT backward, Adam — at B=8, L=2 (a quarter of the L=8 sequence; the step is linear in L)."""
     from oracle import ramnet_ref
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from recipe import make_item
@@ -225,21 +274,33 @@ def cpu_baseline(cfg, H, W, K, args):
     with contextlib.redirect_stdout(sys.stderr):      # the constructor prints (like the reference's); stdout carries ONE JSON line
         m = ERGB2DepthRecurrent(cfg)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=3e-4)
     rng = np.random.default_rng(0)
     cores = torch.get_num_threads()
-    B, L = 2, 2                                   # ~10-30 s of CPU work on the GPU box's host cores
-    seq = [make_item(rng, B, H, W, K, cfg["num_bins_events"], 1, True, 0.0) for _ in range(L)]
     lc = cfg["loss_composition"]
-    t0 = time.time()
-    if args.mode == "train":
-        total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
-        total.backward()
-    else:
-        with torch.no_grad():
-            ramnet_ref.forward_recurrent(sd, cfg, seq[0], None, ramnet_ref.empty_states_lstm(K))
-    dt = time.time() - t0
+
+    def run(B, L):
+        seq = [make_item(rng, B, H, W, K, cfg["num_bins_events"], 1, True, 0.0) for _ in range(L)]
+        t0 = time.time()
+        if args.mode == "train":
+            opt.zero_grad()
+            total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
+            total.backward()
+            opt.step()
+        else:
+            with torch.no_grad():
+                prev, lstm = None, ramnet_ref.empty_states_lstm(K)
+                for item in seq:
+                    _, supers, lstm = ramnet_ref.forward_recurrent(sd, cfg, item, prev, lstm)
+                    prev = supers["image"]
+        return time.time() - t0
+
+    warm = run(1, 1)
+    B, L = args.batch, 2
+    dt = run(B, L)
     return {"value": B * L / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%s step, B=%d L=%d K=%d %dx%d fp32 torch-CPU oracle, %.1f s" % (args.mode, B, L, K, H, W, dt)}
+            "sample": "%s step (fwd, SI loss, BPTT bwd, Adam), B=%d L=%d K=%d %dx%d fp32 torch-CPU oracle, %.1f s after a %.1f s "
+                      "B=1 L=1 warm-up step" % (args.mode, B, L, K, H, W, dt, warm)}
 
 
 def main():
@@ -261,8 +322,7 @@ def main():
     from rpg_ramnet_amd.parallel import FlatGradReducer
     from rpg_ramnet_amd.trainer import sequence_loss, empty_states_lstm
 
-    from rpg_ramnet_amd import ops
-    ops.set_precision(args.precision)
+    from rpg_ramnet_amd import ops, _hip as Hh
     ops.set_wgrad_overlap(args.overlap_wgrad)
     ops.set_decoder_overlap(args.overlap_decoder)
     K, bins, B, L, H, W = 5, args.bins, args.batch, args.seq_len, args.height, args.width
@@ -272,10 +332,23 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):
         model = ERGB2DepthRecurrent(cfg)
     model = model.to(model.gpu)
-    seq = synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=1000 + rank)
     timer = KernelTimer()
     if not args.no_kernel_timing:
         timer.install()
+        Hh.set_tracer(timer.tracer)
+    # input side (outside the timed region): B*K event lists per package through the batched voxeliser, bracketed once
+    timer.on = timer.hbm = not args.no_kernel_timing
+    seq = synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=1000 + rank)
+    torch.cuda.synchronize()
+    vox = timer.summary().get("ramnet_voxelize_batch")
+    timer.rec, timer.on, timer.hbm = [], False, False
+
+    ranks_seen = [0]
+    if world > 1:      # every rank reports in over the collective backend: the driver's SCALE run can confirm N ranks took part
+        t = torch.full((1,), float(rank), device=model.gpu)
+        got = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        ranks_seen = sorted(int(v.item()) for v in got)
 
     if args.mode == "train":
         model.train()
@@ -324,15 +397,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up steps bracket EVERY MFMA launch with HIP events (per-kernel table + choice of the dominant symbol); in the
-    # timed region only the dominant symbol's launches are bracketed: ~7000 event pairs per step cost 3-4 % of the step.
+    # Warm-up steps bracket EVERY MFMA launch and every HBM-bound call with HIP events (per-kernel tables + choice of the
+    # dominant symbol); in the timed region only the dominant symbol's launches are bracketed: ~7000 event pairs per step cost
+    # 3-4 % of the step, ~1000 cost < 0.5 %.
     last = None
-    timer.on = not args.no_kernel_timing
+    timer.on = timer.hbm = not args.no_kernel_timing
     for _ in range(args.warmup):
         last = step()
     fence()
-    warm = timer.summary()
-    timer.rec = []
+    warm = {k: v for k, v in timer.summary().items() if not k.startswith("ramnet_")}
+    warm_hbm = {k: v for k, v in timer.summary().items() if k.startswith("ramnet_")}
+    timer.rec, timer.hbm = [], False
     if warm:
         timer.only = max(warm.items(), key=lambda kv: kv[1][1])[0]
     t0 = time.perf_counter()
@@ -350,103 +425,108 @@ def main():
     loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
-    # ---- extras (outside the timed region that defines `value`): the same step with (a) backward-weights overlapped on a
-    # side stream, (b) the bf16x3 split-operand contraction for forward/backward-data.  2 steps each, 1 warm-up.
-    extras = {}
-    if not args.no_extras and args.mode == "train" and world == 1:
-        def measure(n=2):
-            step()
-            fence()
-            t = time.perf_counter()
-            for _ in range(n):
-                lv = step()
-            fence()
-            e = (time.perf_counter() - t) / n
-            return {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach())}
-        single = not (args.overlap_wgrad or args.overlap_decoder)          # the other schedule: everything on one stream
-        ops.set_wgrad_overlap(single)
-        ops.set_decoder_overlap(single)
-        if not single and timer.only is not None:      # ... with the dominant kernel bracketed: its un-co-scheduled duration
-            timer.on, timer.rec = True, []
-        extras["multi_stream" if single else "single_stream"] = measure()
-        if timer.on:
-            timer.on = False
-            iso = timer.summary().get(timer.only)
-            timer.rec = []
-            if iso:
-                extras["single_stream"]["dominant_kernel"] = {
-                    "kernel": timer.only, "launches": iso[0], "avg_launch_ms": 1e3 * iso[1] / iso[0],
-                    "achieved": iso[2] / iso[1] / 1e12, "unit": "TFLOP/s", "frac": iso[2] / iso[1] / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                    "note": "same kernel with every launch on ONE stream: the timed region co-schedules three streams, so its "
-                            "per-kernel wall durations include time shared with other kernels"}
+    # ---- extras (outside the timed region that defines `value`): the same step with every launch on ONE stream — per-kernel
+    # durations without co-scheduled neighbours (dominant kernel, and the ConvGRU state update per scale).  2 steps, 1 warm-up.
+    extras, gru_step = {}, None
+    if not args.no_extras and args.mode == "train" and world == 1 and (args.overlap_wgrad or args.overlap_decoder):
+        ops.set_wgrad_overlap(False)
+        ops.set_decoder_overlap(False)
+        step()
+        fence()
+        timer.only, only = None, timer.only
+        timer.on, timer.rec = not args.no_kernel_timing, []
+        t = time.perf_counter()
+        for _ in range(2):
+            lv = step()
+        fence()
+        e = (time.perf_counter() - t) / 2
+        timer.on = False
+        extras["single_stream"] = {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach())}
+        iso = timer.summary().get(only)
+        gru_step = timer.summary(by_tag=True)
+        timer.rec, timer.only = [], only
+        if iso:
+            extras["single_stream"]["dominant_kernel"] = {
+                "kernel": only, "launches": iso[0], "avg_launch_ms": 1e3 * iso[1] / iso[0],
+                "achieved": iso[3] / iso[1] / 1e12, "unit": "TFLOP/s (executed)", "frac": iso[3] / iso[1] / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                "algorithmic_achieved": iso[2] / iso[1] / 1e12}
         ops.set_wgrad_overlap(args.overlap_wgrad)
         ops.set_decoder_overlap(args.overlap_decoder)
-        if args.precision == "f32":
-            ops.set_precision("bf16x3")
-            extras["bf16x3_fwd_dgrad"] = dict(measure(), note="forward parity <= 1e-3 vs reference goldens is tested in "
-                                              "tests/test_hip_model.py[bf16x3]; backward-weights stays fp32")
-            ops.set_precision("f32")
 
     if rank == 0:
         samples = world * B * L * args.steps
         if args.mode == "stream":
             updates = world * B * (sum(sched) + L) * args.steps
-        out = {"metric": "depth samples/sec (346x260 cropped to %dx%d, 5-bin grids, K=5 grids + 1 frame per sample; %s)"
-                         % (H, W, {"train": "training step", "infer": "inference", "stream": "asynchronous streaming inference"}[args.mode]),
+        out = {"metric": "depth samples/sec (346x260 cropped to %dx%d, %d-bin grids, K=5 grids + 1 frame per sample; %s)"
+                         % (H, W, bins, {"train": "training step", "infer": "inference", "stream": "asynchronous streaming inference"}[args.mode]),
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.precision == "f32" else "bf16x3(fwd,dgrad)+f32(wgrad)", "data": "synthetic",
-               "config": {"workload": "EventScape-shaped 346x260 -> %dx%d crop, 5 event bins, K=5, batch %d/GPU, seq-len %d, "
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "EventScape-shaped 346x260 -> %dx%d crop, %d event bins, K=5, batch %d/GPU, seq-len %d, "
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam, backward-weights %s"
-                                      % (H, W, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream") +
+                                      % (H, W, bins, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream") +
                                       (", decoders on a second stream" if args.overlap_decoder and args.mode == "train" else ""),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
-               "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+               "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+               "rccl_ranks_seen": ranks_seen, "backend": (args.backend if world > 1 else None)}
         if args.mode == "stream":
             out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
                              "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "
                              "state + decode one depth map; samples/s counts frames"}
         if extras:
             out["extras"] = extras
-        agg = agg_timed
-        if agg:
-            dom = max(agg.items(), key=lambda kv: kv[1][1])
-            name, (n, secs, flops) = dom
-            ach = flops / secs / 1e12
-            traffic = None
-            try:    # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_p_pmc_hbm_traffic.json")))      # tools/pmc_traffic.py
-                ent = pmc.get(name.replace(",1>", ",0>") if name.startswith("conv_igemm") else name)
-                if ent:
-                    traffic = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ent.values()) /
-                               max(1, sum(v["launches"] for v in ent.values())))
-            except (OSError, ValueError, KeyError):
-                pass
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                               "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB, launch-weighted over the kernel's grids, "
-                                               "from profiles/r01_p_pmc_*; gfx950 FETCH_SIZE counts 1/2 of wide reads (MI355X_MICROARCH.md)",
-                               "launches": n, "avg_launch_ms": 1e3 * secs / n,
-                               "algorithmic_gflop_per_launch": flops / n / 1e9}
-            iso = extras.get("single_stream", {}).get("dominant_kernel")
-            if iso and iso["kernel"] == name:      # the same kernel without co-scheduled neighbours (single-stream extras pass)
-                out["roofline"].update({"isolated_achieved": iso["achieved"], "isolated_frac": iso["frac"],
-                                        "isolated_avg_launch_ms": iso["avg_launch_ms"],
-                                        "schedule_note": "the timed region runs three streams (main, decoders, backward-weights): achieved/frac use "
-                                                         "wall durations that include time shared with co-scheduled kernels; isolated_* = same "
-                                                         "kernel, same launches, one stream (extras.single_stream)"})
-            if "wino" in name:   # Winograd F(2x2,3x3) executes 16/36 of the algorithmic multiplies on the MFMA pipe
-                out["roofline"]["mfma_flop_executed_frac_of_peak"] = out["roofline"].get("isolated_achieved", ach) / 2.25 / F32_MFMA_PEAK_TFLOPS
-                out["roofline"]["note"] = ("achieved/frac count the ALGORITHMIC FLOP of the convolution (2*B*H*W*9*Cin*Cout, SURVEY 8d) as the "
-                                           "contract asks; the kernel executes 1/2.25 of them (Winograd), see mfma_flop_executed_frac_of_peak")
-            src = warm if warm else agg
+        if agg_timed:
+            name, (n, secs, alg, ex, _) = max(agg_timed.items(), key=lambda kv: kv[1][1])
+            pmc_file, pmc = newest_pmc_traffic()
+            out["roofline"] = {
+                "bound": "mfma", "kernel": name, "achieved": ex / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic_of(pmc, name), "traffic_source": "profiles/" + pmc_file,
+                "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                "executed_gflop_per_launch": ex / n / 1e9, "algorithmic_gflop_per_launch": alg / n / 1e9,
+                "algorithmic_achieved": alg / secs / 1e12,
+                "note": "achieved/frac = EXECUTED MFMA FLOP (Winograd: 16/36 of the 3x3 layer's, 16/25 for space-to-depth encoders) over "
+                        "HIP-event durations of this kernel in the timed region, which co-schedules three streams (main, decoders, "
+                        "backward-weights) — wall durations include time shared with other kernels; extras.single_stream.dominant_kernel "
+                        "= same launches on one stream.  algorithmic_achieved = layer-level rate (SURVEY 8d count).  traffic = HBM bytes "
+                        "per launch, (2*FETCH_SIZE + WRITE_SIZE), launch-weighted over the kernel's grids (gfx950 FETCH_SIZE counts 1/2 "
+                        "of wide reads, MI355X_MICROARCH.md)"}
             if warm and args.warmup > 0:      # overlap-proof view: all MFMA FLOP of a step over the step's wall time
-                step_flop = sum(v[2] for v in warm.values()) / args.warmup
-                out["step_mfma"] = {"algorithmic_tflop_per_step": step_flop / 1e12,
-                                    "achieved": step_flop / (dt / args.steps) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
-                                    "unit": "TFLOP/s", "frac": step_flop / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS}
-            out["kernels_warmup_steps"] = {k: {"launches": v[0], "ms": 1e3 * v[1], "tflops": v[2] / v[1] / 1e12}
-                                           for k, v in src.items()}
+                step_alg = sum(v[2] for v in warm.values()) / args.warmup
+                step_ex = sum(v[3] for v in warm.values()) / args.warmup
+                out["step_mfma"] = {"executed_tflop_per_step": step_ex / 1e12, "algorithmic_tflop_per_step": step_alg / 1e12,
+                                    "achieved": step_ex / (dt / args.steps) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": step_ex / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                    "algorithmic_achieved": step_alg / (dt / args.steps) / 1e12}
+                out["kernels_warmup_steps"] = {
+                    k: {"launches": v[0], "ms": 1e3 * v[1], "executed_tflops": v[3] / v[1] / 1e12,
+                        "mfma_frac": v[3] / v[1] / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_tflops": v[2] / v[1] / 1e12,
+                        "hbm_bytes_per_launch": traffic_of(pmc, k)} for k, v in warm.items()}
+                hb = {k[len("ramnet_"):]: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "algorithmic_mb_per_launch": v[4] / v[0] / 1e6,
+                                           "achieved_tb_s": v[4] / v[1] / 1e12, "hbm_frac": v[4] / v[1] / 1e12 / HBM_PEAK_TBS}
+                      for k, v in warm_hbm.items() if v[4] > 0}
+                if vox:     # input side: B*K grids per launch, 48 B per event (32 B read + two fp32 atomic RMW) + the grid zero-fill
+                    nb = L * (48.0 * args.events_per_grid * B * K + 4.0 * B * K * bins * H * W)
+                    hb["voxelize_batch"] = {"launches": vox[0], "avg_us": 1e6 * vox[1] / vox[0], "algorithmic_mb_per_launch": nb / vox[0] / 1e6,
+                                            "achieved_tb_s": nb / vox[1] / 1e12, "hbm_frac": nb / vox[1] / 1e12 / HBM_PEAK_TBS,
+                                            "note": "one launch = the %d grids of a package-batch (%d events each); outside the timed step" % (B * K, args.events_per_grid)}
+                out["hbm_kernels"] = dict(hb, peak_tb_s=HBM_PEAK_TBS, note="HBM-bound kernels against the 8 TB/s HBM peak; warm-up steps, "
+                                          "three-stream schedule (durations include co-scheduled time)")
+            if gru_step:
+                # ConvGRU step algorithmic bytes = x read + h read + h' write (+ weights once); FLOP = 3 convs 3x3 2C->C
+                gs = {}
+                for tag, v in sorted(gru_step.items()):
+                    C = int(tag.split("C")[-1])
+                    div = C // 32
+                    npx = B * (H // div) * (W // div)
+                    nbytes = 3.0 * 4 * C * npx + 4.0 * 27 * 2 * C * C
+                    steps_n = v[0] / 2.0                       # two launches per state update
+                    ms = 1e3 * v[1] / steps_n
+                    gs["C%d" % C] = {"ms": ms, "algorithmic_bytes": nbytes, "hbm_frac": nbytes / (ms * 1e-3) / 1e12 / HBM_PEAK_TBS,
+                                     "mfma_frac": v[3] / v[1] / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                     "algorithmic_tflops": v[2] / v[1] / 1e12, "launches_per_step": v[0] / steps_n}
+                out["roofline"]["gru_step"] = dict(gs, note="forward ConvGRU state update per scale (submodules.py:436-454), single-stream "
+                                                   "pass: the step is MFMA-bound (530-810 FLOP/B vs a 20 FLOP/B ridge), so its HBM fraction "
+                                                   "is low BECAUSE it is compute-bound (SURVEY 8d); mfma_frac = executed-MFMA fraction")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, H, W, K, args)
         print(json.dumps(out))

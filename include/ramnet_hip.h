@@ -128,6 +128,9 @@ typedef struct ramnet_wgrad_desc {
 
 const char *ramnet_last_error(void);
 int ramnet_abi_version(void);
+/* Symbol (template arguments included, as rocprofv3 prints it without spaces) of the MFMA kernel the calling thread's most
+ * recent ramnet_conv_launch / ramnet_conv_launch_multi / ramnet_wgrad_launch enqueued; "" before the first launch.  For profilers. */
+const char *ramnet_last_kernel(void);
 
 /* ---- layout plumbing -------------------------------------------------------------------------- */
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] zero-padded (model inputs: model.py:177,200 `.to(self.gpu)`). */
@@ -249,6 +252,13 @@ int ramnet_voxel_indices(const double *events, size_t n_events, int bins, int W,
                          long long *idx_left, long long *idx_right, void *stream);
 /* zero-mean/unit-std over non-zero entries, in place; scratch: 3 doubles.                          */
 int ramnet_normalize_nonzero(float *grid, size_t n, double *scratch, void *stream);
+/* Batched forms (one launch for the B x K grids of a batch of packages): event lists concatenated in `events`, list g =
+ * rows offsets[g] .. offsets[g+1] (device int64 [n_grids+1]; each list sorted by t, normalised by ITS first / last stamp),
+ * max_events = longest list; grids [n_grids][bins][H][W] (zeroed here).  normalize: n = bins*H*W (multiple of 4) per grid,
+ * scratch = 3*n_grids doubles.  Same arithmetic per grid as the single-grid entry points.                             */
+int ramnet_voxelize_batch(const double *events, const long long *offsets, int n_grids, size_t max_events, int bins, int W, int H,
+                          float *grids, void *stream);
+int ramnet_normalize_nonzero_batch(float *grids, int n_grids, size_t n, double *scratch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,7 @@ class WgradDesc(C.Structure):
 _SIGS = {
     "ramnet_abi_version": (C.c_int, []),
     "ramnet_last_error": (C.c_char_p, []),
+    "ramnet_last_kernel": (C.c_char_p, []),
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -98,10 +99,31 @@ _SIGS = {
     "ramnet_voxelize": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ramnet_voxel_indices": (C.c_int, [_fp, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ramnet_normalize_nonzero": (C.c_int, [_fp, C.c_size_t, _fp, _fp]),
+    "ramnet_voxelize_batch": (C.c_int, [_fp, _fp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ramnet_normalize_nonzero_batch": (C.c_int, [_fp, C.c_int, C.c_size_t, _fp, _fp]),
 }
 EXPORTS = tuple(_SIGS)
 
 _lib = None
+_tracer = None          # profiling hook: tracer(name, fn, args) -> result, for every ramnet_* call (bench.py); None = direct calls
+
+
+class _Traced:
+    def __init__(self, l):
+        self._l = l
+
+    def __getattr__(self, name):
+        fn = getattr(self._l, name)
+        tr = _tracer
+        if tr is None:
+            return fn
+        return lambda *a: tr(name, fn, a)
+
+
+def set_tracer(fn):
+    """Route every library call through fn(name, c_function, args) (None restores direct calls)."""
+    global _tracer
+    _tracer = fn
 
 
 class HipLibraryMissing(RuntimeError):
@@ -129,7 +151,7 @@ def lib():
         if l.ramnet_abi_version() != 11:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
-    return _lib
+    return _lib if _tracer is None else _Traced(_lib)
 
 
 def check(code, what):

@@ -235,6 +235,7 @@ int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st) {
     auto go = [&](auto kern, int cr) -> int {
         const size_t lds = (size_t)(((cr * (HG_H + 4) * HP_LD + 3) & ~3) + HG_H * HT_W * HG_LD) * sizeof(float);
         RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        note_kernel("conv_head_wgrad_kernel<%d>", cr);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, q);
         return 0;
     };
@@ -268,6 +269,7 @@ int launch_head(const ramnet_conv_desc &d, hipStream_t st) {
     q.ld = d.ld0, q.ldo = d.ldo, q.B = d.B, q.H = d.Hin, q.W = d.Win, q.Cout = d.Cout, q.relu = d.epi == RAMNET_EPI_RELU;
     q.tiles_x = cdiv(d.Wo, HT_W), q.tiles_y = cdiv(d.Ho, HF_H);
     const dim3 grid(q.tiles_x * q.tiles_y * d.B);
+    note_kernel("conv_head_fwd_kernel<%d>", d.head_cin == 1 ? 1 : d.head_cin == 3 ? 3 : 5);
     if (d.head_cin == 1) hipLaunchKernelGGL(conv_head_fwd_kernel<1>, grid, dim3(256), 0, st, q);
     else if (d.head_cin == 3) hipLaunchKernelGGL(conv_head_fwd_kernel<3>, grid, dim3(256), 0, st, q);
     else hipLaunchKernelGGL(conv_head_fwd_kernel<5>, grid, dim3(256), 0, st, q);

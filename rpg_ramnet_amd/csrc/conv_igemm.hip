@@ -203,6 +203,7 @@ static int launch_cfg(const ramnet_conv_desc &d, const ConvCommon &qc, const Con
         return RAMNET_E_UNSUPPORTED;
     }
     dim3 grid(max_tiles * d.B, qc.CoutPad / BN, qc.nclass);
+    note_kernel("conv_igemm_kernel<%d,%d,%d,%d>", BM, BN, WM, WN);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, qc, qk);
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -180,6 +180,7 @@ static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipSt
     int splits = (se ? atoi(se) : 512) / (gy * gz);
     if (splits > q.ntiles) splits = q.ntiles;
     if (splits < 1) splits = 1;
+    note_kernel("conv_wgrad_kernel<%d,%d,%d>", MAXT, NSUB, CSUB);
     hipLaunchKernelGGL(kern, dim3(splits, gy, gz), dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -448,6 +448,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     }
     const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
+    note_kernel("conv_wino_kernel");
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -255,6 +255,23 @@ __global__ void voxelize_kernel(const double *__restrict__ ev, size_t n, int bin
     }
 }
 
+// G event lists in ONE launch (a batch of B x K grids): blockIdx.y = grid; list g = events[off[g] .. off[g+1]) with its own
+// first / last timestamp, scattered into grids[g].
+__global__ void voxelize_batch_kernel(const double *__restrict__ ev, const long long *__restrict__ off, int bins, int W, int H,
+                                      float *__restrict__ grids) {
+    const int g = blockIdx.y;
+    const long long e0 = off[g], n = off[g + 1] - e0;
+    const double *e = ev + (size_t)e0 * 4;
+    float *grid = grids + (size_t)g * bins * W * H;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * blockDim.x) {
+        long long il, ir;
+        float vl, vr;
+        voxel_event(e, i, (size_t)n, bins, W, H, il, vl, ir, vr);
+        if (il >= 0) atomicAdd(grid + il, vl);
+        if (ir >= 0) atomicAdd(grid + ir, vr);
+    }
+}
+
 __global__ void voxel_indices_kernel(const double *__restrict__ ev, size_t n, int bins, int W, int H, long long *il_out, long long *ir_out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         long long il, ir;
@@ -277,6 +294,48 @@ __global__ void nonzero_stats_kernel(const float *__restrict__ g, size_t n, doub
     if (lane == 0) red[0][wave] = s1, red[1][wave] = s2, red[2][wave] = cnt;
     __syncthreads();
     if (threadIdx.x < 3) atomicAdd(stats + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// batched forms: blockIdx.y = grid, stats[3*g ..]
+__global__ void nonzero_stats_batch_kernel(const float *__restrict__ grids, size_t n, double *stats) {
+    const float *g = grids + (size_t)blockIdx.y * n;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i + 3 < n) {
+            const float4 q = ld4(g + i);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+            for (size_t j = i; j < n; ++j) v[j - i] = g[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1 += (double)v[j], s2 += (double)v[j] * (double)v[j], cnt += v[j] != 0.f ? 1.0 : 0.0;
+    }
+    __shared__ double red[3][4];
+    s1 = wave_sum(s1), s2 = wave_sum(s2), cnt = wave_sum(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[0][wave] = s1, red[1][wave] = s2, red[2][wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 3)
+        atomicAdd(stats + 3 * blockIdx.y + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void normalize_nonzero_batch_kernel(float *__restrict__ grids, size_t n, const double *__restrict__ stats) {
+    float *g = grids + (size_t)blockIdx.y * n;
+    const double cnt = stats[3 * blockIdx.y + 2];
+    if (cnt == 0.0) return;
+    const float mean = (float)(stats[3 * blockIdx.y] / cnt);
+    const float sd = sqrtf((float)(stats[3 * blockIdx.y + 1] / cnt) - mean * mean);
+    for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            float4 q = ld4(g + i);
+            q.x = q.x != 0.f ? (q.x - mean) / sd : 0.f, q.y = q.y != 0.f ? (q.y - mean) / sd : 0.f;
+            q.z = q.z != 0.f ? (q.z - mean) / sd : 0.f, q.w = q.w != 0.f ? (q.w - mean) / sd : 0.f;
+            st4(g + i, q);
+        } else {
+            for (size_t j = i; j < n; ++j) g[j] = g[j] != 0.f ? (g[j] - mean) / sd : 0.f;
+        }
+    }
 }
 
 __global__ void normalize_nonzero_kernel(float *__restrict__ g, size_t n, const double *__restrict__ stats) {
@@ -364,6 +423,35 @@ extern "C" int ramnet_voxelize(const double *events, size_t n_events, int bins, 
     if (n_events == 0) return 0;
     RAMNET_CHECK_ARG(events != nullptr);
     hipLaunchKernelGGL(voxelize_kernel, dim3(grid_for(n_events)), dim3(256), 0, st, events, n_events, bins, W, H, grid);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_voxelize_batch(const double *events, const long long *offsets, int n_grids, size_t max_events, int bins, int W,
+                                     int H, float *grids, void *stream) {
+    RAMNET_CHECK_ARG(grids && offsets && n_grids > 0 && n_grids <= 65535 && bins > 0 && W > 0 && H > 0);
+    hipStream_t st = (hipStream_t)stream;
+    RAMNET_HIP(hipMemsetAsync(grids, 0, (size_t)n_grids * bins * W * H * sizeof(float), st));
+    if (max_events == 0) return 0;
+    RAMNET_CHECK_ARG(events != nullptr);
+    int gx = (int)((max_events + 255) / 256);
+    const int cap = (2048 * 4 + n_grids - 1) / n_grids;       // ~32 workgroups per CU over the whole launch
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(voxelize_batch_kernel, dim3(gx, n_grids), dim3(256), 0, st, events, offsets, bins, W, H, grids);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_normalize_nonzero_batch(float *grids, int n_grids, size_t n, double *scratch, void *stream) {
+    RAMNET_CHECK_ARG(grids && scratch && n > 0 && n % 4 == 0 && n_grids > 0 && n_grids <= 65535);
+    hipStream_t st = (hipStream_t)stream;
+    RAMNET_HIP(hipMemsetAsync(scratch, 0, (size_t)3 * n_grids * sizeof(double), st));
+    int gx = (int)((n / 4 + 255) / 256);
+    const int cap = (2048 * 4 + n_grids - 1) / n_grids;
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(nonzero_stats_batch_kernel, dim3(gx, n_grids), dim3(256), 0, st, grids, n, scratch);
+    hipLaunchKernelGGL(normalize_nonzero_batch_kernel, dim3(gx, n_grids), dim3(256), 0, st, grids, n, scratch);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -14,6 +14,14 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[96] = "";
+void note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 static inline int grid_for(size_t n_items, int block = 256) {
     size_t g = (n_items + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;   // 256 CUs x 8 workgroups, grid-stride the rest
@@ -476,6 +484,7 @@ __global__ void lstm_bwd_kernel(const float *__restrict__ gates, const float *__
 using namespace ramnet;
 
 extern "C" const char *ramnet_last_error(void) { return g_err; }
+extern "C" const char *ramnet_last_kernel(void) { return g_kernel; }
 extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
 
 extern "C" int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream) {

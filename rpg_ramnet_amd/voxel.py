@@ -45,3 +45,27 @@ def normalize_nonzero(grid):
     scratch = torch.empty(3, device=out.device, dtype=torch.float64)
     H.check(H.lib().ramnet_normalize_nonzero(_p(out), out.numel(), _p(scratch), _st()), "ramnet_normalize_nonzero")
     return out
+
+
+def events_to_voxel_grids(event_lists, num_bins, width, height, device=None, normalize=False):
+    """A batch of event lists -> [G, num_bins, height, width] in ONE scatter-add launch (+ one batched nonzero normalisation):
+    the B x K grids of a batch of data packages.  Per grid identical to events_to_voxel_grid / normalize_nonzero."""
+    assert len(event_lists) > 0 and num_bins > 0 and width > 0 and height > 0
+    if device is None:
+        device = event_lists[0].device if torch.is_tensor(event_lists[0]) else torch.device("cuda:0")
+    device = torch.device(device)
+    evs = [_events(e, device) for e in event_lists]
+    counts = [int(e.shape[0]) for e in evs]
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int64).to(device)
+    cat = torch.cat(evs) if sum(counts) else None
+    G, n = len(evs), num_bins * int(height) * int(width)
+    grids = torch.empty(G, num_bins, int(height), int(width), device=device, dtype=torch.float32)
+    L = H.lib()
+    H.check(L.ramnet_voxelize_batch(_p(cat), _p(off), G, max(counts), num_bins, int(width), int(height), _p(grids), _st()),
+            "ramnet_voxelize_batch")
+    if normalize:
+        if n % 4:
+            return torch.stack([normalize_nonzero(g) for g in grids])
+        scratch = torch.empty(3 * G, device=device, dtype=torch.float64)
+        H.check(L.ramnet_normalize_nonzero_batch(_p(grids), G, n, _p(scratch), _st()), "ramnet_normalize_nonzero_batch")
+    return grids

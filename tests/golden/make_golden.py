@@ -291,6 +291,14 @@ def gen_voxel(etu):
 def main():
     mm, sub, loss_mod, metric, etu, lt, ev = import_reference()
     ramnet = load_cfg("train_e2depth_si_grad_loss_statenet_ergb.json")
+    lc = dict(loss_composition=["image", "events1"])   # K=2: supervise the frame and the last event grid
+    # (4) BASELINE.json configs[4] wiring: 10-bin event voxel grids (the head layer then has 10 input channels)
+    gen_network(mm, "seeded_ramnet_bins10", "ERGB2DepthRecurrent", model_cfg(ramnet, num_bins_events=10, every_x_rgb_frame=2),
+                1, 32, 48, False)
+    gen_grads(mm, lt, loss_mod, "seeded_ramnet_bins10", model_cfg(ramnet, num_bins_events=10, every_x_rgb_frame=2, **lc),
+              2, 16, 24, 2, False, 0.2)
+    if "--only-bins10" in sys.argv:
+        return
     b_e = load_cfg("train_e2depth_si_grad_loss_statenet_baseline_e.json")
     b_ergb = load_cfg("train_e2depth_si_grad_loss_statenet_baseline_ergb.json")
     b_rgb = load_cfg("train_e2depth_si_grad_loss_statenet_baseline_rgb.json")
@@ -325,7 +333,6 @@ def main():
                 1, 256, 256, False, lean=True)
 
     # (3) BPTT gradients through the reference trainer's loss assembly
-    lc = dict(loss_composition=["image", "events1"])   # K=2: supervise the frame and the last event grid
     gen_grads(mm, lt, loss_mod, "small_gru", model_cfg(ramnet, **small, **lc), 2, 24, 32, 2, True, 0.2)
     gen_grads(mm, lt, loss_mod, "small_lstm", model_cfg(ramnet, state_combination="convlstm", **small, **lc),
               2, 24, 32, 2, True, 0.2)

@@ -1,0 +1,251 @@
+"""GPU: forward, backward-data and backward-weights of EVERY layer of the BASELINE configs[1] network at its real shape
+(B=8, 256x344 crop, the 13 distinct layers of one pass) on the bench schedule (backward-weights on a side stream), against
+the oracle in float64 on the CPU — the grid-size dependent code paths (pixel-range splits joined by atomics, XCD remap,
+tile-shape choices, persistent workgroups) only run at these sizes.  Plus whole training steps at full resolution
+(configs[1] at B=2, L=2 and the configs[4] shape 480x640 with 10 bins) against the oracle.
+
+Reference semantics: RAM_Net/model/submodules.py:26-35 (ConvLayer), :87-97 (UpsampleConvLayer), :200-215 (ResidualBlock),
+:436-454 (ConvGRU); statenet.py:160-202 for the layer shapes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ramnet_ref
+from recipe import make_item
+from util import assert_close, build_hip_model, nchw, nhwc, ref_cfg
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+B, H, W = 8, 256, 344
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def bench_schedule():
+    """bench.py's default schedule: backward-weights on a side stream, decoders on a second stream."""
+    from rpg_ramnet_amd import ops
+    ops.set_wgrad_overlap(True)
+    ops.set_decoder_overlap(True)
+    yield
+    ops.set_wgrad_overlap(False)
+    ops.set_decoder_overlap(False)
+
+
+def run_pair64(module, oracle_fn, inputs, input_grads=True, seed=0):
+    """module: rpg_ramnet_amd layer (NHWC, cuda); oracle_fn(sd64, *nchw float64 inputs) -> tensor.  Compares the output, every
+    input gradient and every parameter gradient for a random upstream gradient."""
+    module = module.to(dev())
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in module.state_dict().items()}
+    cpu_in = [t.double().requires_grad_(input_grads) for t in inputs]
+    gpu_in = [nhwc(t).to(dev()).requires_grad_(input_grads) for t in inputs]
+    ref = oracle_fn(sd, *cpu_in)
+    got = module(*gpu_in)
+    got_nchw = got if got.shape == ref.shape else got.permute(0, 3, 1, 2)
+    assert_close(got_nchw.detach().cpu().numpy(), ref.detach().numpy(), TOL, "forward")
+    g = torch.Generator().manual_seed(seed)
+    wgt = torch.randn(ref.shape, generator=g)
+    kink = (got_nchw.detach().cpu() == 0) != (ref.detach() == 0)       # ReLU kink: derivative differs by side (test_hip_ops.run_pair)
+    assert float(kink.float().mean()) < 1e-4
+    wgt[kink] = 0.0
+    (ref * wgt.double()).sum().backward()
+    (got_nchw * wgt.to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    if input_grads:
+        for i, (c, gi) in enumerate(zip(cpu_in, gpu_in)):
+            assert gi.grad is not None, "missing input grad %d" % i
+            assert_close(nchw(gi.grad).cpu().numpy(), c.grad.numpy(), TOL, "grad input %d" % i)
+    for k, p in module.named_parameters():
+        assert p.grad is not None, "missing grad for " + k
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), TOL, "grad " + k)
+
+
+def _pre(sd):
+    return {"L." + k: v for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("cin", [5, 1, 10])
+def test_head_layer_full_size(cin, bench_schedule):
+    """head_events (5 bins), head_rgb (1 channel) and the configs[4] 10-bin head (generic kernel): 5x5 s1 -> 32 @ 256x344."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvLayer
+    torch.manual_seed(10 + cin)
+    m = ConvLayer(cin, 32, 5, 1, 2).to(dev())
+    x = torch.randn(B, cin, H, W)
+    y = m(ops.pack_input(x, dev()))
+    w, b = m.conv2d.weight.detach().cpu().double().requires_grad_(True), m.conv2d.bias.detach().cpu().double().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w, b, 1, 2))
+    assert_close(nchw(y).detach().cpu().numpy(), ref.detach().numpy(), TOL, "head forward")
+    wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    wgt[(nchw(y).detach().cpu() == 0) != (ref.detach() == 0)] = 0.0
+    (ref * wgt.double()).sum().backward()
+    (nchw(y) * wgt.to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(m.conv2d.weight.grad.cpu().numpy(), w.grad.numpy(), TOL, "head dW")
+    assert_close(m.conv2d.bias.grad.cpu().numpy(), b.grad.numpy(), TOL, "head db")
+
+
+@pytest.mark.parametrize("cin,cout,div", [(32, 64, 1), (64, 128, 2), (128, 256, 4)])
+def test_encoder_layer_full_size(cin, cout, div, bench_schedule):
+    """encoders: 5x5 stride 2, 32->64 @256x344, 64->128 @128x172, 128->256 @64x86 (space-to-depth Winograd path)."""
+    from rpg_ramnet_amd.model.submodules import ConvLayer
+    torch.manual_seed(20 + div)
+    m = ConvLayer(cin, cout, 5, 2, 2)
+    x = torch.randn(B, cin, H // div, W // div)
+    run_pair64(m, lambda sd, a: torch.relu(torch.nn.functional.conv2d(a, sd["conv2d.weight"], sd["conv2d.bias"], 2, 2)), [x])
+
+
+@pytest.mark.parametrize("C,div", [(64, 2), (128, 4), (256, 8)])
+def test_conv_gru_full_size(C, div, bench_schedule):
+    """ConvGRU state update (update|reset launch, candidate launch) at the three scales: C=64 @128x172 ... C=256 @32x43."""
+    from rpg_ramnet_amd.model.submodules import ConvGRU
+    torch.manual_seed(30 + div)
+    m = ConvGRU(C, C, 3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    x, h = torch.randn(B, C, H // div, W // div), torch.tanh(torch.randn(B, C, H // div, W // div))
+    run_pair64(m, lambda sd, a, hh: ramnet_ref.conv_gru(_pre(sd), "L", a, hh), [x, h])
+
+
+def test_residual_block_full_size(bench_schedule):
+    from rpg_ramnet_amd.model.submodules import ResidualBlock
+    torch.manual_seed(40)
+    m = ResidualBlock(256, 256)
+    run_pair64(m, lambda sd, a: ramnet_ref.residual_block(_pre(sd), "L", a), [torch.randn(B, 256, H // 8, W // 8)])
+
+
+@pytest.mark.parametrize("cin,cout,div,skip", [(256, 128, 8, False), (128, 64, 4, True), (64, 32, 2, True)])
+def test_decoder_layer_full_size(cin, cout, div, skip, bench_schedule):
+    """UpsampleConvLayer: 256->128 from 32x43 (no skip), 128->64 from 64x86, 64->32 from 128x172 (folded Winograd F(2x2,4x4))."""
+    from rpg_ramnet_amd.model.submodules import UpsampleConvLayer
+    torch.manual_seed(50 + div)
+    m = UpsampleConvLayer(cin, cout, 5, padding=2)
+    x = torch.randn(B, cin, H // div, W // div)
+    ins = [x, torch.randn(B, cin, H // div, W // div)] if skip else [x]
+    run_pair64(m, lambda sd, a, s=None: ramnet_ref.upsample_conv_layer(_pre(sd), "L", a if s is None else a + s), ins)
+
+
+def test_pred_layer_full_size():
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(60)
+    x = torch.randn(B, 32, H, W)
+    w, b = torch.randn(1, 32, 1, 1) * 0.2, torch.randn(1) * 0.1
+    xg = nhwc(x).to(dev()).requires_grad_(True)
+    wg, bg = w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    y = ops.PredSigmoid.apply(xg, wg, bg)
+    xc, wc, bc = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.sigmoid(torch.nn.functional.conv2d(xc, wc, bc))
+    assert_close(y.detach().cpu().numpy(), ref.detach().numpy(), TOL, "pred")
+    wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(2))
+    (ref * wgt.double()).sum().backward()
+    (y * wgt.to(dev())).sum().backward()
+    assert_close(nchw(xg.grad).cpu().numpy(), xc.grad.numpy(), TOL, "pred dx")
+    assert_close(wg.grad.cpu().numpy(), wc.grad.numpy(), TOL, "pred dw")
+    assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "pred db")
+
+
+def _training_step_vs_oracle(cfg, Bn, Hn, Wn, L, nan_frac):
+    from rpg_ramnet_amd.trainer import sequence_loss
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    K, lc = cfg["every_x_rgb_frame"], cfg["loss_composition"]
+    rng = np.random.default_rng(11)
+    seq = [make_item(rng, Bn, Hn, Wn, K, cfg["num_bins_events"], cfg["num_bins_rgb"], True, nan_frac) for _ in range(L)]
+    model.zero_grad()
+    total, _ = sequence_loss(model, seq, lc, [1, 1])
+    total.backward()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    seq64 = [{k: v.double() for k, v in it.items()} for it in seq]
+    ref_total, _ = ramnet_ref.sequence_loss(sd, cfg, seq64, lc, [1, 1])
+    ref_total.backward()
+    np.testing.assert_allclose(float(total.detach()), float(ref_total.detach()), rtol=1e-4)
+    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-2 * gmax)
+
+
+def test_config1_training_step_full_resolution_vs_oracle(bench_schedule):
+    """BASELINE configs[1] at reduced batch / length only (B=2, L=2; K=5, 5 bins, 256x344, SI loss on [image, events4]):
+    loss and all 70 parameter gradients of one BPTT step on the bench's three-stream schedule vs the float64 oracle."""
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=5, loss_composition=["image", "events4"])
+    _training_step_vs_oracle(cfg, 2, H, W, 2, 0.0)
+
+
+def test_config4_shape_training_step_vs_oracle(bench_schedule):
+    """BASELINE configs[4] shape: 640x480, 10-bin voxel grids (the 10-channel head runs the generic kernels), 20 % NaN targets;
+    B=1, K=2, L=2 keeps the oracle to seconds."""
+    cfg, _ = ref_cfg("net_seeded_ramnet_bins10.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
+    assert cfg["num_bins_events"] == 10
+    _training_step_vs_oracle(cfg, 1, 480, 640, 2, 0.2)
+
+
+def test_config4_shape_forward_properties():
+    """480x640, 10 bins, B=4, K=5 (one full configs[4] package): deterministic, batch elements independent, outputs in [0,1]."""
+    cfg, _ = ref_cfg("net_seeded_ramnet_bins10.npz", every_x_rgb_frame=5)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    rng = np.random.default_rng(4)
+    item = make_item(rng, 4, 480, 640, 5, 10, 1)
+    perm = torch.tensor([3, 1, 0, 2])
+    lstm = ramnet_ref.empty_states_lstm(5)
+    with torch.no_grad():
+        p1, s1, _ = model(item, None, lstm)
+        p2, s2, _ = model({k: v[perm] for k, v in item.items()}, None, lstm)
+        p3, _, _ = model(item, s1["image"], lstm)
+    assert list(p1.keys()) == ["events0", "events1", "events2", "events3", "events4", "image"]
+    for k in p1:
+        assert p1[k].shape == (4, 1, 480, 640) and float(p1[k].min()) >= 0.0 and float(p1[k].max()) <= 1.0
+        assert torch.equal(p1[k][perm], p2[k]), "batch elements must not interact"
+        assert not torch.equal(p1[k], p3[k]), "the carried state must change the prediction"
+    for a, b in zip(s1["image"], s2["image"]):
+        assert torch.equal(a[perm], b)
+
+
+def test_backward_recovers_after_an_aborted_pass():
+    """a backward pass that raises mid-way must not poison the next one (stale gradient workspaces, a callback
+    that is never queued again): the step after the failure yields the same gradients as a clean run."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(9)
+    seq = [make_item(rng, 2, 32, 48, 2, 5, 1, True, 0.1) for _ in range(2)]
+
+    def grads():
+        model.zero_grad()
+        total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+        total.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    clean = grads()
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("injected failure in backward")
+
+    # fail in the middle: the state after the first package goes through a node whose backward raises
+    model.zero_grad()
+    preds, supers, lstms = model(seq[0], None, ramnet_ref.empty_states_lstm(2))
+    carried = [Boom.apply(s) for s in supers["image"]]
+    preds2, _, _ = model(seq[1], carried, lstms)
+    loss = sum(ops.scale_invariant_loss(preds2[k], seq[1]["depth_" + k].to(model.gpu)) for k in ("image", "events1"))
+    with pytest.raises(RuntimeError, match="injected failure"):
+        loss.backward()
+    assert ops._Engine.dirty, "the aborted pass left weight-gradient workspaces behind (this is what the test exercises)"
+    after = grads()
+    assert not ops._Engine.dirty and ops._Engine.task == -1
+    gmax = max(float(v.abs().max()) for v in clean.values())
+    for k in clean:
+        if not k.endswith("pred.conv2d.bias"):
+            assert_close(after[k].cpu().numpy(), clean[k].cpu().numpy(), 1e-5, "after aborted pass: " + k, floor=1e-2 * gmax)

@@ -62,6 +62,62 @@ def test_network_explicit_weights(golden_dir, tag):
     assert n >= 1
 
 
+def seeded_sd(cfg, arch, z):
+    """Seeded full-width weights: the model class reproduces the reference's torch.manual_seed(0) initialisation
+    (checksums in the fixture prove it), so its CPU state_dict feeds the oracle."""
+    from rpg_ramnet_amd.model import model as mm
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in getattr(mm, arch)(cfg).state_dict().items()}
+    for k, v in sd.items():
+        got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+        np.testing.assert_allclose(got, z["wsum." + k], rtol=1e-5, atol=1e-7, err_msg=k)
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["seeded_ramnet", "seeded_ramnet_lstm", "seeded_base_rgb", "seeded_ramnet_bins10", "seeded_unet"])
+def test_network_seeded_full_width(golden_dir, tag):
+    """Released width (base 32) incl. the 10-bin configs[4] wiring: oracle vs the reference's predictions and states."""
+    z = load(golden_dir, "net_%s.npz" % tag)
+    cfg = json.loads(str(z["config"]))
+    res = run_net(z, seeded_sd(cfg, str(z["arch"]), z))
+    for c, (preds, supers) in enumerate(res):
+        assert len(preds) >= 1
+        for k, v in preds.items():
+            np.testing.assert_allclose(v.numpy(), z["pred%d.%s" % (c, k)], **TOL)
+        for name in [f for f in z.files if f.startswith("super%d.image." % c)]:
+            parts = name.split(".")
+            s = supers["image"][int(parts[2])]
+            s = s[{"h": 0, "c": 1}[parts[3]]] if len(parts) == 4 else s
+            np.testing.assert_allclose(s.numpy(), z[name], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["seeded_ramnet", "seeded_ramnet_bins10"])
+def test_bptt_gradients_seeded_full_width(golden_dir, tag):
+    """Full-width BPTT gradients through the reference trainer's loss assembly (norms + strided samples in the fixture)."""
+    z = load(golden_dir, "grads_%s.npz" % tag)
+    cfg = json.loads(str(z["config"]))
+    sd = {k: v.requires_grad_(True) for k, v in seeded_sd(cfg, "ERGB2DepthRecurrent", z).items()}
+    seq = []
+    for l in range(int(z["L"])):
+        pre = "in%d." % l
+        seq.append({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)})
+    total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, cfg["loss_composition"], [1, 1])
+    total.backward()
+    np.testing.assert_allclose(len(cfg["loss_composition"]) * float(total.detach()), float(z["reported_loss"]), rtol=1e-5)
+    n = 0
+    for k, v in sd.items():
+        if v.grad is None:
+            continue
+        if "g." + k in z.files:
+            np.testing.assert_allclose(v.grad.numpy(), z["g." + k], rtol=2e-3, atol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_allclose(float(v.grad.double().norm()), float(z["gnorm." + k][0]), rtol=1e-3, err_msg=k)
+            np.testing.assert_allclose(v.grad.flatten()[::997].numpy(), z["gsample." + k], rtol=2e-3,
+                                       atol=1e-3 * float(np.abs(z["gsample." + k]).max()) + 1e-9, err_msg=k)
+        n += 1
+    assert n >= 60
+
+
 def test_primitives(golden_dir):
     z = load(golden_dir, "primitives.npz")
 
