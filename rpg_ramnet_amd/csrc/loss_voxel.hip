@@ -326,6 +326,7 @@ __global__ void normalize_nonzero_batch_kernel(float *__restrict__ grids, size_t
     if (cnt == 0.0) return;
     const float mean = (float)(stats[3 * blockIdx.y] / cnt);
     const float sd = sqrtf((float)(stats[3 * blockIdx.y + 1] / cnt) - mean * mean);
+    if (!(sd > 0.f)) return;      // a single distinct nonzero value: left unchanged (event_dataset.py:150 `if stddev > 0`)
     for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
         if (i + 3 < n) {
             float4 q = ld4(g + i);
@@ -343,6 +344,8 @@ __global__ void normalize_nonzero_kernel(float *__restrict__ g, size_t n, const 
     if (cnt == 0.0) return;
     const float mean = (float)(stats[0] / cnt);
     const float sd = sqrtf((float)(stats[1] / cnt) - mean * mean);
+    if (!(sd > 0.f)) return;      // a single distinct nonzero value: left unchanged (event_dataset.py:150 `if stddev > 0`;
+                                  // EventPreprocessor, event_tensor_utils.py:64-66, would turn the whole grid into NaN)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = g[i];
         g[i] = v != 0.f ? (v - mean) / sd : 0.f;

@@ -113,10 +113,53 @@ def test_conv_gru_full_size(C, div, bench_schedule):
 
 
 def test_residual_block_full_size(bench_schedule):
+    """ResidualBlock 256 @ 32x43 (submodules.py:200-215), its two launches checked separately: the block hides a ReLU between
+    them, and among 2.8 M hidden activations a few sit within fp32 rounding of the kink, where the float64 checker takes the
+    other branch (derivative 0 vs 1) — a property of comparing across precisions, not of the kernels.  Each half exposes its
+    ReLU at the output, where run_pair64 masks exactly those elements."""
+    from rpg_ramnet_amd import ops
     from rpg_ramnet_amd.model.submodules import ResidualBlock
     torch.manual_seed(40)
-    m = ResidualBlock(256, 256)
-    run_pair64(m, lambda sd, a: ramnet_ref.residual_block(_pre(sd), "L", a), [torch.randn(B, 256, H // 8, W // 8)])
+    blk = ResidualBlock(256, 256)
+
+    class First(torch.nn.Module):           # relu(conv1(x))
+        def __init__(self):
+            super().__init__()
+            self.conv1 = blk.conv1
+
+        def forward(self, x):
+            cp = blk._cp("c1", [self.conv1.weight], [self.conv1.bias])
+            return ops.ConvAct.apply(x, None, self.conv1.weight, self.conv1.bias, cp, 1, True, False)
+
+    class Second(torch.nn.Module):          # relu(conv2(t) + residual)
+        def __init__(self):
+            super().__init__()
+            self.conv2 = blk.conv2
+
+        def forward(self, t, res):
+            cp = blk._cp("c2", [self.conv2.weight], [self.conv2.bias])
+            return ops.ResConv.apply(t, res, self.conv2.weight, self.conv2.bias, cp)
+
+    F = torch.nn.functional
+    x = torch.randn(B, 256, H // 8, W // 8)
+    run_pair64(First(), lambda sd, a: torch.relu(F.conv2d(a, sd["conv1.weight"], sd["conv1.bias"], 1, 1)), [x])
+    t = torch.relu(torch.randn(B, 256, H // 8, W // 8))
+    run_pair64(Second(), lambda sd, a, r: torch.relu(F.conv2d(a, sd["conv2.weight"], sd["conv2.bias"], 1, 1) + r), [t, x])
+    # and the block as a whole: forward to 2e-4, gradients with the tolerance of the network-level tests
+    m = ResidualBlock(256, 256).to(dev())
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    xc, xg = x.double().requires_grad_(True), nhwc(x).to(dev()).requires_grad_(True)
+    ref, got = ramnet_ref.residual_block(_pre(sd), "L", xc), m(xg)
+    assert_close(nchw(got).detach().cpu().numpy(), ref.detach().numpy(), TOL, "block forward")
+    wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    wgt[(nchw(got).detach().cpu() == 0) != (ref.detach() == 0)] = 0.0
+    (ref * wgt.double()).sum().backward()
+    (nchw(got) * wgt.to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    bad = (nchw(xg.grad).cpu().double() - xc.grad).abs() > TOL * float(xc.grad.abs().max())
+    assert float(bad.float().mean()) < 1e-4, "input gradient differs beyond isolated kink flips"
+    for k, p in m.named_parameters():
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "block grad " + k)
 
 
 @pytest.mark.parametrize("cin,cout,div,skip", [(256, 128, 8, False), (128, 64, 4, True), (64, 32, 2, True)])
@@ -150,6 +193,10 @@ def test_pred_layer_full_size():
 
 
 def _training_step_vs_oracle(cfg, Bn, Hn, Wn, L, nan_frac):
+    """Loss and every parameter gradient of one BPTT step vs the float64 oracle.  Bound per tensor: 2e-3 of its largest entry
+    (the network-level bar of tests/test_hip_model.py), or twice the deviation the oracle ITSELF shows when it runs the same
+    step in float32 (PyTorch's CPU kernels) — at 10^5 pixels x 10^2 layers a handful of hidden ReLU pre-activations sit within
+    fp32 rounding of zero and any fp32 evaluation takes the other branch there."""
     from rpg_ramnet_amd.trainer import sequence_loss
     model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
     K, lc = cfg["every_x_rgb_frame"], cfg["loss_composition"]
@@ -159,15 +206,28 @@ def _training_step_vs_oracle(cfg, Bn, Hn, Wn, L, nan_frac):
     total, _ = sequence_loss(model, seq, lc, [1, 1])
     total.backward()
     torch.cuda.synchronize()
-    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
-    seq64 = [{k: v.double() for k, v in it.items()} for it in seq]
-    ref_total, _ = ramnet_ref.sequence_loss(sd, cfg, seq64, lc, [1, 1])
-    ref_total.backward()
-    np.testing.assert_allclose(float(total.detach()), float(ref_total.detach()), rtol=1e-4)
-    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+
+    def oracle(dtype):
+        sd = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in model.state_dict().items()}
+        sq = [{k: v.to(dtype) for k, v in it.items()} for it in seq]
+        t, _ = ramnet_ref.sequence_loss(sd, cfg, sq, lc, [1, 1])
+        t.backward()
+        return float(t.detach()), {k: v.grad.double() for k, v in sd.items()}
+
+    ref_total, ref = oracle(torch.float64)
+    _, ref32 = oracle(torch.float32)
+    np.testing.assert_allclose(float(total.detach()), ref_total, rtol=1e-4)
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    worst = []
     for k, p in model.named_parameters():
         assert p.grad is not None, k
-        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-2 * gmax)
+        scale = max(float(ref[k].abs().max()), 1e-2 * gmax)
+        err = float((p.grad.cpu().double() - ref[k]).abs().max()) / scale
+        err32 = float((ref32[k] - ref[k]).abs().max()) / scale
+        worst.append((err / max(2e-3, 2 * err32), err, err32, k))
+    worst.sort(reverse=True)
+    print("worst gradients (HIP err, fp32-oracle err):", ["%s %.1e %.1e" % (k, e, e32) for _, e, e32, k in worst[:4]])
+    assert worst[0][0] <= 1.0, "grad %s: rel err %.3e (float32 oracle: %.3e)" % (worst[0][3], worst[0][1], worst[0][2])
 
 
 def test_config1_training_step_full_resolution_vs_oracle(bench_schedule):
