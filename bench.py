@@ -66,7 +66,11 @@ def parse():
     ap.add_argument("--no-overlap-decoder", dest="overlap_decoder", action="store_false",
                     help="run the decoders on the main stream instead of a second stream concurrent with the next state update "
                          "(ops.set_decoder_overlap; default schedule)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) single-stream measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) single-stream / hipGraph measurements")
+    ap.add_argument("--graph", action="store_true",
+                    help="train: the timed step replays ONE hipGraph (gradient zero-fill, forward, loss, BPTT backward, gradient fold; "
+                         "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
+                         "unavailable (no roofline object).  stream / infer modes always report both eager and graph replay")
     return ap.parse_args()
 
 
@@ -350,6 +354,7 @@ def main():
         dist.all_gather(got, t)
         ranks_seen = sorted(int(v.item()) for v in got)
 
+    graphed = {}
     if args.mode == "train":
         model.train()
         reducer = FlatGradReducer(model)
@@ -363,13 +368,29 @@ def main():
             reducer.wait()
             opt.step()
             return total
+
+        def make_graph_step():
+            from rpg_ramnet_amd.graph import GraphedTrainStep
+            g = GraphedTrainStep(model, seq, cfg["loss_composition"], [1, 1], reducer=reducer, warmup=1)
+
+            def gstep():
+                total, _ = g()
+                reducer.all_reduce()
+                reducer.wait()
+                opt.step()
+                return total
+            return gstep
+        if args.graph:
+            timer.on = False
+            step = make_graph_step()
+            args.no_kernel_timing = True
     elif args.mode == "stream":
         model.eval()
         rs = np.random.default_rng(7)
         sched = [int(v) for v in rs.integers(1, 9, size=L)]        # event grids before each frame, drawn from {1..8}
         stream_state = {"s": model.init_states(B, H, W)}
 
-        def step():
+        def eager_step():
             st = stream_state["s"]                                 # state persists ACROSS steps (one long stream)
             with torch.no_grad():
                 for l, item in enumerate(seq):
@@ -380,16 +401,37 @@ def main():
                     pred = model.decode(st)
             stream_state["s"] = st
             return pred.mean()
+
+        from rpg_ramnet_amd.graph import GraphedStream
+        gs = GraphedStream(model, B, H, W)                         # one hipGraph per (update + decode): the default for this mode
+
+        def step():
+            for l, item in enumerate(seq):
+                for k in range(sched[l]):
+                    pred = gs.update_events(item["events%d" % (k % K)])
+                pred = gs.update_image(item["image"])
+            return pred.mean()
+        graphed["eager"] = eager_step
     else:
         model.eval()
 
-        def step():
+        def eager_step():
             prev_super, prev_lstm = None, empty_states_lstm(K)
             with torch.no_grad():
                 for item in seq:
                     preds, supers, prev_lstm = model(item, prev_super, prev_lstm)
                     prev_super = supers["image"]
             return preds["image"].mean()
+
+        from rpg_ramnet_amd.graph import GraphedPackage
+        gp = GraphedPackage(model, seq[0])                         # one hipGraph per data package (K+1 passes)
+
+        def step():
+            gp.reset()
+            for item in seq:
+                preds = gp(item)
+            return preds["image"].mean()
+        graphed["eager"] = eager_step
 
     def fence():
         torch.cuda.synchronize()
@@ -452,6 +494,27 @@ def main():
                 "algorithmic_achieved": iso[2] / iso[1] / 1e12}
         ops.set_wgrad_overlap(args.overlap_wgrad)
         ops.set_decoder_overlap(args.overlap_decoder)
+
+    def measure(fn, n=2):
+        fn()
+        fence()
+        t = time.perf_counter()
+        for _ in range(n):
+            lv = fn()
+        fence()
+        e = (time.perf_counter() - t) / n
+        return {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach())}
+
+    if not args.no_extras and world == 1:
+        timer.on = False
+        if "eager" in graphed:      # stream / infer: the timed region replays hipGraphs; the same work launch by launch
+            extras["eager_launches"] = measure(graphed["eager"])
+        elif args.mode == "train" and not args.graph:
+            try:
+                extras["graph_replay"] = dict(measure(make_graph_step()), note="the same step as ONE hipGraph replay (zero-fill, forward, "
+                                              "loss, BPTT backward, gradient fold) + eager Adam; rpg_ramnet_amd.graph.GraphedTrainStep")
+            except Exception as ex:     # noqa: BLE001 — an extra must not take the headline measurement down
+                extras["graph_replay"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
     if rank == 0:
         samples = world * B * L * args.steps

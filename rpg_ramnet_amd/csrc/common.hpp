@@ -42,6 +42,11 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgr
 
 #define RAMNET_LAUNCH_CHECK() RAMNET_HIP(hipGetLastError())
 
+// Raise a kernel's dynamic-LDS cap to the 160 KB of a CU — once per kernel and process, not per launch (a driver call on the
+// launch path, and nothing that belongs inside a hipGraph stream capture).
+hipError_t allow_full_lds(const void *kernel);
+#define RAMNET_FULL_LDS(kern) RAMNET_HIP(ramnet::allow_full_lds(reinterpret_cast<const void *>(kern)))
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -234,7 +234,7 @@ int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st) {
     if (blocks > q.ntiles) blocks = q.ntiles;
     auto go = [&](auto kern, int cr) -> int {
         const size_t lds = (size_t)(((cr * (HG_H + 4) * HP_LD + 3) & ~3) + HG_H * HT_W * HG_LD) * sizeof(float);
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((kern));
         note_kernel("conv_head_wgrad_kernel<%d>", cr);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, q);
         return 0;

@@ -195,7 +195,7 @@ static int launch_cfg(const ramnet_conv_desc &d, const ConvCommon &qc, const Con
     const size_t lds = ((size_t)qc.patch_floats + 2 * BN * LDP) * sizeof(float);
     static size_t lds_set = 0;   // raise the dynamic-LDS cap once per instantiation
     if (lds > lds_set) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((kern));
         lds_set = 160 * 1024;
     }
     if (lds > 160 * 1024) {

@@ -166,7 +166,7 @@ static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipSt
     size_t lds = ((size_t)q.PH * q.PW * WCK + q.TH * TWID * WBN) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((kern));
         attr_set = true;
     }
     if (lds > 160 * 1024) {

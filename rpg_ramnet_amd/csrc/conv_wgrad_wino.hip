@@ -358,7 +358,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     // reads xm only when its own channels need it, so launch the XM variant whenever any workgroup might
     const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
     auto go = [&](auto kern) -> int {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((kern));
         note_kernel("conv_wgrad_wino_kernel<%d,%d,%d>", (int)xm, (int)gm, cib);
         hipLaunchKernelGGL(kern, grid, dim3(cib * 8), lds, st, d, q);
         return 0;

@@ -234,7 +234,7 @@ int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st) {
     const size_t lds = (size_t)2 * 25 * G24_T * (32 + 64) * sizeof(float);
     const dim3 grid(splits, gy, gz);
     auto go = [&](auto kern) -> int {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((kern));
         note_kernel("conv_wgrad_wino24_kernel<%d,%d>", d.gmask ? 1 : 0, (int)wci);
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, q);
         return 0;

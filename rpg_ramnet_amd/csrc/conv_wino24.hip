@@ -354,11 +354,11 @@ static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk));
     if (flat) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((conv_wino24_kernel<4, true, 8>));
         note_kernel("conv_wino24_kernel<4,1,8>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, true, 8>), grid, dim3(512), lds, st, d, q);
     } else {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((conv_wino24_kernel<4, true, 4>));
         note_kernel("conv_wino24_kernel<4,1,4>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, true, 4>), grid, dim3(512), lds, st, d, q);
     }
@@ -386,15 +386,15 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
     if (wide && flat) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 8>));
         note_kernel("conv_wino24_kernel<4,0,8>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, false, 8>), grid, dim3(512), lds, st, d, q);
     } else if (wide) {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<4, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 4>));
         note_kernel("conv_wino24_kernel<4,0,4>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, false, 4>), grid, dim3(512), lds, st, d, q);
     } else {
-        RAMNET_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wino24_kernel<2, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAMNET_FULL_LDS((conv_wino24_kernel<2, false, 8>));
         note_kernel("conv_wino24_kernel<2,0,8>");
         hipLaunchKernelGGL((conv_wino24_kernel<2, false, 8>), grid, dim3(512), lds, st, d, q);
     }

@@ -2,6 +2,8 @@
 // backward formulas, the adjoint of the bilinear upsample.  All are float4-vectorised grid-stride
 // loops (coalesced 16 B per lane, 1 KiB per wavefront instruction).
 #include <stdarg.h>
+#include <mutex>
+#include <unordered_set>
 #include "common.hpp"
 
 namespace ramnet {
@@ -20,6 +22,16 @@ void note_kernel(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
     va_end(ap);
+}
+
+hipError_t allow_full_lds(const void *kernel) {
+    static std::mutex mu;
+    static std::unordered_set<const void *> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(kernel)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert(kernel);
+    return e;
 }
 
 static inline int grid_for(size_t n_items, int block = 256) {

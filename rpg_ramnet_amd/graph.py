@@ -1,0 +1,175 @@
+"""Sequence-level execution: the launch chains of the RAM-Net hot path captured as hipGraphs.
+
+The reference drives three nested Python loops — sequence (trainer/lstm_trainer.py:256-272), package (model/model.py:176-195),
+layer — and so does the eager path here: ~150 kernel launches per data package, each a ctypes call.  That is invisible at B=8
+(the GPU is the bottleneck) and dominant at batch 1 (streaming inference, BASELINE configs[3]: ~20 launches of a few
+microseconds each per update).  This module records those chains ONCE with HIP stream capture (torch.cuda.CUDAGraph: the
+library launches on torch's current stream, so its kernels, memsets and the side-stream forks are captured as they are) and
+replays them with one host call:
+
+* ``GraphedStream``    — asynchronous inference with a persistent multi-scale state: one graph per (modality update + decode),
+                         state kept in static device buffers (test.py:212-232 call pattern; configs[3]).
+* ``GraphedPackage``   — one data package, K event updates + 1 frame update + K+1 decodes (model.py:176-219), state carried.
+* ``GraphedTrainStep`` — gradient zero-fill, forward over the L packages of a sequence, loss assembly, BPTT backward and the
+                         weight-gradient fold of one optimizer step (lstm_trainer.py:228-390); the optimizer and the gradient
+                         all-reduce stay outside (they bump parameter versions / use the collective library).
+
+Replays are bit-identical to the eager path for forward results; gradients differ only by the order of the atomic partial sums
+(as between two eager runs).  Static input buffers are filled with ``copy_`` (device-to-device or pinned host-to-device).
+"""
+import torch
+
+from . import ops
+from .trainer import empty_states_lstm, sequence_loss
+
+
+def _warm(fn, n=2):
+    """Eager runs before capture: lazy allocations (packs, gradient workspaces, rocBLAS handles, LDS attributes) happen here."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(n):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+
+class GraphedStream:
+    """Streaming inference (batch B, persistent state): ``update_events(grid)`` / ``update_image(frame)`` fold one measurement
+    into the shared state and return the depth prediction decoded from it — one hipGraph replay each."""
+
+    def __init__(self, model, B, H, W):
+        assert not bool(model.baseline), "streaming graphs are built for the asynchronous RAM-Net (not the baselines)"
+        self.model, dev = model, model.gpu
+        self.ev_in = torch.zeros(B, model.num_bins_events, H, W, device=dev)
+        self.im_in = torch.zeros(B, model.num_bins_rgb, H, W, device=dev)
+        self.states = model.init_states(B, H, W)            # static buffers: read and overwritten by every replay
+        self.graphs, self.preds = {}, {}
+        was_training = model.training
+        model.eval()
+        snapshot = [self._clone(s) for s in self.states]
+        for kind, buf, update in (("events", self.ev_in, model.update_events), ("image", self.im_in, model.update_image)):
+            def run(buf=buf, update=update):
+                with torch.no_grad():
+                    new, _ = update(buf, self.states)
+                    pred = model.decode(new)
+                    for dst, src in zip(self.states, new):          # the state advances inside the graph
+                        for d, s in zip(self._flat(dst), self._flat(src)):
+                            d.copy_(s)
+                return pred
+            _warm(run)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                pred = run()
+            self.graphs[kind], self.preds[kind] = g, pred
+        for dst, src in zip(self.states, snapshot):                 # undo the warm-up / capture updates
+            for d, s in zip(self._flat(dst), self._flat(src)):
+                d.copy_(s)
+        model.train(was_training)
+
+    @staticmethod
+    def _flat(s):
+        return list(s) if isinstance(s, (list, tuple)) else [s]
+
+    @classmethod
+    def _clone(cls, s):
+        return [t.clone() for t in s] if isinstance(s, (list, tuple)) else s.clone()
+
+    def reset(self):
+        for s in self.states:
+            for t in self._flat(s):
+                t.zero_()
+
+    def update_events(self, grid):
+        """grid [B, Ce, H, W] (device or pinned host) -> prediction [B,1,H,W] (a static buffer: overwritten by the next call)."""
+        self.ev_in.copy_(grid, non_blocking=True)
+        self.graphs["events"].replay()
+        return self.preds["events"]
+
+    def update_image(self, frame):
+        self.im_in.copy_(frame, non_blocking=True)
+        self.graphs["image"].replay()
+        return self.preds["image"]
+
+
+class GraphedPackage:
+    """One data package through ``model.forward`` (K event grids + 1 frame -> K+1 predictions), state carried in static
+    buffers across calls; ``reset()`` starts a new recording."""
+
+    def __init__(self, model, example_item):
+        self.model = model
+        K = model.every_x_rgb_frame
+        self.item = {k: torch.empty_like(v, device=model.gpu).copy_(v) for k, v in example_item.items() if not k.startswith("depth_")}
+        B, _, H, W = self.item["image"].shape
+        self.states = model.init_states(B, H, W)
+        was_training = model.training
+        model.eval()
+
+        def run():
+            with torch.no_grad():
+                preds, supers, _ = model(self.item, [s.permute(0, 3, 1, 2) for s in self.states], empty_states_lstm(K))
+                for dst, src in zip(self.states, supers["image"]):
+                    dst.copy_(src.permute(0, 2, 3, 1))
+            return preds
+        assert model.state_combination == "convgru" and model.recurrent_block_type == "conv", "graphed package: ConvGRU RAM-Net"
+        _warm(run)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.preds = run()
+        self.reset()
+        model.train(was_training)
+
+    def reset(self):
+        for s in self.states:
+            s.zero_()
+
+    def __call__(self, item):
+        for k, buf in self.item.items():
+            buf.copy_(item[k], non_blocking=True)
+        self.graph.replay()
+        return self.preds
+
+
+class GraphedTrainStep:
+    """zero gradients -> forward over the sequence -> loss (trainer.sequence_loss) -> BPTT backward -> weight-gradient fold, as
+    one hipGraph.  ``sequence`` provides the static input buffers (refill them in place, e.g. ``step.load(new_sequence)``);
+    the gradients land in the parameters' ``.grad`` (the flat buffer of ``parallel.FlatGradReducer`` when one is attached)."""
+
+    def __init__(self, model, sequence, loss_composition, loss_weights, reducer=None, grad_loss_weight=None, warmup=2):
+        self.model, self.reducer = model, reducer
+        self.sequence = [{k: v.to(model.gpu) for k, v in item.items()} for item in sequence]
+        assert model.training, "call model.train() first"
+
+        def zero():
+            if reducer is not None:
+                reducer.zero()
+            else:
+                for p in model.parameters():
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    else:
+                        p.grad.zero_()
+
+        def run():
+            zero()
+            total, reported = sequence_loss(model, self.sequence, loss_composition, loss_weights, grad_loss_weight=grad_loss_weight)
+            total.backward()
+            return total.detach(), reported
+
+        _warm(run, warmup)
+        torch.cuda.empty_cache()
+        ops.invalidate_packs()            # every weight pack is re-run — and therefore recorded — inside the capture
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.total, self.reported = run()
+        ops.invalidate_packs()            # eager code must not trust packs whose refresh now lives in the graph
+
+    def load(self, sequence):
+        for dst, src in zip(self.sequence, sequence):
+            for k, buf in dst.items():
+                buf.copy_(src[k], non_blocking=True)
+
+    def __call__(self):
+        """Replay; returns (differentiated loss, reported loss) as device scalars (static buffers)."""
+        self.graph.replay()
+        return self.total, self.reported

@@ -374,6 +374,18 @@ FOLD_A = ([[.25, 0, 0, 0, 0], [.75, .75, .25, 0, 0], [0, .25, .75, .75, .25], [0
 FOLD_LOST = [[(0, 1), (0,)], [(4,), (3, 4)]]    # [side: near / far edge][slot: distance into the band] -> taps outside the image
 
 
+_CONSTS = {}
+
+
+def _const(name, values, device, dtype):
+    """Small constant matrices on the device, uploaded once (a host-to-device copy has no place inside a hipGraph capture)."""
+    key = (name, str(device), dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
+
+
 # Winograd F(2x2,4x4) of the four parity filters (csrc/conv_wino24.hip; Toom-Cook points 0, 1, -1, 2, inf)
 W24_G = [[0.5, 0, 0, 0], [-0.5, -0.5, -0.5, -0.5], [-1 / 6, 1 / 6, -1 / 6, 1 / 6], [1 / 6, 1 / 3, 2 / 3, 4 / 3], [0, 0, 0, 1]]
 W24_BT = [[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]]
@@ -382,7 +394,7 @@ W24_AT = [[1, 1, 1, 1, 0], [0, 1, -1, 2, 1]]
 
 def fold_weights_wino(w):
     """OIHW 5x5 -> U[class = py*2+px][pos = a*5+b][Cin][Cout] = G W4 G^T of the four 4x4 parity filters (float64)."""
-    G = torch.tensor(W24_G, dtype=torch.float64, device=w.device)
+    G = _const("W24_G", W24_G, w.device, torch.float64)
     u = torch.einsum("at,bs,oipqts->pqabio", G, G, fold_weights(w))
     return u.reshape(4, 25, w.shape[1], w.shape[0])
 
@@ -399,7 +411,7 @@ def pack_fold_wino_dgrad(w):
     """Backward-data of the folded layer on conv_wino24_kernel (RAMNET_IN_PARITY4): Winograd weights of the FLIPPED parity filters
     with the roles of the channels swapped — reduce over (parity class, output channel), produce input channels."""
     Cout, Cin = w.shape[0], w.shape[1]
-    G = torch.tensor(W24_G, dtype=torch.float64, device=w.device)
+    G = _const("W24_G", W24_G, w.device, torch.float64)
     u = torch.einsum("at,bs,ncpqts->abpqnc", G, G, fold_weights(w).flip(4, 5)).reshape(1, 25, 4 * Cout, Cin).float()
     u = u.view(1, 25, 4 * Cout // 16, 4, 4, Cin // 64, 4, 16)                   # cls pos chunk ks j nb cq l15
     return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)
@@ -407,7 +419,7 @@ def pack_fold_wino_dgrad(w):
 
 def fold_weights(w):
     """OIHW 5x5 -> [O][I][py][px][ty][tx]: the 4x4 filter of every output parity, W4 = A_py w A_px^T (float64)."""
-    A = torch.tensor(FOLD_A, dtype=torch.float64, device=w.device)
+    A = _const("FOLD_A", FOLD_A, w.device, torch.float64)
     return torch.einsum("ptk,qsl,oikl->oipqts", A, A, w.double())
 
 
@@ -451,6 +463,17 @@ def s2d_weights_adjoint(g3, I):
     return out
 
 
+# Packed weights are cached per parameter version (an optimizer step bumps it).  A hipGraph replays kernels, not Python: when a
+# training step is captured, every pack kernel has to be IN the graph (the weights change between replays), so the capture
+# starts a new epoch and all packs are re-run — and recorded — once.
+_PACK_EPOCH = 0
+
+
+def invalidate_packs():
+    global _PACK_EPOCH
+    _PACK_EPOCH += 1
+
+
 class PackRef:
     """Handle on the packed weights of a ConvParam; the launch picks the layout (direct / Winograd) that fits it."""
     __slots__ = ("cp", "transposed")
@@ -478,7 +501,7 @@ class ConvParam:
         self._dirty = False
 
     def _versions(self, ts):
-        return tuple((t._version, t.data_ptr()) for t in ts)
+        return (_PACK_EPOCH,) + tuple((t._version, t.data_ptr()) for t in ts)
 
     def _cat_w(self):
         w = self.weights[0] if len(self.weights) == 1 else torch.cat([w.detach() for w in self.weights], 0)
@@ -618,10 +641,10 @@ class ConvParam:
         """dW5 = sum_parities A_py^T dW4 A_px  -  (border GEMM gradients routed back to the taps they summed)."""
         w4, wr, wc = self._ws_fold
         g = ensure_grad(self.weights[0])
-        A = torch.tensor(self._FOLD_A, dtype=torch.float32, device=g.device)                        # [p][t][k]
+        A = _const("FOLD_A", FOLD_A, g.device, torch.float32)                        # [p][t][k]
         d4 = w4.view(2, 2, 4, 4, self.CinWs, self.Cout)[:, :, :, :, :self.Cin]
         if getattr(self, "_fold24_used", False):        # dW4 += G^T dU G
-            G = torch.tensor(W24_G, dtype=torch.float32, device=g.device)
+            G = _const("W24_G", W24_G, g.device, torch.float32)
             d4 = d4 + torch.einsum("at,bs,pqabio->pqtsio", G, G, self._ws_fold24.view(2, 2, 5, 5, self.CinWs, self.Cout))
             self._ws_fold24.zero_()
             self._fold24_used = False

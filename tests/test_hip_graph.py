@@ -1,0 +1,118 @@
+"""GPU: sequence-level execution (rpg_ramnet_amd/graph.py) — the launch chains of the hot path replayed as hipGraphs must give
+the results of the launch-by-launch path (which the other GPU tests pin to the oracle and the reference's goldens).
+Reference loops: model/model.py:176-195 (package), trainer/lstm_trainer.py:256-272 (sequence), test.py:212-232 (streaming)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ramnet_ref
+from recipe import make_item
+from util import assert_close, build_hip_model, ref_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graphed_stream_equals_eager_primitives_and_oracle():
+    """Irregular asynchronous schedule (1..3 event grids between frames), batch 1, persistent state: one hipGraph replay per
+    update+decode == update_events / update_image / decode launch by launch (bit-exact), == the oracle to 1e-3."""
+    from rpg_ramnet_amd.graph import GraphedStream
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    B, H, W = 1, 32, 48
+    gs = GraphedStream(model, B, H, W)
+    rng = np.random.default_rng(2)
+    sched = [2, 1, 3, 1]
+    st = model.init_states(B, H, W)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ncfg = ramnet_ref.normalize_config(cfg)
+    ost = None
+    for n_ev in sched:
+        item = make_item(rng, B, H, W, n_ev, 5, 1)
+        for k in range(n_ev + 1):
+            key = "events%d" % k if k < n_ev else "image"
+            with torch.no_grad():
+                st, _ = (model.update_events if k < n_ev else model.update_image)(item[key], st)
+                want = model.decode(st)
+            got = (gs.update_events if k < n_ev else gs.update_image)(item[key].to(model.gpu))
+            assert torch.equal(got, want), "graph replay differs from the eager launches (%s)" % key
+            with torch.no_grad():
+                if ost is None:
+                    ost = [torch.zeros(B, 64 * 2 ** i, H // 2 ** (i + 1), W // 2 ** (i + 1)) for i in range(3)]
+                ost, _ = ramnet_ref._encode(sd, ncfg, "events" if k < n_ev else "images", item[key], ost, None)
+                ref = ramnet_ref._decode(sd, ncfg, ost)
+            assert_close(got.cpu().numpy(), ref.numpy(), 1e-3, "stream vs oracle " + key)
+    for a, b in zip(gs.states, st):
+        assert torch.equal(a, b)
+    gs.reset()
+    assert all(float(s.abs().sum()) == 0.0 for s in gs.states)
+
+
+def test_graphed_package_equals_model_forward(monkeypatch):
+    """Two consecutive packages (state carried): GraphedPackage == model.forward, also with the decoders on a second stream
+    (the fork/join is captured into the graph)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.graph import GraphedPackage
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=3)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    rng = np.random.default_rng(3)
+    items = [make_item(rng, 2, 32, 48, 3, 5, 1) for _ in range(2)]
+    for overlap in (False, True):
+        ops.set_decoder_overlap(overlap)
+        try:
+            gp = GraphedPackage(model, items[0])
+            prev, lstm = None, ramnet_ref.empty_states_lstm(3)
+            for item in items:
+                with torch.no_grad():
+                    want, supers, lstm = model(item, prev, lstm)
+                prev = supers["image"]
+                got = gp(item)
+                assert list(got.keys()) == list(want.keys())
+                for k in want:
+                    assert torch.equal(got[k], want[k]), (overlap, k)
+        finally:
+            ops.set_decoder_overlap(False)
+
+
+@pytest.mark.parametrize("schedule", ["single_stream", "three_streams"])
+def test_graphed_train_step_equals_eager_steps(schedule):
+    """Three optimizer steps: graph replays (zero-fill, forward, loss, backward, fold) + eager Adam == the eager path.  The
+    second and third step prove that the weight re-packing is INSIDE the graph (Adam changed the weights in between)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.graph import GraphedTrainStep
+    from rpg_ramnet_amd.parallel import FlatGradReducer
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
+    rng = np.random.default_rng(4)
+    seq = [make_item(rng, 2, 32, 48, 2, 5, 1, True, 0.1) for _ in range(2)]
+    on = schedule == "three_streams"
+    ops.set_wgrad_overlap(on)
+    ops.set_decoder_overlap(on)
+    try:
+        losses, weights = {}, {}
+        for mode in ("eager", "graph"):
+            model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+            red = FlatGradReducer(model)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            dseq = [{k: v.to(model.gpu) for k, v in it.items()} for it in seq]
+            g = GraphedTrainStep(model, dseq, cfg["loss_composition"], [1, 1], reducer=red) if mode == "graph" else None
+            out = []
+            for _ in range(3):
+                if g is not None:
+                    total, _ = g()
+                else:
+                    red.zero()
+                    total, _ = sequence_loss(model, dseq, cfg["loss_composition"], [1, 1])
+                    total.backward()
+                out.append((float(total), red.flat.clone()))
+                opt.step()
+            losses[mode] = out
+            weights[mode] = torch.cat([p.detach().flatten() for p in model.parameters()])
+        for i, ((le, ge), (lg, gg)) in enumerate(zip(losses["eager"], losses["graph"])):
+            np.testing.assert_allclose(lg, le, rtol=1e-5, err_msg="loss of step %d" % i)
+            scale = float(ge.abs().max())
+            assert float((gg - ge).abs().max()) / scale < 2e-4 * (i + 1), "gradients of step %d" % i
+        assert float((weights["graph"] - weights["eager"]).abs().max()) < 2e-5
+        assert losses["graph"][2][0] != losses["graph"][0][0]          # the steps really trained
+    finally:
+        ops.set_wgrad_overlap(False)
+        ops.set_decoder_overlap(False)
