@@ -403,15 +403,21 @@ def main():
             return pred.mean()
 
         from rpg_ramnet_amd.graph import GraphedStream
-        gs = GraphedStream(model, B, H, W)                         # one hipGraph per (update + decode): the default for this mode
+        # hipGraph replays; the decode of update k runs on a second stream, concurrent with update k+1 (graph.GraphedStream)
+        gs = GraphedStream(model, B, H, W, pipelined=True)
+        gs_serial = GraphedStream(model, B, H, W, pipelined=False)
 
-        def step():
+        def run_stream(g):
             for l, item in enumerate(seq):
                 for k in range(sched[l]):
-                    pred = gs.update_events(item["events%d" % (k % K)])
-                pred = gs.update_image(item["image"])
-            return pred.mean()
+                    pred = g.update_events(item["events%d" % (k % K)])
+                pred = g.update_image(item["image"])
+            return g.wait(pred).mean()
+
+        def step():
+            return run_stream(gs)
         graphed["eager"] = eager_step
+        graphed["graph_serial"] = lambda: run_stream(gs_serial)
     else:
         model.eval()
 
@@ -509,6 +515,9 @@ def main():
         timer.on = False
         if "eager" in graphed:      # stream / infer: the timed region replays hipGraphs; the same work launch by launch
             extras["eager_launches"] = measure(graphed["eager"])
+            if "graph_serial" in graphed:
+                extras["graph_update_then_decode"] = dict(measure(graphed["graph_serial"]), note="hipGraph replays with the decode of "
+                                                          "update k BEFORE update k+1 on one stream (the timed region overlaps them)")
         elif args.mode == "train" and not args.graph:
             try:
                 extras["graph_replay"] = dict(measure(make_graph_step()), note="the same step as ONE hipGraph replay (zero-fill, forward, "

@@ -36,60 +36,99 @@ def _warm(fn, n=2):
 
 class GraphedStream:
     """Streaming inference (batch B, persistent state): ``update_events(grid)`` / ``update_image(frame)`` fold one measurement
-    into the shared state and return the depth prediction decoded from it — one hipGraph replay each."""
+    into the shared state and return the depth prediction decoded from it — hipGraph replays, no per-kernel host work.
 
-    def __init__(self, model, B, H, W):
+    The state lives in two static buffer sets used in ping-pong (update k reads set s and writes set 1-s: a previous state is
+    never modified in place, as in the eager path).  ``pipelined=True`` replays the decoder graph of update k on a second HIP
+    stream, concurrent with update k+1 on the first: at batch 1 both chains are latency-bound with a fraction of the chip
+    occupied each (a dozen workgroups per launch), so they overlap almost freely.  Predictions are then valid on the caller's
+    stream after ``wait(pred)`` (an event wait, no host sync) and until the second-next update overwrites the buffer."""
+
+    def __init__(self, model, B, H, W, pipelined=False):
         assert not bool(model.baseline), "streaming graphs are built for the asynchronous RAM-Net (not the baselines)"
         self.model, dev = model, model.gpu
+        self.pipelined = pipelined
         self.ev_in = torch.zeros(B, model.num_bins_events, H, W, device=dev)
         self.im_in = torch.zeros(B, model.num_bins_rgb, H, W, device=dev)
-        self.states = model.init_states(B, H, W)            # static buffers: read and overwritten by every replay
-        self.graphs, self.preds = {}, {}
+        self.sets = [model.init_states(B, H, W), model.init_states(B, H, W)]
+        self.cur = 0                                    # index of the set holding the current state
+        self.upd, self.dec, self.pred = {}, [None, None], [None, None]
+        self.side = torch.cuda.Stream(device=dev) if pipelined else None
+        self.dec_done = [None, None]                    # event behind the last decode that READ set i
         was_training = model.training
         model.eval()
-        snapshot = [self._clone(s) for s in self.states]
-        for kind, buf, update in (("events", self.ev_in, model.update_events), ("image", self.im_in, model.update_image)):
-            def run(buf=buf, update=update):
+        for src in (0, 1):
+            for kind, buf, update in (("events", self.ev_in, model.update_events), ("image", self.im_in, model.update_image)):
+                def run(buf=buf, update=update, src=src):
+                    with torch.no_grad():
+                        new, _ = update(buf, self.sets[src])
+                        for dst, s_ in zip(self.sets[1 - src], new):
+                            for d, t in zip(self._flat(dst), self._flat(s_)):
+                                d.copy_(t)
+                _warm(run)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    run()
+                self.upd[(kind, src)] = g
+
+            def decode(src=src):
                 with torch.no_grad():
-                    new, _ = update(buf, self.states)
-                    pred = model.decode(new)
-                    for dst, src in zip(self.states, new):          # the state advances inside the graph
-                        for d, s in zip(self._flat(dst), self._flat(src)):
-                            d.copy_(s)
-                return pred
-            _warm(run)
+                    return model.decode(self.sets[src])
+            _warm(decode)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                pred = run()
-            self.graphs[kind], self.preds[kind] = g, pred
-        for dst, src in zip(self.states, snapshot):                 # undo the warm-up / capture updates
-            for d, s in zip(self._flat(dst), self._flat(src)):
-                d.copy_(s)
+                self.pred[src] = decode()
+            self.dec[src] = g
+        self.reset()
         model.train(was_training)
 
     @staticmethod
     def _flat(s):
         return list(s) if isinstance(s, (list, tuple)) else [s]
 
-    @classmethod
-    def _clone(cls, s):
-        return [t.clone() for t in s] if isinstance(s, (list, tuple)) else s.clone()
+    @property
+    def states(self):
+        """The current multi-scale state (static buffers; valid on the caller's stream)."""
+        return self.sets[self.cur]
 
     def reset(self):
-        for s in self.states:
-            for t in self._flat(s):
-                t.zero_()
+        torch.cuda.synchronize(self.model.gpu)
+        for st in self.sets:
+            for s in st:
+                for t in self._flat(s):
+                    t.zero_()
+        self.cur, self.dec_done = 0, [None, None]
+
+    def _step(self, kind, buf, data):
+        src, dst = self.cur, 1 - self.cur
+        main = torch.cuda.current_stream()
+        if self.dec_done[dst] is not None:              # the decode that still reads the set this update overwrites
+            main.wait_event(self.dec_done[dst])
+        buf.copy_(data, non_blocking=True)
+        self.upd[(kind, src)].replay()
+        self.cur = dst
+        if not self.pipelined:
+            self.dec[dst].replay()
+            return self.pred[dst]
+        self.side.wait_event(main.record_event())
+        with torch.cuda.stream(self.side):
+            self.dec[dst].replay()
+            self.dec_done[dst] = self.side.record_event()
+        return self.pred[dst]
 
     def update_events(self, grid):
-        """grid [B, Ce, H, W] (device or pinned host) -> prediction [B,1,H,W] (a static buffer: overwritten by the next call)."""
-        self.ev_in.copy_(grid, non_blocking=True)
-        self.graphs["events"].replay()
-        return self.preds["events"]
+        """grid [B, Ce, H, W] (device or pinned host) -> prediction [B,1,H,W] (a static buffer; pipelined: see wait())."""
+        return self._step("events", self.ev_in, grid)
 
     def update_image(self, frame):
-        self.im_in.copy_(frame, non_blocking=True)
-        self.graphs["image"].replay()
-        return self.preds["image"]
+        return self._step("image", self.im_in, frame)
+
+    def wait(self, pred=None):
+        """Make the caller's stream wait for the decodes in flight (pipelined mode); returns `pred`."""
+        for e in self.dec_done:
+            if e is not None:
+                torch.cuda.current_stream().wait_event(e)
+        return pred
 
 
 class GraphedPackage:

@@ -12,14 +12,15 @@ from util import assert_close, build_hip_model, ref_cfg
 pytestmark = pytest.mark.gpu
 
 
-def test_graphed_stream_equals_eager_primitives_and_oracle():
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_graphed_stream_equals_eager_primitives_and_oracle(pipelined):
     """Irregular asynchronous schedule (1..3 event grids between frames), batch 1, persistent state: one hipGraph replay per
     update+decode == update_events / update_image / decode launch by launch (bit-exact), == the oracle to 1e-3."""
     from rpg_ramnet_amd.graph import GraphedStream
     cfg, _ = ref_cfg("net_seeded_ramnet.npz")
     model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
     B, H, W = 1, 32, 48
-    gs = GraphedStream(model, B, H, W)
+    gs = GraphedStream(model, B, H, W, pipelined=pipelined)
     rng = np.random.default_rng(2)
     sched = [2, 1, 3, 1]
     st = model.init_states(B, H, W)
@@ -33,7 +34,7 @@ def test_graphed_stream_equals_eager_primitives_and_oracle():
             with torch.no_grad():
                 st, _ = (model.update_events if k < n_ev else model.update_image)(item[key], st)
                 want = model.decode(st)
-            got = (gs.update_events if k < n_ev else gs.update_image)(item[key].to(model.gpu))
+            got = gs.wait((gs.update_events if k < n_ev else gs.update_image)(item[key].to(model.gpu))).clone()
             assert torch.equal(got, want), "graph replay differs from the eager launches (%s)" % key
             with torch.no_grad():
                 if ost is None:
@@ -43,6 +44,28 @@ def test_graphed_stream_equals_eager_primitives_and_oracle():
             assert_close(got.cpu().numpy(), ref.numpy(), 1e-3, "stream vs oracle " + key)
     for a, b in zip(gs.states, st):
         assert torch.equal(a, b)
+    if pipelined:       # back-to-back updates without waiting in between: decodes overlap the next update, results unchanged
+        gs.reset()
+        st = model.init_states(B, H, W)
+        item = make_item(rng, B, H, W, 4, 5, 1)
+        preds = []
+        for k in range(5):
+            key = "events%d" % k if k < 4 else "image"
+            with torch.no_grad():
+                st, _ = (model.update_events if k < 4 else model.update_image)(item[key], st)
+                preds.append(model.decode(st))
+        torch.cuda.synchronize()
+        dev_item = {k: v.to(model.gpu) for k, v in item.items()}
+        got = []
+        for k in range(5):
+            key = "events%d" % k if k < 4 else "image"
+            p = (gs.update_events if k < 4 else gs.update_image)(dev_item[key])
+            if k >= 1:                                   # the previous prediction is still intact while this update runs
+                got.append(prev.clone())                 # (clone is ordered behind the decode through wait())
+            prev = gs.wait(p)
+        got.append(prev.clone())
+        for a, b in zip(got, preds):
+            assert torch.equal(a, b)
     gs.reset()
     assert all(float(s.abs().sum()) == 0.0 for s in gs.states)
 
