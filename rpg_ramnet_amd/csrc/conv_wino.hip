@@ -66,7 +66,8 @@ struct WinoPatch {
     int cmax[2];                          // channels c0 < cmax are valid for the slot (-1: outside the image / no slot)
     int ldst[2];                          // LDS float offset of the slot, or -1
 
-    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid) {
+    // planar: LDS patch [channel quad 2][pixel][4] (conv_wino_r_kernel) instead of [pixel][8]
+    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid, bool planar = false) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int sl = tid + i * 256;
@@ -81,7 +82,7 @@ struct WinoPatch {
                                                                    : (unsigned)((b * s.Hin + iy) * s.Win + ix);
             off0[i] = gp * s.ld0 + qd * 4, off1[i] = gp * s.ld1 + qd * 4, offm[i] = gp * s.ldm + qd * 4;
             cmax[i] = in ? s.Cin - qd * 4 : -1;
-            ldst[i] = slot ? sl * 4 : -1;
+            ldst[i] = !slot ? -1 : planar ? qd * (WPH * WPW * 4) + pix * 4 : sl * 4;
         }
     }
     // issue the global loads of slot i for the 8 channels starting at c0 (wave-uniform)
@@ -359,6 +360,237 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
     { const int chunk = 31; WINO_STAMP(3); }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv_wino_r_kernel: the same convolution with the transform positions SPLIT OVER THE WAVES and the transformed input kept
+// in registers.  Wave w owns row w of the 4x4 transform grid (positions 4w .. 4w+3) for all 32 tiles x 64 channels of the
+// workgroup, on v_mfma_f32_32x32x2_f32: M = 32 tiles, N = 32 channels (two blocks), K = 2 input channels.  Lane (tile = lane & 31,
+// half = lane >> 5) transforms row w of B^T d B for its tile and the channel quad `half` of the 8-channel chunk — and that IS
+// the A operand of the MFMA (lanes 0-31 supply K index 0, lanes 32-63 K index 1: channel j of quad 0 pairs with channel j of
+// quad 1), so the transformed input never goes through LDS: per chunk a wave issues 8 LDS reads of the raw patch instead of
+// 8 reads + 4 writes + 32 operand fetches, and 32 MFMAs of 64 cycles instead of 64 of 32.  Only the raw patch is shared (one
+// barrier per chunk, double-buffered as before).  The price is paid once per workgroup: the output transform needs all four
+// rows of a tile, so the waves exchange their column-transformed partial sums (2 of 4 columns survive: A^T M A) through LDS
+// (70 KB) before the fused epilogue.  Weights: packed per (chunk, block, wave) in MFMA B-operand lane order, 16-byte loads.
+constexpr int RP_PLANE = WPH * WPW * 4;          // floats of one channel-quad plane of the patch
+constexpr int RP_FLOATS = 2 * RP_PLANE;
+constexpr int RO_LD = WBN + 4;                   // row of the exchange buffer [wave 4][column 2][tile 32][64 channels + pad]
+constexpr int RO_FLOATS = 4 * 2 * 32 * RO_LD;
+
+__global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_desc p, const WinoParams q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                  // [2 buffers][2 quads][10 x 18 pixels][4]; the epilogue reuses the space
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hq = lane >> 5;
+
+    const int xslot = blockIdx.x >> 3;    // XCD-aware order, as conv_wino_kernel
+    const int nblk_i = xslot % q.nblk;
+    int bid = (xslot / q.nblk) * 8 + (blockIdx.x & 7);
+    if (bid >= q.tiles_x * q.tiles_y * p.B) return;
+    const int tx_i = bid % q.tiles_x;
+    bid /= q.tiles_x;
+    const int ty_i = bid % q.tiles_y;
+    const int b = bid / q.tiles_y;
+    const int n0 = nblk_i * WBN;
+    const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
+    const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
+
+    // row `wave` of B^T d B: rows (ra, rb) of the tile's 4 x 4 window, te = d[ra] + sb * d[rb]
+    const int tty = l31 >> 3, ttx = l31 & 7;
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sb = wave == 1 ? 1.f : -1.f;
+    const int pra = hq * RP_PLANE + ((2 * tty + ra) * WPW + 2 * ttx) * 4;
+    const int prb = hq * RP_PLANE + ((2 * tty + rb) * WPW + 2 * ttx) * 4;
+    // weights: [chunk][block64][wave 4][position-in-row 4][n-block 2][lane 64][channel j 4]
+    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + wave * 2048 + lane * 4;
+    const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
+
+    WinoPatch pr;
+    pr.init(q.src, b, iy0, ix0, tid, true);
+    float4 breg[4][2];
+    float4 tcur[4], tnext[4], ta, tb;
+    auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
+    auto f4sub = [](float4 x, float4 y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+
+    const int nch = q.nchunks;
+    const int clast = (nch - 1) * WK;
+    pr.load(q.src, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) breg[i >> 1][i & 1] = ld4(wsrc + i * 256);
+    pr.store(patch, q.src, 0);
+    pr.load(q.src, min(WK, clast));
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tcur[c] = te(ld4(patch + pra + c * 4), ld4(patch + prb + c * 4));
+    pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
+    pr.load(q.src, min(2 * WK, clast));
+    __syncthreads();
+    for (int chunk = 0; chunk < nch; ++chunk) {
+        const float *pnext = patch + ((chunk + 1) & 1) * RP_FLOATS;     // patch(i+1)
+        float *pfree = patch + (chunk & 1) * RP_FLOATS;                 // patch(i), consumed during chunk i-1 -> patch(i+2)
+        const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
+        const int c2 = min((chunk + 2) * WK, clast), c3 = min((chunk + 3) * WK, clast);
+        auto side = [&](int k) {                    // compile-time constant after unrolling: one slice behind every MFMA
+            if (k < 8) {
+                if (!(k & 1)) ta = ld4(pnext + pra + (k >> 1) * 4), tb = ld4(pnext + prb + (k >> 1) * 4);
+                else tnext[k >> 1] = te(ta, tb);
+            } else if (k < 10) pr.store_slot(pfree, q.src, c2, k - 8);
+            else if (k < 12) pr.load_slot(q.src, c3, k - 10);
+        };
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            const float4 v = pl == 0 ? f4sub(tcur[0], tcur[2]) : pl == 1 ? f4add(tcur[1], tcur[2]) : pl == 2 ? f4sub(tcur[2], tcur[1]) : f4sub(tcur[1], tcur[3]);
+            const float va[4] = {v.x, v.y, v.z, v.w};
+            const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
+            const float b1[4] = {breg[pl][1].x, breg[pl][1].y, breg[pl][1].z, breg[pl][1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                side(pl * 8 + j * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                side(pl * 8 + j * 2 + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            breg[pl][0] = ld4(wnext + (pl * 2) * 256), breg[pl][1] = ld4(wnext + (pl * 2 + 1) * 256);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tcur[c] = tnext[c];
+        __syncthreads();                           // patch(i+2) visible; patch(i+1) free
+    }
+
+    // ---- exchange: column transform of the wave's row (M A: 2 of 4 columns), all waves -> LDS.
+    // D of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile)
+    float *P = smem;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r];
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
+            P[((wave * 2 + 0) * 32 + m) * RO_LD + f * 32 + l31] = m0 + m1 + m2;
+            P[((wave * 2 + 1) * 32 + m) * RO_LD + f * 32 + l31] = m1 - m2 - m3;
+        }
+    __syncthreads();
+    // row transform A^T (.) across the waves for output pixel pxl (0..127 of the 8 x 16 tile) and channels col .. col+3
+    auto out4 = [&](int pxl, int col) {
+        const int py = pxl >> 4, px = pxl & 15;
+        const float *base = P + ((px & 1) * 32 + (py >> 1) * 8 + (px >> 1)) * RO_LD + col;
+        const float4 t1 = ld4(base + 1 * 64 * RO_LD), t2 = ld4(base + 2 * 64 * RO_LD);
+        if (py & 1) {
+            const float4 t3 = ld4(base + 3 * 64 * RO_LD);
+            return make_float4(t1.x - t2.x - t3.x, t1.y - t2.y - t3.y, t1.z - t2.z - t3.z, t1.w - t2.w - t3.w);
+        }
+        const float4 t0 = ld4(base);
+        return make_float4(t0.x + t1.x + t2.x, t0.y + t1.y + t2.y, t0.z + t1.z + t2.z, t0.w + t1.w + t2.w);
+    };
+    const int epi = p.epi;
+    if (q.vec4 && epi == RAMNET_EPI_LSTM) {
+        // ConvLSTM cell (submodules.py:346-358): the block's 64 columns are 16 hidden channels x gates (i, f, o, g)
+        const int C = p.Cout;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = tid + i * 256, pxl = sl >> 2, qd = sl & 3;
+            const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), chn = nblk_i * 16 + qd * 4;
+            if (oy >= p.Ho || ox >= p.Wo || chn >= C) continue;
+            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
+            const float4 ai = f4add(out4(pxl, qd * 4), ld4(p.bias + chn)), af = f4add(out4(pxl, 16 + qd * 4), ld4(p.bias + C + chn));
+            const float4 ao = f4add(out4(pxl, 32 + qd * 4), ld4(p.bias + 2 * C + chn)), ag = f4add(out4(pxl, 48 + qd * 4), ld4(p.bias + 3 * C + chn));
+            const float4 gi = make_float4(sigmoidf_(ai.x), sigmoidf_(ai.y), sigmoidf_(ai.z), sigmoidf_(ai.w));
+            const float4 gf = make_float4(sigmoidf_(af.x), sigmoidf_(af.y), sigmoidf_(af.z), sigmoidf_(af.w));
+            const float4 go = make_float4(sigmoidf_(ao.x), sigmoidf_(ao.y), sigmoidf_(ao.z), sigmoidf_(ao.w));
+            const float4 gc = make_float4(tanhf(ag.x), tanhf(ag.y), tanhf(ag.z), tanhf(ag.w));
+            const float4 cp = p.e1 ? ld4(p.e1 + pix * p.lde1 + chn) : f4zero();
+            const float4 cn = make_float4(gf.x * cp.x + gi.x * gc.x, gf.y * cp.y + gi.y * gc.y, gf.z * cp.z + gi.z * gc.z, gf.w * cp.w + gi.w * gc.w);
+            st4(p.out + pix * p.ldo + chn, make_float4(go.x * tanhf(cn.x), go.y * tanhf(cn.y), go.z * tanhf(cn.z), go.w * tanhf(cn.w)));
+            st4(p.o1 + pix * p.ldo1 + chn, cn);
+            if (p.o2) {
+                float *g = p.o2 + pix * p.ldo2 + chn;
+                st4(g, gi), st4(g + C, gf), st4(g + 2 * C, go), st4(g + 3 * C, gc);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int sl = tid + i * 256, pxl = sl >> 4, qd = sl & 15;
+        const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), nq = n0 + qd * 4;
+        if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
+        const float4 y = out4(pxl, qd * 4);
+        if (q.s2d_shift) {      // out_s2d: the quad's parity group picks the full-resolution pixel (LINEAR, no bias: checked on the host)
+            const int g = nq >> q.s2d_shift;
+            const size_t pix = ((size_t)b * p.HoF + 2 * oy + (g >> 1)) * p.WoF + 2 * ox + (g & 1);
+            st4(p.out + pix * p.ldo + (nq - (g << q.s2d_shift)), y);
+            continue;
+        }
+        const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
+        const bool addold = epilogue_addold(p, oy * p.osy + p.ooy, ox * p.osx + p.oox);
+        if (q.vec4) {
+            epilogue_store4(p, epi, pix, nq, y, addold);
+        } else {                // channel counts / strides that rule out 16-byte accesses
+            const float ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nq + e < p.Cout) epilogue_store(p, epi, pix, nq + e, ys[e], addold);
+        }
+    }
+}
+
+// B operand of conv_wino_r_kernel: index = (((((chunk * nblk + nb) * 4 + w) * 4 + pl) * 2 + f) * 64 + lane) * 4 + j  ->
+// U[position 4w + pl][input channel chunk*8 + 4*(lane >> 5) + j][output channel nb*64 + f*32 + (lane & 31)]
+__global__ void pack_weight_wino_r_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
+                                          int gates, int R, int N, int nchunks, int nblk, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3), lane = (int)((i >> 2) & 63), f = (int)((i >> 8) & 1), pl = (int)((i >> 9) & 3), wv = (int)((i >> 11) & 3);
+        const size_t jj = i >> 13;
+        const int nb = (int)(jj % nblk), chunk = (int)(jj / nblk);
+        const int n = f * 32 + (lane & 31), pos = 4 * wv + pl;
+        const int r = chunk * WK + 4 * (lane >> 5) + j;
+        int no = nb * WBN + n;
+        bool ok = r < R && no < N;
+        if (gates > 1) {    // ConvLSTM: a 64-column block = 16 hidden channels x (i, f, o, g)
+            const int C = N / gates, chn = nb * 16 + (n & 15);
+            ok = r < R && chn < C;
+            no = (n >> 4) * C + chn;
+        }
+        float v = 0.f;
+        if (ok) {
+            double g[3][3];
+            for (int a = 0; a < 3; ++a)
+                for (int bb = 0; bb < 3; ++bb)
+                    g[a][bb] = transposed ? (double)w[((size_t)r * Cin + no) * 9 + (2 - a) * 3 + (2 - bb)]
+                                          : (double)w[((size_t)no * Cin + r) * 9 + a * 3 + bb];
+            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const int pi = pos >> 2, pj = pos & 3;
+            double s = 0;
+            for (int a = 0; a < 3; ++a)
+                for (int bb = 0; bb < 3; ++bb) s += G[pi][a] * g[a][bb] * G[pj][bb];
+            v = (float)s;
+        }
+        wp[i] = v;
+    }
+}
+
+// Which kernel serves RAMNET_ALGO_WINOGRAD: the register-resident transform (default) or the LDS-transform kernel
+// (RAMNET_WINO_LDS_TRANSFORM=1, kept for A/B measurements; the weight pack follows the same switch).
+static bool wino_reg_transform() {
+    static const char *e = getenv("RAMNET_WINO_LDS_TRANSFORM");
+    return !(e && e[0] == '1');
+}
+
 // OIHW 3x3 -> U = G g G^T in the lane order of the kernel's B operand (see wsrc above); evaluated in double.
 __global__ void pack_weight_wino_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
                                         int gates, int R, int N, int nchunks, int nblk, size_t total) {
@@ -446,8 +678,16 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
                          !d.bias && d.beta == 0.f && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
         q.s2d_shift = log2_exact(d.out_s2d);
     }
-    const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
+    if (wino_reg_transform()) {
+        const size_t lds = (size_t)(RO_FLOATS > 2 * RP_FLOATS ? RO_FLOATS : 2 * RP_FLOATS) * sizeof(float);
+        RAMNET_FULL_LDS(conv_wino_r_kernel);
+        note_kernel("conv_wino_r_kernel");
+        hipLaunchKernelGGL(conv_wino_r_kernel, grid, dim3(256), lds, st, d, q);
+        RAMNET_LAUNCH_CHECK();
+        return 0;
+    }
+    const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
     note_kernel("conv_wino_kernel");
     hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();
@@ -472,8 +712,12 @@ extern "C" int ramnet_pack_weight_wino(const float *w, float *wp, int Cout, int 
     const size_t total = (size_t)nchunks * nblk * WU_FLOATS;
     size_t blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, transposed,
-                       gates, R, N, nchunks, nblk, total);
+    if (wino_reg_transform())
+        hipLaunchKernelGGL(pack_weight_wino_r_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin,
+                           transposed, gates, R, N, nchunks, nblk, total);
+    else
+        hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, transposed,
+                           gates, R, N, nchunks, nblk, total);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
