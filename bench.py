@@ -105,7 +105,7 @@ def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
 def winograd_factor(kernel):
     """Multiplies the MFMA pipe executes per multiply of the tap list the launch was given: F(2x2,3x3) 16 per 36,
     F(2x2,4x4) 25 per 64; direct kernels 1."""
-    if kernel.startswith(("conv_wino_kernel", "conv_wino_r_kernel", "conv_wgrad_wino_kernel")):
+    if kernel.startswith(("conv_wino_kernel", "conv_wino_r_kernel", "conv_wgrad_wino_kernel", "conv_wgrad_wino_r_kernel")):
         return 16.0 / 36.0
     if kernel.startswith(("conv_wino24_kernel", "conv_wgrad_wino24_kernel")):
         return 25.0 / 64.0

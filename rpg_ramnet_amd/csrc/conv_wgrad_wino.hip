@@ -295,6 +295,251 @@ __global__ void __launch_bounds__(CIB * 8, CIB == 32 ? 2 : 1) conv_wgrad_wino_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv_wgrad_wino_r_kernel: the same sums with BOTH transforms kept in registers.  The four waves of a workgroup (32 input x 64
+// output channels) split the ROWS of the 4 x 4 transform grid: wave w accumulates positions 4w .. 4w+3 for all channels of the
+// workgroup (4 positions x 2 output-channel blocks x 32x32 = 128 accumulator VGPRs, as before).  One MFMA step reduces over two
+// tiles: lane (channel = lane & 31, tile parity = lane >> 5) reads its tile's raw input window rows / gradient pixels from LDS
+// (lanes along channels: conflict-free 4-byte reads), forms row w of B^T d B resp. A dy A^T in registers — and those ARE the A / B
+// operands of v_mfma_f32_32x32x2_f32 (K index = tile parity).  Nothing transformed ever goes through LDS: the transform phase
+// between two barriers, the V / Z buffers (49 of 67 KB) and their 32 stores + 16 operand reads per thread and batch are gone; the
+// raw strips are double-buffered, ONE barrier per batch, and the transform of tile pair s+1 sits in the gaps between the MFMAs of
+// tile pair s.
+// TXB = tiles per batch row: 8 (a 2 x 16 pixel strip) or 2 (8 x 4 pixels: the 43- / 86-pixel-wide maps of the coarse scales then
+// lose 2 % instead of 10 % of the work to the partial last strip).
+template <int TXB> struct GrGeom {
+    static constexpr int TYB = 8 / TXB, YH = 2 * TYB, YW = 2 * TXB, PH = YH + 2, PW = YW + 2;
+    static constexpr int XPIX = PH * PW, XSLOTS = XPIX * 8, NXS = (XSLOTS + 255) / 256;
+    static constexpr int XP = XPIX * 32;           // raw input strip [PH x PW pixels][32 channels]
+    static constexpr int YP = 32 * GW_CO;          // raw gradient strip [YH x YW = 32 pixels][64 channels]
+    static constexpr int SX = TXB == 8 ? 4 * 32 : 2 * PW * 32, SY = TXB == 8 ? 4 : 2 * YW;     // step of a tile pair (floats / pixels)
+};
+
+template <bool XM, bool GM, int TXB>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
+    using G = GrGeom<TXB>;
+    constexpr int NT = 256, XQ = 8, GW_CI = 32, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
+    constexpr int PW = G::PW, YW = G::YW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xp = smem;                   // [2][72][32]
+    float *Yp = smem + 2 * GR_XP;       // [2][32][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int c0 = blockIdx.y * GW_CI, n0 = blockIdx.z * GW_CO;
+    const InSrc &s = q.src;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][f][r] = 0.f;
+
+    // ---- raw-data prefetch (as conv_wgrad_wino_kernel<.,.,32>): per-thread slot geometry, wave-uniform base pointers
+    float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
+    unsigned xok = 0, yok = 0;
+    const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
+    const bool use_m = XM && (s.mode == RAMNET_IN_RELUMASK || second);
+    const bool s2d = s.mode == RAMNET_IN_S2D;
+    const int sgrp = s2d ? c0 >> s.ld1 : 0;
+    const int rowS = s2d ? 4 * s.Win : s.Win, colS = s2d ? 2 : 1;
+    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s2d ? s.x0 + ((sgrp >> 1) * 2 * s.Win + (sgrp & 1)) * s.ld0 + (c0 - (sgrp << s.ld1)) : s.x0 + c0;
+    const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
+    const int ldS = second ? s.ld1 : s.ld0;
+    int xpy[NXS], xpx[NXS], xoff[NXS], xmoff[NXS], ypx[NYS], ypy[NYS], yoff[NYS], ymoff[NYS];
+    const int safe_x = (-q.dy0 * rowS - q.dx0 * colS) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;
+    bool xslot[NXS], yslot[NYS];
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+        const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
+        xpy[i] = pix / PW, xpx[i] = pix - xpy[i] * PW;
+        xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
+        xoff[i] = (xpy[i] * rowS + xpx[i] * colS) * ldS + qd * 4;
+        xmoff[i] = (xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NYS; ++i) {
+        const int sl = tid + i * NT, qd = sl & 15, pix = sl >> 4;
+        ypx[i] = pix % YW, ypy[i] = pix / YW;
+        yslot[i] = n0 + qd * 4 < p.Cout;
+        yoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4;
+        ymoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4;
+    }
+    int lb_ty = 0, lb_bx = 0;
+    const float *lb_x = nullptr, *lb_m = nullptr, *lb_g = nullptr, *lb_gm = nullptr;
+    auto load_begin = [&](int batch) {
+        int tt = batch;
+        lb_bx = tt % q.bx_n;
+        tt /= q.bx_n;
+        lb_ty = tt % q.ty_n;
+        const int b = tt / q.ty_n;
+        const long pix = ((long)b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
+        const long corner = pix + (long)q.dy0 * s.Win + q.dx0;
+        const long corner_src = s2d ? ((long)b * p.Ho + G::YH * lb_ty + q.dy0) * rowS + (YW * lb_bx + q.dx0) * colS : corner;
+        lb_x = xsrc + corner_src * ldS;
+        if (use_m) lb_m = msrc + corner * s.ldm;
+        lb_g = p.dout + pix * p.ldg;
+        if (GM) lb_gm = p.gmask + pix * p.ldgm;
+        xok = 0, yok = 0;
+    };
+    auto load_x = [&](int i) {
+        const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
+        const bool ok = xslot[i] && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
+        xr[i] = ld4(lb_x + (ok ? xoff[i] : safe_x));
+        if (use_m) xm[i] = ld4(lb_m + (ok ? xmoff[i] : safe_m));
+        xok |= (ok ? 1u : 0u) << i;
+    };
+    auto load_y = [&](int i) {
+        const bool ok = yslot[i] && G::YH * lb_ty + ypy[i] < p.Ho && YW * lb_bx + ypx[i] < p.Wo;
+        yr[i] = ld4(lb_g + (ok ? yoff[i] : 0));
+        if (GM) ym[i] = ld4(lb_gm + (ok ? ymoff[i] : 0));
+        yok |= (ok ? 1u : 0u) << i;
+    };
+    auto load_raw = [&](int batch) {
+        load_begin(batch);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) load_x(i);
+#pragma unroll
+        for (int i = 0; i < NYS; ++i) load_y(i);
+    };
+    float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
+    auto store_x = [&](int i, float *xb) {
+        const int sl = tid + i * NT;
+        float4 r = xr[i];
+        if (use_m) {
+            if (s.mode == RAMNET_IN_RELUMASK)
+                r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
+            else
+                r = f4mul(r, xm[i]);
+        }
+        if (!((xok >> i) & 1u)) r = f4zero();
+        if (sl < XSLOTS) st4(xb + (sl / XQ) * 32 + (sl % XQ) * 4, r);
+    };
+    bool count_bias = true;                       // false for the clamped re-store of the last batch
+    auto store_y = [&](int i, float *yb) {
+        const int sl = tid + i * NT;
+        float4 r = yr[i];
+        if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
+        if (!((yok >> i) & 1u)) r = f4zero();
+        st4(yb + (sl >> 4) * GW_CO + (sl & 15) * 4, r);
+        if (count_bias) bsum = f4add(bsum, r);
+    };
+
+    // ---- row `wave` of the two transforms.  B^T d B: rows (ra, rb) of the window, te = d[ra] + sb * d[rb];
+    // A dy: ca * g[0][.] + cb * g[1][.]  ((1,0), (1,1), (1,-1), (0,-1))
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sb = wave == 1 ? 1.f : -1.f;
+    const float ca = wave == 3 ? 0.f : 1.f, cb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+    // tile of MFMA step st and K index kk: TXB = 8: (row 0, column 2 st + kk); TXB = 2: (row st, column kk)
+    const int xa_off = (ra * PW + 2 * kk) * 32 + l31, xb_off = (rb * PW + 2 * kk) * 32 + l31;      // + st * G::SX
+    const int y_off = (2 * kk) * GW_CO + l31;                                                       // + st * G::SY pixels
+    float da[4], db[4], g0[2][2], g1[2][2];      // raw operands of the tile pair being prepared
+    float an[4], bn[2][4];
+    auto fetch_x = [&](const float *xc, int st) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) da[c] = xc[xa_off + st * G::SX + c * 32], db[c] = xc[xb_off + st * G::SX + c * 32];
+    };
+    auto fetch_y = [&](const float *yc, int st) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                g0[f][c] = yc[y_off + (st * G::SY + c) * GW_CO + f * 32], g1[f][c] = yc[y_off + (YW + st * G::SY + c) * GW_CO + f * 32];
+    };
+    auto finish_x = [&]() {
+        const float t0 = da[0] + sb * db[0], t1 = da[1] + sb * db[1], t2 = da[2] + sb * db[2], t3 = da[3] + sb * db[3];
+        an[0] = t0 - t2, an[1] = t1 + t2, an[2] = t2 - t1, an[3] = t1 - t3;
+    };
+    auto finish_y = [&](int f) {
+        const float r0 = ca * g0[f][0] + cb * g1[f][0], r1 = ca * g0[f][1] + cb * g1[f][1];
+        bn[f][0] = r0, bn[f][1] = r0 + r1, bn[f][2] = r0 - r1, bn[f][3] = -r1;
+    };
+
+    const int step = gridDim.x;
+    int batch = blockIdx.x;
+    if (batch < q.nbatch) {
+        const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
+        load_raw(batch);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) store_x(i, Xp);
+#pragma unroll
+        for (int i = 0; i < NYS; ++i) store_y(i, Yp);
+        load_raw(min(batch + step, last));
+        __syncthreads();
+        int cur = 0;
+        for (; batch <= last; batch += step, cur ^= 1) {
+            count_bias = batch + step <= last;
+            const int b2 = min(batch + 2 * step, last);
+            const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
+            float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
+            fetch_x(xc, 0), fetch_y(yc, 0);
+            finish_x(), finish_y(0), finish_y(1);
+            // staging slices: raw strip of the next batch -> the other LDS buffer, then the loads of the batch after it
+            auto stage = [&](int k) {                // NXS = 3 (2 x 16 strips) or 2 (8 x 4) input slots per thread
+                if (k < 3) { if (k < NXS) store_x(k, xn); }
+                else if (k < 5) store_y(k - 3, yn);
+                else if (k == 5) load_begin(b2);
+                else if (k < 9) { if (k - 6 < NXS) load_x(k - 6); }
+                else if (k < 11) load_y(k - 9);
+            };
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                float a[4], bv[2][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = an[j], bv[0][j] = bn[0][j], bv[1][j] = bn[1][j];
+                auto gap = [&](int gidx) {          // compile-time constant after unrolling
+                    if (gidx == 0 && st < 3) fetch_x(xc, st + 1);
+                    if (gidx == 1 && st < 3) fetch_y(yc, st + 1);
+                    if (gidx == 2) stage(st * 3);
+                    if (gidx == 3) stage(st * 3 + 1);
+                    if (gidx == 4 && st < 3) finish_x();
+                    if (gidx == 5 && st < 3) finish_y(0);
+                    if (gidx == 6 && st < 3) finish_y(1);
+                    if (gidx == 7) stage(st * 3 + 2);
+                };
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[pl][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pl], bv[f][pl], acc[pl][f], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        gap(pl * 2 + f);
+                    }
+            }
+            __syncthreads();                 // raw strip of the next batch visible; this one free
+        }
+    }
+
+    // D[row = input channel][col = output channel] of position 4 * wave + pl -> ws[(pos*Cin + c)*Cout + n]
+    const int Cin = s.Cin;
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int n = n0 + f * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)(4 * wave + pl) * Cin + c) * p.Cout + n, acc[pl][f][r]);
+            }
+        }
+    if (p.dbias != nullptr && blockIdx.y == 0) {
+        __syncthreads();
+        float *red = smem;                        // [NT/16][64]
+        st4(red + (tid >> 4) * GW_CO + (tid & 15) * 4, bsum);
+        __syncthreads();
+        if (tid < GW_CO) {
+            float t = 0.f;
+            for (int g = 0; g < NT / 16; ++g) t += red[g * GW_CO + tid];
+            if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, t);
+        }
+    }
+}
+
 // ws [16][CinWs][CoutWs] (dU) -> grad OIHW [Cout][Cin][3][3] (+=): dg = G^T dU G
 __global__ void unpack_wgrad_wino_kernel(const float *__restrict__ ws, float *__restrict__ g, int Cout, int Cin, int CinWs, int CoutWs,
                                          int n_off, size_t total) {
@@ -342,6 +587,36 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
+    static const char *lt = getenv("RAMNET_WGRAD_WINO_LDS_TRANSFORM");     // 1: the LDS-transform kernels below (A/B measurements)
+    if (!(lt && lt[0] == '1')) {
+        // batches of 8 tiles: a 2 x 16 or an 8 x 4 pixel strip, whichever pads the map less
+        static const char *tall_env = getenv("RAMNET_WGRAD_WINO_TALL");
+        bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
+        if (tall_env) tall = tall_env[0] == '1';
+        if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
+        const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, GW_CO);
+        // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
+        static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
+        int splits = (se ? atoi(se) : 384) / (gy * gz);
+        if (splits > q.nbatch) splits = q.nbatch;
+        if (splits < 1) splits = 1;
+        const dim3 grid(splits, gy, gz);
+        const size_t lds = (size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + GrGeom<8>::YP) * sizeof(float);
+        const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
+        note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d>", (int)xm, (int)gm, tall ? 2 : 8);
+#define RAMNET_GO(XMv, GMv)                                                                                                  \
+    do {                                                                                                                     \
+        if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2>), grid, dim3(256), lds, st, d, q);               \
+        else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8>), grid, dim3(256), lds, st, d, q);                    \
+    } while (0)
+        if (xm && gm) RAMNET_GO(true, true);
+        else if (xm) RAMNET_GO(true, false);
+        else if (gm) RAMNET_GO(false, true);
+        else RAMNET_GO(false, false);
+#undef RAMNET_GO
+        RAMNET_LAUNCH_CHECK();
+        return 0;
+    }
     // 8-wave workgroups (64 x 64 channels) when both channel counts fill them and the concatenation boundary allows
     static const char *w8 = getenv("RAMNET_WGRAD_WINO8");
     const int w8m = w8 ? atoi(w8) : 1;   // 0: never, 1: whenever the shape allows, 2: only single-tensor inputs, 3: only concatenated

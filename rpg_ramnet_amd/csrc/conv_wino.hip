@@ -66,15 +66,16 @@ struct WinoPatch {
     int cmax[2];                          // channels c0 < cmax are valid for the slot (-1: outside the image / no slot)
     int ldst[2];                          // LDS float offset of the slot, or -1
 
-    // planar: LDS patch [channel quad 2][pixel][4] (conv_wino_r_kernel) instead of [pixel][8]
-    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid, bool planar = false) {
+    // PLANAR: LDS patch [channel quad 2][pixel][4] (conv_wino_r_kernel) instead of [pixel][8]; PH x PW = patch extent
+    template <bool PLANAR = false, int PH = WPH, int PW = WPW>
+    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int sl = tid + i * 256;
             const int pix = sl >> 1, qd = sl & 1;
-            const int py = pix / WPW, px = pix - py * WPW;
+            const int py = pix / PW, px = pix - py * PW;
             const int iy = iy0 + py, ix = ix0 + px;
-            const bool slot = sl < WPH * WPW * 2;
+            const bool slot = sl < PH * PW * 2;
             const bool in = slot && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
             // space-to-depth view: logical pixel (iy, ix) starts at full-resolution pixel (2iy, 2ix); the parity group of a
             // chunk only moves the (wave-uniform) base pointer, see load_slot
@@ -82,7 +83,7 @@ struct WinoPatch {
                                                                    : (unsigned)((b * s.Hin + iy) * s.Win + ix);
             off0[i] = gp * s.ld0 + qd * 4, off1[i] = gp * s.ld1 + qd * 4, offm[i] = gp * s.ldm + qd * 4;
             cmax[i] = in ? s.Cin - qd * 4 : -1;
-            ldst[i] = !slot ? -1 : planar ? qd * (WPH * WPW * 4) + pix * 4 : sl * 4;
+            ldst[i] = !slot ? -1 : PLANAR ? qd * (PH * PW * 4) + pix * 4 : sl * 4;
         }
     }
     // issue the global loads of slot i for the 8 channels starting at c0 (wave-uniform)
@@ -371,12 +372,21 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_des
 // barrier per chunk, double-buffered as before).  The price is paid once per workgroup: the output transform needs all four
 // rows of a tile, so the waves exchange their column-transformed partial sums (2 of 4 columns survive: A^T M A) through LDS
 // (70 KB) before the fused epilogue.  Weights: packed per (chunk, block, wave) in MFMA B-operand lane order, 16-byte loads.
-constexpr int RP_PLANE = WPH * WPW * 4;          // floats of one channel-quad plane of the patch
-constexpr int RP_FLOATS = 2 * RP_PLANE;
+// TX = Winograd tiles per workgroup row: 8 (8 x 16 output pixels) or 2 (32 x 4 pixels: the 43- and 86-pixel-wide maps of the two
+// coarse scales lose 2 % instead of 10 % of the MFMA work to the partial last tile column).
 constexpr int RO_LD = WBN + 4;                   // row of the exchange buffer [wave 4][column 2][tile 32][64 channels + pad]
 constexpr int RO_FLOATS = 4 * 2 * 32 * RO_LD;
+template <int TX> struct RGeom {
+    static constexpr int TY = 32 / TX, TH = 2 * TY, TW = 2 * TX, PH = TH + 2, PW = TW + 2;
+    static constexpr int PLANE = PH * PW * 4;    // floats of one channel-quad plane of the patch
+    static constexpr int PFLOATS = 2 * PLANE;
+    static_assert(PH * PW * 2 <= 512, "two patch slots per thread");
+};
 
+template <int TX>
 __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_desc p, const WinoParams q) {
+    using G = RGeom<TX>;
+    constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;                  // [2 buffers][2 quads][10 x 18 pixels][4]; the epilogue reuses the space
 
@@ -393,16 +403,16 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     const int ty_i = bid % q.tiles_y;
     const int b = bid / q.tiles_y;
     const int n0 = nblk_i * WBN;
-    const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
+    const int oy0 = ty_i * G::TH, ox0 = tx_i * G::TW;
     const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
 
     // row `wave` of B^T d B: rows (ra, rb) of the tile's 4 x 4 window, te = d[ra] + sb * d[rb]
-    const int tty = l31 >> 3, ttx = l31 & 7;
+    const int tty = l31 / TX, ttx = l31 % TX;
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
-    const int pra = hq * RP_PLANE + ((2 * tty + ra) * WPW + 2 * ttx) * 4;
-    const int prb = hq * RP_PLANE + ((2 * tty + rb) * WPW + 2 * ttx) * 4;
+    const int pra = hq * RP_PLANE + ((2 * tty + ra) * RPW + 2 * ttx) * 4;
+    const int prb = hq * RP_PLANE + ((2 * tty + rb) * RPW + 2 * ttx) * 4;
     // weights: [chunk][block64][wave 4][position-in-row 4][n-block 2][lane 64][channel j 4]
     const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + wave * 2048 + lane * 4;
     const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
@@ -416,7 +426,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
     WinoPatch pr;
-    pr.init(q.src, b, iy0, ix0, tid, true);
+    pr.template init<true, G::PH, G::PW>(q.src, b, iy0, ix0, tid);
     float4 breg[4][2];
     float4 tcur[4], tnext[4], ta, tb;
     auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
@@ -435,7 +445,9 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
     pr.load(q.src, min(2 * WK, clast));
     __syncthreads();
-    for (int chunk = 0; chunk < nch; ++chunk) {
+    // one chunk: MFMAs on the transformed rows in `tc`, while the rows of the next chunk are built in `tn` (the loop below
+    // alternates the two register sets instead of copying them)
+    auto body = [&](int chunk, const float4 (&tc)[4], float4 (&tn)[4]) {
         const float *pnext = patch + ((chunk + 1) & 1) * RP_FLOATS;     // patch(i+1)
         float *pfree = patch + (chunk & 1) * RP_FLOATS;                 // patch(i), consumed during chunk i-1 -> patch(i+2)
         const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
@@ -443,13 +455,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         auto side = [&](int k) {                    // compile-time constant after unrolling: one slice behind every MFMA
             if (k < 8) {
                 if (!(k & 1)) ta = ld4(pnext + pra + (k >> 1) * 4), tb = ld4(pnext + prb + (k >> 1) * 4);
-                else tnext[k >> 1] = te(ta, tb);
+                else tn[k >> 1] = te(ta, tb);
             } else if (k < 10) pr.store_slot(pfree, q.src, c2, k - 8);
             else if (k < 12) pr.load_slot(q.src, c3, k - 10);
         };
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl) {
-            const float4 v = pl == 0 ? f4sub(tcur[0], tcur[2]) : pl == 1 ? f4add(tcur[1], tcur[2]) : pl == 2 ? f4sub(tcur[2], tcur[1]) : f4sub(tcur[1], tcur[3]);
+            const float4 v = pl == 0 ? f4sub(tc[0], tc[2]) : pl == 1 ? f4add(tc[1], tc[2]) : pl == 2 ? f4sub(tc[2], tc[1]) : f4sub(tc[1], tc[3]);
             const float va[4] = {v.x, v.y, v.z, v.w};
             const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
             const float b1[4] = {breg[pl][1].x, breg[pl][1].y, breg[pl][1].z, breg[pl][1].w};
@@ -467,9 +479,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             __builtin_amdgcn_sched_barrier(0);
             breg[pl][0] = ld4(wnext + (pl * 2) * 256), breg[pl][1] = ld4(wnext + (pl * 2 + 1) * 256);
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tcur[c] = tnext[c];
         __syncthreads();                           // patch(i+2) visible; patch(i+1) free
+    };
+    for (int chunk = 0; chunk < nch; chunk += 2) {
+        body(chunk, tcur, tnext);
+        if (chunk + 1 < nch) body(chunk + 1, tnext, tcur);      // (uniform over the workgroup)
     }
 
     // ---- exchange: column transform of the wave's row (M A: 2 of 4 columns), all waves -> LDS.
@@ -485,10 +499,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             P[((wave * 2 + 1) * 32 + m) * RO_LD + f * 32 + l31] = m1 - m2 - m3;
         }
     __syncthreads();
-    // row transform A^T (.) across the waves for output pixel pxl (0..127 of the 8 x 16 tile) and channels col .. col+3
+    // row transform A^T (.) across the waves for output pixel pxl (0..127 of the TH x TW tile) and channels col .. col+3
     auto out4 = [&](int pxl, int col) {
-        const int py = pxl >> 4, px = pxl & 15;
-        const float *base = P + ((px & 1) * 32 + (py >> 1) * 8 + (px >> 1)) * RO_LD + col;
+        const int py = pxl / RTW, px = pxl % RTW;
+        const float *base = P + ((px & 1) * 32 + (py >> 1) * TX + (px >> 1)) * RO_LD + col;
         const float4 t1 = ld4(base + 1 * 64 * RO_LD), t2 = ld4(base + 2 * 64 * RO_LD);
         if (py & 1) {
             const float4 t3 = ld4(base + 3 * 64 * RO_LD);
@@ -504,7 +518,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int sl = tid + i * 256, pxl = sl >> 2, qd = sl & 3;
-            const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), chn = nblk_i * 16 + qd * 4;
+            const int oy = oy0 + pxl / RTW, ox = ox0 + pxl % RTW, chn = nblk_i * 16 + qd * 4;
             if (oy >= p.Ho || ox >= p.Wo || chn >= C) continue;
             const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
             const float4 ai = f4add(out4(pxl, qd * 4), ld4(p.bias + chn)), af = f4add(out4(pxl, 16 + qd * 4), ld4(p.bias + C + chn));
@@ -527,7 +541,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int sl = tid + i * 256, pxl = sl >> 4, qd = sl & 15;
-        const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), nq = n0 + qd * 4;
+        const int oy = oy0 + pxl / RTW, ox = ox0 + pxl % RTW, nq = n0 + qd * 4;
         if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
         const float4 y = out4(pxl, qd * 4);
         if (q.s2d_shift) {      // out_s2d: the quad's parity group picks the full-resolution pixel (LINEAR, no bias: checked on the host)
@@ -666,6 +680,11 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     if (d.in_mode == RAMNET_IN_S2D) q.src.Cin = 4 * d.C0, q.src.ld1 = log2_exact(d.C0);
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = d.epi == RAMNET_EPI_LSTM ? cdiv(d.Cout, 16) : cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
+    // register-transform kernel: 8 x 16 or 32 x 4 output pixels per workgroup, whichever pads the map less
+    static const char *tall_env = getenv("RAMNET_WINO_TALL");      // 0 / 1 forces a shape (tuning), default: by padded area
+    bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
+    if (tall_env) tall = tall_env[0] == '1';
+    if (wino_reg_transform() && tall) q.tiles_x = cdiv(d.Wo, 4), q.tiles_y = cdiv(d.Ho, 32);
     q.dy0 = dymin, q.dx0 = dxmin;
     auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
     q.vec4 = d.Cout % 4 == 0 && d.ldo % 4 == 0 && al16(d.out) && al16(d.bias) && (!d.o1 || (d.ldo1 % 4 == 0 && al16(d.o1))) &&
@@ -680,10 +699,16 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     }
     dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
     if (wino_reg_transform()) {
-        const size_t lds = (size_t)(RO_FLOATS > 2 * RP_FLOATS ? RO_FLOATS : 2 * RP_FLOATS) * sizeof(float);
-        RAMNET_FULL_LDS(conv_wino_r_kernel);
-        note_kernel("conv_wino_r_kernel");
-        hipLaunchKernelGGL(conv_wino_r_kernel, grid, dim3(256), lds, st, d, q);
+        const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
+        if (tall) {
+            RAMNET_FULL_LDS(conv_wino_r_kernel<2>);
+            note_kernel("conv_wino_r_kernel<2>");
+            hipLaunchKernelGGL(conv_wino_r_kernel<2>, grid, dim3(256), lds, st, d, q);
+        } else {
+            RAMNET_FULL_LDS(conv_wino_r_kernel<8>);
+            note_kernel("conv_wino_r_kernel<8>");
+            hipLaunchKernelGGL(conv_wino_r_kernel<8>, grid, dim3(256), lds, st, d, q);
+        }
         RAMNET_LAUNCH_CHECK();
         return 0;
     }
