@@ -121,7 +121,7 @@ HBM_CALLS = {
     "ramnet_si_loss_bwd": lambda a: 12.0 * a[2],
     "ramnet_pred_sigmoid_fwd": lambda a: (4.0 * a[2] + 4.0) * a[6],
     "ramnet_pred_sigmoid_bwd": lambda a: (8.0 * a[2] + 8.0) * a[10],
-    "ramnet_gru_bwd_a": lambda a: 28.0 * a[8] * a[7],
+    "ramnet_gru_bwd_a": lambda a: 28.0 * a[8] * a[7],      # (a[9] = leading dimension of dh')
     "ramnet_gru_bwd_b": lambda a: 24.0 * a[6] * a[5],
     "ramnet_pad2_sum": lambda a: 4.0 * a[6] * a[3] * ((2 if a[1] else 1) * a[4] * a[5] + (a[4] + 4) * (a[5] + 4)),
     "ramnet_relu_bwd": lambda a: 12.0 * a[3],

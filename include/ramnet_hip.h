@@ -132,6 +132,14 @@ int ramnet_abi_version(void);
  * recent ramnet_conv_launch / ramnet_conv_launch_multi / ramnet_wgrad_launch enqueued; "" before the first launch.  For profilers. */
 const char *ramnet_last_kernel(void);
 
+/* ---- small fp32 GEMMs (border corrections of the folded upsample-conv and their gradients; csrc/gemm_skinny.hip) ----
+ * trans_a = 0:  C[M][N] (=, or += when accumulate) A[M][K] * B[K][N]       (K % 4 == 0, rows of A 16-byte aligned)
+ * trans_a = 1:  C[M][N] (=, +=)                    A[K][M]^T * B[K][N]    (A is [K][lda >= M]: the reduction runs over its rows)
+ * All matrices row-major with leading dimensions lda / ldb / ldc (floats).  accumulate != 0 adds into C with atomics (and
+ * may split the reduction over workgroups); accumulate == 0 overwrites C.                                              */
+int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                int accumulate, void *stream);
+
 /* ---- layout plumbing -------------------------------------------------------------------------- */
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] zero-padded (model inputs: model.py:177,200 `.to(self.gpu)`). */
 int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream);
@@ -208,7 +216,8 @@ int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int 
  *  stage A: from dh' and saved u,o,h: dpo = dh'*u*(1-o^2) ; dpu = dh'*(o-h)*u*(1-u) ; dh = dh'*(1-u)
  *  stage B: from d(h*r) (dgrad of the candidate conv) : dpr = dhr*h*r*(1-r) ; dh += dhr*r            */
 int ramnet_gru_bwd_a(const float *dhn, const float *ur, const float *o, const float *h, float *dpo,
-                     float *dpur, float *dh, size_t npix, int C, void *stream);
+                     float *dpur, float *dh, size_t npix, int C, int ld_dhn /* floats per pixel of dhn (>= C: channel slices) */,
+                     void *stream);
 int ramnet_gru_bwd_b(const float *dxhr, const float *ur, const float *h, float *dpur, float *dh,
                      size_t npix, int C, void *stream);
 /* ConvLSTM backward point-wise: gates [npix,4C] (activated i,f,o,g), c_prev, c_new, dh', dc' ->

@@ -59,6 +59,7 @@ _SIGS = {
     "ramnet_abi_version": (C.c_int, []),
     "ramnet_last_error": (C.c_char_p, []),
     "ramnet_last_kernel": (C.c_char_p, []),
+    "ramnet_gemm": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 8 + [_fp]),
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -85,7 +86,7 @@ _SIGS = {
     "ramnet_pred_sigmoid_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_relu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_upsample2x_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
-    "ramnet_gru_bwd_a": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
+    "ramnet_gru_bwd_a": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, C.c_int, _fp]),
     "ramnet_gru_bwd_b": (C.c_int, [_fp] * 5 + [C.c_size_t, C.c_int, _fp]),
     "ramnet_lstm_bwd": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
     "ramnet_add": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),

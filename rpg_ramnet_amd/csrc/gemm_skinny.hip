@@ -1,0 +1,98 @@
+// Small fp32 GEMMs of the path — the border corrections of the folded upsample-conv ([border pixels x 5*Cin] x
+// [5*Cin x 2*Cout], their backward-data and backward-weights forms) — on v_mfma_f32_32x32x2_f32, without LDS and without
+// barriers: every WAVE owns one 32 x 32 block of C and reads its operands from global memory directly in MFMA lane layout
+// (the matrices are a few MB and were written by the previous kernel: L2 / Infinity-Cache hits).
+//
+//   NN:  C[M][N]  = A[M][K] * B[K][N]          lane (row m = lane & 31, half = lane >> 5) loads A[m][k0 + 16*half .. +15] as four
+//                                              16-byte loads (the MFMA's K index 0 / 1 = the two halves: a row's 128-byte line
+//                                              is consumed whole), B[k][n = lane & 31] as 128-byte-coalesced 4-byte loads
+//   TN:  C[K][N] += A[R][K]^T * B[R][N]        (weight gradient: reduction over the R pixel rows, split over gridDim.z and
+//                                              joined by atomics) — both operands coalesced along their channel index
+// Loads run one K step (32 values, 1024 MFMA cycles) ahead of the MFMAs and the reduction is split over workgroups until ~8 waves per SIMD are
+// in flight (partial sums meet by atomics): the operand loads are latency-bound, occupancy is what hides them.
+#include "common.hpp"
+
+namespace ramnet {
+
+template <bool TA>
+__global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                     int M, int N, int K, int lda, int ldb, int ldc, int ksplit, int atomic) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int nb = blockIdx.x * 4 + wave, mb = blockIdx.y;            // the 4 waves of a workgroup share the A rows (L1)
+    if (nb * 32 >= N) return;
+    const int m = mb * 32 + l31, n = nb * 32 + l31;
+    const int kper = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
+    const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool mok = m < M, nok = n < N;
+    // one K step = 32 values: half 0 of the wave takes k0 .. k0+15, half 1 k0+16 .. k0+31 (MFMA i pairs k0+i with k0+16+i), so a
+    // row of A is read as one full 128-byte line by its two lanes (4 x 16 bytes each) — no reliance on the L1 keeping it
+    auto load = [&](int k0, float (&a)[16], float (&b)[16]) {
+        const int k = k0 + 16 * kh;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            if (!TA) {
+                float4 v = f4zero();
+                if (mok && k + 4 * qd + 3 < kend) v = ld4(A + (size_t)m * lda + k + 4 * qd);    // K % 4 == 0, 16-byte aligned rows (host)
+                a[4 * qd] = v.x, a[4 * qd + 1] = v.y, a[4 * qd + 2] = v.z, a[4 * qd + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kj = k + 4 * qd + j;
+                const bool ok = kj < kend;
+                if (TA) a[4 * qd + j] = (ok && mok) ? A[(size_t)kj * lda + m] : 0.f;
+                b[4 * qd + j] = (ok && nok) ? B[(size_t)kj * ldb + n] : 0.f;
+            }
+        }
+    };
+    auto mm = [&](const float (&a)[16], const float (&b)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    };
+    float a0[16], b0[16], a1[16], b1[16];       // loads run one step (1024 MFMA cycles) ahead
+    if (kbeg < kend) load(kbeg, a0, b0);
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        if (k0 + 32 < kend) load(k0 + 32, a1, b1);
+        mm(a0, b0);
+        if (k0 + 32 >= kend) break;
+        if (k0 + 64 < kend) load(k0 + 64, a0, b0);
+        mm(a1, b1);
+    }
+    if (!nok) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row >= M) continue;
+        if (atomic) atomicAdd(C + (size_t)row * ldc + n, acc[r]);
+        else C[(size_t)row * ldc + n] = acc[r];
+    }
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                           int accumulate, void *stream) {
+    RAMNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N);
+    if (trans_a) RAMNET_CHECK_ARG(lda >= M);
+    else RAMNET_CHECK_ARG(lda >= K && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0);
+    // split the reduction until ~8 waves per SIMD are in flight (the loads are latency-bound: occupancy hides them); partial
+    // sums meet by atomics, so a plain product zero-fills C first
+    const int blocks = cdiv(M, 32) * cdiv(N, 32);
+    int ksplit = 1;
+    while (blocks * ksplit < 8192 && K / (ksplit * 2) >= 128) ksplit *= 2;
+    if (ksplit > 1 && !accumulate) {
+        RAMNET_CHECK_ARG(ldc == N);
+        RAMNET_HIP(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream));
+    }
+    const int atomic = accumulate || ksplit > 1;
+    const dim3 grid(cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit);
+    if (trans_a) hipLaunchKernelGGL(gemm32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, atomic);
+    else hipLaunchKernelGGL(gemm32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, atomic);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}

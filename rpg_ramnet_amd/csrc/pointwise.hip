@@ -417,13 +417,13 @@ __global__ void space_to_depth2_kernel(const float *__restrict__ x, float *__res
 // ur = [u | r] (2C per pixel).  dpur = [dpu | dpr].
 __global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__restrict__ ur, const float *__restrict__ o,
                                  const float *__restrict__ h, float *__restrict__ dpo, float *__restrict__ dpur,
-                                 float *__restrict__ dh, size_t npix, int C) {
+                                 float *__restrict__ dh, size_t npix, int C, int ldg) {
     const int C4 = C / 4;
     const size_t total = npix * C4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i / C4;
         const int c = (int)(i - pix * C4) * 4;
-        const float4 g = ld4(dhn + pix * C + c), u = ld4(ur + pix * 2 * C + c), oo = ld4(o + pix * C + c);
+        const float4 g = ld4(dhn + pix * ldg + c), u = ld4(ur + pix * 2 * C + c), oo = ld4(o + pix * C + c);
         const float4 hh = h ? ld4(h + pix * C + c) : f4zero();
         float4 a, bq, d;
 #define RN_ONE(f)                                   \
@@ -635,9 +635,10 @@ extern "C" int ramnet_space_to_depth2(const float *x, float *out, int B, int H, 
 }
 
 extern "C" int ramnet_gru_bwd_a(const float *dhn, const float *ur, const float *o, const float *h, float *dpo, float *dpur,
-                                float *dh, size_t npix, int C, void *stream) {
-    RAMNET_CHECK_ARG(dhn && ur && o && dpo && dpur && dh && C % 4 == 0);
-    hipLaunchKernelGGL(gru_bwd_a_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ur, o, h, dpo, dpur, dh, npix, C);
+                                float *dh, size_t npix, int C, int ld_dhn, void *stream) {
+    RAMNET_CHECK_ARG(dhn && ur && o && dpo && dpur && dh && C % 4 == 0 && ld_dhn >= C && ld_dhn % 4 == 0);
+    hipLaunchKernelGGL(gru_bwd_a_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ur, o, h, dpo, dpur, dh, npix, C,
+                       ld_dhn);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

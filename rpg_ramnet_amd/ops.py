@@ -578,6 +578,15 @@ class ConvParam:
             hit = self._packs["border"] = (v, border_matrices(self._cat_w()))
         return hit[1]
 
+    def border_weights_t(self):
+        """border_weights() transposed to [2 sides][2*Cout][5*Cin] (the backward-data operand), cached per parameter version."""
+        v = (self._versions(self.weights), "border_t")
+        hit = self._packs.get("border_t")
+        if hit is None or hit[0] != v:
+            w_rows, w_cols = self.border_weights()
+            hit = self._packs["border_t"] = (v, (w_rows.transpose(1, 2).contiguous(), w_cols.transpose(1, 2).contiguous()))
+        return hit[1]
+
     def bwd(self):
         return PackRef(self, 1)
 
@@ -741,13 +750,21 @@ def pack_input(x, device):
     return out
 
 
+def gemm(a, b, out, trans_a=False, accumulate=False):
+    """out (=, +=) a @ b  (trans_a: a^T @ b) on the library's own MFMA kernel (ramnet_gemm); 2-D row-major, last stride 1."""
+    M, N = out.shape
+    K = a.shape[0] if trans_a else a.shape[1]
+    H.check(H.lib().ramnet_gemm(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(accumulate),
+                                _st()), "ramnet_gemm")
+
+
 def _folded_upsample_conv(x, skip, cp, y, epi):
     """y = act(conv5x5_zero_padded(up2x(x + skip)) + b) without ever forming the upsampled image:
     (1) ONE multi-class launch: each output parity is a 4x4 convolution of the replicate-padded low-res sum — 16 taps instead
         of 25, plain loads — which equals the 5x5 convolution of the REPLICATE-extended upsample;
     (2) the true layer zero-pads instead, so the outermost two rows / columns lose the taps that fall outside: those taps see a
         constant line (the clamped border row / column of the upsample), i.e. four small plain GEMMs
-        [border pixels x 5*Cin] x [5*Cin x 2*Cout] (rocBLAS through torch.bmm; 1-3 % of the layer's FLOP), whose results the
+        [border pixels x 5*Cin] x [5*Cin x 2*Cout] (ramnet_gemm, csrc/gemm_skinny.hip; 1-3 % of the layer's FLOP), whose results the
         epilogue of (1) adds to the pre-activation of the frame pixels (ramnet_conv_desc.frame)."""
     L = H.lib()
     B, Hh, W, Cc = x.shape
@@ -760,8 +777,12 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
     a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
     H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
-    w_rows, w_cols = cp.border_weights()
-    g_rows, g_cols = torch.bmm(a_rows, w_rows), torch.bmm(a_cols, w_cols)         # [2][B*2W][2*Cout], [2][B*2H][2*Cout]
+    w_rows, w_cols = cp.border_weights()                                          # [2 sides][5*Cin][2*Cout]
+    g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
+    g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
+    for s_ in range(2):
+        gemm(a_rows[s_], w_rows[s_], g_rows[s_])
+        gemm(a_cols[s_], w_cols[s_], g_cols[s_])
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     if _FOLD_WINO and _fold_wino_ok(Cc, cp.Cout):   # Winograd F(2x2,4x4) over the four parities
         conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
@@ -848,8 +869,9 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
     g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
     H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
-    wr.baddbmm_(a_rows.transpose(1, 2), g_rows)
-    wc.baddbmm_(a_cols.transpose(1, 2), g_cols)
+    for s_ in range(2):                      # wr[s] += a_rows[s]^T g_rows[s]: the border GEMMs' weight gradient
+        gemm(a_rows[s_], g_rows[s_], wr[s_], trans_a=True, accumulate=True)
+        gemm(a_cols[s_], g_cols[s_], wc[s_], trans_a=True, accumulate=True)
 
 
 # Backward-data of the folded upsample-conv: the adjoint of (four parity convolutions of the replicate-padded input + border GEMMs),
@@ -884,8 +906,12 @@ def _folded_upsample_dgrad(x, dy, y, cp):
     g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
     g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
     H.check(L.ramnet_frame_gather(_p(g), None, _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
-    w_rows, w_cols = cp.border_weights()                                         # [2][5*Cin][2*Cout]
-    d_rows, d_cols = torch.bmm(g_rows, w_rows.transpose(1, 2)), torch.bmm(g_cols, w_cols.transpose(1, 2))
+    wt_rows, wt_cols = cp.border_weights_t()                                      # [2 sides][2*Cout][5*Cin]
+    d_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
+    d_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+    for s_ in range(2):
+        gemm(g_rows[s_], wt_rows[s_], d_rows[s_])
+        gemm(g_cols[s_], wt_cols[s_], d_cols[s_])
     H.check(L.ramnet_up2x_border_col2im(_p(d_rows), _p(d_cols), _p(dx), B, Hh, W, Cc, _st()), "ramnet_up2x_border_col2im")
     return dx
 
@@ -1082,12 +1108,12 @@ class GRUCell(Function):
         cp_ur, cp_o = ctx.cps
         B, Hh, W, Cc = x.shape
         npix = B * Hh * W
-        dhn = dense(dhn).contiguous()
+        dhn = dense(dhn)                  # the [.., C:] half of the next update's [dx | dh] is read in place (ld = 2C)
         L = H.lib()
         dpo = torch.empty_like(o)
         dpur = torch.empty_like(ur)
         dhd = torch.empty_like(o)
-        H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_a")
+        H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, ld(dhn), _st()), "gru_bwd_a")
         taps, tapsd = Taps.get("conv", 3, 1), Taps.get("dgrad1", 3, 1)
         ws, bws = cp_o.grad_ws(wino_ok=Cc % 32 == 0)
         wgrad_side([x, h, ur, dpo], x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)

@@ -307,3 +307,24 @@ def test_folded_upsample_conv_winograd_through_raw_descriptors(Cin, Cout):
             got4 = d4[py, px].permute(3, 2, 0, 1)                                              # [co][ci][t][s]
             assert float((got4 - w4.grad).abs().max() / w4.grad.abs().max()) < 2e-5
     assert float((dbias.cpu().double() - dyr.sum((0, 2, 3))).abs().max() / dyr.sum((0, 2, 3)).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(5504, 256, 1280), (22, 40, 100), (96, 64, 320), (33, 8, 20)])
+def test_gemm_entry_point_raw(M, N, K):
+    """ramnet_gemm (border corrections of the folded upsample-conv): C = A B, C += A^T B with ragged sizes, against float64."""
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(M + N)
+    a, b = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev)
+    c = torch.full((M, N), float("nan"), device=dev)
+    assert L.ramnet_gemm(ptr(a), ptr(b), ptr(c), M, N, K, K, N, N, 0, 0, st) == 0
+    ref = a.double().cpu() @ b.double().cpu()
+    assert float((c.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    # weight-gradient form: W[K][N] += A[R = M][K]^T G[R][N], twice (accumulation over BPTT steps); reduction split + atomics
+    g = torch.randn(M, N, device=dev)
+    w = torch.zeros(K, N, device=dev)
+    for _ in range(2):
+        assert L.ramnet_gemm(ptr(a), ptr(g), ptr(w), K, N, M, K, N, N, 1, 1, st) == 0
+    refw = 2 * (a.double().cpu().t() @ g.double().cpu())
+    assert float((w.cpu().double() - refw).abs().max() / refw.abs().max()) < 1e-5

@@ -130,10 +130,20 @@ def test_graphed_train_step_equals_eager_steps(schedule):
                 opt.step()
             losses[mode] = out
             weights[mode] = torch.cat([p.detach().flatten() for p in model.parameters()])
+        names, off = [], 0
+        for k, p in reversed(list(model.named_parameters())):          # layout of FlatGradReducer.flat
+            names.append((off, off + p.numel(), k))
+            off += p.numel()
         for i, ((le, ge), (lg, gg)) in enumerate(zip(losses["eager"], losses["graph"])):
             np.testing.assert_allclose(lg, le, rtol=1e-5, err_msg="loss of step %d" % i)
             scale = float(ge.abs().max())
-            assert float((gg - ge).abs().max()) / scale < 2e-4 * (i + 1), "gradients of step %d" % i
+            worst = sorted(((float((gg[a:b] - ge[a:b]).abs().max()), k) for a, b, k in names), reverse=True)[:3]
+            # bulk: stale weight packs in the graph would shift every gradient by ~1e-4 of the scale; isolated entries may differ
+            # by one upstream-gradient element (2e-3 of the scale here): after an update whose gradients differ in the order of
+            # their atomic sums (1e-10), a ReLU pre-activation within that distance of zero takes the other branch — two EAGER
+            # runs differ by exactly such single elements too (measured: decoders.1.conv2d.bias, 3.2e-7 of 2.0e-4)
+            assert float((gg - ge).abs().mean()) / scale < 1e-6 * (i + 1), "bulk of the gradients of step %d" % i
+            assert worst[0][0] / scale < 5e-3, "gradients of step %d: %s (scale %.2e)" % (i, worst, scale)
         assert float((weights["graph"] - weights["eager"]).abs().max()) < 2e-5
         assert losses["graph"][2][0] != losses["graph"][0][0]          # the steps really trained
     finally:
