@@ -136,9 +136,10 @@ const char *ramnet_last_kernel(void);
  * trans_a = 0:  C[M][N] (=, or += when accumulate) A[M][K] * B[K][N]       (K % 4 == 0, rows of A 16-byte aligned)
  * trans_a = 1:  C[M][N] (=, +=)                    A[K][M]^T * B[K][N]    (A is [K][lda >= M]: the reduction runs over its rows)
  * All matrices row-major with leading dimensions lda / ldb / ldc (floats).  accumulate != 0 adds into C with atomics (and
- * may split the reduction over workgroups); accumulate == 0 overwrites C.                                              */
+ * splits the reduction over workgroups: backward pass); accumulate == 0 overwrites C, bit-reproducibly (one wave per block).
+ * batch >= 1 independent products in one launch: entry i uses A + i*stride_a, B + i*stride_b, C + i*stride_c (floats).      */
 int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
-                int accumulate, void *stream);
+                int accumulate, int batch, long stride_a, long stride_b, long stride_c, void *stream);
 
 /* ---- layout plumbing -------------------------------------------------------------------------- */
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] zero-padded (model inputs: model.py:177,200 `.to(self.gpu)`). */

@@ -1,57 +1,29 @@
 // Winograd F(2x2, 3x3) backward-weights for gfx950 (MI355X): the 3x3 stride-1 layers of the RAM-Net path (ConvGRU gates /
-// candidate, residual blocks), exact-fp32 arithmetic on v_mfma_f32_32x32x2_f32.
+// candidate, residual blocks; the stride-2 5x5 encoders through their space-to-depth view), exact-fp32 arithmetic on
+// v_mfma_f32_32x32x2_f32.
 //
 //   y = A^T [ (G g G^T) .* (B^T d B) ] A   =>   dU_p[ci][co] = sum_tiles V_p[tile][ci] * Z_p[tile][co],   V = B^T d B,
 //   Z = A dy A^T (the 2x2 output-gradient tile spread to 4x4),   dg = G^T dU G  (ramnet_unpack_wgrad_wino).
 //
 // 16 independent GEMMs, M = input channel, N = output channel, K = Winograd tiles: 16 MACs per tile and channel pair
-// instead of the 36 of the direct form (2.25x fewer MFMAs).  A workgroup owns 32 input x 64 output channels and walks
-// batches of 8 tiles (one 2 x 16 pixel strip of the output).  Per batch it stages the raw 4 x 18 input patch (same fused
-// loaders as everywhere: concatenation, h*r, ReLU mask) and the 2 x 16 gradient strip, transforms both into LDS with the
-// tile index innermost — V[16][32][8], Z[16][64][8], so that one 16-byte LDS read feeds four K = 2 MFMAs — and wave
-// (position half, channel half) accumulates 8 positions x (32 x 32) in registers (128 VGPRs) over its whole tile range.
-// Partial sums of the tile splits meet in a [16][Cin][Cout] fp32 workspace through coalesced atomic adds; the bias
-// gradient (sum of dy) rides along.  Raw data of batch i+1 is written to LDS, and batch i+2 is requested from memory,
-// between the MFMAs of batch i.
+// instead of the 36 of the direct form (2.25x fewer MFMAs).  A workgroup (4 waves) owns 32 input x 64 output channels and
+// walks batches of 8 tiles (a 2 x 16 or an 8 x 4 pixel strip of the output); the four waves split the ROWS of the 4 x 4 transform
+// grid: wave w accumulates positions 4w .. 4w+3 (4 positions x 2 output-channel blocks x 32x32 = 128 accumulator VGPRs) over its
+// whole tile range.  One MFMA step reduces over two tiles: lane (channel = lane & 31, tile parity = lane >> 5) reads its tile's
+// raw input window rows / gradient pixels from LDS (lanes along channels: conflict-free 4-byte reads), forms row w of B^T d B
+// resp. A dy A^T in registers — and those ARE the A / B operands of the MFMA (K index = tile parity).  Nothing transformed goes
+// through LDS; the raw strips (same fused loaders as everywhere: concatenation, h*r, ReLU mask, space-to-depth view) are
+// double-buffered with ONE barrier per batch, and the transform of tile pair s+1 sits in the gaps between the MFMAs of tile
+// pair s.  Partial sums of the tile splits meet in a [16][Cin][Cout] fp32 workspace through coalesced atomic adds; the bias
+// gradient (sum of dy) rides along.
+// Measured against the previous formulation (V[16][ci][8] / Z[16][64][8] in LDS, a transform phase between two barriers per
+// batch; same-box A/B, round 2): the six ConvGRU backward-weights launches of a pass 1.596 -> 1.468 ms.
 #include <stdlib.h>
 #include "common.hpp"
 
 namespace ramnet {
 
 constexpr int GW_CO = 64;                      // output channels per workgroup
-constexpr int GW_T = 8;                        // tiles per batch (2 x 16 output pixels)
-constexpr int GW_LDY = 68;                     // padded raw-patch rows (floats): (2 pixels) * LD == 8 (mod 64) -> conflict-free
-constexpr int GW_XPIX = 4 * 18, GW_YPIX = 2 * 16;
-constexpr int GW_Z = 16 * GW_CO * GW_T;        // 8192 floats
-constexpr int GW_YP = GW_YPIX * GW_LDY;        // 2176
-
-// Geometry of the two workgroup shapes: CIB = 32 input channels (4 waves, two workgroups per CU) or 64 (8 waves, one per CU;
-// the transform and barrier phases are then shared by twice the MFMA work).
-template <int CIB>
-struct GwGeom {
-    static constexpr int NT = CIB * 8;             // threads: one (tile, input channel) transform item each
-    static constexpr int XQ = CIB / 4;             // channel quads per raw input pixel
-    static constexpr int LDX = CIB + 4;            // 36 / 68: (2 pixels) * LD == 8 (mod 64)
-    static constexpr int XSLOTS = GW_XPIX * XQ;
-    static constexpr int NXS = (XSLOTS + NT - 1) / NT;     // 3 for both shapes
-    static constexpr int NYS = GW_YPIX * 16 / NT;          // 2 / 1
-    static constexpr int NZ = GW_CO * GW_T / NT;           // gradient transform items per thread: 2 / 1
-    static constexpr int V = 16 * CIB * GW_T;
-    static constexpr int XP = GW_XPIX * LDX;
-    static constexpr size_t lds = (size_t)(V + GW_Z + XP + GW_YP) * sizeof(float);
-};
-
-#ifdef WW_TRACE   // tools/wgrad_wino_trace.hip: per-wave timestamps at the phase boundaries of the batch loop
-__device__ unsigned long long *g_ww_trace;
-#define WW_STAMP(slot)                                                                                                   \
-    do {                                                                                                                 \
-        if (lane == 0 && nb_done < 32)                                                                                   \
-            g_ww_trace[((((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (G::NT / 64) + wave) * 32 + nb_done) * 4 + (slot)] = \
-                __builtin_amdgcn_s_memtime();                                                                            \
-    } while (0)
-#else
-#define WW_STAMP(slot)
-#endif
 
 struct WgradWinoParams {
     InSrc src;
@@ -60,251 +32,6 @@ struct WgradWinoParams {
 };
 
 // XM: the input loader has a second operand for this workgroup's channels (h*r product / ReLU mask); GM: ReLU mask on dy.
-template <bool XM, bool GM, int CIB>
-__global__ void __launch_bounds__(CIB * 8, CIB == 32 ? 2 : 1) conv_wgrad_wino_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
-    using G = GwGeom<CIB>;
-    constexpr int NT = G::NT, XQ = G::XQ, GW_CI = CIB, GW_LDX = G::LDX, NXS = G::NXS, NYS = G::NYS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *V = smem;              // [16][CIB][8]
-    float *Z = V + G::V;          // [16][64][8]
-    float *Xp = Z + GW_Z;         // [4][18][LDX]
-    float *Yp = Xp + G::XP;       // [2][16][68]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, kk = lane >> 5;
-    const int ch = wave & 1, ph = (wave >> 1) & 1, cih = wave >> 2;   // output-channel half, position half, input-channel half (8 waves)
-    const int c0 = blockIdx.y * GW_CI, n0 = blockIdx.z * GW_CO;
-    const InSrc &s = q.src;
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    // ---- raw-data prefetch.  Slot geometry is per-thread constant; per batch only a wave-uniform base pointer moves.
-    // (The concatenated input switches tensors at C0, a multiple of 32: uniform for the workgroup's 32 channels.)
-    float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
-    unsigned xok = 0, yok = 0;
-    const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
-    const bool use_m = XM && (s.mode == RAMNET_IN_RELUMASK || second);      // wave-uniform: the h*r product only touches the h half
-    // space-to-depth view (RAMNET_IN_S2D, ld1 = log2(C0)): the workgroup's channels lie in ONE parity group (a, c); logical
-    // pixel (i, j) is full-resolution pixel (2i + a, 2j + c): pixel strides double, the group moves the base pointer
-    const bool s2d = s.mode == RAMNET_IN_S2D;
-    const int sgrp = s2d ? c0 >> s.ld1 : 0;
-    const int rowS = s2d ? 4 * s.Win : s.Win, colS = s2d ? 2 : 1;          // logical row / column step in source pixels
-    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s2d ? s.x0 + ((sgrp >> 1) * 2 * s.Win + (sgrp & 1)) * s.ld0 + (c0 - (sgrp << s.ld1)) : s.x0 + c0;
-    const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
-    const int ldS = second ? s.ld1 : s.ld0;
-    int xpy[NXS], xpx[NXS], xoff[NXS], xmoff[NXS], ypx[NYS], ypy[NYS], yoff[NYS], ymoff[NYS];
-    const int safe_x = (-q.dy0 * rowS - q.dx0 * colS) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;   // the strip's own first pixel: always readable
-    bool xslot[NXS], yslot[NYS];
-#pragma unroll
-    for (int i = 0; i < NXS; ++i) {
-        const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
-        xpy[i] = pix / 18, xpx[i] = pix - xpy[i] * 18;
-        xslot[i] = sl < G::XSLOTS && c0 + qd * 4 < s.Cin;
-        xoff[i] = (xpy[i] * rowS + xpx[i] * colS) * ldS + qd * 4;
-        xmoff[i] = (xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < NYS; ++i) {
-        const int sl = tid + i * NT, qd = sl & 15, pix = sl >> 4;
-        ypx[i] = pix & 15, ypy[i] = pix >> 4;
-        yslot[i] = n0 + qd * 4 < p.Cout;
-        yoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4;
-        ymoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4;
-    }
-    int lb_ty = 0, lb_bx = 0;                     // batch being loaded (wave-uniform)
-    const float *lb_x = nullptr, *lb_m = nullptr, *lb_g = nullptr, *lb_gm = nullptr;
-    auto load_begin = [&](int batch) {
-        int tt = batch;
-        lb_bx = tt % q.bx_n;
-        tt /= q.bx_n;
-        lb_ty = tt % q.ty_n;
-        const int b = tt / q.ty_n;
-        const long pix = ((long)b * p.Ho + 2 * lb_ty) * p.Wo + 16 * lb_bx;
-        const long corner = pix + (long)q.dy0 * s.Win + q.dx0;           // patch corner (may lie "before" the image)
-        const long corner_src = s2d ? ((long)b * p.Ho + 2 * lb_ty + q.dy0) * rowS + (16 * lb_bx + q.dx0) * colS : corner;
-        lb_x = xsrc + corner_src * ldS;
-        if (use_m) lb_m = msrc + corner * s.ldm;
-        lb_g = p.dout + pix * p.ldg;
-        if (GM) lb_gm = p.gmask + pix * p.ldgm;
-        xok = 0, yok = 0;
-    };
-    auto load_x = [&](int i) {
-        const int iy = 2 * lb_ty + q.dy0 + xpy[i], ix = 16 * lb_bx + q.dx0 + xpx[i];
-        const bool ok = xslot[i] && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
-        xr[i] = ld4(lb_x + (ok ? xoff[i] : safe_x));
-        if (use_m) xm[i] = ld4(lb_m + (ok ? xmoff[i] : safe_m));
-        xok |= (ok ? 1u : 0u) << i;
-    };
-    auto load_y = [&](int i) {
-        const bool ok = yslot[i] && 2 * lb_ty + ypy[i] < p.Ho && 16 * lb_bx + ypx[i] < p.Wo;
-        yr[i] = ld4(lb_g + (ok ? yoff[i] : 0));
-        if (GM) ym[i] = ld4(lb_gm + (ok ? ymoff[i] : 0));
-        yok |= (ok ? 1u : 0u) << i;
-    };
-    auto load_raw = [&](int batch) {
-        load_begin(batch);
-#pragma unroll
-        for (int i = 0; i < NXS; ++i) load_x(i);
-#pragma unroll
-        for (int i = 0; i < NYS; ++i) load_y(i);
-    };
-    float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
-    auto store_x = [&](int i) {
-        const int sl = tid + i * NT;
-        float4 r = xr[i];
-        if (use_m) {
-            if (s.mode == RAMNET_IN_RELUMASK)
-                r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
-            else
-                r = f4mul(r, xm[i]);
-        }
-        if (!((xok >> i) & 1u)) r = f4zero();
-        if (sl < G::XSLOTS) st4(Xp + (sl / XQ) * GW_LDX + (sl % XQ) * 4, r);
-    };
-    bool count_bias = true;                       // false for the clamped re-store of the last batch
-    auto store_y = [&](int i) {
-        const int sl = tid + i * NT;
-        float4 r = yr[i];
-        if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
-        if (!((yok >> i) & 1u)) r = f4zero();
-        st4(Yp + (sl >> 4) * GW_LDY + (sl & 15) * 4, r);
-        if (count_bias) bsum = f4add(bsum, r);
-    };
-
-    // ---- transforms: thread = (tile tid&7, channel tid>>3 [+32 for the second Z item of the 4-wave shape])
-    const int tt8 = tid & 7, tc = tid >> 3;
-    auto transform = [&]() {
-        {   // V = B^T d B of the 4x4 input window of (tile, input channel)
-            float d[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[r][c] = Xp[(r * 18 + 2 * tt8 + c) * GW_LDX + tc];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float e0 = d[0][c] - d[2][c], e1 = d[1][c] + d[2][c], e2 = d[2][c] - d[1][c], e3 = d[1][c] - d[3][c];
-                d[0][c] = e0, d[1][c] = e1, d[2][c] = e2, d[3][c] = e3;
-            }
-            float *dst = V + tc * GW_T + tt8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dst[(i * 4 + 0) * (GW_CI * GW_T)] = d[i][0] - d[i][2];
-                dst[(i * 4 + 1) * (GW_CI * GW_T)] = d[i][1] + d[i][2];
-                dst[(i * 4 + 2) * (GW_CI * GW_T)] = d[i][2] - d[i][1];
-                dst[(i * 4 + 3) * (GW_CI * GW_T)] = d[i][1] - d[i][3];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < G::NZ; ++k) {   // Z = A dy A^T of the 2x2 gradient tile of (tile, output channel)
-            const int co = tc + CIB * k;
-            const float g00 = Yp[(2 * tt8) * GW_LDY + co], g01 = Yp[(2 * tt8 + 1) * GW_LDY + co];
-            const float g10 = Yp[(16 + 2 * tt8) * GW_LDY + co], g11 = Yp[(16 + 2 * tt8 + 1) * GW_LDY + co];
-            // rows of A dy: (g0*, g0* + g1*, g0* - g1*, -g1*)
-            const float w[4][2] = {{g00, g01}, {g00 + g10, g01 + g11}, {g00 - g10, g01 - g11}, {-g10, -g11}};
-            float *dst = Z + co * GW_T + tt8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dst[(i * 4 + 0) * (GW_CO * GW_T)] = w[i][0];
-                dst[(i * 4 + 1) * (GW_CO * GW_T)] = w[i][0] + w[i][1];
-                dst[(i * 4 + 2) * (GW_CO * GW_T)] = w[i][0] - w[i][1];
-                dst[(i * 4 + 3) * (GW_CO * GW_T)] = -w[i][1];
-            }
-        }
-    };
-
-    const int aoff = (ph * 8 * GW_CI + cih * 32 + l31) * GW_T + kk * 4;
-    const int boff = (ph * 8 * GW_CO + ch * 32 + l31) * GW_T + kk * 4;
-
-    // ---- pipeline: batch list of this workgroup = blockIdx.x, +gridDim.x, ...  The loop body is branch-free: past the end the
-    // "next" batch is clamped to the last one (re-staged into buffers nobody reads; its bias contribution is not re-counted).
-    const int step = gridDim.x;
-    int batch = blockIdx.x;
-    if (batch < q.nbatch) {
-        const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
-        load_raw(batch);
-#pragma unroll
-        for (int i = 0; i < NXS; ++i) store_x(i);
-#pragma unroll
-        for (int i = 0; i < NYS; ++i) store_y(i);
-        load_raw(min(batch + step, last));
-        __syncthreads();
-        transform();
-        __syncthreads();
-        int nb_done = 0;
-        for (; batch <= last; batch += step, ++nb_done) {
-            count_bias = batch + step <= last;
-            WW_STAMP(0);
-            const int b2 = min(batch + 2 * step, last);
-            float4 a = ld4(V + aoff), bv = ld4(Z + boff);
-#pragma unroll
-            for (int pp = 0; pp < 8; ++pp) {
-                float4 an, bn;
-                if (pp + 1 < 8) an = ld4(V + aoff + (pp + 1) * (GW_CI * GW_T)), bn = ld4(Z + boff + (pp + 1) * (GW_CO * GW_T));
-                __builtin_amdgcn_sched_barrier(0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[pp], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // raw data of the next batch -> LDS (its readers, transform(i), finished before the last barrier), then the
-                // loads of the batch after it into the registers just stored
-                if (pp < 3) store_x(pp);
-                else if (pp - 3 < NYS) store_y(pp - 3);
-                if (pp == 4) load_begin(b2);
-                if (pp == 5) load_x(0), load_x(1);
-                if (pp == 6) load_x(2), load_y(0);
-                if (pp == 7 && NYS > 1) load_y(NYS - 1);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[pp], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (pp + 1 < 8) a = an, bv = bn;
-            }
-            WW_STAMP(1);
-            __syncthreads();                 // V, Z free; raw patch of the next batch visible
-            WW_STAMP(2);
-            transform();
-            WW_STAMP(3);
-            __syncthreads();                 // V, Z of the next batch visible; raw patch free
-        }
-    }
-
-    // D[row = input channel][col = output channel] of position ph*8 + pp -> ws[(pos*Cin + c)*Cout + n]
-    const int Cin = s.Cin;
-    const int n = n0 + ch * 32 + l31;
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = c0 + cih * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)(ph * 8 + pp) * Cin + c) * p.Cout + n, acc[pp][r]);
-        }
-    }
-    if (p.dbias != nullptr && blockIdx.y == 0) {
-        __syncthreads();
-        float *red = smem;                        // [NT/16][64]
-        st4(red + (tid >> 4) * GW_CO + (tid & 15) * 4, bsum);
-        __syncthreads();
-        if (tid < GW_CO) {
-            float t = 0.f;
-            for (int g = 0; g < NT / 16; ++g) t += red[g * GW_CO + tid];
-            if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, t);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// conv_wgrad_wino_r_kernel: the same sums with BOTH transforms kept in registers.  The four waves of a workgroup (32 input x 64
-// output channels) split the ROWS of the 4 x 4 transform grid: wave w accumulates positions 4w .. 4w+3 for all channels of the
-// workgroup (4 positions x 2 output-channel blocks x 32x32 = 128 accumulator VGPRs, as before).  One MFMA step reduces over two
-// tiles: lane (channel = lane & 31, tile parity = lane >> 5) reads its tile's raw input window rows / gradient pixels from LDS
-// (lanes along channels: conflict-free 4-byte reads), forms row w of B^T d B resp. A dy A^T in registers — and those ARE the A / B
-// operands of v_mfma_f32_32x32x2_f32 (K index = tile parity).  Nothing transformed ever goes through LDS: the transform phase
-// between two barriers, the V / Z buffers (49 of 67 KB) and their 32 stores + 16 operand reads per thread and batch are gone; the
-// raw strips are double-buffered, ONE barrier per batch, and the transform of tile pair s+1 sits in the gaps between the MFMAs of
-// tile pair s.
 // TXB = tiles per batch row: 8 (a 2 x 16 pixel strip) or 2 (8 x 4 pixels: the 43- / 86-pixel-wide maps of the coarse scales then
 // lose 2 % instead of 10 % of the work to the partial last strip).
 template <int TXB> struct GrGeom {
@@ -587,70 +314,31 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
-    static const char *lt = getenv("RAMNET_WGRAD_WINO_LDS_TRANSFORM");     // 1: the LDS-transform kernels below (A/B measurements)
-    if (!(lt && lt[0] == '1')) {
-        // batches of 8 tiles: a 2 x 16 or an 8 x 4 pixel strip, whichever pads the map less
-        static const char *tall_env = getenv("RAMNET_WGRAD_WINO_TALL");
-        bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
-        if (tall_env) tall = tall_env[0] == '1';
-        if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
-        const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, GW_CO);
-        // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
-        static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
-        int splits = (se ? atoi(se) : 384) / (gy * gz);
-        if (splits > q.nbatch) splits = q.nbatch;
-        if (splits < 1) splits = 1;
-        const dim3 grid(splits, gy, gz);
-        const size_t lds = (size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + GrGeom<8>::YP) * sizeof(float);
-        const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
-        note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d>", (int)xm, (int)gm, tall ? 2 : 8);
-#define RAMNET_GO(XMv, GMv)                                                                                                  \
-    do {                                                                                                                     \
-        if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2>), grid, dim3(256), lds, st, d, q);               \
-        else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8>), grid, dim3(256), lds, st, d, q);                    \
-    } while (0)
-        if (xm && gm) RAMNET_GO(true, true);
-        else if (xm) RAMNET_GO(true, false);
-        else if (gm) RAMNET_GO(false, true);
-        else RAMNET_GO(false, false);
-#undef RAMNET_GO
-        RAMNET_LAUNCH_CHECK();
-        return 0;
-    }
-    // 8-wave workgroups (64 x 64 channels) when both channel counts fill them and the concatenation boundary allows
-    static const char *w8 = getenv("RAMNET_WGRAD_WINO8");
-    const int w8m = w8 ? atoi(w8) : 1;   // 0: never, 1: whenever the shape allows, 2: only single-tensor inputs, 3: only concatenated
-    const bool wide = w8m != 0 && q.src.Cin % 64 == 0 && d.Cout >= 64 && ((!cat && d.in_mode != RAMNET_IN_S2D) || d.C0 % 64 == 0) && (w8m != 2 || !cat) && (w8m != 3 || cat);
-    const int cib = wide ? 64 : 32;
-    const size_t lds = wide ? GwGeom<64>::lds : GwGeom<32>::lds;
-    const int gy = cdiv(q.src.Cin, cib), gz = cdiv(d.Cout, GW_CO);
+    // batches of 8 tiles: a 2 x 16 or an 8 x 4 pixel strip, whichever pads the map less
+    static const char *tall_env = getenv("RAMNET_WGRAD_WINO_TALL");
+    bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
+    if (tall_env) tall = tall_env[0] == '1';
+    if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
+    const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, GW_CO);
+    // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
-    int splits = (se ? atoi(se) : (wide ? 256 : 512)) / (gy * gz);
+    int splits = (se ? atoi(se) : 384) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
     const dim3 grid(splits, gy, gz);
-    // the second loader operand exists for ALL workgroups (ReLU mask) or only for those on the h half (h*r): the kernel
-    // reads xm only when its own channels need it, so launch the XM variant whenever any workgroup might
+    const size_t lds = (size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + GrGeom<8>::YP) * sizeof(float);
     const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
-    auto go = [&](auto kern) -> int {
-        RAMNET_FULL_LDS((kern));
-        note_kernel("conv_wgrad_wino_kernel<%d,%d,%d>", (int)xm, (int)gm, cib);
-        hipLaunchKernelGGL(kern, grid, dim3(cib * 8), lds, st, d, q);
-        return 0;
-    };
-    int rc;
-    if (wide) {
-        if (xm && gm) rc = go(conv_wgrad_wino_kernel<true, true, 64>);
-        else if (xm) rc = go(conv_wgrad_wino_kernel<true, false, 64>);
-        else if (gm) rc = go(conv_wgrad_wino_kernel<false, true, 64>);
-        else rc = go(conv_wgrad_wino_kernel<false, false, 64>);
-    } else {
-        if (xm && gm) rc = go(conv_wgrad_wino_kernel<true, true, 32>);
-        else if (xm) rc = go(conv_wgrad_wino_kernel<true, false, 32>);
-        else if (gm) rc = go(conv_wgrad_wino_kernel<false, true, 32>);
-        else rc = go(conv_wgrad_wino_kernel<false, false, 32>);
-    }
-    if (rc) return rc;
+    note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d>", (int)xm, (int)gm, tall ? 2 : 8);
+#define RAMNET_GO(XMv, GMv)                                                                                                  \
+    do {                                                                                                                     \
+    if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2>), grid, dim3(256), lds, st, d, q);               \
+    else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8>), grid, dim3(256), lds, st, d, q);                    \
+    } while (0)
+    if (xm && gm) RAMNET_GO(true, true);
+    else if (xm) RAMNET_GO(true, false);
+    else if (gm) RAMNET_GO(false, true);
+    else RAMNET_GO(false, false);
+#undef RAMNET_GO
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -1,20 +1,24 @@
 // Winograd F(2x2, 3x3) convolution for gfx950 (MI355X): forward and backward-data of the 3x3 stride-1 layers of the
 // RAM-Net path — ConvGRU gates / candidate (submodules.py:447-452), ConvLSTM gates + cell (submodules.py:346-358), residual
-// blocks (submodules.py:200-215) — exact-fp32 arithmetic on v_mfma_f32_16x16x4_f32.
+// blocks (submodules.py:200-215), and the stride-2 5x5 encoders as 3x3 convolutions of the space-to-depth input — exact-fp32
+// arithmetic on v_mfma_f32_32x32x2_f32.
 //
 //   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A         (Lavin & Gray 2016; 2.25x fewer multiplies than direct)
 //
-// A workgroup (4 waves) owns 8 x 16 output pixels = 4 x 8 Winograd tiles and 64 output channels.  For every chunk of 8
-// input channels it stages the 10 x 18 input patch once (same fused loaders as the direct kernel: concatenation, the
-// GRU's h*r product, the ReLU mask of the backward pass) and transforms it to V[16 positions][32 tiles][8] in LDS — the
-// transformed INPUT is what the four waves share.  A weight tile is consumed by exactly one wave, so the waves split the
-// 64 channels (16 each) and load their B operand from global memory (L2-resident; packed so that one 16-byte lane load
-// holds two positions, 1 KB coalesced per wave-load) directly in the lane layout of the MFMA, one chunk ahead, into a
-// register ring: no weight traffic through LDS.  Each wave keeps ALL 16 positions of its 32 tiles x 16 channels in
-// registers (16 x 2 accumulators of the 16x16 MFMA = 128 VGPRs), so the output transform A^T M A is register-local; the
-// result tile is then staged through the (free) LDS so that the fused epilogues (bias / ReLU / sigmoid / residual / GRU
-// blend / ConvLSTM cell) and their operands go out as 16-byte channel quads.  One barrier per chunk (V and the patch are
-// double-buffered); XCD-aware workgroup order.  Design log: profiles/r01_g_winograd_notes.md.
+// A workgroup (4 waves) owns 32 Winograd tiles (8 x 16 or 32 x 4 output pixels) and 64 output channels.  The ROWS of the 4 x 4
+// transform grid are split over the waves: wave w owns positions 4w .. 4w+3 for all 32 tiles x 64 channels (M = 32 tiles,
+// N = 2 x 32 channels, K = 2 input channels per MFMA; 4 x 2 accumulators of 16 = 128 VGPRs).  Lane (tile = lane & 31,
+// half = lane >> 5) transforms row w of B^T d B for its tile and the channel quad `half` of the 8-channel chunk — and that IS
+// the A operand of the MFMA (lanes 0-31 supply K index 0, lanes 32-63 K index 1: channel j of quad 0 pairs with channel j of
+// quad 1), so the transformed input never goes through LDS.  Only the raw input patch is shared: staged once per chunk with the
+// fused loaders of the path (concatenation, the GRU's h*r product, the ReLU mask of the backward pass, the space-to-depth view),
+// double-buffered, ONE barrier per chunk.  Weights come from global memory (L2-resident) in MFMA B-operand lane order, 16-byte
+// loads, one chunk ahead in a register ring.  The output transform needs all four rows of a tile, so once per workgroup the
+// waves exchange their column-transformed partial sums (A^T M A keeps 2 of 4 columns) through LDS (70 KB) before the fused
+// epilogue (bias / ReLU / sigmoid / residual / GRU blend / ConvLSTM cell, 16-byte channel quads).  XCD-aware workgroup order.
+// Measured against the previous formulation (transformed input V[16][32][8] in LDS, 16x16x4 MFMAs, every wave all 16 positions;
+// same-box A/B, round 2): 7.38 -> 6.74 us per 8-channel chunk, fixed cost per launch 44 -> 38 us, training step 174 -> 186
+// samples/s; profiles/r01_g_winograd_notes.md has the design log of the LDS version.
 #include <stdlib.h>
 #include "common.hpp"
 #include "conv_epilogue.hpp"
@@ -28,8 +32,6 @@ constexpr int WBN = 64;                       // output channels per workgroup
 constexpr int WTH = 8, WTW = 16;              // output pixels per workgroup (4 x 8 tiles of 2 x 2)
 constexpr int WPH = WTH + 2, WPW = WTW + 2;   // input patch
 constexpr int WU_FLOATS = 16 * WBN * WK;      // weights of one (chunk, 64-channel block): 32 KB
-constexpr int WV_FLOATS = 16 * 32 * WK;       // 16 KB
-constexpr int WP_FLOATS = WPH * WPW * WK;     // 5.6 KB
 
 struct WinoParams {
     InSrc src;
@@ -39,22 +41,6 @@ struct WinoParams {
     int vec4;               // all epilogue operands allow 16-byte channel-quad accesses
     int s2d_shift;          // log2(out_s2d) or 0
 };
-
-__device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
-
-#ifndef WINO_ABLATE   // timing experiments only (tools/wino_trace.hip): 1 = no weight reloads, 2 = no transform / patch traffic,
-#define WINO_ABLATE 0  // 4 = no A-operand fetches, 8 = no barrier; results are then wrong by construction
-#endif
-#ifdef WINO_TRACE   // tools/wino_trace.hip: per-wave timestamps at the phase boundaries of the main loop
-__device__ unsigned long long *g_wino_trace;
-#define WINO_STAMP(slot)                                                                                     \
-    do {                                                                                                     \
-        if (lane == 0 && chunk < 32)                                                                         \
-            g_wino_trace[(((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 32 + chunk) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define WINO_STAMP(slot)
-#endif
 
 // Patch prefetcher of the Winograd kernel.  Everything that does not depend on the chunk (pixel offsets of the thread's
 // two slots in each source tensor, in-image flags) is computed once; per chunk the source selection of the concatenated
@@ -66,8 +52,8 @@ struct WinoPatch {
     int cmax[2];                          // channels c0 < cmax are valid for the slot (-1: outside the image / no slot)
     int ldst[2];                          // LDS float offset of the slot, or -1
 
-    // PLANAR: LDS patch [channel quad 2][pixel][4] (conv_wino_r_kernel) instead of [pixel][8]; PH x PW = patch extent
-    template <bool PLANAR = false, int PH = WPH, int PW = WPW>
+    // LDS patch layout: [channel quad 2][PH x PW pixels][4]
+    template <int PH, int PW>
     __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -83,7 +69,7 @@ struct WinoPatch {
                                                                    : (unsigned)((b * s.Hin + iy) * s.Win + ix);
             off0[i] = gp * s.ld0 + qd * 4, off1[i] = gp * s.ld1 + qd * 4, offm[i] = gp * s.ldm + qd * 4;
             cmax[i] = in ? s.Cin - qd * 4 : -1;
-            ldst[i] = !slot ? -1 : PLANAR ? qd * (PH * PW * 4) + pix * 4 : sl * 4;
+            ldst[i] = slot ? qd * (PH * PW * 4) + pix * 4 : -1;
         }
     }
     // issue the global loads of slot i for the 8 channels starting at c0 (wave-uniform)
@@ -120,258 +106,6 @@ struct WinoPatch {
     __device__ __forceinline__ void store(float *__restrict__ patch, const InSrc &s, int c0) const { store_slot(patch, s, c0, 0), store_slot(patch, s, c0, 1); }
 };
 
-// Pipeline, ONE barrier per chunk:
-//   during the MFMAs of chunk i:  patch(i+1) [LDS, stored during chunk i-1] -> V[(i+1)&1];  registers -> patch(i+2);
-//                                 global loads of patch(i+3) and of U(i+1).
-__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const ramnet_conv_desc p, const WinoParams q) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *V = smem;                      // [2][16][32][8]
-    float *patch = V + 2 * WV_FLOATS;     // [2][10][18][8]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, ks = lane >> 4;
-
-    // XCD-aware order (1-D grid): consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Within
-    // an XCD the 64-channel blocks of ONE spatial tile are consecutive, so that the input patch they all read is fetched
-    // from HBM / Infinity Cache once and served to the others by that XCD's L2.
-    const int xslot = blockIdx.x >> 3;
-    const int nblk_i = xslot % q.nblk;
-    int bid = (xslot / q.nblk) * 8 + (blockIdx.x & 7);
-    if (bid >= q.tiles_x * q.tiles_y * p.B) return;
-    const int tx_i = bid % q.tiles_x;
-    bid /= q.tiles_x;
-    const int ty_i = bid % q.tiles_y;
-    const int b = bid / q.tiles_y;
-    const int n0 = nblk_i * WBN;
-    const int oy0 = ty_i * WTH, ox0 = tx_i * WTW;
-    const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
-
-    const int swz = 4 * ((l15 >> 3) & 1);
-    const int aoff = l15 * WK + ((ks * 2) ^ swz);                       // A fragment 0; fragment 1 is 16 rows further
-    // weights: [chunk][block64][position pair 8][n 64][k-slot 4][2 positions][2 channels] -> one 16-byte load per pair
-    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + (wave * 16 + l15) * 16 + ks * 4;
-    const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
-
-    f32x4 acc[16][2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int f = 0; f < 2; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int ti = wave;
-    const int tq = tid & 1, tt = (tid >> 1) & 31;
-    const int tty = tt >> 3, ttx = tt & 7;
-    const int ra = ti == 0 ? 0 : (ti == 2 ? 2 : 1);
-    const int rb = ti == 0 ? 2 : (ti == 1 ? 2 : (ti == 2 ? 1 : 3));
-    const float sb = ti == 1 ? 1.f : -1.f;
-    const int pra = ((2 * tty + ra) * WPW + 2 * ttx) * WK + tq * 4;
-    const int prb = ((2 * tty + rb) * WPW + 2 * ttx) * WK + tq * 4;
-    const int vdst = (ti * 4) * (32 * WK) + tt * WK + ((tq ^ ((tt >> 3) & 1)) * 4);
-
-    WinoPatch pr;
-    pr.init(q.src, b, iy0, ix0, tid);
-    float4 breg[8];                                 // weights of the current chunk (position pairs); refilled with chunk+1 once used
-    // input transform of (tile tt, channel quad tq), row `ti` of B^T d B, in pieces small enough to be issued between
-    // two MFMAs: 8 LDS reads -> te[c] = d[ra][c] +- d[rb][c] -> 4 column combinations -> 4 LDS writes
-    float4 tx[4], ty[4], te[4];
-    auto tr_read = [&](const float *pb, int c) { tx[c] = ld4(pb + pra + c * WK), ty[c] = ld4(pb + prb + c * WK); };
-    auto tr_row = [&](int c) { te[c] = make_float4(tx[c].x + sb * ty[c].x, tx[c].y + sb * ty[c].y, tx[c].z + sb * ty[c].z, tx[c].w + sb * ty[c].w); };
-    auto tr_col = [&](float *vbuf, int j) {
-        float4 r;
-        if (j == 0) r = make_float4(te[0].x - te[2].x, te[0].y - te[2].y, te[0].z - te[2].z, te[0].w - te[2].w);
-        if (j == 1) r = f4add(te[1], te[2]);
-        if (j == 2) r = make_float4(te[2].x - te[1].x, te[2].y - te[1].y, te[2].z - te[1].z, te[2].w - te[1].w);
-        if (j == 3) r = make_float4(te[1].x - te[3].x, te[1].y - te[3].y, te[1].z - te[3].z, te[1].w - te[3].w);
-        st4(vbuf + vdst + j * (32 * WK), r);
-    };
-    auto transform = [&](const float *pb, float *vbuf) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tr_read(pb, c);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tr_row(c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tr_col(vbuf, j);
-    };
-
-    const int nch = q.nchunks;
-    // prologue: patch(0) -> V[0];  patch(1) -> LDS;  patch(2) and U(0) in registers
-    const int clast = (nch - 1) * WK;
-    { const int chunk = 0; WINO_STAMP(2); }
-    pr.load(q.src, 0);
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp) breg[pp] = ld4(wsrc + pp * 1024);
-    pr.store(patch, q.src, 0);
-    pr.load(q.src, min(WK, clast));
-    __syncthreads();
-    transform(patch, V);
-    pr.store(patch + WP_FLOATS, q.src, min(WK, clast));
-    pr.load(q.src, min(2 * WK, clast));
-    __syncthreads();
-    // The loop body is branch-free (loads past the last chunk are clamped to it; the fills they feed go to buffers nobody
-    // reads any more) and hand-interleaved: a 16x16x4 MFMA occupies the matrix pipe for 32 cycles and the wave issues in
-    // order, so work placed behind a GROUP of MFMAs only overlaps the last one.  Each MFMA is therefore followed by its
-    // own small slice of the side work: weight reload, A-operand fetch, and pieces s0/s1 of transform / patch traffic.
-    for (int chunk = 0; chunk < nch; ++chunk) {
-        const float *vcur = V + (chunk & 1) * WV_FLOATS;
-        float *vnext = V + ((chunk + 1) & 1) * WV_FLOATS;
-        const float *pnext = patch + ((chunk + 1) & 1) * WP_FLOATS;     // holds patch(i+1)
-        float *pfree = patch + (chunk & 1) * WP_FLOATS;                 // patch(i): transformed long ago -> patch(i+2)
-        const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
-        const int c2 = min((chunk + 2) * WK, clast), c3 = min((chunk + 3) * WK, clast);
-        WINO_STAMP(0);
-        float2 aq[4][2];                            // A operands, ring over positions (filled two positions ahead)
-        aq[0][0] = ld2(vcur + aoff), aq[0][1] = ld2(vcur + aoff + 16 * WK);
-        aq[1][0] = ld2(vcur + 32 * WK + aoff), aq[1][1] = ld2(vcur + 32 * WK + aoff + 16 * WK);
-        auto side = [&](int pos, int sub) {         // (pos, sub) are compile-time constants after unrolling
-            const int k = pos * 2 + sub;
-            if (k < 4) tr_read(pnext, k);
-            else if (k < 8) tr_row(k - 4);
-            else if (k < 12) tr_col(vnext, k - 8);
-            else if (k < 14) pr.store_slot(pfree, q.src, c2, k - 12);
-            else if (k < 16) pr.load_slot(q.src, c3, k - 14);
-        };
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            const float2 bb = (pos & 1) ? make_float2(breg[pos >> 1].z, breg[pos >> 1].w) : make_float2(breg[pos >> 1].x, breg[pos >> 1].y);
-            const float2 a0 = aq[pos & 3][0], a1 = aq[pos & 3][1];
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bb.x, acc[pos][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#if !(WINO_ABLATE & 1)
-            if (pos >= 2 && !(pos & 1)) breg[(pos >> 1) - 1] = ld4(wnext + ((pos >> 1) - 1) * 1024);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bb.x, acc[pos][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pos + 2 < 16 && !(WINO_ABLATE & 4)) {
-                aq[(pos + 2) & 3][0] = ld2(vcur + (pos + 2) * (32 * WK) + aoff);
-                aq[(pos + 2) & 3][1] = ld2(vcur + (pos + 2) * (32 * WK) + aoff + 16 * WK);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bb.y, acc[pos][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#if !(WINO_ABLATE & 2)
-            side(pos, 0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bb.y, acc[pos][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#if !(WINO_ABLATE & 2)
-            side(pos, 1);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#if !(WINO_ABLATE & 1)
-        breg[7] = ld4(wnext + 7 * 1024);
-#endif
-        WINO_STAMP(1);
-#if !(WINO_ABLATE & 8)
-        __syncthreads();                           // V(i+1), patch(i+2) visible; V(i), patch(i+1) free
-#endif
-    }
-
-    { const int chunk = 31; WINO_STAMP(2); }
-    // ---- output transform + epilogue.  D of the 16x16 MFMA: col = lane&15 (channel), row = 4*(lane>>4) + r (tile)
-    const int epi = p.epi;
-    const int n = n0 + wave * 16 + l15;
-    constexpr int OLD = WBN + 4;                      // row of the LDS output tile [128 pixels][64 channels + pad]
-    float *O = smem;                                  // reuses V / patch (the last barrier of the loop freed them)
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float m0 = acc[i * 4 + 0][f][r], m1 = acc[i * 4 + 1][f][r], m2 = acc[i * 4 + 2][f][r], m3 = acc[i * 4 + 3][f][r];
-                t[i][0] = m0 + m1 + m2;
-                t[i][1] = m1 - m2 - m3;
-            }
-            float y[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                y[0][c] = t[0][c] + t[1][c] + t[2][c];
-                y[1][c] = t[1][c] - t[2][c] - t[3][c];
-            }
-            const int tile = f * 16 + 4 * ks + r;
-            const int ty = tile >> 3, tx = tile & 7;
-            if (q.vec4) {        // stage the tile in LDS so that the stores (and the epilogue operands) go out as 16-byte quads
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) O[((2 * ty + a) * WTW + 2 * tx + c) * OLD + wave * 16 + l15] = y[a][c];
-                continue;
-            }
-            if (n >= p.Cout) continue;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + c;
-                    if (oy >= p.Ho || ox >= p.Wo) continue;
-                    const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
-                    epilogue_store(p, epi, pix, n, y[a][c], epilogue_addold(p, oy * p.osy + p.ooy, ox * p.osx + p.oox));
-                }
-        }
-    }
-    if (q.vec4 && epi == RAMNET_EPI_LSTM) {
-        // ConvLSTM cell (submodules.py:346-358): the block's 64 columns are 16 hidden channels x gates (i, f, o, g)
-        __syncthreads();
-        const int C = p.Cout;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int sl = tid + i * 256, pxl = sl >> 2, qd = sl & 3;
-            const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), chn = nblk_i * 16 + qd * 4;
-            if (oy >= p.Ho || ox >= p.Wo || chn >= C) continue;
-            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
-            const float *orow = O + pxl * OLD + qd * 4;
-            const float4 ai = f4add(ld4(orow), ld4(p.bias + chn)), af = f4add(ld4(orow + 16), ld4(p.bias + C + chn));
-            const float4 ao = f4add(ld4(orow + 32), ld4(p.bias + 2 * C + chn)), ag = f4add(ld4(orow + 48), ld4(p.bias + 3 * C + chn));
-            const float4 gi = make_float4(sigmoidf_(ai.x), sigmoidf_(ai.y), sigmoidf_(ai.z), sigmoidf_(ai.w));
-            const float4 gf = make_float4(sigmoidf_(af.x), sigmoidf_(af.y), sigmoidf_(af.z), sigmoidf_(af.w));
-            const float4 go = make_float4(sigmoidf_(ao.x), sigmoidf_(ao.y), sigmoidf_(ao.z), sigmoidf_(ao.w));
-            const float4 gc = make_float4(tanhf(ag.x), tanhf(ag.y), tanhf(ag.z), tanhf(ag.w));
-            const float4 cp = p.e1 ? ld4(p.e1 + pix * p.lde1 + chn) : f4zero();
-            const float4 cn = make_float4(gf.x * cp.x + gi.x * gc.x, gf.y * cp.y + gi.y * gc.y, gf.z * cp.z + gi.z * gc.z, gf.w * cp.w + gi.w * gc.w);
-            st4(p.out + pix * p.ldo + chn, make_float4(go.x * tanhf(cn.x), go.y * tanhf(cn.y), go.z * tanhf(cn.z), go.w * tanhf(cn.w)));
-            st4(p.o1 + pix * p.ldo1 + chn, cn);
-            if (p.o2) {
-                float *g = p.o2 + pix * p.ldo2 + chn;
-                st4(g, gi), st4(g + C, gf), st4(g + 2 * C, go), st4(g + 3 * C, gc);
-            }
-        }
-    } else if (q.vec4) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int sl = tid + i * 256, pxl = sl >> 4, qd = sl & 15;
-            const int oy = oy0 + (pxl >> 4), ox = ox0 + (pxl & 15), nq = n0 + qd * 4;
-            if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
-            if (q.s2d_shift) {      // out_s2d: the quad's parity group picks the full-resolution pixel (LINEAR, no bias: checked on the host)
-                const int g = nq >> q.s2d_shift;
-                const size_t pix = ((size_t)b * p.HoF + 2 * oy + (g >> 1)) * p.WoF + 2 * ox + (g & 1);
-                st4(p.out + pix * p.ldo + (nq - (g << q.s2d_shift)), ld4(O + pxl * OLD + qd * 4));
-                continue;
-            }
-            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
-            epilogue_store4(p, epi, pix, nq, ld4(O + pxl * OLD + qd * 4), epilogue_addold(p, oy * p.osy + p.ooy, ox * p.osx + p.oox));
-        }
-    }
-    { const int chunk = 31; WINO_STAMP(3); }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// conv_wino_r_kernel: the same convolution with the transform positions SPLIT OVER THE WAVES and the transformed input kept
-// in registers.  Wave w owns row w of the 4x4 transform grid (positions 4w .. 4w+3) for all 32 tiles x 64 channels of the
-// workgroup, on v_mfma_f32_32x32x2_f32: M = 32 tiles, N = 32 channels (two blocks), K = 2 input channels.  Lane (tile = lane & 31,
-// half = lane >> 5) transforms row w of B^T d B for its tile and the channel quad `half` of the 8-channel chunk — and that IS
-// the A operand of the MFMA (lanes 0-31 supply K index 0, lanes 32-63 K index 1: channel j of quad 0 pairs with channel j of
-// quad 1), so the transformed input never goes through LDS: per chunk a wave issues 8 LDS reads of the raw patch instead of
-// 8 reads + 4 writes + 32 operand fetches, and 32 MFMAs of 64 cycles instead of 64 of 32.  Only the raw patch is shared (one
-// barrier per chunk, double-buffered as before).  The price is paid once per workgroup: the output transform needs all four
-// rows of a tile, so the waves exchange their column-transformed partial sums (2 of 4 columns survive: A^T M A) through LDS
-// (70 KB) before the fused epilogue.  Weights: packed per (chunk, block, wave) in MFMA B-operand lane order, 16-byte loads.
 // TX = Winograd tiles per workgroup row: 8 (8 x 16 output pixels) or 2 (32 x 4 pixels: the 43- and 86-pixel-wide maps of the two
 // coarse scales lose 2 % instead of 10 % of the MFMA work to the partial last tile column).
 constexpr int RO_LD = WBN + 4;                   // row of the exchange buffer [wave 4][column 2][tile 32][64 channels + pad]
@@ -394,7 +128,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hq = lane >> 5;
 
-    const int xslot = blockIdx.x >> 3;    // XCD-aware order, as conv_wino_kernel
+    // XCD-aware order (1-D grid): consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Within
+    // an XCD the 64-channel blocks of ONE spatial tile are consecutive, so that the input patch they all read is fetched
+    // from HBM / Infinity Cache once and served to the others by that XCD's L2.
+    const int xslot = blockIdx.x >> 3;
     const int nblk_i = xslot % q.nblk;
     int bid = (xslot / q.nblk) * 8 + (blockIdx.x & 7);
     if (bid >= q.tiles_x * q.tiles_y * p.B) return;
@@ -426,7 +163,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
     WinoPatch pr;
-    pr.template init<true, G::PH, G::PW>(q.src, b, iy0, ix0, tid);
+    pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid);
     float4 breg[4][2];
     float4 tcur[4], tnext[4], ta, tb;
     auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
@@ -563,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     }
 }
 
-// B operand of conv_wino_r_kernel: index = (((((chunk * nblk + nb) * 4 + w) * 4 + pl) * 2 + f) * 64 + lane) * 4 + j  ->
+// OIHW 3x3 -> U = G g G^T (evaluated in double) in the lane order of the kernel's B operand: index = (((((chunk * nblk + nb) * 4 + w) * 4 + pl) * 2 + f) * 64 + lane) * 4 + j  ->
 // U[position 4w + pl][input channel chunk*8 + 4*(lane >> 5) + j][output channel nb*64 + f*32 + (lane & 31)]
 __global__ void pack_weight_wino_r_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
                                           int gates, int R, int N, int nchunks, int nblk, size_t total) {
@@ -577,53 +314,6 @@ __global__ void pack_weight_wino_r_kernel(const float *__restrict__ w, float *__
         bool ok = r < R && no < N;
         if (gates > 1) {    // ConvLSTM: a 64-column block = 16 hidden channels x (i, f, o, g)
             const int C = N / gates, chn = nb * 16 + (n & 15);
-            ok = r < R && chn < C;
-            no = (n >> 4) * C + chn;
-        }
-        float v = 0.f;
-        if (ok) {
-            double g[3][3];
-            for (int a = 0; a < 3; ++a)
-                for (int bb = 0; bb < 3; ++bb)
-                    g[a][bb] = transposed ? (double)w[((size_t)r * Cin + no) * 9 + (2 - a) * 3 + (2 - bb)]
-                                          : (double)w[((size_t)no * Cin + r) * 9 + a * 3 + bb];
-            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-            const int pi = pos >> 2, pj = pos & 3;
-            double s = 0;
-            for (int a = 0; a < 3; ++a)
-                for (int bb = 0; bb < 3; ++bb) s += G[pi][a] * g[a][bb] * G[pj][bb];
-            v = (float)s;
-        }
-        wp[i] = v;
-    }
-}
-
-// Which kernel serves RAMNET_ALGO_WINOGRAD: the register-resident transform (default) or the LDS-transform kernel
-// (RAMNET_WINO_LDS_TRANSFORM=1, kept for A/B measurements; the weight pack follows the same switch).
-static bool wino_reg_transform() {
-    static const char *e = getenv("RAMNET_WINO_LDS_TRANSFORM");
-    return !(e && e[0] == '1');
-}
-
-// OIHW 3x3 -> U = G g G^T in the lane order of the kernel's B operand (see wsrc above); evaluated in double.
-__global__ void pack_weight_wino_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
-                                        int gates, int R, int N, int nchunks, int nblk, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // i = ((((chunk * nblk + nb) * 8 + pp) * 64 + n) * 4 + ks) * 4 + (pos & 1) * 2 + (c & 1),  c = 2 * ks + (c & 1)
-        const int cl = (int)(i & 1), p1 = (int)((i >> 1) & 1), ksl = (int)((i >> 2) & 3);
-        size_t j = i >> 4;
-        const int n = (int)(j % WBN);
-        j /= WBN;
-        const int pos = (int)(j % 8) * 2 + p1;
-        j /= 8;
-        const int nb = (int)(j % nblk);
-        const int chunk = (int)(j / nblk);
-        const int c = 2 * ksl + cl;
-        const int r = chunk * WK + c;
-        int no = nb * WBN + n;
-        bool ok = r < R && no < N;
-        if (gates > 1) {    // ConvLSTM: a 64-column block = 16 hidden channels x (i, f, o, g) -> the epilogue sees the four gates
-            const int C = N / gates, chn = nb * 16 + (n & 15);      // of a channel in one LDS row; original row = gate*C + channel
             ok = r < R && chn < C;
             no = (n >> 4) * C + chn;
         }
@@ -680,11 +370,11 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     if (d.in_mode == RAMNET_IN_S2D) q.src.Cin = 4 * d.C0, q.src.ld1 = log2_exact(d.C0);
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = d.epi == RAMNET_EPI_LSTM ? cdiv(d.Cout, 16) : cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
-    // register-transform kernel: 8 x 16 or 32 x 4 output pixels per workgroup, whichever pads the map less
+    // 8 x 16 or 32 x 4 output pixels per workgroup, whichever pads the map less
     static const char *tall_env = getenv("RAMNET_WINO_TALL");      // 0 / 1 forces a shape (tuning), default: by padded area
     bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
     if (tall_env) tall = tall_env[0] == '1';
-    if (wino_reg_transform() && tall) q.tiles_x = cdiv(d.Wo, 4), q.tiles_y = cdiv(d.Ho, 32);
+    if (tall) q.tiles_x = cdiv(d.Wo, 4), q.tiles_y = cdiv(d.Ho, 32);
     q.dy0 = dymin, q.dx0 = dxmin;
     auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
     q.vec4 = d.Cout % 4 == 0 && d.ldo % 4 == 0 && al16(d.out) && al16(d.bias) && (!d.o1 || (d.ldo1 % 4 == 0 && al16(d.o1))) &&
@@ -698,23 +388,16 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
         q.s2d_shift = log2_exact(d.out_s2d);
     }
     dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
-    if (wino_reg_transform()) {
-        const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
-        if (tall) {
-            RAMNET_FULL_LDS(conv_wino_r_kernel<2>);
-            note_kernel("conv_wino_r_kernel<2>");
-            hipLaunchKernelGGL(conv_wino_r_kernel<2>, grid, dim3(256), lds, st, d, q);
-        } else {
-            RAMNET_FULL_LDS(conv_wino_r_kernel<8>);
-            note_kernel("conv_wino_r_kernel<8>");
-            hipLaunchKernelGGL(conv_wino_r_kernel<8>, grid, dim3(256), lds, st, d, q);
-        }
-        RAMNET_LAUNCH_CHECK();
-        return 0;
+    const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
+    if (tall) {
+        RAMNET_FULL_LDS(conv_wino_r_kernel<2>);
+        note_kernel("conv_wino_r_kernel<2>");
+        hipLaunchKernelGGL(conv_wino_r_kernel<2>, grid, dim3(256), lds, st, d, q);
+    } else {
+        RAMNET_FULL_LDS(conv_wino_r_kernel<8>);
+        note_kernel("conv_wino_r_kernel<8>");
+        hipLaunchKernelGGL(conv_wino_r_kernel<8>, grid, dim3(256), lds, st, d, q);
     }
-    const size_t lds = (size_t)(2 * WV_FLOATS + 2 * WP_FLOATS) * sizeof(float);
-    note_kernel("conv_wino_kernel");
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, st, d, q);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
@@ -737,12 +420,8 @@ extern "C" int ramnet_pack_weight_wino(const float *w, float *wp, int Cout, int 
     const size_t total = (size_t)nchunks * nblk * WU_FLOATS;
     size_t blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
-    if (wino_reg_transform())
-        hipLaunchKernelGGL(pack_weight_wino_r_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin,
-                           transposed, gates, R, N, nchunks, nblk, total);
-    else
-        hipLaunchKernelGGL(pack_weight_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, transposed,
-                           gates, R, N, nchunks, nblk, total);
+    hipLaunchKernelGGL(pack_weight_wino_r_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin,
+                       transposed, gates, R, N, nchunks, nblk, total);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -8,22 +8,26 @@
 //                                              is consumed whole), B[k][n = lane & 31] as 128-byte-coalesced 4-byte loads
 //   TN:  C[K][N] += A[R][K]^T * B[R][N]        (weight gradient: reduction over the R pixel rows, split over gridDim.z and
 //                                              joined by atomics) — both operands coalesced along their channel index
-// Loads run one K step (32 values, 1024 MFMA cycles) ahead of the MFMAs and the reduction is split over workgroups until ~8 waves per SIMD are
-// in flight (partial sums meet by atomics): the operand loads are latency-bound, occupancy is what hides them.
+// Loads run one K step (32 values, 1024 MFMA cycles) ahead of the MFMAs.  The accumulating forms (backward pass) split the
+// reduction over workgroups until ~8 waves per SIMD are in flight (partial sums meet by atomics): the operand loads are
+// latency-bound, occupancy is what hides them.  The plain product (forward pass) stays one wave per block: bit-reproducible.
 #include "common.hpp"
 
 namespace ramnet {
 
 template <bool TA>
 __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
-                                                     int M, int N, int K, int lda, int ldb, int ldc, int ksplit, int atomic) {
+                                                     int M, int N, int K, int lda, int ldb, int ldc, int ksplit, int atomic,
+                                                     long sa, long sb, long sc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int nb = blockIdx.x * 4 + wave, mb = blockIdx.y;            // the 4 waves of a workgroup share the A rows (L1)
     if (nb * 32 >= N) return;
+    const int bi = blockIdx.z / ksplit, ks = blockIdx.z - bi * ksplit;  // batch entry (independent products), reduction slice
+    A += bi * sa, B += bi * sb, C += bi * sc;
     const int m = mb * 32 + l31, n = nb * 32 + l31;
     const int kper = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
-    const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+    const int kbeg = ks * kper, kend = min(K, kbeg + kper);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -76,23 +80,24 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A
 using namespace ramnet;
 
 extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
-                           int accumulate, void *stream) {
-    RAMNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N);
+                           int accumulate, int batch, long stride_a, long stride_b, long stride_c, void *stream) {
+    RAMNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N && batch >= 1);
     if (trans_a) RAMNET_CHECK_ARG(lda >= M);
-    else RAMNET_CHECK_ARG(lda >= K && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0);
-    // split the reduction until ~8 waves per SIMD are in flight (the loads are latency-bound: occupancy hides them); partial
-    // sums meet by atomics, so a plain product zero-fills C first
-    const int blocks = cdiv(M, 32) * cdiv(N, 32);
+    else RAMNET_CHECK_ARG(lda >= K && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && stride_a % 4 == 0);
+    // accumulate (backward pass): the operand loads are latency-bound and occupancy is what hides them, so the reduction is split
+    // over gridDim.z until a few thousand waves are in flight; partial sums meet by atomics in C.  A plain product (forward pass)
+    // stays one wave per block: bit-reproducible, as every forward kernel of the path.
+    const int blocks = batch * cdiv(M, 32) * cdiv(N, 32);
     int ksplit = 1;
-    while (blocks * ksplit < 8192 && K / (ksplit * 2) >= 128) ksplit *= 2;
-    if (ksplit > 1 && !accumulate) {
-        RAMNET_CHECK_ARG(ldc == N);
-        RAMNET_HIP(hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), (hipStream_t)stream));
-    }
-    const int atomic = accumulate || ksplit > 1;
-    const dim3 grid(cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit);
-    if (trans_a) hipLaunchKernelGGL(gemm32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, atomic);
-    else hipLaunchKernelGGL(gemm32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, atomic);
+    if (accumulate)
+        while (blocks * ksplit < 8192 && K / (ksplit * 2) >= 128) ksplit *= 2;
+    const dim3 grid(cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit * batch);
+    if (trans_a)
+        hipLaunchKernelGGL(gemm32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,
+                           stride_a, stride_b, stride_c);
+    else
+        hipLaunchKernelGGL(gemm32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,
+                           stride_a, stride_b, stride_c);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

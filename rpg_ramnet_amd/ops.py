@@ -751,11 +751,13 @@ def pack_input(x, device):
 
 
 def gemm(a, b, out, trans_a=False, accumulate=False):
-    """out (=, +=) a @ b  (trans_a: a^T @ b) on the library's own MFMA kernel (ramnet_gemm); 2-D row-major, last stride 1."""
-    M, N = out.shape
-    K = a.shape[0] if trans_a else a.shape[1]
-    H.check(H.lib().ramnet_gemm(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), int(trans_a), int(accumulate),
-                                _st()), "ramnet_gemm")
+    """out[i] (=, +=) a[i] @ b[i]  (trans_a: a[i]^T @ b[i]) for the entries i of a batch, in ONE launch of the library's own MFMA
+    kernel (ramnet_gemm); a, b, out: [batch][rows][cols] row-major.  Plain products are bit-reproducible (one wave per 32 x 32
+    block, no atomics); accumulate=True splits the reduction and joins by atomics (backward pass)."""
+    nb, M, N = out.shape
+    K = a.shape[1] if trans_a else a.shape[2]
+    H.check(H.lib().ramnet_gemm(_p(a), _p(b), _p(out), M, N, K, a.stride(1), b.stride(1), out.stride(1), int(trans_a), int(accumulate),
+                                nb, a.stride(0), b.stride(0), out.stride(0), _st()), "ramnet_gemm")
 
 
 def _folded_upsample_conv(x, skip, cp, y, epi):
@@ -780,9 +782,8 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     w_rows, w_cols = cp.border_weights()                                          # [2 sides][5*Cin][2*Cout]
     g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
     g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
-    for s_ in range(2):
-        gemm(a_rows[s_], w_rows[s_], g_rows[s_])
-        gemm(a_cols[s_], w_cols[s_], g_cols[s_])
+    gemm(a_rows, w_rows, g_rows)               # both sides of a border in one launch
+    gemm(a_cols, w_cols, g_cols)
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     if _FOLD_WINO and _fold_wino_ok(Cc, cp.Cout):   # Winograd F(2x2,4x4) over the four parities
         conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
@@ -869,9 +870,8 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
     g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
     H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
-    for s_ in range(2):                      # wr[s] += a_rows[s]^T g_rows[s]: the border GEMMs' weight gradient
-        gemm(a_rows[s_], g_rows[s_], wr[s_], trans_a=True, accumulate=True)
-        gemm(a_cols[s_], g_cols[s_], wc[s_], trans_a=True, accumulate=True)
+    gemm(a_rows, g_rows, wr, trans_a=True, accumulate=True)      # wr[s] += a_rows[s]^T g_rows[s]: the border GEMMs' weight gradient
+    gemm(a_cols, g_cols, wc, trans_a=True, accumulate=True)
 
 
 # Backward-data of the folded upsample-conv: the adjoint of (four parity convolutions of the replicate-padded input + border GEMMs),
@@ -907,11 +907,10 @@ def _folded_upsample_dgrad(x, dy, y, cp):
     g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
     H.check(L.ramnet_frame_gather(_p(g), None, _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
     wt_rows, wt_cols = cp.border_weights_t()                                      # [2 sides][2*Cout][5*Cin]
-    d_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
-    d_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
-    for s_ in range(2):
-        gemm(g_rows[s_], wt_rows[s_], d_rows[s_])
-        gemm(g_cols[s_], wt_cols[s_], d_cols[s_])
+    d_rows = torch.zeros(2, B * W2, 5 * Cc, device=dev)       # accumulating form: the reduction may be split (backward pass)
+    d_cols = torch.zeros(2, B * H2, 5 * Cc, device=dev)
+    gemm(g_rows, wt_rows, d_rows, accumulate=True)
+    gemm(g_cols, wt_cols, d_cols, accumulate=True)
     H.check(L.ramnet_up2x_border_col2im(_p(d_rows), _p(d_cols), _p(dx), B, Hh, W, Cc, _st()), "ramnet_up2x_border_col2im")
     return dx
 

@@ -318,13 +318,22 @@ def test_gemm_entry_point_raw(M, N, K):
     torch.manual_seed(M + N)
     a, b = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev)
     c = torch.full((M, N), float("nan"), device=dev)
-    assert L.ramnet_gemm(ptr(a), ptr(b), ptr(c), M, N, K, K, N, N, 0, 0, st) == 0
+    assert L.ramnet_gemm(ptr(a), ptr(b), ptr(c), M, N, K, K, N, N, 0, 0, 1, 0, 0, 0, st) == 0          # one wave per block
     ref = a.double().cpu() @ b.double().cpu()
     assert float((c.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    c1 = torch.full((M, N), float("nan"), device=dev)
+    assert L.ramnet_gemm(ptr(a), ptr(b), ptr(c1), M, N, K, K, N, N, 0, 0, 1, 0, 0, 0, st) == 0
+    assert torch.equal(c, c1), "the plain product must be bit-reproducible"
     # weight-gradient form: W[K][N] += A[R = M][K]^T G[R][N], twice (accumulation over BPTT steps); reduction split + atomics
     g = torch.randn(M, N, device=dev)
     w = torch.zeros(K, N, device=dev)
     for _ in range(2):
-        assert L.ramnet_gemm(ptr(a), ptr(g), ptr(w), K, N, M, K, N, N, 1, 1, st) == 0
+        assert L.ramnet_gemm(ptr(a), ptr(g), ptr(w), K, N, M, K, N, N, 1, 1, 1, 0, 0, 0, st) == 0
     refw = 2 * (a.double().cpu().t() @ g.double().cpu())
     assert float((w.cpu().double() - refw).abs().max() / refw.abs().max()) < 1e-5
+    # a batch of two products in one launch (the two sides of a border)
+    a2, b2 = torch.randn(2, M, K, device=dev), torch.randn(2, K, N, device=dev)
+    c2 = torch.full((2, M, N), float("nan"), device=dev)
+    assert L.ramnet_gemm(ptr(a2), ptr(b2), ptr(c2), M, N, K, K, N, N, 0, 0, 2, M * K, K * N, M * N, st) == 0
+    ref2 = torch.bmm(a2.double().cpu(), b2.double().cpu())
+    assert float((c2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 1e-5
