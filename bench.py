@@ -475,7 +475,7 @@ def main():
 
     # ---- extras (outside the timed region that defines `value`): the same step with every launch on ONE stream — per-kernel
     # durations without co-scheduled neighbours (dominant kernel, and the ConvGRU state update per scale).  2 steps, 1 warm-up.
-    extras, gru_step = {}, None
+    extras, gru_step, iso_hbm = {}, None, None
     if not args.no_extras and args.mode == "train" and world == 1 and (args.overlap_wgrad or args.overlap_decoder):
         ops.set_wgrad_overlap(False)
         ops.set_decoder_overlap(False)
@@ -483,14 +483,16 @@ def main():
         fence()
         timer.only, only = None, timer.only
         timer.on, timer.rec = not args.no_kernel_timing, []
+        timer.hbm = timer.on
         t = time.perf_counter()
         for _ in range(2):
             lv = step()
         fence()
         e = (time.perf_counter() - t) / 2
-        timer.on = False
+        timer.on = timer.hbm = False
         extras["single_stream"] = {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach())}
         iso = timer.summary().get(only)
+        iso_hbm = {k: v for k, v in timer.summary().items() if k.startswith("ramnet_")}
         gru_step = timer.summary(by_tag=True)
         timer.rec, timer.only = [], only
         if iso:
@@ -573,16 +575,19 @@ def main():
                     k: {"launches": v[0], "ms": 1e3 * v[1], "executed_tflops": v[3] / v[1] / 1e12,
                         "mfma_frac": v[3] / v[1] / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_tflops": v[2] / v[1] / 1e12,
                         "hbm_bytes_per_launch": traffic_of(pmc, k)} for k, v in warm.items()}
+                src_hbm = iso_hbm if iso_hbm else warm_hbm       # one-stream pass when available: durations without co-scheduled kernels
                 hb = {k[len("ramnet_"):]: {"launches": v[0], "avg_us": 1e6 * v[1] / v[0], "algorithmic_mb_per_launch": v[4] / v[0] / 1e6,
                                            "achieved_tb_s": v[4] / v[1] / 1e12, "hbm_frac": v[4] / v[1] / 1e12 / HBM_PEAK_TBS}
-                      for k, v in warm_hbm.items() if v[4] > 0}
+                      for k, v in src_hbm.items() if v[4] > 0}
                 if vox:     # input side: B*K grids per launch, 48 B per event (32 B read + two fp32 atomic RMW) + the grid zero-fill
                     nb = L * (48.0 * args.events_per_grid * B * K + 4.0 * B * K * bins * H * W)
                     hb["voxelize_batch"] = {"launches": vox[0], "avg_us": 1e6 * vox[1] / vox[0], "algorithmic_mb_per_launch": nb / vox[0] / 1e6,
                                             "achieved_tb_s": nb / vox[1] / 1e12, "hbm_frac": nb / vox[1] / 1e12 / HBM_PEAK_TBS,
                                             "note": "one launch = the %d grids of a package-batch (%d events each); outside the timed step" % (B * K, args.events_per_grid)}
-                out["hbm_kernels"] = dict(hb, peak_tb_s=HBM_PEAK_TBS, note="HBM-bound kernels against the 8 TB/s HBM peak; warm-up steps, "
-                                          "three-stream schedule (durations include co-scheduled time)")
+                out["hbm_kernels"] = dict(hb, peak_tb_s=HBM_PEAK_TBS, note="HBM-bound kernels against the 8 TB/s HBM spec peak (6.3 TB/s "
+                                          "achievable, MI355X_MICROARCH.md); " + ("one-stream pass (extras.single_stream)" if iso_hbm else
+                                          "warm-up steps on the three-stream schedule: durations include co-scheduled time") +
+                                          "; si_loss_* move 5-8 MB per launch and are launch-latency bound")
             if gru_step:
                 # ConvGRU step algorithmic bytes = x read + h read + h' write (+ weights once); FLOP = 3 convs 3x3 2C->C
                 gs = {}

@@ -573,8 +573,7 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
                                        int lddx, float *dw, float *db, size_t npix, void *stream) {
     RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
     if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
-    int g = grid_for(npix * 8);
-    if (g > 512) g = 512;
+    int g = grid_for(npix * 8);      // (<= 2048 workgroups: 33 atomics each at the end)
     hipLaunchKernelGGL(pred_sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, dx, lddx, dw, db, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;
