@@ -13,8 +13,8 @@
 // raw input window rows / gradient pixels from LDS (lanes along channels: conflict-free 4-byte reads), forms row w of B^T d B
 // resp. A dy A^T in registers — and those ARE the A / B operands of the MFMA (K index = tile parity).  Nothing transformed goes
 // through LDS; the raw strips (same fused loaders as everywhere: concatenation, h*r, ReLU mask, space-to-depth view) are
-// double-buffered with ONE barrier per batch, and the transform of tile pair s+1 sits in the gaps between the MFMAs of tile
-// pair s.  Partial sums of the tile splits meet in a [16][Cin][Cout] fp32 workspace through coalesced atomic adds; the bias
+// double-buffered with ONE barrier per batch (behind tile pair 2, so that the first pair of the next batch is prepared under
+// pair 3), and the transform of tile pair s+1 sits in the gaps between the MFMAs of tile pair s.  Partial sums of the tile splits meet in a [16][Cin][Cout] fp32 workspace through coalesced atomic adds; the bias
 // gradient (sum of dy) rides along.
 // Measured against the previous formulation (V[16][ci][8] / Z[16][64][8] in LDS, a transform phase between two barriers per
 // batch; same-box A/B, round 2): the six ConvGRU backward-weights launches of a pass 1.596 -> 1.468 ms.
@@ -197,13 +197,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         load_raw(min(batch + step, last));
         __syncthreads();
         int cur = 0;
+        fetch_x(Xp, 0), fetch_y(Yp, 0);      // operands of the first tile pair (later batches: prepared under the previous one)
+        finish_x(), finish_y(0), finish_y(1);
         for (; batch <= last; batch += step, cur ^= 1) {
             count_bias = batch + step <= last;
             const int b2 = min(batch + 2 * step, last);
             const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
             float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
-            fetch_x(xc, 0), fetch_y(yc, 0);
-            finish_x(), finish_y(0), finish_y(1);
             // staging slices: raw strip of the next batch -> the other LDS buffer, then the loads of the batch after it
             auto stage = [&](int k) {                // NXS = 3 (2 x 16 strips) or 2 (8 x 4) input slots per thread
                 if (k < 3) { if (k < NXS) store_x(k, xn); }
@@ -217,14 +217,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
                 float a[4], bv[2][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a[j] = an[j], bv[0][j] = bn[0][j], bv[1][j] = bn[1][j];
+                // the operands of the next tile pair are fetched / finished in the gaps; for the last pair of a batch that is the
+                // first pair of the NEXT batch, whose raw strip is complete in the other buffer since the barrier behind pair 2
                 auto gap = [&](int gidx) {          // compile-time constant after unrolling
-                    if (gidx == 0 && st < 3) fetch_x(xc, st + 1);
-                    if (gidx == 1 && st < 3) fetch_y(yc, st + 1);
+                    if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
+                    if (gidx == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3);
                     if (gidx == 2) stage(st * 3);
                     if (gidx == 3) stage(st * 3 + 1);
-                    if (gidx == 4 && st < 3) finish_x();
-                    if (gidx == 5 && st < 3) finish_y(0);
-                    if (gidx == 6 && st < 3) finish_y(1);
+                    if (gidx == 4) finish_x();
+                    if (gidx == 5) finish_y(0);
+                    if (gidx == 6) finish_y(1);
                     if (gidx == 7) stage(st * 3 + 2);
                 };
 #pragma unroll
@@ -236,8 +238,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
                         __builtin_amdgcn_sched_barrier(0);
                         gap(pl * 2 + f);
                     }
+                // raw strip of the next batch (stored under pairs 0 and 1) visible; this batch's strip was last read by the
+                // fetches of pair 3 above (in pair 2's gaps), so its buffer is free for the stores of the next iteration
+                if (st == 2) __syncthreads();
             }
-            __syncthreads();                 // raw strip of the next batch visible; this one free
         }
     }
 
