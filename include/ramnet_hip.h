@@ -229,6 +229,10 @@ int ramnet_lstm_bwd(const float *gates, const float *cprev, const float *cnew, c
 int ramnet_bias_grad(const float *dy, const float *mask, float *db, size_t npix, int C, void *stream);
 /* y = a + b (gradient fan-in) */
 int ramnet_add(const float *a, const float *b, float *y, size_t n, void *stream);
+/* y [npix][Ca + Cb] = channel concatenation of a [npix][lda >= Ca] and b [npix][ldb >= Cb] (UNet skip_type 'concat',
+ * unet.py:11-13; channel counts multiples of 4).  ramnet_split2 is its gradient: the two channel slices of y [npix][ldy], dense. */
+int ramnet_concat2(const float *a, int lda, int Ca, const float *b, int ldb, int Cb, float *y, size_t npix, void *stream);
+int ramnet_split2(const float *y, int ldy, int Ca, int Cb, float *a, float *b, size_t npix, void *stream);
 
 /* ---- scale-invariant loss: model/loss.py:6-9 -------------------------------------------------- */
 /* stats[0..2] = (sum d, sum d^2, count) over non-NaN d = pred - target; loss = w*(S2/n - lambda*(S1/n)^2). */

@@ -90,6 +90,8 @@ _SIGS = {
     "ramnet_gru_bwd_b": (C.c_int, [_fp] * 5 + [C.c_size_t, C.c_int, _fp]),
     "ramnet_lstm_bwd": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
     "ramnet_add": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_split2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_concat2": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
     "ramnet_bias_grad": (C.c_int, [_fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
     "ramnet_si_loss_fwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp]),
     "ramnet_si_loss_bwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp, _fp]),

@@ -112,6 +112,31 @@ __global__ void add_kernel(const float *__restrict__ a, const float *__restrict_
     for (size_t i = n4 * 4 + i0; i < n; i += stride) y[i] = a[i] + b[i];
 }
 
+// y[pix][0:Ca] = a[pix], y[pix][Ca:Ca+Cb] = b[pix]: channel concatenation of two NHWC tensors (UNet skip_type 'concat', unet.py:11-13)
+__global__ void concat2_kernel(const float *__restrict__ a, int lda, int Ca, const float *__restrict__ b, int ldb, int Cb,
+                               float *__restrict__ y, size_t npix) {
+    const int q = (Ca + Cb) / 4;
+    const size_t total = npix * q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / q;
+        const int c = (int)(i - pix * q) * 4;
+        st4(y + pix * (Ca + Cb) + c, c < Ca ? ld4(a + pix * lda + c) : ld4(b + pix * ldb + (c - Ca)));
+    }
+}
+
+// inverse of concat2 (its gradient): a[pix] = y[pix][0:Ca], b[pix] = y[pix][Ca:Ca+Cb], both dense
+__global__ void split2_kernel(const float *__restrict__ y, int ldy, int Ca, int Cb, float *__restrict__ a, float *__restrict__ b, size_t npix) {
+    const int q = (Ca + Cb) / 4;
+    const size_t total = npix * q;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / q;
+        const int c = (int)(i - pix * q) * 4;
+        const float4 v = ld4(y + pix * ldy + c);
+        if (c < Ca) st4(a + pix * Ca + c, v);
+        else st4(b + pix * Cb + (c - Ca), v);
+    }
+}
+
 // db[c] += sum_pixels dy[pix][c] * (mask[pix][c] > 0)   (bias gradient of a layer whose wgrad launch cannot carry it)
 __global__ void bias_grad_kernel(const float *__restrict__ dy, const float *__restrict__ mask, float *__restrict__ db,
                                  size_t npix, int C) {
@@ -551,6 +576,20 @@ extern "C" int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_
 extern "C" int ramnet_bias_grad(const float *dy, const float *mask, float *db, size_t npix, int C, void *stream) {
     RAMNET_CHECK_ARG(dy && db && C > 0 && C % 4 == 0 && C <= 1024);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, dy, mask, db, npix, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_concat2(const float *a, int lda, int Ca, const float *b, int ldb, int Cb, float *y, size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(a && b && y && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= Ca && ldb >= Cb);
+    hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npix * ((Ca + Cb) / 4))), dim3(256), 0, (hipStream_t)stream, a, lda, Ca, b, ldb, Cb, y, npix);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_split2(const float *y, int ldy, int Ca, int Cb, float *a, float *b, size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(y && a && b && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0 && ldy % 4 == 0 && ldy >= Ca + Cb);
+    hipLaunchKernelGGL(split2_kernel, dim3(grid_for(npix * ((Ca + Cb) / 4))), dim3(256), 0, (hipStream_t)stream, y, ldy, Ca, Cb, a, b, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -12,10 +12,13 @@ class UNet(nn.Module):
         if skip_type not in ('sum', 'concat', 'no_skip', None):
             raise KeyError('Could not identify skip_type, please add "skip_type":'
                            ' "sum", "concat" or "no_skip" to config["model"]')
-        if skip_type != 'sum':
-            raise NotImplementedError("UNet on the HIP path: skip_type 'sum' only (the shipped config)")
+        if skip_type not in ('sum', 'concat'):
+            raise NotImplementedError("UNet skip_type %r does not run in the reference either: its decoders are built 2c wide "
+                                      "(unet.py:78) and fed c channels" % (skip_type,))
         assert activation == 'sigmoid' and num_output_channels == 1
         self.num_encoders = num_encoders
+        self.skip_type = skip_type
+        wide = 1 if skip_type == 'sum' else 2          # decoder / pred input width (unet.py:78, :83)
         if use_upsample_conv:
             print('Using UpsampleConvLayer (slow, but no checkerboard artefacts)')
             Up = UpsampleConvLayer
@@ -29,8 +32,8 @@ class UNet(nn.Module):
         self.encoders = nn.ModuleList([ConvLayer(i, o, kernel_size=5, stride=2, padding=2, norm=norm)
                                        for i, o in zip(enc_in, enc_out)])
         self.resblocks = nn.ModuleList([ResidualBlock(max_c, max_c, norm=norm) for _ in range(num_residual_blocks)])
-        self.decoders = nn.ModuleList([Up(c, c // 2, kernel_size=5, padding=2, norm=norm) for c in reversed(enc_out)])
-        self.pred = ConvLayer(base_num_channels, num_output_channels, 1, activation=None, norm=norm)
+        self.decoders = nn.ModuleList([Up(wide * c, c // 2, kernel_size=5, padding=2, norm=norm) for c in reversed(enc_out)])
+        self.pred = ConvLayer(wide * base_num_channels, num_output_channels, 1, activation=None, norm=norm)
 
     def forward(self, x):
         x = self.head(x)
@@ -40,7 +43,11 @@ class UNet(nn.Module):
             blocks.append(x)
         for rb in self.resblocks:
             x = rb(x)
-        for i, dec in enumerate(self.decoders):
-            x = dec(x, blocks[self.num_encoders - i - 1])           # every decoder gets its skip (unet.py:126-127)
-        x = ops.Add.apply(x, head)                                   # head skip (unet.py:129)
+        for i, dec in enumerate(self.decoders):                      # every decoder gets its skip (unet.py:126-127)
+            skip = blocks[self.num_encoders - i - 1]
+            if self.skip_type == 'sum':
+                x = dec(x, skip)                                     # the sum is fused into the layer's loader
+            else:
+                x = dec(ops.Concat.apply(x, skip))
+        x = ops.Add.apply(x, head) if self.skip_type == 'sum' else ops.Concat.apply(x, head)      # head skip (unet.py:129)
         return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

@@ -982,6 +982,7 @@ class ConvAct(Function):
         k, pad = cp.k, cp.k // 2
         Hin, Win = (2 * Hh, 2 * W) if up else (Hh, W)
         if _fold_eligible(x, cp, k, stride, up):
+            dy = dy.contiguous()        # (no-op on the path: the folded kernels' point-wise helpers index dy densely)
             _folded_upsample_wgrad(x, skip, dy, y if relu else None, cp, xpad)
         else:
             ws, bws = cp.grad_ws(wino_ok=(stride == 1 and k == 3 and pad == 1 and mode == H.IN_PLAIN))
@@ -1266,3 +1267,28 @@ class Add(Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
+
+
+class Concat(Function):
+    """Skip concatenation torch.cat([x1, x2], dim=1) (unet.py:11-13) on NHWC tensors; the gradient is the two channel slices
+    (written dense: the decoders' backward kernels take contiguous gradients)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = dense(a), dense(b)
+        assert a.shape[:3] == b.shape[:3]
+        B, Hh, W, Ca = a.shape
+        Cb = b.shape[3]
+        y = torch.empty(B, Hh, W, Ca + Cb, device=a.device)
+        H.check(H.lib().ramnet_concat2(_p(a), ld(a), Ca, _p(b), ld(b), Cb, _p(y), B * Hh * W, _st()), "ramnet_concat2")
+        ctx.c = (Ca, Cb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dense(dy)
+        B, Hh, W, _ = dy.shape
+        Ca, Cb = ctx.c
+        da, db = torch.empty(B, Hh, W, Ca, device=dy.device), torch.empty(B, Hh, W, Cb, device=dy.device)
+        H.check(H.lib().ramnet_split2(_p(dy), ld(dy), Ca, Cb, _p(da), _p(db), B * Hh * W, _st()), "ramnet_split2")
+        return da, db

@@ -65,8 +65,34 @@ def test_reference_golden_explicit_weights(tag):
     run_fixture(tag)
 
 
-def test_reference_golden_unet_explicit_weights():
-    run_fixture("small_unet", "ERGB2Depth")
+@pytest.mark.parametrize("tag", ["small_unet", "small_unet_concat"])
+def test_reference_golden_unet_explicit_weights(tag):
+    """ERGB2Depth / UNet with the reference's weights: skip_type 'sum' (shipped config) and 'concat' (unet.py:11-13)."""
+    run_fixture(tag, "ERGB2Depth")
+
+
+def test_unet_concat_gradients_vs_oracle():
+    """UNet skip_type 'concat': loss and all parameter gradients vs the float64 oracle (the concatenation's gradient is the two
+    channel slices; decoders and pred are twice as wide, unet.py:78-83)."""
+    from rpg_ramnet_amd import ops
+    cfg, z = ref_cfg("net_small_unet_concat.npz")
+    model = build_hip_model("ERGB2Depth", cfg).train()
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}, strict=True)
+    rng = np.random.default_rng(12)
+    item = make_item(rng, 2, 32, 32, 0, 1, cfg["num_bins_rgb"], True, 0.1)
+    preds, _, _ = model(item, None, None)
+    loss = ops.scale_invariant_loss(preds["image"], item["depth_image"].to(model.gpu))
+    model.zero_grad()
+    loss.backward()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    rp, _, _ = ramnet_ref.forward_unet(sd, cfg, {k: v.double() for k, v in item.items()}, None, None)
+    from oracle import loss_ref
+    ref = loss_ref.scale_invariant_loss(rp["image"], item["depth_image"].double())
+    ref.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=1e-4)
+    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+    for k, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-2 * gmax)
 
 
 def test_reference_golden_unet():
