@@ -279,6 +279,7 @@ def test_bench_two_ranks_share_one_gpu_gloo(tmp_path):
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     out = js.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["rccl_ranks_seen"] == [0, 1] and out["backend"] == "gloo"      # every rank reported in over the collective backend
     assert out["value"] > 0 and np.isfinite(out["final_loss"])
 
 
