@@ -142,7 +142,7 @@ class KernelTimer:
         self.hbm = False        # also bracket the HBM-bound calls (warm-up steps only)
         self.names = {}         # launch signature -> kernel symbol
 
-    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None):
+    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None, nbytes=0.0):
         """sig: hashable launch signature -> kernel symbol, learnt while every launch is bracketed (warm-up); with `only` set,
         launches whose signature maps to another symbol run un-bracketed.  tap_ratio = taps in the launch's list / taps of
         the layer it stands for (16/25 folded decoder, 36/25 space-to-depth encoder, else 1)."""
@@ -155,7 +155,7 @@ class KernelTimer:
         name = self.names[sig] = name_of()
         if self.only is not None and name != self.only:
             return
-        self.rec.append((name, s, e, alg, alg * tap_ratio * winograd_factor(name), 0.0, tag))
+        self.rec.append((name, s, e, alg, alg * tap_ratio * winograd_factor(name), nbytes, tag))
 
     def install(self):
         from rpg_ramnet_amd import ops, _hip as Hh
@@ -175,6 +175,22 @@ class KernelTimer:
             return (kind, tuple(x0.shape), id(taps), Cout) + tuple(kw.get(k) if not torch.is_tensor(kw.get(k)) else 1 for k in
                                                                   ("stride", "in_mode", "C0", "C1", "epi", "Ho", "Wo", "wino24", "out_s2d", "beta", "frame", "gview"))
 
+        def conv_bytes(x0, taps, Cout, kw, cin, Ho, Wo, nout, nclass):
+            """Operand bytes of one forward / backward-data launch: every input, mask and epilogue operand read once, every
+            output written once, the weights once (what the launch has to move if nothing is fetched twice)."""
+            px_in, px_out = x0.shape[0] * x0.shape[1] * x0.shape[2], x0.shape[0] * Ho * Wo * nclass
+            mode, c1 = kw.get("in_mode", 0), kw.get("C1", 0)
+            rd = px_in * ((kw.get("C0") or x0.shape[3]) + c1)
+            if mode == Hh.IN_RELUMASK:
+                rd += px_in * x0.shape[3]
+            elif mode == Hh.IN_CAT_MUL:
+                rd += px_in * c1
+            epi = kw.get("epi", Hh.EPI_LINEAR)
+            extra = {Hh.EPI_GRU_BLEND: 3, Hh.EPI_RES_RELU: 1, Hh.EPI_LSTM: 2 + (4 if kw.get("o2") is not None else 0)}.get(epi, 0)
+            extra += 1 if kw.get("beta") else 0
+            wr = px_out * Cout * (1 + extra)
+            return 4.0 * (rd + wr + nclass * taps.n * cin * nout)
+
         def conv(x0, taps, w, out, Cout, **kw):
             if not timer.on:
                 return conv0(x0, taps, w, out, Cout, **kw)
@@ -192,7 +208,7 @@ class KernelTimer:
             if kw.get("epi") in (Hh.EPI_SIGMOID, Hh.EPI_GRU_BLEND) and kw.get("in_mode", 0) in (Hh.IN_CAT, Hh.IN_CAT_MUL):
                 tag = "gru_fwd_C%d" % (kw.get("C1") or 0)
             timer._bracket(lambda: conv0(x0, taps, w, out, Cout, **kw), last, sig_of("c", x0, taps, Cout, kw) + (isinstance(w, ops.PackRef),),
-                           alg, ratio, tag)
+                           alg, ratio, tag, conv_bytes(x0, taps, Cout, kw, cin, Ho, Wo, nout, nclass))
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:
@@ -550,11 +566,13 @@ def main():
         if extras:
             out["extras"] = extras
         if agg_timed:
-            name, (n, secs, alg, ex, _) = max(agg_timed.items(), key=lambda kv: kv[1][1])
+            name, (n, secs, alg, ex, opb) = max(agg_timed.items(), key=lambda kv: kv[1][1])
             pmc_file, pmc = newest_pmc_traffic()
+            traffic = traffic_of(pmc, name)
             out["roofline"] = {
                 "bound": "mfma", "kernel": name, "achieved": ex / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic_of(pmc, name), "traffic_source": "profiles/" + pmc_file,
+                "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": "profiles/" + pmc_file,
+                "operand_bytes_per_launch": opb / n, "traffic_over_operand_bytes": (traffic / (opb / n)) if traffic and opb else None,
                 "launches": n, "avg_launch_ms": 1e3 * secs / n,
                 "executed_gflop_per_launch": ex / n / 1e9, "algorithmic_gflop_per_launch": alg / n / 1e9,
                 "algorithmic_achieved": alg / secs / 1e12,
@@ -563,7 +581,8 @@ def main():
                         "backward-weights) — wall durations include time shared with other kernels; extras.single_stream.dominant_kernel "
                         "= same launches on one stream.  algorithmic_achieved = layer-level rate (SURVEY 8d count).  traffic = HBM bytes "
                         "per launch, (2*FETCH_SIZE + WRITE_SIZE), launch-weighted over the kernel's grids (gfx950 FETCH_SIZE counts 1/2 "
-                        "of wide reads, MI355X_MICROARCH.md)"}
+                        "of wide reads, MI355X_MICROARCH.md); operand_bytes_per_launch = inputs, masks and epilogue operands read once + outputs "
+                        "written once + weights once, averaged over the same launches"}
             if warm and args.warmup > 0:      # overlap-proof view: all MFMA FLOP of a step over the step's wall time
                 step_alg = sum(v[2] for v in warm.values()) / args.warmup
                 step_ex = sum(v[3] for v in warm.values()) / args.warmup

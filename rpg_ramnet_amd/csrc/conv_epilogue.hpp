@@ -35,7 +35,7 @@ __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int ep
     } else if (epi == RAMNET_EPI_RES_RELU) {
         v = fmaxf(v + p.e0[pix * p.lde0 + n], 0.f);
     } else if (epi == RAMNET_EPI_GRU_BLEND) {
-        const float o = tanhf(v);
+        const float o = tanhf_(v);
         const float u = p.e0[pix * p.lde0 + n];
         const float h = p.e1 ? p.e1[pix * p.lde1 + n] : 0.f;
         if (p.o1) p.o1[pix * p.ldo1 + n] = o;
@@ -59,7 +59,7 @@ __device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int e
         const float4 e = ld4(p.e0 + pix * p.lde0 + n);
         v = make_float4(fmaxf(v.x + e.x, 0.f), fmaxf(v.y + e.y, 0.f), fmaxf(v.z + e.z, 0.f), fmaxf(v.w + e.w, 0.f));
     } else if (epi == RAMNET_EPI_GRU_BLEND) {
-        const float4 o = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+        const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w));
         const float4 u = ld4(p.e0 + pix * p.lde0 + n);
         const float4 h = p.e1 ? ld4(p.e1 + pix * p.lde1 + n) : f4zero();
         if (p.o1) st4(p.o1 + pix * p.ldo1 + n, o);

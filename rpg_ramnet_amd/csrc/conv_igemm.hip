@@ -166,10 +166,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ramnet_conv_desc 
                         const float gi = sigmoidf_(acc[ms][0][r] + p.bias[ch]);
                         const float gf = sigmoidf_(acc[ms][1][r] + p.bias[C + ch]);
                         const float go = sigmoidf_(acc[ms][2][r] + p.bias[2 * C + ch]);
-                        const float gc = tanhf(acc[ms][3][r] + p.bias[3 * C + ch]);
+                        const float gc = tanhf_(acc[ms][3][r] + p.bias[3 * C + ch]);
                         const float cp = p.e1 ? p.e1[pix * p.lde1 + ch] : 0.f;
                         const float cn = gf * cp + gi * gc;
-                        p.out[pix * p.ldo + ch] = go * tanhf(cn);
+                        p.out[pix * p.ldo + ch] = go * tanhf_(cn);
                         p.o1[pix * p.ldo1 + ch] = cn;
                         if (p.o2) {
                             float *g = p.o2 + pix * p.ldo2 + ch;

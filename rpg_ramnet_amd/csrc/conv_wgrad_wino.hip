@@ -96,12 +96,28 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     }
     int lb_ty = 0, lb_bx = 0;
     const float *lb_x = nullptr, *lb_m = nullptr, *lb_g = nullptr, *lb_gm = nullptr;
+    // batch -> (image, tile row, strip): divided out once; the walk then advances by the (pre-divided) grid stride with carries —
+    // a few scalar operations per batch instead of two ~40-instruction integer divisions in front of the loads
+    int lb_b = 0, lb_batch = -1;
+    const int st_bx = (int)gridDim.x % q.bx_n, st_ty = ((int)gridDim.x / q.bx_n) % q.ty_n, st_b = ((int)gridDim.x / q.bx_n) / q.ty_n;
     auto load_begin = [&](int batch) {
-        int tt = batch;
-        lb_bx = tt % q.bx_n;
-        tt /= q.bx_n;
-        lb_ty = tt % q.ty_n;
-        const int b = tt / q.ty_n;
+        if (lb_batch < 0) {
+            int tt = batch;
+            lb_bx = tt % q.bx_n;
+            tt /= q.bx_n;
+            lb_ty = tt % q.ty_n;
+            lb_b = tt / q.ty_n;
+        } else if (batch != lb_batch) {         // == lb_batch + gridDim.x (the clamped tail repeats the last batch)
+            lb_bx += st_bx;
+            const int cx = lb_bx >= q.bx_n ? 1 : 0;
+            lb_bx -= cx * q.bx_n;
+            lb_ty += st_ty + cx;
+            const int cy = lb_ty >= q.ty_n ? 1 : 0;
+            lb_ty -= cy * q.ty_n;
+            lb_b += st_b + cy;
+        }
+        lb_batch = batch;
+        const int b = lb_b;
         const long pix = ((long)b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
         const long corner = pix + (long)q.dy0 * s.Win + q.dx0;
         const long corner_src = s2d ? ((long)b * p.Ho + G::YH * lb_ty + q.dy0) * rowS + (YW * lb_bx + q.dx0) * colS : corner;

@@ -263,10 +263,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             const float4 gi = make_float4(sigmoidf_(ai.x), sigmoidf_(ai.y), sigmoidf_(ai.z), sigmoidf_(ai.w));
             const float4 gf = make_float4(sigmoidf_(af.x), sigmoidf_(af.y), sigmoidf_(af.z), sigmoidf_(af.w));
             const float4 go = make_float4(sigmoidf_(ao.x), sigmoidf_(ao.y), sigmoidf_(ao.z), sigmoidf_(ao.w));
-            const float4 gc = make_float4(tanhf(ag.x), tanhf(ag.y), tanhf(ag.z), tanhf(ag.w));
+            const float4 gc = make_float4(tanhf_(ag.x), tanhf_(ag.y), tanhf_(ag.z), tanhf_(ag.w));
             const float4 cp = p.e1 ? ld4(p.e1 + pix * p.lde1 + chn) : f4zero();
             const float4 cn = make_float4(gf.x * cp.x + gi.x * gc.x, gf.y * cp.y + gi.y * gc.y, gf.z * cp.z + gi.z * gc.z, gf.w * cp.w + gi.w * gc.w);
-            st4(p.out + pix * p.ldo + chn, make_float4(go.x * tanhf(cn.x), go.y * tanhf(cn.y), go.z * tanhf(cn.z), go.w * tanhf(cn.w)));
+            st4(p.out + pix * p.ldo + chn, make_float4(go.x * tanhf_(cn.x), go.y * tanhf_(cn.y), go.z * tanhf_(cn.z), go.w * tanhf_(cn.w)));
             st4(p.o1 + pix * p.ldo1 + chn, cn);
             if (p.o2) {
                 float *g = p.o2 + pix * p.ldo2 + chn;

@@ -500,7 +500,7 @@ __global__ void lstm_bwd_kernel(const float *__restrict__ gates, const float *__
         float4 pi, pf, po, pg, dp;
 #define RN_ONE(f)                                                   \
     {                                                               \
-        const float tc = tanhf(cn.f);                               \
+        const float tc = tanhf_(cn.f);                               \
         const float dct = dc.f + dh.f * go.f * (1.0f - tc * tc);    \
         po.f = dh.f * tc * go.f * (1.0f - go.f);                    \
         pf.f = dct * cp.f * gf.f * (1.0f - gf.f);                   \

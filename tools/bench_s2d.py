@@ -54,3 +54,10 @@ for cin, cout, Hh, W in [(32, 64, 256, 344), (64, 128, 128, 172), (128, 256, 64,
     g1 = timeit(lambda: ops.wgrad_launch(xs, taps3, dy, ws3, cout, gmask=y, dbias=bws))
     print("%3d->%3d %3dx%3d (%.1f GFLOP): fwd %.3f -> %.3f (+s2d %.3f)   dgrad %.3f -> %.3f (+d2s %.3f)   wgrad %.3f -> %.3f ms" %
           (cin, cout, Hh, W, gf, f0, f1, t_s2d, d0, d1, t_d2s, g0, g1))
+    # the kernels addressing the space-to-depth view of x in place (RAMNET_IN_S2D loader / out_s2d epilogue): what the model runs
+    tcs = ops.Taps.get("conv_s2d", 3, 1)
+    f2 = timeit(lambda: ops.conv_launch(x, tcs, sp.fwd(), y, cout, in_mode=H.IN_S2D, Hin=Hh // 2, Win=W // 2, bias=b, epi=H.EPI_RELU))
+    d2 = timeit(lambda: ops.conv_launch(dy, ops.Taps.get("dgrad1_s2d", 3, 1), sp.bwd(), dx, sp.Cin, xm=y, in_mode=H.IN_RELUMASK,
+                                        Ho=Hh // 2, Wo=W // 2, out_s2d=cin))
+    g2 = timeit(lambda: ops.wgrad_launch(x, tcs, dy, ws3, cout, in_mode=H.IN_S2D, Hin=Hh // 2, Win=W // 2, gmask=y, dbias=bws))
+    print("        in place: fwd %.3f   dgrad %.3f   wgrad %.3f ms" % (f2, d2, g2))
