@@ -290,6 +290,46 @@ def test_conv_lstm(B, H, W, C):
              [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W)), torch.randn(B, C, H, W)])
 
 
+@pytest.mark.parametrize("scale", [30.0, 300.0])
+def test_gate_nonlinearities_saturate_cleanly(scale):
+    """The epilogues evaluate sigmoid / tanh on v_exp_f32 + v_rcp_f32 (common.hpp).  Pre-activations far outside the usual range
+    (|z| up to several hundred: exp overflows to inf on one side, underflows to 0 on the other) must give exactly the saturated
+    values the reference's torch.sigmoid / torch.tanh give, never NaN, and stay within 1e-6 absolute everywhere else."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvGRU, ConvLSTM
+    torch.manual_seed(17)
+    B, C, H, W = 1, 32, 8, 12
+    x, h, c = torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W)), torch.randn(B, C, H, W)
+    gru, lstm = ConvGRU(C, C, 3), ConvLSTM(C, C, 3)
+    with torch.no_grad():
+        for m in (gru, lstm):
+            for p in m.parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.linspace(-scale, scale, p.numel())[torch.randperm(p.numel())])      # biases spanning +-scale
+    with torch.no_grad():
+        got = gru.to(dev())(nhwc(x).to(dev()), nhwc(h).to(dev()))
+        ref = ramnet_ref.conv_gru({"L." + k: v.cpu().double() for k, v in gru.state_dict().items()}, "L", x.double(), h.double())
+        got = got[0] if isinstance(got, tuple) else got
+        ref = ref[0] if isinstance(ref, tuple) else ref
+        g = nchw(got).cpu().double()
+        assert torch.isfinite(g).all()
+        assert float((g - ref).abs().max()) < 5e-6
+        hl, cl = lstm.to(dev())(nhwc(x).to(dev()), (nhwc(h).to(dev()), nhwc(c).to(dev())))
+        rh, rc = ramnet_ref.conv_lstm({"L." + k: v.cpu().double() for k, v in lstm.state_dict().items()}, "L", x.double(), (h.double(), c.double()))
+        for a, r in ((hl, rh), (cl, rc)):
+            a = nchw(a).cpu().double()
+            assert torch.isfinite(a).all()
+            assert float((a - r).abs().max()) < 5e-6 * max(1.0, float(r.abs().max()))
+        # 1x1 prediction head + sigmoid: exact 0 / 1 where torch saturates
+        xp = nhwc(torch.randn(1, 32, 6, 8) * scale).to(dev())
+        w, b = torch.randn(1, 32, 1, 1), torch.zeros(1)
+        y = ops.PredSigmoid.apply(xp, w.to(dev()), b.to(dev()))
+        r = torch.sigmoid(torch.nn.functional.conv2d(nchw(xp).cpu().double(), w.double(), b.double()))
+        assert torch.isfinite(y).all()
+        assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+        assert float((y.cpu().double() - r).abs().max()) < 1e-4       # (the fp32 pre-activation of magnitude ~scale * 6 rounds at 1e-5 * scale)
+
+
 def test_pred_sigmoid():
     from rpg_ramnet_amd import ops
     torch.manual_seed(7)
