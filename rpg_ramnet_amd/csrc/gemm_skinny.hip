@@ -10,7 +10,9 @@
 //                                              joined by atomics) — both operands coalesced along their channel index
 // Loads run one K step (32 values, 1024 MFMA cycles) ahead of the MFMAs.  The accumulating forms (backward pass) split the
 // reduction over workgroups until ~8 waves per SIMD are in flight (partial sums meet by atomics): the operand loads are
-// latency-bound, occupancy is what hides them.  The plain product (forward pass) stays one wave per block: bit-reproducible.
+// latency-bound, occupancy is what hides them.  The plain product (forward pass) splits the reduction over the four waves of the
+// block's workgroup, which join through LDS in a fixed order: bit-reproducible.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace ramnet {
@@ -18,15 +20,19 @@ namespace ramnet {
 template <bool TA>
 __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int ksplit, int atomic,
-                                                     long sa, long sb, long sc) {
+                                                     int intra, long sa, long sb, long sc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int nb = blockIdx.x * 4 + wave, mb = blockIdx.y;            // the 4 waves of a workgroup share the A rows (L1)
-    if (nb * 32 >= N) return;
-    const int bi = blockIdx.z / ksplit, ks = blockIdx.z - bi * ksplit;  // batch entry (independent products), reduction slice
+    // accumulating forms: the 4 waves of a workgroup own 4 neighbouring blocks (they share the A rows through the L1) and the
+    // reduction is split over gridDim.z; plain product (intra): the 4 waves split the reduction of ONE block and join through LDS
+    // in a fixed order — four times the waves in flight, still bit-reproducible
+    const int nb = intra ? blockIdx.x : blockIdx.x * 4 + wave, mb = blockIdx.y;
+    if (nb * 32 >= N) return;                                           // (uniform over the workgroup when intra)
+    const int bi = blockIdx.z / ksplit, ks = intra ? wave : blockIdx.z - bi * ksplit;  // batch entry (independent products), reduction slice
     A += bi * sa, B += bi * sb, C += bi * sc;
     const int m = mb * 32 + l31, n = nb * 32 + l31;
-    const int kper = ((K + ksplit - 1) / ksplit + 31) / 32 * 32;
+    const int nsl = intra ? 4 : ksplit;
+    const int kper = ((K + nsl - 1) / nsl + 31) / 32 * 32;
     const int kbeg = ks * kper, kend = min(K, kbeg + kper);
     f32x16 acc;
 #pragma unroll
@@ -65,6 +71,17 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A
         if (k0 + 64 < kend) load(k0 + 64, a0, b0);
         mm(a1, b1);
     }
+    if (intra) {
+        __shared__ float red[3][16][64];
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+    }
     if (!nok) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -86,18 +103,20 @@ extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int 
     else RAMNET_CHECK_ARG(lda >= K && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && stride_a % 4 == 0);
     // accumulate (backward pass): the operand loads are latency-bound and occupancy is what hides them, so the reduction is split
     // over gridDim.z until a few thousand waves are in flight; partial sums meet by atomics in C.  A plain product (forward pass)
-    // stays one wave per block: bit-reproducible, as every forward kernel of the path.
+    // splits it over the waves of one workgroup per block instead (fixed-order LDS join): bit-reproducible, as every forward kernel.
     const int blocks = batch * cdiv(M, 32) * cdiv(N, 32);
     int ksplit = 1;
     if (accumulate)
         while (blocks * ksplit < 8192 && K / (ksplit * 2) >= 128) ksplit *= 2;
-    const dim3 grid(cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit * batch);
+    static const char *ie = getenv("RAMNET_GEMM_INTRA");              // tuning knob: 0 = one wave per block for the plain product
+    const int intra = !accumulate && K >= 128 && !(ie && ie[0] == '0');
+    const dim3 grid(intra ? cdiv(N, 32) : cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit * batch);
     if (trans_a)
         hipLaunchKernelGGL(gemm32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,
-                           stride_a, stride_b, stride_c);
+                           intra, stride_a, stride_b, stride_c);
     else
         hipLaunchKernelGGL(gemm32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,
-                           stride_a, stride_b, stride_c);
+                           intra, stride_a, stride_b, stride_c);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
