@@ -374,7 +374,9 @@ def main():
     if args.mode == "train":
         model.train()
         reducer = FlatGradReducer(model)
-        opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=0)
+        # the reference's optimizer (configs/*.json: Adam, lr 3e-4, weight_decay 0) as ONE fused multi-tensor kernel per step: the
+        # foreach form's ~11 launches with their host work sit exposed at the step boundary (GPU idle ~3 ms per step, +0.8 %)
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=0, fused=True)
 
         def step():
             reducer.zero()
