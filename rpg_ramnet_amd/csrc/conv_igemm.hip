@@ -223,6 +223,14 @@ static int check_desc(const ramnet_conv_desc &d) {
     if (d.epi == RAMNET_EPI_RES_RELU) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_GRU_BLEND) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
+    // the patch loaders address their source tensors with 32-bit element offsets (16 GB per tensor: batch ~45 at 256x344x32)
+    {
+        unsigned long long ld = (unsigned long long)d.ld0;
+        if (cat || d.in_mode == RAMNET_IN_UP2X_SKIP) ld = ld > (unsigned long long)d.ld1 ? ld : (unsigned long long)d.ld1;
+        if (d.xm) ld = ld > (unsigned long long)d.ldm ? ld : (unsigned long long)d.ldm;
+        const unsigned long long px = (unsigned long long)d.B * d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1);
+        RAMNET_CHECK_ARG(px * ld < (1ull << 32));
+    }
     RAMNET_CHECK_ARG(d.frame >= 0);
     if (d.frame > 0) RAMNET_CHECK_ARG(d.e0 && d.e1 && (d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR));
     return 0;

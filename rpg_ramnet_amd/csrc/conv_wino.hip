@@ -40,6 +40,7 @@ struct WinoParams {
     int dy0, dx0;           // offset of the first filter tap (-1 for the padded 3x3)
     int vec4;               // all epilogue operands allow 16-byte channel-quad accesses
     int s2d_shift;          // log2(out_s2d) or 0
+    int xg;                 // log2 of the number of XCD-pinned channel-block groups
 };
 
 // Patch prefetcher of the Winograd kernel.  Everything that does not depend on the chunk (pixel offsets of the thread's
@@ -131,9 +132,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     // XCD-aware order (1-D grid): consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a private L2.  Within
     // an XCD the 64-channel blocks of ONE spatial tile are consecutive, so that the input patch they all read is fetched
     // from HBM / Infinity Cache once and served to the others by that XCD's L2.
-    const int xslot = blockIdx.x >> 3;
-    const int nblk_i = xslot % q.nblk;
-    int bid = (xslot / q.nblk) * 8 + (blockIdx.x & 7);
+    // Layers whose packed weights exceed an L2 (4 MB) additionally split the channel blocks into 2^xg groups, each pinned to a set
+    // of XCDs: an XCD then streams only its group's slice of the weights (which stays resident) at the price of the patch being
+    // fetched once per group.  xg = 0: every XCD runs all channel blocks of its tiles.
+    const int xslot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int nbl = q.nblk >> q.xg;                                  // channel blocks per group
+    const int nblk_i = ((xslot % nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
+    int bid = (xslot / nbl) * (8 >> q.xg) + (xcd >> q.xg);
     if (bid >= q.tiles_x * q.tiles_y * p.B) return;
     const int tx_i = bid % q.tiles_x;
     bid /= q.tiles_x;
@@ -387,7 +392,13 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
                          !d.bias && d.beta == 0.f && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
         q.s2d_shift = log2_exact(d.out_s2d);
     }
-    dim3 grid(roundup(q.tiles_x * q.tiles_y * d.B, 8) * q.nblk);
+    // XCD-pinned channel groups for weights that do not fit an L2: 2 groups above 3 MB, 4 above 12 MB (when nblk divides)
+    static const char *xge = getenv("RAMNET_WINO_XCD_GROUPS");      // tuning knob: log2 of the group count
+    const size_t wbytes = (size_t)q.nchunks * q.nblk * WU_FLOATS * sizeof(float);
+    q.xg = xge ? atoi(xge) : (wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0);
+    while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
+    const int lanes = 8 >> q.xg;
+    dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));
     const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
     if (tall) {
         RAMNET_FULL_LDS(conv_wino_r_kernel<2>);
