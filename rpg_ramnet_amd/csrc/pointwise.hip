@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <mutex>
 #include <unordered_set>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace ramnet {
@@ -187,18 +188,35 @@ __global__ void pred_sigmoid_bwd_kernel(const float *__restrict__ x, int ldx, in
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3;
     const size_t stride = (size_t)gridDim.x * (blockDim.x / 8);
     float4 dwp[4] = {f4zero(), f4zero(), f4zero(), f4zero()};   // C <= 128
-    float dbp = 0.f;
-    for (size_t pix = blockIdx.x * (size_t)(blockDim.x / 8) + slot; pix < npix; pix += stride) {
-        const float yy = y[pix];
-        const float dz = dy[pix] * yy * (1.0f - yy);
-        if (sub == 0) dbp += dz;
+    float4 ww[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {            // static register indices (C <= 128)
-            const int c = sub * 4 + 32 * k;
-            if (c < C) {
-                const float4 v = ld4(x + pix * ldx + c), ww = ld4(w + c);
-                if (dx) st4(dx + pix * lddx + c, f4scale(ww, dz));
-                dwp[k] = f4add(dwp[k], f4scale(v, dz));
+    for (int k = 0; k < 4; ++k) ww[k] = sub * 4 + 32 * k < C ? ld4(w + sub * 4 + 32 * k) : f4zero();
+    float dbp = 0.f;
+    // four pixels per trip: their loads are issued back to back (the kernel is a pure stream: what limits it is bytes in flight)
+    for (size_t pix0 = blockIdx.x * (size_t)(blockDim.x / 8) + slot; pix0 < npix; pix0 += 4 * stride) {
+        float dz[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t pix = pix0 + u * stride;
+            const bool ok = pix < npix;
+            const float yy = ok ? y[pix] : 0.f;
+            dz[u] = ok ? dy[pix] * yy * (1.0f - yy) : 0.f;
+            v[u] = ok && sub * 4 < C ? ld4(x + pix * ldx + sub * 4) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t pix = pix0 + u * stride;
+            if (pix >= npix) break;
+            if (sub == 0) dbp += dz[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {            // static register indices (C <= 128)
+                const int c = sub * 4 + 32 * k;
+                if (c < C) {
+                    const float4 xv = k == 0 ? v[u] : ld4(x + pix * ldx + c);
+                    if (dx) st4(dx + pix * lddx + c, f4scale(ww[k], dz[u]));
+                    dwp[k] = f4add(dwp[k], f4scale(xv, dz[u]));
+                }
             }
         }
     }
@@ -612,7 +630,10 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
                                        int lddx, float *dw, float *db, size_t npix, void *stream) {
     RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
     if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
-    int g = grid_for(npix * 8);      // (<= 2048 workgroups: 33 atomics each at the end)
+    int g = grid_for(npix * 8);      // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups
+    static const char *ge = getenv("RAMNET_PRED_BWD_BLOCKS");
+    const int cap = ge ? atoi(ge) : 512;
+    if (g > cap) g = cap;
     hipLaunchKernelGGL(pred_sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, dx, lddx, dw, db, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;
