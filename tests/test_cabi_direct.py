@@ -318,7 +318,7 @@ def test_gemm_entry_point_raw(M, N, K):
     torch.manual_seed(M + N)
     a, b = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev)
     c = torch.full((M, N), float("nan"), device=dev)
-    assert L.ramnet_gemm(ptr(a), ptr(b), ptr(c), M, N, K, K, N, N, 0, 0, 1, 0, 0, 0, st) == 0          # one wave per block
+    assert L.ramnet_gemm(ptr(a), ptr(b), ptr(c), M, N, K, K, N, N, 0, 0, 1, 0, 0, 0, st) == 0          # K >= 128: four waves per block, fixed-order join; below: one wave
     ref = a.double().cpu() @ b.double().cpu()
     assert float((c.cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-5
     c1 = torch.full((M, N), float("nan"), device=dev)
