@@ -15,7 +15,8 @@ log-depth targets) and resident in HBM before the timed region.  Weights: seeded
 Roofline accounting.  The convolutions are MFMA-bound.  Every MFMA launch is classified by the kernel the
 library reports (ramnet_last_kernel) and carries two FLOP counts: ALGORITHMIC (2*B*Ho*Wo*taps*Cin*Cout of the layer it
 stands for) and EXECUTED (what the MFMA pipe really multiplies: Winograd F(2x2,3x3) 16/36 of the 3x3 taps —
-16/25 for the stride-2 5x5 encoders run as 3x3 over the space-to-depth view —, F(2x2,4x4) 25/100 of a folded decoder).
+12.25/25 for the stride-2 5x5 encoders run as 3x3 over the space-to-depth view with the positions of its zero slices skipped —,
+F(2x2,4x4) 25/100 of a folded decoder).
 `roofline.achieved/frac` use the EXECUTED count (a fraction of the fp32 MFMA peak that cannot exceed 1);
 `roofline.algorithmic_achieved` is the layer-level rate.  `traffic` comes from the newest tracked
 profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes of this command, tools/pmc_traffic.py).
@@ -102,6 +103,10 @@ def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
 
 
 # ---------------------------------------------------------------------------------------------------------------- timing
+# 3x3 view of a 5x5 stride-2 layer: the parity group (a, b) of a channel keeps (4 - a) x (4 - b) of the 16 Winograd positions
+S2D_SPARSE_FACTOR = (16 + 12 + 12 + 9) / 64.0
+
+
 def winograd_factor(kernel):
     """Multiplies the MFMA pipe executes per multiply of the tap list the launch was given: F(2x2,3x3) 16 per 36,
     F(2x2,4x4) 25 per 64; direct kernels 1."""
@@ -199,6 +204,8 @@ class KernelTimer:
             nclass = 4 if (kw.get("wino24") and not parity4) else 1
             cin, nout = cin_of(x0, kw, w), Cout * (4 if kw.get("epi") == Hh.EPI_LSTM else 1)
             ratio = taps.n / float(taps.flop_taps)
+            if ops._S2D_SPARSE and (kw.get("in_mode", 0) == Hh.IN_S2D or kw.get("out_s2d")):
+                ratio *= S2D_SPARSE_FACTOR      # positions of the zero slices are not issued (ramnet_conv_desc.s2d_5x5)
             if parity4:     # decoder backward-data: stands for a 5x5 convolution over the full-resolution gradient; runs 16 taps
                 alg = 2.0 * x0.shape[0] * x0.shape[1] * x0.shape[2] * 25 * x0.shape[3] * Cout      # over 4*C0 channels on the
                 ratio = 16.0 * 4 * Ho * Wo / (25.0 * x0.shape[1] * x0.shape[2])                    # padded low-resolution grid
@@ -217,9 +224,12 @@ class KernelTimer:
             nclass = 4 if kw.get("wino24") else 1
             cin = getattr(dw, "head_cin", 0) or cin_of(x0, kw)
             alg = 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout
+            ratio = taps.n / float(taps.flop_taps)
+            if ops._S2D_SPARSE and kw.get("in_mode", 0) == Hh.IN_S2D and getattr(dw, "s2d_5x5", False):
+                ratio *= S2D_SPARSE_FACTOR
             timer._bracket(lambda: wgrad0(x0, taps, dout, dw, Cout, **kw), last,
                            sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "head_cin", 0)),
-                           alg, taps.n / float(taps.flop_taps))
+                           alg, ratio)
 
         def multi(x0, w, out, Cout, classes, **kw):
             if not timer.on:
@@ -578,7 +588,7 @@ def main():
                 "launches": n, "avg_launch_ms": 1e3 * secs / n,
                 "executed_gflop_per_launch": ex / n / 1e9, "algorithmic_gflop_per_launch": alg / n / 1e9,
                 "algorithmic_achieved": alg / secs / 1e12,
-                "note": "achieved/frac = EXECUTED MFMA FLOP (Winograd: 16/36 of the 3x3 layer's, 16/25 for space-to-depth encoders) over "
+                "note": "achieved/frac = EXECUTED MFMA FLOP (Winograd: 16/36 of the 3x3 layer's, 12.25/25 for space-to-depth encoders) over "
                         "HIP-event durations of this kernel in the timed region, which co-schedules three streams (main, decoders, "
                         "backward-weights) — wall durations include time shared with other kernels; extras.single_stream.dominant_kernel "
                         "= same launches on one stream.  algorithmic_achieved = layer-level rate (SURVEY 8d count).  traffic = HBM bytes "

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 11
+#define RAMNET_ABI_VERSION 12
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -99,6 +99,10 @@ typedef struct ramnet_conv_desc {
                                      * space-to-depth view of out [B][HoF = 2*Ho][WoF = 2*Wo][C]: channel (a*2+c)*C + ch of pixel (i, j)
                                      * is stored at out(2i+a, 2j+c, ch) — backward-data of the encoders.  C a power of two >= 8  */
     int head_cin;                   /* RAMNET_ALGO_HEAD: real input channels (1, 3 or 5) among the C0 padded ones of x0       */
+    int s2d_5x5;                    /* 1 (WINOGRAD with in_mode RAMNET_IN_S2D, or with out_s2d): the 3x3 filter over the space-to-depth
+                                     * view is that of a 5x5 stride-2 layer — its slices (dy = +1, row parity 1) and (dx = +1, column
+                                     * parity 1) are zero (11 of 36) — and the kernel skips the Winograd positions those zeros annihilate
+                                     * (12.25 instead of 16 multiplies per tile and channel on average).  0: dense filter.              */
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
@@ -124,6 +128,8 @@ typedef struct ramnet_wgrad_desc {
     int HoG, WoG;                   /* (all 0 = dense [B, Ho, Wo]; DIRECT only): one output parity of the folded upsample-conv  */
     int head_cin;                   /* RAMNET_ALGO_HEAD (dense 5x5 stride-1 taps, Cout <= 32): real input channels (1, 3 or 5); dw keeps
                                      * the DIRECT layout [25][C0][Cout]                                                          */
+    int s2d_5x5;                    /* 1 (WINOGRAD, in_mode RAMNET_IN_S2D): as in ramnet_conv_desc — the positions that only feed the zero
+                                     * slices are not accumulated (their rows of dU stay as they are)                                  */
 } ramnet_wgrad_desc;
 
 const char *ramnet_last_error(void);

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("frame", C.c_int),
         ("out_s2d", C.c_int),
         ("head_cin", C.c_int),
+        ("s2d_5x5", C.c_int),
     ]
 
 
@@ -52,6 +53,7 @@ class WgradDesc(C.Structure):
         ("algo", C.c_int),
         ("gsy", C.c_int), ("gsx", C.c_int), ("goy", C.c_int), ("gox", C.c_int), ("HoG", C.c_int), ("WoG", C.c_int),
         ("head_cin", C.c_int),
+        ("s2d_5x5", C.c_int),
     ]
 
 
@@ -151,7 +153,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 11:
+        if l.ramnet_abi_version() != 12:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

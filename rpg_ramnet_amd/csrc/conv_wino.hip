@@ -41,6 +41,7 @@ struct WinoParams {
     int vec4;               // all epilogue operands allow 16-byte channel-quad accesses
     int s2d_shift;          // log2(out_s2d) or 0
     int xg;                 // log2 of the number of XCD-pinned channel-block groups
+    int sparse;             // ramnet_conv_desc.s2d_5x5: 1 = zero slices by input parity group (forward), 2 = by output group (backward-data)
 };
 
 // Patch prefetcher of the Winograd kernel.  Everything that does not depend on the chunk (pixel offsets of the thread's
@@ -189,7 +190,24 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     __syncthreads();
     // one chunk: MFMAs on the transformed rows in `tc`, while the rows of the next chunk are built in `tn` (the loop below
     // alternates the two register sets instead of copying them)
+    // s2d_5x5 layers (3x3 view of a 5x5 stride-2 filter): a channel group of column parity 1 has no tap at dx = +1, so its column
+    // position 3 of G g G^T is zero, and one of row parity 1 none at dy = +1 (row 3 = this kernel's wave 3); for backward-data the
+    // filter is flipped (position 0 / wave 0) and the group is that of the OUTPUT channels.  Those MFMAs multiply by exact zeros and
+    // are not issued.  runm: bit (pl * 2 + f) = issue MFMA (pl, f); forward: per chunk, backward-data: fixed per workgroup.
+    unsigned runm = 0xffu;
+    if (q.sparse == 2) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int g = (n0 + f * 32) >> q.s2d_shift;
+            if ((g & 2) && wave == 0) runm &= ~(0x55u << f);
+            if (g & 1) runm &= ~(1u << f);
+        }
+    }
     auto body = [&](int chunk, const float4 (&tc)[4], float4 (&tn)[4]) {
+        if (q.sparse == 1) {
+            const int g = (chunk * WK) >> q.src.ld1;
+            runm = ((g & 2) && wave == 3) ? 0u : (g & 1) ? 0x3fu : 0xffu;
+        }
         const float *pnext = patch + ((chunk + 1) & 1) * RP_FLOATS;     // patch(i+1)
         float *pfree = patch + (chunk & 1) * RP_FLOATS;                 // patch(i), consumed during chunk i-1 -> patch(i+2)
         const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
@@ -210,11 +228,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
-                acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
+                if ((runm >> (pl * 2)) & 1u) acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 side(pl * 8 + j * 2);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][1], 0, 0, 0);
+                if ((runm >> (pl * 2 + 1)) & 1u) acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 side(pl * 8 + j * 2 + 1);
             }
@@ -387,6 +405,11 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
              (!d.o2 || (d.ldo2 % 4 == 0 && al16(d.o2)));
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(q.vec4);      // the cell epilogue works on channel quads of the staged tile
     q.s2d_shift = 0;
+    q.sparse = 0;
+    if (d.s2d_5x5) {
+        RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_S2D || d.out_s2d);
+        q.sparse = d.in_mode == RAMNET_IN_S2D ? 1 : (d.out_s2d >= 32 ? 2 : 0);      // (a 32-channel block must lie in one parity group)
+    }
     if (d.out_s2d) {
         RAMNET_CHECK_ARG(d.out_s2d >= 8 && log2_exact(d.out_s2d) > 0 && d.Cout == 4 * d.out_s2d && q.vec4 && d.epi == RAMNET_EPI_LINEAR &&
                          !d.bias && d.beta == 0.f && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);

@@ -199,6 +199,8 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     elif isinstance(w, PackRef):
         wino = uses_winograd(taps, w, stride, epi, in_mode, d.C0, C1)
         d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
+        # the 3x3 view of a 5x5 stride-2 layer read / written in place: 11 of its 36 slices are zero by construction (s2d_weights)
+        d.s2d_5x5 = int(wino and isinstance(w.cp, S2DConvParam) and _S2D_SPARSE and (in_mode == H.IN_S2D or out_s2d > 0))
         w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
     d.ntaps, d.stride = taps.n, stride
@@ -239,6 +241,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     hc = getattr(dw, "head_cin", 0)
     if hc and _HEAD and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
         d.algo, d.head_cin = H.ALGO_HEAD, hc
+    d.s2d_5x5 = int(d.algo == H.ALGO_WINOGRAD and in_mode == H.IN_S2D and _S2D_SPARSE and getattr(dw, "s2d_5x5", False))
     if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
@@ -815,6 +818,8 @@ def _s2d_eligible(x, cp, k, stride, up):
 # The space-to-depth view is read / written in place by the Winograd kernels (RAMNET_IN_S2D loader, out_s2d epilogue) when
 # the channel count is a power of two >= 32; RAMNET_S2D_FUSED=0 materialises it with ramnet_space_to_depth2 instead.
 _S2D_FUSED = _os.environ.get("RAMNET_S2D_FUSED", "1") == "1"
+# ... and skip the Winograd positions that the zero slices of that view annihilate (ramnet_conv_desc.s2d_5x5); RAMNET_S2D_SPARSE=0: dense
+_S2D_SPARSE = _os.environ.get("RAMNET_S2D_SPARSE", "1") == "1"
 
 
 def set_space_to_depth_fused(on):
@@ -958,6 +963,7 @@ class ConvAct(Function):
         if ctx.s2d_fused:   # x is the full-resolution input; the kernels address its space-to-depth view
             sp = cp.s2d()
             ws, bws = sp.grad_ws(wino_ok=True)
+            ws.s2d_5x5 = True
             Hl, Wl = x.shape[1] // 2, x.shape[2] // 2
             wgrad_side([x, dy, y], x, Taps.get("conv_s2d", 3, 1), dy, ws, cp.Cout, in_mode=H.IN_S2D, Hin=Hl, Win=Wl,
                        gmask=y if relu else None, dbias=bws)
