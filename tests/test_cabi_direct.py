@@ -196,6 +196,41 @@ def test_space_to_depth_view_through_raw_descriptors():
     torch.cuda.synchronize()
     assert float((a - b).abs().max() / b.abs().max()) < 1e-5
 
+    # s2d_5x5: with the 3x3 view of a REAL 5x5 stride-2 filter (11 of 36 slices zero) the kernels skip the Winograd positions the
+    # zeros annihilate — the results are those of the dense evaluation, bit for bit (forward, backward-data) / on every slice the
+    # 5x5 filter owns (backward-weights)
+    from rpg_ramnet_amd.ops import s2d_weights, s2d_weights_adjoint
+    w3 = s2d_weights(torch.randn(Cout, Cc, 5, 5, device=dev) * 0.1).contiguous()
+    assert L.ramnet_pack_weight_wino(ptr(w3), ptr(wp), Cout, Cin, 0, 1, st) == 0
+    assert L.ramnet_pack_weight_wino(ptr(w3), ptr(wt), Cout, Cin, 1, 1, st) == 0
+    outs = []
+    for flag in (0, 1):
+        yv, dxv = torch.empty(B, Hl, Wl, Cout, device=dev), torch.empty(B, H, W, Cc, device=dev)
+        d = conv_desc(x, Cc, Cc, _hip.IN_S2D, yv, Cout, wp)
+        d.s2d_5x5 = flag
+        assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+        d = conv_desc(dy, Cout, Cout, _hip.IN_PLAIN, dxv, Cin, wt)
+        d.out_s2d, d.s2d_5x5 = Cc, flag
+        assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+        ws = torch.zeros(16 * Cin * Cout, device=dev)
+        g = _hip.WgradDesc()
+        g.x0, g.ld0, g.C0, g.in_mode = ptr(x), Cc, Cc, _hip.IN_S2D
+        g.B, g.Hin, g.Win, g.ntaps, g.stride = B, Hl, Wl, 9, 1
+        for i in range(9):
+            g.dy[i], g.dx[i] = i // 3 - 1, i % 3 - 1
+        g.dout, g.ldg, g.Cout, g.Ho, g.Wo = ptr(dy), Cout, Cout, Hl, Wl
+        g.dw, g.algo, g.s2d_5x5 = ptr(ws), _hip.ALGO_WINOGRAD, flag
+        assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
+        g3 = torch.zeros(Cout, Cin, 3, 3, device=dev)
+        assert L.ramnet_unpack_wgrad_wino(ptr(ws), ptr(g3), Cout, Cin, Cin, Cout, 0, st) == 0
+        outs.append((yv, dxv, s2d_weights_adjoint(g3, Cc)))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][2] - outs[1][2]).abs().max() / outs[0][2].abs().max()) < 1e-5
+    d = conv_desc(deep, Cin, Cin, _hip.IN_PLAIN, y_deep, Cout, wp)       # the flag needs the in-place view (its group geometry)
+    d.s2d_5x5 = 1
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+
 
 @pytest.mark.parametrize("cin,cpad", [(5, 8), (1, 4), (3, 4)])
 def test_head_layer_through_raw_descriptors(cin, cpad):
