@@ -15,7 +15,8 @@ log-depth targets) and resident in HBM before the timed region.  Weights: seeded
 Roofline accounting.  The convolutions are MFMA-bound.  Every MFMA launch is classified by the kernel the
 library reports (ramnet_last_kernel) and carries two FLOP counts: ALGORITHMIC (2*B*Ho*Wo*taps*Cin*Cout of the layer it
 stands for) and EXECUTED (what the MFMA pipe really multiplies: Winograd F(2x2,3x3) 16/36 of the 3x3 taps —
-12.25/25 for the stride-2 5x5 encoders run as 3x3 over the space-to-depth view with the positions of its zero slices skipped —,
+12.25/25 for forward / backward-data of the stride-2 5x5 encoders run as 3x3 over the space-to-depth view with the positions
+of its zero slices skipped (16/25 for their backward-weights) —,
 F(2x2,4x4) 25/100 of a folded decoder).
 `roofline.achieved/frac` use the EXECUTED count (a fraction of the fp32 MFMA peak that cannot exceed 1);
 `roofline.algorithmic_achieved` is the layer-level rate.  `traffic` comes from the newest tracked
@@ -224,12 +225,9 @@ class KernelTimer:
             nclass = 4 if kw.get("wino24") else 1
             cin = getattr(dw, "head_cin", 0) or cin_of(x0, kw)
             alg = 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout
-            ratio = taps.n / float(taps.flop_taps)
-            if ops._S2D_SPARSE and kw.get("in_mode", 0) == Hh.IN_S2D and getattr(dw, "s2d_5x5", False):
-                ratio *= S2D_SPARSE_FACTOR
             timer._bracket(lambda: wgrad0(x0, taps, dout, dw, Cout, **kw), last,
                            sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "head_cin", 0)),
-                           alg, ratio)
+                           alg, taps.n / float(taps.flop_taps))
 
         def multi(x0, w, out, Cout, classes, **kw):
             if not timer.on:

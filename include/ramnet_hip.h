@@ -128,8 +128,6 @@ typedef struct ramnet_wgrad_desc {
     int HoG, WoG;                   /* (all 0 = dense [B, Ho, Wo]; DIRECT only): one output parity of the folded upsample-conv  */
     int head_cin;                   /* RAMNET_ALGO_HEAD (dense 5x5 stride-1 taps, Cout <= 32): real input channels (1, 3 or 5); dw keeps
                                      * the DIRECT layout [25][C0][Cout]                                                          */
-    int s2d_5x5;                    /* 1 (WINOGRAD, in_mode RAMNET_IN_S2D): as in ramnet_conv_desc — the positions that only feed the zero
-                                     * slices are not accumulated (their rows of dU stay as they are)                                  */
 } ramnet_wgrad_desc;
 
 const char *ramnet_last_error(void);

@@ -53,7 +53,6 @@ class WgradDesc(C.Structure):
         ("algo", C.c_int),
         ("gsy", C.c_int), ("gsx", C.c_int), ("goy", C.c_int), ("gox", C.c_int), ("HoG", C.c_int), ("WoG", C.c_int),
         ("head_cin", C.c_int),
-        ("s2d_5x5", C.c_int),
     ]
 
 

@@ -29,7 +29,6 @@ struct WgradWinoParams {
     InSrc src;
     int bx_n, ty_n, nbatch;     // batches per row, tile rows per image, total
     int dy0, dx0;               // offset of the first filter tap
-    int sparse;                 // ramnet_wgrad_desc.s2d_5x5: skip the positions that only feed the zero slices of the 3x3 view
 };
 
 // XM: the input loader has a second operand for this workgroup's channels (h*r product / ReLU mask); GM: ReLU mask on dy.
@@ -202,13 +201,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         bn[f][0] = r0, bn[f][1] = r0 + r1, bn[f][2] = r0 - r1, bn[f][3] = -r1;
     };
 
-    // s2d_5x5: the workgroup's 32 input channels lie in one parity group of the space-to-depth view; column parity 1 has no tap at
-    // dx = +1 (column position 3 feeds only that slice), row parity 1 none at dy = +1 (row 3 = wave 3): runp = bit pl set -> issue
-    unsigned runp = 0xfu;
-    if (q.sparse) {
-        const int g = c0 >> s.ld1;
-        runp = ((g & 2) && wave == 3) ? 0u : (g & 1) ? 0x7u : 0xfu;
-    }
     const int step = gridDim.x;
     int batch = blockIdx.x;
     if (batch < q.nbatch) {
@@ -258,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
 #pragma unroll
                     for (int f = 0; f < 2; ++f) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if ((runp >> pl) & 1u) acc[pl][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pl], bv[f][pl], acc[pl][f], 0, 0, 0);
+                        acc[pl][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pl], bv[f][pl], acc[pl][f], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         gap(pl * 2 + f);
                     }
@@ -275,7 +267,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            if (!((runp >> pl) & 1u)) continue;
             const int n = n0 + f * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -343,11 +334,6 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.bx_n = cdiv(d.Wo, 16), q.ty_n = cdiv(d.Ho, 2);
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
-    q.sparse = 0;
-    if (d.s2d_5x5) {
-        RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_S2D);
-        q.sparse = 1;
-    }
     // batches of 8 tiles: a 2 x 16 or an 8 x 4 pixel strip, whichever pads the map less
     static const char *tall_env = getenv("RAMNET_WGRAD_WINO_TALL");
     bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;

@@ -119,7 +119,8 @@ template <int TX> struct RGeom {
     static_assert(PH * PW * 2 <= 512, "two patch slots per thread");
 };
 
-template <int TX>
+// SP = WinoParams.sparse as a compile-time constant: the dense kernel (SP = 0) carries no trace of the position masks
+template <int TX, int SP>
 __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_desc p, const WinoParams q) {
     using G = RGeom<TX>;
     constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     // filter is flipped (position 0 / wave 0) and the group is that of the OUTPUT channels.  Those MFMAs multiply by exact zeros and
     // are not issued.  runm: bit (pl * 2 + f) = issue MFMA (pl, f); forward: per chunk, backward-data: fixed per workgroup.
     unsigned runm = 0xffu;
-    if (q.sparse == 2) {
+    if (SP == 2) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             const int g = (n0 + f * 32) >> q.s2d_shift;
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         }
     }
     auto body = [&](int chunk, const float4 (&tc)[4], float4 (&tn)[4]) {
-        if (q.sparse == 1) {
+        if (SP == 1) {
             const int g = (chunk * WK) >> q.src.ld1;
             runm = ((g & 2) && wave == 3) ? 0u : (g & 1) ? 0x3fu : 0xffu;
         }
@@ -228,11 +229,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
-                if ((runm >> (pl * 2)) & 1u) acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
+                if (SP == 0 || ((runm >> (pl * 2)) & 1u)) acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 side(pl * 8 + j * 2);
                 __builtin_amdgcn_sched_barrier(0);
-                if ((runm >> (pl * 2 + 1)) & 1u) acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][1], 0, 0, 0);
+                if (SP == 0 || ((runm >> (pl * 2 + 1)) & 1u)) acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 side(pl * 8 + j * 2 + 1);
             }
@@ -423,15 +424,22 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     const int lanes = 8 >> q.xg;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));
     const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
+#define RAMNET_GO(TXv, SPv)                                                                        \
+    do {                                                                                           \
+        RAMNET_FULL_LDS((conv_wino_r_kernel<TXv, SPv>));                                           \
+        hipLaunchKernelGGL((conv_wino_r_kernel<TXv, SPv>), grid, dim3(256), lds, st, d, q);        \
+    } while (0)
+    note_kernel("conv_wino_r_kernel<%d,%d>", tall ? 2 : 8, q.sparse);
     if (tall) {
-        RAMNET_FULL_LDS(conv_wino_r_kernel<2>);
-        note_kernel("conv_wino_r_kernel<2>");
-        hipLaunchKernelGGL(conv_wino_r_kernel<2>, grid, dim3(256), lds, st, d, q);
+        if (q.sparse == 1) RAMNET_GO(2, 1);
+        else if (q.sparse == 2) RAMNET_GO(2, 2);
+        else RAMNET_GO(2, 0);
     } else {
-        RAMNET_FULL_LDS(conv_wino_r_kernel<8>);
-        note_kernel("conv_wino_r_kernel<8>");
-        hipLaunchKernelGGL(conv_wino_r_kernel<8>, grid, dim3(256), lds, st, d, q);
+        if (q.sparse == 1) RAMNET_GO(8, 1);
+        else if (q.sparse == 2) RAMNET_GO(8, 2);
+        else RAMNET_GO(8, 0);
     }
+#undef RAMNET_GO
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

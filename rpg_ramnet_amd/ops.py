@@ -241,7 +241,6 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     hc = getattr(dw, "head_cin", 0)
     if hc and _HEAD and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
         d.algo, d.head_cin = H.ALGO_HEAD, hc
-    d.s2d_5x5 = int(d.algo == H.ALGO_WINOGRAD and in_mode == H.IN_S2D and _S2D_SPARSE and getattr(dw, "s2d_5x5", False))
     if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
@@ -963,7 +962,6 @@ class ConvAct(Function):
         if ctx.s2d_fused:   # x is the full-resolution input; the kernels address its space-to-depth view
             sp = cp.s2d()
             ws, bws = sp.grad_ws(wino_ok=True)
-            ws.s2d_5x5 = True
             Hl, Wl = x.shape[1] // 2, x.shape[2] // 2
             wgrad_side([x, dy, y], x, Taps.get("conv_s2d", 3, 1), dy, ws, cp.Cout, in_mode=H.IN_S2D, Hin=Hl, Win=Wl,
                        gmask=y if relu else None, dbias=bws)

@@ -197,8 +197,8 @@ def test_space_to_depth_view_through_raw_descriptors():
     assert float((a - b).abs().max() / b.abs().max()) < 1e-5
 
     # s2d_5x5: with the 3x3 view of a REAL 5x5 stride-2 filter (11 of 36 slices zero) the kernels skip the Winograd positions the
-    # zeros annihilate — the results are those of the dense evaluation, bit for bit (forward, backward-data) / on every slice the
-    # 5x5 filter owns (backward-weights)
+    # zeros annihilate — the results are those of the dense evaluation, bit for bit (forward, backward-data); backward-weights is
+    # dense either way and its 5x5 gradient only reads the slices the filter owns
     from rpg_ramnet_amd.ops import s2d_weights, s2d_weights_adjoint
     w3 = s2d_weights(torch.randn(Cout, Cc, 5, 5, device=dev) * 0.1).contiguous()
     assert L.ramnet_pack_weight_wino(ptr(w3), ptr(wp), Cout, Cin, 0, 1, st) == 0
@@ -219,7 +219,7 @@ def test_space_to_depth_view_through_raw_descriptors():
         for i in range(9):
             g.dy[i], g.dx[i] = i // 3 - 1, i % 3 - 1
         g.dout, g.ldg, g.Cout, g.Ho, g.Wo = ptr(dy), Cout, Cout, Hl, Wl
-        g.dw, g.algo, g.s2d_5x5 = ptr(ws), _hip.ALGO_WINOGRAD, flag
+        g.dw, g.algo = ptr(ws), _hip.ALGO_WINOGRAD
         assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
         g3 = torch.zeros(Cout, Cin, 3, 3, device=dev)
         assert L.ramnet_unpack_wgrad_wino(ptr(ws), ptr(g3), Cout, Cin, Cin, Cout, 0, st) == 0
