@@ -44,19 +44,40 @@ struct WinoParams {
     int sparse;             // ramnet_conv_desc.s2d_5x5: 1 = zero slices by input parity group (forward), 2 = by output group (backward-data)
 };
 
-// Patch prefetcher of the Winograd kernel.  Everything that does not depend on the chunk (pixel offsets of the thread's
-// two slots in each source tensor, in-image flags) is computed once; per chunk the source selection of the concatenated
-// input is wave-uniform (C0 % 8 == 0 is required), so a load is a scalar base plus a per-thread 32-bit offset and the
-// whole prefetch costs a dozen vector instructions — the main loop has no cycles to spare next to its 32-cycle MFMAs.
-struct WinoPatch {
-    float4 v[2], m[2];
-    unsigned off0[2], off1[2], offm[2];   // float offsets of (pixel, quad) in x0 / x1 / xm
-    int cmax[2];                          // channels c0 < cmax are valid for the slot (-1: outside the image / no slot)
-    int ldst[2];                          // LDS float offset of the slot, or -1
+// Buffer resource over [p, p + bytes): loads take a 32-bit per-lane byte offset plus a scalar one, and an offset past `bytes`
+// returns 0 — the zero padding of the convolution costs no instruction.  The pointer goes through readfirstlane so that the
+// compiler knows the descriptor is wave-uniform (cdna_hip_programming.md, buffer addressing).
+__device__ __forceinline__ auto wino_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
+}
+constexpr unsigned WOOB = 0x7fffff00u;          // byte offset past every image (images are < 2 GB: checked on the host)
 
-    // LDS patch layout: [channel quad 2][PH x PW pixels][4]
+// Patch prefetcher of the Winograd kernel, MODE = ramnet_in_mode of the launch as a compile-time constant (run-time, wave-uniform
+// branches between the MFMAs are not free: measured 9 % for 32 scalar branch pairs per chunk).  Everything that does not depend
+// on the chunk is computed once: the byte offsets of the thread's two (pixel, channel quad) slots inside image b of each source
+// tensor — WOOB when the pixel lies outside the image, so that the buffer load returns the zero padding — and buffer resources
+// over that image.  Per chunk a slot is ONE buffer load (+ one for the mask / h*r operand) with a scalar byte offset for the
+// channel (and, for the space-to-depth view, the parity pixel), and one 16-byte LDS store.
+template <int MODE>
+struct WinoPatch {
+    static constexpr bool CAT = MODE == RAMNET_IN_CAT || MODE == RAMNET_IN_CAT_MUL;
+    float4 v[2], m[2];
+    unsigned vo0[2], vo1[2], vom[2];      // byte offsets of (pixel, quad) in image b of x0 / x1 / xm, or WOOB
+    unsigned bad[2];                      // WOOB if the slot's quad lies beyond Cin in the LAST chunk (ragged channel counts), else 0
+    int ldst[2];                          // LDS float offset of the slot (a scratch location for the threads without one)
+    decltype(wino_rsrc(nullptr, 0u)) r0, r1, rm;
+
+    // LDS patch layout: [channel quad 2][PH x PW pixels][4]; scratch = float offset of 256 spare 16-byte cells
     template <int PH, int PW>
-    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid) {
+    __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid, int clast, int scratch) {
+        const bool s2d = MODE == RAMNET_IN_S2D;
+        const size_t img = (size_t)(s2d ? 4 : 1) * s.Hin * s.Win;      // pixels of one image as stored
+        r0 = wino_rsrc(s.x0 + (size_t)b * img * s.ld0, (unsigned)(img * s.ld0 * 4));
+        r1 = r0, rm = r0;
+        if (CAT) r1 = wino_rsrc(s.x1 + (size_t)b * img * s.ld1, (unsigned)(img * s.ld1 * 4));
+        if (MODE == RAMNET_IN_CAT_MUL || MODE == RAMNET_IN_RELUMASK) rm = wino_rsrc(s.xm + (size_t)b * img * s.ldm, (unsigned)(img * s.ldm * 4));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int sl = tid + i * 256;
@@ -66,44 +87,46 @@ struct WinoPatch {
             const bool slot = sl < PH * PW * 2;
             const bool in = slot && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
             // space-to-depth view: logical pixel (iy, ix) starts at full-resolution pixel (2iy, 2ix); the parity group of a
-            // chunk only moves the (wave-uniform) base pointer, see load_slot
-            const unsigned gp = !in ? 0u : s.mode == RAMNET_IN_S2D ? (unsigned)((b * 2 * s.Hin + 2 * iy) * 2 * s.Win + 2 * ix)
-                                                                   : (unsigned)((b * s.Hin + iy) * s.Win + ix);
-            off0[i] = gp * s.ld0 + qd * 4, off1[i] = gp * s.ld1 + qd * 4, offm[i] = gp * s.ldm + qd * 4;
-            cmax[i] = in ? s.Cin - qd * 4 : -1;
-            ldst[i] = slot ? qd * (PH * PW * 4) + pix * 4 : -1;
+            // chunk only moves the (wave-uniform) scalar offset, see load_slot
+            const unsigned gp = s2d ? (unsigned)((2 * iy) * 2 * s.Win + 2 * ix) : (unsigned)(iy * s.Win + ix);
+            vo0[i] = in ? (gp * s.ld0 + qd * 4) * 4u : WOOB;
+            vo1[i] = in ? (gp * s.ld1 + qd * 4) * 4u : WOOB;
+            vom[i] = in ? (gp * s.ldm + qd * 4) * 4u : WOOB;
+            bad[i] = clast + qd * 4 < s.Cin ? 0u : WOOB;
+            ldst[i] = slot ? qd * (PH * PW * 4) + pix * 4 : scratch + tid * 4;
         }
     }
-    // issue the global loads of slot i for the 8 channels starting at c0 (wave-uniform)
-    __device__ __forceinline__ void load_slot(const InSrc &s, int c0, int i) {
-        const bool cat = s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL;
-        const bool second = cat && c0 >= s.C0;     // uniform
-        const float *base = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
-        if (s.mode == RAMNET_IN_S2D) {              // ld1 = log2(C0): parity group g = (a*2 + c) of the chunk -> pixel (2i+a, 2j+c)
+    static __device__ __forceinline__ float4 bload(decltype(wino_rsrc(nullptr, 0u)) r, unsigned vo, int so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, so, 0));
+    }
+    // issue the loads of slot i for the 8 channels starting at c0 (wave-uniform)
+    __device__ __forceinline__ void load_slot(const InSrc &s, int c0, int i, int clast) {
+        const unsigned last = c0 == clast ? 0xffffffffu : 0u;           // (scalar)
+        if (MODE == RAMNET_IN_S2D) {            // ld1 = log2(C0): parity group g = (a*2 + c) of the chunk -> pixel (2i+a, 2j+c)
             const int g = c0 >> s.ld1;
-            base = s.x0 + ((g >> 1) * 2 * s.Win + (g & 1)) * s.ld0 + (c0 - (g << s.ld1));
+            v[i] = bload(r0, vo0[i] | (bad[i] & last), (((g >> 1) * 2 * s.Win + (g & 1)) * s.ld0 + (c0 - (g << s.ld1))) * 4);
+        } else if (CAT) {
+            // second (uniform; C0 % 8 == 0: a chunk lies in one tensor) selects descriptor and offsets — no branch, so that the
+            // number of loads in flight is the same on every path (a join would force the compiler to drain them)
+            const bool second = c0 >= s.C0;
+            v[i] = bload(second ? r1 : r0, second ? (vo1[i] | (bad[i] & last)) : vo0[i], (second ? c0 - s.C0 : c0) * 4);
+            if (MODE == RAMNET_IN_CAT_MUL) m[i] = bload(rm, second ? (vom[i] | (bad[i] & last)) : WOOB, (second ? c0 - s.C0 : 0) * 4);
+        } else {
+            v[i] = bload(r0, vo0[i] | (bad[i] & last), c0 * 4);
+            if (MODE == RAMNET_IN_RELUMASK) m[i] = bload(rm, vom[i] | (bad[i] & last), c0 * 4);
         }
-        const bool hasm = s.mode == RAMNET_IN_RELUMASK || (s.mode == RAMNET_IN_CAT_MUL && second);      // uniform
-        const float *mbase = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
-        const bool ok = c0 < cmax[i];
-        const unsigned o = ok ? (second ? off1[i] : off0[i]) : 0u;
-        v[i] = ld4((ok ? base : s.x0) + o);
-        if (hasm) m[i] = ld4((ok ? mbase : s.x0) + (ok ? offm[i] : 0u));
     }
-    __device__ __forceinline__ void load(const InSrc &s, int c0) { load_slot(s, c0, 0), load_slot(s, c0, 1); }
-    // registers of slot i (loaded for channel c0) -> LDS patch [pixel][8]
+    __device__ __forceinline__ void load(const InSrc &s, int c0, int clast) { load_slot(s, c0, 0, clast), load_slot(s, c0, 1, clast); }
+    // registers of slot i (loaded for channel c0) -> LDS patch
     __device__ __forceinline__ void store_slot(float *__restrict__ patch, const InSrc &s, int c0, int i) const {
-        const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
-        const bool hasm = s.mode == RAMNET_IN_RELUMASK || (s.mode == RAMNET_IN_CAT_MUL && second);
         float4 r = v[i];
-        if (hasm) {
-            if (s.mode == RAMNET_IN_RELUMASK)
-                r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
-            else
-                r = f4mul(r, m[i]);
+        if (MODE == RAMNET_IN_RELUMASK)
+            r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
+        if (MODE == RAMNET_IN_CAT_MUL) {        // chunks of x0: the mask load returned zeros, scale by 1 instead (uniform select, no branch)
+            const float one = c0 >= s.C0 ? 0.f : 1.f;
+            r = make_float4(r.x * (m[i].x + one), r.y * (m[i].y + one), r.z * (m[i].z + one), r.w * (m[i].w + one));
         }
-        if (!(c0 < cmax[i])) r = f4zero();
-        if (ldst[i] >= 0) st4(patch + ldst[i], r);
+        st4(patch + ldst[i], r);
     }
     __device__ __forceinline__ void store(float *__restrict__ patch, const InSrc &s, int c0) const { store_slot(patch, s, c0, 0), store_slot(patch, s, c0, 1); }
 };
@@ -120,7 +143,7 @@ template <int TX> struct RGeom {
 };
 
 // SP = WinoParams.sparse as a compile-time constant: the dense kernel (SP = 0) carries no trace of the position masks
-template <int TX, int SP>
+template <int TX, int SP, int MODE>
 __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_desc p, const WinoParams q) {
     using G = RGeom<TX>;
     constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
@@ -169,25 +192,25 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
-    WinoPatch pr;
-    pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid);
+    const int nch = q.nchunks;
+    const int clast = (nch - 1) * WK;
+    WinoPatch<MODE> pr;
+    pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid, clast, 2 * RP_FLOATS);
     float4 breg[4][2];
     float4 tcur[4], tnext[4], ta, tb;
     auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
     auto f4sub = [](float4 x, float4 y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
 
-    const int nch = q.nchunks;
-    const int clast = (nch - 1) * WK;
-    pr.load(q.src, 0);
+    pr.load(q.src, 0, clast);
 #pragma unroll
     for (int i = 0; i < 8; ++i) breg[i >> 1][i & 1] = ld4(wsrc + i * 256);
     pr.store(patch, q.src, 0);
-    pr.load(q.src, min(WK, clast));
+    pr.load(q.src, min(WK, clast), clast);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c) tcur[c] = te(ld4(patch + pra + c * 4), ld4(patch + prb + c * 4));
     pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
-    pr.load(q.src, min(2 * WK, clast));
+    pr.load(q.src, min(2 * WK, clast), clast);
     __syncthreads();
     // one chunk: MFMAs on the transformed rows in `tc`, while the rows of the next chunk are built in `tn` (the loop below
     // alternates the two register sets instead of copying them)
@@ -218,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                 if (!(k & 1)) ta = ld4(pnext + pra + (k >> 1) * 4), tb = ld4(pnext + prb + (k >> 1) * 4);
                 else tn[k >> 1] = te(ta, tb);
             } else if (k < 10) pr.store_slot(pfree, q.src, c2, k - 8);
-            else if (k < 12) pr.load_slot(q.src, c3, k - 10);
+            else if (k < 12) pr.load_slot(q.src, c3, k - 10, clast);
         };
 #pragma unroll
         for (int pl = 0; pl < 4; ++pl) {
@@ -424,21 +447,31 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     const int lanes = 8 >> q.xg;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));
     const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
-#define RAMNET_GO(TXv, SPv)                                                                        \
-    do {                                                                                           \
-        RAMNET_FULL_LDS((conv_wino_r_kernel<TXv, SPv>));                                           \
-        hipLaunchKernelGGL((conv_wino_r_kernel<TXv, SPv>), grid, dim3(256), lds, st, d, q);        \
-    } while (0)
-    note_kernel("conv_wino_r_kernel<%d,%d>", tall ? 2 : 8, q.sparse);
-    if (tall) {
-        if (q.sparse == 1) RAMNET_GO(2, 1);
-        else if (q.sparse == 2) RAMNET_GO(2, 2);
-        else RAMNET_GO(2, 0);
-    } else {
-        if (q.sparse == 1) RAMNET_GO(8, 1);
-        else if (q.sparse == 2) RAMNET_GO(8, 2);
-        else RAMNET_GO(8, 0);
+    // one instantiation per (tile shape, sparse mode, input mode) that occurs: the kernel body has no run-time mode branches
+    {
+        const unsigned long long px = (unsigned long long)d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1);
+        int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
+        ldmax = ldmax > d.ldm ? ldmax : d.ldm;
+        RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
     }
+    const int key = (tall ? 0 : 1000) + q.sparse * 100 + d.in_mode;
+    note_kernel("conv_wino_r_kernel<%d,%d,%d>", tall ? 2 : 8, q.sparse, d.in_mode);
+#define RAMNET_GO(TXv, SPv, MDv)                                                                        \
+    case ((TXv) == 2 ? 0 : 1000) + (SPv) * 100 + (MDv):                                                 \
+        RAMNET_FULL_LDS((conv_wino_r_kernel<TXv, SPv, MDv>));                                           \
+        hipLaunchKernelGGL((conv_wino_r_kernel<TXv, SPv, MDv>), grid, dim3(256), lds, st, d, q);        \
+        break;
+#define RAMNET_GO_TX(TXv)                                                                               \
+    RAMNET_GO(TXv, 0, RAMNET_IN_PLAIN) RAMNET_GO(TXv, 0, RAMNET_IN_CAT) RAMNET_GO(TXv, 0, RAMNET_IN_CAT_MUL)        \
+    RAMNET_GO(TXv, 0, RAMNET_IN_RELUMASK) RAMNET_GO(TXv, 0, RAMNET_IN_S2D) RAMNET_GO(TXv, 1, RAMNET_IN_S2D)         \
+    RAMNET_GO(TXv, 2, RAMNET_IN_PLAIN) RAMNET_GO(TXv, 2, RAMNET_IN_RELUMASK)
+    switch (key) {
+        RAMNET_GO_TX(2)
+        RAMNET_GO_TX(8)
+    default:
+        RAMNET_CHECK_ARG(!"conv_wino_r: unsupported (sparse, input mode) combination");
+    }
+#undef RAMNET_GO_TX
 #undef RAMNET_GO
     RAMNET_LAUNCH_CHECK();
     return 0;
