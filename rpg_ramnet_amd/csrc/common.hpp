@@ -59,6 +59,16 @@ __device__ __forceinline__ float4 f4scale(float4 a, float s) { return make_float
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
+// Buffer resource over [p, p + bytes): loads take a 32-bit per-lane byte offset plus a scalar one, and an offset past `bytes`
+// returns 0 — the zero padding of the convolution costs no instruction.  The pointer goes through readfirstlane so that the
+// compiler knows the descriptor is wave-uniform (cdna_hip_programming.md, buffer addressing).
+__device__ __forceinline__ auto wino_rsrc(const void *p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
+}
+constexpr unsigned WOOB = 0x7fffff00u;          // byte offset past every image (images are < 2 GB: checked on the host)
+
 // Everything the patch loader needs to know about the logical input of a convolution.
 struct InSrc {
     const float *x0, *x1, *xm;

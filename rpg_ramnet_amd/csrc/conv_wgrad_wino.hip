@@ -31,7 +31,10 @@ struct WgradWinoParams {
     int dy0, dx0;               // offset of the first filter tap
 };
 
-// XM: the input loader has a second operand for this workgroup's channels (h*r product / ReLU mask); GM: ReLU mask on dy.
+// XMK: second operand of the input loader — 0 none, 1 ReLU mask (x * (xm > 0)), 2 product (the h*r half of a CAT_MUL input: the
+// workgroups of the plain half load zeros from an out-of-range offset and scale by 1); GM: ReLU mask on dy.  The raw strips are
+// fetched with buffer loads: a pixel outside the image is an out-of-range offset (returns 0), a thread without a slot stores into
+// a scratch cell — the staging slices between the MFMAs carry no branch and no select besides that offset.
 // TXB = tiles per batch row: 8 (a 2 x 16 pixel strip) or 2 (8 x 4 pixels: the 43- / 86-pixel-wide maps of the coarse scales then
 // lose 2 % instead of 10 % of the work to the partial last strip).
 template <int TXB> struct GrGeom {
@@ -42,7 +45,7 @@ template <int TXB> struct GrGeom {
     static constexpr int SX = TXB == 8 ? 4 * 32 : 2 * PW * 32, SY = TXB == 8 ? 4 : 2 * YW;     // step of a tile pair (floats / pixels)
 };
 
-template <bool XM, bool GM, int TXB>
+template <int XMK, bool GM, int TXB>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
     using G = GrGeom<TXB>;
     constexpr int NT = 256, XQ = 8, GW_CI = 32, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
@@ -64,38 +67,39 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][f][r] = 0.f;
 
-    // ---- raw-data prefetch (as conv_wgrad_wino_kernel<.,.,32>): per-thread slot geometry, wave-uniform base pointers
+    // ---- raw-data prefetch: per-thread slot geometry, wave-uniform base pointers, buffer resources rebuilt per batch
     float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
-    unsigned xok = 0, yok = 0;
     const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
-    const bool use_m = XM && (s.mode == RAMNET_IN_RELUMASK || second);
+    const bool use_m = XMK == 1 || (XMK == 2 && second);
+    const float m_one = use_m ? 0.f : 1.f;      // XMK == 2, plain half: r * (0 + 1)
     const bool s2d = s.mode == RAMNET_IN_S2D;
     const int sgrp = s2d ? c0 >> s.ld1 : 0;
     const int rowS = s2d ? 4 * s.Win : s.Win, colS = s2d ? 2 : 1;
     const float *xsrc = second ? s.x1 + (c0 - s.C0) : s2d ? s.x0 + ((sgrp >> 1) * 2 * s.Win + (sgrp & 1)) * s.ld0 + (c0 - (sgrp << s.ld1)) : s.x0 + c0;
     const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
     const int ldS = second ? s.ld1 : s.ld0;
-    int xpy[NXS], xpx[NXS], xoff[NXS], xmoff[NXS], ypx[NYS], ypy[NYS], yoff[NYS], ymoff[NYS];
-    const int safe_x = (-q.dy0 * rowS - q.dx0 * colS) * ldS, safe_m = XM ? (-q.dy0 * s.Win - q.dx0) * s.ldm : 0;
+    int xpy[NXS], xpx[NXS], ypx[NYS], ypy[NYS], xdst[NXS];
+    unsigned xoff[NXS], xmoff[NXS], yoff[NYS], ymoff[NYS];
     bool xslot[NXS], yslot[NYS];
 #pragma unroll
     for (int i = 0; i < NXS; ++i) {
         const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
         xpy[i] = pix / PW, xpx[i] = pix - xpy[i] * PW;
         xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
-        xoff[i] = (xpy[i] * rowS + xpx[i] * colS) * ldS + qd * 4;
-        xmoff[i] = (xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4;
+        xoff[i] = (unsigned)((xpy[i] * rowS + xpx[i] * colS) * ldS + qd * 4) * 4u;
+        xmoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4) * 4u;
+        xdst[i] = sl < XSLOTS ? (sl / XQ) * 32 + (sl % XQ) * 4 : -1;
     }
 #pragma unroll
     for (int i = 0; i < NYS; ++i) {
         const int sl = tid + i * NT, qd = sl & 15, pix = sl >> 4;
         ypx[i] = pix % YW, ypy[i] = pix / YW;
         yslot[i] = n0 + qd * 4 < p.Cout;
-        yoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4;
-        ymoff[i] = (ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4;
+        yoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4) * 4u;
+        ymoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4) * 4u;
     }
     int lb_ty = 0, lb_bx = 0;
-    const float *lb_x = nullptr, *lb_m = nullptr, *lb_g = nullptr, *lb_gm = nullptr;
+    auto rx = wino_rsrc(s.x0, 0u), rmk = rx, rg = rx, rgm = rx;       // resources at the corner of the batch being loaded
     // batch -> (image, tile row, strip): divided out once; the walk then advances by the (pre-divided) grid stride with carries —
     // a few scalar operations per batch instead of two ~40-instruction integer divisions in front of the loads
     int lb_b = 0, lb_batch = -1;
@@ -121,24 +125,25 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         const long pix = ((long)b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
         const long corner = pix + (long)q.dy0 * s.Win + q.dx0;
         const long corner_src = s2d ? ((long)b * p.Ho + G::YH * lb_ty + q.dy0) * rowS + (YW * lb_bx + q.dx0) * colS : corner;
-        lb_x = xsrc + corner_src * ldS;
-        if (use_m) lb_m = msrc + corner * s.ldm;
-        lb_g = p.dout + pix * p.ldg;
-        if (GM) lb_gm = p.gmask + pix * p.ldgm;
-        xok = 0, yok = 0;
+        // the descriptors start at the strip's corner (for a top / left strip that is before the tensor: only out-of-image threads
+        // would reach it, and they get WOOB) and span WOOB bytes: every in-image offset of the strip is below it (images < WOOB),
+        // WOOB itself is out of range and reads as 0
+        rx = wino_rsrc(xsrc + corner_src * ldS, WOOB);
+        if (XMK) rmk = wino_rsrc(msrc + corner * s.ldm, WOOB);
+        rg = wino_rsrc(p.dout + pix * p.ldg, WOOB);
+        if (GM) rgm = wino_rsrc(p.gmask + pix * p.ldgm, WOOB);
     };
+    auto bload = [](decltype(rx) r, unsigned vo) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, 0, 0)); };
     auto load_x = [&](int i) {
         const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
         const bool ok = xslot[i] && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
-        xr[i] = ld4(lb_x + (ok ? xoff[i] : safe_x));
-        if (use_m) xm[i] = ld4(lb_m + (ok ? xmoff[i] : safe_m));
-        xok |= (ok ? 1u : 0u) << i;
+        xr[i] = bload(rx, ok ? xoff[i] : WOOB);
+        if (XMK) xm[i] = bload(rmk, ok && use_m ? xmoff[i] : WOOB);
     };
     auto load_y = [&](int i) {
         const bool ok = yslot[i] && G::YH * lb_ty + ypy[i] < p.Ho && YW * lb_bx + ypx[i] < p.Wo;
-        yr[i] = ld4(lb_g + (ok ? yoff[i] : 0));
-        if (GM) ym[i] = ld4(lb_gm + (ok ? ymoff[i] : 0));
-        yok |= (ok ? 1u : 0u) << i;
+        yr[i] = bload(rg, ok ? yoff[i] : WOOB);
+        if (GM) ym[i] = bload(rgm, ok ? ymoff[i] : WOOB);
     };
     auto load_raw = [&](int batch) {
         load_begin(batch);
@@ -148,26 +153,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         for (int i = 0; i < NYS; ++i) load_y(i);
     };
     float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
+    float *scratch = smem + 2 * (GR_XP + GR_YP) + tid * 4;          // 256 spare 16-byte cells behind the strips
     auto store_x = [&](int i, float *xb) {
-        const int sl = tid + i * NT;
         float4 r = xr[i];
-        if (use_m) {
-            if (s.mode == RAMNET_IN_RELUMASK)
-                r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
-            else
-                r = f4mul(r, xm[i]);
-        }
-        if (!((xok >> i) & 1u)) r = f4zero();
-        if (sl < XSLOTS) st4(xb + (sl / XQ) * 32 + (sl % XQ) * 4, r);
+        if (XMK == 1)
+            r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
+        if (XMK == 2) r = make_float4(r.x * (xm[i].x + m_one), r.y * (xm[i].y + m_one), r.z * (xm[i].z + m_one), r.w * (xm[i].w + m_one));
+        st4(xdst[i] >= 0 ? xb + xdst[i] : scratch, r);
     };
-    bool count_bias = true;                       // false for the clamped re-store of the last batch
+    float bias_on = 1.f;                          // 0 for the clamped re-store of the last batch
     auto store_y = [&](int i, float *yb) {
         const int sl = tid + i * NT;
         float4 r = yr[i];
         if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
-        if (!((yok >> i) & 1u)) r = f4zero();
         st4(yb + (sl >> 4) * GW_CO + (sl & 15) * 4, r);
-        if (count_bias) bsum = f4add(bsum, r);
+        bsum = make_float4(bsum.x + bias_on * r.x, bsum.y + bias_on * r.y, bsum.z + bias_on * r.z, bsum.w + bias_on * r.w);
     };
 
     // ---- row `wave` of the two transforms.  B^T d B: rows (ra, rb) of the window, te = d[ra] + sb * d[rb];
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         fetch_x(Xp, 0), fetch_y(Yp, 0);      // operands of the first tile pair (later batches: prepared under the previous one)
         finish_x(), finish_y(0), finish_y(1);
         for (; batch <= last; batch += step, cur ^= 1) {
-            count_bias = batch + step <= last;
+            bias_on = batch + step <= last ? 1.f : 0.f;
             const int b2 = min(batch + 2 * step, last);
             const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
             float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
@@ -346,18 +346,26 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
     const dim3 grid(splits, gy, gz);
-    const size_t lds = (size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + GrGeom<8>::YP) * sizeof(float);
-    const bool xm = d.in_mode == RAMNET_IN_RELUMASK || d.in_mode == RAMNET_IN_CAT_MUL, gm = d.gmask != nullptr;
-    note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d>", (int)xm, (int)gm, tall ? 2 : 8);
+    const size_t lds = ((size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + GrGeom<8>::YP) + 256 * 4) * sizeof(float);      // strips + scratch cells
+    const int xmk = d.in_mode == RAMNET_IN_RELUMASK ? 1 : d.in_mode == RAMNET_IN_CAT_MUL ? 2 : 0;
+    const bool gm = d.gmask != nullptr;
+    {
+        const unsigned long long px = (unsigned long long)d.Hin * d.Win, ldx = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
+        RAMNET_CHECK_ARG(px * (d.in_mode == RAMNET_IN_S2D ? 4 : 1) * ldx * 4ull < WOOB && px * d.ldm * 4ull < WOOB &&
+                         (unsigned long long)d.Ho * d.Wo * d.ldg * 4ull < WOOB && (unsigned long long)d.Ho * d.Wo * d.ldgm * 4ull < WOOB);
+    }
+    note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d>", xmk, (int)gm, tall ? 2 : 8);
 #define RAMNET_GO(XMv, GMv)                                                                                                  \
     do {                                                                                                                     \
     if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2>), grid, dim3(256), lds, st, d, q);               \
     else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8>), grid, dim3(256), lds, st, d, q);                    \
     } while (0)
-    if (xm && gm) RAMNET_GO(true, true);
-    else if (xm) RAMNET_GO(true, false);
-    else if (gm) RAMNET_GO(false, true);
-    else RAMNET_GO(false, false);
+    if (xmk == 1 && gm) RAMNET_GO(1, true);
+    else if (xmk == 1) RAMNET_GO(1, false);
+    else if (xmk == 2 && gm) RAMNET_GO(2, true);
+    else if (xmk == 2) RAMNET_GO(2, false);
+    else if (gm) RAMNET_GO(0, true);
+    else RAMNET_GO(0, false);
 #undef RAMNET_GO
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -44,16 +44,6 @@ struct WinoParams {
     int sparse;             // ramnet_conv_desc.s2d_5x5: 1 = zero slices by input parity group (forward), 2 = by output group (backward-data)
 };
 
-// Buffer resource over [p, p + bytes): loads take a 32-bit per-lane byte offset plus a scalar one, and an offset past `bytes`
-// returns 0 — the zero padding of the convolution costs no instruction.  The pointer goes through readfirstlane so that the
-// compiler knows the descriptor is wave-uniform (cdna_hip_programming.md, buffer addressing).
-__device__ __forceinline__ auto wino_rsrc(const void *p, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), (short)0, (int)bytes, 0x00020000);
-}
-constexpr unsigned WOOB = 0x7fffff00u;          // byte offset past every image (images are < 2 GB: checked on the host)
-
 // Patch prefetcher of the Winograd kernel, MODE = ramnet_in_mode of the launch as a compile-time constant (run-time, wave-uniform
 // branches between the MFMAs are not free: measured 9 % for 32 scalar branch pairs per chunk).  Everything that does not depend
 // on the chunk is computed once: the byte offsets of the thread's two (pixel, channel quad) slots inside image b of each source
