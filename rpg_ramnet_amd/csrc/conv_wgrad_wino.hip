@@ -102,23 +102,26 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     auto rx = wino_rsrc(s.x0, 0u), rmk = rx, rg = rx, rgm = rx;       // resources at the corner of the batch being loaded
     // batch -> (image, tile row, strip): divided out once; the walk then advances by the (pre-divided) grid stride with carries —
     // a few scalar operations per batch instead of two ~40-instruction integer divisions in front of the loads
-    int lb_b = 0, lb_batch = -1;
+    int lb_b = 0, lb_batch = 0;
     const int st_bx = (int)gridDim.x % q.bx_n, st_ty = ((int)gridDim.x / q.bx_n) % q.ty_n, st_b = ((int)gridDim.x / q.bx_n) / q.ty_n;
+    auto load_first = [&](int batch) {          // (once, in front of the loop: the two integer divisions)
+        int tt = batch;
+        lb_bx = tt % q.bx_n;
+        tt /= q.bx_n;
+        lb_ty = tt % q.ty_n;
+        lb_b = tt / q.ty_n;
+        lb_batch = batch;
+    };
     auto load_begin = [&](int batch) {
-        if (lb_batch < 0) {
-            int tt = batch;
-            lb_bx = tt % q.bx_n;
-            tt /= q.bx_n;
-            lb_ty = tt % q.ty_n;
-            lb_b = tt / q.ty_n;
-        } else if (batch != lb_batch) {         // == lb_batch + gridDim.x (the clamped tail repeats the last batch)
-            lb_bx += st_bx;
+        {                                       // batch == lb_batch (first call, clamped tail) or lb_batch + gridDim.x: branch-free
+            const int adv = batch != lb_batch ? 1 : 0;
+            lb_bx += adv * st_bx;
             const int cx = lb_bx >= q.bx_n ? 1 : 0;
             lb_bx -= cx * q.bx_n;
-            lb_ty += st_ty + cx;
+            lb_ty += adv * st_ty + cx;
             const int cy = lb_ty >= q.ty_n ? 1 : 0;
             lb_ty -= cy * q.ty_n;
-            lb_b += st_b + cy;
+            lb_b += adv * st_b + cy;
         }
         lb_batch = batch;
         const int b = lb_b;
@@ -136,12 +139,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     auto bload = [](decltype(rx) r, unsigned vo) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, 0, 0)); };
     auto load_x = [&](int i) {
         const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
-        const bool ok = xslot[i] && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
+        const bool ok = xslot[i] & ((unsigned)iy < (unsigned)s.Hin) & ((unsigned)ix < (unsigned)s.Win);      // (no short-circuit: no exec regions)
         xr[i] = bload(rx, ok ? xoff[i] : WOOB);
-        if (XMK) xm[i] = bload(rmk, ok && use_m ? xmoff[i] : WOOB);
+        if (XMK) xm[i] = bload(rmk, (ok & use_m) ? xmoff[i] : WOOB);
     };
     auto load_y = [&](int i) {
-        const bool ok = yslot[i] && G::YH * lb_ty + ypy[i] < p.Ho && YW * lb_bx + ypx[i] < p.Wo;
+        const bool ok = yslot[i] & (G::YH * lb_ty + ypy[i] < p.Ho) & (YW * lb_bx + ypx[i] < p.Wo);
         yr[i] = bload(rg, ok ? yoff[i] : WOOB);
         if (GM) ym[i] = bload(rgm, ok ? ymoff[i] : WOOB);
     };
@@ -205,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     int batch = blockIdx.x;
     if (batch < q.nbatch) {
         const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
+        load_first(batch);
         load_raw(batch);
 #pragma unroll
         for (int i = 0; i < NXS; ++i) store_x(i, Xp);
