@@ -38,23 +38,36 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool mok = m < M, nok = n < N;
+    // Operands through buffer loads: the per-lane byte offsets of a K step are computed once (rows / columns past M, N get an
+    // out-of-range offset and read as 0), the step moves the descriptor, whose extent ends with this slice of the reduction —
+    // so the loads of the main loop carry no mask, no branch and no per-lane address arithmetic.
     // one K step = 32 values: half 0 of the wave takes k0 .. k0+15, half 1 k0+16 .. k0+31 (MFMA i pairs k0+i with k0+16+i), so a
     // row of A is read as one full 128-byte line by its two lanes (4 x 16 bytes each) — no reliance on the L1 keeping it
+    unsigned ao[TA ? 16 : 4], bo[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        bo[j] = nok ? (unsigned)(((16 * kh + j) * ldb + n) * 4) : WOOB;
+        if (TA) ao[j] = mok ? (unsigned)(((16 * kh + j) * lda + m) * 4) : WOOB;
+    }
+    if (!TA) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) ao[qd] = mok ? (unsigned)((m * lda + 16 * kh + 4 * qd) * 4) : WOOB;
+    }
     auto load = [&](int k0, float (&a)[16], float (&b)[16]) {
-        const int k = k0 + 16 * kh;
+        // descriptors from row k0 to the end of the slice (the range check looks at the per-lane offset only): rows past kend read 0
+        const auto rb = wino_rsrc(B + (size_t)k0 * ldb, (unsigned)min((size_t)(kend - k0) * ldb * 4, (size_t)WOOB));
+        const auto ra = TA ? wino_rsrc(A + (size_t)k0 * lda, (unsigned)min((size_t)(kend - k0) * lda * 4, (size_t)WOOB)) : wino_rsrc(A + k0, WOOB);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            if (!TA) {
-                float4 v = f4zero();
-                if (mok && k + 4 * qd + 3 < kend) v = ld4(A + (size_t)m * lda + k + 4 * qd);    // K % 4 == 0, 16-byte aligned rows (host)
+            if (!TA) {      // K % 4 == 0 and 16-byte aligned rows (host): a quad never straddles kend
+                const unsigned o = k0 + 16 * kh + 4 * qd < kend ? ao[qd] : WOOB;
+                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)o, 0, 0));
                 a[4 * qd] = v.x, a[4 * qd + 1] = v.y, a[4 * qd + 2] = v.z, a[4 * qd + 3] = v.w;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int kj = k + 4 * qd + j;
-                const bool ok = kj < kend;
-                if (TA) a[4 * qd + j] = (ok && mok) ? A[(size_t)kj * lda + m] : 0.f;
-                b[4 * qd + j] = (ok && nok) ? B[(size_t)kj * ldb + n] : 0.f;
+                if (TA) a[4 * qd + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)ao[4 * qd + j], 0, 0));
+                b[4 * qd + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)bo[4 * qd + j], 0, 0));
             }
         }
     };
