@@ -19,6 +19,9 @@
 // Measured against the previous formulation (transformed input V[16][32][8] in LDS, 16x16x4 MFMAs, every wave all 16 positions;
 // same-box A/B, round 2): 7.38 -> 6.74 us per 8-channel chunk, fixed cost per launch 44 -> 38 us, training step 174 -> 186
 // samples/s; profiles/r01_g_winograd_notes.md has the design log of the LDS version.
+// Nothing between two MFMAs branches or selects: the input mode and the s2d_5x5 masks are template parameters (one instantiation
+// per combination that occurs), the patch prefetch is one buffer load per slot (zero padding = out-of-range offset), the
+// concatenation a descriptor / offset select — 235-313 instructions per two chunks instead of 560, training step 190 -> 197.
 #include <stdlib.h>
 #include "common.hpp"
 #include "conv_epilogue.hpp"
