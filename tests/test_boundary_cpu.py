@@ -272,6 +272,14 @@ def test_cabi_argument_errors_and_host_only_entry_points():
     d = _hip.ConvDesc()                      # all-zero descriptor: null pointers
     assert L.ramnet_conv_launch(ctypes.byref(d), None) == 10001
     assert L.ramnet_si_loss_fwd(None, None, 0, 1.0, 1.0, None, None, None) == 10001
+    # a source tensor beyond the 32-bit element offsets of the patch loaders is refused on the host (dummy non-null pointers:
+    # the check comes before any HIP call)
+    d = _hip.ConvDesc()
+    d.x0 = d.w = d.out = 4096
+    d.ntaps, d.stride, d.B, d.Ho, d.Wo, d.Hin, d.Win, d.Cout = 9, 1, 4096, 64, 64, 4096, 4096, 64
+    d.C0, d.ld0, d.ldo, d.osy, d.osx = 64, 64, 64, 1, 1
+    d.algo = _hip.ALGO_WINOGRAD
+    assert L.ramnet_conv_launch(ctypes.byref(d), None) == 10001 and b"px * ld" in L.ramnet_last_error()
     assert L.ramnet_voxelize(None, 10, 0, 4, 4, None, None) == 10001
     # packed sizes: [tap][chunk16][Cout_pad32][16]
     assert L.ramnet_packed_weight_elems(64, 32, 5, 5, 0, 1) == 25 * 2 * 64 * 16
