@@ -178,7 +178,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
-    const float ca = wave == 3 ? 0.f : 1.f, cb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+    // A dy rows: g0, g0 + g1, g0 - g1, -g1.  Wave 3 reads row 1 in the place of row 0 with coefficient 0 on the second operand and
+    // its sign — like the -r1 of position 3 in every wave — is applied once, to the accumulators, after the loop: one FMA per value
+    const float cb = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+    const int yr0 = wave == 3 ? YW : 0;                             // pixel row offset of the first operand
     // tile of MFMA step st and K index kk: TXB = 8: (row 0, column 2 st + kk); TXB = 2: (row st, column kk)
     const int xa_off = (ra * PW + 2 * kk) * 32 + l31, xb_off = (rb * PW + 2 * kk) * 32 + l31;      // + st * G::SX
     const int y_off = (2 * kk) * GW_CO + l31;                                                       // + st * G::SY pixels
@@ -193,15 +196,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
-                g0[f][c] = yc[y_off + (st * G::SY + c) * GW_CO + f * 32], g1[f][c] = yc[y_off + (YW + st * G::SY + c) * GW_CO + f * 32];
+                g0[f][c] = yc[y_off + (yr0 + st * G::SY + c) * GW_CO + f * 32], g1[f][c] = yc[y_off + (YW + st * G::SY + c) * GW_CO + f * 32];
     };
     auto finish_x = [&]() {
         const float t0 = da[0] + sb * db[0], t1 = da[1] + sb * db[1], t2 = da[2] + sb * db[2], t3 = da[3] + sb * db[3];
         an[0] = t0 - t2, an[1] = t1 + t2, an[2] = t2 - t1, an[3] = t1 - t3;
     };
     auto finish_y = [&](int f) {
-        const float r0 = ca * g0[f][0] + cb * g1[f][0], r1 = ca * g0[f][1] + cb * g1[f][1];
-        bn[f][0] = r0, bn[f][1] = r0 + r1, bn[f][2] = r0 - r1, bn[f][3] = -r1;
+        const float r0 = g0[f][0] + cb * g1[f][0], r1 = g0[f][1] + cb * g1[f][1];
+        bn[f][0] = r0, bn[f][1] = r0 + r1, bn[f][2] = r0 - r1, bn[f][3] = r1;       // (position 3 and wave 3: sign applied at the end)
     };
 
     const int step = gridDim.x;
@@ -275,7 +278,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (c < Cin && n < p.Cout) atomicAdd(p.dw + ((size_t)(4 * wave + pl) * Cin + c) * p.Cout + n, acc[pl][f][r]);
+                if (c < Cin && n < p.Cout)
+                    atomicAdd(p.dw + ((size_t)(4 * wave + pl) * Cin + c) * p.Cout + n, ((wave == 3) != (pl == 3)) ? -acc[pl][f][r] : acc[pl][f][r]);
             }
         }
     if (p.dbias != nullptr && blockIdx.y == 0) {
