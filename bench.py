@@ -483,7 +483,10 @@ def main():
     warm_hbm = {k: v for k, v in timer.summary().items() if k.startswith("ramnet_")}
     timer.rec, timer.hbm = [], False
     if warm:
-        timer.only = max(warm.items(), key=lambda kv: kv[1][1])[0]
+        # dominant kernel = the symbol with the most executed MFMA work per step (what rocprofv3 --stats ranks first too); the
+        # co-scheduled event durations of the warm-up inflate forward and backward launches differently and would make the
+        # choice flip between the instantiations of the same kernel from run to run
+        timer.only = max(warm.items(), key=lambda kv: kv[1][3])[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
