@@ -176,7 +176,7 @@ def algo3x3(request):
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2)])
-@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256), (36, 64), (68, 36)])
 def test_winograd_conv3x3_raw(B, H, W, cin, cout):
     """Winograd forward and backward-data launches (all loader / epilogue combinations the 3x3 layers use) against
     float64 F.conv2d and against the direct kernel; channel counts that are not multiples of the 8 / 64 blocking."""
