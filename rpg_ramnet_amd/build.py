@@ -25,10 +25,15 @@ def _headers_mtime():
 
 
 def _compile(hipcc, src, obj, verbose):
-    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    tmp = "%s.%d.tmp" % (obj, os.getpid())        # concurrent build() calls must not see each other's half-written objects
+    cmd = [hipcc] + FLAGS + ["-c", src, "-o", tmp]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode == 0:
+        os.replace(tmp, obj)
+    elif os.path.exists(tmp):
+        os.remove(tmp)
     return src, r
 
 
@@ -52,10 +57,12 @@ def build(force=False, verbose=False):
                 if verbose:
                     sys.stderr.write(r.stderr)
     if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("hipcc failed linking %s" % LIB)
+        os.replace(tmp, LIB)
     return LIB
 
 

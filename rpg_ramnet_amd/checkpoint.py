@@ -34,23 +34,41 @@ Logger.__module__ = 'logger.logger'     # pickled under the reference's module p
 
 
 class _LoggerModules:
-    """Make `logger.logger.Logger` resolvable while pickling / unpickling outside the reference tree."""
+    """Make `logger.logger.Logger` resolve to THIS module's class while pickling / unpickling — also when another `logger`
+    package (the reference tree's own, in a side-by-side setup) is already imported: its entries in `sys.modules` are saved,
+    overridden for the duration of the call and restored afterwards (pickle checks that the class found under the pickled
+    module path is the very object being saved)."""
+
+    _NAMES = ('logger', 'logger.logger')
 
     def __enter__(self):
-        self.injected = []
-        if 'logger' not in sys.modules:
-            pkg = types.ModuleType('logger')
-            sub = types.ModuleType('logger.logger')
-            sub.Logger = Logger
-            pkg.Logger = Logger
-            pkg.logger = sub
-            sys.modules['logger'], sys.modules['logger.logger'] = pkg, sub
-            self.injected = ['logger', 'logger.logger']
+        self.saved = {m: sys.modules.get(m) for m in self._NAMES}
+        pkg = types.ModuleType('logger')
+        sub = types.ModuleType('logger.logger')
+        sub.Logger = Logger
+        pkg.Logger = Logger
+        pkg.logger = sub
+        sys.modules['logger'], sys.modules['logger.logger'] = pkg, sub
         return self
 
     def __exit__(self, *exc):
-        for m in self.injected:
-            sys.modules.pop(m, None)
+        for m, old in self.saved.items():
+            if old is None:
+                sys.modules.pop(m, None)
+            else:
+                sys.modules[m] = old
+
+
+def _as_own_logger(logger):
+    """A foreign `logger.logger.Logger` instance (the reference's class, same surface) re-wrapped into this module's class so
+    that it pickles under the stand-in modules."""
+    if logger is None:
+        return Logger()
+    if isinstance(logger, Logger):
+        return logger
+    own = Logger()
+    own.entries = dict(getattr(logger, 'entries', {}))
+    return own
 
 
 def checkpoint_name(save_dir, epoch, loss):
@@ -62,7 +80,7 @@ def save_checkpoint(path, model, optimizer, epoch, config, monitor_best=float('i
     state = {
         'arch': type(model).__name__,
         'epoch': epoch,
-        'logger': logger if logger is not None else Logger(),
+        'logger': _as_own_logger(logger),
         'state_dict': model.state_dict(),
         'optimizer': optimizer.state_dict() if optimizer is not None else None,
         'monitor_best': monitor_best,

@@ -232,6 +232,7 @@ int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st) {
     static const char *se = getenv("RAMNET_HEAD_WGRAD_BLOCKS");
     int blocks = se ? atoi(se) : 512;
     if (blocks > q.ntiles) blocks = q.ntiles;
+    if (blocks < 1) blocks = 1;
     auto go = [&](auto kern, int cr) -> int {
         const size_t lds = (size_t)(((cr * (HG_H + 4) * HP_LD + 3) & ~3) + HG_H * HT_W * HG_LD) * sizeof(float);
         RAMNET_FULL_LDS((kern));

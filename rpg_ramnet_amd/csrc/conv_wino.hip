@@ -436,6 +436,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     static const char *xge = getenv("RAMNET_WINO_XCD_GROUPS");      // tuning knob: log2 of the group count
     const size_t wbytes = (size_t)q.nchunks * q.nblk * WU_FLOATS * sizeof(float);
     q.xg = xge ? atoi(xge) : (wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0);
+    q.xg = q.xg < 0 ? 0 : q.xg > 3 ? 3 : q.xg;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));

@@ -114,6 +114,9 @@ extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int 
     RAMNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N && batch >= 1);
     if (trans_a) RAMNET_CHECK_ARG(lda >= M);
     else RAMNET_CHECK_ARG(lda >= K && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && stride_a % 4 == 0);
+    // operands are addressed through 32-bit per-lane byte offsets and buffer extents clamped to WOOB (like the conv launchers)
+    RAMNET_CHECK_ARG((unsigned long long)(trans_a ? K : M) * lda * 4ull < WOOB && (unsigned long long)K * ldb * 4ull < WOOB &&
+                     (unsigned long long)M * ldc * 4ull < WOOB);
     // accumulate (backward pass): the operand loads are latency-bound and occupancy is what hides them, so the reduction is split
     // over gridDim.z until a few thousand waves are in flight; partial sums meet by atomics in C.  A plain product (forward pass)
     // splits it over the waves of one workgroup per block instead (fixed-order LDS join): bit-reproducible, as every forward kernel.

@@ -26,12 +26,18 @@ void note_kernel(const char *fmt, ...) {
 }
 
 hipError_t allow_full_lds(const void *kernel) {
+    // the attribute is scoped to the CURRENT device: key the cache on (device, kernel) so that a process driving several GPUs
+    // opts every one of them in
     static std::mutex mu;
-    static std::unordered_set<const void *> done;
+    static std::unordered_set<unsigned long long> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long key = ((unsigned long long)(uintptr_t)kernel << 8) ^ (unsigned long long)(dev & 0xff);
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count(kernel)) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) done.insert(kernel);
+    if (done.count(key)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert(key);
     return e;
 }
 
@@ -633,7 +639,7 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
     int g = grid_for(npix * 8);      // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups
     static const char *ge = getenv("RAMNET_PRED_BWD_BLOCKS");
     const int cap = ge ? atoi(ge) : 512;
-    if (g > cap) g = cap;
+    if (g > cap && cap >= 1) g = cap;
     hipLaunchKernelGGL(pred_sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, dx, lddx, dw, db, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;

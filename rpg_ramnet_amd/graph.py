@@ -172,7 +172,10 @@ class GraphedPackage:
 class GraphedTrainStep:
     """zero gradients -> forward over the sequence -> loss (trainer.sequence_loss) -> BPTT backward -> weight-gradient fold, as
     one hipGraph.  ``sequence`` provides the static input buffers (refill them in place, e.g. ``step.load(new_sequence)``);
-    the gradients land in the parameters' ``.grad`` (the flat buffer of ``parallel.FlatGradReducer`` when one is attached)."""
+    the gradients land in the parameters' ``.grad`` (the flat buffer of ``parallel.FlatGradReducer`` when one is attached).  The
+    gradient tensors of the capture are owned by this object and re-installed as ``.grad`` at every call, so an
+    ``optimizer.zero_grad()`` (set_to_none=True) between replays is harmless; do not REPLACE ``.grad`` by other tensors and expect
+    the replay to fill those."""
 
     def __init__(self, model, sequence, loss_composition, loss_weights, reducer=None, grad_loss_weight=None, warmup=2):
         self.model, self.reducer = model, reducer
@@ -202,6 +205,17 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.total, self.reported = run()
         ops.invalidate_packs()            # eager code must not trust packs whose refresh now lives in the graph
+        # the graph holds RAW POINTERS to the gradient tensors of the capture: keep them alive, and re-attach them as .grad when the
+        # caller dropped them (optimizer.zero_grad() defaults to set_to_none=True, as the reference trainer's call does) — a replay
+        # into storage the caching allocator took back would corrupt other tensors and leave the optimizer with nothing to step on
+        self.grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
+
+    def _attach(self):
+        if self.reducer is not None:
+            self.reducer.attach()
+        for p, g in self.grads:
+            if p.grad is not g:
+                p.grad = g
 
     def load(self, sequence):
         for dst, src in zip(self.sequence, sequence):
@@ -210,5 +224,6 @@ class GraphedTrainStep:
 
     def __call__(self):
         """Replay; returns (differentiated loss, reported loss) as device scalars (static buffers)."""
+        self._attach()
         self.graph.replay()
         return self.total, self.reported

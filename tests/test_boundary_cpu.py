@@ -245,6 +245,36 @@ def test_checkpoint_written_here_unpickles_without_this_package(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "3", r.stderr[-2000:]
 
 
+def test_checkpoint_save_with_a_foreign_logger_package_already_imported(tmp_path):
+    """the side-by-side setup — the reference tree's own `logger` package is imported before save_checkpoint().  Its
+    sys.modules entries are overridden for the duration of the pickle and restored afterwards; an instance of the foreign
+    Logger class handed in is re-wrapped (entries preserved)."""
+    import sys
+    import types
+    from rpg_ramnet_amd import checkpoint as ck
+    pkg, sub = types.ModuleType("logger"), types.ModuleType("logger.logger")
+
+    class Logger:                       # the reference's class (RAM_Net/logger/logger.py): a different object of the same path
+        def __init__(self):
+            self.entries = {}
+    Logger.__module__, Logger.__qualname__ = "logger.logger", "Logger"
+    sub.Logger = pkg.Logger = Logger
+    pkg.logger = sub
+    sys.modules["logger"], sys.modules["logger.logger"] = pkg, sub
+    try:
+        net = torch.nn.Conv2d(1, 2, 3)
+        foreign = Logger()
+        foreign.entries[1] = {"epoch": 1, "loss": 0.25}
+        p1 = ck.save_checkpoint(str(tmp_path / "a.pth.tar"), net, None, 1, {"arch": "X"})
+        p2 = ck.save_checkpoint(str(tmp_path / "b.pth.tar"), net, None, 2, {"arch": "X"}, logger=foreign)
+        assert sys.modules["logger"] is pkg and sys.modules["logger.logger"] is sub        # restored
+        assert ck.load_checkpoint(p1)["logger"].entries == {}
+        assert ck.load_checkpoint(p2)["logger"].entries[1]["loss"] == 0.25
+        assert sys.modules["logger"] is pkg and sys.modules["logger.logger"] is sub
+    finally:
+        del sys.modules["logger"], sys.modules["logger.logger"]
+
+
 def test_flat_reducer_adopts_grads_allocated_outside_the_flat_buffer():
     """optimizer.zero_grad(set_to_none=True) after zero() makes autograd allocate fresh .grad tensors; all_reduce()
     must fold them back into the flat buffer instead of averaging zeros."""

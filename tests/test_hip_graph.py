@@ -149,3 +149,38 @@ def test_graphed_train_step_equals_eager_steps(schedule):
     finally:
         ops.set_wgrad_overlap(False)
         ops.set_decoder_overlap(False)
+
+
+@pytest.mark.parametrize("with_reducer", [False, True])
+def test_graphed_train_step_survives_zero_grad_set_to_none(with_reducer):
+    """optimizer.zero_grad() (set_to_none=True, the default and what the reference trainer calls) between replays drops
+    every .grad; the graph writes through raw pointers captured once.  The runner owns those gradient tensors and re-attaches
+    them, so the optimizer keeps training and nothing is written into freed memory."""
+    from rpg_ramnet_amd.graph import GraphedTrainStep
+    from rpg_ramnet_amd.parallel import FlatGradReducer
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
+    rng = np.random.default_rng(5)
+    seq = [make_item(rng, 1, 32, 48, 2, 5, 1, True, 0.1) for _ in range(2)]
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    red = FlatGradReducer(model) if with_reducer else None
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    dseq = [{k: v.to(model.gpu) for k, v in it.items()} for it in seq]
+    g = GraphedTrainStep(model, dseq, cfg["loss_composition"], [1, 1], reducer=red)
+    ptrs = {k: p.grad.data_ptr() for k, p in model.named_parameters()}
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()                                  # set_to_none=True
+        assert all(p.grad is None for p in model.parameters())
+        filler = [torch.full((1 << 20,), 7.0, device=model.gpu) for _ in range(8)]      # would land in freed gradient storage
+        total, _ = g()
+        torch.cuda.synchronize()
+        assert all(float(f.min()) == 7.0 and float(f.max()) == 7.0 for f in filler)
+        for k, p in model.named_parameters():
+            assert p.grad is not None and p.grad.data_ptr() == ptrs[k], k
+            assert float(p.grad.abs().max()) > 0 or k.endswith("bias"), k
+        if red is not None:
+            red.all_reduce()
+            red.wait()
+        opt.step()
+        losses.append(float(total))
+    assert losses[2] != losses[0]                        # the optimizer stepped on real gradients
