@@ -60,6 +60,9 @@ def parse():
                     help="train: configs[1]/[2] step; infer: forward over the same sequences; stream: configs[3]-style batch-1 "
                          "asynchronous inference, irregular number of event grids per frame, persistent state")
     ap.add_argument("--state", choices=["convgru", "convlstm"], default="convgru")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group and run the bucketed gradient all-reduce even with ONE rank: executes the RCCL "
+                         "init + side-stream collective path on a single-GPU box (tests/test_hip_model.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap-wgrad", dest="overlap_wgrad", action="store_false",
@@ -331,13 +334,127 @@ def cpu_baseline(cfg, H, W, K, args):
                       "B=1 L=1 warm-up step" % (args.mode, B, L, K, H, W, dt, warm)}
 
 
+def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
+    """BASELINE configs[3] at its own shape: batch-1 asynchronous streaming inference, persistent state, an irregular number of
+    event grids (1..8) before each frame, hipGraph replays with the decode of update k pipelined behind update k+1
+    (graph.GraphedStream).  Returns ms per update+decode and the MFMA roofline of the whole chain: FLOP counted by the launch
+    hooks over ONE eager pass of the same schedule (every launch of the chain), divided by the replayed wall time."""
+    from rpg_ramnet_amd.graph import GraphedStream
+    was_training = model.training
+    model.eval()
+    rs = np.random.default_rng(7)
+    sched = [int(v) for v in rs.integers(1, 9, size=frames)]
+    items = [{k: v[:1].contiguous() for k, v in seq[l % len(seq)].items() if not k.startswith("depth_")} for l in range(frames)]
+    n_upd = sum(sched) + frames
+
+    def eager():
+        st = model.init_states(1, H, W)
+        with torch.no_grad():
+            for l, item in enumerate(items):
+                for k in range(sched[l]):
+                    st, _ = model.update_events(item["events%d" % (k % K)], st)
+                    pred = model.decode(st)
+                st, _ = model.update_image(item["image"], st)
+                pred = model.decode(st)
+        return pred
+
+    on0, only0, hbm0, rec0 = timer.on, timer.only, timer.hbm, timer.rec
+    timer.on, timer.only, timer.hbm, timer.rec = True, None, False, []
+    eager()
+    torch.cuda.synchronize()
+    agg = timer.summary()
+    timer.on, timer.only, timer.hbm, timer.rec = on0, only0, hbm0, rec0
+    alg, ex, nl = sum(v[2] for v in agg.values()), sum(v[3] for v in agg.values()), sum(v[0] for v in agg.values())
+    gs = GraphedStream(model, 1, H, W, pipelined=True)
+
+    def run():
+        for l, item in enumerate(items):
+            for k in range(sched[l]):
+                pred = gs.update_events(item["events%d" % (k % K)])
+            pred = gs.update_image(item["image"])
+        return gs.wait(pred)
+
+    run()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    for _ in range(reps):
+        eager()
+    torch.cuda.synchronize()
+    dte = (time.perf_counter() - t) / reps
+    model.train(was_training)
+    out = {"workload": "configs[3]: batch 1, %dx%d, persistent ConvGRU state, %d event grids + %d frames per pass (grids per frame %s), "
+                       "update + decode per measurement" % (H, W, sum(sched), frames, sched),
+           "ms_per_update_and_decode": 1e3 * dt / n_upd, "updates_per_s": n_upd / dt, "eager_ms_per_update_and_decode": 1e3 * dte / n_upd,
+           "mfma_launches_per_update": nl / float(n_upd)}
+    if ex > 0:
+        out["roofline"] = {"bound": "mfma", "kernel": "whole update+decode chain (%d MFMA launches per update)" % round(nl / float(n_upd)),
+                           "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "algorithmic_gflop_per_update": alg / n_upd / 1e9, "executed_gflop_per_update": ex / n_upd / 1e9,
+                           "achieved": ex / dt / 1e12, "frac": ex / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                           "frac_executed": ex / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_achieved": alg / dt / 1e12,
+                           "frac_algorithmic": alg / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                           "note": "MFMA FLOP of every launch of the chain (executed = what the pipe multiplies, Winograd 16/36 and 25/100; "
+                                   "algorithmic = SURVEY 8d layer count) over the wall time of the pipelined hipGraph replay"}
+    return out
+
+
+def input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank, n=2):
+    """The training step WITH its input side in the timed loop: per step, L batched voxel scatter-adds of
+    fresh event lists (B*K lists of --events-per-grid events each, resident in HBM as the loader's raw `*_events.npy` would be after
+    their upload), the batched nonzero normalisation, and the host-to-device copies of the frames and the two target maps from
+    pinned memory — then the step itself (forward, loss, BPTT backward, all-reduce, Adam) on those tensors."""
+    from rpg_ramnet_amd import voxel
+    dev = model.gpu
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    n_ev = args.events_per_grid
+    lists = []
+    for _ in range(K * B):
+        ev = torch.empty(n_ev, 4, device=dev, dtype=torch.float64)
+        ev[:, 0] = torch.sort(torch.rand(n_ev, device=dev, generator=g, dtype=torch.float64) * 0.05)[0]
+        ev[:, 1] = torch.randint(0, W, (n_ev,), device=dev, generator=g).double()
+        ev[:, 2] = torch.randint(0, H, (n_ev,), device=dev, generator=g).double()
+        ev[:, 3] = torch.randint(0, 2, (n_ev,), device=dev, generator=g).double()
+        lists.append(ev)
+    host = [{k: v.cpu().pin_memory() for k, v in item.items() if not k.startswith("events")} for item in seq]
+
+    def full():
+        for l in range(L):
+            grids = voxel.events_to_voxel_grids(lists, bins, W, H, dev, normalize=True).view(K, B, bins, H, W)
+            for k in range(K):
+                seq[l]["events%d" % k] = grids[k]
+            for k, v in host[l].items():
+                seq[l][k] = v.to(dev, non_blocking=True)
+        return step()
+
+    full()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        lv = full()
+    torch.cuda.synchronize()
+    e = (time.perf_counter() - t) / n
+    return {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach()),
+            "note": "per step: %d voxelize_batch launches (%d lists x %d events each, on-device event lists), batched nonzero "
+                    "normalisation, H2D of %d frames + %d target maps from pinned host memory, then the training step" %
+                    (L, K * B, n_ev, L * B, 2 * L * B)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("RAMNET_BENCH_SINGLE_DEVICE") == "1":     # functional test of the N>1 path on a 1-GPU box
             local = 0
         torch.cuda.set_device(local)
@@ -372,7 +489,7 @@ def main():
     timer.rec, timer.on, timer.hbm = [], False, False
 
     ranks_seen = [0]
-    if world > 1:      # every rank reports in over the collective backend: the driver's SCALE run can confirm N ranks took part
+    if world > 1 or args.force_collective:      # every rank reports in over the collective backend: the driver's SCALE run can confirm N ranks took part
         t = torch.full((1,), float(rank), device=model.gpu)
         got = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(got, t)
@@ -381,7 +498,7 @@ def main():
     graphed = {}
     if args.mode == "train":
         model.train()
-        reducer = FlatGradReducer(model)
+        reducer = FlatGradReducer(model, always_collective=args.force_collective)
         # the reference's optimizer (configs/*.json: Adam, lr 3e-4, weight_decay 0) as ONE fused multi-tensor kernel per step: the
         # foreach form's ~11 launches with their host work sit exposed at the step boundary (GPU idle ~3 ms per step, +0.8 %)
         opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=0, fused=True)
@@ -467,7 +584,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.force_collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -495,7 +612,7 @@ def main():
     timer.on = False
     agg_timed = timer.summary()          # dominant kernel over the timed region (the extras below reuse the timer)
     timer.rec = []
-    if world > 1:
+    if world > 1 or args.force_collective:
         t = torch.tensor([dt], device=model.gpu, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -551,11 +668,35 @@ def main():
                                                           "update k BEFORE update k+1 on one stream (the timed region overlaps them)")
         elif args.mode == "train" and not args.graph:
             try:
+                extras["with_input_side"] = input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank)
+            except Exception as ex:     # noqa: BLE001
+                extras["with_input_side"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            try:
+                extras["stream_b1"] = stream_b1_measure(model, seq, K, H, W, timer)
+            except Exception as ex:     # noqa: BLE001
+                extras["stream_b1"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            try:
                 extras["graph_replay"] = dict(measure(make_graph_step()), note="the same step as ONE hipGraph replay (zero-fill, forward, "
                                               "loss, BPTT backward, gradient fold) + eager Adam; rpg_ramnet_amd.graph.GraphedTrainStep")
             except Exception as ex:     # noqa: BLE001 — an extra must not take the headline measurement down
                 extras["graph_replay"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
+    stream_roof = None
+    if args.mode in ("stream", "infer") and not args.no_kernel_timing and "eager" in graphed:
+        timer.on, timer.only, timer.hbm, timer.rec = True, None, False, []
+        graphed["eager"]()
+        torch.cuda.synchronize()
+        agg = timer.summary()
+        timer.on, timer.rec = False, []
+        salg, sex, snl = sum(v[2] for v in agg.values()), sum(v[3] for v in agg.values()), sum(v[0] for v in agg.values())
+        per = dt / args.steps
+        stream_roof = {"bound": "mfma", "kernel": "whole forward chain (%d MFMA launches per step)" % snl, "peak": F32_MFMA_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "achieved": sex / per / 1e12, "frac": sex / per / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                       "frac_executed": sex / per / 1e12 / F32_MFMA_PEAK_TFLOPS, "algorithmic_achieved": salg / per / 1e12,
+                       "frac_algorithmic": salg / per / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                       "executed_tflop_per_step": sex / 1e12, "algorithmic_tflop_per_step": salg / 1e12, "traffic": None,
+                       "note": "MFMA FLOP of every launch of one step (launch hooks over one eager pass) over the timed wall time per step "
+                               "of the hipGraph replay; per-kernel HIP events do not exist inside a graph replay"}
     if rank == 0:
         samples = world * B * L * args.steps
         if args.mode == "stream":
@@ -571,25 +712,36 @@ def main():
                                       (", decoders on a second stream" if args.overlap_decoder and args.mode == "train" else ""),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
                "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-               "rccl_ranks_seen": ranks_seen, "backend": (args.backend if world > 1 else None)}
+               "rccl_ranks_seen": ranks_seen, "backend": (args.backend if (world > 1 or args.force_collective) else None),
+               "loss_semantics": "per-rank mean over the rank's batch, gradients averaged over ranks (standard DDP)"}
         if args.mode == "stream":
             out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
                              "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "
                              "state + decode one depth map; samples/s counts frames"}
         if extras:
             out["extras"] = extras
+        if stream_roof:
+            out["roofline"] = stream_roof
+            if args.mode == "stream":
+                n_upd = (sum(sched) + L) * B
+                out["roofline"]["algorithmic_gflop_per_update"] = stream_roof["algorithmic_tflop_per_step"] * 1e3 / n_upd
+                out["roofline"]["executed_gflop_per_update"] = stream_roof["executed_tflop_per_step"] * 1e3 / n_upd
         if agg_timed:
             name, (n, secs, alg, ex, opb) = max(agg_timed.items(), key=lambda kv: kv[1][1])
             pmc_file, pmc = newest_pmc_traffic()
             traffic = traffic_of(pmc, name)
             out["roofline"] = {
                 "bound": "mfma", "kernel": name, "achieved": ex / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": "profiles/" + pmc_file,
+                "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "frac_executed": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                "frac_algorithmic": alg / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": "profiles/" + pmc_file,
                 "operand_bytes_per_launch": opb / n, "traffic_over_operand_bytes": (traffic / (opb / n)) if traffic and opb else None,
                 "launches": n, "avg_launch_ms": 1e3 * secs / n,
                 "executed_gflop_per_launch": ex / n / 1e9, "algorithmic_gflop_per_launch": alg / n / 1e9,
                 "algorithmic_achieved": alg / secs / 1e12,
-                "note": "achieved/frac = EXECUTED MFMA FLOP (Winograd: 16/36 of the 3x3 layer's, 12.25/25 for space-to-depth encoders) over "
+                "note": "frac_algorithmic = SURVEY 8d quantity (algorithmic FLOP per launch / average launch duration / peak; can exceed the "
+                        "executed fraction by the Winograd factor 36/16); frac = frac_executed = pipe utilisation.  "
+                        "achieved/frac = EXECUTED MFMA FLOP (Winograd: 16/36 of the 3x3 layer's, 12.25/25 for space-to-depth encoders) over "
                         "HIP-event durations of this kernel in the timed region, which co-schedules three streams (main, decoders, "
                         "backward-weights) — wall durations include time shared with other kernels; extras.single_stream.dominant_kernel "
                         "= same launches on one stream.  algorithmic_achieved = layer-level rate (SURVEY 8d count).  traffic = HBM bytes "
@@ -639,7 +791,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, H, W, K, args)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

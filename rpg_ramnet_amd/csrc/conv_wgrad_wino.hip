@@ -23,7 +23,8 @@
 
 namespace ramnet {
 
-constexpr int GW_CO = 64;                      // output channels per workgroup
+// output channels per workgroup = 32 * NF: NF = 2 (two workgroups per CU) or 4 (one per CU, 256 accumulator VGPRs: every
+// transformed input row then feeds twice the MFMAs)
 
 struct WgradWinoParams {
     InSrc src;
@@ -37,18 +38,20 @@ struct WgradWinoParams {
 // a scratch cell — the staging slices between the MFMAs carry no branch and no select besides that offset.
 // TXB = tiles per batch row: 8 (a 2 x 16 pixel strip) or 2 (8 x 4 pixels: the 43- / 86-pixel-wide maps of the coarse scales then
 // lose 2 % instead of 10 % of the work to the partial last strip).
-template <int TXB> struct GrGeom {
+template <int TXB, int NF = 2> struct GrGeom {
+    static constexpr int GW_CO = 32 * NF;
     static constexpr int TYB = 8 / TXB, YH = 2 * TYB, YW = 2 * TXB, PH = YH + 2, PW = YW + 2;
     static constexpr int XPIX = PH * PW, XSLOTS = XPIX * 8, NXS = (XSLOTS + 255) / 256;
     static constexpr int XP = XPIX * 32;           // raw input strip [PH x PW pixels][32 channels]
-    static constexpr int YP = 32 * GW_CO;          // raw gradient strip [YH x YW = 32 pixels][64 channels]
+    static constexpr int YP = 32 * GW_CO;          // raw gradient strip [YH x YW = 32 pixels][64 / 128 channels]
     static constexpr int SX = TXB == 8 ? 4 * 32 : 2 * PW * 32, SY = TXB == 8 ? 4 : 2 * YW;     // step of a tile pair (floats / pixels)
 };
 
-template <int XMK, bool GM, int TXB>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
-    using G = GrGeom<TXB>;
-    constexpr int NT = 256, XQ = 8, GW_CI = 32, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
+template <int XMK, bool GM, int TXB, int NF>
+__global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
+    using G = GrGeom<TXB, NF>;
+    constexpr int NT = 256, XQ = 8, GW_CI = 32, NXS = G::NXS, NYS = NF, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
+    constexpr int GW_CO = G::GW_CO, YQ = GW_CO / 4;          // channel quads per gradient pixel
     constexpr int PW = G::PW, YW = G::YW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Xp = smem;                   // [2][72][32]
@@ -59,11 +62,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     const int c0 = blockIdx.y * GW_CI, n0 = blockIdx.z * GW_CO;
     const InSrc &s = q.src;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NF];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][f][r] = 0.f;
 
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     }
 #pragma unroll
     for (int i = 0; i < NYS; ++i) {
-        const int sl = tid + i * NT, qd = sl & 15, pix = sl >> 4;
+        const int sl = tid + i * NT, qd = sl % YQ, pix = sl / YQ;
         ypx[i] = pix % YW, ypy[i] = pix / YW;
         yslot[i] = n0 + qd * 4 < p.Cout;
         yoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4) * 4u;
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
 #pragma unroll
         for (int i = 0; i < NYS; ++i) load_y(i);
     };
-    float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid & 15)
+    float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid % YQ)
     float *scratch = smem + 2 * (GR_XP + GR_YP) + tid * 4;          // 256 spare 16-byte cells behind the strips
     auto store_x = [&](int i, float *xb) {
         float4 r = xr[i];
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         const int sl = tid + i * NT;
         float4 r = yr[i];
         if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
-        st4(yb + (sl >> 4) * GW_CO + (sl & 15) * 4, r);
+        st4(yb + (sl / YQ) * GW_CO + (sl % YQ) * 4, r);
         bsum = make_float4(bsum.x + bias_on * r.x, bsum.y + bias_on * r.y, bsum.z + bias_on * r.z, bsum.w + bias_on * r.w);
     };
 
@@ -185,15 +188,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
     // tile of MFMA step st and K index kk: TXB = 8: (row 0, column 2 st + kk); TXB = 2: (row st, column kk)
     const int xa_off = (ra * PW + 2 * kk) * 32 + l31, xb_off = (rb * PW + 2 * kk) * 32 + l31;      // + st * G::SX
     const int y_off = (2 * kk) * GW_CO + l31;                                                       // + st * G::SY pixels
-    float da[4], db[4], g0[2][2], g1[2][2];      // raw operands of the tile pair being prepared
-    float an[4], bn[2][4];
+    float da[4], db[4], g0[NF][2], g1[NF][2];    // raw operands of the tile pair being prepared
+    float an[4], bn[NF][4];
     auto fetch_x = [&](const float *xc, int st) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) da[c] = xc[xa_off + st * G::SX + c * 32], db[c] = xc[xb_off + st * G::SX + c * 32];
     };
-    auto fetch_y = [&](const float *yc, int st) {
+    auto fetch_y = [&](const float *yc, int st, int f0, int f1) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = f0; f < f1; ++f)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 g0[f][c] = yc[y_off + (yr0 + st * G::SY + c) * GW_CO + f * 32], g1[f][c] = yc[y_off + (YW + st * G::SY + c) * GW_CO + f * 32];
@@ -220,46 +223,70 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         load_raw(min(batch + step, last));
         __syncthreads();
         int cur = 0;
-        fetch_x(Xp, 0), fetch_y(Yp, 0);      // operands of the first tile pair (later batches: prepared under the previous one)
-        finish_x(), finish_y(0), finish_y(1);
+        fetch_x(Xp, 0), fetch_y(Yp, 0, 0, NF);      // operands of the first tile pair (later batches: prepared under the previous one)
+        finish_x();
+#pragma unroll
+        for (int f = 0; f < NF; ++f) finish_y(f);
         for (; batch <= last; batch += step, cur ^= 1) {
             bias_on = batch + step <= last ? 1.f : 0.f;
             const int b2 = min(batch + 2 * step, last);
             const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
             float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
             // staging slices: raw strip of the next batch -> the other LDS buffer, then the loads of the batch after it
-            auto stage = [&](int k) {                // NXS = 3 (2 x 16 strips) or 2 (8 x 4) input slots per thread
-                if (k < 3) { if (k < NXS) store_x(k, xn); }
-                else if (k < 5) store_y(k - 3, yn);
-                else if (k == 5) load_begin(b2);
-                else if (k < 9) { if (k - 6 < NXS) load_x(k - 6); }
-                else if (k < 11) load_y(k - 9);
+            // (NXS = 3 (2 x 16 strips) or 2 (8 x 4) input slots, NYS = NF gradient slots per thread; SL slices per tile pair)
+            constexpr int SL = NF == 4 ? 4 : 3, S0 = 3, S1 = S0 + NYS, S2 = S1 + 1, S3 = S2 + 3, S4 = S3 + NYS;
+            static_assert(S4 <= 4 * SL, "staging slices fit the gaps of a batch");
+            auto stage = [&](int k) {
+                if (k < S0) { if (k < NXS) store_x(k, xn); }
+                else if (k < S1) store_y(k - S0, yn);
+                else if (k == S1) load_begin(b2);
+                else if (k < S3) { if (k - S2 < NXS) load_x(k - S2); }
+                else if (k < S4) load_y(k - S3);
             };
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                float a[4], bv[2][4];
+                float a[4], bv[NF][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = an[j], bv[0][j] = bn[0][j], bv[1][j] = bn[1][j];
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = an[j];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) bv[f][j] = bn[f][j];
+                }
                 // the operands of the next tile pair are fetched / finished in the gaps; for the last pair of a batch that is the
                 // first pair of the NEXT batch, whose raw strip is complete in the other buffer since the barrier behind pair 2
                 auto gap = [&](int gidx) {          // compile-time constant after unrolling
-                    if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
-                    if (gidx == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3);
-                    if (gidx == 2) stage(st * 3);
-                    if (gidx == 3) stage(st * 3 + 1);
-                    if (gidx == 4) finish_x();
-                    if (gidx == 5) finish_y(0);
-                    if (gidx == 6) finish_y(1);
-                    if (gidx == 7) stage(st * 3 + 2);
+                    if (NF == 2) {
+                        if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
+                        if (gidx == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 0, 2);
+                        if (gidx == 2) stage(st * 3);
+                        if (gidx == 3) stage(st * 3 + 1);
+                        if (gidx == 4) finish_x();
+                        if (gidx == 5) finish_y(0);
+                        if (gidx == 6) finish_y(1);
+                        if (gidx == 7) stage(st * 3 + 2);
+                    } else {
+                        if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
+                        if (gidx == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 0, 2);
+                        if (gidx == 2) fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 2, 4);
+                        if (gidx == 3) stage(st * 4);
+                        if (gidx == 5) stage(st * 4 + 1);
+                        if (gidx == 7) finish_x();
+                        if (gidx == 8) finish_y(0);
+                        if (gidx == 9) finish_y(1);
+                        if (gidx == 10) stage(st * 4 + 2);
+                        if (gidx == 11) finish_y(2);
+                        if (gidx == 12) finish_y(3);
+                        if (gidx == 14) stage(st * 4 + 3);
+                    }
                 };
 #pragma unroll
                 for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
-                    for (int f = 0; f < 2; ++f) {
+                    for (int f = 0; f < NF; ++f) {
                         __builtin_amdgcn_sched_barrier(0);
                         acc[pl][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pl], bv[f][pl], acc[pl][f], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        gap(pl * 2 + f);
+                        gap(pl * NF + f);
                     }
                 // raw strip of the next batch (stored under pairs 0 and 1) visible; this batch's strip was last read by the
                 // fetches of pair 3 above (in pair 2's gaps), so its buffer is free for the stores of the next iteration
@@ -273,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NF; ++f) {
             const int n = n0 + f * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -284,12 +311,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r_kernel(const ramnet_
         }
     if (p.dbias != nullptr && blockIdx.y == 0) {
         __syncthreads();
-        float *red = smem;                        // [NT/16][64]
-        st4(red + (tid >> 4) * GW_CO + (tid & 15) * 4, bsum);
+        float *red = smem;                        // [NT / YQ][GW_CO]
+        st4(red + (tid / YQ) * GW_CO + (tid % YQ) * 4, bsum);
         __syncthreads();
         if (tid < GW_CO) {
             float t = 0.f;
-            for (int g = 0; g < NT / 16; ++g) t += red[g * GW_CO + tid];
+            for (int g = 0; g < NT / YQ; ++g) t += red[g * GW_CO + tid];
             if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, t);
         }
     }
@@ -347,14 +374,18 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
     if (tall_env) tall = tall_env[0] == '1';
     if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
-    const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, GW_CO);
+    // 128 output channels per workgroup (one workgroup per CU) where the layer has them; RAMNET_WGRAD_NF=2 keeps the 64-channel form
+    static const char *nfe = getenv("RAMNET_WGRAD_NF");
+    const int nf = (d.Cout % 128 == 0 && !(nfe && nfe[0] == '2')) ? 4 : 2;
+    const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
     // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
-    int splits = (se ? atoi(se) : 384) / (gy * gz);
+    static const char *se4 = getenv("RAMNET_WGRAD_BLOCKS4");
+    int splits = (nf == 4 ? (se4 ? atoi(se4) : 256) : (se ? atoi(se) : 384)) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
     const dim3 grid(splits, gy, gz);
-    const size_t lds = ((size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + GrGeom<8>::YP) + 256 * 4) * sizeof(float);      // strips + scratch cells
+    const size_t lds = ((size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + 32 * 32 * nf) + 256 * 4) * sizeof(float);      // strips + scratch cells
     const int xmk = d.in_mode == RAMNET_IN_RELUMASK ? 1 : d.in_mode == RAMNET_IN_CAT_MUL ? 2 : 0;
     const bool gm = d.gmask != nullptr;
     {
@@ -362,11 +393,14 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
         RAMNET_CHECK_ARG(px * (d.in_mode == RAMNET_IN_S2D ? 4 : 1) * ldx * 4ull < WOOB && px * d.ldm * 4ull < WOOB &&
                          (unsigned long long)d.Ho * d.Wo * d.ldg * 4ull < WOOB && (unsigned long long)d.Ho * d.Wo * d.ldgm * 4ull < WOOB);
     }
-    note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d>", xmk, (int)gm, tall ? 2 : 8);
+    note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d,%d>", xmk, (int)gm, tall ? 2 : 8, nf);
 #define RAMNET_GO(XMv, GMv)                                                                                                  \
     do {                                                                                                                     \
-    if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2>), grid, dim3(256), lds, st, d, q);               \
-    else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8>), grid, dim3(256), lds, st, d, q);                    \
+    if (nf == 4) {                                                                                                           \
+        if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 4>), grid, dim3(256), lds, st, d, q);        \
+        else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8, 4>), grid, dim3(256), lds, st, d, q);             \
+    } else if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 2>), grid, dim3(256), lds, st, d, q);     \
+    else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8, 2>), grid, dim3(256), lds, st, d, q);                 \
     } while (0)
     if (xmk == 1 && gm) RAMNET_GO(1, true);
     else if (xmk == 1) RAMNET_GO(1, false);

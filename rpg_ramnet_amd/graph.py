@@ -44,10 +44,14 @@ class GraphedStream:
     occupied each (a dozen workgroups per launch), so they overlap almost freely.  Predictions are then valid on the caller's
     stream after ``wait(pred)`` (an event wait, no host sync) and until the second-next update overwrites the buffer."""
 
-    def __init__(self, model, B, H, W, pipelined=False):
+    def __init__(self, model, B, H, W, pipelined=False, branches=True):
+        """branches: capture the state updates of the three scales as parallel branches of the update graph (they are mutually
+        independent, ops.set_branch_overlap) — the graph's critical path is then head + encoders + ONE state update."""
         assert not bool(model.baseline), "streaming graphs are built for the asynchronous RAM-Net (not the baselines)"
         self.model, dev = model, model.gpu
         self.pipelined = pipelined
+        branch0 = ops.branch_overlap()
+        ops.set_branch_overlap(bool(branches))
         self.ev_in = torch.zeros(B, model.num_bins_events, H, W, device=dev)
         self.im_in = torch.zeros(B, model.num_bins_rgb, H, W, device=dev)
         self.sets = [model.init_states(B, H, W), model.init_states(B, H, W)]
@@ -81,6 +85,7 @@ class GraphedStream:
             self.dec[src] = g
         self.reset()
         model.train(was_training)
+        ops.set_branch_overlap(branch0)
 
     @staticmethod
     def _flat(s):

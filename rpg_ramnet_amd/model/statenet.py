@@ -76,6 +76,9 @@ class StateNetPhasedRecurrent(nn.Module):
         if prev_states_lstm is None:
             prev_states_lstm = {'encoders': [None] * n, 'state_comb': [None] * n}
         super_states, states_lstm = [], {'encoders': [], 'state_comb': []}
+        # inference: the state updates of the scales are mutually independent -> all but the last on streams of their own
+        branch = (not feed_state_forward) and ops.branch_overlap() and not torch.is_grad_enabled() and x.is_cuda
+        joins = []
         for i, encoder in enumerate(encoders):
             if self.recurrent_block_type == 'conv':
                 x, enc_state = encoder(x), None
@@ -83,10 +86,19 @@ class StateNetPhasedRecurrent(nn.Module):
                 x, enc_state = encoder(x, prev_states_lstm['encoders'][i])
             if not feed_state_forward:
                 # RAM-Net: the shared state is updated; the ENCODER feature x feeds the next scale (statenet.py:215-237)
-                if self.state_combination == 'convlstm':
-                    _, super_state = combs[i](x, prev_super_state[i])       # h and c both from the shared state
+                if branch and i < n - 1:
+                    main, side = torch.cuda.current_stream(), ops.branch_stream(x.device, i)
+                    side.wait_stream(main)                                  # x_i (and the state) are ready
+                    with torch.cuda.stream(side):
+                        _, super_state = combs[i](x, prev_super_state[i])
+                    x.record_stream(side)
+                    for t in (prev_super_state[i] if isinstance(prev_super_state[i], (list, tuple)) else (prev_super_state[i],)):
+                        t.record_stream(side)
+                    for t in (super_state if isinstance(super_state, (list, tuple)) else (super_state,)):
+                        t.record_stream(main)                               # consumed on the caller's stream after the join
+                    joins.append(side)
                 else:
-                    _, super_state = combs[i](x, prev_super_state[i])
+                    _, super_state = combs[i](x, prev_super_state[i])       # convlstm: h and c both from the shared state
                 state_comb = super_state
                 super_states.append(super_state)
             else:
@@ -98,6 +110,8 @@ class StateNetPhasedRecurrent(nn.Module):
                 super_states.append(x)
             states_lstm['encoders'].append(enc_state)
             states_lstm['state_comb'].append(state_comb)
+        for side in joins:
+            torch.cuda.current_stream().wait_stream(side)
         return super_states, states_lstm
 
     def forward_events(self, x, prev_super_state, prev_states_lstm, times=None):

@@ -288,6 +288,31 @@ def decode_stream(dev):
     return st
 
 
+# Inference, asynchronous RAM-Net: the state update of scale i depends on the encoder feature x_i and the state h_i only
+# (statenet.py:215-237 — x chains through the encoders, the states do not), so the three ConvGRU / ConvLSTM updates of one
+# measurement are independent of each other and of the next encoder.  With set_branch_overlap(True) every scale but the last runs
+# on a stream of its own (forked behind its encoder, joined at the end of the update): at batch 1 a launch fills a fraction of
+# the chip, and the critical path of an update shrinks from head + 3 encoders + 6 state launches to head + 3 encoders + 2.
+_BRANCH = {}
+_USE_BRANCH = _os.environ.get("RAMNET_BRANCH_STREAMS", "0") == "1"
+
+
+def set_branch_overlap(on):
+    global _USE_BRANCH
+    _USE_BRANCH = bool(on)
+
+
+def branch_overlap():
+    return _USE_BRANCH
+
+
+def branch_stream(dev, i):
+    st = _BRANCH.get((dev, i))
+    if st is None:
+        st = _BRANCH[(dev, i)] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _side_stream(dev):
     st = _SIDE.get(dev)
     if st is None:

@@ -14,7 +14,10 @@ import torch.distributed as dist
 
 
 class FlatGradReducer:
-    def __init__(self, model, process_group=None, num_buckets=3):
+    def __init__(self, model, process_group=None, num_buckets=3, always_collective=False):
+        """always_collective: issue the bucketed collectives even at world size 1 (an initialised process group is required) — the
+        RCCL path of a single-GPU box is then the very code an 8-GPU run executes."""
+        self.always_collective = bool(always_collective)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
         dev = self.params[0].device
@@ -61,7 +64,7 @@ class FlatGradReducer:
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():      # fresh .grad outside the flat buffer
                 v.copy_(p.grad)
                 p.grad = v
-        if w == 1:
+        if w == 1 and not (self.always_collective and dist.is_available() and dist.is_initialized()):
             return
         if self.cuda:
             ready = torch.cuda.current_stream().record_event()

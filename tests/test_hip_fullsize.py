@@ -304,3 +304,123 @@ def test_backward_recovers_after_an_aborted_pass():
     for k in clean:
         if not k.endswith("pred.conv2d.bias"):
             assert_close(after[k].cpu().numpy(), clean[k].cpu().numpy(), 1e-5, "after aborted pass: " + k, floor=1e-2 * gmax)
+
+
+def _report(tag, got, ref):
+    from util import elem_rel_err, rel_err
+    return "%s max-norm %.2e elem(floor 1e-2) %.2e elem(floor 1e-3) %.2e" % (tag, rel_err(got, ref), elem_rel_err(got, ref, 1e-2),
+                                                                          elem_rel_err(got, ref, 1e-3))
+
+
+def test_long_horizon_forward_full_resolution():
+    """48 consecutive Winograd-fp32 state updates at the real resolution (B=1, 256x344, K=5, L=8 packages
+    through ERGB2DepthRecurrent.forward, model/model.py:141-219) against the float64 oracle: every prediction of every package
+    and the three carried states, max-norm AND element-wise relative error <= 1e-3 (north star bar)."""
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=5)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(21)
+    K, L = 5, 8
+    prev, lstm = None, ramnet_ref.empty_states_lstm(K)
+    rprev, rlstm = None, ramnet_ref.empty_states_lstm(K)
+    lines = []
+    with torch.no_grad():
+        for l in range(L):
+            item = make_item(rng, 1, H, W, K, 5, 1)
+            preds, supers, lstm = model(item, prev, lstm)
+            rpreds, rsupers, rlstm = ramnet_ref.forward_recurrent(sd, cfg, {k: v.double() for k, v in item.items()}, rprev, rlstm)
+            prev, rprev = supers["image"], rsupers["image"]
+            for k in rpreds:
+                assert_close(preds[k].cpu().numpy(), rpreds[k].numpy(), 1e-3, "package %d pred %s" % (l, k), elem_tol=1e-3)
+            for i, (s, r) in enumerate(zip(prev, rprev)):
+                assert_close(s.cpu().numpy(), r.numpy(), 1e-3, "package %d state %d" % (l, i), elem_tol=1e-3)
+            lines.append(_report("package %d image" % l, preds["image"].cpu().numpy(), rpreds["image"].numpy()) + " | " +
+                         _report("state2", prev[2].cpu().numpy(), rprev[2].numpy()))
+    print("\n".join(lines))
+
+
+def test_streaming_200_updates_full_resolution():
+    """configs[3]: batch-1 asynchronous streaming with a persistent state, 200 updates at 256x344 on an irregular schedule
+    (1..8 event grids per frame, test.py:212-232 call pattern through update_events / update_image / decode), against the
+    float64 oracle: predictions at checkpoints along the stream and the final states, max-norm and element-wise <= 1e-3."""
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+    ncfg = ramnet_ref.normalize_config(cfg)
+    rng = np.random.default_rng(33)
+    states = model.init_states(1, H, W)
+    ref_states = [torch.zeros(1, 64 * 2 ** i, H >> (i + 1), W >> (i + 1), dtype=torch.float64) for i in range(3)]
+    n, lines = 0, []
+
+    def check(tag):
+        got = model.decode(states).cpu().numpy()
+        ref = ramnet_ref._decode(sd, ncfg, ref_states).numpy()
+        assert_close(got, ref, 1e-3, tag, elem_tol=1e-3)
+        lines.append(_report(tag, got, ref))
+
+    with torch.no_grad():
+        while n < 200:
+            for _ in range(int(rng.integers(1, 9))):
+                ev = torch.from_numpy(rng.standard_normal((1, 5, H, W)).astype(np.float32))
+                states, _ = model.update_events(ev, states)
+                ref_states, _ = ramnet_ref._encode(sd, ncfg, "events", ev.double(), ref_states, None)
+                n += 1
+            img = torch.from_numpy(rng.random((1, 1, H, W)).astype(np.float32))
+            states, _ = model.update_image(img, states)
+            ref_states, _ = ramnet_ref._encode(sd, ncfg, "rgb", img.double(), ref_states, None)
+            n += 1
+            if n % 40 < 9:
+                check("after %d updates" % n)
+        check("after %d updates (end)" % n)
+    for i, (s, r) in enumerate(zip(states, ref_states)):
+        assert_close(s.permute(0, 3, 1, 2).cpu().numpy(), r.numpy(), 1e-3, "final state %d" % i, elem_tol=1e-3)
+        lines.append(_report("final state %d" % i, s.permute(0, 3, 1, 2).cpu().numpy(), r.numpy()))
+    print("\n".join(lines))
+
+
+def test_bench_shape_training_step_properties(bench_schedule):
+    """ONE training step at the bench shape (B=8, L=8, K=5, 256x344) on the bench schedule.  The oracle is
+    bounded to the first two packages (forward is causal, so their SI-loss terms at L=8 equal those of an L=2 run): those
+    terms vs the fp32 oracle, then the whole step as properties — finite loss, every parameter receives a finite non-zero
+    gradient, and a second run of the same step reproduces loss (bit-exact forward) and gradients (atomic order only)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=5, loss_composition=["image", "events4"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(12)
+    L = 8
+    seq = [make_item(rng, B, H, W, 5, 5, 1, True, 0.0) for _ in range(L)]
+    dseq = [{k: v.to(model.gpu) for k, v in it.items()} for it in seq]
+
+    def run():
+        model.zero_grad()
+        total, reported = sequence_loss(model, dseq, cfg["loss_composition"], [1, 1])
+        total.backward()
+        torch.cuda.synchronize()
+        return float(total.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    loss1, g1 = run()
+    loss2, g2 = run()
+    assert np.isfinite(loss1) and abs(loss1 - loss2) <= 1e-6 * abs(loss1), "forward is bit-reproducible (the loss sums by atomics)"
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    for k, v in g1.items():
+        assert bool(torch.isfinite(v).all()), k
+        assert float(v.abs().max()) > 0, k
+        assert_close(g2[k].cpu().numpy(), v.cpu().numpy(), 1e-4, "second run: " + k, floor=1e-2 * gmax)
+    # the first two packages against the oracle (fp32, no_grad: seconds on the host cores)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    terms_ref, terms_hip = [], []
+    with torch.no_grad():
+        prev, lstm = None, ramnet_ref.empty_states_lstm(5)
+        rprev, rlstm = None, ramnet_ref.empty_states_lstm(5)
+        for l in range(2):
+            preds, supers, lstm = model(dseq[l], prev, lstm)
+            rpreds, rsupers, rlstm = ramnet_ref.forward_recurrent(sd, cfg, seq[l], rprev, rlstm)
+            prev, rprev = supers["image"], rsupers["image"]
+            for key in cfg["loss_composition"]:
+                assert_close(preds[key].cpu().numpy(), rpreds[key].numpy(), 1e-3, "package %d pred %s" % (l, key), elem_tol=1e-3)
+                terms_hip.append(float(ops.scale_invariant_loss(preds[key], dseq[l]["depth_" + key])))
+                d = rpreds[key].double() - seq[l]["depth_" + key].double()
+                terms_ref.append(float((d ** 2).mean() - d.mean() ** 2))
+    np.testing.assert_allclose(terms_hip, terms_ref, rtol=1e-4)
+    print("B=8 L=8 step: loss %.6f; first four SI terms hip %s ref %s" % (loss1, terms_hip, terms_ref))

@@ -18,12 +18,31 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def assert_close(a, b, tol, what="", floor=0.0):
-    """floor: absolute scale below which a reference magnitude is treated as cancellation noise (e.g. the SI-loss
+ELEM_FLOOR = 1e-2     # element-wise relative error: a reference entry counts with at least this fraction of the tensor maximum
+
+
+def elem_rel_err(a, b, floor_frac=ELEM_FLOOR):
+    """ELEMENT-WISE relative error max_i |a_i - b_i| / max(|b_i|, floor_frac * max|b|): every entry is judged against its own
+    magnitude; entries below floor_frac of the tensor maximum are judged against that floor (an fp32 evaluation carries an
+    absolute rounding error of ~1e-7..1e-6 of the tensor scale, so entries near zero have no relative accuracy in ANY fp32
+    implementation, the reference's included)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(b), max(floor_frac * float(np.abs(b).max()), 1e-30))
+    return float((np.abs(a - b) / den).max())
+
+
+def assert_close(a, b, tol, what="", floor=0.0, elem_tol=None, elem_floor=ELEM_FLOOR):
+    """Max-norm relative error max|a-b| / max|b| <= tol, and — when elem_tol is given — the element-wise relative error of
+    elem_rel_err() <= elem_tol as a second assertion (the forward goldens and the long-horizon runs use both).
+    floor: absolute scale below which a reference magnitude is treated as cancellation noise (e.g. the SI-loss
     gradient of a bias is a sum that cancels to ~0); pass a fraction of the largest gradient in the model."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     e = float(np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-30))
     assert e <= tol, "%s: rel err %.3e > %.1e (max|ref| %.3e)" % (what, e, tol, float(np.abs(np.asarray(b)).max()))
+    if elem_tol is not None:
+        ee = elem_rel_err(a, b, elem_floor)
+        assert ee <= elem_tol, "%s: element-wise rel err %.3e > %.1e (floor %.0e of max|ref| %.3e)" % (
+            what, ee, elem_tol, elem_floor, float(np.abs(b).max()))
 
 
 def nhwc(t):
