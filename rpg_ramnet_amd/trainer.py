@@ -47,3 +47,66 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
     if grad_loss_weight is not None:
         total = total + grad_loss_weight * torch.stack(gterms).sum() / float(L)
     return total, total.detach() * len(keys_seen)
+
+
+class EpochTrainer:
+    """Epoch-level half of the reference trainer (RAM_Net/base/base_trainer.py:16-61 constructor, :65-123 `train`, :133-158
+    `_save_checkpoint`, :160-179 `_resume_checkpoint`) around a user-supplied epoch function — NOT the control plane: no
+    TensorBoard, no previews, no metric plumbing.
+
+    config keys used exactly as the reference reads them: 'name', 'optimizer_type' + 'optimizer', 'lr_scheduler_type' +
+    'lr_scheduler' + 'lr_scheduler_freq', config['trainer']: 'epochs', 'save_freq', 'save_dir', 'monitor', 'monitor_mode'.
+    ``train_epoch(epoch) -> dict`` returns the epoch's log entries (at least 'loss' and the monitored key).  Order of events per
+    epoch, as in base_trainer.py:103-122: log entry -> best-checkpoint (saved under the epoch name, then renamed to
+    'model_best.pth.tar') -> periodic checkpoint when epoch % save_freq == 0 -> scheduler step when epoch % lr_scheduler_freq == 0.
+    Checkpoints have the reference's dict layout (checkpoint.save_checkpoint)."""
+
+    def __init__(self, model, config, train_epoch, resume=None, train_logger=None, reducer=None):
+        import math
+        import os
+        from . import checkpoint as ck
+        self.model, self.config, self.train_epoch, self.reducer = model, config, train_epoch, reducer
+        self.epochs = config['trainer']['epochs']
+        self.save_freq = config['trainer']['save_freq']
+        self.optimizer = getattr(torch.optim, config['optimizer_type'])(model.parameters(), **config['optimizer'])
+        sched = getattr(torch.optim.lr_scheduler, config.get('lr_scheduler_type', ''), None)
+        self.lr_scheduler = sched(self.optimizer, **config['lr_scheduler']) if sched else None
+        self.lr_scheduler_freq = config.get('lr_scheduler_freq', 1)
+        self.monitor, self.monitor_mode = config['trainer']['monitor'], config['trainer']['monitor_mode']
+        assert self.monitor_mode in ('min', 'max')
+        self.monitor_best = math.inf if self.monitor_mode == 'min' else -math.inf
+        self.start_epoch = 1
+        self.checkpoint_dir = os.path.join(config['trainer']['save_dir'], config['name'])
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        self.train_logger = train_logger if train_logger is not None else ck.Logger()
+        self.lr_history = []
+        if resume:
+            self.start_epoch, c = ck.resume(resume, model, self.optimizer, map_location='cpu')
+            self.monitor_best = c['monitor_best']
+            self.train_logger = c['logger']
+
+    def _save(self, epoch, log, save_best=False):
+        import os
+        from . import checkpoint as ck
+        path = ck.save_checkpoint(ck.checkpoint_name(self.checkpoint_dir, epoch, log['loss']), self.model, self.optimizer, epoch,
+                                  self.config, self.monitor_best, self.train_logger)
+        if save_best:
+            os.rename(path, os.path.join(self.checkpoint_dir, 'model_best.pth.tar'))
+        return path
+
+    def train(self):
+        for epoch in range(self.start_epoch, self.epochs + 1):
+            result = self.train_epoch(epoch)
+            log = {'epoch': epoch}
+            log.update({k: v for k, v in result.items() if 'previews' not in k})
+            self.train_logger.add_entry(log)
+            if (self.monitor_mode == 'min' and log[self.monitor] < self.monitor_best) or \
+                    (self.monitor_mode == 'max' and log[self.monitor] > self.monitor_best):
+                self.monitor_best = log[self.monitor]
+                self._save(epoch, log, save_best=True)
+            if epoch % self.save_freq == 0:
+                self._save(epoch, log)
+            if self.lr_scheduler and epoch % self.lr_scheduler_freq == 0:
+                self.lr_scheduler.step()
+            self.lr_history.append(self.lr_scheduler.get_last_lr()[0] if self.lr_scheduler else self.optimizer.param_groups[0]['lr'])
+        return self.train_logger

@@ -456,3 +456,45 @@ def test_winograd_f2x2_4x4_algebra_cpu():
     for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 23, 31), (2, 7, 13, 17)]:
         idx = ((((cls * 3 + k // 8) * 1 + n // 32) * 25 + pos) * 2 + (n % 32) // 16) * 128 + (((k % 8) // 2) * 16 + n % 16) * 2 + k % 2
         assert packed[idx] == U3[cls, pos, k, n]
+
+
+def test_epoch_trainer_matches_the_reference_base_trainer_fixture(tmp_path):
+    """SURVEY 8f-2, epoch level: rpg_ramnet_amd.trainer.EpochTrainer against tests/golden/trainer.json, which was produced by
+    RUNNING the reference's BaseTrainer (base_trainer.py:36-43, 65-123, 133-158) with the same scripted epoch function
+    (tests/golden/make_golden_trainer.py): learning-rate sequence (ExponentialLR stepped every lr_scheduler_freq epochs),
+    monitor_best sequence, the checkpoint files left behind (periodic + model_best) and the checkpoint dict."""
+    import json
+    import os
+    from rpg_ramnet_amd import checkpoint as ck
+    from rpg_ramnet_amd.trainer import EpochTrainer
+    z = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer.json")))
+    cfg = json.loads(json.dumps(z["config"]))
+    cfg["trainer"]["save_dir"] = str(tmp_path)
+    torch.manual_seed(0)
+    net = torch.nn.Conv2d(1, 2, 3)
+    lrs, mbs = [], []
+
+    def epoch_fn(epoch):
+        lrs.append(t.optimizer.param_groups[0]["lr"])
+        mbs.append(t.monitor_best)
+        loss = z["losses"][epoch - 1]
+        return {"loss": loss, "val_loss": loss + 0.1 * (-1) ** epoch}
+
+    t = EpochTrainer(net, cfg, epoch_fn)
+    t.train()
+    np.testing.assert_allclose(lrs, z["lr_at_epoch_start"], rtol=1e-12)
+    assert t.optimizer.param_groups[0]["lr"] == pytest.approx(z["lr_after_last_epoch"], rel=1e-12)
+    assert [m if m != float("inf") else "inf" for m in mbs] == z["monitor_best_at_epoch_start"]
+    assert t.monitor_best == z["monitor_best_final"]
+    d = os.path.join(str(tmp_path), cfg["name"])
+    assert sorted(f for f in os.listdir(d) if f.endswith(".pth.tar")) == z["files"]
+    c = ck.load_checkpoint(os.path.join(d, "model_best.pth.tar"))
+    assert sorted(c.keys()) == z["checkpoint_keys"]
+    assert c["epoch"] == z["best"]["epoch"] and c["monitor_best"] == z["best"]["monitor_best"] and c["arch"] == z["best"]["arch"]
+    assert len(c["logger"].entries) == z["best"]["logger_entries"] and sorted(c["optimizer"].keys()) == z["best"]["optimizer_keys"]
+    # resume (base_trainer.py:160-179): continues at epoch + 1 with the stored monitor_best and optimizer state
+    cfg["trainer"]["epochs"] = 8
+    t2 = EpochTrainer(torch.nn.Conv2d(1, 2, 3), cfg, lambda e: {"loss": 1.0, "val_loss": 1.0}, resume=os.path.join(d, "model_best.pth.tar"))
+    assert t2.start_epoch == 8 and t2.monitor_best == z["monitor_best_final"]
+    t2.train()
+    assert len(t2.train_logger.entries) == 8

@@ -87,3 +87,26 @@ def test_loader_edge_cases(tree):
     t = D.SynchronizedFramesEventsDataset(base, clip_distance=1000.0, every_x_rgb_frame=1, **FOLDERS).__getitem__(2, seed=1)
     d = t["depth_image"]
     assert d.shape[0] == 1 and float(d[~torch.isnan(d)].min()) >= 0.0 and float(d[~torch.isnan(d)].max()) <= 1.0 and bool(torch.isnan(d).any())
+
+
+def test_sharded_sequence_sampler_partitions_the_index_list():
+    """SURVEY 8e partitioning on the real loader: ranks get disjoint sequences r, r + world, ... of one shared shuffled order,
+    the same count on every rank, a different order per epoch."""
+    from rpg_ramnet_amd.data import ShardedSequenceSampler
+    ds = list(range(37))
+    world = 4
+    per_epoch = []
+    for epoch in (0, 1):
+        got = []
+        for r in range(world):
+            sm = ShardedSequenceSampler(ds, r, world, batch_size=2)
+            sm.set_epoch(epoch)
+            idx = list(sm)
+            assert len(idx) == len(sm) == 8                      # 37 // (4 * 2) batches of 2
+            got.append(idx)
+        flat = [i for g in got for i in g]
+        assert len(set(flat)) == len(flat) and set(flat) <= set(ds)
+        per_epoch.append(got)
+    assert per_epoch[0] != per_epoch[1]
+    plain = [list(ShardedSequenceSampler(ds, r, world, shuffle=False)) for r in range(world)]
+    assert plain[1][:3] == [1, 5, 9] and all(len(p) == 9 for p in plain)
