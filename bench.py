@@ -339,7 +339,7 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
     event grids (1..8) before each frame, hipGraph replays with the decode of update k pipelined behind update k+1
     (graph.GraphedStream).  Returns ms per update+decode and the MFMA roofline of the whole chain: FLOP counted by the launch
     hooks over ONE eager pass of the same schedule (every launch of the chain), divided by the replayed wall time."""
-    from rpg_ramnet_amd.graph import GraphedStream
+    from rpg_ramnet_amd.graph import GraphedStream, StreamPipeline, TimeBatchedStream
     was_training = model.training
     model.eval()
     rs = np.random.default_rng(7)
@@ -365,32 +365,52 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
     agg = timer.summary()
     timer.on, timer.only, timer.hbm, timer.rec = on0, only0, hbm0, rec0
     alg, ex, nl = sum(v[2] for v in agg.values()), sum(v[3] for v in agg.values()), sum(v[0] for v in agg.values())
-    gs = GraphedStream(model, 1, H, W, pipelined=True)
+    def runner(g):
+        def run():
+            for l, item in enumerate(items):
+                for k in range(sched[l]):
+                    pred = g.update_events(item["events%d" % (k % K)])
+                pred = g.update_image(item["image"])
+            return g.wait(pred)
+        return run
 
-    def run():
+    def clock(fn):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+
+    tb = TimeBatchedStream(model, 1, H, W, max_events=8)
+
+    def run_tb():
         for l, item in enumerate(items):
             for k in range(sched[l]):
-                pred = gs.update_events(item["events%d" % (k % K)])
-            pred = gs.update_image(item["image"])
-        return gs.wait(pred)
+                tb.push_events(item["events%d" % (k % K)])
+            pred = tb.push_image(item["image"])
+        return tb.wait(pred)
 
-    run()
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(reps):
-        run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / reps
-    t = time.perf_counter()
-    for _ in range(reps):
-        eager()
-    torch.cuda.synchronize()
-    dte = (time.perf_counter() - t) / reps
+    run_tb()                                            # first pass records the graphs of every group shape of the schedule
+    dt = clock(run_tb)
+    dt3 = clock(runner(StreamPipeline(model, 1, H, W)))
+    dt2 = clock(runner(GraphedStream(model, 1, H, W, pipelined=True)))
+    dt1 = clock(runner(GraphedStream(model, 1, H, W, pipelined=False)))
+    dte = clock(eager)
     model.train(was_training)
     out = {"workload": "configs[3]: batch 1, %dx%d, persistent ConvGRU state, %d event grids + %d frames per pass (grids per frame %s), "
                        "update + decode per measurement" % (H, W, sum(sched), frames, sched),
-           "ms_per_update_and_decode": 1e3 * dt / n_upd, "updates_per_s": n_upd / dt, "eager_ms_per_update_and_decode": 1e3 * dte / n_upd,
-           "mfma_launches_per_update": nl / float(n_upd)}
+           "ms_per_update_and_decode": 1e3 * dt / n_upd, "updates_per_s": n_upd / dt, "runtime": "graph.TimeBatchedStream: the event grids "
+           "up to the next frame form a group — encoders at batch n and decoders at batch n+1 in one launch chain each (they do not depend "
+           "on the order of the updates), state updates one by one per scale; groups pipelined (hipGraph replays, four streams)",
+           "latency_ms_update_then_decode": 1e3 * dt1 / n_upd, "two_stage_ms_per_update_and_decode": 1e3 * dt2 / n_upd,
+           "three_stage_ms_per_update_and_decode": 1e3 * dt3 / n_upd,
+           "eager_ms_per_update_and_decode": 1e3 * dte / n_upd, "mfma_launches_per_update": nl / float(n_upd),
+           "note": "ms_per_update_and_decode = period of the pipelined stream (throughput over a recorded stream, test.py:205-232); "
+                   "latency_ms_update_then_decode = one update followed by its decode as serial graph replays (what a live sensor sees); "
+                   "two_stage = decode of update k beside update k+1 (graph.GraphedStream, the round-2 runtime); three_stage = "
+                   "graph.StreamPipeline (encoders k+1 | updates k | decodes k-1, k-2 per measurement)"}
     if ex > 0:
         out["roofline"] = {"bound": "mfma", "kernel": "whole update+decode chain (%d MFMA launches per update)" % round(nl / float(n_upd)),
                            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -545,9 +565,12 @@ def main():
             stream_state["s"] = st
             return pred.mean()
 
-        from rpg_ramnet_amd.graph import GraphedStream
-        # hipGraph replays; the decode of update k runs on a second stream, concurrent with update k+1 (graph.GraphedStream)
-        gs = GraphedStream(model, B, H, W, pipelined=True)
+        from rpg_ramnet_amd.graph import GraphedStream, StreamPipeline, TimeBatchedStream
+        # hipGraph replays, time-batched groups (graph.TimeBatchedStream); the per-measurement runtimes (three-stage pipeline:
+        # StreamPipeline; decode of update k beside update k+1: GraphedStream pipelined; strictly serial replays) are extras
+        tb = TimeBatchedStream(model, B, H, W, max_events=8)
+        gs_three = StreamPipeline(model, B, H, W)
+        gs_two = GraphedStream(model, B, H, W, pipelined=True)
         gs_serial = GraphedStream(model, B, H, W, pipelined=False)
 
         def run_stream(g):
@@ -558,9 +581,15 @@ def main():
             return g.wait(pred).mean()
 
         def step():
-            return run_stream(gs)
+            for l, item in enumerate(seq):
+                for k in range(sched[l]):
+                    tb.push_events(item["events%d" % (k % K)])
+                pred = tb.push_image(item["image"])
+            return tb.wait(pred).mean()
         graphed["eager"] = eager_step
         graphed["graph_serial"] = lambda: run_stream(gs_serial)
+        graphed["graph_two_stage"] = lambda: run_stream(gs_two)
+        graphed["graph_three_stage"] = lambda: run_stream(gs_three)
     else:
         model.eval()
 
@@ -592,7 +621,9 @@ def main():
     # dominant symbol); in the timed region only the dominant symbol's launches are bracketed: ~7000 event pairs per step cost
     # 3-4 % of the step, ~1000 cost < 0.5 %.
     last = None
-    timer.on = timer.hbm = not args.no_kernel_timing
+    # (stream / infer: the steps replay hipGraphs — and record them on first use —, where HIP events cannot be bracketed; their
+    # FLOP accounting comes from one eager pass below)
+    timer.on = timer.hbm = not args.no_kernel_timing and args.mode == "train"
     for _ in range(args.warmup):
         last = step()
     fence()
@@ -666,6 +697,12 @@ def main():
             if "graph_serial" in graphed:
                 extras["graph_update_then_decode"] = dict(measure(graphed["graph_serial"]), note="hipGraph replays with the decode of "
                                                           "update k BEFORE update k+1 on one stream (the timed region overlaps them)")
+            if "graph_three_stage" in graphed:
+                extras["graph_three_stage"] = dict(measure(graphed["graph_three_stage"]), note="graph.StreamPipeline: encoders k+1 | updates k | "
+                                                   "decodes k-1, k-2, one measurement at a time")
+            if "graph_two_stage" in graphed:
+                extras["graph_two_stage"] = dict(measure(graphed["graph_two_stage"]), note="decode of update k on a second stream beside "
+                                                 "update k+1 (graph.GraphedStream pipelined, the round-2 runtime)")
         elif args.mode == "train" and not args.graph:
             try:
                 extras["with_input_side"] = input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank)

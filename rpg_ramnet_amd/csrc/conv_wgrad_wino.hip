@@ -374,9 +374,12 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
     if (tall_env) tall = tall_env[0] == '1';
     if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
-    // 128 output channels per workgroup (one workgroup per CU) where the layer has them; RAMNET_WGRAD_NF=2 keeps the 64-channel form
+    // RAMNET_WGRAD_NF=4: 128 output channels per workgroup (one workgroup per CU, 512 registers per lane) where the layer has them.
+    // Isolated it is the faster form (six ConvGRU launches 1.522 -> 1.434 ms: 7.25 instead of 11 instructions per MFMA), in the
+    // co-scheduled training step it loses (200.2 -> 190.5 samples/s: a CU that holds such a workgroup holds nothing else, so the
+    // backward-data chain of the other stream no longer fills the gaps) — profiles/r03_h_tuning_notes.md.  Default: 64 channels.
     static const char *nfe = getenv("RAMNET_WGRAD_NF");
-    const int nf = (d.Cout % 128 == 0 && !(nfe && nfe[0] == '2')) ? 4 : 2;
+    const int nf = (d.Cout % 128 == 0 && nfe && nfe[0] == '4') ? 4 : 2;
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
     // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");

@@ -136,7 +136,10 @@ template <int TX> struct RGeom {
 };
 
 // SP = WinoParams.sparse as a compile-time constant: the dense kernel (SP = 0) carries no trace of the position masks
-template <int TX, int SP, int MODE>
+// NF = 32-channel output blocks per workgroup: 2 (64 channels), or 1 for launches that would otherwise put fewer than one
+// workgroup on a CU (batch-1 streaming on the coarse maps: 44-88 workgroups of 32-64 chunks each): twice the workgroups, half the
+// MFMAs per chunk and wave — the same transform work per workgroup, but the launch is latency-bound there, not pipe-bound.
+template <int TX, int SP, int MODE, int NF = 2>
 __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_desc p, const WinoParams q) {
     using G = RGeom<TX>;
     constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
@@ -154,15 +157,16 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     // of XCDs: an XCD then streams only its group's slice of the weights (which stays resident) at the price of the patch being
     // fetched once per group.  xg = 0: every XCD runs all channel blocks of its tiles.
     const int xslot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const int nbl = q.nblk >> q.xg;                                  // channel blocks per group
-    const int nblk_i = ((xslot % nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
+    const int nbl = (q.nblk * (2 / NF)) >> q.xg;                     // (virtual, NF = 1: 32-channel) blocks per group
+    const int nblk_v = ((xslot % nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
+    const int nblk_i = NF == 1 ? nblk_v >> 1 : nblk_v, fh = NF == 1 ? nblk_v & 1 : 0;     // 64-channel block, half of it
     int bid = (xslot / nbl) * (8 >> q.xg) + (xcd >> q.xg);
     if (bid >= q.tiles_x * q.tiles_y * p.B) return;
     const int tx_i = bid % q.tiles_x;
     bid /= q.tiles_x;
     const int ty_i = bid % q.tiles_y;
     const int b = bid / q.tiles_y;
-    const int n0 = nblk_i * WBN;
+    const int n0 = nblk_i * WBN + fh * 32;
     const int oy0 = ty_i * G::TH, ox0 = tx_i * G::TW;
     const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
 
@@ -174,14 +178,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     const int pra = hq * RP_PLANE + ((2 * tty + ra) * RPW + 2 * ttx) * 4;
     const int prb = hq * RP_PLANE + ((2 * tty + rb) * RPW + 2 * ttx) * 4;
     // weights: [chunk][block64][wave 4][position-in-row 4][n-block 2][lane 64][channel j 4]
-    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + wave * 2048 + lane * 4;
+    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + wave * 2048 + fh * 256 + lane * 4;
     const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NF];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
@@ -189,14 +193,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     const int clast = (nch - 1) * WK;
     WinoPatch<MODE> pr;
     pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid, clast, 2 * RP_FLOATS);
-    float4 breg[4][2];
+    float4 breg[4][NF];
     float4 tcur[4], tnext[4], ta, tb;
     auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
     auto f4sub = [](float4 x, float4 y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
 
     pr.load(q.src, 0, clast);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) breg[i >> 1][i & 1] = ld4(wsrc + i * 256);
+    for (int i = 0; i < 8; ++i)
+        if (NF == 2 || !(i & 1)) breg[i >> 1][NF == 2 ? i & 1 : 0] = ld4(wsrc + i * 256);
     pr.store(patch, q.src, 0);
     pr.load(q.src, min(WK, clast), clast);
     __syncthreads();
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     unsigned runm = 0xffu;
     if (SP == 2) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NF; ++f) {
             const int g = (n0 + f * 32) >> q.s2d_shift;
             if ((g & 2) && wave == 0) runm &= ~(0x55u << f);
             if (g & 1) runm &= ~(1u << f);
@@ -241,20 +246,25 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             const float4 v = pl == 0 ? f4sub(tc[0], tc[2]) : pl == 1 ? f4add(tc[1], tc[2]) : pl == 2 ? f4sub(tc[2], tc[1]) : f4sub(tc[1], tc[3]);
             const float va[4] = {v.x, v.y, v.z, v.w};
             const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
-            const float b1[4] = {breg[pl][1].x, breg[pl][1].y, breg[pl][1].z, breg[pl][1].w};
+            const float b1[4] = {breg[pl][NF - 1].x, breg[pl][NF - 1].y, breg[pl][NF - 1].z, breg[pl][NF - 1].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (SP == 0 || ((runm >> (pl * 2)) & 1u)) acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                side(pl * 8 + j * 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (SP == 0 || ((runm >> (pl * 2 + 1)) & 1u)) acc[pl][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                side(pl * 8 + j * 2 + 1);
+                if (NF == 2) {
+                    side(pl * 8 + j * 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (SP == 0 || ((runm >> (pl * 2 + 1)) & 1u)) acc[pl][NF - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][NF - 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    side(pl * 8 + j * 2 + 1);
+                } else {
+                    side(pl * 4 + j);             // 16 gaps per chunk for the same 12 slices
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            breg[pl][0] = ld4(wnext + (pl * 2) * 256), breg[pl][1] = ld4(wnext + (pl * 2 + 1) * 256);
+            breg[pl][0] = ld4(wnext + (pl * 2) * 256);
+            if (NF == 2) breg[pl][NF - 1] = ld4(wnext + (pl * 2 + 1) * 256);
         }
         __syncthreads();                           // patch(i+2) visible; patch(i+1) free
     };
@@ -267,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     // D of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile)
     float *P = smem;
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r];
@@ -289,7 +299,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         return make_float4(t0.x + t1.x + t2.x, t0.y + t1.y + t2.y, t0.z + t1.z + t2.z, t0.w + t1.w + t2.w);
     };
     const int epi = p.epi;
-    if (q.vec4 && epi == RAMNET_EPI_LSTM) {
+    if (NF == 2 && q.vec4 && epi == RAMNET_EPI_LSTM) {
         // ConvLSTM cell (submodules.py:346-358): the block's 64 columns are 16 hidden channels x gates (i, f, o, g)
         const int C = p.Cout;
 #pragma unroll
@@ -316,8 +326,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int sl = tid + i * 256, pxl = sl >> 4, qd = sl & 15;
+    for (int i = 0; i < 4 * NF; ++i) {
+        const int sl = tid + i * 256, pxl = NF == 2 ? sl >> 4 : sl >> 3, qd = NF == 2 ? sl & 15 : sl & 7;
         const int oy = oy0 + pxl / RTW, ox = ox0 + pxl % RTW, nq = n0 + qd * 4;
         if (oy >= p.Ho || ox >= p.Wo || nq >= p.Cout) continue;
         const float4 y = out4(pxl, qd * 4);
@@ -439,7 +449,15 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.xg = q.xg < 0 ? 0 : q.xg > 3 ? 3 : q.xg;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
-    dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));
+    // fewer workgroups than CUs (batch-1 streaming, coarse maps): 32-channel workgroups, twice as many (forward input modes only)
+    static const char *nfe = getenv("RAMNET_WINO_NF");              // tuning knob: 2 keeps 64-channel workgroups everywhere
+    const bool fwd_mode = d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_S2D;
+    const int nf = (q.tiles_x * q.tiles_y * d.B * q.nblk < 256 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && fwd_mode && d.Cout % 64 == 0 &&
+                    !(nfe && nfe[0] == '2')) ? 1 : 2;
+    // such a launch is bound by the latency of its chunk chain, not by the MFMA pipe: skipping the MFMAs of the zero slices buys
+    // nothing there, the wave-uniform tests around them cost (enc2 at batch 1: 1.7 instead of 0.9 us per chunk) -> dense
+    if (nf == 1 && q.sparse == 1) q.sparse = 0;
+    dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
     const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
     // one instantiation per (tile shape, sparse mode, input mode) that occurs: the kernel body has no run-time mode branches
     {
@@ -448,17 +466,25 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
         ldmax = ldmax > d.ldm ? ldmax : d.ldm;
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
     }
-    const int key = (tall ? 0 : 1000) + q.sparse * 100 + d.in_mode;
-    note_kernel("conv_wino_r_kernel<%d,%d,%d>", tall ? 2 : 8, q.sparse, d.in_mode);
+    const int key = (tall ? 0 : 1000) + q.sparse * 100 + d.in_mode + (nf == 1 ? 10000 : 0);
+    if (nf == 1) note_kernel("conv_wino_r_kernel<%d,%d,%d,1>", tall ? 2 : 8, q.sparse, d.in_mode);
+    else note_kernel("conv_wino_r_kernel<%d,%d,%d>", tall ? 2 : 8, q.sparse, d.in_mode);
 #define RAMNET_GO(TXv, SPv, MDv)                                                                        \
     case ((TXv) == 2 ? 0 : 1000) + (SPv) * 100 + (MDv):                                                 \
         RAMNET_FULL_LDS((conv_wino_r_kernel<TXv, SPv, MDv>));                                           \
         hipLaunchKernelGGL((conv_wino_r_kernel<TXv, SPv, MDv>), grid, dim3(256), lds, st, d, q);        \
         break;
+#define RAMNET_GO1(TXv, SPv, MDv)                                                                       \
+    case 10000 + ((TXv) == 2 ? 0 : 1000) + (SPv) * 100 + (MDv):                                         \
+        RAMNET_FULL_LDS((conv_wino_r_kernel<TXv, SPv, MDv, 1>));                                        \
+        hipLaunchKernelGGL((conv_wino_r_kernel<TXv, SPv, MDv, 1>), grid, dim3(256), lds, st, d, q);     \
+        break;
 #define RAMNET_GO_TX(TXv)                                                                               \
     RAMNET_GO(TXv, 0, RAMNET_IN_PLAIN) RAMNET_GO(TXv, 0, RAMNET_IN_CAT) RAMNET_GO(TXv, 0, RAMNET_IN_CAT_MUL)        \
     RAMNET_GO(TXv, 0, RAMNET_IN_RELUMASK) RAMNET_GO(TXv, 0, RAMNET_IN_S2D) RAMNET_GO(TXv, 1, RAMNET_IN_S2D)         \
-    RAMNET_GO(TXv, 2, RAMNET_IN_PLAIN) RAMNET_GO(TXv, 2, RAMNET_IN_RELUMASK)
+    RAMNET_GO(TXv, 2, RAMNET_IN_PLAIN) RAMNET_GO(TXv, 2, RAMNET_IN_RELUMASK)                                        \
+    RAMNET_GO1(TXv, 0, RAMNET_IN_PLAIN) RAMNET_GO1(TXv, 0, RAMNET_IN_CAT) RAMNET_GO1(TXv, 0, RAMNET_IN_CAT_MUL)     \
+    RAMNET_GO1(TXv, 0, RAMNET_IN_S2D) RAMNET_GO1(TXv, 1, RAMNET_IN_S2D)
     switch (key) {
         RAMNET_GO_TX(2)
         RAMNET_GO_TX(8)
@@ -466,6 +492,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
         RAMNET_CHECK_ARG(!"conv_wino_r: unsupported (sparse, input mode) combination");
     }
 #undef RAMNET_GO_TX
+#undef RAMNET_GO1
 #undef RAMNET_GO
     RAMNET_LAUNCH_CHECK();
     return 0;

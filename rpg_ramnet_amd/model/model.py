@@ -53,6 +53,16 @@ def _to_nhwc(s):
     return s.permute(0, 2, 3, 1)
 
 
+def _state_nhwc(s, C):
+    """One scale of a multi-scale state for the primitive API: an NHWC buffer (init_states / a previous update) is taken as it
+    is, an NCHW-shaped view (what forward() returns) is viewed back; ConvLSTM (h, c) pairs element by element."""
+    if isinstance(s, (list, tuple)):
+        return type(s)(_state_nhwc(t, C) for t in s)
+    if torch.is_tensor(s) and s.dim() == 4 and s.shape[-1] == C and s.is_contiguous():
+        return s
+    return _to_nhwc(s)
+
+
 class BaseERGB2Depth(BaseModel):
     def __init__(self, config):
         super().__init__(config)
@@ -117,14 +127,12 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         NCHW-shaped views forward() returns).  Returns (new_states, lstm_state); nothing is modified in place.
         Equivalent to one iteration of the k-loop of model.py:176-195 without the decode."""
         assert not bool(self.baseline), "baselines have no event branch (model.py:181-185)"
-        st = [s if (torch.is_tensor(s) and s.shape[-1] == self.base_num_channels * 2 ** (i + 1) and s.dim() == 4 and
-                    s.is_contiguous()) else _to_nhwc(s) for i, s in enumerate(states)]
+        st = [_state_nhwc(s, self.base_num_channels * 2 ** (i + 1)) for i, s in enumerate(states)]
         return self.statenetphasedrecurrent.forward_events(ops.pack_input(events, self.gpu), st, lstm_state)
 
     def update_image(self, image, states, lstm_state=None):
         """Fold ONE frame [B,Cr,H,W] into the shared state (model.py:196-213 without the decode)."""
-        st = [s if (torch.is_tensor(s) and s.shape[-1] == self.base_num_channels * 2 ** (i + 1) and s.dim() == 4 and
-                    s.is_contiguous()) else _to_nhwc(s) for i, s in enumerate(states)]
+        st = [_state_nhwc(s, self.base_num_channels * 2 ** (i + 1)) for i, s in enumerate(states)]
         return self.statenetphasedrecurrent.forward_images(ops.pack_input(image, self.gpu), st, lstm_state)
 
     def decode(self, states):
@@ -163,9 +171,10 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 pred = net.forward_decoder(ss)
-            for t in ss:
-                for u in (t if isinstance(t, (list, tuple)) else (t,)):
-                    u.record_stream(side)
+            if not torch.cuda.is_current_stream_capturing():       # (inside a capture the graph's edges order the private pool)
+                for t in ss:
+                    for u in (t if isinstance(t, (list, tuple)) else (t,)):
+                        u.record_stream(side)
             return pred
 
         events_as_image = baseline == "ergb0" or (baseline == "e" and lc == "image")
@@ -191,6 +200,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         emit('image', decode(ss), ss, sl)
         if side is not None:                       # predictions are consumed on the caller's stream
             torch.cuda.current_stream().wait_stream(side)
-            for pred in predictions_dict.values():
-                pred.record_stream(torch.cuda.current_stream())
+            if not torch.cuda.is_current_stream_capturing():
+                for pred in predictions_dict.values():
+                    pred.record_stream(torch.cuda.current_stream())
         return predictions_dict, super_state_dict, states_lstm_dict

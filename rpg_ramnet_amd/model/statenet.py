@@ -91,11 +91,12 @@ class StateNetPhasedRecurrent(nn.Module):
                     side.wait_stream(main)                                  # x_i (and the state) are ready
                     with torch.cuda.stream(side):
                         _, super_state = combs[i](x, prev_super_state[i])
-                    x.record_stream(side)
-                    for t in (prev_super_state[i] if isinstance(prev_super_state[i], (list, tuple)) else (prev_super_state[i],)):
-                        t.record_stream(side)
-                    for t in (super_state if isinstance(super_state, (list, tuple)) else (super_state,)):
-                        t.record_stream(main)                               # consumed on the caller's stream after the join
+                    if not torch.cuda.is_current_stream_capturing():       # (a capture orders its private pool by the graph's own edges;
+                        x.record_stream(side)                               # record_stream there left later captures crashing at replay)
+                        for t in (prev_super_state[i] if isinstance(prev_super_state[i], (list, tuple)) else (prev_super_state[i],)):
+                            t.record_stream(side)
+                        for t in (super_state if isinstance(super_state, (list, tuple)) else (super_state,)):
+                            t.record_stream(main)                           # consumed on the caller's stream after the join
                     joins.append(side)
                 else:
                     _, super_state = combs[i](x, prev_super_state[i])       # convlstm: h and c both from the shared state

@@ -94,12 +94,14 @@ class ConvLSTM(nn.Module, _Lazy):
         self.input_size, self.hidden_size = input_size, hidden_size
         self.Gates = nn.Conv2d(input_size + hidden_size, 4 * hidden_size, kernel_size, padding=1)
 
-    def forward(self, x, prev_state=None):
+    def forward(self, x, prev_state=None, out=None):
+        """out: optional (h, c) NHWC buffers that receive the new state (streaming runtimes)."""
         if prev_state is None:
             z = torch.zeros_like(x)
             prev_state = (z, z)
         cp = self._cp("g", [self.Gates.weight], [self.Gates.bias], gates=4)
-        h, c = ops.LSTMCell.apply(x, prev_state[0], prev_state[1], self.Gates.weight, self.Gates.bias, cp)
+        oh, oc = out if out is not None else (None, None)
+        h, c = ops.LSTMCell.apply(x, prev_state[0], prev_state[1], self.Gates.weight, self.Gates.bias, cp, oh, oc)
         return h, c
 
 
@@ -118,13 +120,14 @@ class ConvGRU(nn.Module, _Lazy):
         init.constant_(self.update_gate.bias, 0.)
         init.constant_(self.out_gate.bias, 0.)
 
-    def forward(self, x, prev_state):
+    def forward(self, x, prev_state, out=None):
+        """out: optional NHWC buffer that receives the new state (streaming runtimes)."""
         if prev_state is None:
             prev_state = torch.zeros_like(x)
         u, r, o = self.update_gate, self.reset_gate, self.out_gate
         cp_ur = self._cp("ur", [u.weight, r.weight], [u.bias, r.bias])
         cp_o = self._cp("o", [o.weight], [o.bias])
-        return ops.GRUCell.apply(x, prev_state, u.weight, u.bias, r.weight, r.bias, o.weight, o.bias, cp_ur, cp_o)
+        return ops.GRUCell.apply(x, prev_state, u.weight, u.bias, r.weight, r.bias, o.weight, o.bias, cp_ur, cp_o, out)
 
 
 class RecurrentConvLayer(nn.Module):
@@ -138,8 +141,8 @@ class RecurrentConvLayer(nn.Module):
         block = ConvLSTM if recurrent_block_type == 'convlstm' else ConvGRU
         self.recurrent_block = block(input_size=out_channels, hidden_size=out_channels, kernel_size=3)
 
-    def forward(self, x, prev_state):
-        state = self.recurrent_block(x, prev_state)
+    def forward(self, x, prev_state, out=None):
+        state = self.recurrent_block(x, prev_state) if out is None else self.recurrent_block(x, prev_state, out)
         x = state[0] if self.recurrent_block_type == 'convlstm' else state
         return x, state
 

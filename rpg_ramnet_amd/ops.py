@@ -802,15 +802,28 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
         raise RuntimeError("folded upsample-conv needs un-padded input channels")
     H2, W2 = 2 * Hh, 2 * W
     xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
+    # inference with branch streams: the border path (im2col -> two GEMMs) does not depend on the padded sum and runs beside it
+    side = branch_stream(dev, 8) if (_USE_BRANCH and not torch.is_grad_enabled()) else None
+    main = torch.cuda.current_stream()
+    if side is not None:
+        side.wait_stream(main)
     H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
-    a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
-    a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
-    H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
     w_rows, w_cols = cp.border_weights()                                          # [2 sides][5*Cin][2*Cout]
-    g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
-    g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
-    gemm(a_rows, w_rows, g_rows)               # both sides of a border in one launch
-    gemm(a_cols, w_cols, g_cols)
+    with torch.cuda.stream(side if side is not None else main):
+        a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
+        a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+        H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
+        g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
+        g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
+        gemm(a_rows, w_rows, g_rows)               # both sides of a border in one launch
+        gemm(a_cols, w_cols, g_cols)
+    if side is not None:
+        main.wait_stream(side)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in (x, skip):
+                if t is not None:
+                    t.record_stream(side)
+            g_rows.record_stream(main), g_cols.record_stream(main)
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     if _FOLD_WINO and _fold_wino_ok(Cc, cp.Cout):   # Winograd F(2x2,4x4) over the four parities
         conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
@@ -1112,7 +1125,9 @@ class GRUCell(Function):
     h' = h(1-u) + tanh(W_o*[x, h.r]) u (concat, h.r, tanh and the blend never touch HBM separately)."""
 
     @staticmethod
-    def forward(ctx, x, h, wu, bu, wr, br, wo, bo, cp_ur, cp_o):
+    def forward(ctx, x, h, wu, bu, wr, br, wo, bo, cp_ur, cp_o, out=None):
+        """out: optional NHWC buffer that receives h' (the streaming runtimes write the new state straight into their static
+        state buffers instead of copying it there)."""
         x, h = dense(x), dense(h)
         if x.shape != h.shape:       # the reference fails in torch.cat here (e.g. H, W not divisible by 2**num_encoders)
             raise RuntimeError("Sizes of tensors must match except in dimension 1. Expected %s but got %s (input vs state; "
@@ -1121,7 +1136,9 @@ class GRUCell(Function):
         taps = Taps.get("conv", 3, 1)
         ur = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
         conv_launch(x, taps, cp_ur.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp_ur.bias(), epi=H.EPI_SIGMOID)
-        hn = torch.empty(B, Hh, W, Cc, device=x.device)
+        hn = torch.empty(B, Hh, W, Cc, device=x.device) if out is None else out
+        if out is not None and (tuple(out.shape) != (B, Hh, W, Cc) or not out.is_contiguous() or out.dtype != torch.float32):
+            raise RuntimeError("GRUCell: `out` must be a contiguous fp32 NHWC buffer of the state's shape")
         need = any(ctx.needs_input_grad)
         o = torch.empty_like(hn) if need else None
         conv_launch(x, taps, cp_o.fwd(), hn, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, bias=cp_o.bias(),
@@ -1152,21 +1169,24 @@ class GRUCell(Function):
         ws, bws = cp_ur.grad_ws(wino_ok=Cc % 32 == 0)
         wgrad_side([x, h, dpur], x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)
-        return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None
+        return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None, None
 
 
 class LSTMCell(Function):
     """ConvLSTM (submodules.py:318-358): one launch; the gate non-linearities and the cell update are the epilogue."""
 
     @staticmethod
-    def forward(ctx, x, h, c, w, b, cp):
+    def forward(ctx, x, h, c, w, b, cp, out_h=None, out_c=None):
         x, h, c = dense(x), dense(h), dense(c)
         if x.shape != h.shape or x.shape != c.shape:
             raise RuntimeError("Sizes of tensors must match except in dimension 1. Expected %s but got %s / %s (input vs "
                                "hidden / cell state; NHWC)" % (tuple(x.shape), tuple(h.shape), tuple(c.shape)))
         B, Hh, W, Cc = x.shape
-        hn = torch.empty(B, Hh, W, Cc, device=x.device)
-        cn = torch.empty_like(hn)
+        hn = torch.empty(B, Hh, W, Cc, device=x.device) if out_h is None else out_h
+        cn = torch.empty_like(hn) if out_c is None else out_c
+        for t in (out_h, out_c):
+            if t is not None and (tuple(t.shape) != (B, Hh, W, Cc) or not t.is_contiguous() or t.dtype != torch.float32):
+                raise RuntimeError("LSTMCell: `out_h` / `out_c` must be contiguous fp32 NHWC buffers of the state's shape")
         need = any(ctx.needs_input_grad)
         gates = torch.empty(B, Hh, W, 4 * Cc, device=x.device) if need else None
         conv_launch(x, Taps.get("conv", 3, 1), cp.fwd(), hn, Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp.bias(),
@@ -1191,7 +1211,7 @@ class LSTMCell(Function):
         wgrad_side([x, h, dpre], x, Taps.get("conv", 3, 1), dpre, ws, 4 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
         conv_launch(dpre, Taps.get("dgrad1", 3, 1), cp.bwd(), dxh, 2 * Cc)
-        return dxh[..., :Cc], dxh[..., Cc:], dc, None, None, None
+        return dxh[..., :Cc], dxh[..., Cc:], dc, None, None, None, None, None
 
 
 class PredSigmoid(Function):
