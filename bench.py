@@ -339,7 +339,7 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
     event grids (1..8) before each frame, hipGraph replays with the decode of update k pipelined behind update k+1
     (graph.GraphedStream).  Returns ms per update+decode and the MFMA roofline of the whole chain: FLOP counted by the launch
     hooks over ONE eager pass of the same schedule (every launch of the chain), divided by the replayed wall time."""
-    from rpg_ramnet_amd.graph import GraphedStream, StreamPipeline, TimeBatchedStream
+    from rpg_ramnet_amd.graph import GraphedStream, TimeBatchedStream
     was_training = model.training
     model.eval()
     rs = np.random.default_rng(7)
@@ -394,7 +394,6 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
 
     run_tb()                                            # first pass records the graphs of every group shape of the schedule
     dt = clock(run_tb)
-    dt3 = clock(runner(StreamPipeline(model, 1, H, W)))
     dt2 = clock(runner(GraphedStream(model, 1, H, W, pipelined=True)))
     dt1 = clock(runner(GraphedStream(model, 1, H, W, pipelined=False)))
     dte = clock(eager)
@@ -405,12 +404,11 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
            "up to the next frame form a group — encoders at batch n and decoders at batch n+1 in one launch chain each (they do not depend "
            "on the order of the updates), state updates one by one per scale; groups pipelined (hipGraph replays, four streams)",
            "latency_ms_update_then_decode": 1e3 * dt1 / n_upd, "two_stage_ms_per_update_and_decode": 1e3 * dt2 / n_upd,
-           "three_stage_ms_per_update_and_decode": 1e3 * dt3 / n_upd,
+
            "eager_ms_per_update_and_decode": 1e3 * dte / n_upd, "mfma_launches_per_update": nl / float(n_upd),
            "note": "ms_per_update_and_decode = period of the pipelined stream (throughput over a recorded stream, test.py:205-232); "
                    "latency_ms_update_then_decode = one update followed by its decode as serial graph replays (what a live sensor sees); "
-                   "two_stage = decode of update k beside update k+1 (graph.GraphedStream, the round-2 runtime); three_stage = "
-                   "graph.StreamPipeline (encoders k+1 | updates k | decodes k-1, k-2 per measurement)"}
+                   "two_stage = decode of update k beside update k+1 (graph.GraphedStream, the round-2 runtime)"}
     if ex > 0:
         out["roofline"] = {"bound": "mfma", "kernel": "whole update+decode chain (%d MFMA launches per update)" % round(nl / float(n_upd)),
                            "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -565,11 +563,10 @@ def main():
             stream_state["s"] = st
             return pred.mean()
 
-        from rpg_ramnet_amd.graph import GraphedStream, StreamPipeline, TimeBatchedStream
-        # hipGraph replays, time-batched groups (graph.TimeBatchedStream); the per-measurement runtimes (three-stage pipeline:
-        # StreamPipeline; decode of update k beside update k+1: GraphedStream pipelined; strictly serial replays) are extras
+        from rpg_ramnet_amd.graph import GraphedStream, TimeBatchedStream
+        # hipGraph replays, time-batched groups (graph.TimeBatchedStream); the per-measurement runtimes (decode of update k beside
+        # update k+1: GraphedStream pipelined; strictly serial replays) are extras
         tb = TimeBatchedStream(model, B, H, W, max_events=8)
-        gs_three = StreamPipeline(model, B, H, W)
         gs_two = GraphedStream(model, B, H, W, pipelined=True)
         gs_serial = GraphedStream(model, B, H, W, pipelined=False)
 
@@ -589,7 +586,6 @@ def main():
         graphed["eager"] = eager_step
         graphed["graph_serial"] = lambda: run_stream(gs_serial)
         graphed["graph_two_stage"] = lambda: run_stream(gs_two)
-        graphed["graph_three_stage"] = lambda: run_stream(gs_three)
     else:
         model.eval()
 
@@ -697,9 +693,6 @@ def main():
             if "graph_serial" in graphed:
                 extras["graph_update_then_decode"] = dict(measure(graphed["graph_serial"]), note="hipGraph replays with the decode of "
                                                           "update k BEFORE update k+1 on one stream (the timed region overlaps them)")
-            if "graph_three_stage" in graphed:
-                extras["graph_three_stage"] = dict(measure(graphed["graph_three_stage"]), note="graph.StreamPipeline: encoders k+1 | updates k | "
-                                                   "decodes k-1, k-2, one measurement at a time")
             if "graph_two_stage" in graphed:
                 extras["graph_two_stage"] = dict(measure(graphed["graph_two_stage"]), note="decode of update k on a second stream beside "
                                                  "update k+1 (graph.GraphedStream pipelined, the round-2 runtime)")

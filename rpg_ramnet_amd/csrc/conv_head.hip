@@ -42,7 +42,7 @@ __device__ __forceinline__ void head_stage_patch(float *__restrict__ P, const fl
     for (int i = tid; i < (TH + 4) * HP_W; i += 256) {
         const int py = i / HP_W, px = i - py * HP_W;
         const int iy = oy0 - 2 + py, ix = ox0 - 2 + px;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float v[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
             const float *src = x + ((size_t)(b * H + iy) * W + ix) * ld;
             const float4 a = ld4(src);
@@ -51,13 +51,17 @@ __device__ __forceinline__ void head_stage_patch(float *__restrict__ P, const fl
                 const float4 c = ld4(src + 4);
                 v[4] = c.x, v[5] = c.y, v[6] = c.z, v[7] = c.w;
             }
+            if (CR > 8) {
+                const float4 c = ld4(src + 8);
+                v[8] = c.x, v[9] = c.y, v[10] = c.z, v[11] = c.w;
+            }
         }
 #pragma unroll
         for (int c = 0; c < CR; ++c) P[c * HP_PLANE + py * HP_LD + px] = v[c];
     }
 }
 
-static bool head_channels_ok(int c) { return c == 1 || c == 3 || c == 5; }
+static bool head_channels_ok(int c) { return c == 1 || c == 3 || c == 5 || c == 10; }      // (10: the configs[4] voxel grids)
 
 struct HeadFwdParams {
     const float *x, *wp, *bias;
@@ -224,13 +228,12 @@ int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st) {
     for (int t = 0; t < 25; ++t) RAMNET_CHECK_ARG(d.dy[t] == t / 5 - 2 && d.dx[t] == t % 5 - 2);
     RAMNET_CHECK_ARG(d.head_cin >= 1 && d.head_cin <= d.C0 && head_channels_ok(d.head_cin) && d.Cout <= 32);
     RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win && ((uintptr_t)d.x0 & 15) == 0 && ((uintptr_t)d.dout & 15) == 0 &&
-                     (d.gmask == nullptr || ((uintptr_t)d.gmask & 15) == 0) && (d.head_cin <= 4 || d.C0 >= 8));
+                     (d.gmask == nullptr || ((uintptr_t)d.gmask & 15) == 0) && (d.head_cin <= 4 || d.C0 >= 8) && (d.head_cin <= 8 || d.C0 >= 12));
     HeadWgradParams q;
     q.x = d.x0, q.g = d.dout, q.gm = d.gmask, q.dw = d.dw, q.dbias = d.dbias;
     q.ld = d.ld0, q.ldg = d.ldg, q.ldgm = d.ldgm, q.B = d.B, q.H = d.Hin, q.W = d.Win, q.Cin = d.C0, q.Cout = d.Cout;
     q.tiles_x = cdiv(d.Wo, HT_W), q.tiles_y = cdiv(d.Ho, HG_H), q.ntiles = q.tiles_x * q.tiles_y * d.B;
-    static const char *se = getenv("RAMNET_HEAD_WGRAD_BLOCKS");
-    int blocks = se ? atoi(se) : 512;
+    int blocks = 512;                               // persistent workgroups (256 measured the same)
     if (blocks > q.ntiles) blocks = q.ntiles;
     if (blocks < 1) blocks = 1;
     auto go = [&](auto kern, int cr) -> int {
@@ -243,6 +246,7 @@ int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st) {
     int rc;
     if (d.head_cin == 1) rc = go(conv_head_wgrad_kernel<1>, 1);
     else if (d.head_cin == 3) rc = go(conv_head_wgrad_kernel<3>, 3);
+    else if (d.head_cin == 10) rc = go(conv_head_wgrad_kernel<10>, 10);
     else rc = go(conv_head_wgrad_kernel<5>, 5);
     if (rc) return rc;
     RAMNET_LAUNCH_CHECK();
@@ -264,7 +268,7 @@ int launch_head(const ramnet_conv_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.head_cin >= 1 && d.head_cin <= d.C0 && head_channels_ok(d.head_cin) && d.Cout <= 32);
     RAMNET_CHECK_ARG(d.Ho == d.Hin && d.Wo == d.Win && d.HoF == d.Ho && d.WoF == d.Wo && d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0);
     RAMNET_CHECK_ARG((d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR) && d.beta == 0.f && d.frame == 0 && d.out_s2d == 0);
-    RAMNET_CHECK_ARG(((uintptr_t)d.x0 & 15) == 0 && d.ld0 % 4 == 0 && (d.head_cin <= 4 || d.C0 >= 8));
+    RAMNET_CHECK_ARG(((uintptr_t)d.x0 & 15) == 0 && d.ld0 % 4 == 0 && (d.head_cin <= 4 || d.C0 >= 8) && (d.head_cin <= 8 || d.C0 >= 12));
     HeadFwdParams q;
     q.x = d.x0, q.wp = d.w, q.bias = d.bias, q.out = d.out;
     q.ld = d.ld0, q.ldo = d.ldo, q.B = d.B, q.H = d.Hin, q.W = d.Win, q.Cout = d.Cout, q.relu = d.epi == RAMNET_EPI_RELU;
@@ -273,6 +277,7 @@ int launch_head(const ramnet_conv_desc &d, hipStream_t st) {
     note_kernel("conv_head_fwd_kernel<%d>", d.head_cin == 1 ? 1 : d.head_cin == 3 ? 3 : 5);
     if (d.head_cin == 1) hipLaunchKernelGGL(conv_head_fwd_kernel<1>, grid, dim3(256), 0, st, q);
     else if (d.head_cin == 3) hipLaunchKernelGGL(conv_head_fwd_kernel<3>, grid, dim3(256), 0, st, q);
+    else if (d.head_cin == 10) hipLaunchKernelGGL(conv_head_fwd_kernel<10>, grid, dim3(256), 0, st, q);
     else hipLaunchKernelGGL(conv_head_fwd_kernel<5>, grid, dim3(256), 0, st, q);
     RAMNET_LAUNCH_CHECK();
     return 0;

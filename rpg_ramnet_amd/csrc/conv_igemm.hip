@@ -258,9 +258,8 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
     qc.nclass = n;
     // measured on MI355X (profiles/r01_b_tuning_notes.md): forward 5.55 -> 5.50 ms, backward-data 5.40 -> 5.56 ms per pass,
     // i.e. null within noise — these kernels are MFMA-bound and their operands sit in L2 / Infinity Cache either way.
-    // Kept as an opt-in knob (RAMNET_XCD_SWIZZLE=1) for HBM-bound shapes.
-    static const char *sw = getenv("RAMNET_XCD_SWIZZLE");
-    qc.xcd_swizzle = sw && sw[0] == '1';
+    // Off.
+    qc.xcd_swizzle = 0;
     // ---- tile configuration.  Low-resolution layers (32x43 .. 64x86 pixels) give few 128-pixel tiles: a grid that does
     // not cover the 256 CUs ~3x over leaves CUs idle in the last round (tile quantisation), so shrink the tile there.
     const int lstm = d.epi == RAMNET_EPI_LSTM;
@@ -271,13 +270,11 @@ static int launch_classes(const ramnet_conv_desc *ds, int n, hipStream_t st) {
         return t * d.B * (qc.CoutPad / bn);
     };
     if (!lstm && BN >= 64) {
-        static const char *we = getenv("RAMNET_CONV_WANT");     // tuning knob: minimum workgroups before shrinking tiles
-        const long want = we ? atol(we) : 768;
+        const long want = 768;                                  // minimum workgroups before shrinking tiles
         if (blocks(BM, BN) < want) BM = 64;
         if (blocks(BM, BN) < want && BN == 128) BN = 64;
     }
-    static const char *no256 = getenv("RAMNET_CONV_NO256");
-    if (!lstm && BN == 32 && blocks(256, 32) >= 1024 && !(no256 && no256[0] == '1'))
+    if (!lstm && BN == 32 && blocks(256, 32) >= 1024)
         BM = 256;                    // 32-channel outputs: 16x16-pixel tiles, 2 accumulators per wave per tap
     const int TH = BM / TWID;
     int max_tiles = 0;

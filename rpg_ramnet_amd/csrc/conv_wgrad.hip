@@ -244,10 +244,9 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
     q.tpm = 1;
     if (q.src.Cin <= 16) q.tpm = q.src.Cin <= 4 ? 8 : q.src.Cin <= 8 ? 4 : 2;
     q.ntt = cdiv(d.ntaps, q.tpm);
-    static const char *force = getenv("RAMNET_WGRAD_NSUB");
     // measured (profiles/r01_*layers*): 5x5 layers run 1.5x faster with WBN = 32 (7 tiles/wave, 2 workgroups/CU) than with
     // WBN = 64 (13 tiles/wave, 1 workgroup/CU); 3x3 layers prefer WBN = 64 (5 tiles/wave)
-    const bool narrow = d.Cout <= 32 || d.ntaps > 9 || (force && force[0] == '1');
+    const bool narrow = d.Cout <= 32 || d.ntaps > 9;
     if (narrow) {                                   // WBN = 32: tap tiles spread over 4 waves
         const int per_wave = cdiv(q.ntt, 4);
         if (per_wave <= 1) return launch_wgrad<1, 1>(d, q, st);
@@ -255,8 +254,7 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
         if (per_wave <= 4) return launch_wgrad<4, 1>(d, q, st);     // 16 taps: one parity of the folded upsample-conv
         return launch_wgrad<7, 1>(d, q, st);
     }
-    static const char *nowide = getenv("RAMNET_WGRAD_NOWIDE");
-    if (wide && !(nowide && nowide[0] == '1')) return launch_wgrad<9, 2, 2>(d, q, st);
+    if (wide) return launch_wgrad<9, 2, 2>(d, q, st);
     const int per_wave = cdiv(q.ntt, 2);            // WBN = 64: tap tiles spread over 2 wave pairs
     if (per_wave <= 1) return launch_wgrad<1, 2>(d, q, st);
     if (per_wave <= 5) return launch_wgrad<5, 2>(d, q, st);

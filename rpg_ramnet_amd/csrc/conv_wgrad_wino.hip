@@ -370,9 +370,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.nbatch = q.bx_n * q.ty_n * d.B;
     q.dy0 = dymin, q.dx0 = dxmin;
     // batches of 8 tiles: a 2 x 16 or an 8 x 4 pixel strip, whichever pads the map less
-    static const char *tall_env = getenv("RAMNET_WGRAD_WINO_TALL");
-    bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
-    if (tall_env) tall = tall_env[0] == '1';
+    const bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
     if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
     // RAMNET_WGRAD_NF=4: 128 output channels per workgroup (one workgroup per CU, 512 registers per lane) where the layer has them.
     // Isolated it is the faster form (six ConvGRU launches 1.522 -> 1.434 ms: 7.25 instead of 11 instructions per MFMA), in the
@@ -383,8 +381,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
     // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
     static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
-    static const char *se4 = getenv("RAMNET_WGRAD_BLOCKS4");
-    int splits = (nf == 4 ? (se4 ? atoi(se4) : 256) : (se ? atoi(se) : 384)) / (gy * gz);
+    int splits = (nf == 4 ? 256 : (se ? atoi(se) : 384)) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
     const dim3 grid(splits, gy, gz);

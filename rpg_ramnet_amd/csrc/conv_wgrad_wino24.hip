@@ -227,8 +227,7 @@ int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.tiles_x = cdiv(d.Wo, 2), q.tiles_y = cdiv(d.Ho, 2), q.ntiles = q.tiles_x * q.tiles_y * d.B, q.nbatch = cdiv(q.ntiles, G24_T);
     q.ncob = cdiv(d.Cout, G24_CO);
     const int gy = d.C0 / G24_CI, gz = q.ncob * 4;
-    static const char *se = getenv("RAMNET_WGRAD24_BLOCKS");
-    int splits = (se ? atoi(se) : 256) / (gy * gz);
+    int splits = 256 / (gy * gz);                   // (128 / 384 workgroups measured the same training step)
     if (splits > q.nbatch) splits = q.nbatch;
     if (splits < 1) splits = 1;
     const size_t lds = (size_t)2 * 25 * G24_T * (32 + 64) * sizeof(float);

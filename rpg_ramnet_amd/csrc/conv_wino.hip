@@ -141,6 +141,10 @@ template <int TX> struct RGeom {
 // MFMAs per chunk and wave — the same transform work per workgroup, but the launch is latency-bound there, not pipe-bound.
 template <int TX, int SP, int MODE, int NF = 2>
 __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_desc p, const WinoParams q) {
+    // NF = 1: the exchange buffer holds 32 columns (37 KB instead of 70 KB of LDS), so that these workgroups — of DIFFERENT launches:
+    // the per-scale update chains of the streaming runtime run side by side — share a CU with the decoders' (building it for three
+    // waves per SIMD as well measured no gain on the stream and cost the ConvGRU candidate launch 61 -> 69 us: spills)
+    constexpr int RO_LD = NF == 1 ? 32 + 4 : ramnet::RO_LD;
     using G = RGeom<TX>;
     constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -421,9 +425,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = d.epi == RAMNET_EPI_LSTM ? cdiv(d.Cout, 16) : cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
     // 8 x 16 or 32 x 4 output pixels per workgroup, whichever pads the map less
-    static const char *tall_env = getenv("RAMNET_WINO_TALL");      // 0 / 1 forces a shape (tuning), default: by padded area
-    bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
-    if (tall_env) tall = tall_env[0] == '1';
+    const bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
     if (tall) q.tiles_x = cdiv(d.Wo, 4), q.tiles_y = cdiv(d.Ho, 32);
     q.dy0 = dymin, q.dx0 = dxmin;
     auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
@@ -443,22 +445,18 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
         q.s2d_shift = log2_exact(d.out_s2d);
     }
     // XCD-pinned channel groups for weights that do not fit an L2: 2 groups above 3 MB, 4 above 12 MB (when nblk divides)
-    static const char *xge = getenv("RAMNET_WINO_XCD_GROUPS");      // tuning knob: log2 of the group count
     const size_t wbytes = (size_t)q.nchunks * q.nblk * WU_FLOATS * sizeof(float);
-    q.xg = xge ? atoi(xge) : (wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0);
-    q.xg = q.xg < 0 ? 0 : q.xg > 3 ? 3 : q.xg;
+    q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
     // fewer workgroups than CUs (batch-1 streaming, coarse maps): 32-channel workgroups, twice as many (forward input modes only)
-    static const char *nfe = getenv("RAMNET_WINO_NF");              // tuning knob: 2 keeps 64-channel workgroups everywhere
     const bool fwd_mode = d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_S2D;
-    const int nf = (q.tiles_x * q.tiles_y * d.B * q.nblk < 256 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && fwd_mode && d.Cout % 64 == 0 &&
-                    !(nfe && nfe[0] == '2')) ? 1 : 2;
+    const int nf = (q.tiles_x * q.tiles_y * d.B * q.nblk < 256 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && fwd_mode && d.Cout % 64 == 0) ? 1 : 2;
     // such a launch is bound by the latency of its chunk chain, not by the MFMA pipe: skipping the MFMAs of the zero slices buys
     // nothing there, the wave-uniform tests around them cost (enc2 at batch 1: 1.7 instead of 0.9 us per chunk) -> dense
     if (nf == 1 && q.sparse == 1) q.sparse = 0;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
-    const size_t lds = (size_t)RO_FLOATS * sizeof(float);       // (the two patch buffers, 2 x 2 planes, are smaller)
+    const size_t lds = (size_t)(nf == 1 ? 4 * 2 * 32 * (32 + 4) : RO_FLOATS) * sizeof(float);       // (the two patch buffers, 2 x 2 planes, and the scratch cells are smaller)
     // one instantiation per (tile shape, sparse mode, input mode) that occurs: the kernel body has no run-time mode branches
     {
         const unsigned long long px = (unsigned long long)d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1);

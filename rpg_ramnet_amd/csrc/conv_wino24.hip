@@ -14,6 +14,7 @@
 // 16-byte global (L2) read per position from weights packed in exactly that lane order.  Loads and the transform of chunk
 // i+1 are issued between the MFMAs of chunk i.  The output transform is register-local; bias / ReLU and the border
 // corrections of the folded layer (ramnet_conv_desc.frame) are applied by the shared epilogue.
+#include <stdlib.h>
 #include "common.hpp"
 #include "conv_epilogue.hpp"
 
@@ -59,8 +60,13 @@ struct Wino24Params {
 // (Hp, Wp = its extent), whose four parity sub-grids are the reduction blocks (class = chunk / cpc: window origin and pixel
 // stride 2, zero outside — a buffer load past the tensor returns 0); the output is the dense (Hc+4) x (Wc+4) grid of the padded
 // low-resolution tensor.
-template <int NCQ, bool DG, int TXW>
+// PAIR (32-channel layers: the last decoder): the two column parities px = 0 / 1 of a row parity share ONE transformed input — the
+// class-(py, 1) grid is tiled with its tile origins shifted by one column, so that both classes read the same 5 x 5 windows — and
+// the workgroup's 64 columns are (px, 32 channels): the input transform (25 loads + ~160 VALU per tile and channel, the cost that
+// bounds this kernel at 32 output channels: 35 % MFMA-busy) feeds twice the MFMAs.  NCQ = 4 geometry, chunks of 16.
+template <int NCQ, bool DG, int TXW, bool PAIR = false>
 __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_desc p, const Wino24Params q) {
+    static_assert(!PAIR || (NCQ == 4 && !DG), "pair mode: forward, 64-column workgroups");
     constexpr int W24_K = NCQ == 4 ? 16 : 8;          // input channels per chunk
     constexpr int W24_TX = TXW, W24_TY = (NCQ == 4 ? 32 : 64) / TXW;      // tile columns / rows per workgroup
     constexpr int VEC = W24_K / 4;                    // floats per lane and operand read (k = VEC*ks + j)
@@ -74,14 +80,14 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
 
     // blockIdx.x = ((tile block * nblk + channel block) * 4 + class): the four parities of a tile block read the same input
     int bid = blockIdx.x;
-    const int cls = DG ? 0 : bid & 3;
-    if (!DG) bid >>= 2;
+    const int cls = DG ? 0 : PAIR ? bid & 1 : bid & 3;          // PAIR: the row parity; both column parities in this workgroup
+    if (!DG) bid >>= PAIR ? 1 : 2;
     const int nb = bid % q.nblk;
     bid /= q.nblk;
     const int tbx = bid % q.tiles_x;
     bid /= q.tiles_x;
     const int tby = bid % q.tiles_y, b = bid / q.tiles_y;
-    const int py = cls >> 1, px = cls & 1;
+    const int py = PAIR ? cls : cls >> 1, px = PAIR ? 0 : cls & 1;
     const int n0 = nb * 16 * NCQ;
 
     // ---- input transform item of this thread: (tile, channel of the chunk)
@@ -254,7 +260,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     W24_STAMP(16, 2);
 
     // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue
-    const int n = n0 + cq * 16 + l15;
+    const int ncol = n0 + cq * 16 + l15;
+    const int pxc = PAIR ? ncol >> 5 : px, n = PAIR ? ncol & 31 : ncol;      // PAIR: column = (column parity, channel)
     if (n >= p.Cout) return;
     const int epi = p.epi;
 #pragma unroll
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             s[1][j] = m1 - m2 + 2.f * m3 + m4;
         }
         const int t = th * 16 + 4 * ks + r;
-        const int oy0 = 2 * (tby * W24_TY + t / W24_TX), ox0 = 2 * (tbx * W24_TX + t % W24_TX);
+        const int oy0 = 2 * (tby * W24_TY + t / W24_TX), ox0 = 2 * (tbx * W24_TX + t % W24_TX) - (PAIR ? pxc : 0);
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
             const float y0 = s[a2][0] + s[a2][1] + s[a2][2] + s[a2][3];
@@ -279,8 +286,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
                     if (oy < p.Ho && ox < p.Wo) p.out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.ldo + n] = c2 ? y1 : y0;
                     continue;
                 }
-                if (oy >= q.Hc || ox >= q.Wc) continue;
-                const int oyF = 2 * oy + py, oxF = 2 * ox + px;
+                if (oy >= q.Hc || ox >= q.Wc || (PAIR && ox < 0)) continue;
+                const int oyF = 2 * oy + py, oxF = 2 * ox + pxc;
                 const size_t pix = ((size_t)b * p.HoF + oyF) * p.WoF + oxF;
                 epilogue_store(p, epi, pix, n, (c2 ? y1 : y0) + epilogue_side(p, epi, b, oyF, oxF, n), false);
             }
@@ -292,11 +299,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
 // OIHW 5x5 weights of an UpsampleConvLayer -> U = G W4 G^T of the four 4x4 parity filters W4 = A_py w A_px^T (the bilinear x2
 // upsample folded into the filter) in the lane order of the kernel's B operand; evaluated in double.
 __global__ void pack_weight_fold_wino_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int kc, int ncq,
-                                             size_t total) {
+                                             int pair, size_t total) {
     const double FA[2][4][5] = {{{.25, 0, 0, 0, 0}, {.75, .75, .25, 0, 0}, {0, .25, .75, .75, .25}, {0, 0, 0, .25, .75}},
                                 {{.75, .25, 0, 0, 0}, {.25, .75, .75, .25, 0}, {0, 0, .25, .75, .75}, {0, 0, 0, 0, .25}}};
     const double G[5][4] = {{0.5, 0, 0, 0}, {-0.5, -0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3, 4.0 / 3}, {0, 0, 0, 1}};
-    const int vec = kc / 4, nblk = Cout / (16 * ncq), nch = Cin / kc;
+    const int vec = kc / 4, nblk = pair ? 1 : Cout / (16 * ncq), nch = Cin / kc;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         // i = ((((cls*nch + chunk)*nblk + nb)*25 + pos)*ncq + cq)*64*vec + (ks*16 + l15)*vec + j
         size_t r = i;
@@ -313,8 +320,10 @@ __global__ void pack_weight_fold_wino_kernel(const float *__restrict__ w, float 
         const int nb = (int)(r % nblk);
         r /= nblk;
         const int chunk = (int)(r % nch), cls = (int)(r / nch);
-        const int k = chunk * kc + ks * vec + j, n = (nb * ncq + cq) * 16 + l15;
-        const int py = cls >> 1, px = cls & 1, a = pos / 5, b = pos % 5;
+        const int k = chunk * kc + ks * vec + j, col = (nb * ncq + cq) * 16 + l15;
+        // pair layout (32-channel layers): class = row parity, column = (column parity, channel)
+        const int n = pair ? col & 31 : col;
+        const int py = pair ? cls : cls >> 1, px = pair ? col >> 5 : cls & 1, a = pos / 5, b = pos % 5;
         // U[a][b] = sum_{t,s} G[a][t] G[b][s] sum_{kh,kw} FA[py][t][kh] FA[px][s][kw] w[n][k][kh][kw]
         double ga[5], gb[5];                        // rows of G^T... combined with the fold: ga[kh] = sum_t G[a][t] FA[py][t][kh]
         for (int kh = 0; kh < 5; ++kh) {
@@ -329,8 +338,13 @@ __global__ void pack_weight_fold_wino_kernel(const float *__restrict__ w, float 
     }
 }
 
+static bool fold_wino_pair(int Cout, int Cin) {
+    static const char *e = getenv("RAMNET_FOLD_PAIR");          // A/B knob: 0 = the 32-channel form (64 tiles x 32 channels, chunks of 8)
+    return Cout == 32 && Cin % 32 == 0 && !(e && e[0] == '0');
+}
+
 static bool fold_wino_geometry(int Cout, int Cin, int &kc, int &ncq) {
-    kc = (Cout % 64 == 0 && Cin % 16 == 0) ? 16 : 8, ncq = kc == 16 ? 4 : 2;
+    kc = ((Cout % 64 == 0 && Cin % 16 == 0) || fold_wino_pair(Cout, Cin)) ? 16 : 8, ncq = kc == 16 ? 4 : 2;
     return Cout % 32 == 0 && Cin % (2 * kc) == 0;
 }
 
@@ -370,22 +384,32 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     if (d.in_mode == RAMNET_IN_PARITY4) return launch_wino24_dgrad(d, st);
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
     RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN && d.stride == 1);
-    const bool wide = d.Cout % 64 == 0 && d.C0 % 16 == 0;      // 64-channel workgroups, chunks of 16; else 32 channels, chunks of 8
+    const bool pair = fold_wino_pair(d.Cout, d.C0);            // both column parities of a 32-channel layer in one workgroup
+    const bool wide = pair || (d.Cout % 64 == 0 && d.C0 % 16 == 0);      // 64-column workgroups, chunks of 16; else 32 channels, chunks of 8
     RAMNET_CHECK_ARG(d.C0 % (wide ? 32 : 16) == 0);            // an even number of chunks (the chunk loop is unrolled by two)
     RAMNET_CHECK_ARG(d.C0 % 8 == 0 && d.Cout % 32 == 0 && d.Hin == d.Ho + 4 && d.Win == d.Wo + 4 && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
     RAMNET_CHECK_ARG((d.epi == RAMNET_EPI_RELU || d.epi == RAMNET_EPI_LINEAR) && d.beta == 0.f && d.out_s2d == 0 && d.Ho >= 2 && d.Wo >= 2);
     Wino24Params q;
     q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
-    q.nchunks = d.C0 / (wide ? 16 : 8), q.nblk = d.Cout / (wide ? 64 : 32);
+    q.nchunks = d.C0 / (wide ? 16 : 8), q.nblk = pair ? 1 : d.Cout / (wide ? 64 : 32);
     q.Hc = d.Ho, q.Wc = d.Wo, q.cpc = 1;
     const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
     RAMNET_CHECK_ARG(xb < 0xffffffffull && wb < 0x7fffffffull);
     q.xbytes = (unsigned)xb, q.wbytes = (unsigned)wb;
-    const bool flat = wide && cdiv(d.Wo, 16) * cdiv(d.Ho, 8) < cdiv(d.Wo, 8) * cdiv(d.Ho, 16);      // 8 x 16 instead of 16 x 8 pixels
-    q.tiles_x = cdiv(d.Wo, wide && !flat ? 8 : 16), q.tiles_y = cdiv(d.Ho, flat ? 8 : 16);
+    const int Wt = pair ? d.Wo + 2 : d.Wo;                     // pair: one more tile column (the shifted tiling of column parity 1)
+    const bool flat = wide && cdiv(Wt, 16) * cdiv(d.Ho, 8) < cdiv(Wt, 8) * cdiv(d.Ho, 16);      // 8 x 16 instead of 16 x 8 pixels
+    q.tiles_x = cdiv(Wt, wide && !flat ? 8 : 16), q.tiles_y = cdiv(d.Ho, flat ? 8 : 16);
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
-    const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * 4));
-    if (wide && flat) {
+    const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * (pair ? 2 : 4)));
+    if (pair && flat) {
+        RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 8, true>));
+        note_kernel("conv_wino24_kernel<4,0,8,1>");
+        hipLaunchKernelGGL((conv_wino24_kernel<4, false, 8, true>), grid, dim3(512), lds, st, d, q);
+    } else if (pair) {
+        RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 4, true>));
+        note_kernel("conv_wino24_kernel<4,0,4,1>");
+        hipLaunchKernelGGL((conv_wino24_kernel<4, false, 4, true>), grid, dim3(512), lds, st, d, q);
+    } else if (wide && flat) {
         RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 8>));
         note_kernel("conv_wino24_kernel<4,0,8>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, false, 8>), grid, dim3(512), lds, st, d, q);
@@ -419,7 +443,8 @@ extern "C" int ramnet_pack_weight_fold_wino(const float *w, float *wp, int Cout,
     const size_t total = (size_t)100 * Cout * Cin;
     size_t blocks = (total + 255) / 256;
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(pack_weight_fold_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, kc, ncq, total);
+    hipLaunchKernelGGL(pack_weight_fold_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, kc, ncq,
+                       (int)fold_wino_pair(Cout, Cin), total);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -122,10 +122,9 @@ extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int 
     // splits it over the waves of one workgroup per block instead (fixed-order LDS join): bit-reproducible, as every forward kernel.
     const int blocks = batch * cdiv(M, 32) * cdiv(N, 32);
     int ksplit = 1;
-    if (accumulate)
+    if (accumulate)      // (splitting less — 512 ... 2048 blocks — measured the same training step: 198.2 - 199.2 samples/s)
         while (blocks * ksplit < 8192 && K / (ksplit * 2) >= 128) ksplit *= 2;
-    static const char *ie = getenv("RAMNET_GEMM_INTRA");              // tuning knob: 0 = one wave per block for the plain product
-    const int intra = !accumulate && K >= 128 && !(ie && ie[0] == '0');
+    const int intra = !accumulate && K >= 128;
     const dim3 grid(intra ? cdiv(N, 32) : cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit * batch);
     if (trans_a)
         hipLaunchKernelGGL(gemm32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,

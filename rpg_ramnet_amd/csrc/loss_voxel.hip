@@ -225,14 +225,14 @@ static int msg_args(int B, int H, int W, int ns, MsgArgs &a, size_t &total) {
 // Index arithmetic restated from events_to_voxel_grid_pytorch (utils/event_tensor_utils.py:152-180):
 // float64 normalised time, floor, float32 votes pol*(1-dt) / pol*dt, `0 <= ti < bins` guards.
 #pragma clang fp contract(off)
-__device__ __forceinline__ void voxel_event(const double *__restrict__ ev, size_t i, size_t n, int bins, int W, int H,
-                                            long long &il, float &vl, long long &ir, float &vr) {
-    const double t0 = ev[0], t1 = ev[(n - 1) * 4];
+__device__ __forceinline__ void voxel_vote(double t, double x, double y, double p, double t0, double t1, int bins, int W, int H,
+                                           long long &il, float &vl, long long &ir, float &vr, long long *til_out = nullptr,
+                                           long long *base_out = nullptr) {
     double dT = t1 - t0;
     if (dT == 0.0) dT = 1.0;
-    const double ts = ((double)(bins - 1) * (ev[i * 4] - t0)) / dT;
-    const long long xs = (long long)ev[i * 4 + 1], ys = (long long)ev[i * 4 + 2];
-    float pol = (float)ev[i * 4 + 3];
+    const double ts = ((double)(bins - 1) * (t - t0)) / dT;
+    const long long xs = (long long)x, ys = (long long)y;
+    float pol = (float)p;
     if (pol == 0.f) pol = -1.f;
     const double tis = floor(ts);
     const long long til = (long long)tis;
@@ -243,6 +243,13 @@ __device__ __forceinline__ void voxel_event(const double *__restrict__ ev, size_
     const long long base = xs + ys * (long long)W;
     il = (inside && tis < (double)bins && tis >= 0.0) ? base + til * (long long)W * H : -1;
     ir = (inside && (tis + 1.0) < (double)bins && tis >= 0.0) ? base + (til + 1) * (long long)W * H : -1;
+    if (til_out) *til_out = til;
+    if (base_out) *base_out = base;
+}
+
+__device__ __forceinline__ void voxel_event(const double *__restrict__ ev, size_t i, size_t n, int bins, int W, int H,
+                                            long long &il, float &vl, long long &ir, float &vr) {
+    voxel_vote(ev[i * 4], ev[i * 4 + 1], ev[i * 4 + 2], ev[i * 4 + 3], ev[0], ev[(n - 1) * 4], bins, W, H, il, vl, ir, vr);
 }
 
 __global__ void voxelize_kernel(const double *__restrict__ ev, size_t n, int bins, int W, int H, float *__restrict__ grid) {
@@ -279,32 +286,63 @@ __global__ void voxelize_batch_kernel(const double *__restrict__ ev, const long 
 // by ~19 G random fp32 atomics/s of the memory side (858 us for the 8 M events of a package batch, 0.066 of the HBM roofline);
 // here a list is re-read once per band from L2 / Infinity Cache (6.4 MB per grid) and the cost is the event walk itself.
 __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__restrict__ ev, const long long *__restrict__ off,
-                                                              long long n_single, int bins, int W, int H, int rows,
+                                                              long long n_single, int n_grids, int bins, int W, int H, int rows,
                                                               float *__restrict__ grids) {
     extern __shared__ __attribute__((aligned(16))) float band[];          // [bins][rows][W]
-    const int g = blockIdx.y, y0 = blockIdx.x * rows;
+    // All bands of a grid walk the same event list: they are dealt to ONE XCD (workgroup b runs on XCD b % 8) as consecutive
+    // slots, so that the list streams through that XCD's L2 once instead of once per band from the Infinity Cache (12 bands x 40
+    // grids x 6.4 MB = 3 GB per launch, 5.6 TB/s: the walk was bound by exactly that)
+    const int nbands = (H + rows - 1) / rows;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = (slot / nbands) * 8 + xcd, y0 = (slot % nbands) * rows;
+    if (g >= n_grids) return;
     const int nr = min(rows, H - y0);
     const long long e0 = off ? off[g] : 0, n = off ? off[g + 1] - e0 : n_single;
     const double *e = ev + (size_t)e0 * 4;
     const int cells = bins * rows * W;
     for (int i = threadIdx.x; i < cells; i += blockDim.x) band[i] = 0.f;
+    if (threadIdx.x < 2) reinterpret_cast<int *>(band + cells)[4096 + threadIdx.x] = 0;
     __syncthreads();
     const long long plane = (long long)W * H;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const long long ys = (long long)e[i * 4 + 2];                       // (the same conversion voxel_event applies)
-        if (ys < y0 || ys >= y0 + nr) continue;
-        long long il, ir;
+    const double t0 = n > 0 ? e[0] : 0.0, t1 = n > 0 ? e[(n - 1) * 4] : 0.0;
+    const double2 *e2 = reinterpret_cast<const double2 *>(e);
+    auto vote = [&](long long i) {                  // (the event is re-read: it was loaded a moment ago, L1 / L2 resident)
+        const double2 tx = e2[i * 2], yp = e2[i * 2 + 1];
+        long long il, ir, til, base;
         float vl, vr;
-        voxel_event(e, (size_t)i, (size_t)n, bins, W, H, il, vl, ir, vr);
+        voxel_vote(tx.x, tx.y, yp.x, yp.y, t0, t1, bins, W, H, il, vl, ir, vr, &til, &base);
         // flat index = x + y*W + bin*W*H  ->  band cell (bin*rows + y - y0)*W + x
-        if (il >= 0) {
-            const long long bin = il / plane, rem = il - bin * plane;
-            atomicAdd(band + (int)(bin * rows * W + rem - (long long)y0 * W), vl);
+        const int cell = (int)(til * rows * W + base - (long long)y0 * W);
+        if (il >= 0) atomicAdd(band + cell, vl);
+        if (ir >= 0) atomicAdd(band + cell + rows * W, vr);
+    };
+    // A workgroup walks the whole list of its grid but only ~rows/H of the events fall into its band.  Phase 1 of a batch tests
+    // the row of every event on the double itself ((long long)y truncates towards zero: trunc(y) in [y0, y0 + nr) <=> y in [y0, y0 +
+    // nr) for y0 > 0, y in (-1, nr) for y0 = 0) — whole events, two 16-byte loads per lane, a wave covers 2 KB contiguous — and
+    // queues the hits in LDS; phase 2 votes on the queue with all lanes busy.  Voting inside the walk ran the ~300-instruction vote
+    // path (f64 division, floor, conversions) in EVERY wave iteration for the 5 lanes of 64 that had a hit: 250 us per workgroup.
+    const double band_lo = y0 == 0 ? -1.0 : (double)y0, band_hi = (double)(y0 + nr);
+    auto in_band = [&](double y) { return (y0 == 0 ? y > band_lo : y >= band_lo) && y < band_hi; };
+    constexpr int U = 4, QCAP = 4096;               // events per thread and batch; a batch has U * 1024 = QCAP events
+    int *queue = reinterpret_cast<int *>(band + cells);            // [QCAP] event offsets inside the batch, behind the band
+    int *qn = queue + QCAP;                                      // [2] fill counters, alternating by batch
+    const long long stride = blockDim.x;
+    int par = 0;
+    for (long long b0 = 0; b0 < n; b0 += (long long)U * stride, par ^= 1) {
+        double2 yp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = b0 + u * stride + threadIdx.x;
+            yp[u] = i < n ? e2[i * 2 + 1] : make_double2(-2.0, 0.0);
         }
-        if (ir >= 0) {
-            const long long bin = ir / plane, rem = ir - bin * plane;
-            atomicAdd(band + (int)(bin * rows * W + rem - (long long)y0 * W), vr);
-        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (in_band(yp[u].x)) queue[atomicAdd(qn + par, 1)] = u * (int)stride + (int)threadIdx.x;
+        __syncthreads();
+        const int cnt = qn[par];
+        if (threadIdx.x == 0) qn[par ^ 1] = 0;      // (read again only behind the next barrier)
+        for (int k = threadIdx.x; k < cnt; k += (int)stride) vote(b0 + queue[k]);
+        __syncthreads();                            // the queue is drained before the next batch refills it
     }
     __syncthreads();
     float *grid = grids + (size_t)g * bins * plane;
@@ -461,10 +499,14 @@ extern "C" int ramnet_msg_loss_bwd(const float *ws, const double *stats, const f
 }
 
 // rows of a band: as many as 160 KB of LDS hold for all bins (0: a single row does not fit -> global-atomic form)
-static int voxel_band_rows(int bins, int W, int H) {
-    static const char *e = getenv("RAMNET_VOXEL_BANDS");                    // tuning / A-B knob: 0 = global-atomic form
-    if (e && e[0] == '0') return 0;
-    const long long cap = (160 * 1024 - 512) / 4;
+static int voxel_band_rows(int bins, int W, int H, int n_grids) {
+    // A band workgroup re-reads the whole list of its grid (H / rows = 12 bands at 260 x 346 x 5 bins): at full chip width that is
+    // Infinity-Cache bandwidth (8 M events: 514 us against 858 us for the atomic form, 0.11 against 0.066 of the HBM roofline), but
+    // a launch of a few grids leaves most CUs idle while every workgroup still walks 6.4 MB (5 grids: 283 us against 99 us) -> the
+    // atomic form below for small launches.  What would lift both: a counting / partition pass so that a band reads only its own
+    // events (96 instead of 384 bytes of traffic per event) — not built.
+    if (n_grids < 16) return 0;
+    const long long cap = (160 * 1024 - 512) / 4 - (4096 + 2);      // floats left for the band beside the hit queue
     long long rows = cap / ((long long)bins * W);
     if (rows > H) rows = H;
     return (int)rows;
@@ -473,8 +515,9 @@ static int voxel_band_rows(int bins, int W, int H) {
 static int launch_voxel_bands(const double *events, const long long *offsets, long long n_single, int n_grids, int bins, int W, int H,
                               int rows, float *grids, hipStream_t st) {
     RAMNET_FULL_LDS(voxelize_bands_kernel);
-    const size_t lds = (size_t)bins * rows * W * sizeof(float);
-    hipLaunchKernelGGL(voxelize_bands_kernel, dim3(cdiv(H, rows), n_grids), dim3(1024), lds, st, events, offsets, n_single, bins, W, H, rows, grids);
+    const size_t lds = ((size_t)bins * rows * W + 4096 + 2) * sizeof(float);
+    hipLaunchKernelGGL(voxelize_bands_kernel, dim3(8 * cdiv(n_grids, 8) * cdiv(H, rows)), dim3(1024), lds, st, events, offsets, n_single,
+                       n_grids, bins, W, H, rows, grids);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
@@ -482,7 +525,7 @@ static int launch_voxel_bands(const double *events, const long long *offsets, lo
 extern "C" int ramnet_voxelize(const double *events, size_t n_events, int bins, int W, int H, float *grid, void *stream) {
     RAMNET_CHECK_ARG(grid && bins > 0 && W > 0 && H > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int rows = voxel_band_rows(bins, W, H);
+    const int rows = voxel_band_rows(bins, W, H, 1);
     if (rows > 0 && (events != nullptr || n_events == 0)) return launch_voxel_bands(events, nullptr, (long long)n_events, 1, bins, W, H, rows, grid, st);
     RAMNET_HIP(hipMemsetAsync(grid, 0, (size_t)bins * W * H * sizeof(float), st));
     if (n_events == 0) return 0;
@@ -496,7 +539,7 @@ extern "C" int ramnet_voxelize_batch(const double *events, const long long *offs
                                      int H, float *grids, void *stream) {
     RAMNET_CHECK_ARG(grids && offsets && n_grids > 0 && n_grids <= 65535 && bins > 0 && W > 0 && H > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int rows = voxel_band_rows(bins, W, H);
+    const int rows = voxel_band_rows(bins, W, H, n_grids);
     if (rows > 0 && (events != nullptr || max_events == 0)) return launch_voxel_bands(events, offsets, 0, n_grids, bins, W, H, rows, grids, st);
     RAMNET_HIP(hipMemsetAsync(grids, 0, (size_t)n_grids * bins * W * H * sizeof(float), st));
     if (max_events == 0) return 0;

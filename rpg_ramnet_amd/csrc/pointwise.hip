@@ -637,9 +637,7 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
     RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
     if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
     int g = grid_for(npix * 8);      // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups
-    static const char *ge = getenv("RAMNET_PRED_BWD_BLOCKS");
-    const int cap = ge ? atoi(ge) : 512;
-    if (g > cap && cap >= 1) g = cap;
+    if (g > 512) g = 512;
     hipLaunchKernelGGL(pred_sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, dx, lddx, dw, db, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;

@@ -9,8 +9,6 @@ replays them with one host call:
 
 * ``GraphedStream``    — asynchronous inference with a persistent multi-scale state: one graph per (modality update + decode),
                          state kept in static device buffers (test.py:212-232 call pattern; configs[3]).
-* ``StreamPipeline``   — the same stream as a three-stage pipeline over consecutive measurements (encoders of k+1, state updates
-                         of k as parallel branches, decodes of k-1 / k-2 on alternating streams): the throughput runtime.
 * ``TimeBatchedStream`` — a recorded stream in groups of consecutive measurements: encoders and decoders of a group at batch n / n+1
                          (they do not depend on the order of the updates), the state updates one by one per scale.
 * ``GraphedPackage``   — one data package, K event updates + 1 frame update + K+1 decodes (model.py:176-219), state carried.
@@ -48,16 +46,17 @@ class GraphedStream:
     occupied each (a dozen workgroups per launch), so they overlap almost freely.  Predictions are then valid on the caller's
     stream after ``wait(pred)`` (an event wait, no host sync) and until the second-next update overwrites the buffer."""
 
-    def __init__(self, model, B, H, W, pipelined=False, branches=True):
+    def __init__(self, model, B, H, W, pipelined=False, branches=False):
         """branches: capture the state updates of the three scales as parallel branches of the update graph (they are mutually
-        independent, ops.set_branch_overlap) — the graph's critical path is then head + encoders + ONE state update."""
+        independent, ops.set_branch_overlap).  Off by default: measured no gain at batch 1 (the hipGraph executor does not run the
+        branches side by side), and on ROCm 7.2 a graph recorded with such forks left the NEXT capture of the process crashing at
+        replay (tests/test_hip_graph.py order: GraphedStream, then GraphedPackage) — TimeBatchedStream uses one
+        graph per chain on a HIP stream of its own instead."""
         assert not bool(model.baseline), "streaming graphs are built for the asynchronous RAM-Net (not the baselines)"
         self.model, dev = model, model.gpu
         self.pipelined = pipelined
-        import os
-        branches = bool(branches) and os.environ.get("RAMNET_STREAM_BRANCHES", "1") == "1"
         branch0 = ops.branch_overlap()
-        ops.set_branch_overlap(branches)
+        ops.set_branch_overlap(bool(branches))
         self.ev_in = torch.zeros(B, model.num_bins_events, H, W, device=dev)
         self.im_in = torch.zeros(B, model.num_bins_rgb, H, W, device=dev)
         self.sets = [model.init_states(B, H, W), model.init_states(B, H, W)]
@@ -142,152 +141,6 @@ class GraphedStream:
         return pred
 
 
-class StreamPipeline:
-    """Throughput runtime for asynchronous inference over a recorded stream (test.py:205-232 walks a dataset: every measurement is
-    known in advance): consecutive measurements run as a three-stage software pipeline of hipGraph replays on four HIP streams,
-
-        E: input repack + head + the three strided encoders of measurement k+1     (they do not depend on the state),
-        G: the three state updates of measurement k as parallel graph branches      (statenet.py:215-237: x chains, states do not),
-        D0 / D1 (alternating): residual blocks + decoders + prediction for measurement k-1 / k-2,
-
-    so the period per update+decode is the longest stage instead of the sum of the 30 launches of the chain.  At batch 1 every
-    launch of the chain occupies a fraction of the chip (44-350 workgroups for 256 CUs), which is what leaves room for four
-    chains side by side.  States rotate through `sets` static buffer sets (update k reads set k % sets, writes the next one; a set
-    is overwritten only after the decode that reads it has finished: event waits, no host sync), so a previous state is never
-    modified in place — results are bit-identical to update_events / update_image / decode called one by one.
-    Predictions are static buffers: valid on the caller's stream after ``wait(pred)`` and until `sets` further updates."""
-
-    def __init__(self, model, B, H, W, sets=3):
-        assert not bool(model.baseline) and model.recurrent_block_type == "conv", "pipeline: asynchronous RAM-Net with conv encoders"
-        assert sets >= 3
-        self.model, self.N, dev = model, sets, model.gpu
-        net = model.statenetphasedrecurrent
-        self.inp = {"events": [torch.zeros(B, model.num_bins_events, H, W, device=dev) for _ in range(sets)],
-                    "image": [torch.zeros(B, model.num_bins_rgb, H, W, device=dev) for _ in range(sets)]}
-        self.sets = [model.init_states(B, H, W) for _ in range(sets)]
-        self.E, self.G = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        self.D = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        self.enc, self.gru, self.dec, self.feat, self.pred = {}, {}, [None] * sets, {}, [None] * sets
-        was_training = model.training
-        model.eval()
-        n = net.num_encoders
-
-        def flat(s_):
-            return list(s_) if isinstance(s_, (list, tuple)) else [s_]
-
-        for kind, head, encoders, combs in (("events", net.head_events, net.encoders_events, net.state_combination_events),
-                                            ("image", net.head_rgb, net.encoders_rgb, net.state_combination_images)):
-            for slot in range(sets):
-                def enc_stage(kind=kind, slot=slot, head=head, encoders=encoders):
-                    with torch.no_grad():
-                        x = head(ops.pack_input(self.inp[kind][slot], dev))
-                        feats = []
-                        for e in encoders:
-                            x = e(x)
-                            feats.append(x)
-                    return feats
-                _warm(enc_stage)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.feat[(kind, slot)] = enc_stage()
-                self.enc[(kind, slot)] = g
-
-                def gru_stage(kind=kind, slot=slot, combs=combs):
-                    feats, src, dst = self.feat[(kind, slot)], self.sets[slot], self.sets[(slot + 1) % sets]
-                    main = torch.cuda.current_stream()
-                    sides = []
-                    with torch.no_grad():
-                        for i in range(n):
-                            st = main
-                            if i < n - 1:           # the scales are independent: all but the last as parallel branches
-                                st = ops.branch_stream(dev, i)
-                                st.wait_stream(main)
-                                sides.append(st)
-                            with torch.cuda.stream(st):
-                                _, new = combs[i](feats[i], src[i])
-                                for d, t in zip(flat(dst[i]), flat(new)):
-                                    d.copy_(t)
-                    for st in sides:
-                        main.wait_stream(st)
-                _warm(gru_stage)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    gru_stage()
-                self.gru[(kind, slot)] = g
-        branch0 = ops.branch_overlap()
-        ops.set_branch_overlap(True)            # decoder border path beside the padded sum (ops._folded_upsample_conv)
-        for slot in range(sets):
-            def dec_stage(slot=slot):
-                with torch.no_grad():
-                    return model.decode(self.sets[slot])
-            _warm(dec_stage)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.pred[slot] = dec_stage()
-            self.dec[slot] = g
-        ops.set_branch_overlap(branch0)
-        model.train(was_training)
-        self.reset()
-
-    def reset(self):
-        torch.cuda.synchronize(self.model.gpu)
-        for st in self.sets:
-            for s_ in st:
-                for t in (s_ if isinstance(s_, (list, tuple)) else [s_]):
-                    t.zero_()
-        self.k = 0
-        self.gru_done = [None] * self.N          # event behind the state update that used slot i (its features and source set)
-        self.dec_done = [None] * self.N          # event behind the decode that read set i (and wrote prediction buffer i)
-
-    @property
-    def states(self):
-        """The current multi-scale state (static buffers; valid after wait())."""
-        return self.sets[self.k % self.N]
-
-    def _step(self, kind, data):
-        N, k = self.N, self.k
-        s, d = k % N, (k + 1) % N
-        cur = torch.cuda.current_stream()
-        E, G, D = self.E, self.G, self.D[k % 2]
-        E.wait_stream(cur)                                   # `data` was produced on the caller's stream
-        if self.gru_done[s] is not None:                     # the update that still reads this slot's features
-            E.wait_event(self.gru_done[s])
-        with torch.cuda.stream(E):
-            self.inp[kind][s].copy_(data, non_blocking=True)
-            self.enc[(kind, s)].replay()
-            enc_done = E.record_event()
-        if torch.is_tensor(data) and data.is_cuda:
-            data.record_stream(E)
-        G.wait_event(enc_done)
-        if self.dec_done[d] is not None:                     # the decode that still reads the set this update overwrites
-            G.wait_event(self.dec_done[d])
-        with torch.cuda.stream(G):
-            self.gru[(kind, s)].replay()
-            self.gru_done[s] = G.record_event()
-        D.wait_event(self.gru_done[s])
-        if self.dec_done[d] is not None:                     # the other decode stream wrote this prediction buffer N updates ago
-            D.wait_event(self.dec_done[d])
-        with torch.cuda.stream(D):
-            self.dec[d].replay()
-            self.dec_done[d] = D.record_event()
-        self.k = k + 1
-        return self.pred[d]
-
-    def update_events(self, grid):
-        return self._step("events", grid)
-
-    def update_image(self, frame):
-        return self._step("image", frame)
-
-    def wait(self, pred=None):
-        """Make the caller's stream wait for everything in flight (updates and decodes); returns `pred`."""
-        cur = torch.cuda.current_stream()
-        for e in self.gru_done + self.dec_done:
-            if e is not None:
-                cur.wait_event(e)
-        return pred
-
-
 class TimeBatchedStream:
     """Throughput runtime for a recorded asynchronous stream that exploits what RAM-Net's wiring allows and the reference's loop
     (test.py:205-232, model.py:176-195) does not: only the state updates are sequential in time.
@@ -302,7 +155,8 @@ class TimeBatchedStream:
     At batch 1 a launch of this path occupies 44-350 workgroups of a 256-CU chip and is bound by the latency of its own chain;
     batching over time gives the encoder and decoder launches the grid sizes (and the efficiency) of the training shapes and
     takes 2/3 of the launches off the critical path.  Groups are pipelined: encoders of group g+1 | updates of group g | decodes
-    of group g-1 (hipGraph replays on four HIP streams, two buffer parities, event waits — no host sync).
+    of group g-1 (hipGraph replays — one graph per chain, each on a HIP stream of its own: encoders, one update chain per scale,
+    two alternating decode streams —, two buffer parities, event waits, no host sync).
     Results are bit-identical to update_events / update_image / decode called one by one (every kernel computes a batch element
     independently of the others).  ``push_events`` buffers a grid, ``push_image`` buffers the frame and closes the group,
     ``flush`` closes a group without a frame; both return the group's predictions [n (+1), B, 1, H, W] as a static buffer that
@@ -321,7 +175,8 @@ class TimeBatchedStream:
         def batched(s_):
             return [torch.zeros((T * B,) + tuple(t.shape[1:]), device=dev) for t in s_] if self.pair else torch.zeros((T * B,) + tuple(s_.shape[1:]), device=dev)
         self.S = [[batched(s_) for s_ in self.carry] for _ in range(2)]
-        self.SE, self.SG = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.SE = torch.cuda.Stream(device=dev)
+        self.SG = [torch.cuda.Stream(device=dev) for _ in range(net.num_encoders)]       # one update chain per scale
         self.SD = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.graphs, self.feat, self.pred = {}, {}, {}
         self.reset()
@@ -349,30 +204,21 @@ class TimeBatchedStream:
         B = self.B
         return [t[j * B:(j + 1) * B] for t in s_] if self.pair else s_[j * B:(j + 1) * B]
 
-    def _upd(self, n, f, p):
-        net, B, dev = self.net, self.B, self.model.gpu
+    def _upd(self, n, f, p, i):
+        """The n + f state updates of scale i, one by one (the recurrence of a scale involves that scale only): each writes its
+        new state into slot j of the batched state buffer, the last one is copied into the carried state."""
+        net, B = self.net, self.B
         fe, fi = self.feat[(n, f, p)]
-        main = torch.cuda.current_stream()
-        sides = []
         with torch.no_grad():
-            for i in range(net.num_encoders):
-                st = main
-                if i < net.num_encoders - 1:            # the recurrence of a scale involves that scale only
-                    st = ops.branch_stream(dev, i)
-                    st.wait_stream(main)
-                    sides.append(st)
-                with torch.cuda.stream(st):
-                    h = self.carry[i]
-                    for j in range(n + f):
-                        comb = net.state_combination_events[i] if j < n else net.state_combination_images[i]
-                        x = fe[i][j * B:(j + 1) * B] if j < n else fi[i]
-                        dst = self._slot(self.S[p][i], j)
-                        comb(x, h, dst)
-                        h = dst
-                    for d, t in zip(self.carry[i] if self.pair else [self.carry[i]], h if self.pair else [h]):
-                        d.copy_(t)
-        for st in sides:
-            main.wait_stream(st)
+            h = self.carry[i]
+            for j in range(n + f):
+                comb = net.state_combination_events[i] if j < n else net.state_combination_images[i]
+                x = fe[i][j * B:(j + 1) * B] if j < n else fi[i]
+                dst = self._slot(self.S[p][i], j)
+                comb(x, h, dst)
+                h = dst
+            for d, t in zip(self.carry[i] if self.pair else [self.carry[i]], h if self.pair else [h]):
+                d.copy_(t)
 
     def _dec(self, n, f, p):
         m = (n + f) * self.B
@@ -386,23 +232,23 @@ class TimeBatchedStream:
         torch.cuda.synchronize(self.model.gpu)
         was_training = self.model.training
         self.model.eval()
-        branch0 = ops.branch_overlap()
-        ops.set_branch_overlap(True)                # decoder border path beside the padded sum
         flat = [t for s_ in self.carry for t in (s_ if self.pair else [s_])]
         saved = [t.clone() for t in flat]
+        stages = [(lambda: self._enc(n, f, p), self.feat)]
+        stages += [(lambda i=i: self._upd(n, f, p, i), None) for i in range(self.net.num_encoders)]      # one graph per scale
+        stages += [(lambda: self._dec(n, f, p), self.pred)]
         gs = []
-        for stage, store in ((self._enc, self.feat), (self._upd, None), (self._dec, self.pred)):
-            _warm(lambda: stage(n, f, p))
+        for stage, store in stages:
+            _warm(stage)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = stage(n, f, p)
+                out = stage()
             if store is not None:
                 store[key] = out
             gs.append(g)
         for t, v in zip(flat, saved):
             t.copy_(v)
         torch.cuda.synchronize(self.model.gpu)
-        ops.set_branch_overlap(branch0)
         self.model.train(was_training)
         self.graphs[key] = gs
 
@@ -423,8 +269,8 @@ class TimeBatchedStream:
         """First measurement of a group: its input and feature buffers are free once the updates of the group two back are done."""
         if not self.opened:
             self.SE.wait_stream(torch.cuda.current_stream())
-            if self.g_done[self.p] is not None:
-                self.SE.wait_event(self.g_done[self.p])
+            for e in self.g_done[self.p] or ():
+                self.SE.wait_event(e)
             self.opened = True
 
     def push_events(self, grid):
@@ -460,18 +306,23 @@ class TimeBatchedStream:
             self._capture(key)
             self.opened = False
             self._open()
-        ge, gg, gd = self.graphs[key]
+        gs = self.graphs[key]
+        ge, gd = gs[0], gs[-1]
         with torch.cuda.stream(self.SE):
             ge.replay()
             e_done = self.SE.record_event()
-        self.SG.wait_event(e_done)
-        if self.d_done[p] is not None:                   # the decode that still reads this parity's batched states
-            self.SG.wait_event(self.d_done[p])
-        with torch.cuda.stream(self.SG):
-            gg.replay()
-            self.g_done[p] = self.SG.record_event()
+        done = []
+        for SG, gg in zip(self.SG, gs[1:-1]):
+            SG.wait_event(e_done)
+            if self.d_done[p] is not None:               # the decode that still reads this parity's batched states
+                SG.wait_event(self.d_done[p])
+            with torch.cuda.stream(SG):
+                gg.replay()
+                done.append(SG.record_event())
+        self.g_done[p] = done
         D = self.SD[p]
-        D.wait_event(self.g_done[p])
+        for e in done:
+            D.wait_event(e)
         with torch.cuda.stream(D):
             gd.replay()
             self.d_done[p] = D.record_event()
@@ -481,7 +332,7 @@ class TimeBatchedStream:
     def wait(self, pred=None):
         """Make the caller's stream wait for everything in flight; returns `pred`."""
         cur = torch.cuda.current_stream()
-        for e in self.g_done + self.d_done:
+        for e in [x for g in self.g_done for x in (g or ())] + self.d_done:
             if e is not None:
                 cur.wait_event(e)
         return pred

@@ -19,7 +19,7 @@ _NULL = None
 # 3x3 stride-1 layers (ConvGRU gates / candidate, residual blocks) run Winograd F(2x2,3x3) in fp32 — 2.25x fewer
 # multiplies, rounding error ~1e-6 relative (tests/test_hip_ops.py) — unless switched off (RAMNET_WINOGRAD=0).
 _WINOGRAD = _os.environ.get("RAMNET_WINOGRAD", "1") == "1"
-_WINO_MIN_CIN = int(_os.environ.get("RAMNET_WINOGRAD_MIN_CIN", "32"))
+_WINO_MIN_CIN = 32        # smallest reduction depth that uses the Winograd kernels
 
 
 def set_winograd(on):
@@ -38,9 +38,9 @@ _FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
 
 
 _FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
-_FOLD_WINO_MIN_COUT = int(_os.environ.get("RAMNET_FOLD_WINOGRAD_MIN_COUT", "32"))
+_FOLD_WINO_MIN_COUT = 32
 _FOLD_WINO_WGRAD = _os.environ.get("RAMNET_FOLD_WINOGRAD_WGRAD", "1") == "1"
-_SAVE_XPAD = _os.environ.get("RAMNET_SAVE_XPAD", "0") == "1"      # keep pad2(x + skip) of a folded decoder layer for its backward (+2 GB, no measurable gain: off)
+_SAVE_XPAD = False         # keep pad2(x + skip) of a folded decoder layer for its backward: +2 GB, no measurable gain
 
 
 def set_fold_winograd_wgrad(on):
@@ -50,10 +50,16 @@ def set_fold_winograd_wgrad(on):
     _FOLD_WINO_WGRAD = bool(on)
 
 
+def _fold_pair(Cout, Cin):
+    """32-channel layers (the last decoder): both column parities of a row parity in one 64-column workgroup that shares the
+    transformed input (conv_wino24_kernel<.., PAIR>); RAMNET_FOLD_PAIR=0 keeps the 64-tile x 32-channel form."""
+    return Cout == 32 and Cin % 32 == 0 and _os.environ.get("RAMNET_FOLD_PAIR", "1") != "0"
+
+
 def _fold_wino_ok(Cin, Cout):
-    """conv_wino24_kernel shapes: 64-channel workgroups with chunks of 16, else 32-channel ones with chunks of 8; an even
+    """conv_wino24_kernel shapes: 64-column workgroups with chunks of 16, else 32-channel ones with chunks of 8; an even
     number of chunks."""
-    kc = 16 if (Cout % 64 == 0 and Cin % 16 == 0) else 8
+    kc = 16 if ((Cout % 64 == 0 and Cin % 16 == 0) or _fold_pair(Cout, Cin)) else 8
     return Cout % 32 == 0 and Cout >= _FOLD_WINO_MIN_COUT and Cin % (2 * kc) == 0
 
 
@@ -283,7 +289,7 @@ def decoder_overlap():
 def decode_stream(dev):
     st = _DECODE.get(dev)
     if st is None:
-        st = _DECODE[dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("RAMNET_DECODE_PRIORITY", "0")))
+        st = _DECODE[dev] = torch.cuda.Stream(device=dev)
     _DECODE_USED.add(dev)
     return st
 
@@ -294,7 +300,7 @@ def decode_stream(dev):
 # on a stream of its own (forked behind its encoder, joined at the end of the update): at batch 1 a launch fills a fraction of
 # the chip, and the critical path of an update shrinks from head + 3 encoders + 6 state launches to head + 3 encoders + 2.
 _BRANCH = {}
-_USE_BRANCH = _os.environ.get("RAMNET_BRANCH_STREAMS", "0") == "1"
+_USE_BRANCH = False
 
 
 def set_branch_overlap(on):
@@ -316,7 +322,7 @@ def branch_stream(dev, i):
 def _side_stream(dev):
     st = _SIDE.get(dev)
     if st is None:
-        st = _SIDE[dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("RAMNET_WGRAD_PRIORITY", "0")))
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)       # (a lower stream priority measured no effect)
     return st
 
 
@@ -429,6 +435,9 @@ def fold_weights_wino(w):
 def pack_fold_wino(w):
     """fold_weights_wino() in the lane order of conv_wino24_kernel's B operand (layout: include/ramnet_hip.h)."""
     Cout, Cin = w.shape[0], w.shape[1]
+    if _fold_pair(Cout, Cin):       # class = row parity py, the workgroup's 64 columns = (column parity px, 32 channels)
+        u = fold_weights_wino(w).float().view(2, 2, 25, Cin, 32).permute(0, 2, 3, 1, 4).reshape(2, 25, Cin // 16, 4, 4, 1, 4, 16)
+        return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)
     kc, ncq = (16, 4) if (Cout % 64 == 0 and Cin % 16 == 0) else (8, 2)     # chunk size, 16-channel groups per workgroup
     u = fold_weights_wino(w).float().view(4, 25, Cin // kc, 4, kc // 4, Cout // (16 * ncq), ncq, 16)      # cls pos chunk ks j nb cq l15
     return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)                                       # cls chunk nb pos cq ks l15 j
@@ -853,10 +862,10 @@ def _s2d_eligible(x, cp, k, stride, up):
 
 
 # The space-to-depth view is read / written in place by the Winograd kernels (RAMNET_IN_S2D loader, out_s2d epilogue) when
-# the channel count is a power of two >= 32; RAMNET_S2D_FUSED=0 materialises it with ramnet_space_to_depth2 instead.
-_S2D_FUSED = _os.environ.get("RAMNET_S2D_FUSED", "1") == "1"
-# ... and skip the Winograd positions that the zero slices of that view annihilate (ramnet_conv_desc.s2d_5x5); RAMNET_S2D_SPARSE=0: dense
-_S2D_SPARSE = _os.environ.get("RAMNET_S2D_SPARSE", "1") == "1"
+# the channel count is a power of two >= 32; ops.set_space_to_depth_fused(False) materialises it with ramnet_space_to_depth2 instead.
+_S2D_FUSED = True
+# ... and skip the Winograd positions that the zero slices of that view annihilate (ramnet_conv_desc.s2d_5x5)
+_S2D_SPARSE = True
 
 
 def set_space_to_depth_fused(on):

@@ -451,6 +451,12 @@ def test_winograd_f2x2_4x4_algebra_cpu():
     for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 31, 63), (2, 7, 21, 37), (1, 13, 6, 50)]:
         idx = ((((cls * 2 + k // 16) * 1 + n // 64) * 25 + pos) * 4 + (n % 64) // 16) * 256 + (((k % 16) // 4) * 16 + n % 16) * 4 + k % 4
         assert packed[idx] == U2[cls, pos, k, n]
+    w4 = torch.randn(32, 64, 5, 5)                                 # 32-channel layer, Cin % 32 == 0: pair layout — class = row parity,
+    packed, U4 = ops.pack_fold_wino(w4), ops.fold_weights_wino(w4).float()      # column = (column parity, channel), chunks of 16
+    for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 63, 31), (2, 7, 21, 17), (1, 13, 38, 5)]:
+        py, col = cls >> 1, (cls & 1) * 32 + n
+        idx = (((py * 4 + k // 16) * 25 + pos) * 4 + col // 16) * 256 + (((k % 16) // 4) * 16 + col % 16) * 4 + k % 4
+        assert packed[idx] == U4[cls, pos, k, n]
     w3 = torch.randn(32, 24, 5, 5)                                 # 32-channel layers: chunks of 8, two 16-channel groups
     packed, U3 = ops.pack_fold_wino(w3), ops.fold_weights_wino(w3).float()
     for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 23, 31), (2, 7, 13, 17)]:

@@ -233,7 +233,7 @@ def test_config1_training_step_full_resolution_vs_oracle(bench_schedule):
 
 
 def test_config4_shape_training_step_vs_oracle(bench_schedule):
-    """BASELINE configs[4] shape: 640x480, 10-bin voxel grids (the 10-channel head runs the generic kernels), 20 % NaN targets;
+    """BASELINE configs[4] shape: 640x480, 10-bin voxel grids (the 10-channel head runs conv_head_*<10> since round 3), 20 % NaN targets;
     B=1, K=2, L=2 keeps the oracle to seconds."""
     cfg, _ = ref_cfg("net_seeded_ramnet_bins10.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
     assert cfg["num_bins_events"] == 10

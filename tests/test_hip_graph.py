@@ -219,53 +219,6 @@ def test_branch_streams_equal_serial_updates():
                 assert torch.equal(u, v)
 
 
-@pytest.mark.parametrize("tag", ["net_seeded_ramnet.npz", "net_seeded_ramnet_lstm.npz"])
-def test_stream_pipeline_equals_eager_primitives(tag):
-    """graph.StreamPipeline (encoders of k+1 | state updates of k as parallel branches | decodes of k-1, k-2 on alternating
-    streams, three rotating state sets) over an irregular schedule == update_events / update_image / decode one by one, bit
-    for bit — once with a wait after every update, once back to back (the stages of consecutive measurements really overlap)."""
-    from rpg_ramnet_amd.graph import StreamPipeline
-    cfg, _ = ref_cfg(tag)
-    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
-    B, H, W = 1, 64, 96
-    sp = StreamPipeline(model, B, H, W)
-    rng = np.random.default_rng(6)
-    keys = []
-    for n_ev in (2, 0, 3, 1, 5):
-        keys += ["events"] * n_ev + ["image"]
-    data = [torch.from_numpy((rng.standard_normal((B, 5, H, W)) if k == "events" else rng.random((B, 1, H, W))).astype(np.float32)).to(model.gpu)
-            for k in keys]
-    want, st = [], model.init_states(B, H, W)
-    with torch.no_grad():
-        for k, x in zip(keys, data):
-            st, _ = (model.update_events if k == "events" else model.update_image)(x, st)
-            want.append(model.decode(st).clone())
-    torch.cuda.synchronize()
-
-    def flat(s):
-        return [t for u in s for t in (u if isinstance(u, (list, tuple)) else [u])]
-
-    for mode in ("serial", "back_to_back"):
-        sp.reset()
-        got, pending = [], []
-        for k, x in zip(keys, data):
-            p = (sp.update_events if k == "events" else sp.update_image)(x)
-            if mode == "serial":
-                got.append(sp.wait(p).clone())
-            else:
-                pending.append(p)
-                if len(pending) == 2:                    # a prediction buffer stays intact for `sets` = 3 further updates
-                    got.append(sp.wait(pending.pop(0)).clone())
-        got += [sp.wait(p).clone() for p in pending]
-        torch.cuda.synchronize()
-        assert len(got) == len(want)
-        for i, (a, b) in enumerate(zip(got, want)):
-            assert torch.equal(a, b), "%s: prediction %d (%s)" % (mode, i, keys[i])
-        sp.wait()
-        for a, b in zip(flat(sp.states), flat(st)):
-            assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("tag,B", [("net_seeded_ramnet.npz", 1), ("net_seeded_ramnet_lstm.npz", 2)])
 def test_time_batched_stream_equals_eager_primitives(tag, B):
     """graph.TimeBatchedStream: the encoders of the event grids up to the next frame at batch n, the n + 1 decodes as one batched

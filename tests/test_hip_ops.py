@@ -412,6 +412,31 @@ def test_voxel_grids_batched_equals_per_grid():
         np.testing.assert_allclose(gn.cpu().numpy(), voxel_ref.normalize_nonzero(ref), rtol=1e-4, atol=2e-5)
 
 
+def test_voxel_row_band_kernel_equals_oracle():
+    """Launches of >= 16 grids run the row-band kernel (votes resolved in LDS, every cell written once, no zero-fill): 20 ragged
+    lists at the real sensor size (260 x 346: 12 bands, the last one partial) incl. an empty list, a single event, events on the
+    last row / column, the band boundaries, polarity 0 and fractional coordinates — against the oracle per grid, and against the
+    global-atomic form (the per-grid entry point)."""
+    from recipe import synth_events
+    from rpg_ramnet_amd import voxel
+    rng = np.random.default_rng(18)
+    W, H, bins = 346, 260, 5
+    sizes = [30000, 1, 0, 777, 20000, 5, 4096, 4097, 8191, 12345] + [3000] * 10
+    lists = [synth_events(rng, n, W, H) for n in sizes]
+    lists[3][:7, 1] = W - 1
+    lists[3][:7, 2] = H - 1                    # last row / column
+    lists[3][7:11, 2] = [0.0, 22.0, 23.0, 259.0]                # band boundaries (23 rows per band)
+    lists[4][:4, 2] = [-0.5, 0.5, 22.9, 259.5]                  # (long long)y truncates towards zero: -0.5 is row 0
+    lists[4][5:7, 1] = [345.9, 0.4]
+    assert len(lists) >= 16
+    got = voxel.events_to_voxel_grids([torch.from_numpy(e).to(dev()) for e in lists], bins, W, H)
+    for i, (g, ev) in enumerate(zip(got, lists)):
+        ref = voxel_ref.events_to_voxel_grid(ev, bins, W, H) if len(ev) else np.zeros((bins, H, W), np.float32)
+        np.testing.assert_allclose(g.cpu().numpy(), ref, atol=2e-5, err_msg="grid %d vs oracle" % i)
+        one = voxel.events_to_voxel_grid(torch.from_numpy(ev).to(dev()), bins, W, H)
+        np.testing.assert_allclose(g.cpu().numpy(), one.cpu().numpy(), atol=2e-5, err_msg="grid %d vs the atomic form" % i)
+
+
 @pytest.mark.parametrize("B,H,W,nan_frac", [(2, 32, 48, 0.0), (3, 24, 40, 0.2), (1, 16, 16, 0.5)])
 def test_multi_scale_grad_loss_vs_oracle(B, H, W, nan_frac):
     """Next-row component.  PARITY UNPINNED against kornia itself; checked against the oracle restatement
