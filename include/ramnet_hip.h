@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 12
+#define RAMNET_ABI_VERSION 13      /* 13: pair layout of ramnet_pack_weight_fold_wino for 32-channel layers; head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -28,7 +28,7 @@ extern "C" {
 enum ramnet_in_mode {
     RAMNET_IN_PLAIN = 0,     /* x0[C0]                                                          */
     RAMNET_IN_CAT = 1,       /* cat(x0[C0], x1[C1])            ConvGRU/ConvLSTM  submodules.py:343,447 */
-    RAMNET_IN_CAT_MUL = 2,   /* cat(x0[C0], x1[C1] * xm[C1])   ConvGRU candidate submodules.py:450  */
+    RAMNET_IN_CAT_MUL = 2,   /* cat(x0[C0], x1[C1] * xm[C1])   ConvGRU candidate submodules.py:450; WINOGRAD: C0 = 0 allowed (input = x1 * xm) */
     RAMNET_IN_UP2X = 3,      /* bilinear x2 (align_corners=False) of x0          submodules.py:88   */
     RAMNET_IN_UP2X_SKIP = 4, /* bilinear x2 of (x0 + x1)       decoder skip sum  statenet.py:305-308 */
     RAMNET_IN_RELUMASK = 5,  /* x0 * (xm > 0)                  backward through a ReLU             */
@@ -86,7 +86,7 @@ typedef struct ramnet_conv_desc {
     int HoF, WoF;                   /* full output tensor extent                                    */
     int osy, osx, ooy, oox;         /* output pixel = (a*osy+ooy, b*osx+oox)                        */
     int epi;
-    float beta;                     /* pre-activation += beta*out_old (LINEAR and RELU; 0 = overwrite), see `frame` */
+    float beta;                     /* pre-activation += beta*out_old (LINEAR, RELU, SIGMOID, GRU_BLEND; 0 = overwrite), see `frame` */
     const float *e0, *e1;           /* epilogue operands                                            */
     int lde0, lde1;
     float *out, *o1, *o2;
@@ -158,12 +158,15 @@ int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, i
 /* Folded upsample-conv (RAMNET_ALGO_WINOGRAD24): OIHW 5x5 weights of an UpsampleConvLayer (submodules.py:69-97) -> Winograd-domain
  * weights of the four 4x4 parity filters in the kernel's layout (see ramnet_algo above); 100*Cout*Cin floats.
  * ramnet_fold_wino_supported: Cout % 32 == 0 and an even number of input-channel chunks (Cin % 32 == 0, or Cin % 16 == 0 with
- * 32-channel workgroups).                                                                                     */
+ * 32-channel workgroups).  ABI 13: a layer with Cout == 32 and Cin % 32 == 0 is packed in the PAIR layout — class = row parity
+ * py (2 classes), the workgroup's 64 columns = (column parity px, channel): [py][Cin/16][25 positions][4 column groups of 16]
+ * [64 lanes][4] — and launched with both column parities in one workgroup sharing the transformed input (RAMNET_FOLD_PAIR=0 in
+ * the environment of BOTH packer and launcher restores the [4 classes] x 32-channel layout).                    */
 int ramnet_fold_wino_supported(int Cout, int Cin);
 size_t ramnet_packed_weight_elems_fold_wino(int Cout, int Cin);
 int ramnet_pack_weight_fold_wino(const float *w_oihw, float *wp, int Cout, int Cin, void *stream);
 /* Head layers (RAMNET_ALGO_HEAD): OIHW [Cout<=32][Cin][5][5] -> [25*Cin rounded up to even][32], row = tap*Cin + channel.
- * ramnet_head_supported: does the head kernel serve this channel pair (Cin in {1,3,5}, Cout <= 32)?              */
+ * ramnet_head_supported: does the head kernel serve this channel pair (Cin in {1,3,5,10}, Cout <= 32)?           */
 size_t ramnet_packed_weight_elems_head(int Cin);
 int ramnet_head_supported(int Cin, int Cout);
 int ramnet_pack_weight_head(const float *w_oihw, float *wp, int Cout, int Cin, void *stream);
@@ -263,7 +266,7 @@ int ramnet_msg_loss_bwd(const float *ws, const double *stats, const float *gscal
                         float *dws, float *dpred, void *stream);
 
 /* ---- event -> voxel grid: utils/event_tensor_utils.py:120-187, :52-66 ----------------------- */
-/* events: [N,4] float64 rows (t,x,y,p) sorted by t, on device.  grid [bins,H,W] fp32 is zeroed here. */
+/* events: [N,4] float64 rows (t,x,y,p) sorted by t, on device (16-byte aligned).  grid [bins,H,W] fp32: every cell is written. */
 int ramnet_voxelize(const double *events, size_t n_events, int bins, int W, int H, float *grid, void *stream);
 /* same index arithmetic, but emits the int64 flat indices (or -1) for bit-exactness tests.        */
 int ramnet_voxel_indices(const double *events, size_t n_events, int bins, int W, int H,
@@ -273,7 +276,8 @@ int ramnet_normalize_nonzero(float *grid, size_t n, double *scratch, void *strea
 /* Batched forms (one launch for the B x K grids of a batch of packages): event lists concatenated in `events`, list g =
  * rows offsets[g] .. offsets[g+1] (device int64 [n_grids+1]; each list sorted by t, normalised by ITS first / last stamp),
  * max_events = longest list; grids [n_grids][bins][H][W] (zeroed here).  normalize: n = bins*H*W (multiple of 4) per grid,
- * scratch = 3*n_grids doubles.  Same arithmetic per grid as the single-grid entry points.                             */
+ * scratch = 3*n_grids doubles.  Same arithmetic per grid as the single-grid entry points.  Launches of >= 16 grids resolve the
+ * votes in LDS row bands (no global atomics, no zero-fill pass); smaller ones scatter with global fp32 atomics.             */
 int ramnet_voxelize_batch(const double *events, const long long *offsets, int n_grids, size_t max_events, int bins, int W, int H,
                           float *grids, void *stream);
 int ramnet_normalize_nonzero_batch(float *grids, int n_grids, size_t n, double *scratch, void *stream);

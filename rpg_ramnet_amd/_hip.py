@@ -152,7 +152,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 12:
+        if l.ramnet_abi_version() != 13:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

@@ -465,8 +465,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
     }
     const int key = (tall ? 0 : 1000) + q.sparse * 100 + d.in_mode + (nf == 1 ? 10000 : 0);
-    if (nf == 1) note_kernel("conv_wino_r_kernel<%d,%d,%d,1>", tall ? 2 : 8, q.sparse, d.in_mode);
-    else note_kernel("conv_wino_r_kernel<%d,%d,%d>", tall ? 2 : 8, q.sparse, d.in_mode);
+    note_kernel("conv_wino_r_kernel<%d,%d,%d,%d>", tall ? 2 : 8, q.sparse, d.in_mode, nf);
 #define RAMNET_GO(TXv, SPv, MDv)                                                                        \
     case ((TXv) == 2 ? 0 : 1000) + (SPv) * 100 + (MDv):                                                 \
         RAMNET_FULL_LDS((conv_wino_r_kernel<TXv, SPv, MDv>));                                           \

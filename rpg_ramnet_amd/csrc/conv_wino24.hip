@@ -369,11 +369,11 @@ static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
     const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk));
     if (flat) {
         RAMNET_FULL_LDS((conv_wino24_kernel<4, true, 8>));
-        note_kernel("conv_wino24_kernel<4,1,8>");
+        note_kernel("conv_wino24_kernel<4,1,8,0>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, true, 8>), grid, dim3(512), lds, st, d, q);
     } else {
         RAMNET_FULL_LDS((conv_wino24_kernel<4, true, 4>));
-        note_kernel("conv_wino24_kernel<4,1,4>");
+        note_kernel("conv_wino24_kernel<4,1,4,0>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, true, 4>), grid, dim3(512), lds, st, d, q);
     }
     RAMNET_LAUNCH_CHECK();
@@ -411,15 +411,15 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
         hipLaunchKernelGGL((conv_wino24_kernel<4, false, 4, true>), grid, dim3(512), lds, st, d, q);
     } else if (wide && flat) {
         RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 8>));
-        note_kernel("conv_wino24_kernel<4,0,8>");
+        note_kernel("conv_wino24_kernel<4,0,8,0>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, false, 8>), grid, dim3(512), lds, st, d, q);
     } else if (wide) {
         RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 4>));
-        note_kernel("conv_wino24_kernel<4,0,4>");
+        note_kernel("conv_wino24_kernel<4,0,4,0>");
         hipLaunchKernelGGL((conv_wino24_kernel<4, false, 4>), grid, dim3(512), lds, st, d, q);
     } else {
         RAMNET_FULL_LDS((conv_wino24_kernel<2, false, 8>));
-        note_kernel("conv_wino24_kernel<2,0,8>");
+        note_kernel("conv_wino24_kernel<2,0,8,0>");
         hipLaunchKernelGGL((conv_wino24_kernel<2, false, 8>), grid, dim3(512), lds, st, d, q);
     }
     RAMNET_LAUNCH_CHECK();

@@ -327,22 +327,36 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
     int *queue = reinterpret_cast<int *>(band + cells);            // [QCAP] event offsets inside the batch, behind the band
     int *qn = queue + QCAP;                                      // [2] fill counters, alternating by batch
     const long long stride = blockDim.x;
-    int par = 0;
-    for (long long b0 = 0; b0 < n; b0 += (long long)U * stride, par ^= 1) {
-        double2 yp[U];
+    // The rows of batch k+1 are requested before batch k is tested and voted on: the two barriers of a batch wait for the LDS
+    // traffic only (s_waitcnt lgkmcnt(0); a __syncthreads() would also drain the loads in flight), so the walk is not a chain of
+    // exposed load latencies (78 % of the wave cycles were waits: 49 batches x ~5 us per workgroup).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto load_rows = [&](long long b0, double2 (&yp)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = b0 + u * stride + threadIdx.x;
-            yp[u] = i < n ? e2[i * 2 + 1] : make_double2(-2.0, 0.0);
+            const long long i = b0 + u * stride + threadIdx.x;       // (clamped, not predicated: no exec-mask regions around the loads)
+            yp[u] = e2[(i < n ? i : n - 1) * 2 + 1];
         }
+    };
+    int par = 0;
+    auto batch = [&](long long b0, const double2 (&cur)[U], double2 (&nxt)[U]) {
+        load_rows(min(b0 + (long long)U * stride, n - 1), nxt);      // in flight until the NEXT batch tests them
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (in_band(yp[u].x)) queue[atomicAdd(qn + par, 1)] = u * (int)stride + (int)threadIdx.x;
-        __syncthreads();
+            if (in_band(cur[u].x) & (b0 + u * stride + threadIdx.x < n)) queue[atomicAdd(qn + par, 1)] = u * (int)stride + (int)threadIdx.x;
+        lds_barrier();
         const int cnt = qn[par];
         if (threadIdx.x == 0) qn[par ^ 1] = 0;      // (read again only behind the next barrier)
         for (int k = threadIdx.x; k < cnt; k += (int)stride) vote(b0 + queue[k]);
-        __syncthreads();                            // the queue is drained before the next batch refills it
+        lds_barrier();                              // the queue is drained before the next batch refills it
+        par ^= 1;
+    };
+    double2 ra[U], rb[U];                           // two register sets in ping-pong (a copy would wait for the loads in flight)
+    if (n > 0) load_rows(0, ra);
+    const long long bstep = (long long)U * stride;
+    for (long long b0 = 0; b0 < n; b0 += 2 * bstep) {
+        batch(b0, ra, rb);
+        if (b0 + bstep < n) batch(b0 + bstep, rb, ra);     // (uniform over the workgroup)
     }
     __syncthreads();
     float *grid = grids + (size_t)g * bins * plane;
