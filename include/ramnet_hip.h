@@ -28,7 +28,7 @@ extern "C" {
 enum ramnet_in_mode {
     RAMNET_IN_PLAIN = 0,     /* x0[C0]                                                          */
     RAMNET_IN_CAT = 1,       /* cat(x0[C0], x1[C1])            ConvGRU/ConvLSTM  submodules.py:343,447 */
-    RAMNET_IN_CAT_MUL = 2,   /* cat(x0[C0], x1[C1] * xm[C1])   ConvGRU candidate submodules.py:450; WINOGRAD: C0 = 0 allowed (input = x1 * xm) */
+    RAMNET_IN_CAT_MUL = 2,   /* cat(x0[C0], x1[C1] * xm[C1])   ConvGRU candidate submodules.py:450  */
     RAMNET_IN_UP2X = 3,      /* bilinear x2 (align_corners=False) of x0          submodules.py:88   */
     RAMNET_IN_UP2X_SKIP = 4, /* bilinear x2 of (x0 + x1)       decoder skip sum  statenet.py:305-308 */
     RAMNET_IN_RELUMASK = 5,  /* x0 * (xm > 0)                  backward through a ReLU             */
@@ -86,7 +86,7 @@ typedef struct ramnet_conv_desc {
     int HoF, WoF;                   /* full output tensor extent                                    */
     int osy, osx, ooy, oox;         /* output pixel = (a*osy+ooy, b*osx+oox)                        */
     int epi;
-    float beta;                     /* pre-activation += beta*out_old (LINEAR, RELU, SIGMOID, GRU_BLEND; 0 = overwrite), see `frame` */
+    float beta;                     /* pre-activation += beta*out_old (LINEAR and RELU; 0 = overwrite), see `frame` */
     const float *e0, *e1;           /* epilogue operands                                            */
     int lde0, lde1;
     float *out, *o1, *o2;

@@ -25,16 +25,9 @@ __device__ __forceinline__ float epilogue_side(const ramnet_conv_desc &p, int ep
     return v;
 }
 
-// beta != 0 adds beta * out_old to the PRE-ACTIVATION (LINEAR / RELU: accumulation over launches; SIGMOID / GRU_BLEND: the streaming
-// runtime hoists the state-independent half W_x * x + b of a ConvGRU convolution out of the sequential update, writes it into the
-// output buffer as one batched launch, and the per-step launch over h alone completes it in place).
-__device__ __forceinline__ bool epilogue_preact(int epi) {
-    return epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR || epi == RAMNET_EPI_SIGMOID || epi == RAMNET_EPI_GRU_BLEND;
-}
-
 __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int epi, size_t pix, int n, float acc, bool addold) {
     float v = acc + (p.bias ? p.bias[n] : 0.f);
-    if (addold && epilogue_preact(epi)) v += p.beta * p.out[pix * p.ldo + n];
+    if (addold && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR)) v += p.beta * p.out[pix * p.ldo + n];
     if (epi == RAMNET_EPI_RELU) {
         v = fmaxf(v, 0.f);
     } else if (epi == RAMNET_EPI_SIGMOID) {
@@ -54,7 +47,7 @@ __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int ep
 // Four consecutive output channels n..n+3 of one pixel (all pointers 16-byte aligned, Cout % 4 == 0: checked on the host).
 __device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int epi, size_t pix, int n, float4 acc, bool addold) {
     float4 v = p.bias ? f4add(acc, ld4(p.bias + n)) : acc;
-    if (addold && epilogue_preact(epi)) {
+    if (addold && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR)) {
         const float4 old = ld4(p.out + pix * p.ldo + n);
         v = make_float4(v.x + p.beta * old.x, v.y + p.beta * old.y, v.z + p.beta * old.z, v.w + p.beta * old.w);
     }

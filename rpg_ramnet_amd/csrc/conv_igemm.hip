@@ -213,9 +213,7 @@ static int check_desc(const ramnet_conv_desc &d) {
     RAMNET_CHECK_ARG(d.x0 && d.w && d.out);
     RAMNET_CHECK_ARG(d.ntaps >= 1 && d.ntaps <= 25 && (d.stride == 1 || d.stride == 2));
     RAMNET_CHECK_ARG(d.B > 0 && d.Ho > 0 && d.Wo > 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0);
-    // (C0 = 0: the Winograd kernel with RAMNET_IN_CAT_MUL and no x0 part — the whole input is x1 * xm, the hoisted ConvGRU candidate)
-    RAMNET_CHECK_ARG((d.C0 > 0 || (d.algo == RAMNET_ALGO_WINOGRAD && d.in_mode == RAMNET_IN_CAT_MUL)) && d.C0 >= 0 && d.C0 % 4 == 0 &&
-                     d.ld0 % 4 == 0 && d.ldo > 0);
+    RAMNET_CHECK_ARG(d.C0 > 0 && d.C0 % 4 == 0 && d.ld0 % 4 == 0 && d.ldo > 0);
     RAMNET_CHECK_ARG(d.osy >= 1 && d.osx >= 1);
     const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
     if (cat) RAMNET_CHECK_ARG(d.x1 && d.C1 > 0 && d.C1 % 4 == 0 && d.ld1 % 4 == 0);

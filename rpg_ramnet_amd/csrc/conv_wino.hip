@@ -449,12 +449,19 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
-    // fewer workgroups than CUs (batch-1 streaming, coarse maps): 32-channel workgroups, twice as many (forward input modes only)
-    const bool fwd_mode = d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_S2D;
-    const int nf = (q.tiles_x * q.tiles_y * d.B * q.nblk < 256 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && fwd_mode && d.Cout % 64 == 0) ? 1 : 2;
-    // such a launch is bound by the latency of its chunk chain, not by the MFMA pipe: skipping the MFMAs of the zero slices buys
-    // nothing there, the wave-uniform tests around them cost (enc2 at batch 1: 1.7 instead of 0.9 us per chunk) -> dense
-    if (nf == 1 && q.sparse == 1) q.sparse = 0;
+    // Less than one full round of 64-channel workgroups (2 per CU: 512 slots) -> 32-channel workgroups, twice as many: at batch 1
+    // (44-176 workgroups) the launch is bound by the latency of a workgroup's chunk chain, which halves; at the training batch the
+    // 32 x 43 maps give 352 workgroups (residual blocks, ConvGRU candidate, encoder 2: 42-46 % MFMA-busy on a chip whose CUs hold one or
+    // two of them), and 704 half-size workgroups — three fit a CU: 158 VGPRs, 37 KB of LDS — spread evenly over it.
+    const bool nf1_mode = d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL ||
+                          d.in_mode == RAMNET_IN_S2D || d.in_mode == RAMNET_IN_RELUMASK;
+    const int wgs2 = q.tiles_x * q.tiles_y * d.B * q.nblk;
+    // (same-box A/B of the threshold 512 against 256 at B = 8: residual conv 0.093 -> 0.081 ms forward, 0.094 -> 0.084 backward-data,
+    // ConvGRU candidate at 32 x 43 0.177 -> 0.163 ms, training step 202.2 -> 203.4 / 204.0 samples/s)
+    const int nf = (wgs2 < 512 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && nf1_mode && d.Cout % 64 == 0) ? 1 : 2;
+    // a launch of fewer workgroups than CUs is latency-bound: skipping the MFMAs of the zero slices buys nothing there, the
+    // wave-uniform tests around them cost (enc2 at batch 1: 1.7 instead of 0.9 us per chunk) -> dense
+    if (nf == 1 && q.sparse == 1 && wgs2 < 256) q.sparse = 0;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
     const size_t lds = (size_t)(nf == 1 ? 4 * 2 * 32 * (32 + 4) : RO_FLOATS) * sizeof(float);       // (the two patch buffers, 2 x 2 planes, and the scratch cells are smaller)
     // one instantiation per (tile shape, sparse mode, input mode) that occurs: the kernel body has no run-time mode branches
@@ -481,7 +488,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     RAMNET_GO(TXv, 0, RAMNET_IN_RELUMASK) RAMNET_GO(TXv, 0, RAMNET_IN_S2D) RAMNET_GO(TXv, 1, RAMNET_IN_S2D)         \
     RAMNET_GO(TXv, 2, RAMNET_IN_PLAIN) RAMNET_GO(TXv, 2, RAMNET_IN_RELUMASK)                                        \
     RAMNET_GO1(TXv, 0, RAMNET_IN_PLAIN) RAMNET_GO1(TXv, 0, RAMNET_IN_CAT) RAMNET_GO1(TXv, 0, RAMNET_IN_CAT_MUL)     \
-    RAMNET_GO1(TXv, 0, RAMNET_IN_S2D) RAMNET_GO1(TXv, 1, RAMNET_IN_S2D)
+    RAMNET_GO1(TXv, 0, RAMNET_IN_S2D) RAMNET_GO1(TXv, 1, RAMNET_IN_S2D) RAMNET_GO1(TXv, 0, RAMNET_IN_RELUMASK)
     switch (key) {
         RAMNET_GO_TX(2)
         RAMNET_GO_TX(8)

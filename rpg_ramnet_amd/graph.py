@@ -162,14 +162,10 @@ class TimeBatchedStream:
     ``flush`` closes a group without a frame; both return the group's predictions [n (+1), B, 1, H, W] as a static buffer that
     stays valid (after ``wait``) until the second-next group of the same shape."""
 
-    def __init__(self, model, B, H, W, max_events=8, hoist=True):
-        """hoist (ConvGRU states): the state-independent half W_x * x + b of the update convolutions of a whole group as two
-        batched launches per scale in the encoder stage; the sequential updates then convolve the state alone (submodules.GRUSplit).
-        Results then agree with the one-by-one calls to fp32 rounding instead of bit for bit."""
+    def __init__(self, model, B, H, W, max_events=8):
         assert not bool(model.baseline) and model.recurrent_block_type == "conv", "time-batched stream: asynchronous RAM-Net, conv encoders"
         self.model, self.B, self.H, self.W, self.NM, dev = model, B, H, W, max_events, model.gpu
         self.net = net = model.statenetphasedrecurrent
-        self.hoist = bool(hoist) and model.state_combination == "convgru"
         T = max_events + 1
         self.in_ev = [torch.zeros(max_events * B, model.num_bins_events, H, W, device=dev) for _ in range(2)]
         self.in_im = [torch.zeros(B, model.num_bins_rgb, H, W, device=dev) for _ in range(2)]
@@ -179,11 +175,6 @@ class TimeBatchedStream:
         def batched(s_):
             return [torch.zeros((T * B,) + tuple(t.shape[1:]), device=dev) for t in s_] if self.pair else torch.zeros((T * B,) + tuple(s_.shape[1:]), device=dev)
         self.S = [[batched(s_) for s_ in self.carry] for _ in range(2)]
-        if self.hoist:
-            from .model.submodules import GRUSplit
-            self.split = {kind: [GRUSplit(c.recurrent_block) for c in combs]
-                          for kind, combs in (("events", net.state_combination_events), ("image", net.state_combination_images))}
-            self.UR = [[torch.zeros((T * B,) + tuple(s_.shape[1:3]) + (2 * s_.shape[3],), device=dev) for s_ in self.carry] for _ in range(2)]
         self.SE = torch.cuda.Stream(device=dev)
         self.SG = [torch.cuda.Stream(device=dev) for _ in range(net.num_encoders)]       # one update chain per scale
         self.SD = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
@@ -207,12 +198,6 @@ class TimeBatchedStream:
                 for e in net.encoders_rgb:
                     x = e(x)
                     fi.append(x)
-            if self.hoist:          # pre-activations of the whole group: P into the gate buffer, Q into the state slots
-                for i in range(net.num_encoders):
-                    if n:
-                        self.split["events"][i].preact(fe[i], self.UR[p][i][:n * B], self.S[p][i][:n * B])
-                    if f:
-                        self.split["image"][i].preact(fi[i], self.UR[p][i][n * B:(n + 1) * B], self.S[p][i][n * B:(n + 1) * B])
         return fe, fi
 
     def _slot(self, s_, j):
@@ -228,11 +213,8 @@ class TimeBatchedStream:
             h = self.carry[i]
             for j in range(n + f):
                 dst = self._slot(self.S[p][i], j)
-                if self.hoist:
-                    self.split["events" if j < n else "image"][i].step(h, self.UR[p][i][j * B:(j + 1) * B], dst)
-                else:
-                    comb = net.state_combination_events[i] if j < n else net.state_combination_images[i]
-                    comb(fe[i][j * B:(j + 1) * B] if j < n else fi[i], h, dst)
+                comb = net.state_combination_events[i] if j < n else net.state_combination_images[i]
+                comb(fe[i][j * B:(j + 1) * B] if j < n else fi[i], h, dst)
                 h = dst
             for d, t in zip(self.carry[i] if self.pair else [self.carry[i]], h if self.pair else [h]):
                 d.copy_(t)
@@ -288,8 +270,6 @@ class TimeBatchedStream:
             self.SE.wait_stream(torch.cuda.current_stream())
             for e in self.g_done[self.p] or ():
                 self.SE.wait_event(e)
-            if self.hoist and self.d_done[self.p] is not None:      # the encoder stage writes pre-activations into the state slots
-                self.SE.wait_event(self.d_done[self.p])              # that the decode of the group two back reads
             self.opened = True
 
     def push_events(self, grid):

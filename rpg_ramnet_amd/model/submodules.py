@@ -130,37 +130,6 @@ class ConvGRU(nn.Module, _Lazy):
         return ops.GRUCell.apply(x, prev_state, u.weight, u.bias, r.weight, r.bias, o.weight, o.bias, cp_ur, cp_o, out)
 
 
-class GRUSplit:
-    """ConvGRU with the state-independent half of its three convolutions hoisted (inference, streaming runtimes):
-    W * [x, h] = W_x * x + W_h * h, so  P = W_x^{u,r} * x + b_{u,r}  and  Q = W_x^o * x + b_o  of ALL measurements of a group are two
-    batched launches (`preact`), and the sequential update (`step`) convolves the state alone — half the reduction depth — and
-    completes P / Q in place (ramnet_conv_desc.beta on the SIGMOID / GRU_BLEND epilogues).  Same sums as ConvGRU.forward
-    (submodules.py:436-454), associated differently: results agree to fp32 rounding (~1e-7), not bit for bit."""
-
-    def __init__(self, gru):
-        u, r, o, C = gru.update_gate, gru.reset_gate, gru.out_gate, gru.hidden_size
-        assert gru.input_size == C
-        self.C = C
-        self.cp_x_ur = ops.ConvParam([u.weight[:, :C], r.weight[:, :C]], [u.bias, r.bias])
-        self.cp_x_o = ops.ConvParam([o.weight[:, :C]], [o.bias])
-        self.cp_h_ur = ops.ConvParam([u.weight[:, C:], r.weight[:, C:]], [])
-        self.cp_h_o = ops.ConvParam([o.weight[:, C:]], [])
-
-    def preact(self, x, ur_out, q_out):
-        """x [n, h, w, C] -> ur_out [n, h, w, 2C] = W_x^{u,r} * x + b, q_out [n, h, w, C] = W_x^o * x + b (pre-activations)."""
-        taps = ops.Taps.get("conv", 3, 1)
-        ops.conv_launch(x, taps, self.cp_x_ur.fwd(), ur_out, 2 * self.C, bias=self.cp_x_ur.bias())
-        ops.conv_launch(x, taps, self.cp_x_o.fwd(), q_out, self.C, bias=self.cp_x_o.bias())
-
-    def step(self, h, ur, hn):
-        """One update: ur (holding P) becomes [u | r] = sigmoid(P + W_h^{u,r} * h); hn (holding Q) becomes the new state
-        h (1 - u) + tanh(Q + W_h^o * (h . r)) u.  h is not modified."""
-        taps, C = ops.Taps.get("conv", 3, 1), self.C
-        ops.conv_launch(h, taps, self.cp_h_ur.fwd(), ur, 2 * C, epi=ops.H.EPI_SIGMOID, beta=1.0)
-        ops.conv_launch(h, taps, self.cp_h_o.fwd(), hn, C, x1=h, xm=ur, xm_off=C, in_mode=ops.H.IN_CAT_MUL, C0=0, C1=C,
-                        epi=ops.H.EPI_GRU_BLEND, beta=1.0, e0=ur, e1=h)
-
-
 class RecurrentConvLayer(nn.Module):
     """State-combination block: the recurrent cell alone, kernel forced to 3 (submodules.py:112-114)."""
 

@@ -272,39 +272,6 @@ def test_conv_gru(B, H, W, C, algo3x3):
              [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W))])
 
 
-@pytest.mark.parametrize("n,H,W,C", [(3, 8, 16, 64), (1, 32, 43, 256), (4, 64, 86, 128), (2, 128, 172, 64)])
-def test_conv_gru_hoisted_vs_oracle(n, H, W, C):
-    """submodules.GRUSplit (the streaming runtimes' ConvGRU): the state-independent half of the three convolutions for n
-    measurements as two batched launches, then n sequential updates that convolve the state alone and complete the
-    pre-activations in place — against oracle.ramnet_ref.conv_gru (submodules.py:436-454) step by step in float64, at the real
-    batch-1 map sizes of the three scales (32 x 43 x 256, 64 x 86 x 128, 128 x 172 x 64)."""
-    from rpg_ramnet_amd.model.submodules import ConvGRU, GRUSplit
-    torch.manual_seed(15)
-    m = ConvGRU(C, C, 3)
-    with torch.no_grad():
-        for p in m.parameters():
-            if p.dim() == 1:
-                p.uniform_(-0.1, 0.1)
-    m = m.to(dev())
-    sd = {"L." + k: v.detach().cpu().double() for k, v in m.state_dict().items()}
-    xs = torch.randn(n, C, H, W)
-    h0 = torch.tanh(torch.randn(1, C, H, W))
-    sp = GRUSplit(m)
-    x = nhwc(xs).to(dev())
-    ur = torch.empty(n, H, W, 2 * C, device=dev())
-    S = torch.empty(n, H, W, C, device=dev())
-    with torch.no_grad():
-        sp.preact(x, ur, S)
-        h = nhwc(h0).to(dev())
-        for j in range(n):
-            sp.step(h, ur[j:j + 1], S[j:j + 1])
-            h = S[j:j + 1]
-    ref = h0.double()
-    for j in range(n):
-        ref = ramnet_ref.conv_gru(sd, "L", xs[j:j + 1].double(), ref)
-        assert_close(nchw(S[j:j + 1]).cpu().numpy(), ref.numpy(), TOL, "hoisted ConvGRU step %d" % j)
-
-
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_conv_lstm(B, H, W, C):
     from rpg_ramnet_amd.model.submodules import ConvLSTM
