@@ -16,28 +16,47 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// stats[0] += sum d, stats[1] += sum d^2, stats[2] += count over non-NaN d = pred - target
-__global__ void si_stats_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, double *stats) {
+// stats[0] += sum d, stats[1] += sum d^2, stats[2] += count over non-NaN d = pred - target; stats[3] = arrival ticket: the LAST
+// workgroup to arrive reads the three sums back and writes the loss (model/loss.py:6-9) — one launch instead of statistics +
+// finalize.  At most 256 workgroups of 16-byte loads: the three double atomics per workgroup all hit the same three addresses
+// (~12 ns each, serialised), which is what the 2048-workgroup version spent its 27 us on.
+__global__ void __launch_bounds__(1024) si_stats_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight, float lambda,
+                                double *stats, float *loss) {
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = pred[i] - target[i];
+    auto acc = [&](float d) {
         if (d == d) {
             s1 += (double)d;
             s2 += (double)d * (double)d;
             cnt += 1.0;
         }
+    };
+    const bool vec = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15) == 0;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 p = ld4(pred + 4 * i), t = ld4(target + 4 * i);
+        acc(p.x - t.x), acc(p.y - t.y), acc(p.z - t.z), acc(p.w - t.w);
     }
-    __shared__ double red[3][4];
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc(pred[i] - target[i]);
+    __shared__ double red[3][16];
     s1 = wave_sum(s1), s2 = wave_sum(s2), cnt = wave_sum(cnt);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (lane == 0) red[0][wave] = s1, red[1][wave] = s2, red[2][wave] = cnt;
     __syncthreads();
-    if (threadIdx.x < 3) atomicAdd(stats + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
-}
-
-__global__ void si_finalize_kernel(const double *stats, float weight, float lambda, float *loss) {
-    const double n = stats[2], m = stats[0] / n;
-    *loss = (float)((double)weight * (stats[1] / n - (double)lambda * m * m));
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; ++k) {
+            double t = 0.0;
+            for (int w = 0; w < nw; ++w) t += red[k][w];
+            atomicAdd(stats + k, t);
+        }
+        __threadfence();                                        // the sums are performed before the ticket
+        const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), 1ull);
+        if (ticket == (unsigned long long)gridDim.x - 1) {      // every other workgroup's sums are in: read them where they live
+            __threadfence();
+            const double S1 = atomicAdd(stats + 0, 0.0), S2 = atomicAdd(stats + 1, 0.0), N = atomicAdd(stats + 2, 0.0);
+            const double m = S1 / N;
+            *loss = (float)((double)weight * (S2 / N - (double)lambda * m * m));
+        }
+    }
 }
 
 __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight, float lambda,
@@ -452,9 +471,10 @@ using namespace ramnet;
 extern "C" int ramnet_si_loss_fwd(const float *pred, const float *target, size_t n, float weight, float lambda, double *stats, float *loss, void *stream) {
     RAMNET_CHECK_ARG(pred && target && stats && loss && n > 0);
     hipStream_t st = (hipStream_t)stream;
-    RAMNET_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(double), st));
-    hipLaunchKernelGGL(si_stats_kernel, dim3(grid_for(n)), dim3(256), 0, st, pred, target, n, stats);
-    hipLaunchKernelGGL(si_finalize_kernel, dim3(1), dim3(1), 0, st, stats, weight, lambda, loss);
+    RAMNET_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
+    int g = grid_for(n / 4 + 1, 1024);               // 1024-thread workgroups: a few loads per thread, few arrivals on the three sums
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(si_stats_kernel, dim3(g), dim3(1024), 0, st, pred, target, n, weight, lambda, stats, loss);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

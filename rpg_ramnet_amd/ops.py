@@ -1252,7 +1252,7 @@ class SILoss(Function):
     @staticmethod
     def forward(ctx, pred, target, weight, n_lambda):
         pred, target = pred.contiguous(), target.contiguous()
-        stats = torch.empty(3, device=pred.device, dtype=torch.float64)
+        stats = torch.empty(4, device=pred.device, dtype=torch.float64)      # sums + the reduction's arrival ticket
         loss = torch.empty((), device=pred.device)
         H.check(H.lib().ramnet_si_loss_fwd(_p(pred), _p(target), pred.numel(), weight, n_lambda, _p(stats), _p(loss), _st()), "si_fwd")
         ctx.save_for_backward(pred, target, stats)

@@ -56,7 +56,7 @@ def test_loss_and_voxel_entry_points_raw():
     g = torch.Generator(device=dev).manual_seed(1)
     pred, tgt = torch.rand(4096, device=dev, generator=g), torch.rand(4096, device=dev, generator=g)
     tgt[::7] = float("nan")
-    stats = torch.empty(3, dtype=torch.float64, device=dev)
+    stats = torch.empty(4, dtype=torch.float64, device=dev)
     loss = torch.empty((), device=dev)
     assert L.ramnet_si_loss_fwd(ptr(pred), ptr(tgt), 4096, 1.0, 1.0, ptr(stats), ptr(loss), st) == 0
     d = (pred - tgt)[~torch.isnan(tgt)].double()
