@@ -1,4 +1,7 @@
 // Scale-invariant loss reductions and event -> voxel-grid binning (HBM / atomic bound).
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.hpp"
 
 namespace ramnet {
@@ -304,9 +307,27 @@ __global__ void voxelize_batch_kernel(const double *__restrict__ ev, const long 
 // band is written once with plain coalesced stores — no zero-fill pass, no global atomics.  The global-atomic form above is bound
 // by ~19 G random fp32 atomics/s of the memory side (858 us for the 8 M events of a package batch, 0.066 of the HBM roofline);
 // here a list is re-read once per band from L2 / Infinity Cache (6.4 MB per grid) and the cost is the event walk itself.
+// Band id of every event of every grid (0 .. nbands-1, 255 = outside the image rows): one byte per event, so that a band workgroup
+// walks 200 KB of ids instead of the 6.4 MB list of its grid and fetches whole events for its hits only.  ids[g * stride + j].
+__global__ void voxel_band_ids_kernel(const double *__restrict__ ev, const long long *__restrict__ off, long long n_single, int H, int rows,
+                                      unsigned char *__restrict__ ids, long long stride) {
+    const int g = blockIdx.y;
+    const long long e0 = off ? off[g] : 0, n = off ? off[g + 1] - e0 : n_single;
+    const double *e = ev + (size_t)e0 * 4;
+    unsigned char *idg = ids + (size_t)g * stride;
+    for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < n; j += (long long)gridDim.x * blockDim.x) {
+        const double y = e[j * 4 + 2];
+        // (long long)y truncates towards zero: rows -0.x are row 0; the int conversion is exact for the in-range values
+        const bool in = y > -1.0 && y < (double)H;
+        idg[j] = in ? (unsigned char)((y < 0.0 ? 0 : (int)y) / rows) : (unsigned char)255;
+    }
+}
+
+template <bool IDS>
 __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__restrict__ ev, const long long *__restrict__ off,
                                                               long long n_single, int n_grids, int bins, int W, int H, int rows,
-                                                              float *__restrict__ grids) {
+                                                              float *__restrict__ grids, const unsigned char *__restrict__ ids,
+                                                              long long ids_stride) {
     extern __shared__ __attribute__((aligned(16))) float band[];          // [bins][rows][W]
     // All bands of a grid walk the same event list: they are dealt to ONE XCD (workgroup b runs on XCD b % 8) as consecutive
     // slots, so that the list streams through that XCD's L2 once instead of once per band from the Infinity Cache (12 bands x 40
@@ -320,7 +341,7 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
     const double *e = ev + (size_t)e0 * 4;
     const int cells = bins * rows * W;
     for (int i = threadIdx.x; i < cells; i += blockDim.x) band[i] = 0.f;
-    if (threadIdx.x < 2) reinterpret_cast<int *>(band + cells)[4096 + threadIdx.x] = 0;
+    if (threadIdx.x < 2) reinterpret_cast<int *>(band + cells)[(IDS ? 8192 : 4096) + threadIdx.x] = 0;
     __syncthreads();
     const long long plane = (long long)W * H;
     const double t0 = n > 0 ? e[0] : 0.0, t1 = n > 0 ? e[(n - 1) * 4] : 0.0;
@@ -342,7 +363,7 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
     // path (f64 division, floor, conversions) in EVERY wave iteration for the 5 lanes of 64 that had a hit: 250 us per workgroup.
     const double band_lo = y0 == 0 ? -1.0 : (double)y0, band_hi = (double)(y0 + nr);
     auto in_band = [&](double y) { return (y0 == 0 ? y > band_lo : y >= band_lo) && y < band_hi; };
-    constexpr int U = 4, QCAP = 4096;               // events per thread and batch; a batch has U * 1024 = QCAP events
+    constexpr int U = IDS ? 8 : 4, QCAP = U * 1024;  // events per thread and batch; a batch has U * 1024 = QCAP events
     int *queue = reinterpret_cast<int *>(band + cells);            // [QCAP] event offsets inside the batch, behind the band
     int *qn = queue + QCAP;                                      // [2] fill counters, alternating by batch
     const long long stride = blockDim.x;
@@ -350,19 +371,8 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
     // traffic only (s_waitcnt lgkmcnt(0); a __syncthreads() would also drain the loads in flight), so the walk is not a chain of
     // exposed load latencies (78 % of the wave cycles were waits: 49 batches x ~5 us per workgroup).
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto load_rows = [&](long long b0, double2 (&yp)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long long i = b0 + u * stride + threadIdx.x;       // (clamped, not predicated: no exec-mask regions around the loads)
-            yp[u] = e2[(i < n ? i : n - 1) * 2 + 1];
-        }
-    };
     int par = 0;
-    auto batch = [&](long long b0, const double2 (&cur)[U], double2 (&nxt)[U]) {
-        load_rows(min(b0 + (long long)U * stride, n - 1), nxt);      // in flight until the NEXT batch tests them
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (in_band(cur[u].x) & (b0 + u * stride + threadIdx.x < n)) queue[atomicAdd(qn + par, 1)] = u * (int)stride + (int)threadIdx.x;
+    auto drain = [&](long long b0) {
         lds_barrier();
         const int cnt = qn[par];
         if (threadIdx.x == 0) qn[par ^ 1] = 0;      // (read again only behind the next barrier)
@@ -370,12 +380,48 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
         lds_barrier();                              // the queue is drained before the next batch refills it
         par ^= 1;
     };
-    double2 ra[U], rb[U];                           // two register sets in ping-pong (a copy would wait for the loads in flight)
-    if (n > 0) load_rows(0, ra);
     const long long bstep = (long long)U * stride;
-    for (long long b0 = 0; b0 < n; b0 += 2 * bstep) {
-        batch(b0, ra, rb);
-        if (b0 + bstep < n) batch(b0 + bstep, rb, ra);     // (uniform over the workgroup)
+    if constexpr (IDS) {
+        // eight band ids per thread and batch (one 8-byte load); a batch of 8192 events leaves ~550 hits in the queue
+        const unsigned char *idg = ids + (size_t)g * ids_stride;
+        const unsigned char mine = (unsigned char)(y0 / rows);
+        auto load_ids = [&](long long b0) {
+            const long long j = b0 + (long long)threadIdx.x * U;
+            return j < n ? *reinterpret_cast<const uint2 *>(idg + j) : make_uint2(0xffffffffu, 0xffffffffu);     // (stride % 16 == 0)
+        };
+        uint2 cur = load_ids(0);
+        for (long long b0 = 0; b0 < n; b0 += bstep) {
+            const uint2 nxt = load_ids(b0 + bstep);                  // in flight across the barriers of this batch
+            const long long j = b0 + (long long)threadIdx.x * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned b = ((u < 4 ? cur.x : cur.y) >> (8 * (u & 3))) & 0xffu;
+                if ((b == mine) & (j + u < n)) queue[atomicAdd(qn + par, 1)] = (int)threadIdx.x * U + u;
+            }
+            drain(b0);
+            cur = nxt;
+        }
+    } else {
+        auto load_rows = [&](long long b0, double2 (&yp)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long i = b0 + u * stride + threadIdx.x;       // (clamped, not predicated: no exec-mask regions around the loads)
+                yp[u] = e2[(i < n ? i : n - 1) * 2 + 1];
+            }
+        };
+        auto batch = [&](long long b0, const double2 (&cur)[U], double2 (&nxt)[U]) {
+            load_rows(min(b0 + bstep, n - 1), nxt);                      // in flight until the NEXT batch tests them
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (in_band(cur[u].x) & (b0 + u * stride + threadIdx.x < n)) queue[atomicAdd(qn + par, 1)] = u * (int)stride + (int)threadIdx.x;
+            drain(b0);
+        };
+        double2 ra[U], rb[U];                           // two register sets in ping-pong (a copy would wait for the loads in flight)
+        if (n > 0) load_rows(0, ra);
+        for (long long b0 = 0; b0 < n; b0 += 2 * bstep) {
+            batch(b0, ra, rb);
+            if (b0 + bstep < n) batch(b0 + bstep, rb, ra);     // (uniform over the workgroup)
+        }
     }
     __syncthreads();
     float *grid = grids + (size_t)g * bins * plane;
@@ -532,26 +578,69 @@ extern "C" int ramnet_msg_loss_bwd(const float *ws, const double *stats, const f
     return 0;
 }
 
-// rows of a band: as many as 160 KB of LDS hold for all bins (0: a single row does not fit -> global-atomic form)
-static int voxel_band_rows(int bins, int W, int H, int n_grids) {
-    // A band workgroup re-reads the whole list of its grid (H / rows = 12 bands at 260 x 346 x 5 bins): at full chip width that is
-    // Infinity-Cache bandwidth (8 M events: 514 us against 858 us for the atomic form, 0.11 against 0.066 of the HBM roofline), but
-    // a launch of a few grids leaves most CUs idle while every workgroup still walks 6.4 MB (5 grids: 283 us against 99 us) -> the
-    // atomic form below for small launches.  What would lift both: a counting / partition pass so that a band reads only its own
-    // events (96 instead of 384 bytes of traffic per event) — not built.
+// rows of a band: as many as 160 KB of LDS hold for all bins beside the hit queue (0: not even one row fits, or a launch too small
+// to fill the chip -> global-atomic form)
+static int voxel_band_rows(int bins, int W, int H, int n_grids, int queue_ints) {
+    // Row bands resolve the votes in LDS and write every cell once (no global atomics, no zero-fill), but every band of a grid
+    // has to find ITS events in that grid's list.  Walking the list itself (6.4 MB per workgroup, 12 bands: 3 GB of L2 fills per
+    // 8 M events) measured 464-514 us against 858 us for the atomic form; with a one-byte band id per event written by a first
+    // pass, a band walks 200 KB and fetches whole events for its hits only.  A launch of a few grids (batch-1 streams: 5 grids =
+    // 60-75 workgroups) cannot fill the chip either way (283 vs 99 us) -> atomic form.
     if (n_grids < 16) return 0;
-    const long long cap = (160 * 1024 - 512) / 4 - (4096 + 2);      // floats left for the band beside the hit queue
+    const long long cap = (160 * 1024 - 512) / 4 - (queue_ints + 2);
     long long rows = cap / ((long long)bins * W);
     if (rows > H) rows = H;
+    if (rows > 0 && (H + rows - 1) / rows > 254) return 0;          // band ids are bytes
     return (int)rows;
 }
 
-static int launch_voxel_bands(const double *events, const long long *offsets, long long n_single, int n_grids, int bins, int W, int H,
-                              int rows, float *grids, hipStream_t st) {
-    RAMNET_FULL_LDS(voxelize_bands_kernel);
+// Scratch for the band ids (one byte per event): owned by the library, one buffer per (device, stream), grown on demand —
+// hipMalloc synchronises, so never while the stream is capturing (the id-less walk is used then).
+static unsigned char *voxel_id_scratch(hipStream_t st, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<unsigned char *, size_t>> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto &b = bufs[{dev, st}];
+    if (b.second >= bytes) return b.first;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (b.first) {
+        if (hipStreamSynchronize(st) != hipSuccess) return nullptr;      // launches that still read the old buffer
+        (void)hipFree(b.first);
+        b = {nullptr, 0};
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+    b = {static_cast<unsigned char *>(p), want};
+    return b.first;
+}
+
+static int launch_voxel_bands(const double *events, const long long *offsets, long long n_single, int n_grids, size_t max_events,
+                              int bins, int W, int H, float *grids, hipStream_t st) {
+    const long long stride = (long long)((max_events + 15) / 16 * 16);
+    const int rows_ids = voxel_band_rows(bins, W, H, n_grids, 8192);
+    unsigned char *ids = rows_ids > 0 && max_events > 0 ? voxel_id_scratch(st, (size_t)stride * n_grids) : nullptr;
+    if (ids) {
+        int gx = (int)((max_events + 255) / 256);
+        const int cap = (2048 * 4 + n_grids - 1) / n_grids;
+        if (gx > cap) gx = cap;
+        hipLaunchKernelGGL(voxel_band_ids_kernel, dim3(gx, n_grids), dim3(256), 0, st, events, offsets, n_single, H, rows_ids, ids, stride);
+        RAMNET_FULL_LDS(voxelize_bands_kernel<true>);
+        const size_t lds = ((size_t)bins * rows_ids * W + 8192 + 2) * sizeof(float);
+        hipLaunchKernelGGL(voxelize_bands_kernel<true>, dim3(8 * cdiv(n_grids, 8) * cdiv(H, rows_ids)), dim3(1024), lds, st, events, offsets,
+                           n_single, n_grids, bins, W, H, rows_ids, grids, ids, stride);
+        RAMNET_LAUNCH_CHECK();
+        return 0;
+    }
+    const int rows = voxel_band_rows(bins, W, H, n_grids, 4096);
+    if (rows <= 0) return -1;                                          // caller falls back to the atomic form
+    RAMNET_FULL_LDS(voxelize_bands_kernel<false>);
     const size_t lds = ((size_t)bins * rows * W + 4096 + 2) * sizeof(float);
-    hipLaunchKernelGGL(voxelize_bands_kernel, dim3(8 * cdiv(n_grids, 8) * cdiv(H, rows)), dim3(1024), lds, st, events, offsets, n_single,
-                       n_grids, bins, W, H, rows, grids);
+    hipLaunchKernelGGL(voxelize_bands_kernel<false>, dim3(8 * cdiv(n_grids, 8) * cdiv(H, rows)), dim3(1024), lds, st, events, offsets, n_single,
+                       n_grids, bins, W, H, rows, grids, nullptr, 0);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
@@ -559,8 +648,6 @@ static int launch_voxel_bands(const double *events, const long long *offsets, lo
 extern "C" int ramnet_voxelize(const double *events, size_t n_events, int bins, int W, int H, float *grid, void *stream) {
     RAMNET_CHECK_ARG(grid && bins > 0 && W > 0 && H > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int rows = voxel_band_rows(bins, W, H, 1);
-    if (rows > 0 && (events != nullptr || n_events == 0)) return launch_voxel_bands(events, nullptr, (long long)n_events, 1, bins, W, H, rows, grid, st);
     RAMNET_HIP(hipMemsetAsync(grid, 0, (size_t)bins * W * H * sizeof(float), st));
     if (n_events == 0) return 0;
     RAMNET_CHECK_ARG(events != nullptr);
@@ -573,8 +660,10 @@ extern "C" int ramnet_voxelize_batch(const double *events, const long long *offs
                                      int H, float *grids, void *stream) {
     RAMNET_CHECK_ARG(grids && offsets && n_grids > 0 && n_grids <= 65535 && bins > 0 && W > 0 && H > 0);
     hipStream_t st = (hipStream_t)stream;
-    const int rows = voxel_band_rows(bins, W, H, n_grids);
-    if (rows > 0 && (events != nullptr || max_events == 0)) return launch_voxel_bands(events, offsets, 0, n_grids, bins, W, H, rows, grids, st);
+    if (n_grids >= 16 && (events != nullptr || max_events == 0)) {
+        const int rc = launch_voxel_bands(events, offsets, 0, n_grids, max_events, bins, W, H, grids, st);
+        if (rc >= 0) return rc;
+    }
     RAMNET_HIP(hipMemsetAsync(grids, 0, (size_t)n_grids * bins * W * H * sizeof(float), st));
     if (max_events == 0) return 0;
     RAMNET_CHECK_ARG(events != nullptr);

@@ -46,17 +46,10 @@ class GraphedStream:
     occupied each (a dozen workgroups per launch), so they overlap almost freely.  Predictions are then valid on the caller's
     stream after ``wait(pred)`` (an event wait, no host sync) and until the second-next update overwrites the buffer."""
 
-    def __init__(self, model, B, H, W, pipelined=False, branches=False):
-        """branches: capture the state updates of the three scales as parallel branches of the update graph (they are mutually
-        independent, ops.set_branch_overlap).  Off by default: measured no gain at batch 1 (the hipGraph executor does not run the
-        branches side by side), and on ROCm 7.2 a graph recorded with such forks left the NEXT capture of the process crashing at
-        replay (tests/test_hip_graph.py order: GraphedStream, then GraphedPackage) — TimeBatchedStream uses one
-        graph per chain on a HIP stream of its own instead."""
+    def __init__(self, model, B, H, W, pipelined=False):
         assert not bool(model.baseline), "streaming graphs are built for the asynchronous RAM-Net (not the baselines)"
         self.model, dev = model, model.gpu
         self.pipelined = pipelined
-        branch0 = ops.branch_overlap()
-        ops.set_branch_overlap(bool(branches))
         self.ev_in = torch.zeros(B, model.num_bins_events, H, W, device=dev)
         self.im_in = torch.zeros(B, model.num_bins_rgb, H, W, device=dev)
         self.sets = [model.init_states(B, H, W), model.init_states(B, H, W)]
@@ -90,7 +83,6 @@ class GraphedStream:
             self.dec[src] = g
         self.reset()
         model.train(was_training)
-        ops.set_branch_overlap(branch0)
 
     @staticmethod
     def _flat(s):
