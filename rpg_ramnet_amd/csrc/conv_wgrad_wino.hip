@@ -102,7 +102,12 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
         ymoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4) * 4u;
     }
     int lb_ty = 0, lb_bx = 0;
-    auto rx = wino_rsrc(s.x0, 0u), rmk = rx, rg = rx, rgm = rx;       // resources at the corner of the batch being loaded
+    // Buffer resources built ONCE: each starts `pad` pixels in front of its tensor (the strip of a top / left batch begins before the
+    // image: only out-of-image threads would reach that, and they read WOOB) and spans WOOB bytes; a batch then only moves four scalar
+    // byte offsets (32-bit: tensors are < WOOB bytes, checked on the host) instead of rebuilding four descriptors from 64-bit pointers
+    const int pad_src = s2d ? -(q.dy0 * (4 * s.Win) + q.dx0 * 2) : -(q.dy0 * s.Win + q.dx0), pad_m = -(q.dy0 * s.Win + q.dx0);
+    const int padS = pad_src > 0 ? pad_src : 0, padM = pad_m > 0 ? pad_m : 0;
+    unsigned so_x = 0, so_m = 0, so_g = 0, so_gm = 0;
     // batch -> (image, tile row, strip): divided out once; the walk then advances by the (pre-divided) grid stride with carries —
     // a few scalar operations per batch instead of two ~40-instruction integer divisions in front of the loads
     int lb_b = 0, lb_batch = 0;
@@ -128,28 +133,31 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
         }
         lb_batch = batch;
         const int b = lb_b;
-        const long pix = ((long)b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
-        const long corner = pix + (long)q.dy0 * s.Win + q.dx0;
-        const long corner_src = s2d ? ((long)b * p.Ho + G::YH * lb_ty + q.dy0) * rowS + (YW * lb_bx + q.dx0) * colS : corner;
-        // the descriptors start at the strip's corner (for a top / left strip that is before the tensor: only out-of-image threads
-        // would reach it, and they get WOOB) and span WOOB bytes: every in-image offset of the strip is below it (images < WOOB),
-        // WOOB itself is out of range and reads as 0
-        rx = wino_rsrc(xsrc + corner_src * ldS, WOOB);
-        if (XMK) rmk = wino_rsrc(msrc + corner * s.ldm, WOOB);
-        rg = wino_rsrc(p.dout + pix * p.ldg, WOOB);
-        if (GM) rgm = wino_rsrc(p.gmask + pix * p.ldgm, WOOB);
+        const int pix = (b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
+        const int corner = pix + q.dy0 * s.Win + q.dx0;
+        const int corner_src = s2d ? (b * p.Ho + G::YH * lb_ty + q.dy0) * rowS + (YW * lb_bx + q.dx0) * colS : corner;
+        so_x = (unsigned)((corner_src + padS) * ldS) * 4u;
+        if (XMK) so_m = (unsigned)((corner + padM) * s.ldm) * 4u;
+        so_g = (unsigned)(pix * p.ldg) * 4u;
+        if (GM) so_gm = (unsigned)(pix * p.ldgm) * 4u;
     };
-    auto bload = [](decltype(rx) r, unsigned vo) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, 0, 0)); };
+    const auto rx = wino_rsrc(xsrc - (long)padS * ldS, WOOB);
+    const auto rmk = XMK ? wino_rsrc(msrc - (long)padM * s.ldm, WOOB) : rx;
+    const auto rg = wino_rsrc(p.dout, WOOB);
+    const auto rgm = GM ? wino_rsrc(p.gmask, WOOB) : rg;
+    auto bload = [](decltype(rx) r, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
+    };
     auto load_x = [&](int i) {
         const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
         const bool ok = xslot[i] & ((unsigned)iy < (unsigned)s.Hin) & ((unsigned)ix < (unsigned)s.Win);      // (no short-circuit: no exec regions)
-        xr[i] = bload(rx, ok ? xoff[i] : WOOB);
-        if (XMK) xm[i] = bload(rmk, (ok & use_m) ? xmoff[i] : WOOB);
+        xr[i] = bload(rx, ok ? xoff[i] : WOOB, so_x);
+        if (XMK) xm[i] = bload(rmk, (ok & use_m) ? xmoff[i] : WOOB, so_m);
     };
     auto load_y = [&](int i) {
         const bool ok = yslot[i] & (G::YH * lb_ty + ypy[i] < p.Ho) & (YW * lb_bx + ypx[i] < p.Wo);
-        yr[i] = bload(rg, ok ? yoff[i] : WOOB);
-        if (GM) ym[i] = bload(rgm, ok ? ymoff[i] : WOOB);
+        yr[i] = bload(rg, ok ? yoff[i] : WOOB, so_g);
+        if (GM) ym[i] = bload(rgm, ok ? ymoff[i] : WOOB, so_gm);
     };
     auto load_raw = [&](int batch) {
         load_begin(batch);

@@ -372,6 +372,16 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
     // exposed load latencies (78 % of the wave cycles were waits: 49 batches x ~5 us per workgroup).
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     int par = 0;
+    // queue append, aggregated per wave: ONE LDS atomic per wave (lane 0, by the number of hits of the wave) instead of one per hit —
+    // ~550 returning atomics per batch on the same LDS word serialise
+    auto push = [&](bool hit, int value) {
+        const unsigned long long mask = __ballot(hit);
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(qn + par, __popcll(mask));
+        base = __shfl(base, 0);
+        if (hit) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+    };
     auto drain = [&](long long b0) {
         lds_barrier();
         const int cnt = qn[par];
@@ -396,7 +406,7 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const unsigned b = ((u < 4 ? cur.x : cur.y) >> (8 * (u & 3))) & 0xffu;
-                if ((b == mine) & (j + u < n)) queue[atomicAdd(qn + par, 1)] = (int)threadIdx.x * U + u;
+                push((b == mine) & (j + u < n), (int)threadIdx.x * U + u);
             }
             drain(b0);
             cur = nxt;
@@ -412,8 +422,7 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
         auto batch = [&](long long b0, const double2 (&cur)[U], double2 (&nxt)[U]) {
             load_rows(min(b0 + bstep, n - 1), nxt);                      // in flight until the NEXT batch tests them
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (in_band(cur[u].x) & (b0 + u * stride + threadIdx.x < n)) queue[atomicAdd(qn + par, 1)] = u * (int)stride + (int)threadIdx.x;
+            for (int u = 0; u < U; ++u) push(in_band(cur[u].x) & (b0 + u * stride + threadIdx.x < n), u * (int)stride + (int)threadIdx.x);
             drain(b0);
         };
         double2 ra[U], rb[U];                           // two register sets in ping-pong (a copy would wait for the loads in flight)
