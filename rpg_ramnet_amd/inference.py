@@ -29,12 +29,23 @@ def empty_states(every_x_rgb_frame):
     return {'image': None}, lstm
 
 
+def _time_batched_ok(model):
+    return (type(model).__name__ == "ERGB2DepthRecurrent" and not bool(model.baseline) and model.recurrent_block_type == "conv"
+            and torch.device(model.gpu).type == "cuda")
+
+
 def stream_dataset(model, dataset, every_x_rgb_frame, output_folder=None, settle=2, calculate_scale=False,
-                   reg_factor=5.70378, clip_distance=1000.0, max_items=None):
+                   reg_factor=5.70378, clip_distance=1000.0, max_items=None, time_batched="auto"):
     """Run ``model`` over ``dataset`` (items ``(sequence, dataset_idx)``, sequence_length 1) the way test.py does and
-    optionally write predictions / targets as .npy.  Returns {'items', 'saved', 'scale': (mean, min, max) or None}."""
+    optionally write predictions / targets as .npy.  Returns {'items', 'saved', 'scale': (mean, min, max) or None}.
+
+    time_batched ("auto" = whenever the model allows it): a data package IS one group of ``graph.TimeBatchedStream`` — its K event
+    grids encode at batch K, its K + 1 decodes run as one chain, only the state updates are sequential — with the same outputs
+    bit for bit; False calls ``model(package, ...)`` as test.py:230-232 does."""
     was_training = model.training
     model.eval()
+    use_tb = _time_batched_ok(model) if time_batched == "auto" else bool(time_batched)
+    tb, K = None, every_x_rgb_frame
     n = len(dataset) if max_items is None else min(len(dataset), max_items)
     scale = np.empty(n) if calculate_scale else None
     saved = 0
@@ -46,7 +57,20 @@ def stream_dataset(model, dataset, every_x_rgb_frame, output_folder=None, settle
                 prev_super, prev_lstm = empty_states(every_x_rgb_frame)
                 sequence_idx = 0
             package = {k: v[None, :] for k, v in item[0].items()}
-            preds, new_super, new_lstm = model(package, prev_super['image'], prev_lstm)
+            if use_tb:
+                if tb is None:
+                    from .graph import TimeBatchedStream
+                    tb = TimeBatchedStream(model, 1, package['image'].shape[2], package['image'].shape[3], max_events=K + 1)
+                if sequence_idx == 0:
+                    tb.reset()                                    # a new recording starts from the zero state
+                for k in range(K):
+                    tb.push_events(package['events{}'.format(k)])
+                out = tb.wait(tb.push_image(package['image']))    # [K + 1, 1, 1, H, W]
+                preds = {'events{}'.format(k): out[k] for k in range(K)}
+                preds['image'] = out[K]
+                new_super, new_lstm = prev_super, prev_lstm        # (the runtime carries the state)
+            else:
+                preds, new_super, new_lstm = model(package, prev_super['image'], prev_lstm)
             if output_folder and sequence_idx >= settle:
                 for key, img in preds.items():
                     d = join(output_folder, "npy", key)

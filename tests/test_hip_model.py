@@ -470,6 +470,13 @@ def test_streaming_inference_driver_and_folder_evaluation(tmp_path):
     model = build_hip_model("ERGB2DepthRecurrent", cfg)
     out = str(tmp_path / "out")
     info = inference.stream_dataset(model, ds, K, output_folder=out, calculate_scale=True, reg_factor=5.70378, clip_distance=1000.0)
+    # (the default runs every package as one group of graph.TimeBatchedStream; the per-call form of test.py writes the same bytes)
+    out1 = str(tmp_path / "out_percall")
+    info1 = inference.stream_dataset(model, ds, K, output_folder=out1, time_batched=False)
+    assert info1["saved"] == info["saved"]
+    for key in ["events%d" % k for k in range(K)] + ["image"]:
+        for name in sorted(os.listdir(os.path.join(out1, "npy", key))):
+            assert np.array_equal(np.load(os.path.join(out, "npy", key, name)), np.load(os.path.join(out1, "npy", key, name))), (key, name)
     sizes = ds.cumulative_sizes
     assert info["items"] == len(ds) and info["saved"] == len(ds) - 2 * len(sizes)
     assert len(info["scale"]) == 3          # (NaN here: the synthetic targets contain NaN pixels and test.py:378 uses np.sum)
