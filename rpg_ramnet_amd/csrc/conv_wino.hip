@@ -458,6 +458,8 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     const int wgs2 = q.tiles_x * q.tiles_y * d.B * q.nblk;
     // (same-box A/B of the threshold 512 against 256 at B = 8: residual conv 0.093 -> 0.081 ms forward, 0.094 -> 0.084 backward-data,
     // ConvGRU candidate at 32 x 43 0.177 -> 0.163 ms, training step 202.2 -> 203.4 / 204.0 samples/s)
+    // threshold sweep at B = 8 (same box): 512 -> 204.6 / 204.5 samples/s, 1024 -> 203.5 (ConvGRU gates at 32 x 43: 0.258 -> 0.276 ms),
+    // 1536 -> 201.6, everything -> 198.7: beyond the partial first round the doubled transform work costs more than the fill buys
     const int nf = (wgs2 < 512 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && nf1_mode && d.Cout % 64 == 0) ? 1 : 2;
     // a launch of fewer workgroups than CUs is latency-bound: skipping the MFMAs of the zero slices buys nothing there, the
     // wave-uniform tests around them cost (enc2 at batch 1: 1.7 instead of 0.9 us per chunk) -> dense
