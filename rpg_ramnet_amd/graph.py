@@ -150,7 +150,8 @@ class TimeBatchedStream:
     of group g-1 (hipGraph replays — one graph per chain, each on a HIP stream of its own: encoders, one update chain per scale,
     two alternating decode streams —, two buffer parities, event waits, no host sync).
     Results are bit-identical to update_events / update_image / decode called one by one (every kernel computes a batch element
-    independently of the others).  ``push_events`` buffers a grid, ``push_image`` buffers the frame and closes the group,
+    independently of the others).  The graphs are recorded lazily per group shape and recorded again when a parameter of the model
+    has been modified in place since (optimizer step, load_state_dict): they read the packed weights by address.  ``push_events`` buffers a grid, ``push_image`` buffers the frame and closes the group,
     ``flush`` closes a group without a frame; both return the group's predictions [n (+1), B, 1, H, W] as a static buffer that
     stays valid (after ``wait``) until the second-next group of the same shape."""
 
@@ -171,6 +172,7 @@ class TimeBatchedStream:
         self.SG = [torch.cuda.Stream(device=dev) for _ in range(net.num_encoders)]       # one update chain per scale
         self.SD = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.graphs, self.feat, self.pred = {}, {}, {}
+        self._wv = self._weights_version()
         self.reset()
 
     # ---- the three stages of a group (n event grids, f = 1 if a frame closes it) on buffer parity p
@@ -290,9 +292,16 @@ class TimeBatchedStream:
         """Close a group that has no frame (end of the stream); None if nothing is buffered."""
         return self._close(0) if self.n else None
 
+    def _weights_version(self):
+        return sum(p._version for p in self.model.parameters())
+
     def _close(self, f):
         key = (self.n, f, self.p)
         n, p = self.n, self.p
+        v = self._weights_version()
+        if v != self._wv:           # the recorded graphs read weight packs made for the old values (and freed since): record again
+            torch.cuda.synchronize(self.model.gpu)
+            self.graphs, self.feat, self.pred, self._wv = {}, {}, {}, v
         if key not in self.graphs:
             self._capture(key)
             self.opened = False

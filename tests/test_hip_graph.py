@@ -265,3 +265,44 @@ def test_time_batched_stream_equals_eager_primitives(tag, B):
             assert torch.equal(a, b), "pass %d: prediction %d (%s)" % (run, i, keys[i])
         for a, b in zip(flat(tb.states), flat(st)):
             assert torch.equal(a, b)
+
+
+def test_time_batched_stream_follows_weight_updates():
+    """The recorded graphs read packed weights by address: after an in-place parameter update (optimizer step, load_state_dict) the
+    runtime records them again instead of replaying stale — or freed — packs."""
+    from rpg_ramnet_amd.graph import TimeBatchedStream
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    B, H, W = 1, 32, 48
+    tb = TimeBatchedStream(model, B, H, W, max_events=3)
+    rng = np.random.default_rng(26)
+    ev = [torch.from_numpy(rng.standard_normal((B, 5, H, W)).astype(np.float32)).to(model.gpu) for _ in range(2)]
+    im = torch.from_numpy(rng.random((B, 1, H, W)).astype(np.float32)).to(model.gpu)
+
+    def eager():
+        st = model.init_states(B, H, W)
+        out = []
+        with torch.no_grad():
+            for x in ev:
+                st, _ = model.update_events(x, st)
+                out.append(model.decode(st).clone())
+            st, _ = model.update_image(im, st)
+            out.append(model.decode(st).clone())
+        return out
+
+    def batched():
+        tb.reset()
+        for x in ev:
+            tb.push_events(x)
+        return list(tb.wait(tb.push_image(im)).clone())
+
+    for a, b in zip(batched(), eager()):
+        assert torch.equal(a, b)
+    before = batched()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.05)
+    after = batched()
+    assert not torch.equal(after[-1], before[-1])
+    for a, b in zip(after, eager()):
+        assert torch.equal(a, b)
