@@ -462,6 +462,54 @@ def input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank, n=2):
                     (L, K * B, n_ev, L * B, 2 * L * B)}
 
 
+class ClockSampler:
+    """Best-effort effective shader clock during the timed region: a background thread polls `rocm-smi --showclocks
+    --json` and keeps the sclk readings; the roofline keeps the 2.4 GHz spec peak, `clock_ghz` says what the chip really ran at
+    (the largest launches draw the power budget: 2.10-2.16 GHz measured with GRBM_GUI_ACTIVE, tools/effective_clock.py)."""
+
+    def __init__(self, period=0.25):
+        import shutil
+        import threading
+        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self.samples, self.stop, self.period = [], threading.Event(), period
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.exe else None
+
+    def _read(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run([self.exe, "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            card = next(iter(json.loads(out).values()))
+            for k, v in card.items():
+                if "sclk" in k.lower():
+                    m = re.search(r"(\d+(?:\.\d+)?)\s*mhz", str(v).lower())
+                    if m:
+                        return float(m.group(1)) * 1e-3
+        except Exception:      # noqa: BLE001 — a missing / differently formatted tool must not touch the measurement
+            return None
+        return None
+
+    def _run(self):
+        while not self.stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            self.stop.wait(self.period)
+
+    def __enter__(self):
+        if self.thread:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.thread:
+            self.thread.join(timeout=10)
+
+    def ghz(self):
+        return (sum(self.samples) / len(self.samples)) if self.samples else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -633,9 +681,11 @@ def main():
     # (stream / infer: the steps replay hipGraphs — and record them on first use —, where HIP events cannot be bracketed; their
     # FLOP accounting comes from one eager pass below)
     timer.on = timer.hbm = not args.no_kernel_timing and args.mode == "train"
-    for _ in range(args.warmup):
-        last = step()
-    fence()
+    # (the clock is sampled over the WARM-UP steps — the same workload, untimed: nothing polls the driver inside the timed region)
+    with ClockSampler() if (rank == 0 and args.mode == "train" and args.warmup > 0) else contextlib.nullcontext() as clock:
+        for _ in range(args.warmup):
+            last = step()
+        fence()
     warm = {k: v for k, v in timer.summary().items() if not k.startswith("ramnet_")}
     warm_hbm = {k: v for k, v in timer.summary().items() if k.startswith("ramnet_")}
     timer.rec, timer.hbm = [], False
@@ -780,6 +830,8 @@ def main():
                 "bound": "mfma", "kernel": name, "achieved": ex / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "frac_executed": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
                 "frac_algorithmic": alg / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                "clock_ghz": clock.ghz() if clock is not None else None, "clock_source": "rocm-smi --showclocks sclk, mean over the warm-up steps "
+                "(None: tool absent); peak = spec clock 2.4 GHz",
                 "traffic": traffic, "traffic_source": "profiles/" + pmc_file,
                 "operand_bytes_per_launch": opb / n, "traffic_over_operand_bytes": (traffic / (opb / n)) if traffic and opb else None,
                 "launches": n, "avg_launch_ms": 1e3 * secs / n,
