@@ -479,7 +479,7 @@ class ClockSampler:
         import subprocess
         try:
             out = subprocess.run([self.exe, "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
-            card = next(iter(json.loads(out).values()))
+            card = next(iter(json.loads(out[out.index("{"):]).values()))      # (a warning line may precede the JSON)
             for k, v in card.items():
                 if "sclk" in k.lower():
                     m = re.search(r"(\d+(?:\.\d+)?)\s*mhz", str(v).lower())
