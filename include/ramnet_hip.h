@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 13      /* 13: pair layout of ramnet_pack_weight_fold_wino for 32-channel layers; head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 14      /* 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -198,6 +198,11 @@ int ramnet_pred_sigmoid_fwd(const float *x, int ldx, int C, const float *w, cons
 /* backward of the above: dx[npix,C] = dz*w, dw[C] += sum dz*x, db += sum dz, dz = dy*y*(1-y).      */
 int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy,
                             float *dx, int lddx, float *dw, float *db, size_t npix, void *stream);
+/* The same layer WITHOUT the sigmoid (a normalisation follows: `norm` BN / IN, submodules.py:29-33): z = conv1x1(x) [+ b] (b may be
+ * NULL) and its backward dx = dz*w, dw += sum dz*x, db += sum dz (db may be NULL).                                       */
+int ramnet_pred_linear_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *z, size_t npix, void *stream);
+int ramnet_pred_linear_bwd(const float *x, int ldx, int C, const float *w, const float *dz, float *dx, int lddx, float *dw, float *db,
+                           size_t npix, void *stream);
 /* dx = dy * (y > 0) */
 int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *stream);
 /* Folded upsample-conv (UpsampleConvLayer forward as four 4x4 parity convolutions of the LOW-resolution input):
@@ -234,6 +239,20 @@ int ramnet_lstm_bwd(const float *gates, const float *cprev, const float *cnew, c
                     const float *dcn, float *dpre, float *dcprev, size_t npix, int C, void *stream);
 /* db[C] += sum_pixels dy * (mask > 0): bias gradient of the transposed-conv decoder (submodules.py:38-66). */
 int ramnet_bias_grad(const float *dy, const float *mask, float *db, size_t npix, int C, void *stream);
+/* ---- BatchNorm / InstanceNorm of `norm: "BN" | "IN"` layers: submodules.py:13-24, 29-30, 52-62, 82-94, 188-193, 203-210 ------
+ * NHWC tensors [groups][npix][C] (row stride ld* >= C); groups = 1 for BatchNorm (npix = B*H*W), B for InstanceNorm (npix = H*W).
+ * ramnet_norm_partial: part[((g * nslab + s) * C + c) * 2 + {0, 1}] = (sum a', sum a'*b) over the pixels p = s (mod nslab) ... of
+ *   group g in fp64, a' = a when y == NULL (forward: a = b = x gives mean and variance) or a * act'(y) (backward: a = dy; act:
+ *   0 none, 1 ReLU, 2 sigmoid, y = the layer's activated output); nslab from ramnet_norm_slabs; the caller sums over s.
+ * ramnet_norm_apply:   out = act(x * scale[g][c] + shift[g][c] [+ res]).
+ * ramnet_norm_bwd:     dx = c1[g][c] * dy' + c2[g][c] * x + c3[g][c], dy' = dy * act'(y); dres (optional) = dy'.            */
+int ramnet_norm_slabs(int groups, long npix, int C);
+int ramnet_norm_partial(const float *a, int lda, const float *y, int ldy, int act, const float *b, int ldb, int groups, long npix,
+                        int C, int nslab, double *part, void *stream);
+int ramnet_norm_apply(const float *x, int ldx, const float *scale, const float *shift, const float *res, int ldr, int act, float *out,
+                      int ldo, int groups, long npix, int C, void *stream);
+int ramnet_norm_bwd(const float *dy, int lddy, const float *y, int ldy, int act, const float *x, int ldx, const float *c1, const float *c2,
+                    const float *c3, float *dx, int lddx, float *dres, int lddres, int groups, long npix, int C, void *stream);
 /* y = a + b (gradient fan-in) */
 int ramnet_add(const float *a, const float *b, float *y, size_t n, void *stream);
 /* y [npix][Ca + Cb] = channel concatenation of a [npix][lda >= Ca] and b [npix][ldb >= Cb] (UNet skip_type 'concat',

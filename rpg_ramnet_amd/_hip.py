@@ -85,11 +85,18 @@ _SIGS = {
     "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),
     "ramnet_pred_sigmoid_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_pred_sigmoid_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_pred_linear_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_pred_linear_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_relu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_upsample2x_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_gru_bwd_a": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, C.c_int, _fp]),
     "ramnet_gru_bwd_b": (C.c_int, [_fp] * 5 + [C.c_size_t, C.c_int, _fp]),
     "ramnet_lstm_bwd": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
+    "ramnet_norm_slabs": (C.c_int, [C.c_int, C.c_long, C.c_int]),
+    "ramnet_norm_partial": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, _fp, _fp]),
+    "ramnet_norm_apply": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_long, C.c_int, _fp]),
+    "ramnet_norm_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int,
+                                  C.c_int, C.c_long, C.c_int, _fp]),
     "ramnet_add": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_split2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_concat2": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
@@ -152,7 +159,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 13:
+        if l.ramnet_abi_version() != 14:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

@@ -168,6 +168,7 @@ __global__ void bias_grad_kernel(const float *__restrict__ dy, const float *__re
 
 // ------------------------------------------------------------------------------------------ prediction head
 // 8 lanes per pixel, each owns channel quads q, q+8, ...; butterfly over the 8 lanes.
+template <bool SIG>
 __global__ void pred_sigmoid_fwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
                                         const float *__restrict__ bias, float *__restrict__ y, size_t npix) {
     const int sub = threadIdx.x & 7;
@@ -182,7 +183,7 @@ __global__ void pred_sigmoid_fwd_kernel(const float *__restrict__ x, int ldx, in
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
-        if (sub == 0) y[pix] = sigmoidf_(s + b0);
+        if (sub == 0) y[pix] = SIG ? sigmoidf_(s + b0) : s + b0;
     }
 }
 
@@ -206,8 +207,8 @@ __global__ void pred_sigmoid_bwd_kernel(const float *__restrict__ x, int ldx, in
         for (int u = 0; u < 4; ++u) {
             const size_t pix = pix0 + u * stride;
             const bool ok = pix < npix;
-            const float yy = ok ? y[pix] : 0.f;
-            dz[u] = ok ? dy[pix] * yy * (1.0f - yy) : 0.f;
+            const float yy = ok && y ? y[pix] : 0.f;         // y == NULL: the linear layer (no sigmoid)
+            dz[u] = ok ? (y ? dy[pix] * yy * (1.0f - yy) : dy[pix]) : 0.f;
             v[u] = ok && sub * 4 < C ? ld4(x + pix * ldx + sub * 4) : f4zero();
         }
 #pragma unroll
@@ -246,7 +247,7 @@ __global__ void pred_sigmoid_bwd_kernel(const float *__restrict__ x, int ldx, in
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int g = 0; g < 32; ++g) s += red[g];
-        atomicAdd(db, s);
+        if (db) atomicAdd(db, s);
     }
 }
 
@@ -627,20 +628,35 @@ extern "C" int ramnet_add(const float *a, const float *b, float *y, size_t n, vo
 
 extern "C" int ramnet_pred_sigmoid_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t npix, void *stream) {
     RAMNET_CHECK_ARG(x && w && y && C > 0 && C % 4 == 0 && ldx % 4 == 0);
-    hipLaunchKernelGGL(pred_sigmoid_fwd_kernel, dim3(grid_for(npix * 8)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, y, npix);
+    hipLaunchKernelGGL(pred_sigmoid_fwd_kernel<true>, dim3(grid_for(npix * 8)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, y, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, float *dx,
-                                       int lddx, float *dw, float *db, size_t npix, void *stream) {
-    RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
+static int pred_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, float *dx, int lddx, float *dw, float *db,
+                    size_t npix, void *stream) {
     if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
     int g = grid_for(npix * 8);      // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups
     if (g > 512) g = 512;
     hipLaunchKernelGGL(pred_sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, dx, lddx, dw, db, npix);
     RAMNET_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, float *dx,
+                                       int lddx, float *dw, float *db, size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
+    return pred_bwd(x, ldx, C, w, y, dy, dx, lddx, dw, db, npix, stream);
+}
+extern "C" int ramnet_pred_linear_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *z, size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(x && w && z && C > 0 && C % 4 == 0 && ldx % 4 == 0);
+    hipLaunchKernelGGL(pred_sigmoid_fwd_kernel<false>, dim3(grid_for(npix * 8)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, z, npix);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ramnet_pred_linear_bwd(const float *x, int ldx, int C, const float *w, const float *dz, float *dx, int lddx, float *dw, float *db,
+                                      size_t npix, void *stream) {
+    RAMNET_CHECK_ARG(x && w && dz && dw && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
+    return pred_bwd(x, ldx, C, w, nullptr, dz, dx, lddx, dw, db, npix, stream);
 }
 
 extern "C" int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int C, void *stream) {

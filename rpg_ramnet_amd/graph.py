@@ -157,6 +157,9 @@ class TimeBatchedStream:
 
     def __init__(self, model, B, H, W, max_events=8):
         assert not bool(model.baseline) and model.recurrent_block_type == "conv", "time-batched stream: asynchronous RAM-Net, conv encoders"
+        if getattr(model, "norm", None) in ("BN", "IN") and model.training:
+            raise RuntimeError("time-batched stream with norm layers: eval mode only (batching the encoders / decoders over time would "
+                               "change the batch statistics of a training-mode BatchNorm)")
         self.model, self.B, self.H, self.W, self.NM, dev = model, B, H, W, max_events, model.gpu
         self.net = net = model.statenetphasedrecurrent
         T = max_events + 1

@@ -132,4 +132,6 @@ class StateNetPhasedRecurrent(nn.Module):
             x = rb(x)
         for i, dec in enumerate(self.decoders):
             x = dec(x) if i == 0 else dec(x, pick(super_states[self.num_encoders - i - 1]))   # no skip into decoder 0
+        if self.norm in ('BN', 'IN'):          # conv1x1 -> norm -> sigmoid (statenet.py:116-117, 313)
+            return self.pred(x, act='sigmoid').permute(0, 3, 1, 2)           # NHWC [B,H,W,1] -> NCHW view
         return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

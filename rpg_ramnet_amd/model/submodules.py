@@ -12,9 +12,14 @@ from torch.nn import init
 from .. import ops
 
 
-def _check_norm(norm):
-    if norm in ("BN", "IN"):
-        raise NotImplementedError("norm=%r: no shipped RAM-Net config uses BN/IN (all use 'none'); not on the HIP path" % norm)
+def _norm_layer(norm, channels, track=True):
+    """The reference's norm member (submodules.py:19-24, 55-59, 85-89; ResidualBlock :188-193 builds its InstanceNorm WITHOUT running
+    statistics): a parameter / buffer holder with the same state_dict keys; ops.norm_act computes it.  Any other string ('none') = no norm."""
+    if norm == 'BN':
+        return nn.BatchNorm2d(channels, momentum=0.1)
+    if norm == 'IN':
+        return nn.InstanceNorm2d(channels, track_running_stats=track)
+    return None
 
 
 class _Lazy:
@@ -30,59 +35,87 @@ class _Lazy:
 class ConvLayer(nn.Module, _Lazy):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
         super().__init__()
-        _check_norm(norm)
         assert kernel_size in (1, 3, 5) and padding == kernel_size // 2, "HIP path: 'same' 1x1/3x3/5x5 convs"
         assert activation in ('relu', None)
-        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=True)
-        self.stride, self.relu = stride, activation == 'relu'
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=norm != 'BN')
+        self.stride, self.relu, self.norm = stride, activation == 'relu', norm
+        if norm in ('BN', 'IN'):
+            self.norm_layer = _norm_layer(norm, out_channels)
 
     def cp(self):
         return self._cp("c", [self.conv2d.weight], [self.conv2d.bias])
 
-    def forward(self, x):
+    def forward(self, x, act=None):
+        """act: activation applied instead of the layer's own (the prediction layer's sigmoid, statenet.py:313)."""
+        if self.norm in ('BN', 'IN'):
+            c = self.conv2d
+            if c.out_channels == 1 and c.kernel_size == (1, 1):       # the prediction layer: its own one-channel kernels
+                t = ops.PredLinear.apply(x, c.weight, c.bias)
+            else:
+                t = ops.ConvAct.apply(x, None, c.weight, c.bias, self.cp(), self.stride, False, False)
+            return ops.norm_act(t, self.norm_layer, act or ('relu' if self.relu else None))
+        assert act is None
         return ops.ConvAct.apply(x, None, self.conv2d.weight, self.conv2d.bias, self.cp(), self.stride, self.relu, False)
 
 
 class UpsampleConvLayer(nn.Module, _Lazy):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
         super().__init__()
-        _check_norm(norm)
         assert kernel_size == 5 and padding == 2 and stride == 1 and activation == 'relu'
-        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=True)
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=norm != 'BN')
+        self.norm = norm
+        if norm in ('BN', 'IN'):
+            self.norm_layer = _norm_layer(norm, out_channels)
 
     def cp(self):
         return self._cp("c", [self.conv2d.weight], [self.conv2d.bias])
 
     def forward(self, x, skip=None):
-        """relu(conv5x5(bilinear_x2(x [+ skip]))) — upsample and skip sum are fused into the conv's tile loader."""
+        """relu([norm](conv5x5(bilinear_x2(x [+ skip])))) — upsample and skip sum are fused into the conv's tile loader."""
+        if self.norm in ('BN', 'IN'):
+            t = ops.ConvAct.apply(x, skip, self.conv2d.weight, self.conv2d.bias, self.cp(), 1, False, True)
+            return ops.norm_act(t, self.norm_layer, 'relu')
         return ops.ConvAct.apply(x, skip, self.conv2d.weight, self.conv2d.bias, self.cp(), 1, True, True)
 
 
 class TransposedConvLayer(nn.Module, _Lazy):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, activation='relu', norm=None):
         super().__init__()
-        _check_norm(norm)
         assert kernel_size == 5 and padding == 2 and activation == 'relu'
         self.transposed_conv2d = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=2, padding=padding,
-                                                    output_padding=1, bias=True)
+                                                    output_padding=1, bias=norm != 'BN')
+        self.norm = norm
+        if norm in ('BN', 'IN'):
+            self.norm_layer = _norm_layer(norm, out_channels)
 
     def forward(self, x, skip=None):
         if skip is not None:
             x = ops.Add.apply(x, skip)
         t = self.transposed_conv2d
-        return ops.TConvAct.apply(x, t.weight, t.bias, self._cp("t", [t.weight], [t.bias]))
+        cp = self._cp("t", [t.weight], [t.bias])
+        if self.norm in ('BN', 'IN'):
+            return ops.norm_act(ops.TConvAct.apply(x, t.weight, t.bias, cp, False), self.norm_layer, 'relu')
+        return ops.TConvAct.apply(x, t.weight, t.bias, cp)
 
 
 class ResidualBlock(nn.Module, _Lazy):
     def __init__(self, in_channels, out_channels, norm=None):
         super().__init__()
-        _check_norm(norm)
-        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
-        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=norm != 'BN')
+        self.norm = norm
+        if norm in ('BN', 'IN'):        # (construction order of submodules.py:186-196: conv1, bn1, bn2, conv2)
+            self.bn1 = _norm_layer(norm, out_channels, track=False)
+            self.bn2 = _norm_layer(norm, out_channels, track=False)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=norm != 'BN')
 
     def forward(self, x):
         c1 = self._cp("c1", [self.conv1.weight], [self.conv1.bias])
         c2 = self._cp("c2", [self.conv2.weight], [self.conv2.bias])
+        if self.norm in ('BN', 'IN'):
+            t = ops.ConvAct.apply(x, None, self.conv1.weight, self.conv1.bias, c1, 1, False, False)
+            t = ops.norm_act(t, self.bn1, 'relu')
+            t = ops.ConvAct.apply(t, None, self.conv2.weight, self.conv2.bias, c2, 1, False, False)
+            return ops.norm_act(t, self.bn2, 'relu', res=x)
         t = ops.ConvAct.apply(x, None, self.conv1.weight, self.conv1.bias, c1, 1, True, False)
         return ops.ResConv.apply(t, x, self.conv2.weight, self.conv2.bias, c2)
 

@@ -16,7 +16,7 @@ class UNet(nn.Module):
             raise NotImplementedError("UNet skip_type %r does not run in the reference either: its decoders are built 2c wide "
                                       "(unet.py:78) and fed c channels" % (skip_type,))
         assert activation == 'sigmoid' and num_output_channels == 1
-        self.num_encoders = num_encoders
+        self.num_encoders, self.norm = num_encoders, norm
         self.skip_type = skip_type
         wide = 1 if skip_type == 'sum' else 2          # decoder / pred input width (unet.py:78, :83)
         if use_upsample_conv:
@@ -50,4 +50,6 @@ class UNet(nn.Module):
             else:
                 x = dec(ops.Concat.apply(x, skip))
         x = ops.Add.apply(x, head) if self.skip_type == 'sum' else ops.Concat.apply(x, head)      # head skip (unet.py:129)
+        if self.norm in ('BN', 'IN'):
+            return self.pred(x, act='sigmoid').permute(0, 3, 1, 2)           # NHWC [B,H,W,1] -> NCHW view
         return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

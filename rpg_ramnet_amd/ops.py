@@ -633,6 +633,8 @@ class ConvParam:
         return self._s2d
 
     def bias(self):
+        if self.biases[0] is None:          # norm 'BN': the convolution has no bias (submodules.py:13)
+            return None
         if len(self.biases) == 1:
             return self.biases[0].detach()
         v = self._versions(self.biases)
@@ -716,7 +718,7 @@ class ConvParam:
         if self._fold_used:
             self._finalize_fold()
         if not self._ws_used:
-            if self.biases[0].shape[0] == self.Cout:
+            if self.biases[0] is not None and self.biases[0].shape[0] == self.Cout:
                 ensure_grad(self.biases[0]).add_(self._bws)
             self._bws.zero_()
             self._dirty = False
@@ -731,7 +733,7 @@ class ConvParam:
             else:
                 H.check(H.lib().ramnet_unpack_wgrad(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off,
                                                     self.k, self.k, _st()), "ramnet_unpack_wgrad")
-            if b.shape[0] == n:                        # (transposed conv: bias has Cout_t entries, handled by its op)
+            if b is not None and b.shape[0] == n:      # (transposed conv: bias has Cout_t entries, handled by its op)
                 ensure_grad(b).add_(self._bws[off:off + n])
             off += n
         self._ws.zero_()
@@ -769,7 +771,8 @@ class S2DConvParam(ConvParam):
         else:
             H.check(L.ramnet_unpack_wgrad(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, 3, 3, _st()), "ramnet_unpack_wgrad")
         ensure_grad(w).add_(s2d_weights_adjoint(g3, self.parent.Cin))
-        ensure_grad(b).add_(self._bws)
+        if b is not None:
+            ensure_grad(b).add_(self._bws)
         self._ws.zero_()
         self._bws.zero_()
         self._dirty = self._ws_used = False
@@ -1068,14 +1071,15 @@ class TConvAct(Function):
     computes, so forward = 4 sub-pixel launches of the backward-data form, backward-data = a plain stride-2 conv."""
 
     @staticmethod
-    def forward(ctx, x, w, b, cp):
+    def forward(ctx, x, w, b, cp, relu=True):
         x = dense(x)
         B, Hh, W, _ = x.shape
         Ct = cp.Cin                                    # ConvParam sees (O=Cin_t, I=Cout_t): produced channels = cp.Cin
         y = torch.empty(B, 2 * Hh, 2 * W, Ct, device=x.device)
         conv_launch_multi(x, cp.bwd(), y, Ct, [(Taps.get("dgrad2", 5, 2, py, px), Hh, W, (2, 2, py, px))
-                                               for py in range(2) for px in range(2)], bias=cp.bias(), epi=H.EPI_RELU)
-        ctx.cp = cp
+                                               for py in range(2) for px in range(2)], bias=cp.bias(),
+                          epi=H.EPI_RELU if relu else H.EPI_LINEAR)
+        ctx.cp, ctx.relu = cp, relu
         ctx.save_for_backward(x, y)
         return y
 
@@ -1087,15 +1091,17 @@ class TConvAct(Function):
         B, Hh, W, Cx = x.shape
         taps = Taps.get("conv", 5, 2)
         ws, _ = cp.grad_ws()
+        mask, mode = (y, H.IN_RELUMASK) if ctx.relu else (None, H.IN_PLAIN)
         # weight gradient of the stride-2 conv (input = masked dy, output gradient = x); bias gradient = sum of masked dy
-        wgrad_launch(dy, taps, x, ws, Cx, stride=2, xm=y, in_mode=H.IN_RELUMASK)
-        dyc = dy.contiguous()
-        H.check(H.lib().ramnet_bias_grad(_p(dyc), _p(y), _p(ensure_grad(cp.biases[0])), B * 4 * Hh * W, cp.Cin, _st()), "bias_grad")
+        wgrad_launch(dy, taps, x, ws, Cx, stride=2, xm=mask, in_mode=mode)
+        if cp.biases[0] is not None:
+            dyc = dy.contiguous()
+            H.check(H.lib().ramnet_bias_grad(_p(dyc), _p(mask), _p(ensure_grad(cp.biases[0])), B * 4 * Hh * W, cp.Cin, _st()), "bias_grad")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, Hh, W, Cx, device=x.device)
-            conv_launch(dy, taps, cp.fwd(), dx, Cx, stride=2, xm=y, in_mode=H.IN_RELUMASK)
-        return dx, None, None, None
+            conv_launch(dy, taps, cp.fwd(), dx, Cx, stride=2, xm=mask, in_mode=mode)
+        return dx, None, None, None, None
 
 
 class ResConv(Function):
@@ -1127,6 +1133,108 @@ class ResConv(Function):
             dres = torch.empty_like(y)      # stream still reads dpre: hand it a buffer of its own
             H.check(H.lib().ramnet_relu_bwd(_p(dy), _p(y), _p(dres), y.numel(), _st()), "ramnet_relu_bwd")
         return dt, dres, None, None, None
+
+
+def norm_stats(x, groups):
+    """(mean, biased variance) of an NHWC tensor per (group, channel), fp64 [groups][C]: group = the whole batch (1: BatchNorm) or one
+    image (B: InstanceNorm).  One HIP reduction into per-slab partial sums + a tiny fixed-order sum."""
+    B, Hh, W, Cc = x.shape
+    npix = B * Hh * W // groups
+    L = H.lib()
+    nslab = L.ramnet_norm_slabs(groups, npix, Cc)
+    part = torch.empty(groups, nslab, Cc, 2, device=x.device, dtype=torch.float64)
+    H.check(L.ramnet_norm_partial(_p(x), Cc, None, 0, 0, _p(x), Cc, groups, npix, Cc, nslab, _p(part), _st()), "ramnet_norm_partial")
+    s = part.sum(1)
+    mean = s[..., 0] / npix
+    return mean, (s[..., 1] / npix - mean * mean).clamp_(min=0.0)
+
+
+class NormAct(Function):
+    """BatchNorm2d / InstanceNorm2d [+ residual] [+ ReLU | sigmoid] behind a convolution (submodules.py:29-33, 60-64, 92-96,
+    203-214): y = act((x - mean) * rstd * gamma + beta [+ res]).  mean / rstd [groups][C] come from norm_act(): the statistics of
+    x itself (batch_stats: their dependence on x is part of the gradient) or the layer's running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, mean, rstd, batch_stats, act):
+        x, res = dense(x).contiguous(), (dense(res).contiguous() if res is not None else None)
+        B, Hh, W, Cc = x.shape
+        groups = mean.shape[0]
+        npix = B * Hh * W // groups
+        scale = rstd if gamma is None else rstd * gamma.detach().double()
+        shift = -mean * scale if beta is None else beta.detach().double() - mean * scale
+        scale, shift = scale.float().contiguous(), shift.float().contiguous()
+        y = torch.empty_like(x)
+        H.check(H.lib().ramnet_norm_apply(_p(x), Cc, _p(scale), _p(shift), _p(res), Cc, act, _p(y), Cc, groups, npix, Cc, _st()),
+                "ramnet_norm_apply")
+        ctx.batch_stats, ctx.act, ctx.has_res = batch_stats, act, res is not None
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        dy = dense(dy).contiguous()
+        B, Hh, W, Cc = x.shape
+        groups = mean.shape[0]
+        npix = B * Hh * W // groups
+        L = H.lib()
+        act = ctx.act
+        nslab = L.ramnet_norm_slabs(groups, npix, Cc)
+        part = torch.empty(groups, nslab, Cc, 2, device=x.device, dtype=torch.float64)
+        H.check(L.ramnet_norm_partial(_p(dy), Cc, _p(y) if act else None, Cc, act, _p(x), Cc, groups, npix, Cc, nslab, _p(part), _st()),
+                "ramnet_norm_partial")
+        s = part.sum(1)
+        s1 = s[..., 0]                                   # sum g,   g = dy * act'(y)
+        s2 = rstd * (s[..., 1] - mean * s1)              # sum g * xhat
+        g64 = gamma.detach().double() if gamma is not None else torch.ones(Cc, device=x.device, dtype=torch.float64)
+        c1 = (g64 * rstd).expand(groups, Cc)
+        if ctx.batch_stats:       # dx = gamma * rstd * (g - s1 / N - xhat * s2 / N)
+            c2 = -g64 * rstd * rstd * s2 / npix
+            c3 = -g64 * rstd * s1 / npix - c2 * mean
+        else:                     # running statistics: constants
+            c2 = c3 = torch.zeros_like(c1)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        c1, c2, c3 = c1.float().contiguous(), c2.float().contiguous(), c3.float().contiguous()      # (named: alive across the launch)
+        H.check(L.ramnet_norm_bwd(_p(dy), Cc, _p(y) if act else None, Cc, act, _p(x), Cc, _p(c1), _p(c2), _p(c3), _p(dx), Cc, _p(dres), Cc,
+                                  groups, npix, Cc, _st()), "ramnet_norm_bwd")
+        dgamma = s2.sum(0).float() if gamma is not None else None
+        dbeta = s1.sum(0).float() if gamma is not None else None
+        return dx, dgamma, dbeta, dres, None, None, None, None
+
+
+_ACT_CODE = {None: 0, "relu": 1, "sigmoid": 2}
+
+
+def norm_act(x, layer, act=None, res=None):
+    """`layer` (nn.BatchNorm2d | nn.InstanceNorm2d: the parameter / buffer holder with the reference's state_dict keys) applied to the
+    NHWC tensor x, then [+ res] and the activation.  Statistics and running-buffer updates follow torch: BatchNorm uses the batch
+    statistics in training mode (running = (1 - m) running + m (mean, UNBIASED variance), num_batches_tracked += 1) and the running
+    ones in eval mode; InstanceNorm uses per-image statistics unless it tracks running statistics AND is in eval mode, and in
+    training mode feeds the batch mean of its per-image (mean, unbiased variance) into the running buffers."""
+    B, Hh, W, Cc = x.shape
+    inst = isinstance(layer, torch.nn.InstanceNorm2d)
+    tracked = layer.running_mean is not None
+    use_input = layer.training or not tracked
+    if use_input:
+        groups = B if inst else 1
+        mean, var = norm_stats(x.detach(), groups)
+        n = B * Hh * W // groups
+        if tracked and layer.training:
+            if n < 2:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ([B, Cc, Hh, W],))
+            with torch.no_grad():
+                m = layer.momentum
+                if not inst:
+                    layer.num_batches_tracked += 1
+                    if m is None:
+                        m = 1.0 / float(layer.num_batches_tracked)
+                layer.running_mean.mul_(1.0 - m).add_((m * mean.mean(0)).to(layer.running_mean.dtype))
+                layer.running_var.mul_(1.0 - m).add_((m * (var * (n / (n - 1.0))).mean(0)).to(layer.running_var.dtype))
+    else:
+        mean, var = layer.running_mean.detach().double()[None], layer.running_var.detach().double()[None]
+    rstd = (var + layer.eps).rsqrt()
+    return NormAct.apply(x, layer.weight, layer.bias, res, mean, rstd, use_input, _ACT_CODE[act])
 
 
 class GRUCell(Function):
@@ -1243,6 +1351,31 @@ class PredSigmoid(Function):
         dx = torch.empty(B, Hh, W, Cc, device=x.device) if ctx.needs_input_grad[0] else None
         H.check(H.lib().ramnet_pred_sigmoid_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), _p(dx), Cc,
                                                 _p(ensure_grad(w)), _p(ensure_grad(b)), B * Hh * W, _st()), "pred_bwd")
+        return dx, None, None
+
+
+class PredLinear(Function):
+    """The prediction layer's 1x1 convolution to ONE channel without its sigmoid (a norm layer follows, submodules.py:29-33):
+    NHWC [B,H,W,C] -> [B,H,W,1]; the bias is absent under norm 'BN'."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = dense(x)
+        B, Hh, W, Cc = x.shape
+        z = torch.empty(B, Hh, W, 1, device=x.device)
+        H.check(H.lib().ramnet_pred_linear_fwd(_p(x), ld(x), Cc, _p(w.detach()), _p(b.detach()) if b is not None else None, _p(z),
+                                               B * Hh * W, _st()), "pred_linear_fwd")
+        ctx.save_for_backward(x, w, b)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, b = ctx.saved_tensors
+        B, Hh, W, Cc = x.shape
+        dz = dz.contiguous()
+        dx = torch.empty(B, Hh, W, Cc, device=x.device) if ctx.needs_input_grad[0] else None
+        H.check(H.lib().ramnet_pred_linear_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(dz), _p(dx), Cc, _p(ensure_grad(w)),
+                                               _p(ensure_grad(b)) if b is not None else None, B * Hh * W, _st()), "pred_linear_bwd")
         return dx, None, None
 
 

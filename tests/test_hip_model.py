@@ -510,3 +510,65 @@ def test_streaming_inference_driver_and_folder_evaluation(tmp_path):
     assert res["files"] == len(names)
     np.testing.assert_allclose(res["abs_rel_diff"], np.mean(ref), rtol=2e-4)
     assert "80_abs_rel_diff" in res
+
+
+# ------------------------------------------------------------------------------------------------ norm 'BN' / 'IN'
+def _is_buffer(k):
+    return k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")
+
+
+@pytest.mark.parametrize("tag,arch", [("small_gru_bn", "ERGB2DepthRecurrent"), ("small_gru_in", "ERGB2DepthRecurrent"),
+                                      ("small_lstm_tconv_bn", "ERGB2DepthRecurrent"), ("small_unet_bn", "ERGB2Depth"),
+                                      ("small_unet_in", "ERGB2Depth")])
+def test_norm_layers_vs_reference_fixture(tag, arch):
+    """`norm: "BN" | "IN"` (submodules.py:13-24, 29-30, 188-193, 203-210) on the HIP path: the reference's state_dict (incl. the norm
+    buffers) loads strictly; two training-mode calls (batch / per-image statistics, running buffers updated) and one eval-mode call
+    (running statistics) reproduce the reference's predictions and buffers."""
+    z = load_golden("norm_%s.npz" % tag)
+    cfg = json.loads(str(z["config"]))
+    model = build_hip_model(arch, cfg)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}, strict=True)
+    K = cfg["every_x_rgb_frame"]
+    prev_super, prev_lstm = None, ramnet_ref.empty_states_lstm(K)
+    ncalls = int(z["train_calls"]) + 1
+    with torch.no_grad():
+        for c in range(ncalls):
+            model.train(c < ncalls - 1)
+            pre = "in%d." % c
+            item = {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+            preds, supers, lstms = model(item, prev_super, prev_lstm)
+            for k, v in preds.items():
+                assert_close(v.cpu().numpy(), z["pred%d.%s" % (c, k)], TOL, "%s call %d pred %s" % (tag, c, k), elem_tol=TOL)
+            sd = model.state_dict()
+            for k in [f for f in z.files if f.startswith("buf%d." % c)]:
+                np.testing.assert_allclose(sd[k[5:]].cpu().numpy(), z[k], rtol=2e-4, atol=1e-6, err_msg=k)
+            if arch == "ERGB2DepthRecurrent":
+                prev_super, prev_lstm = supers["image"], lstms
+
+
+@pytest.mark.parametrize("tag", ["small_gru_bn", "small_gru_in"])
+def test_norm_layers_bptt_gradients_vs_reference_fixture(tag):
+    """2-package BPTT in training mode through the norm layers: loss, every parameter gradient (incl. the BatchNorm affine pairs) and
+    the running buffers against the reference's own trainer (norm_grads_*.npz)."""
+    from rpg_ramnet_amd.trainer import sequence_loss
+    z = load_golden("norm_grads_%s.npz" % tag)
+    cfg = json.loads(str(z["config"]))
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}, strict=True)
+    seq = []
+    for l in range(int(z["L"])):
+        pre = "in%d." % l
+        seq.append({k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)})
+    total, reported = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+    np.testing.assert_allclose(float(reported), float(z["reported_loss"]), rtol=1e-4)
+    model.zero_grad()
+    total.backward()
+    gmax = max(float(p.grad.abs().max()) for p in model.parameters())
+    n = 0
+    for k, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), z["g." + k], 5e-3, "grad " + k, floor=1e-2 * gmax)
+        n += 1
+    assert n > 20
+    for k, v in model.state_dict().items():
+        if _is_buffer(k):
+            np.testing.assert_allclose(v.cpu().numpy(), z["buf." + k], rtol=2e-4, atol=1e-6, err_msg=k)

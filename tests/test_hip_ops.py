@@ -15,10 +15,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def run_pair(module, oracle_fn, inputs, seed=0):
-    """module: rpg_ramnet_amd layer (NHWC, cuda); oracle_fn(sd, *nchw_cpu_inputs) -> tensor or tuple."""
+def run_pair(module, oracle_fn, inputs, seed=0, grad_floor=0.0):
+    """module: rpg_ramnet_amd layer (NHWC, cuda); oracle_fn(sd, *nchw_cpu_inputs) -> tensor or tuple.
+    grad_floor: parameter gradients below this fraction of the largest one count as cancellation noise (a bias in front of a
+    normalisation has an analytically ZERO gradient: both sides return rounding residue)."""
     module = module.to(dev())
-    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in module.state_dict().items()}
+    params = dict(module.named_parameters())          # (buffers — the running statistics of norm layers — carry no gradient)
+    sd = {k: (v.detach().cpu().clone().requires_grad_(True) if k in params else v.detach().cpu().clone())
+          for k, v in module.state_dict().items()}
     cpu_in = [None if t is None else t.clone().requires_grad_(True) for t in inputs]
     gpu_in = [None if t is None else nhwc(t).to(dev()).requires_grad_(True) for t in inputs]
     ref = oracle_fn(sd, *cpu_in)
@@ -44,9 +48,13 @@ def run_pair(module, oracle_fn, inputs, seed=0):
         if c is not None and c.grad is not None:
             assert gi.grad is not None, "missing input grad %d" % i
             assert_close(nchw(gi.grad).cpu().numpy(), c.grad.numpy(), TOL, "grad input %d" % i)
+    gmax = max(float(sd[k].grad.abs().max()) for k in params)
     for k, p in module.named_parameters():
         assert p.grad is not None, "missing grad for " + k
-        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), TOL, "grad " + k)
+        assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), TOL, "grad " + k, floor=grad_floor * gmax)
+    for k, v in module.state_dict().items():           # running statistics updated by a training-mode forward
+        if k not in params:
+            np.testing.assert_allclose(v.cpu().numpy(), sd[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
 SHAPES = [(2, 16, 32), (1, 8, 16), (3, 9, 37), (2, 24, 20)]
@@ -257,6 +265,55 @@ def test_residual_block(B, H, W, C, algo3x3):
     m = ResidualBlock(C, C)
     run_pair(m, lambda sd, a: ramnet_ref.residual_block({"L." + k: v for k, v in sd.items()}, "L", a),
              [torch.randn(B, C, H, W)])
+
+
+def _randomise_norm(m, seed):
+    """Non-trivial affine parameters and running statistics for every norm member of m."""
+    g = torch.Generator().manual_seed(seed)
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.InstanceNorm2d)):
+            with torch.no_grad():
+                if mod.weight is not None:
+                    mod.weight.copy_(1.0 + 0.3 * torch.randn(mod.weight.shape, generator=g))
+                    mod.bias.copy_(0.2 * torch.randn(mod.bias.shape, generator=g))
+                if mod.running_mean is not None:
+                    mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+                    mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("norm", ["BN", "IN"])
+@pytest.mark.parametrize("layer", ["conv_s2", "conv_s1_c12", "pred", "upconv", "upconv_skip", "tconv", "resblock"])
+def test_norm_layers(layer, norm, training):
+    """ConvLayer / UpsampleConvLayer / TransposedConvLayer / ResidualBlock with `norm` 'BN' | 'IN' (submodules.py:13-24, 29-30, 52-62,
+    82-94, 188-193, 203-210): forward, input and parameter gradients (incl. the BatchNorm affine pair) and the running-buffer update
+    against the oracle, in training mode (statistics of the input) and in eval mode (running statistics)."""
+    from rpg_ramnet_amd.model import submodules as S
+    torch.manual_seed(11)
+    B, Hh, W = 2, 12, 20
+    nk = dict(norm=norm, training=training)
+    if layer == "conv_s2":
+        m, ins = S.ConvLayer(32, 64, 5, 2, 2, norm=norm), [torch.randn(B, 32, Hh, W)]
+        fn = lambda sd, a: ramnet_ref.conv_layer(sd, "L", a, 2, 2, **nk)  # noqa: E731
+    elif layer == "conv_s1_c12":       # a channel count that is not a multiple of 16 (scalar path of the kernels: 12 = 3 quads)
+        m, ins = S.ConvLayer(8, 12, 3, 1, 1, norm=norm), [torch.randn(B, 8, Hh, W)]
+        fn = lambda sd, a: ramnet_ref.conv_layer(sd, "L", a, 1, 1, **nk)  # noqa: E731
+    elif layer == "pred":              # conv1x1 -> norm -> (no activation): ONE output channel
+        m, ins = S.ConvLayer(32, 1, 1, activation=None, norm=norm), [torch.randn(B, 32, Hh, W)]
+        fn = lambda sd, a: ramnet_ref.conv_layer(sd, "L", a, 1, 0, relu=False, **nk)  # noqa: E731
+    elif layer in ("upconv", "upconv_skip"):
+        m = S.UpsampleConvLayer(64, 32, 5, padding=2, norm=norm)
+        ins = [torch.randn(B, 64, Hh, W)] + ([torch.randn(B, 64, Hh, W)] if layer == "upconv_skip" else [])
+        fn = lambda sd, a, b=None: ramnet_ref.upsample_conv_layer(sd, "L", a if b is None else a + b, **nk)  # noqa: E731
+    elif layer == "tconv":
+        m, ins = S.TransposedConvLayer(64, 32, 5, padding=2, norm=norm), [torch.randn(B, 64, Hh, W)]
+        fn = lambda sd, a: ramnet_ref.transposed_conv_layer(sd, "L", a, **nk)  # noqa: E731
+    else:
+        m, ins = S.ResidualBlock(64, 64, norm=norm), [torch.randn(B, 64, Hh, W)]
+        fn = lambda sd, a: ramnet_ref.residual_block(sd, "L", a, **nk)  # noqa: E731
+    _randomise_norm(m, 5)
+    m.train(training)
+    run_pair(m, lambda sd, *a: fn({"L." + k: v for k, v in sd.items()}, *a), ins, grad_floor=1e-2)
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256), (1, 16, 32, 128)])

@@ -225,3 +225,59 @@ def test_msg_loss_restatement_is_consistent():
     g = loss_ref.spatial_gradient(ramp)
     assert torch.allclose(g[:, :, 0, :, 1:-1], torch.ones(2, 1, 32, 30))     # d/dx of a unit ramp
     assert torch.allclose(g[:, :, 1], torch.zeros(2, 1, 32, 32))
+
+
+# ------------------------------------------------------------------------------------------------ norm 'BN' / 'IN'
+NORM_NETS = ["small_gru_bn", "small_gru_in", "small_lstm_tconv_bn", "small_unet_bn", "small_unet_in"]
+
+
+def norm_items(z, c):
+    pre = "in%d." % c
+    return {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+
+
+def is_buffer(k):
+    return k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")
+
+
+@pytest.mark.parametrize("tag", NORM_NETS)
+def test_norm_layers_training_and_eval_calls(golden_dir, tag):
+    """BatchNorm / InstanceNorm variants (submodules.py:13-24, 29-30, 188-193): two training-mode calls (batch / per-image statistics,
+    running buffers updated in place) and one eval-mode call (running statistics) of the reference, predictions and buffers."""
+    z = load(golden_dir, "norm_%s.npz" % tag)
+    cfg = json.loads(str(z["config"]))
+    arch, sd = str(z["arch"]), {k: v.clone() for k, v in sd_from(z).items()}
+    fwd = ramnet_ref.forward_recurrent if arch == "ERGB2DepthRecurrent" else ramnet_ref.forward_unet
+    prev_super, prev_lstm = None, ramnet_ref.empty_states_lstm(cfg["every_x_rgb_frame"])
+    ncalls = int(z["train_calls"]) + 1
+    with torch.no_grad():
+        for c in range(ncalls):
+            preds, supers, lstms = fwd(sd, dict(cfg, training=c < ncalls - 1), norm_items(z, c), prev_super, prev_lstm)
+            for k, v in preds.items():
+                np.testing.assert_allclose(v.numpy(), z["pred%d.%s" % (c, k)], rtol=1e-4, atol=2e-6, err_msg="call %d %s" % (c, k))
+            for k in [f for f in z.files if f.startswith("buf%d." % c)]:
+                np.testing.assert_allclose(sd[k[5:]].numpy(), z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+            if arch == "ERGB2DepthRecurrent":
+                prev_super, prev_lstm = supers["image"], lstms
+    assert any(is_buffer(k) for k in sd) or cfg["norm"] == "IN"
+
+
+@pytest.mark.parametrize("tag", ["small_gru_bn", "small_gru_in"])
+def test_norm_layers_bptt_gradients(golden_dir, tag):
+    z = load(golden_dir, "norm_grads_%s.npz" % tag)
+    cfg = json.loads(str(z["config"]))
+    sd = {k: (v.clone() if is_buffer(k) else v.clone().requires_grad_(True)) for k, v in sd_from(z).items()}
+    seq = [norm_items(z, l) for l in range(int(z["L"]))]
+    total, _ = ramnet_ref.sequence_loss(sd, dict(cfg, training=True), seq, cfg["loss_composition"], [1, 1])
+    total.backward()
+    np.testing.assert_allclose(len(cfg["loss_composition"]) * float(total.detach()), float(z["reported_loss"]), rtol=1e-5)
+    n = 0
+    for k, v in sd.items():
+        if is_buffer(k):
+            np.testing.assert_allclose(v.numpy(), z["buf." + k], rtol=1e-5, atol=1e-6, err_msg=k)
+            continue
+        want = z["g." + k]
+        got = v.grad.numpy()          # (only the REPORTED loss carries the aliased-dict factor, lstm_trainer.py:281)
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-5 * max(1.0, float(np.abs(want).max())), err_msg=k)
+        n += 1
+    assert n > 20
