@@ -372,3 +372,59 @@ def test_gemm_entry_point_raw(M, N, K):
     assert L.ramnet_gemm(ptr(a2), ptr(b2), ptr(c2), M, N, K, K, N, N, 0, 0, 2, M * K, K * N, M * N, st) == 0
     ref2 = torch.bmm(a2.double().cpu(), b2.double().cpu())
     assert float((c2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("groups_mode", ["batch", "instance"])
+@pytest.mark.parametrize("C_", [32, 6])
+def test_norm_entry_points_raw(groups_mode, C_):
+    """ramnet_norm_partial / _apply / _bwd with raw pointers (16-byte channel quads and the scalar path): batch / instance
+    normalisation + ReLU forward and backward against float64 autograd of the textbook formula."""
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(3)
+    B, H, W = 3, 9, 14
+    x = torch.randn(B, H, W, C_, device=dev) * 2 + 0.5
+    gamma, beta = torch.rand(C_, device=dev) + 0.5, torch.randn(C_, device=dev) * 0.2
+    dy = torch.randn(B, H, W, C_, device=dev)
+    G = 1 if groups_mode == "batch" else B
+    npix = B * H * W // G
+    nslab = L.ramnet_norm_slabs(G, npix, C_)
+    assert nslab >= 1
+    part = torch.empty(G, nslab, C_, 2, dtype=torch.float64, device=dev)
+    assert L.ramnet_norm_partial(ptr(x), C_, None, 0, 0, ptr(x), C_, G, npix, C_, nslab, ptr(part), st) == 0, L.ramnet_last_error()
+    s = part.sum(1)
+    mean = s[..., 0] / npix
+    var = s[..., 1] / npix - mean * mean
+    xd = x.double().cpu().requires_grad_(True)
+    xr = xd.reshape(G, npix, C_)
+    mu, vv = xr.mean(1, keepdim=True), xr.var(1, unbiased=False, keepdim=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), mu[:, 0].detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(var.cpu().numpy(), vv[:, 0].detach().numpy(), rtol=1e-5)
+    eps = 1e-5
+    rstd = (var + eps).rsqrt()
+    scale = (rstd * gamma.double()).float().contiguous()
+    shift = (beta.double() - mean * rstd * gamma.double()).float().contiguous()
+    y = torch.empty_like(x)
+    assert L.ramnet_norm_apply(ptr(x), C_, ptr(scale), ptr(shift), None, 0, 1, ptr(y), C_, G, npix, C_, st) == 0, L.ramnet_last_error()
+    ref = torch.relu((xr - mu) / (vv + eps).sqrt() * gamma.double().cpu() + beta.double().cpu()).reshape(B, H, W, C_)
+    assert float((y.cpu().double() - ref.detach()).abs().max()) < 2e-5
+    (ref * dy.double().cpu()).sum().backward()
+    assert L.ramnet_norm_partial(ptr(dy), C_, ptr(y), C_, 1, ptr(x), C_, G, npix, C_, nslab, ptr(part), st) == 0
+    s = part.sum(1)
+    s1 = s[..., 0]
+    s2 = rstd * (s[..., 1] - mean * s1)
+    g64 = gamma.double()
+    c1 = (g64 * rstd).float().contiguous()
+    c2d = -g64 * rstd * rstd * s2 / npix
+    c3 = (-g64 * rstd * s1 / npix - c2d * mean).float().contiguous()
+    c2 = c2d.float().contiguous()
+    dx = torch.empty_like(x)
+    assert L.ramnet_norm_bwd(ptr(dy), C_, ptr(y), C_, 1, ptr(x), C_, ptr(c1), ptr(c2), ptr(c3), ptr(dx), C_, None, 0, G, npix, C_, st) == 0, \
+        L.ramnet_last_error()
+    # pixels on the ReLU kink of either side are excluded (the fp32 output is 0 where the fp64 one is 1e-8)
+    ok = ((y.cpu() > 0) == (ref.detach() > 0)).all(dim=-1, keepdim=True).expand_as(dx)
+    err = ((dx.cpu().double() - xd.grad)[ok]).abs().max() / xd.grad.abs().max()
+    assert float(err) < 1e-4, float(err)
+    # refused: a row stride below the channel count
+    assert L.ramnet_norm_apply(ptr(x), C_ - 1, ptr(scale), ptr(shift), None, 0, 1, ptr(y), C_, G, npix, C_, st) == 10001
