@@ -244,11 +244,22 @@ int ramnet_bias_grad(const float *dy, const float *mask, float *db, size_t npix,
  * ramnet_norm_partial: part[((g * nslab + s) * C + c) * 2 + {0, 1}] = (sum a', sum a'*b) over the pixels p = s (mod nslab) ... of
  *   group g in fp64, a' = a when y == NULL (forward: a = b = x gives mean and variance) or a * act'(y) (backward: a = dy; act:
  *   0 none, 1 ReLU, 2 sigmoid, y = the layer's activated output); nslab from ramnet_norm_slabs; the caller sums over s.
+ * ramnet_norm_finalize: mean, rstd [groups][C] (fp64), scale = gamma * rstd, shift = beta - mean * scale (fp32; gamma / beta may be
+ *   NULL = 1 / 0) from the partial sums — or, use_running != 0 (eval mode, groups = 1), from the running buffers.  update_running:
+ *   running = (1 - momentum) * running + momentum * mean over the groups of (mean, UNBIASED variance), as torch's BatchNorm2d /
+ *   InstanceNorm2d(track_running_stats=True) in training mode; num_batches_tracked (int64, may be NULL) += 1.
+ * ramnet_norm_finalize_bwd: from the backward's partial sums: c1, c2, c3 [groups][C] of ramnet_norm_bwd (batch_stats = the forward
+ *   normalised with the statistics of x itself; 0 = running statistics: c2 = c3 = 0), dgamma / dbeta [C] (=, may be NULL).
  * ramnet_norm_apply:   out = act(x * scale[g][c] + shift[g][c] [+ res]).
  * ramnet_norm_bwd:     dx = c1[g][c] * dy' + c2[g][c] * x + c3[g][c], dy' = dy * act'(y); dres (optional) = dy'.            */
 int ramnet_norm_slabs(int groups, long npix, int C);
 int ramnet_norm_partial(const float *a, int lda, const float *y, int ldy, int act, const float *b, int ldb, int groups, long npix,
                         int C, int nslab, double *part, void *stream);
+int ramnet_norm_finalize(const double *part, int groups, int nslab, int C, long npix, double eps, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, double momentum, int update_running, int use_running,
+                         long long *num_batches_tracked, double *mean, double *rstd, float *scale, float *shift, void *stream);
+int ramnet_norm_finalize_bwd(const double *part, int groups, int nslab, int C, long npix, const double *mean, const double *rstd,
+                             const float *gamma, int batch_stats, float *c1, float *c2, float *c3, float *dgamma, float *dbeta, void *stream);
 int ramnet_norm_apply(const float *x, int ldx, const float *scale, const float *shift, const float *res, int ldr, int act, float *out,
                       int ldo, int groups, long npix, int C, void *stream);
 int ramnet_norm_bwd(const float *dy, int lddy, const float *y, int ldy, int act, const float *x, int ldx, const float *c1, const float *c2,

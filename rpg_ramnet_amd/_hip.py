@@ -94,6 +94,9 @@ _SIGS = {
     "ramnet_lstm_bwd": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, _fp]),
     "ramnet_norm_slabs": (C.c_int, [C.c_int, C.c_long, C.c_int]),
     "ramnet_norm_partial": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, _fp, _fp]),
+    "ramnet_norm_finalize": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_double, _fp, _fp, _fp, _fp, C.c_double, C.c_int, C.c_int,
+                                       _fp, _fp, _fp, _fp, _fp, _fp]),
+    "ramnet_norm_finalize_bwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_long, _fp, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]),
     "ramnet_norm_apply": (C.c_int, [_fp, C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_long, C.c_int, _fp]),
     "ramnet_norm_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int,
                                   C.c_int, C.c_long, C.c_int, _fp]),

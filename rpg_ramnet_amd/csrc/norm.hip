@@ -4,11 +4,13 @@
 //
 //   ramnet_norm_partial   per (group, channel) partial sums  sum a, sum a*b  in fp64  (forward: a = b = x -> mean / variance;
 //                         backward: a = dy * act'(y), b = x -> the two reductions of the normalisation's gradient)
+//   ramnet_norm_finalize  partial sums (or the running buffers) -> mean, rstd (fp64), scale = gamma * rstd, shift = beta - mean * scale,
+//                         and torch's running-buffer update, one thread per channel
 //   ramnet_norm_apply     y = act(x * scale[g][c] + shift[g][c] [+ residual])
+//   ramnet_norm_finalize_bwd  partial sums of the backward -> c1, c2, c3 [groups][C], dgamma, dbeta
 //   ramnet_norm_bwd       dx = c1[g][c] * (dy * act'(y)) + c2[g][c] * x + c3[g][c]   [, dres = dy * act'(y)]
 //
-// group = the statistics' extent: 1 for BatchNorm (all B*H*W pixels), B for InstanceNorm (H*W pixels of one image).  The tiny
-// [groups][C] vectors between the kernels (mean, rstd, running statistics, scale / shift, c1..c3) are formed by the host side.
+// group = the statistics' extent: 1 for BatchNorm (all B*H*W pixels), B for InstanceNorm (H*W pixels of one image).
 // Lanes run along channels (consecutive addresses: 16-byte loads when C % 4 == 0), a workgroup's thread rows along pixels.
 #include "common.hpp"
 
@@ -111,6 +113,87 @@ __global__ void __launch_bounds__(256) norm_pointwise_kernel(const float *__rest
     }
 }
 
+// Sum of the per-slab partials of (group g, channel c) by the 16 slab lanes of a channel (fixed order: bit-reproducible); the
+// result is valid in lane 0.  Block = 256 threads = 16 channels x 16 slab lanes.
+__device__ __forceinline__ void norm_slab_sum(const double *__restrict__ part, int g, int nslab, int C, int c, int lane, double (*red)[16][2],
+                                              double &s0, double &s1) {
+    const int cl = threadIdx.x & 15;
+    s0 = 0.0, s1 = 0.0;
+    if (c < C)
+        for (int s = lane; s < nslab; s += 16) {
+            const double *q = part + (((size_t)g * nslab + s) * C + c) * 2;
+            s0 += q[0], s1 += q[1];
+        }
+    __syncthreads();                    // (the previous group's reads of `red` are done)
+    red[lane][cl][0] = s0, red[lane][cl][1] = s1;
+    __syncthreads();
+    if (lane == 0)
+        for (int l = 1; l < 16; ++l) s0 += red[l][cl][0], s1 += red[l][cl][1];
+}
+
+// 16 channels per block: fixed-order sum over the slabs, statistics of every group, running-buffer update (torch semantics:
+// running = (1 - m) * running + m * mean over the groups of (mean, UNBIASED variance); num_batches_tracked += 1 when given).
+// use_running: mean / variance ARE the running buffers (eval mode; groups = 1, `part` unused).
+__global__ void norm_finalize_kernel(const double *__restrict__ part, int groups, int nslab, int C, double npix, double eps,
+                                     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ rmean,
+                                     float *__restrict__ rvar, double momentum, int update, int use_running, long long *__restrict__ tracked,
+                                     double *__restrict__ mean, double *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift) {
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+    const bool own = lane == 0 && c < C;
+    if (c == 0 && lane == 0 && tracked != nullptr && update) tracked[0] += 1;
+    const double ga = own && gamma ? (double)gamma[c] : 1.0, be = own && beta ? (double)beta[c] : 0.0;
+    double am = 0.0, av = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        double m = 0.0, v = 1.0;
+        if (use_running) {
+            if (own) m = (double)rmean[c], v = (double)rvar[c];
+        } else {
+            double s0, s1;
+            norm_slab_sum(part, g, nslab, C, c, lane, red, s0, s1);
+            m = s0 / npix;
+            v = s1 / npix - m * m;
+            v = v > 0.0 ? v : 0.0;
+            am += m, av += v * (npix / (npix - 1.0));
+        }
+        if (!own) continue;
+        const double r = 1.0 / sqrt(v + eps), sc = ga * r;
+        mean[g * C + c] = m, rstd[g * C + c] = r;
+        scale[g * C + c] = (float)sc, shift[g * C + c] = (float)(be - m * sc);
+    }
+    if (own && update && !use_running && rmean != nullptr) {
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * am / groups);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * av / groups);
+    }
+}
+
+// part = (sum g, sum g * x) per (group, slab, channel), g = dy * act'(y)  ->  dx = c1 * g + c2 * x + c3 with
+// c1 = gamma * rstd, and under batch statistics c2 = -gamma * rstd^2 * S2 / N, c3 = -gamma * rstd * S1 / N - c2 * mean
+// (S1 = sum g, S2 = sum g * xhat = rstd * (sum g x - mean * S1)); dgamma = sum_groups S2, dbeta = sum_groups S1.
+__global__ void norm_finalize_bwd_kernel(const double *__restrict__ part, int groups, int nslab, int C, double npix,
+                                         const double *__restrict__ mean, const double *__restrict__ rstd, const float *__restrict__ gamma,
+                                         int batch_stats, float *__restrict__ c1, float *__restrict__ c2, float *__restrict__ c3,
+                                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double red[16][16][2];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), lane = threadIdx.x >> 4;
+    const bool own = lane == 0 && c < C;
+    const double ga = own && gamma ? (double)gamma[c] : 1.0;
+    double dg = 0.0, db = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        double s1, sx;
+        norm_slab_sum(part, g, nslab, C, c, lane, red, s1, sx);
+        if (!own) continue;
+        const double m = mean[g * C + c], r = rstd[g * C + c], s2 = r * (sx - m * s1);
+        const double k2 = batch_stats ? -ga * r * r * s2 / npix : 0.0;
+        c1[g * C + c] = (float)(ga * r);
+        c2[g * C + c] = (float)k2;
+        c3[g * C + c] = (float)(batch_stats ? -ga * r * s1 / npix - k2 * m : 0.0);
+        dg += s2, db += s1;
+    }
+    if (own && dgamma) dgamma[c] = (float)dg;
+    if (own && dbeta) dbeta[c] = (float)db;
+}
+
 static int pointwise_blocks(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b > 16384 ? 16384 : b < 1 ? 1 : b);
@@ -123,7 +206,7 @@ using namespace ramnet;
 extern "C" int ramnet_norm_slabs(int groups, long npix, int C) {
     const int V = C % 4 == 0 ? 4 : 1, CQ = C / V, TC = CQ < 256 ? CQ : 256, rows = 256 / TC;
     long n = (npix + (long)rows * 8 - 1) / ((long)rows * 8);
-    const long cap = 2048 / (groups < 2048 ? groups : 2048);
+    const long cap = 1024 / (groups < 1024 ? groups : 1024);        // ~1024 workgroups stream at full rate; the joins stay short
     if (n > cap) n = cap;
     return (int)(n < 1 ? 1 : n);
 }
@@ -172,6 +255,29 @@ extern "C" int ramnet_norm_bwd(const float *dy, int lddy, const float *y, int ld
     else
         hipLaunchKernelGGL((norm_pointwise_kernel<1, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, act, x, ldx, c1, c2, c3,
                            nullptr, 0, dx, lddx, dres, lddres, npix, groups, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_norm_finalize(const double *part, int groups, int nslab, int C, long npix, double eps, const float *gamma, const float *beta,
+                                    float *running_mean, float *running_var, double momentum, int update_running, int use_running,
+                                    long long *num_batches_tracked, double *mean, double *rstd, float *scale, float *shift, void *stream) {
+    RAMNET_CHECK_ARG(groups > 0 && C > 0 && npix > 0 && mean && rstd && scale && shift && (use_running || (part && nslab > 0)));
+    RAMNET_CHECK_ARG(!use_running || (running_mean && running_var && groups == 1));
+    RAMNET_CHECK_ARG(!update_running || use_running || !running_mean || npix > 1);
+    RAMNET_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, groups, nslab, C, (double)npix, eps, gamma,
+                       beta, running_mean, running_var, momentum, update_running, use_running, num_batches_tracked, mean, rstd, scale, shift);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_norm_finalize_bwd(const double *part, int groups, int nslab, int C, long npix, const double *mean, const double *rstd,
+                                        const float *gamma, int batch_stats, float *c1, float *c2, float *c3, float *dgamma, float *dbeta,
+                                        void *stream) {
+    RAMNET_CHECK_ARG(part && groups > 0 && nslab > 0 && C > 0 && npix > 0 && mean && rstd && c1 && c2 && c3);
+    hipLaunchKernelGGL(norm_finalize_bwd_kernel, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, part, groups, nslab, C, (double)npix, mean,
+                       rstd, gamma, batch_stats, c1, c2, c3, dgamma, dbeta);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

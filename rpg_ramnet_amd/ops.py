@@ -1135,15 +1135,21 @@ class ResConv(Function):
         return dt, dres, None, None, None
 
 
-def norm_stats(x, groups):
-    """(mean, biased variance) of an NHWC tensor per (group, channel), fp64 [groups][C]: group = the whole batch (1: BatchNorm) or one
-    image (B: InstanceNorm).  One HIP reduction into per-slab partial sums + a tiny fixed-order sum."""
-    B, Hh, W, Cc = x.shape
+def _norm_partial(a, y, act, b, groups):
+    """Per (group, slab, channel) partial sums (sum a', sum a' * b) in fp64, a' = a or a * act'(y) (csrc/norm.hip)."""
+    B, Hh, W, Cc = b.shape
     npix = B * Hh * W // groups
     L = H.lib()
     nslab = L.ramnet_norm_slabs(groups, npix, Cc)
-    part = torch.empty(groups, nslab, Cc, 2, device=x.device, dtype=torch.float64)
-    H.check(L.ramnet_norm_partial(_p(x), Cc, None, 0, 0, _p(x), Cc, groups, npix, Cc, nslab, _p(part), _st()), "ramnet_norm_partial")
+    part = torch.empty(groups, nslab, Cc, 2, device=b.device, dtype=torch.float64)
+    H.check(L.ramnet_norm_partial(_p(a), Cc, _p(y), Cc, act, _p(b), Cc, groups, npix, Cc, nslab, _p(part), _st()), "ramnet_norm_partial")
+    return part, nslab, npix
+
+
+def norm_stats(x, groups):
+    """(mean, biased variance) of an NHWC tensor per (group, channel), fp64 [groups][C]: group = the whole batch (1: BatchNorm) or one
+    image (B: InstanceNorm)."""
+    part, _, npix = _norm_partial(x, None, 0, x, groups)
     s = part.sum(1)
     mean = s[..., 0] / npix
     return mean, (s[..., 1] / npix - mean * mean).clamp_(min=0.0)
@@ -1151,21 +1157,17 @@ def norm_stats(x, groups):
 
 class NormAct(Function):
     """BatchNorm2d / InstanceNorm2d [+ residual] [+ ReLU | sigmoid] behind a convolution (submodules.py:29-33, 60-64, 92-96,
-    203-214): y = act((x - mean) * rstd * gamma + beta [+ res]).  mean / rstd [groups][C] come from norm_act(): the statistics of
-    x itself (batch_stats: their dependence on x is part of the gradient) or the layer's running statistics."""
+    203-214): y = act(x * scale + shift [+ res]) with scale = gamma * rstd, shift = beta - mean * scale [groups][C] from norm_act():
+    the statistics of x itself (batch_stats: their dependence on x is part of the gradient) or the layer's running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, mean, rstd, batch_stats, act):
+    def forward(ctx, x, gamma, beta, res, mean, rstd, scale, shift, batch_stats, act):
         x, res = dense(x).contiguous(), (dense(res).contiguous() if res is not None else None)
         B, Hh, W, Cc = x.shape
         groups = mean.shape[0]
-        npix = B * Hh * W // groups
-        scale = rstd if gamma is None else rstd * gamma.detach().double()
-        shift = -mean * scale if beta is None else beta.detach().double() - mean * scale
-        scale, shift = scale.float().contiguous(), shift.float().contiguous()
         y = torch.empty_like(x)
-        H.check(H.lib().ramnet_norm_apply(_p(x), Cc, _p(scale), _p(shift), _p(res), Cc, act, _p(y), Cc, groups, npix, Cc, _st()),
-                "ramnet_norm_apply")
+        H.check(H.lib().ramnet_norm_apply(_p(x), Cc, _p(scale), _p(shift), _p(res), Cc, act, _p(y), Cc, groups, B * Hh * W // groups, Cc,
+                                          _st()), "ramnet_norm_apply")
         ctx.batch_stats, ctx.act, ctx.has_res = batch_stats, act, res is not None
         ctx.save_for_backward(x, y, gamma, mean, rstd)
         return y
@@ -1174,33 +1176,19 @@ class NormAct(Function):
     def backward(ctx, dy):
         x, y, gamma, mean, rstd = ctx.saved_tensors
         dy = dense(dy).contiguous()
-        B, Hh, W, Cc = x.shape
-        groups = mean.shape[0]
-        npix = B * Hh * W // groups
-        L = H.lib()
-        act = ctx.act
-        nslab = L.ramnet_norm_slabs(groups, npix, Cc)
-        part = torch.empty(groups, nslab, Cc, 2, device=x.device, dtype=torch.float64)
-        H.check(L.ramnet_norm_partial(_p(dy), Cc, _p(y) if act else None, Cc, act, _p(x), Cc, groups, npix, Cc, nslab, _p(part), _st()),
-                "ramnet_norm_partial")
-        s = part.sum(1)
-        s1 = s[..., 0]                                   # sum g,   g = dy * act'(y)
-        s2 = rstd * (s[..., 1] - mean * s1)              # sum g * xhat
-        g64 = gamma.detach().double() if gamma is not None else torch.ones(Cc, device=x.device, dtype=torch.float64)
-        c1 = (g64 * rstd).expand(groups, Cc)
-        if ctx.batch_stats:       # dx = gamma * rstd * (g - s1 / N - xhat * s2 / N)
-            c2 = -g64 * rstd * rstd * s2 / npix
-            c3 = -g64 * rstd * s1 / npix - c2 * mean
-        else:                     # running statistics: constants
-            c2 = c3 = torch.zeros_like(c1)
+        Cc = x.shape[3]
+        groups, act, L = mean.shape[0], ctx.act, H.lib()
+        part, nslab, npix = _norm_partial(dy, y if act else None, act, x, groups)
+        c = torch.empty(3, groups, Cc, device=x.device)
+        dgb = torch.empty(2, Cc, device=x.device) if gamma is not None else None
+        H.check(L.ramnet_norm_finalize_bwd(_p(part), groups, nslab, Cc, npix, _p(mean), _p(rstd), _p(gamma.detach()) if gamma is not None else None,
+                                           int(ctx.batch_stats), _p(c[0]), _p(c[1]), _p(c[2]), _p(dgb[0]) if dgb is not None else None,
+                                           _p(dgb[1]) if dgb is not None else None, _st()), "ramnet_norm_finalize_bwd")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        c1, c2, c3 = c1.float().contiguous(), c2.float().contiguous(), c3.float().contiguous()      # (named: alive across the launch)
-        H.check(L.ramnet_norm_bwd(_p(dy), Cc, _p(y) if act else None, Cc, act, _p(x), Cc, _p(c1), _p(c2), _p(c3), _p(dx), Cc, _p(dres), Cc,
+        H.check(L.ramnet_norm_bwd(_p(dy), Cc, _p(y) if act else None, Cc, act, _p(x), Cc, _p(c[0]), _p(c[1]), _p(c[2]), _p(dx), Cc, _p(dres), Cc,
                                   groups, npix, Cc, _st()), "ramnet_norm_bwd")
-        dgamma = s2.sum(0).float() if gamma is not None else None
-        dbeta = s1.sum(0).float() if gamma is not None else None
-        return dx, dgamma, dbeta, dres, None, None, None, None
+        return dx, (dgb[0] if dgb is not None else None), (dgb[1] if dgb is not None else None), dres, None, None, None, None, None, None
 
 
 _ACT_CODE = {None: 0, "relu": 1, "sigmoid": 2}
@@ -1208,33 +1196,36 @@ _ACT_CODE = {None: 0, "relu": 1, "sigmoid": 2}
 
 def norm_act(x, layer, act=None, res=None):
     """`layer` (nn.BatchNorm2d | nn.InstanceNorm2d: the parameter / buffer holder with the reference's state_dict keys) applied to the
-    NHWC tensor x, then [+ res] and the activation.  Statistics and running-buffer updates follow torch: BatchNorm uses the batch
-    statistics in training mode (running = (1 - m) running + m (mean, UNBIASED variance), num_batches_tracked += 1) and the running
-    ones in eval mode; InstanceNorm uses per-image statistics unless it tracks running statistics AND is in eval mode, and in
-    training mode feeds the batch mean of its per-image (mean, unbiased variance) into the running buffers."""
+    NHWC tensor x, then [+ res] and the activation: three launches (partial sums, finalize, apply).  Statistics and running-buffer
+    updates follow torch: BatchNorm uses the batch statistics in training mode (running = (1 - m) running + m (mean, UNBIASED
+    variance), num_batches_tracked += 1) and the running ones in eval mode; InstanceNorm uses per-image statistics unless it tracks
+    running statistics AND is in eval mode, and in training mode feeds the batch mean of its per-image (mean, unbiased variance)
+    into the running buffers."""
+    x = dense(x).contiguous()
     B, Hh, W, Cc = x.shape
     inst = isinstance(layer, torch.nn.InstanceNorm2d)
     tracked = layer.running_mean is not None
     use_input = layer.training or not tracked
+    groups = (B if inst else 1) if use_input else 1
+    npix = B * Hh * W // groups
+    update = bool(tracked and layer.training)
+    if update and npix < 2:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ([B, Cc, Hh, W],))
+    if update and layer.momentum is None:
+        raise NotImplementedError("cumulative moving average (momentum=None): the reference builds its norm layers with momentum 0.1")
+    dev = x.device
+    mr = torch.empty(2, groups, Cc, device=dev, dtype=torch.float64)
+    ss = torch.empty(2, groups, Cc, device=dev)
+    part, nslab = None, 0
     if use_input:
-        groups = B if inst else 1
-        mean, var = norm_stats(x.detach(), groups)
-        n = B * Hh * W // groups
-        if tracked and layer.training:
-            if n < 2:
-                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ([B, Cc, Hh, W],))
-            with torch.no_grad():
-                m = layer.momentum
-                if not inst:
-                    layer.num_batches_tracked += 1
-                    if m is None:
-                        m = 1.0 / float(layer.num_batches_tracked)
-                layer.running_mean.mul_(1.0 - m).add_((m * mean.mean(0)).to(layer.running_mean.dtype))
-                layer.running_var.mul_(1.0 - m).add_((m * (var * (n / (n - 1.0))).mean(0)).to(layer.running_var.dtype))
-    else:
-        mean, var = layer.running_mean.detach().double()[None], layer.running_var.detach().double()[None]
-    rstd = (var + layer.eps).rsqrt()
-    return NormAct.apply(x, layer.weight, layer.bias, res, mean, rstd, use_input, _ACT_CODE[act])
+        part, nslab, _ = _norm_partial(x, None, 0, x, groups)
+    g, b = layer.weight, layer.bias
+    H.check(H.lib().ramnet_norm_finalize(_p(part), groups, nslab, Cc, npix, float(layer.eps), _p(g.detach()) if g is not None else None,
+                                         _p(b.detach()) if b is not None else None, _p(layer.running_mean), _p(layer.running_var),
+                                         float(layer.momentum or 0.0), int(update), int(not use_input),
+                                         _p(layer.num_batches_tracked) if (update and not inst) else None,
+                                         _p(mr[0]), _p(mr[1]), _p(ss[0]), _p(ss[1]), _st()), "ramnet_norm_finalize")
+    return NormAct.apply(x, g, b, res, mr[0], mr[1], ss[0], ss[1], use_input, _ACT_CODE[act])
 
 
 class GRUCell(Function):

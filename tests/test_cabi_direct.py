@@ -405,6 +405,20 @@ def test_norm_entry_points_raw(groups_mode, C_):
     rstd = (var + eps).rsqrt()
     scale = (rstd * gamma.double()).float().contiguous()
     shift = (beta.double() - mean * rstd * gamma.double()).float().contiguous()
+    # the same vectors from the library's own finalize kernel, with torch's running-buffer update
+    rm, rv = torch.zeros(C_, device=dev), torch.ones(C_, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    mr = torch.empty(2, G, C_, dtype=torch.float64, device=dev)
+    ss = torch.empty(2, G, C_, device=dev)
+    assert L.ramnet_norm_finalize(ptr(part), G, nslab, C_, npix, eps, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1, 0, ptr(nbt),
+                                  ptr(mr[0]), ptr(mr[1]), ptr(ss[0]), ptr(ss[1]), st) == 0, L.ramnet_last_error()
+    np.testing.assert_allclose(mr[0].cpu().numpy(), mean.cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(mr[1].cpu().numpy(), rstd.cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(ss[0].cpu().numpy(), scale.reshape(G, C_).cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(ss[1].cpu().numpy(), shift.reshape(G, C_).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * mean.mean(0).cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * (var * npix / (npix - 1)).mean(0)).cpu().numpy(), rtol=1e-6)
+    assert int(nbt) == 1
     y = torch.empty_like(x)
     assert L.ramnet_norm_apply(ptr(x), C_, ptr(scale), ptr(shift), None, 0, 1, ptr(y), C_, G, npix, C_, st) == 0, L.ramnet_last_error()
     ref = torch.relu((xr - mu) / (vv + eps).sqrt() * gamma.double().cpu() + beta.double().cpu()).reshape(B, H, W, C_)
@@ -419,6 +433,14 @@ def test_norm_entry_points_raw(groups_mode, C_):
     c2d = -g64 * rstd * rstd * s2 / npix
     c3 = (-g64 * rstd * s1 / npix - c2d * mean).float().contiguous()
     c2 = c2d.float().contiguous()
+    cc = torch.empty(3, G, C_, device=dev)
+    dgb = torch.empty(2, C_, device=dev)
+    assert L.ramnet_norm_finalize_bwd(ptr(part), G, nslab, C_, npix, ptr(mr[0]), ptr(mr[1]), ptr(gamma), 1, ptr(cc[0]), ptr(cc[1]), ptr(cc[2]),
+                                      ptr(dgb[0]), ptr(dgb[1]), st) == 0, L.ramnet_last_error()
+    for got, want in ((cc[0], c1), (cc[1], c2), (cc[2], c3)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.reshape(G, C_).cpu().numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(dgb[0].cpu().numpy(), s2.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dgb[1].cpu().numpy(), s1.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-6)
     dx = torch.empty_like(x)
     assert L.ramnet_norm_bwd(ptr(dy), C_, ptr(y), C_, 1, ptr(x), C_, ptr(c1), ptr(c2), ptr(c3), ptr(dx), C_, None, 0, G, npix, C_, st) == 0, \
         L.ramnet_last_error()
