@@ -23,6 +23,7 @@
 // per combination that occurs), the patch prefetch is one buffer load per slot (zero padding = out-of-range offset), the
 // concatenation a descriptor / offset select — 235-313 instructions per two chunks instead of 560, training step 190 -> 197.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "conv_epilogue.hpp"
 
@@ -327,6 +328,60 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                 st4(g, gi), st4(g + C, gf), st4(g + 2 * C, go), st4(g + 3 * C, gc);
             }
         }
+        return;
+    }
+    if (q.vec4 && !q.s2d_shift) {
+        // Channel-quad epilogue in two phases: every global operand of the thread's 4 * NF output quads (bias, residual / update gate,
+        // previous state, accumulated output) is REQUESTED first, then the quads are transformed out of LDS, activated and stored.
+        // One epilogue kind per straight-line instantiation: the former per-quad `switch (epi)` around the loads made every quad wait
+        // for its own round trips (2-3 serialized L2 / HBM latencies x 8 quads per thread, 5500 instructions of branches).
+        constexpr int NI = 4 * NF;
+        const int qd = NF == 2 ? tid & 15 : tid & 7, nq = n0 + qd * 4;       // (the same quad for all i: 256 threads = 16 x 16 quads)
+        const bool nok = nq < p.Cout;
+        const int nqs = nok ? nq : 0;
+        const float4 bias4 = p.bias ? ld4(p.bias + nqs) : f4zero();
+        const bool addold = p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
+        bool ok[NI];
+        size_t pix[NI];
+        int pxl[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int sl = tid + i * 256;
+            pxl[i] = NF == 2 ? sl >> 4 : sl >> 3;
+            const int oy = oy0 + pxl[i] / RTW, ox = ox0 + pxl[i] % RTW;
+            ok[i] = nok && oy < p.Ho && ox < p.Wo;
+            pix[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;     // (a valid address either way)
+        }
+        auto run = [&](auto kind) {
+            constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend
+            float4 ea[NI], eb[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                ea[i] = K >= 1 ? ld4(p.e0 + pix[i] * p.lde0 + nqs) : addold ? ld4(p.out + pix[i] * p.ldo + nqs) : f4zero();
+                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : f4zero();
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (!ok[i]) continue;
+                float4 v = f4add(out4(pxl[i], qd * 4), bias4);
+                if (K == 0) {
+                    if (addold) v = make_float4(v.x + p.beta * ea[i].x, v.y + p.beta * ea[i].y, v.z + p.beta * ea[i].z, v.w + p.beta * ea[i].w);
+                    if (epi == RAMNET_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    else if (epi == RAMNET_EPI_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+                } else if (K == 1) {
+                    v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
+                } else {
+                    const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
+                    if (p.o1) st4(p.o1 + pix[i] * p.ldo1 + nq, o);
+                    v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
+                                    h.w * (1.0f - u.w) + o.w * u.w);
+                }
+                st4(p.out + pix[i] * p.ldo + nq, v);
+            }
+        };
+        if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
+        else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
         return;
     }
 #pragma unroll
