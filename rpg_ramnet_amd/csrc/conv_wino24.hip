@@ -259,11 +259,19 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     }
     W24_STAMP(16, 2);
 
-    // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue
+    // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue.
+    // All 16 outputs of the lane are finished in registers (bias — ONE load —, border corrections, ReLU) and stored at the end: with the
+    // stores interleaved, every border-correction block (a conditional load) was followed by a wait for ALL memory operations, i.e. for
+    // the previous output's store (stores count in vmcnt on gfx9): 16 serialized write latencies per workgroup, which holds its CU alone.
     const int ncol = n0 + cq * 16 + l15;
     const int pxc = PAIR ? ncol >> 5 : px, n = PAIR ? ncol & 31 : ncol;      // PAIR: column = (column parity, channel)
     if (n >= p.Cout) return;
     const int epi = p.epi;
+    const float bias_n = (!DG && p.bias) ? p.bias[n] : 0.f;
+    const bool relu = epi == RAMNET_EPI_RELU;
+    float ov[16];
+    size_t op[16];
+    bool oo[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float s[2][5];
@@ -281,18 +289,25 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             const float y1 = s[a2][1] - s[a2][2] + 2.f * s[a2][3] + s[a2][4];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
-                const int oy = oy0 + a2, ox = ox0 + c2;
+                const int oy = oy0 + a2, ox = ox0 + c2, idx = (r * 2 + a2) * 2 + c2;
                 if (DG) {                           // dense output grid, plain store
-                    if (oy < p.Ho && ox < p.Wo) p.out[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.ldo + n] = c2 ? y1 : y0;
+                    oo[idx] = oy < p.Ho && ox < p.Wo;
+                    op[idx] = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.ldo + n;
+                    ov[idx] = c2 ? y1 : y0;
                     continue;
                 }
-                if (oy >= q.Hc || ox >= q.Wc || (PAIR && ox < 0)) continue;
+                oo[idx] = !(oy >= q.Hc || ox >= q.Wc || (PAIR && ox < 0));
                 const int oyF = 2 * oy + py, oxF = 2 * ox + pxc;
-                const size_t pix = ((size_t)b * p.HoF + oyF) * p.WoF + oxF;
-                epilogue_store(p, epi, pix, n, (c2 ? y1 : y0) + epilogue_side(p, epi, b, oyF, oxF, n), false);
+                op[idx] = (((size_t)b * p.HoF + oyF) * p.WoF + oxF) * p.ldo + n;
+                float v = (c2 ? y1 : y0) + bias_n;
+                if (oo[idx]) v += epilogue_side(p, epi, b, oyF, oxF, n);
+                ov[idx] = relu ? fmaxf(v, 0.f) : v;
             }
         }
     }
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx)
+        if (oo[idx]) p.out[op[idx]] = ov[idx];
     W24_STAMP(16, 3);
 }
 
