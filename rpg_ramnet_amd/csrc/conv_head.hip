@@ -87,6 +87,9 @@ __global__ void __launch_bounds__(256, 2) conv_head_fwd_kernel(const HeadFwdPara
     float wreg[G::NS];
 #pragma unroll
     for (int s = 0; s < G::NS; ++s) wreg[s] = p.wp[(2 * s + h) * 32 + n];
+    // (loaded HERE, in front of the patch staging that waits for all its loads: a bias load still pending at the epilogue makes the
+    // compiler wait for ALL memory operations — i.e. for the previous STORE — in front of each of the 64 conditional stores)
+    const float bv = (p.bias && n < p.Cout) ? p.bias[n] : 0.f;
 
     head_stage_patch<CR, HF_H>(P, p.x, p.ld, b, oy0, ox0, p.H, p.W, tid);
     __syncthreads();
@@ -108,7 +111,6 @@ __global__ void __launch_bounds__(256, 2) conv_head_fwd_kernel(const HeadFwdPara
     }
 
     if (n >= p.Cout) return;
-    const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int oy = oy0 + wave * 4 + t;
