@@ -6,6 +6,7 @@ kernel into per-layer [tap][Cin][Cout] workspaces over ALL time steps of a BPTT 
 ``param.grad`` (OIHW) once, by a callback queued on the autograd engine (the reference gets the same sums from
 autograd's per-use accumulation, lstm_trainer.py:450).
 """
+import contextlib
 import ctypes as C
 import os as _os
 
@@ -324,6 +325,23 @@ def _side_stream(dev):
     if st is None:
         st = _SIDE[dev] = torch.cuda.Stream(device=dev)       # (a lower stream priority measured no effect)
     return st
+
+
+@contextlib.contextmanager
+def side_work(tensors, dev):
+    """Everything enqueued inside runs on the backward-weights side stream (behind what the current stream has enqueued so far);
+    `tensors` = what it reads of the current stream's tensors (kept alive for the side stream).  Inline when the side stream is off."""
+    if not _USE_SIDE:
+        yield
+        return
+    side = _side_stream(dev)
+    side.wait_event(torch.cuda.current_stream().record_event())
+    with torch.cuda.stream(side):
+        yield
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    _Engine.side_used = dev
 
 
 def wgrad_side(tensors, *args, **kw):
@@ -905,27 +923,31 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     H2, W2 = 2 * Hh, 2 * W
     dev = x.device
     w4, wr, wc, bws = cp.grad_ws_fold()
-    if xpad is None:            # not kept by forward (RAMNET_SAVE_XPAD=0): recompute pad2(x + skip)
-        xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
-        H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
-    if _FOLD_WINO_WGRAD and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
-                                                                             (Cc % 64 == 0 and cp.Cout % 32 == 0)):
-        # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
-        wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, 0, 0), dy, cp.grad_ws_fold24(), cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
-                   gview=(0, 0, 0, 0, H2, W2), wino24=True)
-    else:
-        for py in range(2):
-            for px in range(2):
-                wgrad_side([xpad, dy, y], xpad, Taps.get("fold", 4, 0, py, px), dy, w4, cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
-                           gview=(2, 2, py, px, H2, W2), dw_off=(py * 2 + px) * 16 * cp.CinWs * cp.Cout)
-    a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
-    a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
-    H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
-    g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
-    g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
-    H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
-    gemm(a_rows, g_rows, wr, trans_a=True, accumulate=True)      # wr[s] += a_rows[s]^T g_rows[s]: the border GEMMs' weight gradient
-    gemm(a_cols, g_cols, wc, trans_a=True, accumulate=True)
+    # The WHOLE backward-weights path of the layer — the recomputed padded sum, the Winograd launch, the unrolled border lines, the
+    # frame of dy and the two border-GEMM gradients (~0.3 ms of small, latency-bound launches per layer and time step) — runs on the
+    # side stream: nothing of it is needed before the end of the backward pass (round 3; before, only the Winograd launch did).
+    with side_work([x, skip, dy, y, xpad], dev):
+        if xpad is None:            # not kept by forward (RAMNET_SAVE_XPAD=0): recompute pad2(x + skip)
+            xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
+            H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
+        if _FOLD_WINO_WGRAD and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
+                                                                                 (Cc % 64 == 0 and cp.Cout % 32 == 0)):
+            # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
+            wgrad_launch(xpad, Taps.get("fold", 4, 0, 0, 0), dy, cp.grad_ws_fold24(), cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
+                         gview=(0, 0, 0, 0, H2, W2), wino24=True)
+        else:
+            for py in range(2):
+                for px in range(2):
+                    wgrad_launch(xpad, Taps.get("fold", 4, 0, py, px), dy, w4, cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
+                                 gview=(2, 2, py, px, H2, W2), dw_off=(py * 2 + px) * 16 * cp.CinWs * cp.Cout)
+        a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
+        a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+        H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
+        g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
+        g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
+        H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
+        gemm(a_rows, g_rows, wr, trans_a=True, accumulate=True)      # wr[s] += a_rows[s]^T g_rows[s]: the border GEMMs' weight gradient
+        gemm(a_cols, g_cols, wc, trans_a=True, accumulate=True)
 
 
 # Backward-data of the folded upsample-conv: the adjoint of (four parity convolutions of the replicate-padded input + border GEMMs),

@@ -31,7 +31,9 @@ PKG = os.path.join(ROOT, "rpg_ramnet_amd")
 OUT = os.path.join(PKG, "abl")
 SCRATCH = os.environ.get("RAMNET_ABL_SCRATCH", "/tmp/ramnet_abl")
 MASKS = {"conv_wgrad_wino": [0, 1, 2, 4, 8, 16, 3, 7, 15, 128, 256, 384],
-         "conv_wino": [0, 1, 2, 4, 8, 16, 32, 3, 7, 39, 47, 64, 128, 192]}
+         "conv_wino": [0, 1, 2, 4, 8, 16, 32, 3, 7, 39, 47, 64, 128, 192],
+         "conv_wino24": [0, 1, 2, 4, 8, 32, 39, 47, 64, 128, 192]}        # the folded decoders: timed with `bench_layers.py --only dec`
+ONLY = {"conv_wgrad_wino": "gru", "conv_wino": "gru", "conv_wino24": "dec"}
 
 
 def _sub(s, old, new, count=1):
@@ -81,6 +83,27 @@ def patch_wino(s):
     return _sub(s, "__builtin_amdgcn_sched_barrier(0);", "if (!(ABL & 16)) __builtin_amdgcn_sched_barrier(0);", 0)
 
 
+def patch_wino24(s):
+    """1 no window loads, 2 no LDS reads of the transformed input, 4 no transform (arithmetic + LDS writes), 8 no barrier, 32 no weight
+    loads, 64 no epilogue, 128 no main loop."""
+    s = _sub(s, '#include "conv_epilogue.hpp"\n',
+             '#include "conv_epilogue.hpp"\n#ifndef ABL\n#define ABL 0\n#endif\n#define W24_ABLATE ((ABL & 1) | ((ABL & 32) ? 2 : 0))\n'
+             '#define OPQ4(QQ) asm volatile("" : "+v"((QQ).x), "+v"((QQ).y), "+v"((QQ).z), "+v"((QQ).w))\n')
+    s = _sub(s, "    auto tr_col = [&](int c) {\n", "    auto tr_col = [&](int c) {\n        if (ABL & 4) return;\n")
+    s = _sub(s, "    auto tr_row = [&](float *vbuf, int i) {\n", "    auto tr_row = [&](float *vbuf, int i) {\n        if (ABL & 4) return;\n")
+    s = _sub(s, "                if (pos + 2 < 25) aq[(pp + 1) & 1][0] = ldv(vb + (pos + 2) * W24_PS + aoff);\n"
+                "                if (pos + 3 < 25) aq[(pp + 1) & 1][1] = ldv(vb + (pos + 3) * W24_PS + aoff);",
+             "                if (ABL & 2) { OPQ4(aq[(pp + 1) & 1][0]); OPQ4(aq[(pp + 1) & 1][1]); } else {\n"
+             "                if (pos + 2 < 25) aq[(pp + 1) & 1][0] = ldv(vb + (pos + 2) * W24_PS + aoff);\n"
+             "                if (pos + 3 < 25) aq[(pp + 1) & 1][1] = ldv(vb + (pos + 3) * W24_PS + aoff); }")
+    s = _sub(s, "            W24_STAMP(chunk, 4);\n            __syncthreads();", "            W24_STAMP(chunk, 4);\n            if (!(ABL & 8)) __syncthreads();")
+    s = _sub(s, "    for (int chunk0 = 0; chunk0 < nch; chunk0 += 2) {", "    for (int chunk0 = 0; chunk0 < ((ABL & 128) ? 0 : nch); chunk0 += 2) {")
+    s = _sub(s, "    // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue.",
+             "    if (ABL & 64) { float t = 0.f; for (int i = 0; i < 25; ++i) for (int r = 0; r < 4; ++r) t += acc[i][r]; if (t == 123.456f) p.out[0] = t; return; }\n"
+             "    // ---- output transform A^T M A (A^T = [1 1 1 1 0; 0 1 -1 2 1]) of the lane's 4 tiles x 1 channel, fused epilogue.")
+    return s
+
+
 def build():
     sys.path.insert(0, ROOT)
     from rpg_ramnet_amd import build as B
@@ -90,7 +113,7 @@ def build():
     os.makedirs(os.path.join(SCRATCH, "include"))
     shutil.copytree(B.CSRC, src)
     shutil.copy(os.path.join(ROOT, "include", "ramnet_hip.h"), os.path.join(SCRATCH, "include"))
-    for stem, fn in (("conv_wgrad_wino", patch_wgrad), ("conv_wino", patch_wino)):
+    for stem, fn in (("conv_wgrad_wino", patch_wgrad), ("conv_wino", patch_wino), ("conv_wino24", patch_wino24)):
         p = os.path.join(src, stem + ".hip")
         with open(p) as f:
             s = f.read()
@@ -121,15 +144,18 @@ def run():
                 lib = os.path.join(OUT, "%s_%d.so" % (stem, m))
                 if not os.path.exists(lib):
                     continue
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_layers.py"), "--only", "gru", "--reps", "20"],
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_layers.py"), "--only", ONLY[stem], "--reps", "20"],
                                    env=dict(os.environ, RAMNET_HIP_LIB=lib), capture_output=True, text=True, timeout=300)
                 line = [l for l in r.stdout.splitlines() if l.startswith("sum")]
                 f = line[0].split() if line else []
-                msg = "%-16s ABL=%-3d  six ConvGRU launches: forward %s  backward-data %s  backward-weights %s ms" % (
-                    stem, m, f[3] if f else "?", f[6] if f else "?", f[9] if f else "?")
+                msg = "%-16s ABL=%-3d  %s: forward %s  backward-data %s  backward-weights %s ms" % (
+                    stem, m, "six ConvGRU launches" if ONLY[stem] == "gru" else "three decoders (+ plain variants)",
+                    f[3] if f else "?", f[6] if f else "?", f[9] if f else "?")
                 print(msg)
                 out.write(msg + "\n")
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2:                                   # restrict to some kernels: build conv_wino24
+        MASKS = {k: v for k, v in MASKS.items() if k in sys.argv[2:]}
     {"build": build, "run": run}[sys.argv[1] if len(sys.argv) > 1 else "build"]()
