@@ -247,26 +247,40 @@ static int msg_args(int B, int H, int W, int ns, MsgArgs &a, size_t &total) {
 // Index arithmetic restated from events_to_voxel_grid_pytorch (utils/event_tensor_utils.py:152-180):
 // float64 normalised time, floor, float32 votes pol*(1-dt) / pol*dt, `0 <= ti < bins` guards.
 #pragma clang fp contract(off)
-__device__ __forceinline__ void voxel_vote(double t, double x, double y, double p, double t0, double t1, int bins, int W, int H,
-                                           long long &il, float &vl, long long &ir, float &vr, long long *til_out = nullptr,
-                                           long long *base_out = nullptr) {
+// (xs, ys, pol) of an event and whether it lies inside the image; then the two votes of (t, xs, ys, pol) — split so that the sorted form
+// can carry the integer coordinates between its two passes; voxel_vote() is the composition, operation for operation as before.
+__device__ __forceinline__ bool voxel_coord(double x, double y, double p, int W, int H, long long &xs, long long &ys, float &pol) {
+    xs = (long long)x, ys = (long long)y;
+    pol = (float)p;
+    if (pol == 0.f) pol = -1.f;
+    return xs >= 0 && xs < W && ys >= 0 && ys < H;        // the reference would raise on an OOB index
+}
+
+__device__ __forceinline__ void voxel_vote_t(double t, long long xs, long long ys, float pol, bool inside, double t0, double t1, int bins, int W,
+                                             int H, long long &il, float &vl, long long &ir, float &vr, long long *til_out = nullptr,
+                                             long long *base_out = nullptr) {
     double dT = t1 - t0;
     if (dT == 0.0) dT = 1.0;
     const double ts = ((double)(bins - 1) * (t - t0)) / dT;
-    const long long xs = (long long)x, ys = (long long)y;
-    float pol = (float)p;
-    if (pol == 0.f) pol = -1.f;
     const double tis = floor(ts);
     const long long til = (long long)tis;
     const float dts = (float)(ts - tis);
     vl = pol * (1.0f - dts);
     vr = pol * dts;
-    const bool inside = xs >= 0 && xs < W && ys >= 0 && ys < H;   // the reference would raise on an OOB index
     const long long base = xs + ys * (long long)W;
     il = (inside && tis < (double)bins && tis >= 0.0) ? base + til * (long long)W * H : -1;
     ir = (inside && (tis + 1.0) < (double)bins && tis >= 0.0) ? base + (til + 1) * (long long)W * H : -1;
     if (til_out) *til_out = til;
     if (base_out) *base_out = base;
+}
+
+__device__ __forceinline__ void voxel_vote(double t, double x, double y, double p, double t0, double t1, int bins, int W, int H,
+                                           long long &il, float &vl, long long &ir, float &vr, long long *til_out = nullptr,
+                                           long long *base_out = nullptr) {
+    long long xs, ys;
+    float pol;
+    const bool inside = voxel_coord(x, y, p, W, H, xs, ys, pol);
+    voxel_vote_t(t, xs, ys, pol, inside, t0, t1, bins, W, H, il, vl, ir, vr, til_out, base_out);
 }
 
 __device__ __forceinline__ void voxel_event(const double *__restrict__ ev, size_t i, size_t n, int bins, int W, int H,
@@ -437,6 +451,150 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
     const int per = nr * W;                                                  // cells of one bin's band: contiguous in the grid
     for (int bin = 0; bin < bins; ++bin)
         for (int i = threadIdx.x; i < per; i += blockDim.x) grid[(size_t)bin * plane + (size_t)y0 * W + i] = band[bin * rows * W + i];
+}
+
+// ---- sorted form (round 3, batches of >= 16 grids): every band reads ITS events as one contiguous run per chunk instead of walking its
+// grid's whole list.  Pass 1 (voxel_sort_chunks_kernel): a workgroup takes a chunk of VS_CH consecutive events of one grid (whole events,
+// coalesced), converts the coordinates exactly like voxel_vote (voxel_coord), drops the events outside the image (they have no votes), counts
+// the rest per band with LDS atomics (the returned value is the event's rank inside its band) and writes a 16-byte record
+// {t (f64), x | y << 16, polarity (f32)} per event, grouped by band, to rec[g][chunk * VS_CH ...] plus the chunk's band offsets to
+// tab[g][chunk][band].  Pass 2 (voxelize_sorted_kernel): workgroup (band, grid) holds the band in LDS as before and, chunk by chunk, reads its
+// run of records (contiguous 16-byte loads, ~VS_CH / bands entries) and votes (voxel_vote_t: the same double arithmetic on t) — no scan of
+// foreign events, no gather, no barrier inside the walk, four chunks of loads in flight.  HBM: the events once (256 MB per 8 M), the records
+// written and read once (2 x 128 MB), the grids once.  The order of the LDS vote atomics is as undefined as in the other forms.
+constexpr int VS_CH = 8192;          // events per sort chunk: 1024 threads x 8
+constexpr double VS_ONE = 1099511627776.0;       // 2^40: fixed-point unit of the vote sums
+
+__global__ void __launch_bounds__(1024) voxel_sort_chunks_kernel(const double *__restrict__ ev, const long long *__restrict__ off, int W, int H,
+                                                                 int rows, int nbands, int4 *__restrict__ rec, long long rec_stride,
+                                                                 int *__restrict__ tab, int nchunks) {
+    __shared__ int cnt[256];
+    const int g = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
+    const long long e0 = off[g], n = off[g + 1] - e0;
+    const double2 *e2 = reinterpret_cast<const double2 *>(ev + (size_t)e0 * 4);
+    if (tid < 256) cnt[tid] = 0;
+    __syncthreads();
+    const long long j0 = (long long)w * VS_CH;
+    int id[8], rank[8];
+    int4 r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long j = j0 + u * 1024 + tid;
+        double2 tx = make_double2(0.0, -1.0), yp = make_double2(-1.0, 0.0);
+        if (j < n) tx = e2[j * 2], yp = e2[j * 2 + 1];
+        // voxel_coord() without its 64-bit conversions: (long long)v truncates towards zero, so 0 <= (long long)v < N  <=>  -1 < v < N
+        // (a NaN fails both tests, as it fails `inside`), and inside that range the 32-bit conversion is the same integer
+        const bool inside = j < n && tx.y > -1.0 && tx.y < (double)W && yp.x > -1.0 && yp.x < (double)H;
+        const int xs = inside ? (int)tx.y : 0, ys = inside ? (int)yp.x : 0;
+        float pol = (float)yp.y;
+        if (pol == 0.f) pol = -1.f;
+        id[u] = inside ? ys / rows : 255;
+        const long long tb = __double_as_longlong(tx.x);
+        r[u] = make_int4((int)(tb & 0xffffffffll), (int)(tb >> 32), xs | (ys << 16), __float_as_int(pol));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rank[u] = id[u] < 255 ? atomicAdd(&cnt[id[u]], 1) : 0;
+    __syncthreads();
+    int *t = tab + ((size_t)g * nchunks + w) * (nbands + 1);
+    if (tid == 0) {
+        int acc = 0;
+        for (int b = 0; b < nbands; ++b) {
+            const int c = cnt[b];
+            cnt[b] = acc, t[b] = acc;
+            acc += c;
+        }
+        t[nbands] = acc;
+    }
+    __syncthreads();
+    int4 *rg = rec + (size_t)g * rec_stride + j0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (id[u] < 255) rg[cnt[id[u]] + rank[u]] = r[u];
+}
+
+__global__ void __launch_bounds__(1024) voxelize_sorted_kernel(const double *__restrict__ ev, const long long *__restrict__ off, int n_grids, int bins,
+                                                               int W, int H, int rows, float *__restrict__ grids, const int4 *__restrict__ rec,
+                                                               long long rec_stride, const int *__restrict__ tab, int nchunks) {
+    // Votes are summed as 64-bit FIXED-POINT integers (2^-40 units): an fp32 vote of magnitude >= 2^-16 is represented exactly, so the sum of
+    // a cell is exact and independent of the order of the atomics — bit-reproducible, and at least as accurate as the reference's sequential
+    // fp32 sum (one rounding, at the final conversion).  And it is what makes the pass fast: measured on gfx950, LDS integer atomics (32- and
+    // 64-bit) cost ~3 us of this kernel, ds_add_f32 73 us (16 M votes; ~0.4 float atomics per clock and CU).
+    extern __shared__ __attribute__((aligned(16))) long long band64[];    // [bins][rows][W]
+    long long *band = band64;
+    const int nbands = (H + rows - 1) / rows;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;              // the bands of a grid on one XCD, as voxelize_bands_kernel
+    const int g = (slot / nbands) * 8 + xcd, bi = slot % nbands, y0 = bi * rows;
+    if (g >= n_grids) return;
+    const int nr = min(rows, H - y0), tid = threadIdx.x;
+    const long long e0 = off[g], n = off[g + 1] - e0;
+    const double *e = ev + (size_t)e0 * 4;
+    const int cells = bins * rows * W;
+    for (int i = tid; i < cells; i += blockDim.x) band[i] = 0;
+    const long long plane = (long long)W * H;
+    const double t0 = n > 0 ? e[0] : 0.0, t1 = n > 0 ? e[(n - 1) * 4] : 0.0;
+    // voxel_vote_t() on the record, with 32-bit index arithmetic: the same double operations on t (ts, floor, dt and the two fp32 votes are
+    // bit-identical), and the bin index converted only where voxel_vote_t's own guards (0 <= tis, tis [+ 1] < bins) hold — the same cells get
+    // the same votes; the 64-bit conversions and multiplications of the general form (~300 instructions per event) are what bound this pass
+    double dT = t1 - t0;
+    if (dT == 0.0) dT = 1.0;
+    const double scale = (double)(bins - 1), dbins = (double)bins;
+    const int rw = rows * W;
+    auto vote = [&](int4 r) {
+        const double t = __longlong_as_double(((long long)r.y << 32) | (unsigned long long)(unsigned)r.x);
+        const double ts = (scale * (t - t0)) / dT;
+        const double tis = floor(ts);
+        const float dts = (float)(ts - tis), pol = __int_as_float(r.w);
+        const float vl = pol * (1.0f - dts), vr = pol * dts;
+        const bool okl = tis < dbins && tis >= 0.0, okr = (tis + 1.0) < dbins && tis >= 0.0;
+        const int til = okl ? (int)tis : 0;
+        const int cell = til * rw + ((int)((unsigned)r.z >> 16) - y0) * W + (r.z & 0xffff);       // (bin * rows + y - y0) * W + x
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(band);
+        if (okl) atomicAdd(acc + cell, (unsigned long long)__double2ll_rn((double)vl * VS_ONE));
+        if (okr) atomicAdd(acc + cell + rw, (unsigned long long)__double2ll_rn((double)vr * VS_ONE));
+    };
+    const int4 *rg = rec + (size_t)g * rec_stride;
+    // (start, length) of this band's run in every chunk -> LDS behind the band: the walk then has ONE dependent memory round trip per stage
+    // (the records), requested a stage ahead of the votes (a workgroup holds its CU alone — 151 KB of LDS — so nothing else hides latency)
+    int *tl = reinterpret_cast<int *>(band + cells);
+    {
+        const int *tg = tab + (size_t)g * nchunks * (nbands + 1) + bi;
+        for (int w = tid; w < nchunks; w += blockDim.x) {
+            const int a = tg[(size_t)w * (nbands + 1)], b = tg[(size_t)w * (nbands + 1) + 1];
+            tl[2 * w] = w * VS_CH + a, tl[2 * w + 1] = b - a;
+        }
+    }
+    __syncthreads();
+    auto fetch = [&](int w0, int4 (&r)[4], int (&len)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = w0 + u < nchunks ? w0 + u : nchunks - 1;
+            len[u] = w0 + u < nchunks ? tl[2 * w + 1] : 0;
+            r[u] = tid < len[u] ? rg[tl[2 * w] + tid] : make_int4(0, 0, 0, 0);
+        }
+    };
+    auto votes = [&](int w0, const int4 (&r)[4], const int (&len)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (tid < len[u]) vote(r[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)                  // a band that holds more than 1024 events of a chunk (uneven event density)
+            for (int k = tid + 1024; k < len[u]; k += 1024) vote(rg[tl[2 * (w0 + u)] + k]);
+    };
+    int4 ra[4], rb[4];
+    int la[4], lb[4];
+    fetch(0, ra, la);
+    for (int w0 = 0; w0 < nchunks; w0 += 8) {
+        fetch(w0 + 4, rb, lb);
+        votes(w0, ra, la);
+        fetch(w0 + 8, ra, la);
+        votes(w0 + 4, rb, lb);
+    }
+    __syncthreads();
+    float *grid = grids + (size_t)g * bins * plane;
+    const int per = nr * W;                                                  // cells of one bin's band: contiguous in the grid
+    for (int bin = 0; bin < bins; ++bin)
+        for (int i = tid; i < per; i += blockDim.x)
+            grid[(size_t)bin * plane + (size_t)y0 * W + i] = (float)((double)band[bin * rows * W + i] * (1.0 / VS_ONE));
 }
 
 __global__ void voxel_indices_kernel(const double *__restrict__ ev, size_t n, int bins, int W, int H, long long *il_out, long long *ir_out) {
@@ -629,6 +787,27 @@ static unsigned char *voxel_id_scratch(hipStream_t st, size_t bytes) {
 
 static int launch_voxel_bands(const double *events, const long long *offsets, long long n_single, int n_grids, size_t max_events,
                               int bins, int W, int H, float *grids, hipStream_t st) {
+    static const char *vs = getenv("RAMNET_VOXEL_SORTED");
+    if (offsets != nullptr && max_events > 0 && max_events < (1u << 30) && W <= 32767 && H <= 32767 && !(vs && vs[0] == '0')) {      // sorted form
+        const int nchunks = (int)((max_events + VS_CH - 1) / VS_CH);
+        const int rows = voxel_band_rows(2 * bins, W, H, n_grids, 2 * nchunks + 16);       // (8-byte cells)
+        const int nbands = rows > 0 ? cdiv(H, rows) : 0;
+        const long long rstride = (long long)nchunks * VS_CH;
+        const size_t rec_bytes = (size_t)n_grids * rstride * sizeof(int4), tab_bytes = (size_t)n_grids * nchunks * (nbands + 1) * sizeof(int);
+        unsigned char *scratch = rows > 0 ? voxel_id_scratch(st, rec_bytes + tab_bytes) : nullptr;
+        if (scratch) {
+            int4 *rec = reinterpret_cast<int4 *>(scratch);
+            int *tab = reinterpret_cast<int *>(scratch + rec_bytes);
+            hipLaunchKernelGGL(voxel_sort_chunks_kernel, dim3(nchunks, n_grids), dim3(1024), 0, st, events, offsets, W, H, rows, nbands, rec, rstride,
+                               tab, nchunks);
+            RAMNET_FULL_LDS(voxelize_sorted_kernel);
+            const size_t lds = (size_t)bins * rows * W * sizeof(long long) + (2 * nchunks + 16) * sizeof(int);
+            hipLaunchKernelGGL(voxelize_sorted_kernel, dim3(8 * cdiv(n_grids, 8) * nbands), dim3(1024), lds, st, events, offsets, n_grids, bins, W, H,
+                               rows, grids, rec, rstride, tab, nchunks);
+            RAMNET_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const long long stride = (long long)((max_events + 15) / 16 * 16);
     const int rows_ids = voxel_band_rows(bins, W, H, n_grids, 8192);
     unsigned char *ids = rows_ids > 0 && max_events > 0 ? voxel_id_scratch(st, (size_t)stride * n_grids) : nullptr;
