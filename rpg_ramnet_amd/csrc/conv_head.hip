@@ -201,18 +201,25 @@ __global__ void __launch_bounds__(256, 2) conv_head_wgrad_kernel(const HeadWgrad
         }
     }
 
-    // fold the four waves' partials in LDS, then one atomic per element into ws[tap][Cin][Cout]
+    // fold the four waves' partials in LDS, then one atomic per element into ws[tap][Cin][Cout].  The waves take turns (plain
+    // read-add-write: the lanes of ONE wave own distinct elements) — fp32 LDS atomics run at ~0.4 per clock and CU on gfx950
+    // (profiles/r03_h_tuning_notes.md, voxelizer), MT * 4096 of them per workgroup were ~20 us of every workgroup's tail
     __syncthreads();
     float *red = smem;                              // [MT*32][32]  (red + bred = 5120 floats fit below the gradient tile's end)
-    for (int i = tid; i < MT * 32 * 32; i += 256) red[i] = 0.f;
     float *bred = smem + MT * 1024;                 // [32][32], behind red
-    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(red + (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31, acc[t][r]);
-    st4(bred + (tid >> 3) * 32 + (tid & 7) * 4, bsum);
-    __syncthreads();
+                for (int r = 0; r < 16; ++r) {
+                    float *q = red + (t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31;
+                    *q = (w == 0 ? 0.f : *q) + acc[t][r];
+                }
+        }
+        if (w == 0) st4(bred + (tid >> 3) * 32 + (tid & 7) * 4, bsum);
+        __syncthreads();
+    }
     for (int i = tid; i < G::KT * 32; i += 256) {
         const int n = i & 31, m = i >> 5;
         const int tap = m / CR, c = m - tap * CR;
