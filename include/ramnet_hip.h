@@ -273,7 +273,9 @@ int ramnet_split2(const float *y, int ldy, int Ca, int Cb, float *a, float *b, s
 
 /* ---- scale-invariant loss: model/loss.py:6-9 -------------------------------------------------- */
 /* stats[0..2] = (sum d, sum d^2, count) over non-NaN d = pred - target; loss = w*(S2/n - lambda*(S1/n)^2).  `stats` holds FOUR
- * doubles (ABI 13: [3] is the arrival ticket of the single-launch reduction; the backward reads [0..2]).               */
+ * doubles ([3] is scratch of the reduction; the backward reads [0..2]).  One launch: every workgroup stores its partial sums to a
+ * scratch the library owns per (device, stream), the last one to arrive adds them in a fixed order (bit-reproducible loss); inside a
+ * stream capture that finds no scratch yet: zero-fill + atomics on `stats`.                                              */
 int ramnet_si_loss_fwd(const float *pred, const float *target, size_t n, float weight, float lambda,
                        double *stats, float *loss, void *stream);
 /* dpred = gscale * w * (2 d/n - 2 lambda mean/n) on valid pixels, 0 elsewhere (gscale: device scalar). */
