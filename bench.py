@@ -296,7 +296,8 @@ def traffic_of(pmc, name):
 def cpu_baseline(cfg, H, W, K, args):
     """The oracle (CPU restatement, fixture-pinned to the reference) timed on this box's host cores on a bounded sample of the
     same workload: one untimed warm-up step at B=1, L=1, then ONE full training step — forward, SI loss
-    on [image, events4], BPTT backward, Adam — at B=8, L=2 (a quarter of the L=8 sequence; the step is linear in L)."""
+    on [image, events4], BPTT backward, Adam — at B=8, L=1 (one data package per sequence, an eighth of the L=8 step, which is linear in L:
+    ~25 s of CPU work on the 128 host cores, 40 s on a loaded box)."""
     from oracle import ramnet_ref
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from recipe import make_item
@@ -327,7 +328,7 @@ def cpu_baseline(cfg, H, W, K, args):
         return time.time() - t0
 
     warm = run(1, 1)
-    B, L = args.batch, 2
+    B, L = args.batch, 1
     dt = run(B, L)
     return {"value": B * L / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "%s step (fwd, SI loss, BPTT bwd, Adam), B=%d L=%d K=%d %dx%d fp32 torch-CPU oracle, %.1f s after a %.1f s "
