@@ -307,19 +307,37 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     if (NF == 2 && q.vec4 && epi == RAMNET_EPI_LSTM) {
         // ConvLSTM cell (submodules.py:346-358): the block's 64 columns are 16 hidden channels x gates (i, f, o, g)
         const int C = p.Cout;
+        // (two phases like the quad epilogue below: the four gate biases — ONE quad per thread — and the previous cell state of both
+        // pixels are requested before the gates are transformed out of LDS)
+        const int qd = tid & 3, chn = nblk_i * 16 + qd * 4;
+        const bool cok = chn < C;
+        const int chs = cok ? chn : 0;
+        const float4 bi = p.bias ? ld4(p.bias + chs) : f4zero(), bf = p.bias ? ld4(p.bias + C + chs) : f4zero();
+        const float4 bo = p.bias ? ld4(p.bias + 2 * C + chs) : f4zero(), bg = p.bias ? ld4(p.bias + 3 * C + chs) : f4zero();
+        bool ok[2];
+        size_t pixv[2];
+        int pxlv[2];
+        float4 cpv[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int sl = tid + i * 256, pxl = sl >> 2, qd = sl & 3;
-            const int oy = oy0 + pxl / RTW, ox = ox0 + pxl % RTW, chn = nblk_i * 16 + qd * 4;
-            if (oy >= p.Ho || ox >= p.Wo || chn >= C) continue;
-            const size_t pix = ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox);
-            const float4 ai = f4add(out4(pxl, qd * 4), ld4(p.bias + chn)), af = f4add(out4(pxl, 16 + qd * 4), ld4(p.bias + C + chn));
-            const float4 ao = f4add(out4(pxl, 32 + qd * 4), ld4(p.bias + 2 * C + chn)), ag = f4add(out4(pxl, 48 + qd * 4), ld4(p.bias + 3 * C + chn));
+            pxlv[i] = (tid + i * 256) >> 2;
+            const int oy = oy0 + pxlv[i] / RTW, ox = ox0 + pxlv[i] % RTW;
+            ok[i] = cok && oy < p.Ho && ox < p.Wo;
+            pixv[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;
+            cpv[i] = p.e1 ? ld4(p.e1 + pixv[i] * p.lde1 + chs) : f4zero();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!ok[i]) continue;
+            const int pxl = pxlv[i];
+            const size_t pix = pixv[i];
+            const float4 ai = f4add(out4(pxl, qd * 4), bi), af = f4add(out4(pxl, 16 + qd * 4), bf);
+            const float4 ao = f4add(out4(pxl, 32 + qd * 4), bo), ag = f4add(out4(pxl, 48 + qd * 4), bg);
             const float4 gi = make_float4(sigmoidf_(ai.x), sigmoidf_(ai.y), sigmoidf_(ai.z), sigmoidf_(ai.w));
             const float4 gf = make_float4(sigmoidf_(af.x), sigmoidf_(af.y), sigmoidf_(af.z), sigmoidf_(af.w));
             const float4 go = make_float4(sigmoidf_(ao.x), sigmoidf_(ao.y), sigmoidf_(ao.z), sigmoidf_(ao.w));
             const float4 gc = make_float4(tanhf_(ag.x), tanhf_(ag.y), tanhf_(ag.z), tanhf_(ag.w));
-            const float4 cp = p.e1 ? ld4(p.e1 + pix * p.lde1 + chn) : f4zero();
+            const float4 cp = cpv[i];
             const float4 cn = make_float4(gf.x * cp.x + gi.x * gc.x, gf.y * cp.y + gi.y * gc.y, gf.z * cp.z + gi.z * gc.z, gf.w * cp.w + gi.w * gc.w);
             st4(p.out + pix * p.ldo + chn, make_float4(go.x * tanhf_(cn.x), go.y * tanhf_(cn.y), go.z * tanhf_(cn.z), go.w * tanhf_(cn.w)));
             st4(p.o1 + pix * p.ldo1 + chn, cn);
