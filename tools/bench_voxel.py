@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Event -> voxel-grid binning at the package-batch size of the bench config: 40 grids x 200 000 events, 5 bins, 256 x 344
 (ramnet_voxelize_batch); us per launch and fraction of the HBM roofline on SURVEY 8d's algorithmic bytes (32 B per event read, 2 x 8 B
-of vote traffic, one write of the grids).  Usage (GPU box): python tools/bench_voxel.py [grids] [events]"""
+of vote traffic, one write of the grids).  Usage (GPU box): python tools/bench_voxel.py [grids] [events] [bins] [height] [width]"""
 import os
 import sys
 
@@ -15,7 +15,9 @@ from rpg_ramnet_amd import voxel  # noqa: E402
 def main():
     G = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
-    bins, Hh, W = 5, 256, 344
+    bins = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    Hh = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+    W = int(sys.argv[5]) if len(sys.argv) > 5 else 344
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
     ev = np.empty((G, N, 4))
