@@ -144,6 +144,11 @@ const char *ramnet_last_kernel(void);
  * batch >= 1 independent products in one launch: entry i uses A + i*stride_a, B + i*stride_b, C + i*stride_c (floats).      */
 int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                 int accumulate, int batch, long stride_a, long stride_b, long stride_c, void *stream);
+/* Two such batched products in ONE launch (the row and the column border of a decoder layer): same N, leading dimensions and mode,
+ * their own operands, M, K (trans_a: the reduction length) and batch counts.                                              */
+int ramnet_gemm2(const float *A, const float *B, float *C, int M, long stride_a, long stride_b, long stride_c, int batch, const float *A2,
+                 const float *B2, float *C2, int M2, long stride_a2, long stride_b2, long stride_c2, int batch2, int N, int K, int K2, int lda,
+                 int ldb, int ldc, int trans_a, int accumulate, void *stream);
 
 /* ---- layout plumbing -------------------------------------------------------------------------- */
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] zero-padded (model inputs: model.py:177,200 `.to(self.gpu)`). */

@@ -61,6 +61,8 @@ _SIGS = {
     "ramnet_last_error": (C.c_char_p, []),
     "ramnet_last_kernel": (C.c_char_p, []),
     "ramnet_gemm": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 9 + [C.c_long] * 3 + [_fp]),
+    "ramnet_gemm2": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, _fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

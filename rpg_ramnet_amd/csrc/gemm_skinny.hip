@@ -17,10 +17,19 @@
 
 namespace ramnet {
 
+// A launch may carry TWO problems of the same N, leading dimensions and mode (the row and the column border of a decoder layer differ in
+// M — forward / backward-data — or in the reduction length K — weight gradient): batch entries [0, nb1) belong to (A, B, C, M), the rest to the second set.
+struct Gemm2nd {
+    const float *A, *B;
+    float *C;
+    int M, K, nb1;
+    long sa, sb, sc;
+};
+
 template <bool TA>
 __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                      int M, int N, int K, int lda, int ldb, int ldc, int ksplit, int atomic,
-                                                     int intra, long sa, long sb, long sc) {
+                                                     int intra, long sa, long sb, long sc, const Gemm2nd two) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     // accumulating forms: the 4 waves of a workgroup own 4 neighbouring blocks (they share the A rows through the L1) and the
@@ -28,7 +37,13 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A
     // in a fixed order — four times the waves in flight, still bit-reproducible
     const int nb = intra ? blockIdx.x : blockIdx.x * 4 + wave, mb = blockIdx.y;
     if (nb * 32 >= N) return;                                           // (uniform over the workgroup when intra)
-    const int bi = blockIdx.z / ksplit, ks = intra ? wave : blockIdx.z - bi * ksplit;  // batch entry (independent products), reduction slice
+    int bi = blockIdx.z / ksplit;                                        // batch entry (independent products)
+    const int ks = intra ? wave : blockIdx.z - bi * ksplit;             // reduction slice
+    if (bi >= two.nb1) {
+        bi -= two.nb1;
+        A = two.A, B = two.B, C = two.C, M = two.M, K = two.K, sa = two.sa, sb = two.sb, sc = two.sc;
+    }
+    if (mb * 32 >= M) return;                                           // (uniform over the workgroup: the other problem is taller)
     A += bi * sa, B += bi * sb, C += bi * sc;
     const int m = mb * 32 + l31, n = nb * 32 + l31;
     const int nsl = intra ? 4 : ksplit;
@@ -109,29 +124,48 @@ __global__ void __launch_bounds__(256) gemm32_kernel(const float *__restrict__ A
 
 using namespace ramnet;
 
-extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
-                           int accumulate, int batch, long stride_a, long stride_b, long stride_c, void *stream) {
-    RAMNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N && batch >= 1);
-    if (trans_a) RAMNET_CHECK_ARG(lda >= M);
-    else RAMNET_CHECK_ARG(lda >= K && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && stride_a % 4 == 0);
+static int launch_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a, int accumulate,
+                       int batch, long stride_a, long stride_b, long stride_c, const float *A2, const float *B2, float *C2, int M2, int K2, int batch2,
+                       long stride_a2, long stride_b2, long stride_c2, void *stream) {
+    const int Mmax = M > M2 ? M : M2, Kmax = K > K2 ? K : K2;
+    RAMNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && ldb >= N && ldc >= N && batch >= 1 && batch2 >= 0);
+    if (batch2 > 0) RAMNET_CHECK_ARG(A2 && B2 && C2 && M2 > 0 && K2 > 0 && ((uintptr_t)A2 & 15) == 0 && stride_a2 % 4 == 0 && (trans_a || K2 % 4 == 0));
+    if (trans_a) RAMNET_CHECK_ARG(lda >= Mmax);
+    else RAMNET_CHECK_ARG(lda >= Kmax && K % 4 == 0 && lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && stride_a % 4 == 0);
     // operands are addressed through 32-bit per-lane byte offsets and buffer extents clamped to WOOB (like the conv launchers)
-    RAMNET_CHECK_ARG((unsigned long long)(trans_a ? K : M) * lda * 4ull < WOOB && (unsigned long long)K * ldb * 4ull < WOOB &&
-                     (unsigned long long)M * ldc * 4ull < WOOB);
+    RAMNET_CHECK_ARG((unsigned long long)(trans_a ? Kmax : Mmax) * lda * 4ull < WOOB && (unsigned long long)Kmax * ldb * 4ull < WOOB &&
+                     (unsigned long long)Mmax * ldc * 4ull < WOOB);
     // accumulate (backward pass): the operand loads are latency-bound and occupancy is what hides them, so the reduction is split
     // over gridDim.z until a few thousand waves are in flight; partial sums meet by atomics in C.  A plain product (forward pass)
     // splits it over the waves of one workgroup per block instead (fixed-order LDS join): bit-reproducible, as every forward kernel.
-    const int blocks = batch * cdiv(M, 32) * cdiv(N, 32);
+    const int nb = batch + batch2;
+    const int blocks = nb * cdiv(Mmax, 32) * cdiv(N, 32);
     int ksplit = 1;
     if (accumulate)      // (splitting less — 512 ... 2048 blocks — measured the same training step: 198.2 - 199.2 samples/s)
-        while (blocks * ksplit < 8192 && K / (ksplit * 2) >= 128) ksplit *= 2;
-    const int intra = !accumulate && K >= 128;
-    const dim3 grid(intra ? cdiv(N, 32) : cdiv(cdiv(N, 32), 4), cdiv(M, 32), ksplit * batch);
+        while (blocks * ksplit < 8192 && Kmax / (ksplit * 2) >= 128) ksplit *= 2;
+    const int intra = !accumulate && Kmax >= 128;
+    const dim3 grid(intra ? cdiv(N, 32) : cdiv(cdiv(N, 32), 4), cdiv(Mmax, 32), ksplit * nb);
+    const Gemm2nd two = {A2, B2, C2, M2, K2, batch, stride_a2, stride_b2, stride_c2};
     if (trans_a)
         hipLaunchKernelGGL(gemm32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,
-                           intra, stride_a, stride_b, stride_c);
+                           intra, stride_a, stride_b, stride_c, two);
     else
         hipLaunchKernelGGL(gemm32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, lda, ldb, ldc, ksplit, accumulate,
-                           intra, stride_a, stride_b, stride_c);
+                           intra, stride_a, stride_b, stride_c, two);
     RAMNET_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int ramnet_gemm(const float *A, const float *B, float *C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                           int accumulate, int batch, long stride_a, long stride_b, long stride_c, void *stream) {
+    return launch_gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, accumulate, batch, stride_a, stride_b, stride_c, nullptr, nullptr, nullptr, 0, 0, 0, 0,
+                       0, 0, stream);
+}
+
+extern "C" int ramnet_gemm2(const float *A, const float *B, float *C, int M, long stride_a, long stride_b, long stride_c, int batch, const float *A2,
+                            const float *B2, float *C2, int M2, long stride_a2, long stride_b2, long stride_c2, int batch2, int N, int K, int K2, int lda,
+                            int ldb, int ldc, int trans_a, int accumulate, void *stream) {
+    RAMNET_CHECK_ARG(batch2 >= 1);
+    return launch_gemm(A, B, C, M, N, K, lda, ldb, ldc, trans_a, accumulate, batch, stride_a, stride_b, stride_c, A2, B2, C2, M2, K2, batch2, stride_a2,
+                       stride_b2, stride_c2, stream);
 }

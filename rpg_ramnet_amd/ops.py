@@ -817,6 +817,19 @@ def gemm(a, b, out, trans_a=False, accumulate=False):
                                 nb, a.stride(0), b.stride(0), out.stride(0), _st()), "ramnet_gemm")
 
 
+def gemm2(a1, b1, out1, a2, b2, out2, trans_a=False, accumulate=False):
+    """gemm(a1, b1, out1) and gemm(a2, b2, out2) in ONE launch (ramnet_gemm2): the row and the column border of a decoder layer — same
+    N, leading dimensions and mode; the two problems differ in M (forward, backward-data) or in the reduction length (weight gradient)."""
+    nb1, M1, N = out1.shape
+    nb2, M2, N2 = out2.shape
+    K1 = a1.shape[1] if trans_a else a1.shape[2]
+    K2 = a2.shape[1] if trans_a else a2.shape[2]
+    assert N == N2 and a1.stride(1) == a2.stride(1) and b1.stride(1) == b2.stride(1) and out1.stride(1) == out2.stride(1)
+    H.check(H.lib().ramnet_gemm2(_p(a1), _p(b1), _p(out1), M1, a1.stride(0), b1.stride(0), out1.stride(0), nb1, _p(a2), _p(b2), _p(out2), M2,
+                                 a2.stride(0), b2.stride(0), out2.stride(0), nb2, N, K1, K2, a1.stride(1), b1.stride(1), out1.stride(1),
+                                 int(trans_a), int(accumulate), _st()), "ramnet_gemm2")
+
+
 def _folded_upsample_conv(x, skip, cp, y, epi):
     """y = act(conv5x5_zero_padded(up2x(x + skip)) + b) without ever forming the upsampled image:
     (1) ONE multi-class launch: each output parity is a 4x4 convolution of the replicate-padded low-res sum — 16 taps instead
@@ -845,8 +858,7 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
         H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
         g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
         g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
-        gemm(a_rows, w_rows, g_rows)               # both sides of a border in one launch
-        gemm(a_cols, w_cols, g_cols)
+        gemm2(a_rows, w_rows, g_rows, a_cols, w_cols, g_cols)      # the two sides of both borders in one launch
     if side is not None:
         main.wait_stream(side)
         if not torch.cuda.is_current_stream_capturing():
@@ -946,8 +958,7 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
         g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
         g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
         H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
-        gemm(a_rows, g_rows, wr, trans_a=True, accumulate=True)      # wr[s] += a_rows[s]^T g_rows[s]: the border GEMMs' weight gradient
-        gemm(a_cols, g_cols, wc, trans_a=True, accumulate=True)
+        gemm2(a_rows, g_rows, wr, a_cols, g_cols, wc, trans_a=True, accumulate=True)      # w[s] += a[s]^T g[s]: the border GEMMs' weight gradient
 
 
 # Backward-data of the folded upsample-conv: the adjoint of (four parity convolutions of the replicate-padded input + border GEMMs),
@@ -985,8 +996,7 @@ def _folded_upsample_dgrad(x, dy, y, cp):
     wt_rows, wt_cols = cp.border_weights_t()                                      # [2 sides][2*Cout][5*Cin]
     d_rows = torch.zeros(2, B * W2, 5 * Cc, device=dev)       # accumulating form: the reduction may be split (backward pass)
     d_cols = torch.zeros(2, B * H2, 5 * Cc, device=dev)
-    gemm(g_rows, wt_rows, d_rows, accumulate=True)
-    gemm(g_cols, wt_cols, d_cols, accumulate=True)
+    gemm2(g_rows, wt_rows, d_rows, g_cols, wt_cols, d_cols, accumulate=True)
     H.check(L.ramnet_up2x_border_col2im(_p(d_rows), _p(d_cols), _p(dx), B, Hh, W, Cc, _st()), "ramnet_up2x_border_col2im")
     return dx
 
