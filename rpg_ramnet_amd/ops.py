@@ -994,9 +994,9 @@ def _folded_upsample_dgrad(x, dy, y, cp):
     g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
     H.check(L.ramnet_frame_gather(_p(g), None, _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
     wt_rows, wt_cols = cp.border_weights_t()                                      # [2 sides][2*Cout][5*Cin]
-    d_rows = torch.zeros(2, B * W2, 5 * Cc, device=dev)       # accumulating form: the reduction may be split (backward pass)
-    d_cols = torch.zeros(2, B * H2, 5 * Cc, device=dev)
-    gemm2(g_rows, wt_rows, d_rows, g_cols, wt_cols, d_cols, accumulate=True)
+    d_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)       # plain product (the reduction is 2 * Cout <= 256 long: nothing to split, no zero-fill)
+    d_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+    gemm2(g_rows, wt_rows, d_rows, g_cols, wt_cols, d_cols)
     H.check(L.ramnet_up2x_border_col2im(_p(d_rows), _p(d_cols), _p(dx), B, Hh, W, Cc, _st()), "ramnet_up2x_border_col2im")
     return dx
 
