@@ -217,6 +217,8 @@ int ramnet_pad2_sum(const float *x, const float *skip, float *out, int B, int H,
  * rows [2][B*2W][5][C] (top / bottom image row, columns clamped), cols [2][B*2H][5][C] (left / right image column, rows outside
  * the image zero).                                                                                                      */
 int ramnet_up2x_border_im2col(const float *x, const float *skip, float *rows, float *cols, int B, int H, int W, int C, void *stream);
+/* ramnet_pad2_sum and ramnet_up2x_border_im2col in one launch (the forward of a folded decoder layer needs both). */
+int ramnet_pad2_sum_im2col(const float *x, const float *skip, float *out, float *rows, float *cols, int B, int H, int W, int C, void *stream);
 /* Backward-data of the folded upsample-conv: adjoint of ramnet_pad2_sum (dx[B][H][W][C] = dxpad summed over the padded pixels that
  * copy each pixel; also the skip gradient) and adjoint of ramnet_up2x_border_im2col (gradients of the unrolled border lines
  * rows [2][B*2W][5][C] / cols [2][B*2H][5][C] gathered by the border pixels of dx through their bilinear weights, +=).                                */

@@ -286,21 +286,24 @@ __global__ void upsample2x_bwd_kernel(const float *__restrict__ dup, float *__re
 
 // ---- folded upsample-conv helpers ---------------------------------------------------------------------------------
 // replicate-padded sum: out[b][i+2][j+2] = (x + skip)[clamp i][clamp j]
-__global__ void pad2_sum_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ out, int B, int H, int W, int C) {
+__device__ __forceinline__ void pad2_sum_item(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ out, size_t i, int H,
+                                              int W, int C) {
     const int C4 = C / 4, Hp = H + 4, Wp = W + 4;
-    const size_t total = (size_t)B * Hp * Wp * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        size_t j = i / C4;
-        const int xx = (int)(j % Wp);
-        j /= Wp;
-        const int yy = (int)(j % Hp), b = (int)(j / Hp);
-        const int sy = min(max(yy - 2, 0), H - 1), sx = min(max(xx - 2, 0), W - 1);
-        const size_t src = (((size_t)b * H + sy) * W + sx) * C + c;
-        float4 v = ld4(x + src);
-        if (skip) v = f4add(v, ld4(skip + src));
-        st4(out + i * 4, v);
-    }
+    const int c = (int)(i % C4) * 4;
+    size_t j = i / C4;
+    const int xx = (int)(j % Wp);
+    j /= Wp;
+    const int yy = (int)(j % Hp), b = (int)(j / Hp);
+    const int sy = min(max(yy - 2, 0), H - 1), sx = min(max(xx - 2, 0), W - 1);
+    const size_t src = (((size_t)b * H + sy) * W + sx) * C + c;
+    float4 v = ld4(x + src);
+    if (skip) v = f4add(v, ld4(skip + src));
+    st4(out + i * 4, v);
+}
+
+__global__ void pad2_sum_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ out, int B, int H, int W, int C) {
+    const size_t total = (size_t)B * (H + 4) * (W + 4) * (C / 4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) pad2_sum_item(x, skip, out, i, H, W, C);
 }
 
 // u(r, c) = bilinear x2 upsample of (x + skip) at high-res pixel (r, c) INSIDE the image (F.interpolate, align_corners=False)
@@ -325,29 +328,45 @@ __device__ __forceinline__ float4 up2x_at(const float *__restrict__ x, const flo
 // Border lines of u = up2x(x + skip), unrolled along the 5 taps (im2col) for the border-correction GEMMs of the folded
 // upsample-conv:  rows [2 sides][B*2W][5][C]: side 0/1 = top/bottom image row, entry (o_x, kx) = u[row][clamp(o_x + kx - 2)];
 //                 cols [2 sides][B*2H][5][C]: side 0/1 = left/right image column, entry (o_y, ky) = u[o_y + ky - 2][col], 0 outside.
+__device__ __forceinline__ void up2x_border_im2col_item(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ rows,
+                                                        float *__restrict__ cols, size_t i, int B, int H, int W, int C) {
+    const int C4 = C / 4, H2 = 2 * H, W2 = 2 * W;
+    const size_t nrows = (size_t)2 * B * W2 * 5 * C4;
+    const bool isrow = i < nrows;
+    size_t j = isrow ? i : i - nrows;
+    const int ch = (int)(j % C4) * 4;
+    j /= C4;
+    const int k = (int)(j % 5);
+    j /= 5;
+    const int L = isrow ? W2 : H2;
+    const int o = (int)(j % L);
+    j /= L;
+    const int b = (int)(j % B), side = (int)(j / B);
+    float4 v = f4zero();
+    if (isrow) {
+        v = up2x_at(x, skip, b, H, W, C, side ? H2 - 1 : 0, min(max(o + k - 2, 0), W2 - 1), ch);
+    } else {
+        const int r = o + k - 2;
+        if (r >= 0 && r < H2) v = up2x_at(x, skip, b, H, W, C, r, side ? W2 - 1 : 0, ch);
+    }
+    st4((isrow ? rows : cols) + (isrow ? i : i - nrows) * 4, v);
+}
+
 __global__ void up2x_border_im2col_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ rows,
                                           float *__restrict__ cols, int B, int H, int W, int C) {
-    const int C4 = C / 4, H2 = 2 * H, W2 = 2 * W;
-    const size_t nrows = (size_t)2 * B * W2 * 5 * C4, ncols = (size_t)2 * B * H2 * 5 * C4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nrows + ncols; i += (size_t)gridDim.x * blockDim.x) {
-        const bool isrow = i < nrows;
-        size_t j = isrow ? i : i - nrows;
-        const int ch = (int)(j % C4) * 4;
-        j /= C4;
-        const int k = (int)(j % 5);
-        j /= 5;
-        const int L = isrow ? W2 : H2;
-        const int o = (int)(j % L);
-        j /= L;
-        const int b = (int)(j % B), side = (int)(j / B);
-        float4 v = f4zero();
-        if (isrow) {
-            v = up2x_at(x, skip, b, H, W, C, side ? H2 - 1 : 0, min(max(o + k - 2, 0), W2 - 1), ch);
-        } else {
-            const int r = o + k - 2;
-            if (r >= 0 && r < H2) v = up2x_at(x, skip, b, H, W, C, r, side ? W2 - 1 : 0, ch);
-        }
-        st4((isrow ? rows : cols) + (isrow ? i : i - nrows) * 4, v);
+    const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        up2x_border_im2col_item(x, skip, rows, cols, i, B, H, W, C);
+}
+
+// Both of the above in ONE launch (they read the same two tensors and are needed by the same decoder launch): items [0, npad) are cells
+// of the padded sum, the rest entries of the unrolled border lines.
+__global__ void pad2_sum_im2col_kernel(const float *__restrict__ x, const float *__restrict__ skip, float *__restrict__ out, float *__restrict__ rows,
+                                       float *__restrict__ cols, int B, int H, int W, int C) {
+    const size_t npad = (size_t)B * (H + 4) * (W + 4) * (C / 4), n = npad + (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < npad) pad2_sum_item(x, skip, out, i, H, W, C);
+        else up2x_border_im2col_item(x, skip, rows, cols, i - npad, B, H, W, C);
     }
 }
 
@@ -677,6 +696,15 @@ extern "C" int ramnet_up2x_border_im2col(const float *x, const float *skip, floa
     RAMNET_CHECK_ARG(x && rows && cols && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
     const size_t n = (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
     hipLaunchKernelGGL(up2x_border_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, rows, cols, B, H, W, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pad2_sum_im2col(const float *x, const float *skip, float *out, float *rows, float *cols, int B, int H, int W, int C,
+                                      void *stream) {
+    RAMNET_CHECK_ARG(x && out && rows && cols && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+    const size_t n = (size_t)B * (H + 4) * (W + 4) * (C / 4) + (size_t)2 * B * (2 * W + 2 * H) * 5 * (C / 4);
+    hipLaunchKernelGGL(pad2_sum_im2col_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, skip, out, rows, cols, B, H, W, C);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -850,12 +850,16 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     main = torch.cuda.current_stream()
     if side is not None:
         side.wait_stream(main)
-    H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
     w_rows, w_cols = cp.border_weights()                                          # [2 sides][5*Cin][2*Cout]
+    if side is not None:
+        H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
     with torch.cuda.stream(side if side is not None else main):
         a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
         a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
-        H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
+        if side is not None:
+            H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
+        else:       # the padded sum and the unrolled border lines in ONE launch
+            H.check(L.ramnet_pad2_sum_im2col(_p(x), _p(skip), _p(xpad), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_pad2_sum_im2col")
         g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
         g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
         gemm2(a_rows, w_rows, g_rows, a_cols, w_cols, g_cols)      # the two sides of both borders in one launch
@@ -939,9 +943,13 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
     # frame of dy and the two border-GEMM gradients (~0.3 ms of small, latency-bound launches per layer and time step) — runs on the
     # side stream: nothing of it is needed before the end of the backward pass (round 3; before, only the Winograd launch did).
     with side_work([x, skip, dy, y, xpad], dev):
-        if xpad is None:            # not kept by forward (RAMNET_SAVE_XPAD=0): recompute pad2(x + skip)
+        a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
+        a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
+        if xpad is None:            # not kept by forward (RAMNET_SAVE_XPAD=0): recompute pad2(x + skip), together with the border lines
             xpad = torch.empty(B, Hh + 4, W + 4, Cc, device=dev)
-            H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
+            H.check(L.ramnet_pad2_sum_im2col(_p(x), _p(skip), _p(xpad), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_pad2_sum_im2col")
+        else:
+            H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
         if _FOLD_WINO_WGRAD and Cc == cp.CinWs and ((Cc % 32 == 0 and cp.Cout % 64 == 0) or
                                                                                  (Cc % 64 == 0 and cp.Cout % 32 == 0)):
             # one launch, all four parities, in the Winograd F(2x2,4x4) domain (csrc/conv_wgrad_wino24.hip)
@@ -952,9 +960,6 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
                 for px in range(2):
                     wgrad_launch(xpad, Taps.get("fold", 4, 0, py, px), dy, w4, cp.Cout, gmask=y, dbias=bws, Ho=Hh, Wo=W,
                                  gview=(2, 2, py, px, H2, W2), dw_off=(py * 2 + px) * 16 * cp.CinWs * cp.Cout)
-        a_rows = torch.empty(2, B * W2, 5 * Cc, device=dev)
-        a_cols = torch.empty(2, B * H2, 5 * Cc, device=dev)
-        H.check(L.ramnet_up2x_border_im2col(_p(x), _p(skip), _p(a_rows), _p(a_cols), B, Hh, W, Cc, _st()), "ramnet_up2x_border_im2col")
         g_rows = torch.empty(2, B * W2, 2 * cp.Cout, device=dev)
         g_cols = torch.empty(2, B * H2, 2 * cp.Cout, device=dev)
         H.check(L.ramnet_frame_gather(_p(dy), _p(y), _p(g_rows), _p(g_cols), B, H2, W2, cp.Cout, _st()), "ramnet_frame_gather")
