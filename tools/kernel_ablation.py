@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where the time goes INSIDE the two Winograd kernels: timing builds with one ingredient of the main loop removed.
+"""Where the time goes INSIDE the Winograd kernels (3x3 forward / backward-data, 3x3 backward-weights, the folded decoders' F(2x2,4x4)):
+timing builds with one ingredient of the main loop removed.
 
 The script copies csrc/ to a scratch directory, patches `conv_wino.hip` (forward / backward-data) and `conv_wgrad_wino.hip`
 (backward-weights) so that a compile-time bit mask ABL switches parts of the loop off — the results of such a build are WRONG, its
@@ -17,8 +18,8 @@ duration is what is measured — and links one library per mask into rpg_ramnet_
       256  (backward-weights) no atomic adds of the partial sums
 
 Usage (container, then GPU box):
-  python tools/kernel_ablation.py build                  # all masks of `MASKS`
-  gpurun -- 'python tools/kernel_ablation.py run'        # -> gpurun_out/ablation.txt
+  python tools/kernel_ablation.py build [kernel ...]     # all masks of `MASKS` (optionally of the named kernels only, e.g. conv_wino24)
+  gpurun -- 'python tools/kernel_ablation.py run [kernel ...]'        # -> gpurun_out/ablation.txt
 Results of round 3: profiles/r03_k_ablation.txt, discussed in profiles/r03_h_tuning_notes.md."""
 import os
 import shutil
