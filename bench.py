@@ -439,15 +439,22 @@ def input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank, n=2):
         ev[:, 2] = torch.randint(0, H, (n_ev,), device=dev, generator=g).double()
         ev[:, 3] = torch.randint(0, 2, (n_ev,), device=dev, generator=g).double()
         lists.append(ev)
+    from rpg_ramnet_amd.data import DevicePrefetcher
     host = [{k: v.cpu().pin_memory() for k, v in item.items() if not k.startswith("events")} for item in seq]
 
+    def host_sequences():               # the loader's side: the same pinned host sequence over and over
+        while True:
+            yield host
+    uploads = iter(DevicePrefetcher(host_sequences(), dev))      # frames / targets of step n + 1 go up on a copy stream during step n
+
     def full():
+        frames = next(uploads)
         for l in range(L):
             grids = voxel.events_to_voxel_grids(lists, bins, W, H, dev, normalize=True).view(K, B, bins, H, W)
             for k in range(K):
                 seq[l]["events%d" % k] = grids[k]
-            for k, v in host[l].items():
-                seq[l][k] = v.to(dev, non_blocking=True)
+            for k, v in frames[l].items():
+                seq[l][k] = v
         return step()
 
     full()
@@ -459,7 +466,7 @@ def input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank, n=2):
     e = (time.perf_counter() - t) / n
     return {"value": B * L / e, "ms_per_step": 1e3 * e, "final_loss": float(lv.detach()),
             "note": "per step: %d voxelize_batch launches (%d lists x %d events each, on-device event lists), batched nonzero "
-                    "normalisation, H2D of %d frames + %d target maps from pinned host memory, then the training step" %
+                    "normalisation, H2D of %d frames + %d target maps from pinned host memory on a copy stream during the previous step (data.DevicePrefetcher), then the training step" %
                     (L, K * B, n_ev, L * B, 2 * L * B)}
 
 

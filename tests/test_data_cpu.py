@@ -110,3 +110,17 @@ def test_sharded_sequence_sampler_partitions_the_index_list():
     assert per_epoch[0] != per_epoch[1]
     plain = [list(ShardedSequenceSampler(ds, r, world, shuffle=False)) for r in range(world)]
     assert plain[1][:3] == [1, 5, 9] and all(len(p) == 9 for p in plain)
+
+
+def test_device_prefetcher_passes_sequences_through_on_cpu():
+    """data.DevicePrefetcher on a CPU device: same structure, same values, every element of the loader exactly once, in order."""
+    import torch
+    from rpg_ramnet_amd.data import DevicePrefetcher
+    seqs = [[{"image": torch.full((1, 1, 2, 2), float(10 * s + l)), "events0": torch.zeros(1, 5, 2, 2), "meta": "k%d" % s} for l in range(3)]
+            for s in range(4)]
+    out = list(DevicePrefetcher(seqs, "cpu"))
+    assert len(out) == 4 and all(len(o) == 3 for o in out)
+    for s, o in enumerate(out):
+        for l, item in enumerate(o):
+            assert item["meta"] == "k%d" % s and float(item["image"].mean()) == 10 * s + l and item["events0"].shape == (1, 5, 2, 2)
+    assert list(DevicePrefetcher([], "cpu")) == []

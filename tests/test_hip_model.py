@@ -572,3 +572,22 @@ def test_norm_layers_bptt_gradients_vs_reference_fixture(tag):
     for k, v in model.state_dict().items():
         if _is_buffer(k):
             np.testing.assert_allclose(v.cpu().numpy(), z["buf." + k], rtol=2e-4, atol=1e-6, err_msg=k)
+
+
+def test_device_prefetcher_uploads_ahead_on_a_copy_stream():
+    """data.DevicePrefetcher on the GPU: every sequence arrives on the device with the host values, in order, while later ones are
+    already in flight; consuming them with compute in between (the training pattern) sees no stale or recycled buffer."""
+    from rpg_ramnet_amd.data import DevicePrefetcher
+    g = torch.Generator().manual_seed(3)
+    seqs = [[{"image": torch.rand(2, 1, 64, 80, generator=g), "depth_image": torch.rand(2, 1, 64, 80, generator=g)} for _ in range(3)]
+            for _ in range(6)]
+    dev = torch.device("cuda:0")
+    busy = torch.randn(2048, 2048, device=dev)
+    sums = []
+    for seq in DevicePrefetcher(seqs, dev):
+        busy = busy @ busy * 1e-3                      # compute between the hand-outs
+        assert all(v.is_cuda for item in seq for v in item.values())
+        sums.append([float(item["image"].double().sum() + 2 * item["depth_image"].double().sum()) for item in seq])
+    torch.cuda.synchronize()
+    want = [[float(item["image"].double().sum() + 2 * item["depth_image"].double().sum()) for item in seq] for seq in seqs]
+    np.testing.assert_allclose(np.array(sums), np.array(want), rtol=1e-12)
