@@ -72,6 +72,13 @@ def parse():
                     help="run the decoders on the main stream instead of a second stream concurrent with the next state update "
                          "(ops.set_decoder_overlap; default schedule)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (untimed-for-value) single-stream / hipGraph measurements")
+    ap.add_argument("--dp-exact-loss", action="store_true",
+                    help="N>1: all-reduce the SI-loss statistics (sum d, sum d^2, n per supervised map) before the backward so that the "
+                         "N-rank gradient equals the single-rank gradient on the concatenated batch (model/loss.py:9 takes mean(d)^2 over "
+                         "the WHOLE batch; SURVEY 8e).  Default: per-rank loss + gradient averaging (standard DDP)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, initialise the process group, let every rank report in over the collective backend, print the "
+                         "JSON line (value null) and exit before any GPU work: the launch contract alone (CPU test)")
     ap.add_argument("--graph", action="store_true",
                     help="train: the timed step replays ONE hipGraph (gradient zero-fill, forward, loss, BPTT backward, gradient fold; "
                          "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
@@ -518,28 +525,68 @@ class ClockSampler:
         return (sum(self.samples) / len(self.samples)) if self.samples else None
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no torch.distributed.run environment around it: start the N ranks here (one process per
+    GPU, rendezvous on 127.0.0.1, a free port) by re-executing this file under torch.distributed.run with the same arguments; rank
+    0's JSON line is the child's stdout.  Under torch.distributed.run (WORLD_SIZE set) this is never reached."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend_note = None
     if world > 1 or args.force_collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        ndev = torch.cuda.device_count()
         if os.environ.get("RAMNET_BENCH_SINGLE_DEVICE") == "1":     # functional test of the N>1 path on a 1-GPU box
             local = 0
+        elif 0 < ndev < world:                                      # fewer GPUs than ranks (a 1-GPU box asked for --gpus 2): ranks share devices
+            local = local % ndev
+        if args.backend == "nccl" and ndev < world:
+            # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the functional run of the N>1 path goes over gloo, and says so
+            args.backend = "gloo"
+            backend_note = "gloo (fewer devices than ranks: %d < %d; RCCL needs one device per rank)" % (ndev, world)
+        if args.launch_check:
+            dist.init_process_group(args.backend)
+            got = [None] * world
+            dist.all_gather_object(got, rank)
+            if rank == 0:
+                print(json.dumps({"metric": "launch check", "value": None, "n_gpus": world, "rccl_ranks_seen": sorted(got),
+                                  "backend": backend_note or args.backend}))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         torch.cuda.set_device(local)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: pass the number of ranks torch.distributed.run starts" % (args.gpus, world)
     from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent
     from rpg_ramnet_amd.parallel import FlatGradReducer
-    from rpg_ramnet_amd.trainer import sequence_loss, empty_states_lstm
+    from rpg_ramnet_amd.trainer import sequence_loss, empty_states_lstm, LOSS_SEMANTICS
 
     from rpg_ramnet_amd import ops, _hip as Hh
     ops.set_wgrad_overlap(args.overlap_wgrad)
@@ -581,7 +628,7 @@ def main():
 
         def step():
             reducer.zero()
-            total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+            total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1], dp_exact=args.dp_exact_loss)
             total.backward()
             reducer.all_reduce()
             reducer.wait()
@@ -818,8 +865,8 @@ def main():
                                       (", decoders on a second stream" if args.overlap_decoder and args.mode == "train" else ""),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
                "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-               "rccl_ranks_seen": ranks_seen, "backend": (args.backend if (world > 1 or args.force_collective) else None),
-               "loss_semantics": "per-rank mean over the rank's batch, gradients averaged over ranks (standard DDP)"}
+               "rccl_ranks_seen": ranks_seen, "backend": ((backend_note or args.backend) if (world > 1 or args.force_collective) else None),
+               "loss_semantics": LOSS_SEMANTICS[bool(args.dp_exact_loss and args.mode == "train")]}
         if args.mode == "stream":
             out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
                              "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "

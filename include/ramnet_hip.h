@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 14      /* 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss); 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -285,6 +285,10 @@ int ramnet_split2(const float *y, int ldy, int Ca, int Cb, float *a, float *b, s
  * stream capture that finds no scratch yet: zero-fill + atomics on `stats`.                                              */
 int ramnet_si_loss_fwd(const float *pred, const float *target, size_t n, float weight, float lambda,
                        double *stats, float *loss, void *stream);
+/* loss = w*(S2/n - lambda*(S1/n)^2) from GIVEN statistics stats[0..2] — the exact data-parallel form: every rank computes the
+ * sums of its maps (ramnet_si_loss_fwd), the sums are all-reduced, and loss / gradient follow from the global ones, so that
+ * mean(d)^2 is taken over the whole batch as model/loss.py:9 does (ramnet_si_loss_bwd reads the same stats).                    */
+int ramnet_si_loss_from_stats(const double *stats, float weight, float lambda, float *loss, void *stream);
 /* dpred = gscale * w * (2 d/n - 2 lambda mean/n) on valid pixels, 0 elsewhere (gscale: device scalar). */
 int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float weight, float lambda,
                        const double *stats, const float *gscale, float *dpred, void *stream);

@@ -108,6 +108,7 @@ _SIGS = {
     "ramnet_concat2": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
     "ramnet_bias_grad": (C.c_int, [_fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
     "ramnet_si_loss_fwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp]),
+    "ramnet_si_loss_from_stats": (C.c_int, [_fp, C.c_float, C.c_float, _fp, _fp]),
     "ramnet_si_loss_bwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp, _fp]),
     "ramnet_depth_metrics": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "ramnet_msg_workspace_elems": (C.c_size_t, [C.c_int] * 4),
@@ -165,7 +166,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 14:
+        if l.ramnet_abi_version() != 15:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

@@ -121,6 +121,12 @@ __global__ void __launch_bounds__(1024) si_stats_fold_kernel(const float *__rest
     }
 }
 
+// loss from given statistics (the data-parallel exact form: stats = the all-reduced sums of every rank's maps)
+__global__ void si_from_stats_kernel(const double *__restrict__ stats, float weight, float lambda, float *loss) {
+    const double m = stats[0] / stats[2];
+    *loss = (float)((double)weight * (stats[1] / stats[2] - (double)lambda * m * m));
+}
+
 __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight, float lambda,
                               const double *__restrict__ stats, const float *__restrict__ gscale, float *__restrict__ dpred) {
     // d - lambda*mean is formed in double: rounding the mean to fp32 would add the SAME offset to every pixel, and
@@ -756,6 +762,13 @@ extern "C" int ramnet_si_loss_fwd(const float *pred, const float *target, size_t
     }
     RAMNET_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
     hipLaunchKernelGGL(si_stats_kernel, dim3(g), dim3(1024), 0, st, pred, target, n, weight, lambda, stats, loss);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_si_loss_from_stats(const double *stats, float weight, float lambda, float *loss, void *stream) {
+    RAMNET_CHECK_ARG(stats && loss);
+    hipLaunchKernelGGL(si_from_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, stats, weight, lambda, loss);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

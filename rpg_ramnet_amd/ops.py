@@ -51,10 +51,13 @@ def set_fold_winograd_wgrad(on):
     _FOLD_WINO_WGRAD = bool(on)
 
 
+_FOLD_PAIR_ENV = _os.environ.get("RAMNET_FOLD_PAIR", "1") != "0"      # read ONCE, like conv_wino24.hip's function-local static
+
+
 def _fold_pair(Cout, Cin):
     """32-channel layers (the last decoder): both column parities of a row parity in one 64-column workgroup that shares the
     transformed input (conv_wino24_kernel<.., PAIR>); RAMNET_FOLD_PAIR=0 keeps the 64-tile x 32-channel form."""
-    return Cout == 32 and Cin % 32 == 0 and _os.environ.get("RAMNET_FOLD_PAIR", "1") != "0"
+    return Cout == 32 and Cin % 32 == 0 and _FOLD_PAIR_ENV
 
 
 def _fold_wino_ok(Cin, Cout):
@@ -848,9 +851,11 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
     # inference with branch streams: the border path (im2col -> two GEMMs) does not depend on the padded sum and runs beside it
     side = branch_stream(dev, 8) if (_USE_BRANCH and not torch.is_grad_enabled()) else None
     main = torch.cuda.current_stream()
+    # every lazily packed operand the side stream reads is packed (on main, on a cache miss: first call, after an optimizer step or
+    # load_state_dict) BEFORE the side stream waits on main — the wait then orders gemm2 behind the kernels that write the border weights
+    w_rows, w_cols = cp.border_weights()                                          # [2 sides][5*Cin][2*Cout]
     if side is not None:
         side.wait_stream(main)
-    w_rows, w_cols = cp.border_weights()                                          # [2 sides][5*Cin][2*Cout]
     if side is not None:
         H.check(L.ramnet_pad2_sum(_p(x), _p(skip), _p(xpad), B, Hh, W, Cc, _st()), "ramnet_pad2_sum")
     with torch.cuda.stream(side if side is not None else main):
@@ -1427,6 +1432,37 @@ class SILoss(Function):
         d = torch.empty_like(pred)
         H.check(H.lib().ramnet_si_loss_bwd(_p(pred), _p(target), pred.numel(), ctx.wl[0], ctx.wl[1], _p(stats), _p(g), _p(d), _st()), "si_bwd")
         return d, None, None, None
+
+
+def si_local_stats(pred, target, out_row):
+    """(sum d, sum d^2, n) of ONE supervised map into out_row (4 doubles of a caller-owned table; [3] is the reduction's scratch):
+    the per-rank half of the exact data-parallel SI loss.  Not differentiated — SILossFromStats carries the gradient."""
+    pred, target = pred.contiguous(), target.contiguous()
+    dummy = torch.empty((), device=pred.device)
+    H.check(H.lib().ramnet_si_loss_fwd(_p(pred), _p(target), pred.numel(), 1.0, 1.0, _p(out_row), _p(dummy), _st()), "si_fwd")
+
+
+class SILossFromStats(Function):
+    """scale_invariant_loss (model/loss.py:6-9) of the GLOBAL batch from all-reduced statistics: loss = w (S2/n - lambda (S1/n)^2);
+    d loss / d pred_i = w (2 d_i / n - 2 lambda S1 / n^2) with the global n, S1 — this rank's share of the single-process gradient on
+    the concatenated batch.  `gain` = world size: the reducer AVERAGES gradients over ranks, and the shares have to ADD UP."""
+
+    @staticmethod
+    def forward(ctx, pred, target, stats, weight, n_lambda, gain):
+        pred, target = pred.contiguous(), target.contiguous()
+        loss = torch.empty((), device=pred.device)
+        H.check(H.lib().ramnet_si_loss_from_stats(_p(stats), weight, n_lambda, _p(loss), _st()), "si_from_stats")
+        ctx.save_for_backward(pred, target, stats)
+        ctx.wl = (weight * gain, n_lambda)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(pred)
+        H.check(H.lib().ramnet_si_loss_bwd(_p(pred), _p(target), pred.numel(), ctx.wl[0], ctx.wl[1], _p(stats), _p(g), _p(d), _st()), "si_bwd")
+        return d, None, None, None, None, None
 
 
 class MSGLoss(Function):

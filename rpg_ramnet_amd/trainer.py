@@ -19,12 +19,28 @@ def empty_states_lstm(K):
     return d
 
 
-def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=None, grad_loss_weight=None):
+LOSS_SEMANTICS = {
+    False: "per-rank mean over the rank's batch, gradients averaged over ranks (standard DDP)",
+    True: "exact global batch: SI statistics (sum d, sum d^2, n per supervised map) all-reduced before the backward; the N-rank "
+          "gradient equals the single-rank gradient on the concatenated batch (model/loss.py:9)",
+}
+
+
+def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=None, grad_loss_weight=None, dp_exact=False,
+                  process_group=None):
     """BPTT over the L packages of `sequence` (list of item dicts with 'depth_<key>' targets).
     grad_loss_weight: weight of the multi-scale gradient loss (config['grad_loss']['weight'], 0.25 in the released
     recipe; lstm_trainer.py:162-168, :197-199) or None for the SI loss alone.
+    dp_exact (data parallel; default off): the reference's loss takes mean(d)^2 over the WHOLE batch (model/loss.py:9),
+    which an average of per-rank losses is not.  With dp_exact every rank computes (sum d, sum d^2, n) of each of its supervised
+    maps, ONE all-reduce sums the [terms x 4] table over the ranks before the backward, and every term's value and gradient follow
+    from the global sums (ops.SILossFromStats) — after the reducer's gradient average the N-rank gradient is the single-rank one on
+    the concatenated batch, and every rank reports the global loss.  (The multi-scale gradient loss normalises per scale by its own
+    valid-pixel count: it stays per rank.)
     Returns (loss to call .backward() on, loss value the reference would report)."""
     loss_params = loss_params or {"weight": 1.0, "n_lambda": 1.0}
+    if dp_exact:
+        return _sequence_loss_dp_exact(model, sequence, loss_composition, loss_weights, loss_params, grad_loss_weight, process_group)
     gterms = []
     L = len(sequence)
     assert L > 0
@@ -46,6 +62,41 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
     total = torch.stack(terms).sum() / float(L)
     if grad_loss_weight is not None:
         total = total + grad_loss_weight * torch.stack(gterms).sum() / float(L)
+    return total, total.detach() * len(keys_seen)
+
+
+def _sequence_loss_dp_exact(model, sequence, loss_composition, loss_weights, loss_params, grad_loss_weight, group):
+    import torch.distributed as dist
+    L = len(sequence)
+    assert L > 0
+    K = model.every_x_rgb_frame
+    prev_super, prev_lstm = None, empty_states_lstm(K)
+    sup, gterms, keys_seen = [], [], []
+    for item in sequence:
+        preds, supers, lstms = model(item, prev_super, prev_lstm)
+        for key, value in preds.items():
+            if not loss_composition or key in loss_composition:
+                w = loss_weights[loss_composition.index(key)]
+                target = item['depth_' + key].to(model.gpu).float()
+                sup.append((w, value.float(), target))
+                if grad_loss_weight is not None:
+                    gterms.append(w * ops.multi_scale_grad_loss(value, target))
+                if key not in keys_seen:
+                    keys_seen.append(key)
+        prev_super, prev_lstm = supers['image'], lstms
+    table = torch.empty(len(sup), 4, device=model.gpu, dtype=torch.float64)
+    for i, (_, value, target) in enumerate(sup):
+        ops.si_local_stats(value.detach(), target, table[i])
+    world = 1
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)       # stream-ordered on the compute stream: 32 B per term
+    terms = [w * ops.SILossFromStats.apply(value, target, table[i], float(loss_params["weight"]), float(loss_params["n_lambda"]),
+                                           float(world)) for i, (w, value, target) in enumerate(sup)]
+    total = torch.stack(terms).sum() / float(L)
+    if grad_loss_weight is not None:
+        total = total + grad_loss_weight * torch.stack(gterms).sum() / float(L)
+    # value: SILossFromStats.forward returns the global loss itself (the gain only scales its backward)
     return total, total.detach() * len(keys_seen)
 
 
@@ -78,6 +129,9 @@ class EpochTrainer:
         self.start_epoch = 1
         self.checkpoint_dir = os.path.join(config['trainer']['save_dir'], config['name'])
         os.makedirs(self.checkpoint_dir, exist_ok=True)
+        import json                      # base_trainer.py:50-51: the reference's test / evaluation tooling reads it beside the checkpoints
+        with open(os.path.join(self.checkpoint_dir, 'config.json'), 'w') as f:
+            json.dump(config, f, indent=4, sort_keys=False)
         self.train_logger = train_logger if train_logger is not None else ck.Logger()
         self.lr_history = []
         if resume:
@@ -91,7 +145,9 @@ class EpochTrainer:
         path = ck.save_checkpoint(ck.checkpoint_name(self.checkpoint_dir, epoch, log['loss']), self.model, self.optimizer, epoch,
                                   self.config, self.monitor_best, self.train_logger)
         if save_best:
-            os.rename(path, os.path.join(self.checkpoint_dir, 'model_best.pth.tar'))
+            best = os.path.join(self.checkpoint_dir, 'model_best.pth.tar')
+            os.rename(path, best)
+            path = best
         return path
 
     def train(self):

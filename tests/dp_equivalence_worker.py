@@ -38,6 +38,8 @@ def main():
         return red.flat.clone()
 
     mine = shard_indices(n_seq, rank, world)
+    if "--exact" in sys.argv:
+        return exact_mode(model, red, cfg, batch, mine, n_seq, rank, world)
     own = local_grads(mine)
     assert all(p.grad.data_ptr() == red.views[p].data_ptr() for p in model.parameters())
     red.all_reduce()
@@ -60,6 +62,58 @@ def main():
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def exact_mode(model, red, cfg, batch, mine, n_seq, rank, world):
+    """dp_exact: SI statistics all-reduced before the backward -> averaged gradient == gradient of ONE process on the concatenated
+    batch (model/loss.py:9: mean(d)^2 over the whole batch), checked against the HIP model itself and against the fp64 oracle."""
+    from rpg_ramnet_amd.trainer import sequence_loss
+    lc = cfg["loss_composition"]
+    red.zero()
+    total, reported = sequence_loss(model, batch(mine), lc, [1, 1], dp_exact=True)
+    total.backward()
+    red.all_reduce()
+    red.wait()
+    torch.cuda.synchronize()
+    avg, loss_dp = red.flat.clone(), float(total.detach())
+    # the standard-DDP gradient of the same shards, for contrast
+    red.zero()
+    t2, _ = sequence_loss(model, batch(mine), lc, [1, 1])
+    t2.backward()
+    red.all_reduce()
+    red.wait()
+    torch.cuda.synchronize()
+    ddp = red.flat.clone()
+    losses = [None] * world
+    dist.all_gather_object(losses, loss_dp)
+    if rank == 0:
+        full = [i for r in range(world) for i in range(r, n_seq, world)]      # concatenation in rank order (order is irrelevant to the loss)
+        red.zero()
+        t1, _ = sequence_loss(model, batch(full), lc, [1, 1])
+        t1.backward()
+        torch.cuda.synchronize()
+        single = red.flat.clone()
+        from oracle import ramnet_ref
+        sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+        seq64 = [{k: v.double().cpu() for k, v in it.items()} for it in batch(full)]
+        ref, _ = ramnet_ref.sequence_loss(sd, cfg, seq64, lc, [1, 1])
+        ref.backward()
+        gmax = max(float(v.grad.abs().max()) for v in sd.values())
+        worst = 0.0
+        for k, p in model.named_parameters():
+            g = avg[_offset(red, p):_offset(red, p) + p.numel()].view_as(p).cpu().double()
+            worst = max(worst, float((g - sd[k].grad).abs().max() / max(float(sd[k].grad.abs().max()), 1e-2 * gmax)))
+        scale = float(single.abs().max())
+        print(json.dumps({"rank": rank, "losses": losses, "loss_single": float(t1.detach()), "loss_oracle": float(ref.detach()),
+                          "err_vs_single_rank_concat": float((avg - single).abs().max()) / scale,
+                          "ddp_vs_single_rank_concat": float((ddp - single).abs().max()) / scale,
+                          "err_vs_oracle_concat": worst, "n": int(avg.numel())}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _offset(red, p):
+    return (red.views[p].data_ptr() - red.flat.data_ptr()) // 4
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -202,6 +203,29 @@ def test_data_parallel_gradient_average_gloo_world2():
         net(data[idx]).square().mean().backward()
         grads.append(torch.cat([p.grad.flatten() for p in reversed(list(net.parameters()))]))
     np.testing.assert_allclose(res[0][2], ((grads[0] + grads[1]) / 2).numpy(), rtol=1e-5, atol=1e-8)
+
+
+def test_bench_plain_command_starts_its_own_ranks():
+    """The driver's multi-GPU command is `python bench.py --gpus N ...` with no torch.distributed.run around it: bench.py must start
+    its N ranks itself (rendezvous on 127.0.0.1), every rank must report in over the collective backend and rank 0 alone prints ONE
+    JSON line.  --launch-check stops before any GPU work, so the launch contract runs here (gloo: no device in this container)."""
+    import json as js
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = js.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == [0, 1]
+    # ... and under torch.distributed.run (the other launch contract) the same file does not re-launch
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 100), os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    assert js.loads(lines[0])["rccl_ranks_seen"] == [0, 1]
 
 
 def test_checkpoint_layout_round_trip_and_reference_pickle(tmp_path):

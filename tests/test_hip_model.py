@@ -305,6 +305,53 @@ def test_data_parallel_hip_model_gradient_equivalence():
     assert out["err_vs_single_rank_mean"] < 1e-4         # ... which is what a single process computes (atomic order only)
 
 
+def test_data_parallel_exact_global_batch_loss():
+    """VERDICT r3 item 1b / SURVEY 8e: with dp_exact the (sum d, sum d^2, n) of every supervised map are all-reduced before the
+    backward; the 2-rank averaged gradient then equals the single-rank gradient on the CONCATENATED batch (model/loss.py:9 takes
+    mean(d)^2 over the whole batch) — against the HIP model in one process and against the fp64 oracle — and every rank reports the
+    global loss.  The standard-DDP gradient of the same shards differs measurably (the test would not notice a no-op otherwise)."""
+    import json as js
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29400 + os.getpid() % 90), os.path.join(root, "tests", "dp_equivalence_worker.py"), "--exact"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = js.loads(lines[0])
+    assert out["n"] == 14884353
+    assert abs(out["losses"][0] - out["losses"][1]) == 0.0                         # both ranks hold the global loss
+    assert abs(out["losses"][0] - out["loss_single"]) < 1e-5 * abs(out["loss_single"])
+    assert abs(out["losses"][0] - out["loss_oracle"]) < 1e-4 * abs(out["loss_oracle"])
+    assert out["err_vs_single_rank_concat"] < 1e-4                                  # atomic order only
+    assert out["err_vs_oracle_concat"] < 2e-3
+    assert out["ddp_vs_single_rank_concat"] > 10 * out["err_vs_single_rank_concat"]  # per-rank means are NOT the global-batch loss
+
+
+def test_bench_plain_command_self_launches_two_ranks():
+    """`python bench.py --gpus 2` the way the driver types it — no torch.distributed.run, no WORLD_SIZE in the
+    environment — starts its two ranks itself.  On this 1-GPU box both ranks share cuda:0 and the collectives go over gloo (RCCL
+    refuses two ranks on one device); the line says so.  With --dp-exact-loss the exact global-batch semantics are declared."""
+    import json as js
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "32", "--width", "48",
+           "--batch", "2", "--seq-len", "2", "--events-per-grid", "2000", "--no-cpu-baseline", "--dp-exact-loss"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = js.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == [0, 1] and out["config"]["global_batch"] == 4
+    assert out["backend"].startswith("gloo") and "exact global batch" in out["loss_semantics"]
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
 def test_rccl_world1_reducer_and_bench_step():
     """VERDICT r2 #6a: the RCCL (`nccl`) backend has to EXECUTE before the driver's 8-GPU run does it for the first time.  World
     size 1 on this box: process-group init with device_id, FlatGradReducer's bucketed all_reduce on its side stream + wait(), the
