@@ -123,6 +123,8 @@ def winograd_factor(kernel):
     F(2x2,4x4) 25 per 64; direct kernels 1."""
     if kernel.startswith(("conv_wino_kernel", "conv_wino_r_kernel", "conv_wgrad_wino_kernel", "conv_wgrad_wino_r_kernel")):
         return 16.0 / 36.0
+    if kernel.startswith("conv_wino_r6_kernel"):      # F(2x4,3x3): a 4 x 6 grid of products per 2 x 4 outputs x 9 taps
+        return 24.0 / 72.0
     if kernel.startswith(("conv_wino24_kernel", "conv_wgrad_wino24_kernel")):
         return 25.0 / 64.0
     return 1.0

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss); 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -55,7 +55,9 @@ enum ramnet_in_mode {
  * U[cls][pos = a*5+b][k][n] = sum_{t,s} G[a][t] W4[n][k][py][px][t][s] G[b][s] (W4 = the 4x4 parity filters, G below) stored at
  * ((((cls*(C0/KC) + k/KC)*(Cout/(16*NCQ)) + n/(16*NCQ))*25 + pos)*NCQ + (n%(16*NCQ))/16)*16*KC + (((k%KC)/(KC/4))*16 + n%16)*(KC/4) + k%(KC/4).
  * G = [1/2 0 0 0; -1/2 -1/2 -1/2 -1/2; -1/6 1/6 -1/6 1/6; 1/6 1/3 2/3 4/3; 0 0 0 1] (Toom-Cook points 0, 1, -1, 2, inf).  */
-enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3 };
+/* RAMNET_ALGO_WINOGRAD_2X4: F(2x4,3x3) — 2 x 4 output tiles, 3 instead of 4 multiplies per output (csrc/conv_wino6.hip); the same launches
+ * as RAMNET_ALGO_WINOGRAD restricted to what ramnet_conv_wino_variant() accepts, w from ramnet_pack_weight_wino2x4()                 */
+enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3, RAMNET_ALGO_WINOGRAD_2X4 = 4 };
 
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {
@@ -160,6 +162,16 @@ size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transpo
  * (flipped taps, reduce over O); gates=4 (forward only) groups the ConvLSTM gates of 16 hidden channels per block.  */
 size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed, int gates);
 int ramnet_pack_weight_wino(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, int gates, void *stream);
+/* Winograd F(2x4,3x3) weights U = G2 g G4^T (G2 of F(2,3), G4 of F(4,3)) in the lane order of conv_wino_r6_kernel's B operand:
+ * [Cin/8][Cout/64][row 4][column 6][n-block 2][lane 64][4], zero padded; transposed=1: the backward-data operator.            */
+size_t ramnet_packed_weight_elems_wino2x4(int Cout, int Cin, int transposed);
+int ramnet_pack_weight_wino2x4(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, void *stream);
+/* 1 when a launch that qualifies for RAMNET_ALGO_WINOGRAD (d->algo set so, every other field final) runs faster as
+ * RAMNET_ALGO_WINOGRAD_2X4 — the caller then sets d->algo and d->w (ramnet_pack_weight_wino2x4) accordingly; else 0.              */
+int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force);   /* force: skip the size heuristics (tests) */
+/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel workgroups a launch must have (default 512;
+ * < 0 keeps the current value); nf = 1 / 2 forces 32- / 64-channel workgroups, 0 = the launcher's choice (< 0 keeps).              */
+int ramnet_wino2x4_config(int min_wgs, int nf);
 /* Folded upsample-conv (RAMNET_ALGO_WINOGRAD24): OIHW 5x5 weights of an UpsampleConvLayer (submodules.py:69-97) -> Winograd-domain
  * weights of the four 4x4 parity filters in the kernel's layout (see ramnet_algo above); 100*Cout*Cin floats.
  * ramnet_fold_wino_supported: Cout % 32 == 0 and an even number of input-channel chunks (Cin % 32 == 0, or Cin % 16 == 0 with

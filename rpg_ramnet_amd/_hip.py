@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet_hip.so")     # (override: A/B builds)
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D, IN_PARITY4 = range(8)
-ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24 = 0, 1, 2, 3
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24, ALGO_WINOGRAD_2X4 = 0, 1, 2, 3, 4
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM = range(6)
 
 _fp = C.c_void_p
@@ -68,6 +68,10 @@ _SIGS = {
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 4),
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_packed_weight_elems_wino2x4": (C.c_size_t, [C.c_int] * 3),
+    "ramnet_pack_weight_wino2x4": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_wino2x4_config": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_conv_wino_variant": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
     "ramnet_head_supported": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_pack_weight_head": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),

@@ -17,6 +17,7 @@ constexpr int WCK = 32;       // input channels per block of the weight-gradient
 void set_error(const char *fmt, ...);
 void note_kernel(const char *fmt, ...);   // symbol (template arguments included) of the MFMA kernel a launcher enqueued: ramnet_last_kernel()
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st);   // conv_wino.hip
+int launch_wino6(const ramnet_conv_desc &d, hipStream_t st);  // conv_wino6.hip: F(2x4,3x3)
 int launch_head(const ramnet_conv_desc &d, hipStream_t st);   // conv_head.hip
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st); // conv_wino24.hip
 int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino24.hip

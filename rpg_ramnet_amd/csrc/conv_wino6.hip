@@ -1,0 +1,431 @@
+// Winograd F(2x4, 3x3) convolution for gfx950 (MI355X): forward and backward-data of the 3x3 stride-1 layers of the RAM-Net path on
+// the two FINE scales — ConvGRU gates / candidate (submodules.py:447-452) and every backward-data launch of those layers — exact-fp32
+// arithmetic on v_mfma_f32_32x32x2_f32.
+//
+//   Y = A2^T [ sum_ci (G2 g G4^T) .* (B2^T d B4) ] A4        F(2,3) down the rows, F(4,3) along the columns (Lavin & Gray 2016)
+//
+// A 2 x 4 output tile costs a 4 x 6 grid of products: 3 multiplies per output and channel pair against 4 for F(2x2,3x3) and 9 direct.
+// Why 2 x 4 and not 4 x 4 (2.25 per output): the register-transform formulation of conv_wino.hip gives every wave ONE ROW of the
+// transform grid (the lane builds its row of B^T d B in registers and that row IS the MFMA's A operand).  Four rows = four waves = one
+// per SIMD, all equally loaded; six rows put two waves on two of the four SIMDs (75 % of the pipe at best = 3.0 multiplies per output,
+// the same as here) or need 288 accumulator registers per wave.  The columns carry the larger transform instead: a wave owns 6 positions
+// for 32 tiles x (32 * NF) output channels — 96 * NF accumulator registers.
+//   NF = 2: 64 channels per workgroup, 48 MFMAs per 8-channel chunk and wave for 12 LDS reads + ~80 transform instructions (2.1 per
+//           MFMA; F(2x2,3x3): 2.3); 192 accumulators + the operand rings = one wave per SIMD, one workgroup per CU;
+//   NF = 1: 32 channels, two workgroups per CU (launches that would not fill the chip otherwise).
+// Everything else follows conv_wino.hip: only the raw patch is shared (fused loaders, double-buffered, one barrier per chunk, three
+// (pixel, quad) slots per thread for the 18 x 18 / 34 x 10 / 10 x 34 patch of a 256-pixel workgroup tile), weights stream from L2 in
+// B-operand lane order one chunk ahead, the waves exchange their column-transformed rows (4 of 6 columns) through LDS once per
+// workgroup in front of the two-phase channel-quad epilogue.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.hpp"
+#include "conv_epilogue.hpp"
+#include "conv_wino_common.hpp"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ramnet {
+
+constexpr int W6_BN = 64;                        // output channels per 64-channel block of the packed weights
+constexpr int W6_U_FLOATS = 24 * W6_BN * WK;     // weights of one (chunk, 64-channel block): 24 positions x 64 x 8 = 48 KB
+
+// TXG = tiles per workgroup row: 4 (16 x 16 output pixels), 2 (32 rows x 8 columns) or 8 (8 x 32)
+template <int TXG> struct R6Geom {
+    static constexpr int TYG = 32 / TXG, TH = 2 * TYG, TW = 4 * TXG, PH = TH + 2, PW = TW + 2;
+    static constexpr int PLANE = PH * PW * 4;    // floats of one channel-quad plane of the patch
+    static constexpr int PFLOATS = 2 * PLANE;
+    static_assert(PH * PW * 2 <= 768, "three patch slots per thread");
+};
+
+template <int TXG, int MODE, int NF>
+__global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(const ramnet_conv_desc p, const WinoParams q) {
+    constexpr int RO_LD = NF * 32 + 4;           // row of the exchange buffer [wave 4][column 4][tile 32][channels + pad]
+    using G = R6Geom<TXG>;
+    constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *patch = smem;                         // [2 buffers][2 quads][PH x PW pixels][4] + 256 scratch cells; the epilogue reuses the space
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hq = lane >> 5;
+
+    // XCD-aware order as in conv_wino.hip: the channel blocks of ONE spatial tile are consecutive on one XCD
+    const int xslot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int nbl = (q.nblk * (2 / NF)) >> q.xg;
+    const int nblk_v = ((xslot % nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
+    const int nblk_i = NF == 1 ? nblk_v >> 1 : nblk_v, fh = NF == 1 ? nblk_v & 1 : 0;
+    int bid = (xslot / nbl) * (8 >> q.xg) + (xcd >> q.xg);
+    if (bid >= q.tiles_x * q.tiles_y * p.B) return;
+    const int tx_i = bid % q.tiles_x;
+    bid /= q.tiles_x;
+    const int ty_i = bid % q.tiles_y;
+    const int b = bid / q.tiles_y;
+    const int n0 = nblk_i * W6_BN + fh * 32;
+    const int oy0 = ty_i * G::TH, ox0 = tx_i * G::TW;
+    const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
+
+    // row `wave` of B2^T d: rows (ra, rb) of the tile's 4 x 6 window, t[j] = d[ra][j] + sb * d[rb][j]
+    const int tty = l31 / TXG, ttx = l31 % TXG;
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sb = wave == 1 ? 1.f : -1.f;
+    const int pra = hq * RP_PLANE + ((2 * tty + ra) * RPW + 4 * ttx) * 4;
+    const int prb = hq * RP_PLANE + ((2 * tty + rb) * RPW + 4 * ttx) * 4;
+    // weights: [chunk][block64][wave 4][position-in-row 6][n-block 2][lane 64][channel j 4]
+    const float *wsrc = p.w + (size_t)nblk_i * W6_U_FLOATS + wave * 3072 + fh * 256 + lane * 4;
+    const size_t wchunk = (size_t)q.nblk * W6_U_FLOATS;
+
+    f32x16 acc[6][NF];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
+
+    const int nch = q.nchunks;
+    const int clast = (nch - 1) * WK;
+    WinoPatch<MODE, 3> pr;
+    pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid, clast, 2 * RP_FLOATS);
+    float4 breg[6][NF];
+    float4 tcur[6], tnext[6], ta, tb;
+    auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
+    // x + s * y on channel quads (one v_fma per channel)
+    auto fma4 = [](float s, float4 y, float4 x) { return make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w); };
+    auto sub4 = [](float4 x, float4 y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+
+    pr.load(q.src, 0, clast);
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        if (NF == 2 || !(i & 1)) breg[i >> 1][NF == 2 ? i & 1 : 0] = ld4(wsrc + i * 256);
+    pr.store(patch, q.src, 0);
+    pr.load(q.src, min(WK, clast), clast);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 6; ++c) tcur[c] = te(ld4(patch + pra + c * 4), ld4(patch + prb + c * 4));
+    pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
+    pr.load(q.src, min(2 * WK, clast), clast);
+    __syncthreads();
+    // one chunk: MFMAs on the row in `tc` (column transform B4 in registers, position by position), while the row of the next chunk
+    // is read and combined into `tn` and the patch of chunk + 2 / + 3 is stored / requested — one slice behind every MFMA
+    auto body = [&](int chunk, const float4 (&tc)[6], float4 (&tn)[6]) {
+        const float *pnext = patch + ((chunk + 1) & 1) * RP_FLOATS;     // patch(i+1)
+        float *pfree = patch + (chunk & 1) * RP_FLOATS;                 // patch(i), consumed during chunk i-1 -> patch(i+2)
+        const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
+        const int c2 = min((chunk + 2) * WK, clast), c3 = min((chunk + 3) * WK, clast);
+        auto side = [&](int k) {                    // compile-time constant after unrolling
+            if (k < 12) {
+                if (!(k & 1)) ta = ld4(pnext + pra + (k >> 1) * 4), tb = ld4(pnext + prb + (k >> 1) * 4);
+                else tn[k >> 1] = te(ta, tb);
+            } else if (k < 15) pr.store_slot(pfree, q.src, c2, k - 12);
+            else if (k < 18) pr.load_slot(q.src, c3, k - 15, clast);
+        };
+        float4 s0, s1;                               // shared sub-expressions of positions (1, 2) and (3, 4)
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl) {
+            // B4^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+            float4 v;
+            if (pl == 0) v = fma4(4.f, tc[0], fma4(-5.f, tc[2], tc[4]));
+            else if (pl == 1) s0 = fma4(-4.f, tc[2], tc[4]), s1 = fma4(-4.f, tc[1], tc[3]), v = f4add(s0, s1);
+            else if (pl == 2) v = sub4(s0, s1);
+            else if (pl == 3) s0 = sub4(tc[4], tc[2]), s1 = sub4(tc[3], tc[1]), v = fma4(2.f, s1, s0);
+            else if (pl == 4) v = fma4(-2.f, s1, s0);
+            else v = fma4(4.f, tc[1], fma4(-5.f, tc[3], tc[5]));
+            const float va[4] = {v.x, v.y, v.z, v.w};
+            const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
+            const float b1[4] = {breg[pl][NF - 1].x, breg[pl][NF - 1].y, breg[pl][NF - 1].z, breg[pl][NF - 1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (NF == 2) {
+                    // 48 gaps, 18 slices: one behind each of the first 18 MFMA pairs' halves is too dense for the LDS reads'
+                    // latency — spread them: a slice behind every MFMA of positions 0 .. 2 (24 gaps), positions 3 .. 5 carry none
+                    if (pl < 3) side(pl * 8 + j * 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[pl][NF - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][NF - 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pl < 3) side(pl * 8 + j * 2 + 1);
+                } else {
+                    side(pl * 4 + j);                // 24 gaps per chunk for the 18 slices
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            breg[pl][0] = ld4(wnext + (pl * 2) * 256);
+            if (NF == 2) breg[pl][NF - 1] = ld4(wnext + (pl * 2 + 1) * 256);
+        }
+        __syncthreads();                           // patch(i+2) visible; patch(i+1) free
+    };
+    // (do-while: nch >= 1.  A `for` loop leaves a path around the loop on which the exchange below would read the zero-initialised
+    // accumulators — the compiler then carries 192 zeros in VGPRs across the loop beside the AGPR accumulators and spills the loop's
+    // own addresses: 256 VGPRs + 29-85 scratch reloads with `s_waitcnt vmcnt(0)` per chunk, against 197 VGPRs and none this way)
+    int chunk = 0;
+    do {
+        body(chunk, tcur, tnext);
+        if (chunk + 1 < nch) body(chunk + 1, tnext, tcur);      // (uniform over the workgroup)
+        chunk += 2;
+    } while (chunk < nch);
+
+    // ---- exchange: column transform of the wave's row (M A4: 4 of 6 columns), all waves -> LDS.
+    // A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+    // D of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile)
+    float *P = smem;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r], m4 = acc[4][f][r], m5 = acc[5][f][r];
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
+            const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
+            float *dst = P + ((wave * 4) * 32 + m) * RO_LD + f * 32 + l31;
+            dst[0 * 32 * RO_LD] = m0 + a12 + a34;
+            dst[1 * 32 * RO_LD] = d12 + 2.f * d34;
+            dst[2 * 32 * RO_LD] = a12 + 4.f * a34;
+            dst[3 * 32 * RO_LD] = d12 + 8.f * d34 + m5;
+        }
+    __syncthreads();
+    // row transform A2^T (.) across the waves for output pixel pxl (0..255 of the TH x TW tile) and channels col .. col+3
+    auto out4 = [&](int pxl, int col) {
+        const int py = pxl / RTW, px = pxl % RTW;
+        const float *base = P + ((px & 3) * 32 + (py >> 1) * TXG + (px >> 2)) * RO_LD + col;
+        const float4 t1 = ld4(base + 1 * 128 * RO_LD), t2 = ld4(base + 2 * 128 * RO_LD);
+        if (py & 1) {
+            const float4 t3 = ld4(base + 3 * 128 * RO_LD);
+            return make_float4(t1.x - t2.x - t3.x, t1.y - t2.y - t3.y, t1.z - t2.z - t3.z, t1.w - t2.w - t3.w);
+        }
+        const float4 t0 = ld4(base);
+        return make_float4(t0.x + t1.x + t2.x, t0.y + t1.y + t2.y, t0.z + t1.z + t2.z, t0.w + t1.w + t2.w);
+    };
+    const int epi = p.epi;
+    // Channel-quad epilogue in two phases (conv_wino.hip): every global operand of the thread's 8 * NF output quads is REQUESTED first —
+    // in two halves of 4 * NF, so that the GRU blend's three operands per quad stay in registers —, then the quads are transformed out
+    // of LDS, activated and stored.  The launcher only selects this kernel for 16-byte-accessible operands (q.vec4) and no s2d output.
+    constexpr int NI = 4 * NF;
+    const int qd = NF == 2 ? tid & 15 : tid & 7, nq = n0 + qd * 4;       // (the same quad for all i: 256 threads = 16 x 16 quads)
+    const bool nok = nq < p.Cout;
+    const int nqs = nok ? nq : 0;
+    const float4 bias4 = p.bias ? ld4(p.bias + nqs) : f4zero();
+    const bool addold = p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
+    auto run = [&](auto kind) {
+        constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bool ok[NI];
+            size_t pix[NI];
+            int pxl[NI];
+            float4 ea[NI], eb[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int sl = tid + (half * NI + i) * 256;
+                pxl[i] = NF == 2 ? sl >> 4 : sl >> 3;
+                const int oy = oy0 + pxl[i] / RTW, ox = ox0 + pxl[i] % RTW;
+                ok[i] = nok && oy < p.Ho && ox < p.Wo;
+                pix[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;     // (a valid address either way)
+                ea[i] = K >= 1 ? ld4(p.e0 + pix[i] * p.lde0 + nqs) : addold ? ld4(p.out + pix[i] * p.ldo + nqs) : f4zero();
+                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : f4zero();
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if (!ok[i]) continue;
+                float4 v = f4add(out4(pxl[i], qd * 4), bias4);
+                if (K == 0) {
+                    if (addold) v = make_float4(v.x + p.beta * ea[i].x, v.y + p.beta * ea[i].y, v.z + p.beta * ea[i].z, v.w + p.beta * ea[i].w);
+                    if (epi == RAMNET_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    else if (epi == RAMNET_EPI_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+                } else if (K == 1) {
+                    v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
+                } else {
+                    const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
+                    if (p.o1) st4(p.o1 + pix[i] * p.ldo1 + nq, o);
+                    v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
+                                    h.w * (1.0f - u.w) + o.w * u.w);
+                }
+                st4(p.out + pix[i] * p.ldo + nq, v);
+            }
+        }
+    };
+    if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
+    else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+}
+
+// OIHW 3x3 -> U = G2 g G4^T (evaluated in double) in the lane order of the kernel's B operand:
+// index = (((((chunk * nblk + nb) * 4 + w) * 6 + pl) * 2 + f) * 64 + lane) * 4 + j  ->
+// U[row w][column pl][input channel chunk*8 + 4*(lane >> 5) + j][output channel nb*64 + f*32 + (lane & 31)]
+__global__ void pack_weight_wino_r6_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int transposed,
+                                           int R, int N, int nchunks, int nblk, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3), lane = (int)((i >> 2) & 63), f = (int)((i >> 8) & 1);
+        size_t jj = i >> 9;
+        const int pl = (int)(jj % 6);
+        jj /= 6;
+        const int wv = (int)(jj & 3);
+        jj >>= 2;
+        const int nb = (int)(jj % nblk), chunk = (int)(jj / nblk);
+        const int n = f * 32 + (lane & 31);
+        const int r = chunk * WK + 4 * (lane >> 5) + j;
+        const int no = nb * W6_BN + n;
+        float v = 0.f;
+        if (r < R && no < N) {
+            double g[3][3];
+            for (int a = 0; a < 3; ++a)
+                for (int bb = 0; bb < 3; ++bb)
+                    g[a][bb] = transposed ? (double)w[((size_t)r * Cin + no) * 9 + (2 - a) * 3 + (2 - bb)]
+                                          : (double)w[((size_t)no * Cin + r) * 9 + a * 3 + bb];
+            const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const double G4[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            double s = 0;
+            for (int a = 0; a < 3; ++a)
+                for (int bb = 0; bb < 3; ++bb) s += G2[wv][a] * g[a][bb] * G4[pl][bb];
+            v = (float)s;
+        }
+        wp[i] = v;
+    }
+}
+
+static void wino6_geometry(int Cout, int Cin, int transposed, int &R, int &N, int &nchunks, int &nblk) {
+    R = transposed ? Cout : Cin;
+    N = transposed ? Cin : Cout;
+    nchunks = cdiv(R, WK);
+    nblk = cdiv(N, W6_BN);
+}
+
+// Workgroup tile of F(2x4,3x3) for an Ho x Wo map: 32 tiles of 2 x 4 pixels as 16 x 16 (TXG 4), 32 x 8 (TXG 2) or 8 x 32 (TXG 8),
+// whichever pads the map least; returns the padded area.
+static long wino6_tile(int Ho, int Wo, int &txg) {
+    const int shapes[3] = {4, 2, 8};
+    long best = -1;
+    for (int s = 0; s < 3; ++s) {
+        const int t = shapes[s], th = 2 * (32 / t), tw = 4 * t;
+        const long a = (long)cdiv(Ho, th) * th * cdiv(Wo, tw) * tw;
+        if (best < 0 || a < best) best = a, txg = t;
+    }
+    return best;
+}
+
+static bool wino6_vec4(const ramnet_conv_desc &d) {
+    auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
+    return d.Cout % 4 == 0 && d.ldo % 4 == 0 && al16(d.out) && al16(d.bias) && (!d.o1 || (d.ldo1 % 4 == 0 && al16(d.o1))) &&
+           (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1)));
+}
+
+// Does this WINOGRAD-eligible launch run F(2x4,3x3)?  Dense 3x3 layers with plain / concatenated / masked inputs and the channel-quad
+// epilogues (no ConvLSTM cell, no space-to-depth view), 64-channel output blocks, on maps where (a) the 2 x 4 tiling wastes less than
+// a quarter of what it saves and (b) the launch still fills the chip with 64-channel workgroups at ONE per CU.
+static int g_w6_min_wgs = 512, g_w6_nf = 0;     // ramnet_wino2x4_config(): launch-size threshold, forced NF (0 = by launch size)
+
+int wino6_eligible(const ramnet_conv_desc &d, int force) {
+    if (d.ntaps != 9 || d.stride != 1 || d.s2d_5x5 || d.out_s2d || d.frame) return 0;
+    if (d.in_mode != RAMNET_IN_PLAIN && d.in_mode != RAMNET_IN_CAT && d.in_mode != RAMNET_IN_CAT_MUL && d.in_mode != RAMNET_IN_RELUMASK) return 0;
+    if (d.epi == RAMNET_EPI_LSTM || d.Cout % 64 != 0 || !wino6_vec4(d)) return 0;
+    int txg;
+    const long a6 = wino6_tile(d.Ho, d.Wo, txg);
+    const long a4t = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32, a4w = (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
+    const long a4 = a4t < a4w ? a4t : a4w;
+    if (force) return 1;                                            // (tests: every structurally eligible launch)
+    if (3 * a6 > 4 * a4 * 0.9) return 0;                            // less than 10 % fewer MFMAs: not worth the larger tiles
+    const long wgs = a6 / 256 * d.B * cdiv(d.Cout, 64);
+    return wgs >= g_w6_min_wgs ? 1 : 0;
+}
+
+int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
+    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && !d.s2d_5x5 && !d.out_s2d && !d.frame && d.epi != RAMNET_EPI_LSTM);
+    RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK);
+    if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
+    RAMNET_CHECK_ARG(wino6_vec4(d) && d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0);
+    int dymin = 127, dxmin = 127;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        dymin = d.dy[t] < dymin ? d.dy[t] : dymin;
+        dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin;
+    }
+    for (int t = 0; t < 9; ++t) {
+        const int a = d.dy[t] - dymin, c = d.dx[t] - dxmin;
+        RAMNET_CHECK_ARG(a >= 0 && a < 3 && c >= 0 && c < 3);
+        seen |= 1u << (a * 3 + c);
+    }
+    RAMNET_CHECK_ARG(seen == 0x1ffu);
+    const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
+    WinoParams q;
+    q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
+    q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
+    q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
+    q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    q.nchunks = cdiv(q.src.Cin, WK), q.nblk = cdiv(d.Cout, W6_BN);
+    int txg;
+    wino6_tile(d.Ho, d.Wo, txg);
+    q.tiles_x = cdiv(d.Wo, 4 * txg), q.tiles_y = cdiv(d.Ho, 2 * (32 / txg));
+    q.dy0 = dymin, q.dx0 = dxmin;
+    q.vec4 = 1, q.s2d_shift = 0, q.sparse = 0;
+    // XCD-pinned channel groups for weights that do not fit an L2 (conv_wino.hip)
+    const size_t wbytes = (size_t)q.nchunks * q.nblk * W6_U_FLOATS * sizeof(float);
+    q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
+    while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
+    const int lanes = 8 >> q.xg;
+    const int nf = g_w6_nf == 1 ? 1 : 2;                            // 32-channel workgroups (two per CU) on request only
+    dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
+    const size_t ex = (size_t)4 * 4 * 32 * (nf * 32 + 4) * sizeof(float);
+    {
+        const unsigned long long px = (unsigned long long)d.Hin * d.Win;
+        int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
+        ldmax = ldmax > d.ldm ? ldmax : d.ldm;
+        RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
+    }
+    note_kernel("conv_wino_r6_kernel<%d,%d,%d>", txg, d.in_mode, nf);
+#define RAMNET_GO6(TXv, MDv, NFv)                                                                                   \
+    case (TXv) * 100 + (MDv) * 4 + (NFv): {                                                                         \
+        const size_t pf = (size_t)(2 * R6Geom<TXv>::PFLOATS + 256 * 4) * sizeof(float);                             \
+        RAMNET_FULL_LDS((conv_wino_r6_kernel<TXv, MDv, NFv>));                                                      \
+        hipLaunchKernelGGL((conv_wino_r6_kernel<TXv, MDv, NFv>), grid, dim3(256), ex > pf ? ex : pf, st, d, q);     \
+    } break;
+#define RAMNET_GO6_TX(TXv)                                                                                          \
+    RAMNET_GO6(TXv, RAMNET_IN_PLAIN, 2) RAMNET_GO6(TXv, RAMNET_IN_CAT, 2) RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL, 2)     \
+    RAMNET_GO6(TXv, RAMNET_IN_RELUMASK, 2) RAMNET_GO6(TXv, RAMNET_IN_PLAIN, 1) RAMNET_GO6(TXv, RAMNET_IN_CAT, 1)    \
+    RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL, 1) RAMNET_GO6(TXv, RAMNET_IN_RELUMASK, 1)
+    switch (txg * 100 + d.in_mode * 4 + nf) {
+        RAMNET_GO6_TX(4)
+        RAMNET_GO6_TX(2)
+        RAMNET_GO6_TX(8)
+    default:
+        RAMNET_CHECK_ARG(!"conv_wino_r6: unsupported (tile, input mode) combination");
+    }
+#undef RAMNET_GO6_TX
+#undef RAMNET_GO6
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_wino2x4_config(int min_wgs, int nf) {
+    RAMNET_CHECK_ARG(nf >= -1 && nf <= 2);
+    if (min_wgs >= 0) g_w6_min_wgs = min_wgs;
+    if (nf >= 0) g_w6_nf = nf;
+    return 0;
+}
+
+extern "C" int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force) { return d ? wino6_eligible(*d, force) : 0; }
+
+extern "C" size_t ramnet_packed_weight_elems_wino2x4(int Cout, int Cin, int transposed) {
+    int R, N, nchunks, nblk;
+    wino6_geometry(Cout, Cin, transposed, R, N, nchunks, nblk);
+    return (size_t)nchunks * nblk * W6_U_FLOATS;
+}
+
+extern "C" int ramnet_pack_weight_wino2x4(const float *w, float *wp, int Cout, int Cin, int transposed, void *stream) {
+    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0);
+    int R, N, nchunks, nblk;
+    wino6_geometry(Cout, Cin, transposed, R, N, nchunks, nblk);
+    const size_t total = (size_t)nchunks * nblk * W6_U_FLOATS;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weight_wino_r6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin,
+                       transposed, R, N, nchunks, nblk, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}

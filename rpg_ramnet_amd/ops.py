@@ -28,6 +28,21 @@ def set_winograd(on):
     _WINOGRAD = bool(on)
 
 
+_WINO_2X4 = "auto"
+
+
+def set_winograd_2x4(mode, nf=None, min_wgs=None):
+    """F(2x4,3x3) variant of the Winograd forward / backward-data launches (csrc/conv_wino6.hip): "auto" = where the library's size
+    heuristics pick it (large maps: the two fine scales at the training batch), "off" = F(2x2,3x3) everywhere, "force" = every
+    structurally eligible launch (tests).  nf: 1 / 2 = 32- / 64-channel workgroups, 0 = the launcher's choice; min_wgs: launch-size
+    threshold of "auto" (library defaults when None)."""
+    global _WINO_2X4
+    assert mode in ("auto", "off", "force")
+    _WINO_2X4 = mode
+    if nf is not None or min_wgs is not None:
+        H.check(H.lib().ramnet_wino2x4_config(-1 if min_wgs is None else int(min_wgs), -1 if nf is None else int(nf)), "wino2x4_config")
+
+
 def get_winograd():
     return _WINOGRAD
 
@@ -203,6 +218,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
     d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
     d.algo = H.ALGO_DIRECT
+    ref = None
     if isinstance(w, PackRef) and beta == 0.0 and frame == 0 and os == (1, 1, 0, 0) and uses_head(taps, w, stride, epi, in_mode):
         d.algo, d.head_cin = H.ALGO_HEAD, w.cp.Cin
         w = w.cp.pack(0, "head")
@@ -211,6 +227,8 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
         d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
         # the 3x3 view of a 5x5 stride-2 layer read / written in place: 11 of its 36 slices are zero by construction (s2d_weights)
         d.s2d_5x5 = int(wino and isinstance(w.cp, S2DConvParam) and _S2D_SPARSE and (in_mode == H.IN_S2D or out_s2d > 0))
+        if wino and w.cp.gates == 1 and os == (1, 1, 0, 0) and not isinstance(w.cp, S2DConvParam):
+            ref = w                      # candidate for F(2x4,3x3): the library decides once the descriptor is complete (below)
         w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
     d.ntaps, d.stride = taps.n, stride
@@ -227,6 +245,9 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.ldo, d.ldo1, d.ldo2 = ld(out), (ld(o1) if o1 is not None else 0), (ld(o2) if o2 is not None else 0)
     if wino24:          # w = ConvParam.pack_fold_wino(): all four parities in one Winograd F(2x2,4x4) launch
         d.algo = H.ALGO_WINOGRAD24
+    if ref is not None and _WINO_2X4 != "off" and H.lib().ramnet_conv_wino_variant(C.byref(d), int(_WINO_2X4 == "force")):
+        # F(2x4,3x3) on the fine scales (csrc/conv_wino6.hip): its own Winograd-domain pack of the same parameters
+        d.algo, d.w = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4"))
     return d
 
 
@@ -571,6 +592,10 @@ class ConvParam:
             out = torch.empty(L.ramnet_packed_weight_elems_head(self.Cin), device=w.device, dtype=torch.float32)
             H.check(L.ramnet_pack_weight_head(_p(w), _p(out), self.Cout, self.Cin, _st()), "ramnet_pack_weight_head")
             return out
+        if wino == "2x4":
+            out = torch.empty(L.ramnet_packed_weight_elems_wino2x4(self.Cout, self.Cin, transposed), device=w.device, dtype=torch.float32)
+            H.check(L.ramnet_pack_weight_wino2x4(_p(w), _p(out), self.Cout, self.Cin, transposed, _st()), "ramnet_pack_weight_wino2x4")
+            return out
         if wino:
             n = L.ramnet_packed_weight_elems_wino(self.Cout, self.Cin, transposed, g)
             out = torch.empty(n, device=w.device, dtype=torch.float32)
@@ -584,7 +609,7 @@ class ConvParam:
     def pack(self, transposed, wino=False):
         """Packed weights for the forward (transposed=0) / backward-data (1) launch, re-packed when a parameter changes."""
         v = self._versions(self.weights)
-        wino = wino if wino == "head" else bool(wino)
+        wino = wino if wino in ("head", "2x4") else bool(wino)
         key = (transposed, wino)
         hit = self._packs.get(key)
         if hit is None or hit[0] != v:

@@ -175,14 +175,74 @@ def test_transposed_conv(B, H, W, cin, cout, skip):
     run_pair(m, oracle, [x, s] if skip else [x])
 
 
-@pytest.fixture(params=["winograd", "direct"])
+@pytest.fixture(params=["winograd", "direct", "winograd2x4", "winograd2x4_nf1"])
 def algo3x3(request):
-    """3x3 stride-1 layers: Winograd F(2x2,3x3) (default) and the direct implicit GEMM, both against the oracle."""
+    """3x3 stride-1 layers: Winograd F(2x2,3x3) (default at these sizes), the direct implicit GEMM, and F(2x4,3x3) (the fine-scale
+    kernel of the training batch, forced here for every eligible launch; 64- and 32-channel workgroups), all against the oracle."""
     from rpg_ramnet_amd import ops
     old = ops.get_winograd()
-    ops.set_winograd(request.param == "winograd")
+    ops.set_winograd(request.param != "direct")
+    if request.param.startswith("winograd2x4"):
+        ops.set_winograd_2x4("force", nf=1 if request.param.endswith("nf1") else 2)
     yield request.param
     ops.set_winograd(old)
+    ops.set_winograd_2x4("auto", nf=0)
+
+
+@pytest.mark.parametrize("nf", [2, 1])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (1, 32, 8), (2, 8, 32), (1, 64, 86)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 128), (40, 64), (128, 64), (36, 64)])
+def test_winograd2x4_conv3x3_raw(B, H, W, cin, cout, nf):
+    """F(2x4,3x3) forward and backward-data launches (csrc/conv_wino6.hip; loaders PLAIN / RELUMASK, epilogues RES_RELU / LINEAR /
+    beta accumulation; the three workgroup tile shapes 16x16, 32x8, 8x32; ragged maps and reduction depths that are not multiples
+    of 8) against float64 F.conv2d and against F(2x2,3x3); the library must report the r6 kernel for every launch."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops, _hip as Hh
+    torch.manual_seed(11)
+    w = torch.randn(cout, cin, 3, 3) * 0.1
+    b = torch.randn(cout) * 0.1
+    cp = ops.ConvParam([torch.nn.Parameter(w.to(dev()))], [torch.nn.Parameter(b.to(dev()))])
+    x = torch.randn(B, cin, H, W)
+    xg = nhwc(x).to(dev()).contiguous()
+    res = torch.randn(B, cout, H, W)
+    resg = nhwc(res).to(dev()).contiguous()
+    taps, tapsd = ops.Taps.get("conv", 3, 1), ops.Taps.get("dgrad1", 3, 1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    outs = {}
+    for mode in ("force", "off"):
+        ops.set_winograd_2x4(mode, nf=nf)
+        try:
+            kern = []
+            y = torch.full((B, H, W, cout), float("nan"), device=dev())
+            ops.conv_launch(xg, taps, cp.fwd(), y, cout, bias=cp.bias(), epi=Hh.EPI_RES_RELU, e0=resg)
+            kern.append(Hh.lib().ramnet_last_kernel().decode())
+            dx = torch.full((B, H, W, cin), float("nan"), device=dev())
+            if cin % 64 == 0:
+                ops.conv_launch(y, tapsd, cp.bwd(), dx, cin, xm=resg, in_mode=Hh.IN_RELUMASK)
+                kern.append(Hh.lib().ramnet_last_kernel().decode())
+                acc = xg.clone()
+                ops.conv_launch(y, tapsd, cp.bwd(), acc, cin, beta=1.0)
+                kern.append(Hh.lib().ramnet_last_kernel().decode())
+            else:
+                acc = None
+        finally:
+            ops.set_winograd_2x4("auto", nf=0)
+        assert all(k.startswith("conv_wino_r6_kernel" if mode == "force" else "conv_wino_r_kernel") for k in kern), kern
+        if mode == "force":
+            assert all(k.endswith(",%d>" % nf) for k in kern), kern
+        outs[mode] = (y, dx, acc)
+    yref = torch.relu(ref + res.double())
+    dy = torch.where(res > 0, yref, torch.zeros_like(yref))                     # the RELUMASK loader of the backward pass
+    dxref = F.conv_transpose2d(dy, w.double(), None, 1, 1)
+    accref = x.double() + F.conv_transpose2d(yref, w.double(), None, 1, 1)
+    for mode in ("force", "off"):
+        y, dx, acc = outs[mode]
+        assert_close(nchw(y).cpu().numpy(), yref.numpy(), TOL, "forward 2x4=%s" % mode)
+        if acc is not None:
+            assert_close(nchw(dx).cpu().numpy(), dxref.numpy(), TOL, "dgrad 2x4=%s" % mode)
+            assert_close(nchw(acc).cpu().numpy(), accref.numpy(), TOL, "dgrad beta 2x4=%s" % mode)
+    # rounding of F(2x4,3x3) in fp32 stays within a few ulp of F(2x2,3x3)
+    assert_close(outs["force"][0].cpu().numpy(), outs["off"][0].cpu().numpy(), 2e-5, "F(2x4) vs F(2x2)")
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2)])

@@ -30,7 +30,10 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=344)
     ap.add_argument("--only", default="")
+    ap.add_argument("--wino2x4", default="auto", help="auto | off | force[,nf[,min_wgs]]: F(2x4,3x3) selection (ops.set_winograd_2x4)")
     a = ap.parse_args()
+    w24 = a.wino2x4.split(",")
+    ops.set_winograd_2x4(w24[0], nf=int(w24[1]) if len(w24) > 1 else None, min_wgs=int(w24[2]) if len(w24) > 2 else None)
     dev = torch.device("cuda:0")
     B, Hh, Ww = a.batch, a.height, a.width
     # (name, kind, Cin(real), Cout, k, stride, Hin, Win)   kind: conv | up | gru_ur | gru_o | lstm
@@ -124,8 +127,10 @@ def main():
                 dy = torch.randn(B, Hin, Win, 4 * C, device=dev)
                 g = lambda: ops.wgrad_launch(x, taps, dy, ws, 4 * C, x1=h, in_mode=H.IN_CAT, C1=C, dbias=bws)  # noqa: E731
             d = lambda: ops.conv_launch(dy, tapsd, cp.bwd(), dx, 2 * C)  # noqa: E731
-        tf, td, tg = timeit(f, a.reps), timeit(d, a.reps), timeit(g, a.reps)
-        print("%-12s %8.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f" % (name, gfl, tf, gfl / tf, td, gfl / td, tg, gfl / tg))
+        tf = timeit(f, a.reps)
+        kf = H.lib().ramnet_last_kernel().decode()
+        td, tg = timeit(d, a.reps), timeit(g, a.reps)
+        print("%-12s %8.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f  %s" % (name, gfl, tf, gfl / tf, td, gfl / td, tg, gfl / tg, kf))
         if kind != "lstm":
             tot[0] += gfl
             tot[1] += tf
