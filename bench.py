@@ -64,6 +64,9 @@ def parse():
                     help="initialise the process group and run the bucketed gradient all-reduce even with ONE rank: executes the RCCL "
                          "init + side-stream collective path on a single-GPU box (tests/test_hip_model.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-infer-baseline", action="store_true",
+                    help="train mode: also time the CPU oracle's inference (B=8, no_grad, 1 warm + 3 timed packages, ~30 s) and print it as "
+                         "cpu_baseline_infer beside extras.stream_b1 (the infer / stream modes always print it as cpu_baseline)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-overlap-wgrad", dest="overlap_wgrad", action="store_false",
                     help="run backward-weights on the main stream instead of co-scheduling it with backward-data on a side stream "
@@ -79,6 +82,7 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, initialise the process group, let every rank report in over the collective backend, print the "
                          "JSON line (value null) and exit before any GPU work: the launch contract alone (CPU test)")
+    ap.add_argument("--wino2x4", default="auto", help="F(2x4,3x3) kernel selection for A/B runs: auto (library heuristics) | off | force")
     ap.add_argument("--graph", action="store_true",
                     help="train: the timed step replays ONE hipGraph (gradient zero-fill, forward, loss, BPTT backward, gradient fold; "
                          "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
@@ -302,15 +306,18 @@ def traffic_of(pmc, name):
     return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit.values()) / max(1, n)
 
 
-def cpu_baseline(cfg, H, W, K, args):
+def cpu_baseline(cfg, H, W, K, args, mode=None):
     """The oracle (CPU restatement, fixture-pinned to the reference) timed on this box's host cores on a bounded sample of the
-    same workload: one untimed warm-up step at B=1, L=1, then ONE full training step — forward, SI loss
-    on [image, events4], BPTT backward, Adam — at B=8, L=1 (one data package per sequence, an eighth of the L=8 step, which is linear in L:
-    ~25 s of CPU work on the 128 host cores, 40 s on a loaded box)."""
+    same workload.  One untimed warm-up at B=1, L=1 first.
+    train: ONE full training step — forward, SI loss on [image, events4], BPTT backward over the packages, Adam — at B=8, L=2
+    (two data packages per sequence: a quarter of the L=8 step, which is linear in L; ~50-60 s of CPU work on the 128 host cores).
+    infer / stream: forward under no_grad at B=8 with persistent state: 1 warm-up package, then 3 timed packages (BASELINE.md asks 3 + 5;
+    bounded to keep the run to minutes: a package-batch is ~5-8 s here)."""
     from oracle import ramnet_ref
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from recipe import make_item
     from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent
+    mode = mode or args.mode
     torch.manual_seed(0)
     with contextlib.redirect_stdout(sys.stderr):      # the constructor prints (like the reference's); stdout carries ONE JSON line
         m = ERGB2DepthRecurrent(cfg)
@@ -320,28 +327,38 @@ def cpu_baseline(cfg, H, W, K, args):
     cores = torch.get_num_threads()
     lc = cfg["loss_composition"]
 
-    def run(B, L):
+    def train_step(B, L):
         seq = [make_item(rng, B, H, W, K, cfg["num_bins_events"], 1, True, 0.0) for _ in range(L)]
         t0 = time.time()
-        if args.mode == "train":
-            opt.zero_grad()
-            total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
-            total.backward()
-            opt.step()
-        else:
-            with torch.no_grad():
-                prev, lstm = None, ramnet_ref.empty_states_lstm(K)
-                for item in seq:
-                    _, supers, lstm = ramnet_ref.forward_recurrent(sd, cfg, item, prev, lstm)
-                    prev = supers["image"]
+        opt.zero_grad()
+        total, _ = ramnet_ref.sequence_loss(sd, cfg, seq, lc, [1, 1])
+        total.backward()
+        opt.step()
         return time.time() - t0
 
-    warm = run(1, 1)
-    B, L = args.batch, 1
-    dt = run(B, L)
-    return {"value": B * L / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%s step (fwd, SI loss, BPTT bwd, Adam), B=%d L=%d K=%d %dx%d fp32 torch-CPU oracle, %.1f s after a %.1f s "
-                      "B=1 L=1 warm-up step" % (args.mode, B, L, K, H, W, dt, warm)}
+    def infer(B, warm, timed):
+        seq = [make_item(rng, B, H, W, K, cfg["num_bins_events"], 1, True, 0.0) for _ in range(warm + timed)]
+        with torch.no_grad():
+            prev, lstm = None, ramnet_ref.empty_states_lstm(K)
+            for i, item in enumerate(seq):
+                if i == warm:
+                    t0 = time.time()
+                _, supers, lstm = ramnet_ref.forward_recurrent(sd, cfg, item, prev, lstm)
+                prev = supers["image"]
+        return time.time() - t0
+
+    if mode == "train":
+        warm = train_step(1, 1)
+        B, L = args.batch, min(2, args.seq_len)
+        dt = train_step(B, L)
+        return {"value": B * L / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": "train step (fwd, SI loss, BPTT bwd, Adam), B=%d L=%d K=%d %dx%d fp32 torch-CPU oracle (own restatement, fixture-pinned "
+                          "to the reference), %.1f s after a %.1f s B=1 L=1 warm-up step" % (B, L, K, H, W, dt, warm)}
+    B, warm_n, timed_n = args.batch, 1, 3
+    dt = infer(B, warm_n, timed_n)
+    return {"value": B * timed_n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "inference (no_grad, persistent state), B=%d K=%d %dx%d fp32 torch-CPU oracle (own restatement, fixture-pinned to the "
+                      "reference): %d warm-up + %d timed packages, %.1f s" % (B, K, H, W, warm_n, timed_n, dt)}
 
 
 def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
@@ -593,6 +610,7 @@ def main():
     from rpg_ramnet_amd import ops, _hip as Hh
     ops.set_wgrad_overlap(args.overlap_wgrad)
     ops.set_decoder_overlap(args.overlap_decoder)
+    ops.set_winograd_2x4(args.wino2x4)
     K, bins, B, L, H, W = 5, args.bins, args.batch, args.seq_len, args.height, args.width
     cfg = dict(RELEASED, num_bins_events=bins, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)
@@ -947,6 +965,8 @@ def main():
                                                    "is low BECAUSE it is compute-bound (SURVEY 8d); mfma_frac = executed-MFMA fraction")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, H, W, K, args)
+            if args.cpu_infer_baseline and args.mode == "train":
+                out["cpu_baseline_infer"] = cpu_baseline(cfg, H, W, K, args, mode="infer")
         print(json.dumps(out))
     if world > 1 or args.force_collective:
         dist.destroy_process_group()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -155,6 +155,12 @@ int ramnet_gemm2(const float *A, const float *B, float *C, int M, long stride_a,
 /* ---- layout plumbing -------------------------------------------------------------------------- */
 /* NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] zero-padded (model inputs: model.py:177,200 `.to(self.gpu)`). */
 int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream);
+/* Full-frame mode: reflect-pad [B][C][H][W] to [Hc][Wc] with `top` rows above and `left` columns to the left (the rest below / right),
+ * torch.nn.ReflectionPad2d semantics — what utils/inference_utils.py:287-314 (CropParameters) does in front of the network for sizes
+ * that are not multiples of 2^num_encoders (260 x 346 -> 264 x 352).  nhwc = 1: written as the model's NHWC input with channels
+ * zero-padded to Cpad (the repack of ramnet_nchw_to_nhwc_pad fused in); nhwc = 0: NCHW (Cpad ignored).                        */
+int ramnet_reflect_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, int top, int left, int Hc, int Wc, int nhwc,
+                       void *stream);
 /* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
 size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
 /* Winograd F(2x2,3x3) weights U = G g G^T of a 3x3 conv in the lane order of the kernel's B operand
@@ -169,7 +175,7 @@ int ramnet_pack_weight_wino2x4(const float *w_oihw, float *wp, int Cout, int Cin
 /* 1 when a launch that qualifies for RAMNET_ALGO_WINOGRAD (d->algo set so, every other field final) runs faster as
  * RAMNET_ALGO_WINOGRAD_2X4 — the caller then sets d->algo and d->w (ramnet_pack_weight_wino2x4) accordingly; else 0.              */
 int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force);   /* force: skip the size heuristics (tests) */
-/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel workgroups a launch must have (default 512;
+/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel workgroups a launch must have (default 320;
  * < 0 keeps the current value); nf = 1 / 2 forces 32- / 64-channel workgroups, 0 = the launcher's choice (< 0 keeps).              */
 int ramnet_wino2x4_config(int min_wgs, int nf);
 /* Folded upsample-conv (RAMNET_ALGO_WINOGRAD24): OIHW 5x5 weights of an UpsampleConvLayer (submodules.py:69-97) -> Winograd-domain
@@ -304,6 +310,19 @@ int ramnet_si_loss_from_stats(const double *stats, float weight, float lambda, f
 /* dpred = gscale * w * (2 d/n - 2 lambda mean/n) on valid pixels, 0 elsewhere (gscale: device scalar). */
 int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float weight, float lambda,
                        const double *stats, const float *gscale, float *dpred, void *stream);
+
+/* scale_invariant_log_loss (model/loss.py:12-15): the same statistic on d = log(pred) - log(target) (no weight argument in the reference).
+ * stats: 4 doubles as above (zeroed here).                                                                             */
+int ramnet_si_log_loss_fwd(const float *pred, const float *target, size_t n, float lambda, double *stats, float *loss, void *stream);
+int ramnet_si_log_loss_bwd(const float *pred, const float *target, size_t n, float lambda, const double *stats, const float *gscale,
+                           float *dpred, void *stream);
+/* mse_loss (model/loss.py:18-19) as the trainer's extra term uses it (lstm_trainer.py:169-185): mean squared error over the non-NaN
+ * TARGET entries of [B][H][W] maps; half = 1: both maps first go through F.interpolate(scale_factor=0.5, 'bilinear', align_corners=False)
+ * (2 x 2 block means; a NaN in a target block masks the cell; odd trailing rows / columns are dropped).  stats: 4 doubles
+ * ([0] = sum d^2, [1] = count, zeroed here); dpred [B][H][W] = gscale * d loss / d pred (every element written).            */
+int ramnet_mse_loss_fwd(const float *pred, const float *target, int B, int H, int W, int half, double *stats, float *loss, void *stream);
+int ramnet_mse_loss_bwd(const float *pred, const float *target, int B, int H, int W, int half, const double *stats, const float *gscale,
+                        float *dpred, void *stream);
 
 /* ---- depth post-processing + error sums: evaluation.py:74-96, :201-241; model/metric.py:8-33 --------------
  * pred/target: normalised log depth; mask = nan_to_num(metric target) < cutoff (evaluation.py:367).  out11 (zeroed here):

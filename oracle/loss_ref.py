@@ -2,7 +2,9 @@
 
 Reference (relative to /root/reference/RAM_Net):
   * scale_invariant_loss ....... model/loss.py:6-9     (pinned by golden vectors)
+  * scale_invariant_log_loss ... model/loss.py:12-15   (pinned: tests/golden/loss_extra.npz)
   * mse_loss ................... model/loss.py:18-19    (pinned)
+  * trainer loss assembly with the half-resolution mse term ... trainer/lstm_trainer.py:152-226 (pinned: loss_extra.npz)
   * MultiScaleGradient ......... model/loss.py:22-70   (PARITY UNPINNED, see below)
   * abs_rel_diff & friends ..... model/metric.py:8-33  (pinned)
   * prepare_depth_data ......... evaluation.py:74-96   (pinned)
@@ -32,6 +34,33 @@ def si_loss_grad(y_input, y_target, weight=1.0, n_lambda=1.0):
 def mse_loss(y_input, y_target):
     m = ~torch.isnan(y_target)
     return F.mse_loss(y_input[m], y_target[m])
+
+
+def scale_invariant_log_loss(y_input, y_target, n_lambda=1.0):
+    """model/loss.py:12-15: the scale-invariant statistic on d = log(input) - log(target), NaN entries of d dropped."""
+    d = torch.log(y_input) - torch.log(y_target)
+    d = d[~torch.isnan(d)]
+    return (d * d).mean() - n_lambda * d.mean() ** 2
+
+
+def mse_loss_downsampled(y_input, y_target, downsampling_factor=0.5):
+    """The trainer's mse term (lstm_trainer.py:169-185): both maps through F.interpolate(bilinear, align_corners=False,
+    recompute_scale_factor=False) when the factor is not 1, then mse_loss over the non-NaN target entries."""
+    if downsampling_factor != 1.0:
+        y_target = F.interpolate(y_target, scale_factor=downsampling_factor, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+        y_input = F.interpolate(y_input, scale_factor=downsampling_factor, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+    return mse_loss(y_input, y_target)
+
+
+def total_batch_loss(preds, targets, weights, L, loss="scale_invariant_loss", loss_params=None, mse=None):
+    """calculate_losses + calculate_total_batch_loss (lstm_trainer.py:152-226) for ONE supervised key: `preds` / `targets` / `weights`
+    list the L*terms supervised maps; loss = sum(w * nominal) / L [+ mse_weight * sum(w * mse_ds) / L]."""
+    fn = {"scale_invariant_loss": scale_invariant_loss, "scale_invariant_log_loss": scale_invariant_log_loss, "mse_loss": mse_loss}[loss]
+    total = sum(w * fn(p, t, **(loss_params or {})) for p, t, w in zip(preds, targets, weights)) / float(L)
+    if mse is not None:
+        total = total + mse.get("weight", 1.0) * sum(w * mse_loss_downsampled(p, t, mse.get("downsampling_factor", 0.5))
+                                                     for p, t, w in zip(preds, targets, weights)) / float(L)
+    return total
 
 
 def spatial_gradient(x):

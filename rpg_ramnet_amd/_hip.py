@@ -64,6 +64,7 @@ _SIGS = {
     "ramnet_gemm2": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, _fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "ramnet_reflect_pad": (C.c_int, [_fp, _fp] + [C.c_int] * 10 + [_fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 4),
@@ -114,6 +115,10 @@ _SIGS = {
     "ramnet_si_loss_fwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp]),
     "ramnet_si_loss_from_stats": (C.c_int, [_fp, C.c_float, C.c_float, _fp, _fp]),
     "ramnet_si_loss_bwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, _fp, _fp, _fp, _fp]),
+    "ramnet_si_log_loss_fwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, _fp, _fp, _fp]),
+    "ramnet_si_log_loss_bwd": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, _fp, _fp, _fp, _fp]),
+    "ramnet_mse_loss_fwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "ramnet_mse_loss_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ramnet_depth_metrics": (C.c_int, [_fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "ramnet_msg_workspace_elems": (C.c_size_t, [C.c_int] * 4),
     "ramnet_msg_loss_fwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),

@@ -13,6 +13,9 @@ OBJ = os.path.join(PKG, "build")
 HEADER = os.path.join(PKG, "..", "include", "ramnet_hip.h")
 LIB = os.path.join(PKG, "librpg_ramnet_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# per-file additions.  conv_wino6.hip: its main loop places single scalar fp32 operations between MFMAs by hand; the SLP vectoriser
+# pairs neighbours into 2-wide vectors that the backend scalarises again through v_mov shuffles (4 moves per 2 v_fma)
+EXTRA_FLAGS = {"conv_wino6.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -26,7 +29,7 @@ def _headers_mtime():
 
 def _compile(hipcc, src, obj, verbose):
     tmp = "%s.%d.tmp" % (obj, os.getpid())        # concurrent build() calls must not see each other's half-written objects
-    cmd = [hipcc] + FLAGS + ["-c", src, "-o", tmp]
+    cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", tmp]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

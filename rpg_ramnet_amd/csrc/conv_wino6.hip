@@ -31,9 +31,16 @@ constexpr int W6_BN = 64;                        // output channels per 64-chann
 constexpr int W6_U_FLOATS = 24 * W6_BN * WK;     // weights of one (chunk, 64-channel block): 24 positions x 64 x 8 = 48 KB
 
 // TXG = tiles per workgroup row: 4 (16 x 16 output pixels), 2 (32 rows x 8 columns) or 8 (8 x 32)
+// LDS layout of a patch plane: pixel (py, px) at slot py * PWS + px + ((py >> 1) & 3), PWS = PW + 3.  A lane reads the 16 bytes of pixel
+// (2 tty + r, 4 ttx + j) of its tile; ds_read_b128 serves 16 lanes per cycle ({0-3, 12-15, 20-27}, ...) from 64 banks, and with the dense
+// layout all 16 fall on the same 16 banks (4-way conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.65, the LDS pipe ~60 % busy).
+// The skew makes the low two bits of the slot index differ between the four tile rows of every lane group and the tile column supplies
+// the next two: conflict-free for the three tile shapes (brute-forced over all rows, columns and lane groups).  Planes are padded to
+// 4 mod 8 slots so that the two quads of a 16-byte store land on different banks.
 template <int TXG> struct R6Geom {
-    static constexpr int TYG = 32 / TXG, TH = 2 * TYG, TW = 4 * TXG, PH = TH + 2, PW = TW + 2;
-    static constexpr int PLANE = PH * PW * 4;    // floats of one channel-quad plane of the patch
+    static constexpr int TYG = 32 / TXG, TH = 2 * TYG, TW = 4 * TXG, PH = TH + 2, PW = TW + 2, PWS = PW + 3;
+    static constexpr int PSLOTS = PH * PWS + ((4 - (PH * PWS) % 8) + 8) % 8;
+    static constexpr int PLANE = PSLOTS * 4;     // floats of one channel-quad plane of the patch
     static constexpr int PFLOATS = 2 * PLANE;
     static_assert(PH * PW * 2 <= 768, "three patch slots per thread");
 };
@@ -42,7 +49,7 @@ template <int TXG, int MODE, int NF>
 __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(const ramnet_conv_desc p, const WinoParams q) {
     constexpr int RO_LD = NF * 32 + 4;           // row of the exchange buffer [wave 4][column 4][tile 32][channels + pad]
     using G = R6Geom<TXG>;
-    constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PW, RTW = G::TW;
+    constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PWS, RTW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *patch = smem;                         // [2 buffers][2 quads][PH x PW pixels][4] + 256 scratch cells; the epilogue reuses the space
 
@@ -70,11 +77,9 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
-    const int pra = hq * RP_PLANE + ((2 * tty + ra) * RPW + 4 * ttx) * 4;
-    const int prb = hq * RP_PLANE + ((2 * tty + rb) * RPW + 4 * ttx) * 4;
+    const int pra = hq * RP_PLANE + ((2 * tty + ra) * RPW + 4 * ttx + (((2 * tty + ra) >> 1) & 3)) * 4;
+    const int prb = hq * RP_PLANE + ((2 * tty + rb) * RPW + 4 * ttx + (((2 * tty + rb) >> 1) & 3)) * 4;
     // weights: [chunk][block64][wave 4][position-in-row 6][n-block 2][lane 64][channel j 4]
-    const float *wsrc = p.w + (size_t)nblk_i * W6_U_FLOATS + wave * 3072 + fh * 256 + lane * 4;
-    const size_t wchunk = (size_t)q.nblk * W6_U_FLOATS;
 
     f32x16 acc[6][NF];
 #pragma unroll
@@ -87,75 +92,141 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
     const int nch = q.nchunks;
     const int clast = (nch - 1) * WK;
     WinoPatch<MODE, 3> pr;
-    pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid, clast, 2 * RP_FLOATS);
+    pr.template init<G::PH, G::PW, G::PWS, G::PLANE, true>(q.src, b, iy0, ix0, tid, clast, 2 * RP_FLOATS);
+    // weights: buffer loads with the chunk / position offset in a scalar register (no per-load address arithmetic on the vector side)
+    const auto wrs = wino_rsrc(p.w, (unsigned)((size_t)nch * q.nblk * W6_U_FLOATS * sizeof(float)));
+    const unsigned wvo = (unsigned)((wave * 3072 + fh * 256 + lane * 4) * 4);
+    const int wblk = nblk_i * W6_U_FLOATS * 4, wchunk = q.nblk * W6_U_FLOATS * 4;      // bytes
+    auto wload = [&](int chunk, int i) {             // B operands (position i >> 1, n-block i & 1) of `chunk`
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wvo, chunk * wchunk + wblk + i * 1024, 0));
+    };
     float4 breg[6][NF];
-    float4 tcur[6], tnext[6], ta, tb;
-    auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
-    // x + s * y on channel quads (one v_fma per channel)
-    auto fma4 = [](float s, float4 y, float4 x) { return make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w); };
-    auto sub4 = [](float4 x, float4 y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
+    float tA[6][4], tB[6][4];                        // row `wave` of B2^T d for the chunk in flight / the next one: [column][channel]
+    // A operands (4 channels = 4 K steps) of the positions in flight and the next ones: a ring of 4.  LD = how many positions ahead
+    // the column transform runs: consecutive MFMAs of a wave must go to DIFFERENT accumulators (an instruction between two MFMAs on the
+    // same accumulator costs ~43 cycles, MI355X_MICROARCH.md) — with two n-blocks (NF = 2) a position alternates its two accumulators;
+    // with one (NF = 1) the positions are taken in PAIRS (p, p + 1) alternating, so two positions' operands are live at a time.
+    constexpr int LD = NF == 2 ? 1 : 2;
+    float vb[4][4];
+    float4 qa[6], qb[6];
+    float sa[4], sd[4];                              // shared sub-expressions of positions (1, 2) and (3, 4)
+    // one slice (i = 0..7) of the column transform B4 of position q from the row t: <= 2 channels per slice
+    //   B4^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+    // (vi = ring slot of the position: (q + 2 * chunk parity) & 3 — six positions do not divide the ring of four, so the slots of
+    // consecutive chunks are shifted by two: the next chunk's first positions never land on the ones the last MFMAs still read)
+    auto colop = [&](int qp, int vi, int i, const float (&t)[6][4]) {
+        float(&v)[4] = vb[vi];
+        if (qp == 0) {
+            if (i < 4) v[i] = fmaf(-5.f, t[2][i], t[4][i]);
+            else v[i - 4] = fmaf(4.f, t[0][i - 4], v[i - 4]);
+        } else if (qp == 1) {
+            if (i < 2) sa[2 * i] = fmaf(-4.f, t[2][2 * i], t[4][2 * i]), sa[2 * i + 1] = fmaf(-4.f, t[2][2 * i + 1], t[4][2 * i + 1]);
+            else if (i < 4) sd[2 * i - 4] = fmaf(-4.f, t[1][2 * i - 4], t[3][2 * i - 4]), sd[2 * i - 3] = fmaf(-4.f, t[1][2 * i - 3], t[3][2 * i - 3]);
+            else v[i - 4] = sa[i - 4] + sd[i - 4];
+        } else if (qp == 2) {
+            if (i >= 4) v[i - 4] = sa[i - 4] - sd[i - 4];
+        } else if (qp == 3) {
+            if (i < 2) sa[2 * i] = t[4][2 * i] - t[2][2 * i], sa[2 * i + 1] = t[4][2 * i + 1] - t[2][2 * i + 1];
+            else if (i < 4) sd[2 * i - 4] = t[3][2 * i - 4] - t[1][2 * i - 4], sd[2 * i - 3] = t[3][2 * i - 3] - t[1][2 * i - 3];
+            else v[i - 4] = fmaf(2.f, sd[i - 4], sa[i - 4]);
+        } else if (qp == 4) {
+            if (i >= 4) v[i - 4] = fmaf(-2.f, sd[i - 4], sa[i - 4]);
+        } else {
+            if (i < 4) v[i] = fmaf(-5.f, t[3][i], t[5][i]);
+            else v[i - 4] = fmaf(4.f, t[1][i - 4], v[i - 4]);
+        }
+    };
 
     pr.load(q.src, 0, clast);
 #pragma unroll
     for (int i = 0; i < 12; ++i)
-        if (NF == 2 || !(i & 1)) breg[i >> 1][NF == 2 ? i & 1 : 0] = ld4(wsrc + i * 256);
+        if (NF == 2 || !(i & 1)) breg[i >> 1][NF == 2 ? i & 1 : 0] = wload(0, i);
     pr.store(patch, q.src, 0);
     pr.load(q.src, min(WK, clast), clast);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 6; ++c) tcur[c] = te(ld4(patch + pra + c * 4), ld4(patch + prb + c * 4));
+    for (int c = 0; c < 6; ++c) {
+        const float4 x = ld4(patch + pra + c * 4), y = ld4(patch + prb + c * 4);
+        tA[c][0] = x.x + sb * y.x, tA[c][1] = x.y + sb * y.y, tA[c][2] = x.z + sb * y.z, tA[c][3] = x.w + sb * y.w;
+    }
+#pragma unroll
+    for (int qp = 0; qp < LD; ++qp)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) colop(qp, qp, i, tA);
     pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
     pr.load(q.src, min(2 * WK, clast), clast);
     __syncthreads();
-    // one chunk: MFMAs on the row in `tc` (column transform B4 in registers, position by position), while the row of the next chunk
-    // is read and combined into `tn` and the patch of chunk + 2 / + 3 is stored / requested — one slice behind every MFMA
-    auto body = [&](int chunk, const float4 (&tc)[6], float4 (&tn)[6]) {
+    // One chunk = 6 positions x 4 K steps x NF n-blocks of MFMAs.  Everything else of the chunk is cut into 48 SLOTS, one behind every
+    // MFMA (NF = 2) or two (NF = 1), each a handful of instructions — a wave that is alone on its SIMD (NF = 2) has nobody to fill the
+    // pipe while it issues a block of 12 VALU, so no gap carries more than ~4:
+    //   slots  0..11   LDS reads of the NEXT chunk's two window rows (column j = slot >> 1)
+    //   slots  4..27   their combination t[j][c] = d[ra][j][c] + sb * d[rb][j][c], one channel per slot
+    //   slots 8g..8g+7 the column transform of position g + LD (positions 0 .. LD-1 of the NEXT chunk for g + LD >= 6)
+    //   slots 28..30   patch of chunk + 2 (registers -> LDS), slots 33 / 35 / 37: request the patch of chunk + 3
+    //   behind the last MFMA that reads them: the B operands of the same positions for the next chunk
+    auto body = [&](auto par, int chunk, const float (&tc)[6][4], float (&tn)[6][4]) {
+        constexpr int PAR = decltype(par)::value;    // chunk & 1 as a compile-time constant: the two instantiations alternate
         const float *pnext = patch + ((chunk + 1) & 1) * RP_FLOATS;     // patch(i+1)
         float *pfree = patch + (chunk & 1) * RP_FLOATS;                 // patch(i), consumed during chunk i-1 -> patch(i+2)
-        const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
+        const int cw = min(chunk + 1, nch - 1);
         const int c2 = min((chunk + 2) * WK, clast), c3 = min((chunk + 3) * WK, clast);
-        auto side = [&](int k) {                    // compile-time constant after unrolling
-            if (k < 12) {
-                if (!(k & 1)) ta = ld4(pnext + pra + (k >> 1) * 4), tb = ld4(pnext + prb + (k >> 1) * 4);
-                else tn[k >> 1] = te(ta, tb);
-            } else if (k < 15) pr.store_slot(pfree, q.src, c2, k - 12);
-            else if (k < 18) pr.load_slot(q.src, c3, k - 15, clast);
+        auto slot = [&](int s) {                     // compile-time constant after unrolling
+            const int g = s >> 3, i = s & 7;
+            if (s < 12) {
+                if (!(s & 1)) qa[s >> 1] = ld4(pnext + pra + (s >> 1) * 4);
+                else qb[s >> 1] = ld4(pnext + prb + (s >> 1) * 4);
+            }
+            if (s >= 4 && s < 28) {
+                const int j = (s - 4) >> 2, c = (s - 4) & 3;
+                const float x = c == 0 ? qa[j].x : c == 1 ? qa[j].y : c == 2 ? qa[j].z : qa[j].w;
+                const float y = c == 0 ? qb[j].x : c == 1 ? qb[j].y : c == 2 ? qb[j].z : qb[j].w;
+                tn[j][c] = fmaf(sb, y, x);
+                asm volatile("" : "+v"(tn[j][c]));  // (a use at this point: the compiler otherwise sinks the row into the next chunk's code)
+            }
+            if (g + LD < 6) colop(g + LD, (g + LD + 2 * PAR) & 3, i, tc);
+            else colop(g + LD - 6, (g + LD - 6 + 2 * (PAR ^ 1)) & 3, i, tn);
+            if (s >= 28 && s < 31) pr.store_slot(pfree, q.src, c2, s - 28);
+            if (s == 33 || s == 35 || s == 37) pr.load_slot(q.src, c3, (s - 33) >> 1, clast);
+            if (NF == 2 && i == 7) breg[g][0] = wload(cw, g * 2), breg[g][NF - 1] = wload(cw, g * 2 + 1);
+            if (NF == 1 && (s & 15) == 15) breg[g - 1][0] = wload(cw, (g - 1) * 2), breg[g][0] = wload(cw, g * 2);
         };
-        float4 s0, s1;                               // shared sub-expressions of positions (1, 2) and (3, 4)
+        if (NF == 2) {
 #pragma unroll
-        for (int pl = 0; pl < 6; ++pl) {
-            // B4^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-            float4 v;
-            if (pl == 0) v = fma4(4.f, tc[0], fma4(-5.f, tc[2], tc[4]));
-            else if (pl == 1) s0 = fma4(-4.f, tc[2], tc[4]), s1 = fma4(-4.f, tc[1], tc[3]), v = f4add(s0, s1);
-            else if (pl == 2) v = sub4(s0, s1);
-            else if (pl == 3) s0 = sub4(tc[4], tc[2]), s1 = sub4(tc[3], tc[1]), v = fma4(2.f, s1, s0);
-            else if (pl == 4) v = fma4(-2.f, s1, s0);
-            else v = fma4(4.f, tc[1], fma4(-5.f, tc[3], tc[5]));
-            const float va[4] = {v.x, v.y, v.z, v.w};
-            const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
-            const float b1[4] = {breg[pl][NF - 1].x, breg[pl][NF - 1].y, breg[pl][NF - 1].z, breg[pl][NF - 1].w};
+            for (int pl = 0; pl < 6; ++pl) {
+                const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
+                const float b1[4] = {breg[pl][NF - 1].x, breg[pl][NF - 1].y, breg[pl][NF - 1].z, breg[pl][NF - 1].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __builtin_amdgcn_sched_barrier(0);
-                acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b0[j], acc[pl][0], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (NF == 2) {
-                    // 48 gaps, 18 slices: one behind each of the first 18 MFMA pairs' halves is too dense for the LDS reads'
-                    // latency — spread them: a slice behind every MFMA of positions 0 .. 2 (24 gaps), positions 3 .. 5 carry none
-                    if (pl < 3) side(pl * 8 + j * 2);
+                for (int j = 0; j < 4; ++j) {
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[pl][NF - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j], b1[j], acc[pl][NF - 1], 0, 0, 0);
+                    acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(pl + 2 * PAR) & 3][j], b0[j], acc[pl][0], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (pl < 3) side(pl * 8 + j * 2 + 1);
-                } else {
-                    side(pl * 4 + j);                // 24 gaps per chunk for the 18 slices
+                    slot(pl * 8 + j * 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[pl][NF - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(pl + 2 * PAR) & 3][j], b1[j], acc[pl][NF - 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    slot(pl * 8 + j * 2 + 1);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            breg[pl][0] = ld4(wnext + (pl * 2) * 256);
-            if (NF == 2) breg[pl][NF - 1] = ld4(wnext + (pl * 2 + 1) * 256);
+        } else {
+#pragma unroll
+            for (int gp = 0; gp < 3; ++gp) {
+                const int p0 = 2 * gp, p1 = 2 * gp + 1;
+                const float b0[4] = {breg[p0][0].x, breg[p0][0].y, breg[p0][0].z, breg[p0][0].w};
+                const float b1[4] = {breg[p1][0].x, breg[p1][0].y, breg[p1][0].z, breg[p1][0].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[p0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p0 + 2 * PAR) & 3][j], b0[j], acc[p0][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    slot(gp * 16 + j * 4), slot(gp * 16 + j * 4 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[p1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p1 + 2 * PAR) & 3][j], b1[j], acc[p1][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    slot(gp * 16 + j * 4 + 2), slot(gp * 16 + j * 4 + 3);
+                }
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                           // patch(i+2) visible; patch(i+1) free
     };
     // (do-while: nch >= 1.  A `for` loop leaves a path around the loop on which the exchange below would read the zero-initialised
@@ -163,8 +234,8 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
     // own addresses: 256 VGPRs + 29-85 scratch reloads with `s_waitcnt vmcnt(0)` per chunk, against 197 VGPRs and none this way)
     int chunk = 0;
     do {
-        body(chunk, tcur, tnext);
-        if (chunk + 1 < nch) body(chunk + 1, tnext, tcur);      // (uniform over the workgroup)
+        body(std::integral_constant<int, 0>{}, chunk, tA, tB);
+        if (chunk + 1 < nch) body(std::integral_constant<int, 1>{}, chunk + 1, tB, tA);      // (uniform over the workgroup)
         chunk += 2;
     } while (chunk < nch);
 
@@ -315,7 +386,7 @@ static bool wino6_vec4(const ramnet_conv_desc &d) {
 // Does this WINOGRAD-eligible launch run F(2x4,3x3)?  Dense 3x3 layers with plain / concatenated / masked inputs and the channel-quad
 // epilogues (no ConvLSTM cell, no space-to-depth view), 64-channel output blocks, on maps where (a) the 2 x 4 tiling wastes less than
 // a quarter of what it saves and (b) the launch still fills the chip with 64-channel workgroups at ONE per CU.
-static int g_w6_min_wgs = 512, g_w6_nf = 0;     // ramnet_wino2x4_config(): launch-size threshold, forced NF (0 = by launch size)
+static int g_w6_min_wgs = 320, g_w6_nf = 0;     // ramnet_wino2x4_config(): launch-size threshold, forced NF (0 = by launch size)
 
 int wino6_eligible(const ramnet_conv_desc &d, int force) {
     if (d.ntaps != 9 || d.stride != 1 || d.s2d_5x5 || d.out_s2d || d.frame) return 0;
@@ -365,7 +436,7 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
     q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
-    const int nf = g_w6_nf == 1 ? 1 : 2;                            // 32-channel workgroups (two per CU) on request only
+    const int nf = g_w6_nf == 2 ? 2 : 1;                            // 64-channel workgroups (one per CU: exposed prologue / epilogue) on request only
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
     const size_t ex = (size_t)4 * 4 * 32 * (nf * 32 + 4) * sizeof(float);
     {

@@ -35,7 +35,9 @@ struct WinoPatch {
     decltype(wino_rsrc(nullptr, 0u)) r0, r1, rm;
 
     // LDS patch layout: [channel quad 2][PH x PW pixels][4]; scratch = float offset of 256 spare 16-byte cells
-    template <int PH, int PW>
+    // PWS / PLANE / SKEW: row pitch in pixels, floats per quad plane, and a per-row column skew of ((row >> 1) & 3) pixels — the
+    // bank-conflict-free layout of conv_wino6.hip (defaults: the dense layout of conv_wino.hip)
+    template <int PH, int PW, int PWS = PW, int PLANE = PH * PW * 4, bool SKEW = false>
     __device__ __forceinline__ void init(const InSrc &s, int b, int iy0, int ix0, int tid, int clast, int scratch) {
         const bool s2d = MODE == RAMNET_IN_S2D;
         const size_t img = (size_t)(s2d ? 4 : 1) * s.Hin * s.Win;      // pixels of one image as stored
@@ -58,7 +60,7 @@ struct WinoPatch {
             vo1[i] = in ? (gp * s.ld1 + qd * 4) * 4u : WOOB;
             vom[i] = in ? (gp * s.ldm + qd * 4) * 4u : WOOB;
             bad[i] = clast + qd * 4 < s.Cin ? 0u : WOOB;
-            ldst[i] = slot ? qd * (PH * PW * 4) + pix * 4 : scratch + tid * 4;
+            ldst[i] = slot ? qd * PLANE + (py * PWS + px + (SKEW ? ((py >> 1) & 3) : 0)) * 4 : scratch + tid * 4;
         }
     }
     static __device__ __forceinline__ float4 bload(decltype(wino_rsrc(nullptr, 0u)) r, unsigned vo, int so) {

@@ -19,10 +19,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+template <bool LOG> __device__ __forceinline__ float si_diff(float p, float t) { return LOG ? logf(p) - logf(t) : p - t; }
+
 // stats[0] += sum d, stats[1] += sum d^2, stats[2] += count over non-NaN d = pred - target; stats[3] = arrival ticket: the LAST
 // workgroup to arrive reads the three sums back and writes the loss (model/loss.py:6-9) — one launch instead of statistics +
 // finalize.  At most 256 workgroups of 16-byte loads: the three double atomics per workgroup all hit the same three addresses
 // (~12 ns each, serialised), which is what the 2048-workgroup version spent its 27 us on.
+// LOG: scale_invariant_log_loss (model/loss.py:12-15): d = log(pred) - log(target) instead of pred - target
+template <bool LOG>
 __global__ void __launch_bounds__(1024) si_stats_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight, float lambda,
                                 double *stats, float *loss) {
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
@@ -37,9 +41,9 @@ __global__ void __launch_bounds__(1024) si_stats_kernel(const float *__restrict_
     const size_t n4 = vec ? n / 4 : 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 p = ld4(pred + 4 * i), t = ld4(target + 4 * i);
-        acc(p.x - t.x), acc(p.y - t.y), acc(p.z - t.z), acc(p.w - t.w);
+        acc(si_diff<LOG>(p.x, t.x)), acc(si_diff<LOG>(p.y, t.y)), acc(si_diff<LOG>(p.z, t.z)), acc(si_diff<LOG>(p.w, t.w));
     }
-    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc(pred[i] - target[i]);
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc(si_diff<LOG>(pred[i], target[i]));
     __shared__ double red[3][16];
     s1 = wave_sum(s1), s2 = wave_sum(s2), cnt = wave_sum(cnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -65,6 +69,7 @@ __global__ void __launch_bounds__(1024) si_stats_kernel(const float *__restrict_
 // The same statistics without the zero-fill launch and without contended atomics: every workgroup stores its three partial sums to
 // part[workgroup][3] (a scratch owned by the library, one per device and stream), the LAST one to arrive — a self-resetting ticket behind
 // the partials — adds them in a fixed order with all its threads and writes stats[0..2] and the loss.  One launch, bit-reproducible.
+template <bool LOG>
 __global__ void __launch_bounds__(1024) si_stats_fold_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight,
                                                             float lambda, double *stats, float *loss, double *part, unsigned long long *ticket) {
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
@@ -79,9 +84,9 @@ __global__ void __launch_bounds__(1024) si_stats_fold_kernel(const float *__rest
     const size_t n4 = vec ? n / 4 : 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 p = ld4(pred + 4 * i), t = ld4(target + 4 * i);
-        acc(p.x - t.x), acc(p.y - t.y), acc(p.z - t.z), acc(p.w - t.w);
+        acc(si_diff<LOG>(p.x, t.x)), acc(si_diff<LOG>(p.y, t.y)), acc(si_diff<LOG>(p.z, t.z)), acc(si_diff<LOG>(p.w, t.w));
     }
-    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc(pred[i] - target[i]);
+    for (size_t i = 4 * n4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc(si_diff<LOG>(pred[i], target[i]));
     __shared__ double red[3][16];
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -127,6 +132,7 @@ __global__ void si_from_stats_kernel(const double *__restrict__ stats, float wei
     *loss = (float)((double)weight * (stats[1] / stats[2] - (double)lambda * m * m));
 }
 
+template <bool LOG>
 __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ target, size_t n, float weight, float lambda,
                               const double *__restrict__ stats, const float *__restrict__ gscale, float *__restrict__ dpred) {
     // d - lambda*mean is formed in double: rounding the mean to fp32 would add the SAME offset to every pixel, and
@@ -134,8 +140,72 @@ __global__ void si_bwd_kernel(const float *__restrict__ pred, const float *__res
     const double cnt = stats[2], mean = stats[0] / cnt;
     const double s2 = 2.0 * (double)((gscale ? *gscale : 1.0f) * weight) / cnt;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = pred[i] - target[i];
-        dpred[i] = (d == d) ? (float)(s2 * ((double)d - (double)lambda * mean)) : 0.f;
+        const float d = si_diff<LOG>(pred[i], target[i]);
+        const double g = s2 * ((double)d - (double)lambda * mean);
+        dpred[i] = (d == d) ? (float)(LOG ? g / (double)pred[i] : g) : 0.f;      // (LOG: d log(pred) / d pred)
+    }
+}
+
+// mse_loss (model/loss.py:18-19) of the trainer's extra term (lstm_trainer.py:169-185): F.mse_loss over the non-NaN TARGET entries, at full
+// resolution (HALF = false) or after F.interpolate(scale_factor=0.5, mode='bilinear', align_corners=False) of both maps (HALF: output cell
+// (i, j) = the mean of the 2 x 2 block at (2i, 2j), evaluated in torch's order of operations; a NaN anywhere in the target block makes the
+// cell NaN, i.e. masked; an odd trailing row / column is dropped).  stats[0] = sum d^2, stats[1] = count, stats[3] = arrival ticket.
+template <bool HALF> __device__ __forceinline__ float mse_cell(const float *__restrict__ m, int W, int y, int x) {
+    if (!HALF) return m[(size_t)y * W + x];
+    const float *r0 = m + (size_t)(2 * y) * W + 2 * x, *r1 = r0 + W;
+    return 0.5f * (0.5f * r0[0] + 0.5f * r0[1]) + 0.5f * (0.5f * r1[0] + 0.5f * r1[1]);
+}
+
+template <bool HALF>
+__global__ void __launch_bounds__(1024) mse_stats_kernel(const float *__restrict__ pred, const float *__restrict__ target, int B, int H, int W,
+                                                        double *stats, float *loss) {
+    const int Ho = HALF ? H / 2 : H, Wo = HALF ? W / 2 : W;
+    const size_t n = (size_t)B * Ho * Wo;
+    double s2 = 0.0, cnt = 0.0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+        const size_t b = i / ((size_t)Wo * Ho);
+        const float t = mse_cell<HALF>(target + b * H * W, W, y, x);
+        if (t == t) {
+            const float d = mse_cell<HALF>(pred + b * H * W, W, y, x) - t;
+            s2 += (double)d * (double)d, cnt += 1.0;
+        }
+    }
+    __shared__ double red[2][16];
+    s2 = wave_sum(s2), cnt = wave_sum(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) red[0][wave] = s2, red[1][wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, c = 0.0;
+        for (int w = 0; w < nw; ++w) a += red[0][w], c += red[1][w];
+        atomicAdd(stats + 0, a), atomicAdd(stats + 1, c);
+        __threadfence();
+        const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long *>(stats + 3), 1ull);
+        if (ticket == (unsigned long long)gridDim.x - 1) {
+            __threadfence();
+            const double S = atomicAdd(stats + 0, 0.0), N = atomicAdd(stats + 1, 0.0);
+            *loss = (float)(S / N);
+        }
+    }
+}
+
+template <bool HALF>
+__global__ void mse_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ target, int B, int H, int W,
+                               const double *__restrict__ stats, const float *__restrict__ gscale, float *__restrict__ dpred) {
+    const int Ho = HALF ? H / 2 : H, Wo = HALF ? W / 2 : W;
+    const size_t n = (size_t)B * H * W;
+    const double s = 2.0 * (double)(gscale ? *gscale : 1.0f) / stats[1] * (HALF ? 0.25 : 1.0);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const size_t b = i / ((size_t)W * H);
+        const int cy = HALF ? y >> 1 : y, cx = HALF ? x >> 1 : x;
+        float g = 0.f;
+        if (cy < Ho && cx < Wo) {
+            const float t = mse_cell<HALF>(target + b * H * W, W, cy, cx);
+            if (t == t) g = (float)(s * (double)(mse_cell<HALF>(pred + b * H * W, W, cy, cx) - t));
+        }
+        dpred[i] = g;
     }
 }
 
@@ -755,13 +825,55 @@ extern "C" int ramnet_si_loss_fwd(const float *pred, const float *target, size_t
     if (g > 256) g = 256;
     if (double *part = si_scratch(st)) {             // one launch, no zero-fill (NULL inside a stream capture before the scratch exists)
         if (g > 64) g = 64;                          // (64 workgroups: 11.2 us in rocprofv3 against 13.2 with 256, 12.4 with 128, 11.7 with 32)
-        hipLaunchKernelGGL(si_stats_fold_kernel, dim3(g), dim3(1024), 0, st, pred, target, n, weight, lambda, stats, loss, part,
+        hipLaunchKernelGGL(si_stats_fold_kernel<false>, dim3(g), dim3(1024), 0, st, pred, target, n, weight, lambda, stats, loss, part,
                            reinterpret_cast<unsigned long long *>(part + 3 * 256));
         RAMNET_LAUNCH_CHECK();
         return 0;
     }
     RAMNET_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
-    hipLaunchKernelGGL(si_stats_kernel, dim3(g), dim3(1024), 0, st, pred, target, n, weight, lambda, stats, loss);
+    hipLaunchKernelGGL(si_stats_kernel<false>, dim3(g), dim3(1024), 0, st, pred, target, n, weight, lambda, stats, loss);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_si_log_loss_fwd(const float *pred, const float *target, size_t n, float lambda, double *stats, float *loss, void *stream) {
+    RAMNET_CHECK_ARG(pred && target && stats && loss && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    int g = grid_for(n / 4 + 1, 1024);
+    if (g > 256) g = 256;
+    RAMNET_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
+    hipLaunchKernelGGL(si_stats_kernel<true>, dim3(g), dim3(1024), 0, st, pred, target, n, 1.0f, lambda, stats, loss);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_si_log_loss_bwd(const float *pred, const float *target, size_t n, float lambda, const double *stats,
+                                      const float *gscale, float *dpred, void *stream) {
+    RAMNET_CHECK_ARG(pred && target && stats && dpred && n > 0);
+    hipLaunchKernelGGL(si_bwd_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, 1.0f, lambda, stats, gscale, dpred);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_mse_loss_fwd(const float *pred, const float *target, int B, int H, int W, int half, double *stats, float *loss, void *stream) {
+    RAMNET_CHECK_ARG(pred && target && stats && loss && B > 0 && H > 0 && W > 0 && (!half || (H >= 2 && W >= 2)));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)B * (half ? H / 2 : H) * (half ? W / 2 : W);
+    int g = grid_for(n, 1024);
+    if (g > 256) g = 256;
+    RAMNET_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(double), st));
+    if (half) hipLaunchKernelGGL(mse_stats_kernel<true>, dim3(g), dim3(1024), 0, st, pred, target, B, H, W, stats, loss);
+    else hipLaunchKernelGGL(mse_stats_kernel<false>, dim3(g), dim3(1024), 0, st, pred, target, B, H, W, stats, loss);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_mse_loss_bwd(const float *pred, const float *target, int B, int H, int W, int half, const double *stats,
+                                   const float *gscale, float *dpred, void *stream) {
+    RAMNET_CHECK_ARG(pred && target && stats && dpred && B > 0 && H > 0 && W > 0);
+    const size_t n = (size_t)B * H * W;
+    if (half) hipLaunchKernelGGL(mse_bwd_kernel<true>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, B, H, W, stats, gscale, dpred);
+    else hipLaunchKernelGGL(mse_bwd_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, B, H, W, stats, gscale, dpred);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }
@@ -776,7 +888,7 @@ extern "C" int ramnet_si_loss_from_stats(const double *stats, float weight, floa
 extern "C" int ramnet_si_loss_bwd(const float *pred, const float *target, size_t n, float weight, float lambda, const double *stats,
                                   const float *gscale, float *dpred, void *stream) {
     RAMNET_CHECK_ARG(pred && target && stats && dpred && n > 0);
-    hipLaunchKernelGGL(si_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, weight, lambda, stats, gscale, dpred);
+    hipLaunchKernelGGL(si_bwd_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, weight, lambda, stats, gscale, dpred);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

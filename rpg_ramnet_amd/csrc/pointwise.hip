@@ -66,6 +66,36 @@ __global__ void nchw_to_nhwc_pad_kernel(const float *__restrict__ src, float *__
     }
 }
 
+// Full-frame mode (utils/inference_utils.py:287-314 CropParameters: ReflectionPad2d to the next multiple of 2^num_encoders): the model
+// input [B][C][H][W] is reflect-padded to [Hc][Wc] (top / left = ceil of half the excess) WHILE it is repacked — NHWC with channels
+// zero-padded to Cpad (nhwc = 1, the model's input repack) or NCHW (CropParameters.pad).  Reflection without the border pixel:
+// k < 0 -> -k, k >= n -> 2 (n - 1) - k (torch.nn.ReflectionPad2d).
+__global__ void reflect_pad_kernel(const float *__restrict__ src, float *__restrict__ dst, int B, int C, int H, int W, int Cpad, int top, int left,
+                                   int Hc, int Wc, int nhwc) {
+    const size_t npix = (size_t)B * Hc * Wc;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % Wc), y = (int)((i / Wc) % Hc);
+        const size_t b = i / ((size_t)Wc * Hc);
+        int sy = y - top, sx = x - left;
+        sy = sy < 0 ? -sy : (sy >= H ? 2 * (H - 1) - sy : sy);
+        sx = sx < 0 ? -sx : (sx >= W ? 2 * (W - 1) - sx : sx);
+        const float *in = src + (b * C * H + sy) * (size_t)W + sx;
+        if (nhwc) {
+            float *out = dst + i * Cpad;
+            for (int c = 0; c < Cpad; c += 4) {
+                float4 v;
+                v.x = c + 0 < C ? in[(size_t)(c + 0) * H * W] : 0.f;
+                v.y = c + 1 < C ? in[(size_t)(c + 1) * H * W] : 0.f;
+                v.z = c + 2 < C ? in[(size_t)(c + 2) * H * W] : 0.f;
+                v.w = c + 3 < C ? in[(size_t)(c + 3) * H * W] : 0.f;
+                st4(out + c, v);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) dst[((b * C + c) * Hc + y) * (size_t)Wc + x] = in[(size_t)c * H * W];
+        }
+    }
+}
+
 // OIHW -> [tap][chunk][n][16].  transposed: reduce over O (backward-data), outputs = I.
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int T,
                                    int transposed, int gates, int R, int N, int nchunks, int NPad, size_t total) {
@@ -572,6 +602,17 @@ extern "C" int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int 
     RAMNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 4 == 0);
     const size_t npix = (size_t)B * H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H * W, Cpad);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_reflect_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, int top, int left, int Hc, int Wc, int nhwc,
+                                  void *stream) {
+    RAMNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && top >= 0 && left >= 0 && Hc >= H + top && Wc >= W + left);
+    RAMNET_CHECK_ARG(top < H && Hc - H - top < H && left < W && Wc - W - left < W);          // reflection needs pad < extent
+    RAMNET_CHECK_ARG(!nhwc || (Cpad >= C && Cpad % 4 == 0));
+    const size_t npix = (size_t)B * Hc * Wc;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H, W, Cpad, top, left, Hc, Wc, nhwc);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

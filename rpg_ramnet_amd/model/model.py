@@ -83,6 +83,26 @@ class BaseERGB2Depth(BaseModel):
         self.loss_composition = config.get('loss_composition', False)
         self.kernel_size = int(config.get('kernel_size', 5))
         self.gpu = torch.device('cuda:' + str(config['gpu']))     # KeyError when absent, like model.py:77
+        self.full_frame = False
+        self._crops = {}
+
+    def set_full_frame(self, on=True):
+        """Full-frame mode (not in the reference's model; its helper utils/inference_utils.py:287-314 CropParameters describes it): inputs
+        whose height / width are not multiples of 2^num_encoders — the raw 260 x 346 frames, which the reference network itself cannot
+        run — are reflect-padded to the next multiple (264 x 352) inside the input repack, the states live at the
+        padded size, and every prediction is cropped back to the frame.  Off (default): such inputs fail as in the reference."""
+        self.full_frame = bool(on)
+        return self
+
+    def _crop_for(self, H, W):
+        """CropParameters of an H x W input in full-frame mode, or None when nothing has to be padded."""
+        if not self.full_frame:
+            return None
+        key = (H, W)
+        if key not in self._crops:
+            self._crops[key] = ops.CropParameters(W, H, self.num_encoders)
+        c = self._crops[key]
+        return None if c.identity else c
 
 
 class ERGB2Depth(BaseERGB2Depth):
@@ -94,8 +114,10 @@ class ERGB2Depth(BaseERGB2Depth):
                          norm=self.norm, use_upsample_conv=self.use_upsample_conv)
 
     def forward(self, item, prev_super_states, prev_states_lstm):
-        x = ops.pack_input(item["image"], self.gpu)
-        return {"image": self.unet(x)}, {'image': None}, prev_states_lstm
+        crop = self._crop_for(*item["image"].shape[2:])
+        x = ops.pack_input(item["image"], self.gpu, crop)
+        pred = self.unet(x)
+        return {"image": pred if crop is None else crop.crop(pred)}, {'image': None}, prev_states_lstm
 
 
 class ERGB2DepthRecurrent(BaseERGB2Depth):
@@ -128,23 +150,27 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         Equivalent to one iteration of the k-loop of model.py:176-195 without the decode."""
         assert not bool(self.baseline), "baselines have no event branch (model.py:181-185)"
         st = [_state_nhwc(s, self.base_num_channels * 2 ** (i + 1)) for i, s in enumerate(states)]
-        return self.statenetphasedrecurrent.forward_events(ops.pack_input(events, self.gpu), st, lstm_state)
+        return self.statenetphasedrecurrent.forward_events(ops.pack_input(events, self.gpu, self._crop_for(*events.shape[2:])), st, lstm_state)
 
     def update_image(self, image, states, lstm_state=None):
         """Fold ONE frame [B,Cr,H,W] into the shared state (model.py:196-213 without the decode)."""
         st = [_state_nhwc(s, self.base_num_channels * 2 ** (i + 1)) for i, s in enumerate(states)]
-        return self.statenetphasedrecurrent.forward_images(ops.pack_input(image, self.gpu), st, lstm_state)
+        return self.statenetphasedrecurrent.forward_images(ops.pack_input(image, self.gpu, self._crop_for(*image.shape[2:])), st, lstm_state)
 
-    def decode(self, states):
-        """Depth prediction [B,1,H,W] in [0,1] from the current state (statenet.py:290-315)."""
-        return self.statenetphasedrecurrent.forward_decoder(states)
+    def decode(self, states, frame_hw=None):
+        """Depth prediction [B,1,H,W] in [0,1] from the current state (statenet.py:290-315).  frame_hw (full-frame mode): the (height,
+        width) of the frames the state was built from — the prediction is cropped back to it."""
+        pred = self.statenetphasedrecurrent.forward_decoder(states)
+        crop = self._crop_for(*frame_hw) if frame_hw is not None else None
+        return pred if crop is None else crop.crop(pred)
 
     def forward(self, item, prev_super_states, prev_states_lstm):
         net = self.statenetphasedrecurrent
         predictions_dict, super_state_dict, states_lstm_dict = {}, {}, {}
+        crop = self._crop_for(*item['image'].shape[2:])
         if prev_super_states is None:
             B, _, H, W = item['image'].shape
-            states = self.init_states(B, H, W)
+            states = self.init_states(B, H, W) if crop is None else self.init_states(B, crop.height_crop_size, crop.width_crop_size)
         else:
             states = [_to_nhwc(s) for s in prev_super_states]
         K, baseline, lc = self.every_x_rgb_frame, self.baseline, self.loss_composition
@@ -154,7 +180,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                                            'state_comb': [_to_nhwc(s) for s in d['state_comb']]}
 
         def emit(key, pred, ss, sl):
-            predictions_dict[key] = pred
+            predictions_dict[key] = pred if crop is None else crop.crop(pred)
             views = [_to_nchw(s) for s in ss]
             super_state_dict[key] = views
             comb = []
@@ -185,7 +211,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
             else:
                 loop_range, last = K, lstm_in(prev_states_lstm['events{}'.format(K - 1)])
             for k in range(loop_range):
-                x = ops.pack_input(item['events{}'.format(k)], self.gpu)
+                x = ops.pack_input(item['events{}'.format(k)], self.gpu, crop)
                 if baseline == "ergb0" or baseline == 'e':
                     ss, sl = net.forward_images(x, states, last)
                 else:
@@ -193,7 +219,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                 emit('events{}'.format(k), decode(ss), ss, sl)
                 states, last = ss, sl
 
-        x = ops.pack_input(item['image'], self.gpu)
+        x = ops.pack_input(item['image'], self.gpu, crop)
         if not bool(baseline) or baseline == "rgb" or (baseline == "e" and lc != "image"):
             last = lstm_in(prev_states_lstm['image'])
         ss, sl = net.forward_images(x, states, last)

@@ -825,14 +825,60 @@ class S2DConvParam(ConvParam):
 
 
 # ------------------------------------------------------------------------------------------------ operators
-def pack_input(x, device):
-    """Model input NCHW (any device) -> NHWC with channels zero-padded to a multiple of 4 (model.py:177,200)."""
+def pack_input(x, device, crop=None):
+    """Model input NCHW (any device) -> NHWC with channels zero-padded to a multiple of 4 (model.py:177,200).
+    crop: a CropParameters (full-frame mode, utils/inference_utils.py:287-314) — the frame is reflect-padded to crop.height_crop_size x
+    crop.width_crop_size inside the same launch."""
     x = x.to(device=device, dtype=torch.float32).contiguous()
     B, Cc, Hh, W = x.shape
     cp = (Cc + 3) // 4 * 4
+    if crop is not None and (crop.height_crop_size, crop.width_crop_size) != (Hh, W):
+        assert (crop.height, crop.width) == (Hh, W), "full-frame mode: CropParameters built for %dx%d, input is %dx%d" % (crop.height, crop.width, Hh, W)
+        out = torch.empty(B, crop.height_crop_size, crop.width_crop_size, cp, device=device)
+        H.check(H.lib().ramnet_reflect_pad(_p(x), _p(out), B, Cc, Hh, W, cp, crop.padding_top, crop.padding_left, crop.height_crop_size,
+                                           crop.width_crop_size, 1, _st()), "ramnet_reflect_pad")
+        return out
     out = torch.empty(B, Hh, W, cp, device=device)
     H.check(H.lib().ramnet_nchw_to_nhwc_pad(_p(x), _p(out), B, Cc, Hh, W, cp, _st()), "ramnet_nchw_to_nhwc_pad")
     return out
+
+
+class CropParameters:
+    """utils/inference_utils.py:278-314: the smallest size >= (height, width) divisible by 2^num_encoders, the reflection padding that
+    centres the frame in it (top / left get the ceil of half the excess) and the window that crops a network output back.  Same
+    attribute names as the reference's class; `pad` is the HIP reflect-pad launch instead of torch.nn.ReflectionPad2d."""
+
+    def __init__(self, width, height, num_encoders):
+        from math import ceil, floor
+        self.height, self.width, self.num_encoders = height, width, num_encoders
+        f = 2 ** num_encoders
+        self.width_crop_size = int(f * ceil(width / f))
+        self.height_crop_size = int(f * ceil(height / f))
+        self.padding_top = ceil(0.5 * (self.height_crop_size - height))
+        self.padding_bottom = floor(0.5 * (self.height_crop_size - height))
+        self.padding_left = ceil(0.5 * (self.width_crop_size - width))
+        self.padding_right = floor(0.5 * (self.width_crop_size - width))
+        self.cx, self.cy = floor(self.width_crop_size / 2), floor(self.height_crop_size / 2)
+        self.ix0, self.ix1 = self.cx - floor(width / 2), self.cx + ceil(width / 2)
+        self.iy0, self.iy1 = self.cy - floor(height / 2), self.cy + ceil(height / 2)
+
+    @property
+    def identity(self):
+        return (self.height_crop_size, self.width_crop_size) == (self.height, self.width)
+
+    def pad(self, x):
+        """[B, C, height, width] (any device) -> reflect-padded [B, C, height_crop_size, width_crop_size] on the current device."""
+        x = x.to(device=torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32).contiguous()
+        B, Cc, Hh, W = x.shape
+        assert (Hh, W) == (self.height, self.width)
+        out = torch.empty(B, Cc, self.height_crop_size, self.width_crop_size, device=x.device)
+        H.check(H.lib().ramnet_reflect_pad(_p(x), _p(out), B, Cc, Hh, W, 0, self.padding_top, self.padding_left, self.height_crop_size,
+                                           self.width_crop_size, 0, _st()), "ramnet_reflect_pad")
+        return out
+
+    def crop(self, y):
+        """Network output [..., height_crop_size, width_crop_size] -> the original frame's window (a view)."""
+        return y[..., self.iy0:self.iy1, self.ix0:self.ix1]
 
 
 def gemm(a, b, out, trans_a=False, accumulate=False):
@@ -1488,6 +1534,68 @@ class SILossFromStats(Function):
         d = torch.empty_like(pred)
         H.check(H.lib().ramnet_si_loss_bwd(_p(pred), _p(target), pred.numel(), ctx.wl[0], ctx.wl[1], _p(stats), _p(g), _p(d), _st()), "si_bwd")
         return d, None, None, None, None, None
+
+
+class SILogLoss(Function):
+    """scale_invariant_log_loss (model/loss.py:12-15): mean(d^2) - lambda * mean(d)^2 over non-NaN d = log(pred) - log(target)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, n_lambda):
+        pred, target = pred.contiguous(), target.contiguous()
+        stats = torch.empty(4, device=pred.device, dtype=torch.float64)
+        loss = torch.empty((), device=pred.device)
+        H.check(H.lib().ramnet_si_log_loss_fwd(_p(pred), _p(target), pred.numel(), n_lambda, _p(stats), _p(loss), _st()), "si_log_fwd")
+        ctx.save_for_backward(pred, target, stats)
+        ctx.n_lambda = n_lambda
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        g = g.contiguous().float()
+        d = torch.empty_like(pred)
+        H.check(H.lib().ramnet_si_log_loss_bwd(_p(pred), _p(target), pred.numel(), ctx.n_lambda, _p(stats), _p(g), _p(d), _st()), "si_log_bwd")
+        return d, None, None
+
+
+class MSELoss(Function):
+    """mse_loss (model/loss.py:18-19) over the non-NaN target entries; half: both maps first through the bilinear x0.5 resize of
+    lstm_trainer.py:173-181 (fused into the reduction: no half-resolution tensors exist)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, half):
+        pred, target = pred.contiguous(), target.contiguous()
+        assert pred.dim() == 4 and pred.shape[1] == 1 and pred.shape == target.shape, "mse_loss: [B, 1, H, W] maps"
+        B, _, Hh, W = pred.shape
+        stats = torch.empty(4, device=pred.device, dtype=torch.float64)
+        loss = torch.empty((), device=pred.device)
+        H.check(H.lib().ramnet_mse_loss_fwd(_p(pred), _p(target), B, Hh, W, int(half), _p(stats), _p(loss), _st()), "mse_fwd")
+        ctx.save_for_backward(pred, target, stats)
+        ctx.half = int(half)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        B, _, Hh, W = pred.shape
+        g = g.contiguous().float()
+        d = torch.empty_like(pred)
+        H.check(H.lib().ramnet_mse_loss_bwd(_p(pred), _p(target), B, Hh, W, ctx.half, _p(stats), _p(g), _p(d), _st()), "mse_bwd")
+        return d, None, None
+
+
+def scale_invariant_log_loss(y_input, y_target, n_lambda=1.0):
+    """Drop-in for model.loss.scale_invariant_log_loss (model/loss.py:12-15) on device tensors."""
+    return SILogLoss.apply(y_input.float(), y_target.to(y_input.device).float(), float(n_lambda))
+
+
+def mse_loss(y_input, y_target, downsampling_factor=1.0):
+    """Drop-in for model.loss.mse_loss (model/loss.py:18-19); downsampling_factor 0.5 reproduces the trainer's half-resolution form
+    (lstm_trainer.py:169-185: both maps through F.interpolate(scale_factor=0.5, 'bilinear', align_corners=False) first).  Other factors
+    are refused: no shipped configuration sets one."""
+    if downsampling_factor not in (1.0, 0.5):
+        raise NotImplementedError("mse_loss: downsampling_factor %r (1.0 and the trainer's default 0.5 are built)" % (downsampling_factor,))
+    return MSELoss.apply(y_input.float(), y_target.to(y_input.device).float(), downsampling_factor == 0.5)
 
 
 class MSGLoss(Function):

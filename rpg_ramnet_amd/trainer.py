@@ -26,8 +26,21 @@ LOSS_SEMANTICS = {
 }
 
 
+LOSS_TYPES = ("scale_invariant_loss", "scale_invariant_log_loss", "mse_loss")      # config['loss']['type'] (train.py:192 getattr(module_loss, ...))
+
+
+def _nominal_loss(loss_type, value, target, loss_params):
+    if loss_type == "scale_invariant_loss":
+        return ops.scale_invariant_loss(value, target, **loss_params)
+    if loss_type == "scale_invariant_log_loss":
+        return ops.scale_invariant_log_loss(value, target, **{k: v for k, v in loss_params.items() if k == "n_lambda"})
+    if loss_type == "mse_loss":
+        return ops.mse_loss(value, target)
+    raise KeyError(loss_type)
+
+
 def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=None, grad_loss_weight=None, dp_exact=False,
-                  process_group=None):
+                  process_group=None, loss_type="scale_invariant_loss", mse_loss=None):
     """BPTT over the L packages of `sequence` (list of item dicts with 'depth_<key>' targets).
     grad_loss_weight: weight of the multi-scale gradient loss (config['grad_loss']['weight'], 0.25 in the released
     recipe; lstm_trainer.py:162-168, :197-199) or None for the SI loss alone.
@@ -37,11 +50,17 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
     from the global sums (ops.SILossFromStats) — after the reducer's gradient average the N-rank gradient is the single-rank one on
     the concatenated batch, and every rank reports the global loss.  (The multi-scale gradient loss normalises per scale by its own
     valid-pixel count: it stays per rank.)
+    loss_type: config['loss']['type'] — 'scale_invariant_loss' (every shipped config), 'scale_invariant_log_loss' (model/loss.py:12-15)
+    or 'mse_loss' (:18-19); loss_params = config['loss']['config'].
+    mse_loss: config['mse_loss'] (lstm_trainer.py:76-90) — {'weight': 1.0, 'downsampling_factor': 0.5} — adds
+    weight * sum_terms w_key * mse(bilinear x factor of prediction and target) / L (lstm_trainer.py:169-185, :205-208), or None.
     Returns (loss to call .backward() on, loss value the reference would report)."""
-    loss_params = loss_params or {"weight": 1.0, "n_lambda": 1.0}
+    if loss_params is None:
+        loss_params = {"weight": 1.0, "n_lambda": 1.0} if loss_type == "scale_invariant_loss" else {}
     if dp_exact:
+        assert loss_type == "scale_invariant_loss" and mse_loss is None, "dp_exact: the scale-invariant loss only"
         return _sequence_loss_dp_exact(model, sequence, loss_composition, loss_weights, loss_params, grad_loss_weight, process_group)
-    gterms = []
+    gterms, mterms = [], []
     L = len(sequence)
     assert L > 0
     K = model.every_x_rgb_frame
@@ -53,15 +72,19 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
             if not loss_composition or key in loss_composition:
                 w = loss_weights[loss_composition.index(key)]
                 target = item['depth_' + key].to(model.gpu)
-                terms.append(w * ops.scale_invariant_loss(value, target, **loss_params))
+                terms.append(w * _nominal_loss(loss_type, value, target, loss_params))
                 if grad_loss_weight is not None:
                     gterms.append(w * ops.multi_scale_grad_loss(value, target))
+                if mse_loss is not None:
+                    mterms.append(w * ops.mse_loss(value, target, mse_loss.get('downsampling_factor', 0.5)))
                 if key not in keys_seen:
                     keys_seen.append(key)
         prev_super, prev_lstm = supers['image'], lstms
     total = torch.stack(terms).sum() / float(L)
     if grad_loss_weight is not None:
         total = total + grad_loss_weight * torch.stack(gterms).sum() / float(L)
+    if mse_loss is not None:
+        total = total + float(mse_loss.get('weight', 1.0)) * torch.stack(mterms).sum() / float(L)
     return total, total.detach() * len(keys_seen)
 
 

@@ -205,6 +205,36 @@ def test_data_parallel_gradient_average_gloo_world2():
     np.testing.assert_allclose(res[0][2], ((grads[0] + grads[1]) / 2).numpy(), rtol=1e-5, atol=1e-8)
 
 
+def test_crop_parameters_match_the_reference():
+    """Full-frame helper: ops.CropParameters reproduces every field of the reference's CropParameters (utils/inference_utils.py:287-314;
+    fixture produced by the reference class itself) — the raw DAVIS frame 260 x 346 -> 264 x 352 with a (2, 2, 3, 3) reflection border
+    — and the oracle run on a torch-reflect-padded frame and cropped with those fields gives the reference network's cropped output."""
+    from rpg_ramnet_amd.ops import CropParameters
+    from oracle import ramnet_ref
+    z = load_golden("crop.npz")
+    names = json.loads(str(z["field_names"]))
+    for tag in ("davis", "odd", "odd2", "exact"):
+        f = dict(zip(names, (int(v) for v in z[tag + ".fields"])))
+        c = CropParameters(f["width"], f["height"], f["num_encoders"])
+        assert {k: getattr(c, k) for k in names} == f, tag
+        assert c.identity == (tag == "exact")
+    f = dict(zip(names, (int(v) for v in z["davis.fields"])))
+    assert (f["height_crop_size"], f["width_crop_size"], f["padding_top"], f["padding_left"]) == (264, 352, 2, 3)
+    cfg = json.loads(str(z["net.config"]))
+    from rpg_ramnet_amd.model import model as mm
+    torch.manual_seed(0)
+    sd = {k: v.detach() for k, v in mm.ERGB2DepthRecurrent(cfg).state_dict().items()}
+    c = CropParameters(35, 26, 3)
+    pad = torch.nn.ReflectionPad2d((c.padding_left, c.padding_right, c.padding_top, c.padding_bottom))
+    prev, lstm = None, ramnet_ref.empty_states_lstm(2)
+    for l in range(2):
+        item = {k: pad(torch.from_numpy(z["net.item%d.%s" % (l, k)])) for k in ("events0", "events1", "image")}
+        preds, supers, lstm = ramnet_ref.forward_recurrent(sd, cfg, item, prev, lstm)
+        prev = supers["image"]
+        for k, v in preds.items():
+            np.testing.assert_allclose(c.crop(v).numpy(), z["net.pred%d.%s" % (l, k)], rtol=0, atol=2e-6)
+
+
 def test_bench_plain_command_starts_its_own_ranks():
     """The driver's multi-GPU command is `python bench.py --gpus N ...` with no torch.distributed.run around it: bench.py must start
     its N ranks itself (rendezvous on 127.0.0.1), every rank must report in over the collective backend and rank 0 alone prints ONE

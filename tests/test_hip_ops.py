@@ -482,6 +482,53 @@ def test_si_loss_golden_and_grad():
         np.testing.assert_allclose(float(l2), float(z["si%d.loss_w05_l085" % i]), rtol=1e-5)
 
 
+def test_log_and_mse_losses_vs_reference_golden():
+    """ops.scale_invariant_log_loss (model/loss.py:12-15) and ops.mse_loss at full / half resolution (model/loss.py:18-19 behind the
+    bilinear x0.5 resize of lstm_trainer.py:173-181, fused into the reduction) — value and gradient against vectors produced by the
+    reference's own functions (tests/golden/loss_extra.npz); even and odd map sizes, 0 / 20 / 60 % NaN targets."""
+    from rpg_ramnet_amd import ops
+    z = load_golden("loss_extra.npz")
+    for i in range(3):
+        t = torch.from_numpy(z["c%d.target" % i]).to(dev())
+        for lam in (100, 85):
+            p = torch.from_numpy(z["c%d.pred" % i]).to(dev()).requires_grad_(True)
+            l = ops.scale_invariant_log_loss(p, t, lam / 100.0)
+            np.testing.assert_allclose(float(l.detach()), float(z["c%d.silog%d.loss" % (i, lam)]), rtol=1e-5)
+            (2.0 * l).backward()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), 2.0 * z["c%d.silog%d.grad" % (i, lam)], rtol=1e-4, atol=1e-8)
+        for f in (100, 50):
+            p = torch.from_numpy(z["c%d.pred" % i]).to(dev()).requires_grad_(True)
+            l = ops.mse_loss(p, t, f / 100.0)
+            np.testing.assert_allclose(float(l.detach()), float(z["c%d.mse%d.loss" % (i, f)]), rtol=1e-5)
+            (2.0 * l).backward()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), 2.0 * z["c%d.mse%d.grad" % (i, f)], rtol=1e-4, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        ops.mse_loss(p, t, 0.25)
+
+
+def test_trainer_loss_assembly_with_mse_term_vs_reference_golden():
+    """trainer.sequence_loss with config['mse_loss'] = {weight 0.7, downsampling_factor 0.5}: loss value and the gradient that reaches
+    the predictions equal what the reference's LSTMTrainer.calculate_losses / calculate_total_batch_loss produce (loss_extra.npz 'asm.*':
+    two supervised maps with weights 1.0 / 0.5, SI loss + mse term).  The model is a stub that replays the stored predictions as the two
+    keys of ONE package, so this side divides by L = 1 where the fixture divided by L = 2."""
+    from rpg_ramnet_amd import trainer
+    z = load_golden("loss_extra.npz")
+    preds = [torch.from_numpy(z["asm.pred%d" % l]).to(dev()).requires_grad_(True) for l in range(2)]
+
+    class Replay:
+        every_x_rgb_frame, gpu = 1, dev()
+
+        def __call__(self, item, prev_super, prev_lstm):
+            return {"events0": preds[0], "image": preds[1]}, {"image": None}, prev_lstm
+    item = {"depth_events0": torch.from_numpy(z["asm.target0"]), "depth_image": torch.from_numpy(z["asm.target1"])}
+    total, reported = trainer.sequence_loss(Replay(), [item], ["events0", "image"], [float(w) for w in z["asm.weights"]],
+                                            mse_loss={"weight": float(z["asm.mse_weight"]), "downsampling_factor": float(z["asm.mse_factor"])})
+    np.testing.assert_allclose(float(total.detach()), 2.0 * float(z["asm.loss"]), rtol=1e-5)
+    total.backward()
+    for l in range(2):
+        np.testing.assert_allclose(preds[l].grad.cpu().numpy(), 2.0 * z["asm.grad%d" % l], rtol=1e-4, atol=1e-9)
+
+
 VOX = ["rand", "rand10", "onebin", "single", "same_t", "corners", "int_ts_pm1"]
 
 

@@ -190,6 +190,35 @@ def test_si_loss_and_metrics(golden_dir):
         np.testing.assert_allclose(loss_ref.abs_rel_diff(p2, t2), z["depth%d.abs_rel" % clip], rtol=1e-6)
 
 
+def test_log_and_mse_losses_and_trainer_assembly(golden_dir):
+    """scale_invariant_log_loss (model/loss.py:12-15), mse_loss at full / half resolution and the trainer's assembly with the mse
+    term (lstm_trainer.py:152-226) against vectors produced by the reference's own functions and LSTMTrainer methods
+    (tests/golden/make_golden_losses.py); values and gradients (autograd through the restatement)."""
+    z = load(golden_dir, "loss_extra.npz")
+    for i in range(3):
+        t = torch.from_numpy(z["c%d.target" % i])
+        for lam in (100, 85):
+            p = torch.from_numpy(z["c%d.pred" % i]).requires_grad_(True)
+            l = loss_ref.scale_invariant_log_loss(p, t, lam / 100.0)
+            l.backward()
+            np.testing.assert_allclose(l.detach().numpy(), z["c%d.silog%d.loss" % (i, lam)], rtol=1e-5)
+            np.testing.assert_allclose(p.grad.numpy(), z["c%d.silog%d.grad" % (i, lam)], rtol=1e-4, atol=1e-8)
+        for f in (100, 50):
+            p = torch.from_numpy(z["c%d.pred" % i]).requires_grad_(True)
+            l = loss_ref.mse_loss_downsampled(p, t, f / 100.0)
+            l.backward()
+            np.testing.assert_allclose(l.detach().numpy(), z["c%d.mse%d.loss" % (i, f)], rtol=1e-6)
+            np.testing.assert_allclose(p.grad.numpy(), z["c%d.mse%d.grad" % (i, f)], rtol=1e-5, atol=1e-10)
+    preds = [torch.from_numpy(z["asm.pred%d" % l]).requires_grad_(True) for l in range(2)]
+    tgts = [torch.from_numpy(z["asm.target%d" % l]) for l in range(2)]
+    total = loss_ref.total_batch_loss(preds, tgts, [float(w) for w in z["asm.weights"]], 2, loss_params={"weight": 1.0, "n_lambda": 1.0},
+                                      mse={"weight": float(z["asm.mse_weight"]), "downsampling_factor": float(z["asm.mse_factor"])})
+    total.backward()
+    np.testing.assert_allclose(total.detach().numpy(), z["asm.loss"], rtol=1e-5)
+    for l in range(2):
+        np.testing.assert_allclose(preds[l].grad.numpy(), z["asm.grad%d" % l], rtol=1e-4, atol=1e-9)
+
+
 VOX = ["rand", "rand10", "onebin", "single", "same_t", "corners", "int_ts_pm1"]
 
 
