@@ -175,7 +175,7 @@ int ramnet_pack_weight_wino2x4(const float *w_oihw, float *wp, int Cout, int Cin
 /* 1 when a launch that qualifies for RAMNET_ALGO_WINOGRAD (d->algo set so, every other field final) runs faster as
  * RAMNET_ALGO_WINOGRAD_2X4 — the caller then sets d->algo and d->w (ramnet_pack_weight_wino2x4) accordingly; else 0.              */
 int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force);   /* force: skip the size heuristics (tests) */
-/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel workgroups a launch must have (default 320;
+/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel workgroups a launch must have (default 150;
  * < 0 keeps the current value); nf = 1 / 2 forces 32- / 64-channel workgroups, 0 = the launcher's choice (< 0 keeps).              */
 int ramnet_wino2x4_config(int min_wgs, int nf);
 /* Folded upsample-conv (RAMNET_ALGO_WINOGRAD24): OIHW 5x5 weights of an UpsampleConvLayer (submodules.py:69-97) -> Winograd-domain

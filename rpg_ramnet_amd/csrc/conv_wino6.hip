@@ -386,7 +386,7 @@ static bool wino6_vec4(const ramnet_conv_desc &d) {
 // Does this WINOGRAD-eligible launch run F(2x4,3x3)?  Dense 3x3 layers with plain / concatenated / masked inputs and the channel-quad
 // epilogues (no ConvLSTM cell, no space-to-depth view), 64-channel output blocks, on maps where (a) the 2 x 4 tiling wastes less than
 // a quarter of what it saves and (b) the launch still fills the chip with 64-channel workgroups at ONE per CU.
-static int g_w6_min_wgs = 320, g_w6_nf = 0;     // ramnet_wino2x4_config(): launch-size threshold, forced NF (0 = by launch size)
+static int g_w6_min_wgs = 150, g_w6_nf = 0;     // ramnet_wino2x4_config(): launch-size threshold, forced NF (0 = by launch size)
 
 int wino6_eligible(const ramnet_conv_desc &d, int force) {
     if (d.ntaps != 9 || d.stride != 1 || d.s2d_5x5 || d.out_s2d || d.frame) return 0;
