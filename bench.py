@@ -83,7 +83,8 @@ def parse():
                     help="start the ranks, initialise the process group, let every rank report in over the collective backend, print the "
                          "JSON line (value null) and exit before any GPU work: the launch contract alone (CPU test)")
     ap.add_argument("--wino2x4", default="auto", help="F(2x4,3x3) kernel selection for A/B runs: auto (library heuristics) | off | force, "
-                    "optionally ,nf,min_wgs (ops.set_winograd_2x4)")
+                    "optionally ,min_wgs (ops.set_winograd_2x4)")
+    ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
     ap.add_argument("--graph", action="store_true",
                     help="train: the timed step replays ONE hipGraph (gradient zero-fill, forward, loss, BPTT backward, gradient fold; "
                          "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
@@ -611,8 +612,9 @@ def main():
     from rpg_ramnet_amd import ops, _hip as Hh
     ops.set_wgrad_overlap(args.overlap_wgrad)
     ops.set_decoder_overlap(args.overlap_decoder)
+    ops.set_wgrad_slabs(not args.wgrad_atomic)
     w24 = args.wino2x4.split(",")
-    ops.set_winograd_2x4(w24[0], nf=int(w24[1]) if len(w24) > 1 else None, min_wgs=int(w24[2]) if len(w24) > 2 else None)
+    ops.set_winograd_2x4(w24[0], min_wgs=int(w24[1]) if len(w24) > 1 else None)
     K, bins, B, L, H, W = 5, args.bins, args.batch, args.seq_len, args.height, args.width
     cfg = dict(RELEASED, num_bins_events=bins, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)

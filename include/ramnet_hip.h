@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -130,6 +130,11 @@ typedef struct ramnet_wgrad_desc {
     int HoG, WoG;                   /* (all 0 = dense [B, Ho, Wo]; DIRECT only): one output parity of the folded upsample-conv  */
     int head_cin;                   /* RAMNET_ALGO_HEAD (dense 5x5 stride-1 taps, Cout <= 32): real input channels (1, 3 or 5); dw keeps
                                      * the DIRECT layout [25][C0][Cout]                                                          */
+    int dw_slabs;                   /* RAMNET_ALGO_WINOGRAD: 0 = dw is ONE [16][Cin][Cout] workspace, the tile splits of a launch meet in it by
+                                     * atomic adds; S > 0 = dw is [S][16][Cin][Cout] and dbias [S][Cout] (S >= 1, ramnet_wgrad_wino_slabs()):
+                                     * split s owns slab s and joins it by plain read-modify-write — no atomics, and with the launches of
+                                     * a layer serialised on one stream the gradient is bit-reproducible; ramnet_reduce_slabs() folds the
+                                     * slabs into slab 0 before ramnet_unpack_wgrad_wino().  Other algorithms ignore it.           */
 } ramnet_wgrad_desc;
 
 const char *ramnet_last_error(void);
@@ -161,6 +166,10 @@ int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, i
  * zero-padded to Cpad (the repack of ramnet_nchw_to_nhwc_pad fused in); nhwc = 0: NCHW (Cpad ignored).                        */
 int ramnet_reflect_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, int top, int left, int Hc, int Wc, int nhwc,
                        void *stream);
+/* Slabs the Winograd backward-weights launches of a Cin -> Cout layer use at most (ramnet_wgrad_desc.dw_slabs), and the ordered fold
+ * slab 0 += slab 1 + ... + slab S-1 (n floats each, n % 4 == 0; slabs 1.. are zeroed) at the end of a backward pass.            */
+int ramnet_wgrad_wino_slabs(int Cin, int Cout);
+int ramnet_reduce_slabs(float *ws, int slabs, size_t n, void *stream);
 /* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
 size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
 /* Winograd F(2x2,3x3) weights U = G g G^T of a 3x3 conv in the lane order of the kernel's B operand
@@ -175,9 +184,9 @@ int ramnet_pack_weight_wino2x4(const float *w_oihw, float *wp, int Cout, int Cin
 /* 1 when a launch that qualifies for RAMNET_ALGO_WINOGRAD (d->algo set so, every other field final) runs faster as
  * RAMNET_ALGO_WINOGRAD_2X4 — the caller then sets d->algo and d->w (ramnet_pack_weight_wino2x4) accordingly; else 0.              */
 int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force);   /* force: skip the size heuristics (tests) */
-/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel workgroups a launch must have (default 150;
- * < 0 keeps the current value); nf = 1 / 2 forces 32- / 64-channel workgroups, 0 = the launcher's choice (< 0 keeps).              */
-int ramnet_wino2x4_config(int min_wgs, int nf);
+/* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel x 256-pixel blocks of output a launch must
+ * have (default 150; < 0 keeps the current value).                                                                              */
+int ramnet_wino2x4_config(int min_wgs);
 /* Folded upsample-conv (RAMNET_ALGO_WINOGRAD24): OIHW 5x5 weights of an UpsampleConvLayer (submodules.py:69-97) -> Winograd-domain
  * weights of the four 4x4 parity filters in the kernel's layout (see ramnet_algo above); 100*Cout*Cin floats.
  * ramnet_fold_wino_supported: Cout % 32 == 0 and an even number of input-channel chunks (Cin % 32 == 0, or Cin % 16 == 0 with

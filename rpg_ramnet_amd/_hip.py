@@ -53,6 +53,7 @@ class WgradDesc(C.Structure):
         ("algo", C.c_int),
         ("gsy", C.c_int), ("gsx", C.c_int), ("goy", C.c_int), ("gox", C.c_int), ("HoG", C.c_int), ("WoG", C.c_int),
         ("head_cin", C.c_int),
+        ("dw_slabs", C.c_int),
     ]
 
 
@@ -65,13 +66,15 @@ _SIGS = {
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_reflect_pad": (C.c_int, [_fp, _fp] + [C.c_int] * 10 + [_fp]),
+    "ramnet_wgrad_wino_slabs": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_reduce_slabs": (C.c_int, [_fp, C.c_int, C.c_size_t, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_wino": (C.c_size_t, [C.c_int] * 4),
     "ramnet_pack_weight_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_packed_weight_elems_wino2x4": (C.c_size_t, [C.c_int] * 3),
     "ramnet_pack_weight_wino2x4": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
-    "ramnet_wino2x4_config": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_wino2x4_config": (C.c_int, [C.c_int]),
     "ramnet_conv_wino_variant": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
     "ramnet_head_supported": (C.c_int, [C.c_int, C.c_int]),

@@ -26,6 +26,8 @@ namespace ramnet {
 // output channels per workgroup = 32 * NF: NF = 2 (two workgroups per CU) or 4 (one per CU, 256 accumulator VGPRs: every
 // transformed input row then feeds twice the MFMAs)
 
+constexpr int WGRAD_WINO_TARGET = 384;      // workgroups per launch the tile splits aim at
+
 struct WgradWinoParams {
     InSrc src;
     int bx_n, ty_n, nbatch;     // batches per row, tile rows per image, total
@@ -304,19 +306,54 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
     }
 
     // D[row = input channel][col = output channel] of position 4 * wave + pl -> ws[(pos*Cin + c)*Cout + n]
+    // dw_slabs > 0: the tile split blockIdx.x owns slab blockIdx.x of the workspace and joins it by a plain read-modify-write — the
+    // launches of a layer are serialised on their stream and no other workgroup of this launch touches the slab, so the sums are
+    // formed in a fixed order (bit-reproducible gradients); ramnet_reduce_slabs adds the slabs up, in order, when the pass ends.
+    // dw_slabs == 0 (callers that pass one [16][Cin][Cout] workspace): the splits meet by atomic adds.
     const int Cin = s.Cin;
-#pragma unroll
-    for (int pl = 0; pl < 4; ++pl)
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const int n = n0 + f * 32 + l31;
+    const bool slabs = p.dw_slabs > 0;
+    float *dwb = p.dw + (slabs ? (size_t)blockIdx.x * 16 * Cin * p.Cout : 0);
+    if (slabs) {
+        // software-pipelined: the 16 old values of group g + 1 are requested before group g is stored (the compiler cannot prove that the
+        // stores do not alias the next loads and would otherwise expose one memory round trip per group: 8 per workgroup)
+        float old[2][16];
+        auto grp_load = [&](int g, float (&o)[16]) {
+            const int pl = g / NF, f = g % NF, n = n0 + f * 32 + l31;
+            const float *col = dwb + (size_t)(4 * wave + pl) * Cin * p.Cout + n;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (c < Cin && n < p.Cout)
-                    atomicAdd(p.dw + ((size_t)(4 * wave + pl) * Cin + c) * p.Cout + n, ((wave == 3) != (pl == 3)) ? -acc[pl][f][r] : acc[pl][f][r]);
+                o[r] = (c < Cin && n < p.Cout) ? col[(size_t)c * p.Cout] : 0.f;
+            }
+        };
+        grp_load(0, old[0]);
+#pragma unroll
+        for (int g = 0; g < 4 * NF; ++g) {
+            if (g + 1 < 4 * NF) grp_load(g + 1, old[(g + 1) & 1]);
+            const int pl = g / NF, f = g % NF, n = n0 + f * 32 + l31;
+            float *col = dwb + (size_t)(4 * wave + pl) * Cin * p.Cout + n;
+            const bool neg = (wave == 3) != (pl == 3);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (c < Cin && n < p.Cout) col[(size_t)c * p.Cout] = old[g & 1][r] + (neg ? -acc[pl][f][r] : acc[pl][f][r]);
             }
         }
+    } else {
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int n = n0 + f * 32 + l31;
+                float *col = dwb + (size_t)(4 * wave + pl) * Cin * p.Cout + n;
+                const bool neg = (wave == 3) != (pl == 3);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (c < Cin && n < p.Cout) atomicAdd(col + (size_t)c * p.Cout, neg ? -acc[pl][f][r] : acc[pl][f][r]);
+                }
+            }
+    }
     if (p.dbias != nullptr && blockIdx.y == 0) {
         __syncthreads();
         float *red = smem;                        // [NT / YQ][GW_CO]
@@ -325,8 +362,24 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
         if (tid < GW_CO) {
             float t = 0.f;
             for (int g = 0; g < NT / YQ; ++g) t += red[g * GW_CO + tid];
-            if (n0 + tid < p.Cout) atomicAdd(p.dbias + n0 + tid, t);
+            if (n0 + tid < p.Cout) {
+                if (slabs) p.dbias[(size_t)blockIdx.x * p.Cout + n0 + tid] += t;      // (one workgroup per (slab, channel block): blockIdx.y == 0)
+                else atomicAdd(p.dbias + n0 + tid, t);
+            }
         }
+    }
+}
+
+// slab 0 += slab 1 + slab 2 + ... in that order (n floats per slab), the others are zeroed for the next pass
+__global__ void reduce_slabs_kernel(float *__restrict__ ws, int slabs, size_t n) {
+    for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        float4 a = ld4(ws + i);
+        for (int s = 1; s < slabs; ++s) {
+            const float4 b = ld4(ws + (size_t)s * n + i);
+            a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            st4(ws + (size_t)s * n + i, f4zero());
+        }
+        st4(ws + i, a);
     }
 }
 
@@ -387,10 +440,11 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     static const char *nfe = getenv("RAMNET_WGRAD_NF");
     const int nf = (d.Cout % 128 == 0 && nfe && nfe[0] == '4') ? 4 : 2;
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
-    // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room
-    static const char *se = getenv("RAMNET_WGRAD_BLOCKS");
-    int splits = (nf == 4 ? 256 : (se ? atoi(se) : 384)) / (gy * gz);
+    // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room (measured
+    // 256 ... 512: profiles/r03_h_tuning_notes.md)
+    int splits = (nf == 4 ? 256 : WGRAD_WINO_TARGET) / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
+    if (d.dw_slabs > 0 && splits > d.dw_slabs) splits = d.dw_slabs;
     if (splits < 1) splits = 1;
     const dim3 grid(splits, gy, gz);
     const size_t lds = ((size_t)2 * ((tall ? GrGeom<2>::XP : GrGeom<8>::XP) + 32 * 32 * nf) + 256 * 4) * sizeof(float);      // strips + scratch cells
@@ -424,6 +478,21 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
 }  // namespace ramnet
 
 using namespace ramnet;
+
+extern "C" int ramnet_wgrad_wino_slabs(int Cin, int Cout) {
+    const int s = WGRAD_WINO_TARGET / (cdiv(Cin, 32) * cdiv(Cout, 64));
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int ramnet_reduce_slabs(float *ws, int slabs, size_t n, void *stream) {
+    RAMNET_CHECK_ARG(ws && slabs >= 1 && n > 0 && n % 4 == 0 && ((uintptr_t)ws & 15) == 0);
+    if (slabs == 1) return 0;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, slabs, n);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int ramnet_unpack_wgrad_wino(const float *ws, float *grad, int Cout, int Cin, int CinWs, int CoutWs, int n_off, void *stream) {
     RAMNET_CHECK_ARG(ws && grad && Cout > 0 && Cin > 0 && CinWs >= Cin && n_off >= 0 && CoutWs >= n_off + Cout);

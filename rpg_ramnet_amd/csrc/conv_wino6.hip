@@ -9,10 +9,10 @@
 // transform grid (the lane builds its row of B^T d B in registers and that row IS the MFMA's A operand).  Four rows = four waves = one
 // per SIMD, all equally loaded; six rows put two waves on two of the four SIMDs (75 % of the pipe at best = 3.0 multiplies per output,
 // the same as here) or need 288 accumulator registers per wave.  The columns carry the larger transform instead: a wave owns 6 positions
-// for 32 tiles x (32 * NF) output channels — 96 * NF accumulator registers.
-//   NF = 2: 64 channels per workgroup, 48 MFMAs per 8-channel chunk and wave for 12 LDS reads + ~80 transform instructions (2.1 per
-//           MFMA; F(2x2,3x3): 2.3); 192 accumulators + the operand rings = one wave per SIMD, one workgroup per CU;
-//   NF = 1: 32 channels, two workgroups per CU (launches that would not fill the chip otherwise).
+// for 32 tiles x 32 output channels — 96 accumulator registers, two workgroups per CU.  (A 64-channel form — 192 accumulators in AGPRs, 48
+// MFMAs per chunk for the same transform work, one wave per SIMD — was built and measured: its main loop is as fast, but with ONE
+// workgroup per CU nothing hides a workgroup's prologue and epilogue: fixed cost per launch 74 against 39 us, slower at every depth the
+// network has — profiles/r04_h_tuning_notes.md.  Removed.)
 // Everything else follows conv_wino.hip: only the raw patch is shared (fused loaders, double-buffered, one barrier per chunk, three
 // (pixel, quad) slots per thread for the 18 x 18 / 34 x 10 / 10 x 34 patch of a 256-pixel workgroup tile), weights stream from L2 in
 // B-operand lane order one chunk ahead, the waves exchange their column-transformed rows (4 of 6 columns) through LDS once per
@@ -45,8 +45,9 @@ template <int TXG> struct R6Geom {
     static_assert(PH * PW * 2 <= 768, "three patch slots per thread");
 };
 
-template <int TXG, int MODE, int NF>
-__global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(const ramnet_conv_desc p, const WinoParams q) {
+template <int TXG, int MODE>
+__global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_desc p, const WinoParams q) {
+    constexpr int NF = 1;                        // 32-channel output blocks per workgroup (the index algebra below keeps the general form)
     constexpr int RO_LD = NF * 32 + 4;           // row of the exchange buffer [wave 4][column 4][tile 32][channels + pad]
     using G = R6Geom<TXG>;
     constexpr int RP_PLANE = G::PLANE, RP_FLOATS = G::PFLOATS, RPW = G::PWS, RTW = G::TW;
@@ -104,9 +105,9 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
     float tA[6][4], tB[6][4];                        // row `wave` of B2^T d for the chunk in flight / the next one: [column][channel]
     // A operands (4 channels = 4 K steps) of the positions in flight and the next ones: a ring of 4.  LD = how many positions ahead
     // the column transform runs: consecutive MFMAs of a wave must go to DIFFERENT accumulators (an instruction between two MFMAs on the
-    // same accumulator costs ~43 cycles, MI355X_MICROARCH.md) — with two n-blocks (NF = 2) a position alternates its two accumulators;
-    // with one (NF = 1) the positions are taken in PAIRS (p, p + 1) alternating, so two positions' operands are live at a time.
-    constexpr int LD = NF == 2 ? 1 : 2;
+    // same accumulator costs ~43 cycles, MI355X_MICROARCH.md): the positions are taken in PAIRS (p, p + 1), alternating, so two
+    // positions' operands are live at a time and the transform runs two positions ahead.
+    constexpr int LD = 2;
     float vb[4][4];
     float4 qa[6], qb[6];
     float sa[4], sd[4];                              // shared sub-expressions of positions (1, 2) and (3, 4)
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
     pr.load(q.src, 0, clast);
 #pragma unroll
     for (int i = 0; i < 12; ++i)
-        if (NF == 2 || !(i & 1)) breg[i >> 1][NF == 2 ? i & 1 : 0] = wload(0, i);
+        if (!(i & 1)) breg[i >> 1][0] = wload(0, i);
     pr.store(patch, q.src, 0);
     pr.load(q.src, min(WK, clast), clast);
     __syncthreads();
@@ -156,9 +157,8 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
     pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
     pr.load(q.src, min(2 * WK, clast), clast);
     __syncthreads();
-    // One chunk = 6 positions x 4 K steps x NF n-blocks of MFMAs.  Everything else of the chunk is cut into 48 SLOTS, one behind every
-    // MFMA (NF = 2) or two (NF = 1), each a handful of instructions — a wave that is alone on its SIMD (NF = 2) has nobody to fill the
-    // pipe while it issues a block of 12 VALU, so no gap carries more than ~4:
+    // One chunk = 6 positions x 4 K steps of MFMAs.  Everything else of the chunk is cut into 48 SLOTS, two behind every MFMA, each a
+    // handful of instructions: a block of 12 VALU between two MFMAs is a bubble in the pipe, so no gap carries more than ~6:
     //   slots  0..11   LDS reads of the NEXT chunk's two window rows (column j = slot >> 1)
     //   slots  4..27   their combination t[j][c] = d[ra][j][c] + sb * d[rb][j][c], one channel per slot
     //   slots 8g..8g+7 the column transform of position g + LD (positions 0 .. LD-1 of the NEXT chunk for g + LD >= 6)
@@ -187,43 +187,23 @@ __global__ void __launch_bounds__(256, NF == 2 ? 1 : 2) conv_wino_r6_kernel(cons
             else colop(g + LD - 6, (g + LD - 6 + 2 * (PAR ^ 1)) & 3, i, tn);
             if (s >= 28 && s < 31) pr.store_slot(pfree, q.src, c2, s - 28);
             if (s == 33 || s == 35 || s == 37) pr.load_slot(q.src, c3, (s - 33) >> 1, clast);
-            if (NF == 2 && i == 7) breg[g][0] = wload(cw, g * 2), breg[g][NF - 1] = wload(cw, g * 2 + 1);
-            if (NF == 1 && (s & 15) == 15) breg[g - 1][0] = wload(cw, (g - 1) * 2), breg[g][0] = wload(cw, g * 2);
+            if ((s & 15) == 15) breg[g - 1][0] = wload(cw, (g - 1) * 2), breg[g][0] = wload(cw, g * 2);
         };
-        if (NF == 2) {
 #pragma unroll
-            for (int pl = 0; pl < 6; ++pl) {
-                const float b0[4] = {breg[pl][0].x, breg[pl][0].y, breg[pl][0].z, breg[pl][0].w};
-                const float b1[4] = {breg[pl][NF - 1].x, breg[pl][NF - 1].y, breg[pl][NF - 1].z, breg[pl][NF - 1].w};
+        for (int gp = 0; gp < 3; ++gp) {
+            const int p0 = 2 * gp, p1 = 2 * gp + 1;
+            const float b0[4] = {breg[p0][0].x, breg[p0][0].y, breg[p0][0].z, breg[p0][0].w};
+            const float b1[4] = {breg[p1][0].x, breg[p1][0].y, breg[p1][0].z, breg[p1][0].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[pl][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(pl + 2 * PAR) & 3][j], b0[j], acc[pl][0], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    slot(pl * 8 + j * 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[pl][NF - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(pl + 2 * PAR) & 3][j], b1[j], acc[pl][NF - 1], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    slot(pl * 8 + j * 2 + 1);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int gp = 0; gp < 3; ++gp) {
-                const int p0 = 2 * gp, p1 = 2 * gp + 1;
-                const float b0[4] = {breg[p0][0].x, breg[p0][0].y, breg[p0][0].z, breg[p0][0].w};
-                const float b1[4] = {breg[p1][0].x, breg[p1][0].y, breg[p1][0].z, breg[p1][0].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[p0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p0 + 2 * PAR) & 3][j], b0[j], acc[p0][0], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    slot(gp * 16 + j * 4), slot(gp * 16 + j * 4 + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[p1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p1 + 2 * PAR) & 3][j], b1[j], acc[p1][0], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    slot(gp * 16 + j * 4 + 2), slot(gp * 16 + j * 4 + 3);
-                }
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+                acc[p0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p0 + 2 * PAR) & 3][j], b0[j], acc[p0][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                slot(gp * 16 + j * 4), slot(gp * 16 + j * 4 + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[p1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p1 + 2 * PAR) & 3][j], b1[j], acc[p1][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                slot(gp * 16 + j * 4 + 2), slot(gp * 16 + j * 4 + 3);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -386,7 +366,7 @@ static bool wino6_vec4(const ramnet_conv_desc &d) {
 // Does this WINOGRAD-eligible launch run F(2x4,3x3)?  Dense 3x3 layers with plain / concatenated / masked inputs and the channel-quad
 // epilogues (no ConvLSTM cell, no space-to-depth view), 64-channel output blocks, on maps where (a) the 2 x 4 tiling wastes less than
 // a quarter of what it saves and (b) the launch still fills the chip with 64-channel workgroups at ONE per CU.
-static int g_w6_min_wgs = 150, g_w6_nf = 0;     // ramnet_wino2x4_config(): launch-size threshold, forced NF (0 = by launch size)
+static int g_w6_min_wgs = 150;                  // ramnet_wino2x4_config(): launch-size threshold (64-channel workgroups of 256 pixels)
 
 int wino6_eligible(const ramnet_conv_desc &d, int force) {
     if (d.ntaps != 9 || d.stride != 1 || d.s2d_5x5 || d.out_s2d || d.frame) return 0;
@@ -436,7 +416,7 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
     q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
-    const int nf = g_w6_nf == 2 ? 2 : 1;                            // 64-channel workgroups (one per CU: exposed prologue / epilogue) on request only
+    const int nf = 1;                                               // 32-channel workgroups
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
     const size_t ex = (size_t)4 * 4 * 32 * (nf * 32 + 4) * sizeof(float);
     {
@@ -445,18 +425,16 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
         ldmax = ldmax > d.ldm ? ldmax : d.ldm;
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
     }
-    note_kernel("conv_wino_r6_kernel<%d,%d,%d>", txg, d.in_mode, nf);
-#define RAMNET_GO6(TXv, MDv, NFv)                                                                                   \
-    case (TXv) * 100 + (MDv) * 4 + (NFv): {                                                                         \
+    note_kernel("conv_wino_r6_kernel<%d,%d>", txg, d.in_mode);
+#define RAMNET_GO6(TXv, MDv)                                                                                        \
+    case (TXv) * 100 + (MDv): {                                                                                     \
         const size_t pf = (size_t)(2 * R6Geom<TXv>::PFLOATS + 256 * 4) * sizeof(float);                             \
-        RAMNET_FULL_LDS((conv_wino_r6_kernel<TXv, MDv, NFv>));                                                      \
-        hipLaunchKernelGGL((conv_wino_r6_kernel<TXv, MDv, NFv>), grid, dim3(256), ex > pf ? ex : pf, st, d, q);     \
+        RAMNET_FULL_LDS((conv_wino_r6_kernel<TXv, MDv>));                                                           \
+        hipLaunchKernelGGL((conv_wino_r6_kernel<TXv, MDv>), grid, dim3(256), ex > pf ? ex : pf, st, d, q);          \
     } break;
 #define RAMNET_GO6_TX(TXv)                                                                                          \
-    RAMNET_GO6(TXv, RAMNET_IN_PLAIN, 2) RAMNET_GO6(TXv, RAMNET_IN_CAT, 2) RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL, 2)     \
-    RAMNET_GO6(TXv, RAMNET_IN_RELUMASK, 2) RAMNET_GO6(TXv, RAMNET_IN_PLAIN, 1) RAMNET_GO6(TXv, RAMNET_IN_CAT, 1)    \
-    RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL, 1) RAMNET_GO6(TXv, RAMNET_IN_RELUMASK, 1)
-    switch (txg * 100 + d.in_mode * 4 + nf) {
+    RAMNET_GO6(TXv, RAMNET_IN_PLAIN) RAMNET_GO6(TXv, RAMNET_IN_CAT) RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL) RAMNET_GO6(TXv, RAMNET_IN_RELUMASK)
+    switch (txg * 100 + d.in_mode) {
         RAMNET_GO6_TX(4)
         RAMNET_GO6_TX(2)
         RAMNET_GO6_TX(8)
@@ -473,10 +451,8 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
 
 using namespace ramnet;
 
-extern "C" int ramnet_wino2x4_config(int min_wgs, int nf) {
-    RAMNET_CHECK_ARG(nf >= -1 && nf <= 2);
+extern "C" int ramnet_wino2x4_config(int min_wgs) {
     if (min_wgs >= 0) g_w6_min_wgs = min_wgs;
-    if (nf >= 0) g_w6_nf = nf;
     return 0;
 }
 

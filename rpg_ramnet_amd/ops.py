@@ -29,18 +29,26 @@ def set_winograd(on):
 
 
 _WINO_2X4 = "auto"
+_WGRAD_SLABS = True
 
 
-def set_winograd_2x4(mode, nf=None, min_wgs=None):
+def set_wgrad_slabs(on):
+    """Winograd backward-weights: tile splits join per-split slabs of the workspace by plain read-modify-write (default: no atomics,
+    bit-reproducible gradients) or meet in slab 0 by atomic adds (A/B runs)."""
+    global _WGRAD_SLABS
+    _WGRAD_SLABS = bool(on)
+
+
+
+def set_winograd_2x4(mode, min_wgs=None):
     """F(2x4,3x3) variant of the Winograd forward / backward-data launches (csrc/conv_wino6.hip): "auto" = where the library's size
     heuristics pick it (large maps: the two fine scales at the training batch), "off" = F(2x2,3x3) everywhere, "force" = every
-    structurally eligible launch (tests).  nf: 1 / 2 = 32- / 64-channel workgroups, 0 = the launcher's choice; min_wgs: launch-size
-    threshold of "auto" (library defaults when None)."""
+    structurally eligible launch (tests).  min_wgs: launch-size threshold of "auto" (library default when None)."""
     global _WINO_2X4
     assert mode in ("auto", "off", "force")
     _WINO_2X4 = mode
-    if nf is not None or min_wgs is not None:
-        H.check(H.lib().ramnet_wino2x4_config(-1 if min_wgs is None else int(min_wgs), -1 if nf is None else int(nf)), "wino2x4_config")
+    if min_wgs is not None:
+        H.check(H.lib().ramnet_wino2x4_config(int(min_wgs)), "wino2x4_config")
 
 
 def get_winograd():
@@ -267,6 +275,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     if gview is not None:      # dout / gmask addressed as (oy*gsy + goy, ox*gsx + gox) of [B, HoG, WoG]
         d.gsy, d.gsx, d.goy, d.gox, d.HoG, d.WoG = gview
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
+    d.dw_slabs = getattr(dw, "slabs", 0) if (d.algo == H.ALGO_WINOGRAD and _WGRAD_SLABS) else 0     # per-split slabs (read-modify-write joins)
     if wino24:          # folded upsample-conv in the Winograd F(2x2,4x4) domain: dw = [4][25][C0][Cout]
         d.algo = H.ALGO_WINOGRAD24
     hc = getattr(dw, "head_cin", 0)
@@ -695,8 +704,12 @@ class ConvParam:
         if self._ws is None:
             dev = self.weights[0].device
             slots = 16 if self.k == 3 else self.k * self.k       # 3x3: room for the Winograd-domain gradient dU
-            self._ws = torch.zeros(slots * self.CinWs * self.Cout, device=dev)
-            self._bws = torch.zeros(self.Cout, device=dev)
+            # 3x3 layers: one slab per tile split of the Winograd backward-weights launch (joined by plain read-modify-write: no atomics,
+            # bit-reproducible sums; ramnet_wgrad_desc.dw_slabs) — folded into slab 0 by finalize(); other layers: one slab
+            self._slabs = H.lib().ramnet_wgrad_wino_slabs(self.CinWs, self.Cout) if self.k == 3 else 1
+            self._ws = torch.zeros(self._slabs * slots * self.CinWs * self.Cout, device=dev)
+            self._bws = torch.zeros(self._slabs * self.Cout, device=dev)
+            self._ws.slabs = self._slabs
         _Engine.enter()         # (a new pass after an aborted one resets _dirty first)
         if not self._dirty:     # one algorithm per backward pass: every launch of the pass accumulates into the same layout
             self._ws.wino = bool(wino_ok and _WINOGRAD and self.k == 3
@@ -760,12 +773,20 @@ class ConvParam:
                 t.zero_()
         self._dirty = self._ws_used = self._fold_used = self._fold24_used = False
 
+    def _join_slabs(self):
+        """Winograd backward-weights slabs -> slab 0 (fixed order), weights and bias."""
+        if getattr(self, "_slabs", 1) > 1 and getattr(self._ws, "wino", False):
+            H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), self._slabs, self._ws.numel() // self._slabs, _st()), "ramnet_reduce_slabs")
+            H.check(H.lib().ramnet_reduce_slabs(_p(self._bws), self._slabs, self.Cout, _st()), "ramnet_reduce_slabs")
+
     def finalize(self):
         if self._fold_used:
             self._finalize_fold()
+        if self._ws_used:
+            self._join_slabs()
         if not self._ws_used:
             if self.biases[0] is not None and self.biases[0].shape[0] == self.Cout:
-                ensure_grad(self.biases[0]).add_(self._bws)
+                ensure_grad(self.biases[0]).add_(self._bws[:self.Cout])
             self._bws.zero_()
             self._dirty = False
             return
@@ -812,13 +833,14 @@ class S2DConvParam(ConvParam):
         w, b = self.parent.weights[0], self.parent.biases[0]
         g3 = torch.zeros(self.Cout, self.Cin, 3, 3, device=w.device)
         L = H.lib()
+        self._join_slabs()
         if getattr(self._ws, "wino", False):
             H.check(L.ramnet_unpack_wgrad_wino(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino")
         else:
             H.check(L.ramnet_unpack_wgrad(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, 3, 3, _st()), "ramnet_unpack_wgrad")
         ensure_grad(w).add_(s2d_weights_adjoint(g3, self.parent.Cin))
         if b is not None:
-            ensure_grad(b).add_(self._bws)
+            ensure_grad(b).add_(self._bws[:self.Cout])
         self._ws.zero_()
         self._bws.zero_()
         self._dirty = self._ws_used = False

@@ -30,10 +30,10 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=344)
     ap.add_argument("--only", default="")
-    ap.add_argument("--wino2x4", default="auto", help="auto | off | force[,nf[,min_wgs]]: F(2x4,3x3) selection (ops.set_winograd_2x4)")
+    ap.add_argument("--wino2x4", default="auto", help="auto | off | force[,min_wgs]: F(2x4,3x3) selection (ops.set_winograd_2x4)")
     a = ap.parse_args()
     w24 = a.wino2x4.split(",")
-    ops.set_winograd_2x4(w24[0], nf=int(w24[1]) if len(w24) > 1 else None, min_wgs=int(w24[2]) if len(w24) > 2 else None)
+    ops.set_winograd_2x4(w24[0], min_wgs=int(w24[1]) if len(w24) > 1 else None)
     dev = torch.device("cuda:0")
     B, Hh, Ww = a.batch, a.height, a.width
     # (name, kind, Cin(real), Cout, k, stride, Hin, Win)   kind: conv | up | gru_ur | gru_o | lstm

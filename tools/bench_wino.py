@@ -42,18 +42,18 @@ def main():
         x = torch.randn(B, Hh, Ww, cin, device=dev)
         y = torch.empty(B, Hh, Ww, cout, device=dev)
         t = {}
-        for name, on, m24, nf in (("wino", True, "off", 0), ("direct", False, "off", 0), ("w2x4", True, "force", 2), ("w2x4nf1", True, "force", 1)):
+        for name, on, m24 in (("wino", True, "off"), ("direct", False, "off"), ("w2x4", True, "force")):
             ops.set_winograd(on)
-            ops.set_winograd_2x4(m24, nf=nf)
+            ops.set_winograd_2x4(m24)
             t[name] = timeit(lambda: ops.conv_launch(x, taps, cp.fwd(), y, cout, bias=cp.bias(), epi=epi))
         ops.set_winograd(True)
-        ops.set_winograd_2x4("auto", nf=0)
+        ops.set_winograd_2x4("auto")
         gf = 2.0 * B * Hh * Ww * 9 * cin * cout / 1e9
         rows.append((cin, t, gf))
-        print("Cin %4d  chunks %3d | F(2x2) %.3f ms (%6.1f TF/s eq.) | F(2x4) %.3f ms (%6.1f) | F(2x4) 32-ch %.3f ms (%6.1f) | direct %.3f ms (%6.1f TF/s)" %
-              (cin, cin // 8, t["wino"], gf / t["wino"], t["w2x4"], gf / t["w2x4"], t["w2x4nf1"], gf / t["w2x4nf1"], t["direct"], gf / t["direct"]))
+        print("Cin %4d  chunks %3d | F(2x2) %.3f ms (%6.1f TF/s eq.) | F(2x4) %.3f ms (%6.1f) | direct %.3f ms (%6.1f TF/s)" %
+              (cin, cin // 8, t["wino"], gf / t["wino"], t["w2x4"], gf / t["w2x4"], t["direct"], gf / t["direct"]))
     (c0, t0, _), (c1, t1, _) = rows[1], rows[-1]
-    for k in ("wino", "w2x4", "w2x4nf1"):
+    for k in ("wino", "w2x4"):
         per_chunk = (t1[k] - t0[k]) / ((c1 - c0) / 8)
         print("%-8s %.2f us per 8-channel chunk, fixed cost %.1f us" % (k, per_chunk * 1e3, (t0[k] - per_chunk * c0 / 8) * 1e3))
 
