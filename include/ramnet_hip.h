@@ -197,6 +197,15 @@ int ramnet_wino2x4_config(int min_wgs);
 int ramnet_fold_wino_supported(int Cout, int Cin);
 size_t ramnet_packed_weight_elems_fold_wino(int Cout, int Cin);
 int ramnet_pack_weight_fold_wino(const float *w_oihw, float *wp, int Cout, int Cin, void *stream);
+/* The rest of a folded decoder's weight algebra (once per optimizer step and layer; torch.einsum chains until round 3):
+ * _dgrad: Winograd weights of the flipped parity filters for the backward-data launch (RAMNET_IN_PARITY4; Cin % 64 == 0), 100*Cout*Cin floats;
+ * border weights: rows / cols [2 sides][5*Cin][2*Cout] = minus the taps the zero padding removes at the image border, and their
+ *   transposes [2][2*Cout][5*Cin] (backward-data operands);
+ * fold_unpack_wgrad: grad [Cout][Cin][5][5] += the fold of the pass's workspaces — w4 [64 = (py,px,ty,tx)][CinWs][Cout] (direct parity launches),
+ *   dU [4][25][CinWs][Cout] (Winograd-domain launches; may be NULL), wr / wc [2][5*Cin][2*Cout] (border-GEMM gradients) — which it zeroes.   */
+int ramnet_pack_weight_fold_wino_dgrad(const float *w_oihw, float *wp, int Cout, int Cin, void *stream);
+int ramnet_pack_border_weights(const float *w_oihw, float *rows, float *cols, float *rows_t, float *cols_t, int Cout, int Cin, void *stream);
+int ramnet_fold_unpack_wgrad(float *w4, float *dU, float *wr, float *wc, float *grad, int Cout, int Cin, int CinWs, void *stream);
 /* Head layers (RAMNET_ALGO_HEAD): OIHW [Cout<=32][Cin][5][5] -> [25*Cin rounded up to even][32], row = tap*Cin + channel.
  * ramnet_head_supported: does the head kernel serve this channel pair (Cin in {1,3,5,10}, Cout <= 32)?           */
 size_t ramnet_packed_weight_elems_head(int Cin);

@@ -82,6 +82,9 @@ _SIGS = {
     "ramnet_fold_wino_supported": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_packed_weight_elems_fold_wino": (C.c_size_t, [C.c_int, C.c_int]),
     "ramnet_pack_weight_fold_wino": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    "ramnet_pack_weight_fold_wino_dgrad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    "ramnet_pack_border_weights": (C.c_int, [_fp] * 5 + [C.c_int, C.c_int, _fp]),
+    "ramnet_fold_unpack_wgrad": (C.c_int, [_fp] * 5 + [C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpad2_fold": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_up2x_border_col2im": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_pad2_sum": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

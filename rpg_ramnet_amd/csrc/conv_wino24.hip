@@ -441,6 +441,121 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     return 0;
 }
 
+// Backward-data of the folded layer on conv_wino24_kernel (RAMNET_IN_PARITY4): Winograd weights of the FLIPPED parity filters with the roles
+// of the channels swapped — reduce over k = (parity class (p, q), output channel n), produce input channels c.  Layout = the forward pack's
+// with one class, chunks of 16 and 64-column blocks: i = ((((chunk*NB + nb)*25 + pos)*4 + cq)*4 + ks)*64 + l15*4 + j,
+// k = chunk*16 + ks*4 + j = (p*2 + q)*Cout + n, c = nb*64 + cq*16 + l15;
+// U[a][b][k][c] = sum_{t,s} G[a][t] G[b][s] W4[n][c][p][q][3-t][3-s],  W4 = FA_p w FA_q^T (double arithmetic, like the forward pack)
+__global__ void pack_weight_fold_wino_dgrad_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, size_t total) {
+    const double FA[2][4][5] = {{{.25, 0, 0, 0, 0}, {.75, .75, .25, 0, 0}, {0, .25, .75, .75, .25}, {0, 0, 0, .25, .75}},
+                                {{.75, .25, 0, 0, 0}, {.25, .75, .75, .25, 0}, {0, 0, .25, .75, .75}, {0, 0, 0, 0, .25}}};
+    const double G[5][4] = {{0.5, 0, 0, 0}, {-0.5, -0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3, 4.0 / 3}, {0, 0, 0, 1}};
+    const int NB = Cin / 64;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int j = (int)(r & 3), l15 = (int)((r >> 2) & 15), ks = (int)((r >> 6) & 3), cq = (int)((r >> 8) & 3);
+        r >>= 10;
+        const int pos = (int)(r % 25);
+        r /= 25;
+        const int nb = (int)(r % NB), chunk = (int)(r / NB);
+        const int k = chunk * 16 + ks * 4 + j, c = nb * 64 + cq * 16 + l15;
+        const int pq = k / Cout, n = k - pq * Cout, pp = pq >> 1, qq = pq & 1, a = pos / 5, b = pos % 5;
+        double ga[5], gb[5];
+        for (int kh = 0; kh < 5; ++kh) {
+            ga[kh] = 0, gb[kh] = 0;
+            for (int t = 0; t < 4; ++t) ga[kh] += G[a][t] * FA[pp][3 - t][kh], gb[kh] += G[b][t] * FA[qq][3 - t][kh];
+        }
+        double u = 0;
+        const float *wk = w + ((size_t)n * Cin + c) * 25;
+        for (int kh = 0; kh < 5; ++kh)
+            for (int kw = 0; kw < 5; ++kw) u += ga[kh] * gb[kw] * (double)wk[kh * 5 + kw];
+        wp[i] = (float)u;
+    }
+}
+
+// Border matrices of the folded layer (ops._folded_upsample_conv): the layer zero-pads where the folded form replicate-extends, so the taps
+// that fall outside the image are taken out again through two small GEMMs per border.  rows[side][kx*Cin + ci][slot*Cout + co] =
+// -sum_{a in LOST[side][slot]} w[co][ci][a][kx]; cols the same with the lost direction along kx; *_t = their transposes (backward-data).
+__global__ void pack_border_weights_kernel(const float *__restrict__ w, float *__restrict__ rows, float *__restrict__ cols, float *__restrict__ rows_t,
+                                           float *__restrict__ cols_t, int Cout, int Cin, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int co = (int)(r % Cout);
+        r /= Cout;
+        const int slot = (int)(r & 1);
+        r >>= 1;
+        const int ci = (int)(r % Cin);
+        r /= Cin;
+        const int kb = (int)(r % 5), side = (int)(r / 5);
+        // LOST = [[(0, 1), (0,)], [(4,), (3, 4)]]
+        const int a0 = side == 0 ? 0 : (slot == 0 ? 4 : 3), na = side == 0 ? (slot == 0 ? 2 : 1) : (slot == 0 ? 1 : 2);
+        const float *wk = w + ((size_t)co * Cin + ci) * 25;
+        float sr = 0.f, sc = 0.f;
+        for (int e = 0; e < na; ++e) sr += wk[(a0 + e) * 5 + kb], sc += wk[kb * 5 + (a0 + e)];
+        const size_t K = (size_t)kb * Cin + ci, N = (size_t)slot * Cout + co;
+        rows[((size_t)side * 5 * Cin + K) * 2 * Cout + N] = -sr;
+        cols[((size_t)side * 5 * Cin + K) * 2 * Cout + N] = -sc;
+        rows_t[((size_t)side * 2 * Cout + N) * 5 * Cin + K] = -sr;
+        cols_t[((size_t)side * 2 * Cout + N) * 5 * Cin + K] = -sc;
+    }
+}
+
+// End of a backward pass of a folded decoder: dW5[o][i][k][l] += sum_{p,q,t,s} FA[p][t][k] FA[q][s][l] dW4[p][q][t][s][i][o]
+//   - (border-GEMM gradients routed back to the taps they summed),   dW4 = w4 (direct parity launches) + G^T dU G (Winograd-domain launches).
+// One thread per (o, i); the workspaces it reads are zeroed for the next pass.
+__global__ void fold_unpack_wgrad_kernel(float *__restrict__ w4, float *__restrict__ dU, float *__restrict__ wr, float *__restrict__ wc,
+                                         float *__restrict__ grad, int Cout, int Cin, int CinWs) {
+    const float FA[2][4][5] = {{{.25f, 0, 0, 0, 0}, {.75f, .75f, .25f, 0, 0}, {0, .25f, .75f, .75f, .25f}, {0, 0, 0, .25f, .75f}},
+                               {{.75f, .25f, 0, 0, 0}, {.25f, .75f, .75f, .25f, 0}, {0, 0, .25f, .75f, .75f}, {0, 0, 0, 0, .25f}}};
+    const float G[5][4] = {{0.5f, 0, 0, 0}, {-0.5f, -0.5f, -0.5f, -0.5f}, {-1.f / 6, 1.f / 6, -1.f / 6, 1.f / 6}, {1.f / 6, 1.f / 3, 2.f / 3, 4.f / 3}, {0, 0, 0, 1.f}};
+    const size_t total = (size_t)Cout * Cin;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % Cout), i = (int)(idx / Cout);        // (consecutive threads: consecutive o = the workspaces' fastest index)
+        float g5[25];
+        for (int e = 0; e < 25; ++e) g5[e] = 0.f;
+        for (int pq = 0; pq < 4; ++pq) {
+            const int pp = pq >> 1, qq = pq & 1;
+            float d4[16];
+            for (int ts = 0; ts < 16; ++ts) {
+                float *cell = w4 + ((size_t)(pq * 16 + ts) * CinWs + i) * Cout + o;
+                d4[ts] = *cell;
+                *cell = 0.f;
+            }
+            if (dU != nullptr) {
+                for (int ab = 0; ab < 25; ++ab) {
+                    float *cell = dU + ((size_t)(pq * 25 + ab) * CinWs + i) * Cout + o;
+                    const float u = *cell;
+                    *cell = 0.f;
+                    const int a = ab / 5, b = ab % 5;
+                    for (int t = 0; t < 4; ++t)
+                        for (int s = 0; s < 4; ++s) d4[t * 4 + s] += G[a][t] * G[b][s] * u;
+                }
+            }
+            for (int t = 0; t < 4; ++t)
+                for (int s = 0; s < 4; ++s) {
+                    const float v = d4[t * 4 + s];
+                    for (int k = 0; k < 5; ++k) {
+                        const float fk = FA[pp][t][k] * v;
+                        for (int l = 0; l < 5; ++l) g5[k * 5 + l] += fk * FA[qq][s][l];
+                    }
+                }
+        }
+        for (int side = 0; side < 2; ++side)
+            for (int slot = 0; slot < 2; ++slot) {
+                const int a0 = side == 0 ? 0 : (slot == 0 ? 4 : 3), na = side == 0 ? (slot == 0 ? 2 : 1) : (slot == 0 ? 1 : 2);
+                for (int kb = 0; kb < 5; ++kb) {
+                    float *rc = wr + (((size_t)side * 5 + kb) * Cin + i) * 2 * Cout + (size_t)slot * Cout + o;
+                    float *cc = wc + (((size_t)side * 5 + kb) * Cin + i) * 2 * Cout + (size_t)slot * Cout + o;
+                    const float r = *rc, c = *cc;
+                    *rc = 0.f, *cc = 0.f;
+                    for (int e = 0; e < na; ++e) g5[(a0 + e) * 5 + kb] -= r, g5[kb * 5 + (a0 + e)] -= c;
+                }
+            }
+        float *g = grad + ((size_t)o * Cin + i) * 25;
+        for (int e = 0; e < 25; ++e) g[e] += g5[e];
+    }
+}
+
 }  // namespace ramnet
 
 using namespace ramnet;
@@ -460,6 +575,36 @@ extern "C" int ramnet_pack_weight_fold_wino(const float *w, float *wp, int Cout,
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(pack_weight_fold_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, kc, ncq,
                        (int)fold_wino_pair(Cout, Cin), total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pack_weight_fold_wino_dgrad(const float *w, float *wp, int Cout, int Cin, void *stream) {
+    RAMNET_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && Cin % 64 == 0 && (4 * Cout) % 16 == 0);
+    const size_t total = (size_t)100 * Cout * Cin;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weight_fold_wino_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Cout, Cin, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pack_border_weights(const float *w, float *rows, float *cols, float *rows_t, float *cols_t, int Cout, int Cin, void *stream) {
+    RAMNET_CHECK_ARG(w && rows && cols && rows_t && cols_t && Cout > 0 && Cin > 0);
+    const size_t total = (size_t)2 * 5 * Cin * 2 * Cout;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_border_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, rows, cols, rows_t, cols_t, Cout, Cin, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_fold_unpack_wgrad(float *w4, float *dU, float *wr, float *wc, float *grad, int Cout, int Cin, int CinWs, void *stream) {
+    RAMNET_CHECK_ARG(w4 && wr && wc && grad && Cout > 0 && Cin > 0 && CinWs >= Cin);
+    const size_t total = (size_t)Cout * Cin;
+    size_t blocks = (total + 127) / 128;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(fold_unpack_wgrad_kernel, dim3((unsigned)blocks), dim3(128), 0, (hipStream_t)stream, w4, dU, wr, wc, grad, Cout, Cin, CinWs);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

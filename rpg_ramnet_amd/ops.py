@@ -510,6 +510,25 @@ def fold_weights(w):
     return torch.einsum("ptk,qsl,oikl->oipqts", A, A, w.double())
 
 
+def fold_unpack_torch(w4, dU, wr, wc, Cout, Cin, CinWs):
+    """Plain-torch statement of ramnet_fold_unpack_wgrad (the product path runs the kernel; tests compare the two): the OIHW 5x5 gradient
+    that the workspaces of a folded decoder's backward pass stand for."""
+    A = _const("FOLD_A", FOLD_A, w4.device, torch.float32)                        # [p][t][k]
+    d4 = w4.view(2, 2, 4, 4, CinWs, Cout)[:, :, :, :, :Cin]
+    if dU is not None:        # dW4 += G^T dU G
+        G = _const("W24_G", W24_G, w4.device, torch.float32)
+        d4 = d4 + torch.einsum("at,bs,pqabio->pqtsio", G, G, dU.view(2, 2, 5, 5, CinWs, Cout))[:, :, :, :, :Cin]
+    g = torch.einsum("ptk,qsl,pqtsio->oikl", A, A, d4).contiguous()
+    r = wr.view(2, 5, Cin, 2, Cout)          # [side][kx][ci][slot][co]
+    c = wc.view(2, 5, Cin, 2, Cout)          # [side][ky][ci][slot][co]
+    for side in range(2):
+        for slot in range(2):
+            for a in FOLD_LOST[side][slot]:
+                g[:, :, a, :].sub_(r[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][kx]
+                g[:, :, :, a].sub_(c[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][ky]
+    return g
+
+
 def border_matrices(w):
     """(Wrows, Wcols), each [2 sides][5*Cin][2*Cout]: MINUS the sums of the taps the zero padding removes at the image border.
     Rows: K index = (kx, ci), N index = (slot, co), lost direction ky; columns the same with ky <-> kx."""
@@ -658,25 +677,33 @@ class ConvParam:
         v = (self._versions(self.weights), "fold24d")
         hit = self._packs.get("fold24d")
         if hit is None or hit[0] != v:
-            hit = self._packs["fold24d"] = (v, pack_fold_wino_dgrad(self._cat_w()))
+            L, w = H.lib(), self._cat_w()
+            out = torch.empty(L.ramnet_packed_weight_elems_fold_wino(self.Cout, self.Cin), device=w.device, dtype=torch.float32)
+            H.check(L.ramnet_pack_weight_fold_wino_dgrad(_p(w), _p(out), self.Cout, self.Cin, _st()), "ramnet_pack_weight_fold_wino_dgrad")
+            hit = self._packs["fold24d"] = (v, out)
         return hit[1]
 
-    def border_weights(self):
-        """border_matrices() of the current weights, cached per parameter version."""
+    def _border_pack(self):
+        """(rows, cols, rows^T, cols^T) of the border matrices (border_matrices() is the plain-torch statement of the same; one launch of
+        ramnet_pack_border_weights), cached per parameter version."""
         v = (self._versions(self.weights), "border")
         hit = self._packs.get("border")
         if hit is None or hit[0] != v:
-            hit = self._packs["border"] = (v, border_matrices(self._cat_w()))
+            w = self._cat_w()
+            rows, cols = (torch.empty(2, 5 * self.Cin, 2 * self.Cout, device=w.device) for _ in range(2))
+            rows_t, cols_t = (torch.empty(2, 2 * self.Cout, 5 * self.Cin, device=w.device) for _ in range(2))
+            H.check(H.lib().ramnet_pack_border_weights(_p(w), _p(rows), _p(cols), _p(rows_t), _p(cols_t), self.Cout, self.Cin, _st()),
+                    "ramnet_pack_border_weights")
+            hit = self._packs["border"] = (v, (rows, cols, rows_t, cols_t))
         return hit[1]
 
+    def border_weights(self):
+        """[2 sides][5*Cin][2*Cout] row / column border matrices of the current weights."""
+        return self._border_pack()[:2]
+
     def border_weights_t(self):
-        """border_weights() transposed to [2 sides][2*Cout][5*Cin] (the backward-data operand), cached per parameter version."""
-        v = (self._versions(self.weights), "border_t")
-        hit = self._packs.get("border_t")
-        if hit is None or hit[0] != v:
-            w_rows, w_cols = self.border_weights()
-            hit = self._packs["border_t"] = (v, (w_rows.transpose(1, 2).contiguous(), w_cols.transpose(1, 2).contiguous()))
-        return hit[1]
+        """border_weights() transposed to [2 sides][2*Cout][5*Cin] (the backward-data operand)."""
+        return self._border_pack()[2:]
 
     def bwd(self):
         return PackRef(self, 1)
@@ -744,26 +771,15 @@ class ConvParam:
         return self._ws_fold24
 
     def _finalize_fold(self):
-        """dW5 = sum_parities A_py^T dW4 A_px  -  (border GEMM gradients routed back to the taps they summed)."""
+        """dW5 += sum_parities A_py^T dW4 A_px  -  (border GEMM gradients routed back to the taps they summed), dW4 = the direct parity
+        launches' workspace + G^T dU G of the Winograd-domain launches: one launch (ramnet_fold_unpack_wgrad), which also zeroes the
+        workspaces for the next pass."""
         w4, wr, wc = self._ws_fold
         g = ensure_grad(self.weights[0])
-        A = _const("FOLD_A", FOLD_A, g.device, torch.float32)                        # [p][t][k]
-        d4 = w4.view(2, 2, 4, 4, self.CinWs, self.Cout)[:, :, :, :, :self.Cin]
-        if getattr(self, "_fold24_used", False):        # dW4 += G^T dU G
-            G = _const("W24_G", W24_G, g.device, torch.float32)
-            d4 = d4 + torch.einsum("at,bs,pqabio->pqtsio", G, G, self._ws_fold24.view(2, 2, 5, 5, self.CinWs, self.Cout))
-            self._ws_fold24.zero_()
-            self._fold24_used = False
-        g.add_(torch.einsum("ptk,qsl,pqtsio->oikl", A, A, d4))
-        lost = FOLD_LOST
-        r = wr.view(2, 5, self.Cin, 2, self.Cout)          # [side][kx][ci][slot][co]
-        c = wc.view(2, 5, self.Cin, 2, self.Cout)          # [side][ky][ci][slot][co]
-        for side in range(2):
-            for slot in range(2):
-                for a in lost[side][slot]:
-                    g[:, :, a, :].sub_(r[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][kx]
-                    g[:, :, :, a].sub_(c[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][ky]
-        w4.zero_(), wr.zero_(), wc.zero_()
+        dU = self._ws_fold24 if getattr(self, "_fold24_used", False) else None
+        H.check(H.lib().ramnet_fold_unpack_wgrad(_p(w4), _p(dU), _p(wr), _p(wc), _p(g), self.Cout, self.Cin, self.CinWs, _st()),
+                "ramnet_fold_unpack_wgrad")
+        self._fold24_used = False
         self._fold_used = False
 
     def discard(self):
