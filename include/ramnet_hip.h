@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -137,6 +137,11 @@ typedef struct ramnet_wgrad_desc {
                                      * slabs into slab 0 before ramnet_unpack_wgrad_wino().  Other algorithms ignore it.           */
 } ramnet_wgrad_desc;
 
+/* Process-wide A/B options (they replace the RAMNET_* environment knobs of rounds 1-3): "voxel_sorted" (1; 0 = row-band / atomic
+ * voxelizer forms), "fold_pair" (1; 0 = 32-channel folded decoders as 64 tiles x 32 channels — changes the layout ramnet_pack_weight_fold_wino
+ * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel).  ramnet_get_option: -1 if unknown.  */
+int ramnet_set_option(const char *name, int value);
+int ramnet_get_option(const char *name);
 const char *ramnet_last_error(void);
 int ramnet_abi_version(void);
 /* Symbol (template arguments included, as rocprofv3 prints it without spaces) of the MFMA kernel the calling thread's most

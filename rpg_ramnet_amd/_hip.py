@@ -60,6 +60,8 @@ class WgradDesc(C.Structure):
 _SIGS = {
     "ramnet_abi_version": (C.c_int, []),
     "ramnet_last_error": (C.c_char_p, []),
+    "ramnet_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "ramnet_get_option": (C.c_int, [C.c_char_p]),
     "ramnet_last_kernel": (C.c_char_p, []),
     "ramnet_gemm": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 9 + [C.c_long] * 3 + [_fp]),
     "ramnet_gemm2": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, _fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long,

@@ -176,8 +176,7 @@ static int launch_wgrad(const ramnet_wgrad_desc &d, const WgradDerived &q, hipSt
     const int gy = cdiv(q.src.Cin, WCK), gz = cdiv(d.Cout, WBN);
     // one resident wave of workgroups (256 CUs x blocks/CU the register budget admits): fewer pixel splits = fewer
     // atomic partial-sum merges, and every CU still gets an equal share
-    static const char *se = getenv("RAMNET_WGRAD_BLOCKS");    // tuning knob: target workgroups per launch
-    int splits = (se ? atoi(se) : 512) / (gy * gz);
+    int splits = g_opt_wgrad_blocks / (gy * gz);                // (ramnet_set_option("wgrad_blocks"): default 512)
     if (splits > q.ntiles) splits = q.ntiles;
     if (splits < 1) splits = 1;
     note_kernel("conv_wgrad_kernel<%d,%d,%d>", MAXT, NSUB, CSUB);

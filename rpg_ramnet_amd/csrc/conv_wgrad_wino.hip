@@ -433,16 +433,14 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     // batches of 8 tiles: a 2 x 16 or an 8 x 4 pixel strip, whichever pads the map less
     const bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 8) * 8 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 2) * 2;
     if (tall) q.bx_n = cdiv(d.Wo, 4), q.ty_n = cdiv(d.Ho, 8), q.nbatch = q.bx_n * q.ty_n * d.B;
-    // RAMNET_WGRAD_NF=4: 128 output channels per workgroup (one workgroup per CU, 512 registers per lane) where the layer has them.
-    // Isolated it is the faster form (six ConvGRU launches 1.522 -> 1.434 ms: 7.25 instead of 11 instructions per MFMA), in the
-    // co-scheduled training step it loses (200.2 -> 190.5 samples/s: a CU that holds such a workgroup holds nothing else, so the
-    // backward-data chain of the other stream no longer fills the gaps) — profiles/r03_h_tuning_notes.md.  Default: 64 channels.
-    static const char *nfe = getenv("RAMNET_WGRAD_NF");
-    const int nf = (d.Cout % 128 == 0 && nfe && nfe[0] == '4') ? 4 : 2;
+    // (A 128-channel workgroup — NF = 4: 256 accumulators, one workgroup per CU, 7.25 instead of 11 instructions per MFMA — was built in
+    // round 3: six ConvGRU launches 1.522 -> 1.434 ms alone, training step 200.2 -> 190.5 samples/s co-scheduled; its launch path and
+    // environment knob were removed in round 4, the kernel template keeps the parameter.)
+    const int nf = 2;
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
     // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room (measured
     // 256 ... 512: profiles/r03_h_tuning_notes.md)
-    int splits = (nf == 4 ? 256 : WGRAD_WINO_TARGET) / (gy * gz);
+    int splits = WGRAD_WINO_TARGET / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
     if (d.dw_slabs > 0 && splits > d.dw_slabs) splits = d.dw_slabs;
     if (splits < 1) splits = 1;
@@ -458,10 +456,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d,%d>", xmk, (int)gm, tall ? 2 : 8, nf);
 #define RAMNET_GO(XMv, GMv)                                                                                                  \
     do {                                                                                                                     \
-    if (nf == 4) {                                                                                                           \
-        if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 4>), grid, dim3(256), lds, st, d, q);        \
-        else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8, 4>), grid, dim3(256), lds, st, d, q);             \
-    } else if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 2>), grid, dim3(256), lds, st, d, q);     \
+    if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 2>), grid, dim3(256), lds, st, d, q);            \
     else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8, 2>), grid, dim3(256), lds, st, d, q);                 \
     } while (0)
     if (xmk == 1 && gm) RAMNET_GO(1, true);

@@ -354,8 +354,7 @@ __global__ void pack_weight_fold_wino_kernel(const float *__restrict__ w, float 
 }
 
 static bool fold_wino_pair(int Cout, int Cin) {
-    static const char *e = getenv("RAMNET_FOLD_PAIR");          // A/B knob: 0 = the 32-channel form (64 tiles x 32 channels, chunks of 8)
-    return Cout == 32 && Cin % 32 == 0 && !(e && e[0] == '0');
+    return Cout == 32 && Cin % 32 == 0 && g_opt_fold_pair;      // (ramnet_set_option("fold_pair", 0): the 32-channel form, 64 tiles x 32 channels, chunks of 8)
 }
 
 static bool fold_wino_geometry(int Cout, int Cin, int &kc, int &ncq) {

@@ -1000,8 +1000,7 @@ static unsigned char *voxel_id_scratch(hipStream_t st, size_t bytes) {
 
 static int launch_voxel_bands(const double *events, const long long *offsets, long long n_single, int n_grids, size_t max_events,
                               int bins, int W, int H, float *grids, hipStream_t st) {
-    static const char *vs = getenv("RAMNET_VOXEL_SORTED");
-    if (offsets != nullptr && max_events > 0 && max_events < (1u << 30) && W <= 32767 && H <= 32767 && !(vs && vs[0] == '0')) {      // sorted form
+    if (offsets != nullptr && max_events > 0 && max_events < (1u << 30) && W <= 32767 && H <= 32767 && g_opt_voxel_sorted) {      // sorted form
         const int nchunks = (int)((max_events + VS_CH - 1) / VS_CH);
         const int rows = voxel_band_rows(2 * bins, W, H, n_grids, 2 * nchunks + 16, 2);    // (8-byte cells)
         const int nbands = rows > 0 ? cdiv(H, rows) : 0;

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <unordered_set>
 #include <stdlib.h>
+#include <string.h>
 #include "common.hpp"
 
 namespace ramnet {
@@ -597,6 +598,26 @@ using namespace ramnet;
 extern "C" const char *ramnet_last_error(void) { return g_err; }
 extern "C" const char *ramnet_last_kernel(void) { return g_kernel; }
 extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
+
+// Process-wide A/B options (tests and tuning runs; the environment variables they replace are gone since round 4)
+namespace ramnet {
+int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512;
+}
+extern "C" int ramnet_set_option(const char *name, int value) {
+    RAMNET_CHECK_ARG(name != nullptr);
+    if (!strcmp(name, "voxel_sorted")) ramnet::g_opt_voxel_sorted = value != 0;
+    else if (!strcmp(name, "fold_pair")) ramnet::g_opt_fold_pair = value != 0;
+    else if (!strcmp(name, "wgrad_blocks")) { RAMNET_CHECK_ARG(value >= 1); ramnet::g_opt_wgrad_blocks = value; }
+    else RAMNET_CHECK_ARG(!"ramnet_set_option: unknown option");
+    return 0;
+}
+extern "C" int ramnet_get_option(const char *name) {
+    if (name == nullptr) return -1;
+    if (!strcmp(name, "voxel_sorted")) return ramnet::g_opt_voxel_sorted;
+    if (!strcmp(name, "fold_pair")) return ramnet::g_opt_fold_pair;
+    if (!strcmp(name, "wgrad_blocks")) return ramnet::g_opt_wgrad_blocks;
+    return -1;
+}
 
 extern "C" int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream) {
     RAMNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 4 == 0);

@@ -19,7 +19,7 @@ _NULL = None
 
 # 3x3 stride-1 layers (ConvGRU gates / candidate, residual blocks) run Winograd F(2x2,3x3) in fp32 — 2.25x fewer
 # multiplies, rounding error ~1e-6 relative (tests/test_hip_ops.py) — unless switched off (RAMNET_WINOGRAD=0).
-_WINOGRAD = _os.environ.get("RAMNET_WINOGRAD", "1") == "1"
+_WINOGRAD = True
 _WINO_MIN_CIN = 32        # smallest reduction depth that uses the Winograd kernels
 
 
@@ -58,12 +58,12 @@ def get_winograd():
 # UpsampleConvLayer forward as four 4x4 parity convolutions of the low-resolution input (16 instead of 25 MACs per output,
 # no interpolation in the loader) plus small border-correction GEMMs.  RAMNET_FOLD_UPSAMPLE=0 /
 # set_fold_upsample(False) keeps the direct 5x5 kernel with the bilinear loader.
-_FOLD_UP = _os.environ.get("RAMNET_FOLD_UPSAMPLE", "1") == "1"
+_FOLD_UP = True
 
 
-_FOLD_WINO = _os.environ.get("RAMNET_FOLD_WINOGRAD", "1") == "1"
+_FOLD_WINO = True
 _FOLD_WINO_MIN_COUT = 32
-_FOLD_WINO_WGRAD = _os.environ.get("RAMNET_FOLD_WINOGRAD_WGRAD", "1") == "1"
+_FOLD_WINO_WGRAD = True
 _SAVE_XPAD = False         # keep pad2(x + skip) of a folded decoder layer for its backward: +2 GB, no measurable gain
 
 
@@ -74,13 +74,16 @@ def set_fold_winograd_wgrad(on):
     _FOLD_WINO_WGRAD = bool(on)
 
 
-_FOLD_PAIR_ENV = _os.environ.get("RAMNET_FOLD_PAIR", "1") != "0"      # read ONCE, like conv_wino24.hip's function-local static
+def set_fold_pair(on):
+    """32-channel folded decoders in the pair form (default) or as 64 tiles x 32 channels; the library option and the packs follow."""
+    H.check(H.lib().ramnet_set_option(b"fold_pair", int(bool(on))), "set_option")
+    invalidate_packs()
 
 
 def _fold_pair(Cout, Cin):
     """32-channel layers (the last decoder): both column parities of a row parity in one 64-column workgroup that shares the
     transformed input (conv_wino24_kernel<.., PAIR>); RAMNET_FOLD_PAIR=0 keeps the 64-tile x 32-channel form."""
-    return Cout == 32 and Cin % 32 == 0 and _FOLD_PAIR_ENV
+    return Cout == 32 and Cin % 32 == 0 and bool(H.lib().ramnet_get_option(b"fold_pair"))
 
 
 def _fold_wino_ok(Cin, Cout):
@@ -197,7 +200,7 @@ def uses_winograd(taps, w, stride, epi, in_mode, C0, C1):
 
 # The two 5x5 head layers (1 / 5 real input channels -> 32 maps at full resolution) on their own kernel:
 # dense (tap, channel) reduction with the weights in registers.  RAMNET_HEAD_KERNEL=0 / set_head_kernel(False): generic kernel.
-_HEAD = _os.environ.get("RAMNET_HEAD_KERNEL", "1") == "1"
+_HEAD = True
 
 
 def set_head_kernel(on):
@@ -293,7 +296,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
 # (its inputs are ready), the end-of-backward fold waits for the side stream; inputs are record_stream()'ed so the
 # caching allocator does not recycle them while the side stream still reads them.
 _SIDE = {}
-_USE_SIDE = _os.environ.get("RAMNET_WGRAD_STREAM", "0") == "1"
+_USE_SIDE = False
 
 
 def set_wgrad_overlap(on):
@@ -307,7 +310,7 @@ def set_wgrad_overlap(on):
 # update k: with set_decoder_overlap(True) the model runs its decoders on a second stream, in forward and — because
 # autograd runs a node's backward on its forward stream — in backward, so the two kernel chains fill each other's tails.
 _DECODE = {}
-_USE_DECODE = _os.environ.get("RAMNET_DECODE_STREAM", "0") == "1"
+_USE_DECODE = False
 _DECODE_USED = set()
 
 
@@ -995,7 +998,7 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
 
 # Stride-2 5x5 layers (the encoders) as 3x3 stride-1 convolutions of the space-to-depth input on the Winograd kernels
 # (DESIGN 3.1d).  RAMNET_S2D=0 / set_space_to_depth(False) keeps the direct stride-2 kernels.
-_S2D = _os.environ.get("RAMNET_S2D", "1") == "1"
+_S2D = True
 
 
 def set_space_to_depth(on):
@@ -1083,7 +1086,7 @@ def _folded_upsample_wgrad(x, skip, dy, y, cp, xpad=None):
 # Backward-data of the folded upsample-conv: the adjoint of (four parity convolutions of the replicate-padded input + border GEMMs),
 # i.e. conv_wino24_kernel over the parity sub-grids of dy * mask with the flipped filters -> gradient of the padded tensor ->
 # replicate-padding adjoint, plus the border GEMMs' adjoint scattered through the bilinear taps.  RAMNET_FOLD_DGRAD=0: direct 5x5 kernel on the full-resolution grid + bilinear adjoint.
-_FOLD_DGRAD = _os.environ.get("RAMNET_FOLD_DGRAD", "1") == "1"
+_FOLD_DGRAD = True
 
 
 def set_fold_dgrad(on):

@@ -145,19 +145,32 @@ def test_residual_block_full_size(bench_schedule):
     run_pair64(First(), lambda sd, a: torch.relu(F.conv2d(a, sd["conv1.weight"], sd["conv1.bias"], 1, 1)), [x])
     t = torch.relu(torch.randn(B, 256, H // 8, W // 8))
     run_pair64(Second(), lambda sd, a, r: torch.relu(F.conv2d(a, sd["conv2.weight"], sd["conv2.bias"], 1, 1) + r), [t, x])
-    # and the block as a whole: forward to 2e-4, gradients with the tolerance of the network-level tests
+    # and the block as a whole: forward to 2e-4, gradients with the tolerance of the network-level tests.  The hidden ReLU: an
+    # activation whose pre-activation is ~0 can take a different side in fp32 than in the fp64 oracle; ONE such flip changes the input
+    # gradient at the 3 x 3 pixels around it in all 256 channels and a whole rank-1 slice of dW1 (measured with F(2x4,3x3), whose fp32
+    # error is ~3e-6 of the maximum against ~1e-6 for F(2x2): 1 flip among 2.8 M activations, 4.8e-3 on conv1.weight).  The derivative
+    # at a kink is therefore compared ON THE BRANCH THE FP32 EVALUATION TOOK: the oracle's hidden mask is the HIP block's own
+    # (relu(conv1(x)) through the same operator), the values stay fp64; at most a handful of activations may differ, each within rounding of 0.
     m = ResidualBlock(256, 256).to(dev())
     sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
     xc, xg = x.double().requires_grad_(True), nhwc(x).to(dev()).requires_grad_(True)
-    ref, got = ramnet_ref.residual_block(_pre(sd), "L", xc), m(xg)
+    with torch.no_grad():
+        t_hip = ops.ConvAct.apply(nhwc(x).to(dev()), None, m.conv1.weight, m.conv1.bias, m._cp("c1", [m.conv1.weight], [m.conv1.bias]), 1, True, False)
+    t64 = F.conv2d(xc, sd["conv1.weight"], sd["conv1.bias"], 1, 1)
+    mask = nchw(t_hip).cpu() > 0
+    flips = mask != (t64.detach() > 0)
+    assert int(flips.sum()) <= 8 and float(t64.detach()[flips].abs().max() if flips.any() else 0.0) < 1e-4 * float(t64.detach().abs().max())
+    ref = torch.relu(F.conv2d(t64 * mask.double(), sd["conv2.weight"], sd["conv2.bias"], 1, 1) + xc)
+    got = m(xg)
     assert_close(nchw(got).detach().cpu().numpy(), ref.detach().numpy(), TOL, "block forward")
+    assert_close(ref.detach().numpy(), ramnet_ref.residual_block(_pre({k: v.detach() for k, v in sd.items()}), "L", x.double()).numpy(), 1e-6,
+                 "masked oracle == oracle")
     wgt = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
     wgt[(nchw(got).detach().cpu() == 0) != (ref.detach() == 0)] = 0.0
     (ref * wgt.double()).sum().backward()
     (nchw(got) * wgt.to(dev())).sum().backward()
     torch.cuda.synchronize()
-    bad = (nchw(xg.grad).cpu().double() - xc.grad).abs() > TOL * float(xc.grad.abs().max())
-    assert float(bad.float().mean()) < 1e-4, "input gradient differs beyond isolated kink flips"
+    assert_close(nchw(xg.grad).cpu().numpy(), xc.grad.numpy(), TOL, "block grad input")
     for k, p in m.named_parameters():
         assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "block grad " + k)
 

@@ -735,28 +735,24 @@ def test_voxel_sorted_form_exact_and_bit_reproducible():
         assert np.array_equal(got == 0, want == 0) or np.abs(got[(got == 0) != (want == 0)]).max() < 1e-12
 
 
-def test_voxel_row_band_fallback_form(monkeypatch):
-    """RAMNET_VOXEL_SORTED=0 (and any launch inside a stream capture that finds no scratch) keeps the row-band kernels: same grids up to
-    the order of their fp32 LDS atomics.  (The knob is read once per process: the library is driven in a child interpreter.)"""
-    import subprocess
-    import sys
-    code = """
-import numpy as np, torch, sys
-sys.path.insert(0, %r)
-from recipe import synth_events
-from rpg_ramnet_amd import voxel
-from oracle import voxel_ref
-rng = np.random.default_rng(3)
-lists = [synth_events(rng, n, 346, 260) for n in [5000, 0, 1, 7000] + [1500] * 14]
-got = voxel.events_to_voxel_grids([torch.from_numpy(e).cuda() for e in lists], 5, 346, 260)
-for g, ev in zip(got, lists):
-    ref = voxel_ref.events_to_voxel_grid(ev, 5, 346, 260) if len(ev) else np.zeros((5, 260, 346), np.float32)
-    np.testing.assert_allclose(g.cpu().numpy(), ref, atol=2e-5)
-print("fallback ok")
-""" % os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    env = dict(os.environ, RAMNET_VOXEL_SORTED="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout + r.stderr
+def test_voxel_row_band_fallback_form():
+    """ramnet_set_option("voxel_sorted", 0) (and any launch inside a stream capture that finds no scratch) keeps the row-band kernels:
+    same grids up to the order of their fp32 LDS atomics."""
+    from rpg_ramnet_amd import voxel
+    from recipe import synth_events
+    L = Hh.lib()
+    rng = np.random.default_rng(3)
+    lists = [synth_events(rng, n, 346, 260) for n in [5000, 0, 1, 7000] + [1500] * 14]
+    assert L.ramnet_get_option(b"voxel_sorted") == 1 and L.ramnet_get_option(b"no_such_option") == -1
+    Hh.check(L.ramnet_set_option(b"voxel_sorted", 0), "set_option")
+    try:
+        got = voxel.events_to_voxel_grids([torch.from_numpy(e).to(dev()) for e in lists], 5, 346, 260)
+    finally:
+        Hh.check(L.ramnet_set_option(b"voxel_sorted", 1), "set_option")
+    for g, ev in zip(got, lists):
+        ref = voxel_ref.events_to_voxel_grid(ev, 5, 346, 260) if len(ev) else np.zeros((5, 260, 346), np.float32)
+        np.testing.assert_allclose(g.cpu().numpy(), ref, atol=2e-5)
+    assert L.ramnet_set_option(b"no_such_option", 1) != 0
 
 
 @pytest.mark.parametrize("B,H,W,nan_frac", [(2, 32, 48, 0.0), (3, 24, 40, 0.2), (1, 16, 16, 0.5)])
