@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=8)
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=344)
+    ap.add_argument("--full-frame", action="store_true",
+                    help="the raw 260 x 346 frame (SURVEY 8d 'also report 264x352'): inputs and targets at 260 x 346, model.set_full_frame() reflect-pads "
+                         "them to 264 x 352 inside the input repack and crops the predictions back (utils/inference_utils.py:287-314)")
     ap.add_argument("--events-per-grid", type=int, default=200000)
     ap.add_argument("--bins", type=int, default=5, help="event voxel-grid bins (configs[4] uses 10)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for 1-GPU functional tests)")
@@ -563,7 +566,12 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the children's stdout carries rank 0's JSON line; anything else a library prints there (gloo's connection banner) goes to stderr, so that
+    # this process prints exactly ONE line on stdout as the single-process run does
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+    return p.wait()
 
 
 def main():
@@ -615,6 +623,9 @@ def main():
     ops.set_wgrad_slabs(not args.wgrad_atomic)
     w24 = args.wino2x4.split(",")
     ops.set_winograd_2x4(w24[0], min_wgs=int(w24[1]) if len(w24) > 1 else None)
+    if args.full_frame:
+        assert args.mode == "train", "--full-frame: the training step (the graph runtimes of the other modes have static 8-aligned buffers)"
+        args.height, args.width, args.no_extras = 260, 346, True
     K, bins, B, L, H, W = 5, args.bins, args.batch, args.seq_len, args.height, args.width
     cfg = dict(RELEASED, num_bins_events=bins, gpu=local, every_x_rgb_frame=K, baseline=False, loss_composition=["image", "events4"],
                state_combination=args.state)
@@ -622,6 +633,8 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):
         model = ERGB2DepthRecurrent(cfg)
     model = model.to(model.gpu)
+    if args.full_frame:
+        model.set_full_frame(True)
     timer = KernelTimer()
     if not args.no_kernel_timing:
         timer.install()
@@ -878,14 +891,16 @@ def main():
         samples = world * B * L * args.steps
         if args.mode == "stream":
             updates = world * B * (sum(sched) + L) * args.steps
-        out = {"metric": "depth samples/sec (346x260 cropped to %dx%d, %d-bin grids, K=5 grids + 1 frame per sample; %s)"
-                         % (H, W, bins, {"train": "training step", "infer": "inference", "stream": "asynchronous streaming inference"}[args.mode]),
+        geom = ("346x260 full frame, reflect-padded to 264x352 in the input repack" if args.full_frame else
+                "346x260 cropped to %dx%d" % (H, W) if (H, W) == (256, 344) else "%dx%d" % (W, H))
+        out = {"metric": "depth samples/sec (%s, %d-bin grids, K=5 grids + 1 frame per sample; %s)"
+                         % (geom, bins, {"train": "training step", "infer": "inference", "stream": "asynchronous streaming inference"}[args.mode]),
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "EventScape-shaped 346x260 -> %dx%d crop, %d event bins, K=5, batch %d/GPU, seq-len %d, "
+               "config": {"workload": "EventScape-shaped %s, %d event bins, K=5, batch %d/GPU, seq-len %d, "
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam, backward-weights %s"
-                                      % (H, W, bins, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream") +
+                                      % (("346x260 -> 256x344 crop" if (H, W) == (256, 344) else geom), bins, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream") +
                                       (", decoders on a second stream" if args.overlap_decoder and args.mode == "train" else ""),
                           "global_batch": B * world, "seq_len": L, "parallelism": "dp%d" % world},
                "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
@@ -968,7 +983,8 @@ def main():
                                                    "pass: the step is MFMA-bound (530-810 FLOP/B vs a 20 FLOP/B ridge), so its HBM fraction "
                                                    "is low BECAUSE it is compute-bound (SURVEY 8d); mfma_frac = executed-MFMA fraction")
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, H, W, K, args)
+            # (full-frame mode: the oracle, like the reference network, only takes multiples of 8 — it is timed at the padded size)
+            out["cpu_baseline"] = cpu_baseline(cfg, 264 if args.full_frame else H, 352 if args.full_frame else W, K, args)
             if args.cpu_infer_baseline and args.mode == "train":
                 out["cpu_baseline_infer"] = cpu_baseline(cfg, H, W, K, args, mode="infer")
         print(json.dumps(out))
