@@ -31,10 +31,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "rpg_ramnet_amd")
 OUT = os.path.join(PKG, "abl")
 SCRATCH = os.environ.get("RAMNET_ABL_SCRATCH", "/tmp/ramnet_abl")
-MASKS = {"conv_wgrad_wino": [0, 1, 2, 4, 8, 16, 3, 7, 15, 128, 256, 384],
+MASKS = {"conv_wino6": [0, 1, 2, 4, 8, 32, 6, 7, 39, 47, 64, 128, 192],        # F(2x4,3x3): the six ConvGRU launches at B = 8 run it
+         "conv_wgrad_wino": [0, 1, 2, 4, 8, 16, 3, 7, 15, 128, 256, 384],
          "conv_wino": [0, 1, 2, 4, 8, 16, 32, 3, 7, 39, 47, 64, 128, 192],
          "conv_wino24": [0, 1, 2, 4, 8, 32, 39, 47, 64, 128, 192]}        # the folded decoders: timed with `bench_layers.py --only dec`
-ONLY = {"conv_wgrad_wino": "gru", "conv_wino": "gru", "conv_wino24": "dec"}
+ONLY = {"conv_wgrad_wino": "gru", "conv_wino": "gru", "conv_wino24": "dec", "conv_wino6": "gru"}
 
 
 def _sub(s, old, new, count=1):
@@ -54,8 +55,11 @@ def patch_wgrad(s):
     s = _sub(s, "            auto stage = [&](int k) {\n", "            auto stage = [&](int k) {\n                if (ABL & 1) return;\n")
     s = _sub(s, "if (st == 2) __syncthreads();", "if (st == 2 && !(ABL & 8)) __syncthreads();")
     s = _sub(s, "        for (; batch <= last; batch += step, cur ^= 1) {", "        for (; batch <= ((ABL & 128) ? -1 : last); batch += step, cur ^= 1) {")
-    s = _sub(s, "                if (c < Cin && n < p.Cout)\n                    atomicAdd(",
-             "                if (c < Cin && n < p.Cout && (!(ABL & 256) || acc[pl][f][r] == 123.456f))\n                    atomicAdd(")
+    # (256: no join of the partial sums — the slab read-modify-write of round 4 and the atomic form)
+    s = _sub(s, "                if (c < Cin && n < p.Cout) col[(size_t)c * p.Cout] = old[g & 1][r] +",
+             "                if (c < Cin && n < p.Cout && (!(ABL & 256) || acc[pl][f][r] == 123.456f)) col[(size_t)c * p.Cout] = old[g & 1][r] +")
+    s = _sub(s, "                    if (c < Cin && n < p.Cout) atomicAdd(col + (size_t)c * p.Cout,",
+             "                    if (c < Cin && n < p.Cout && (!(ABL & 256) || acc[pl][f][r] == 123.456f)) atomicAdd(col + (size_t)c * p.Cout,")
     return _sub(s, "__builtin_amdgcn_sched_barrier(0);", "if (!(ABL & 16)) __builtin_amdgcn_sched_barrier(0);", 0)
 
 
@@ -82,6 +86,33 @@ def patch_wino(s):
              " if (t == 123.456f) p.out[0] = t; return; }\n    // ---- exchange: column transform of the wave's row")
     s = _sub(s, "    for (int chunk = 0; chunk < nch; chunk += 2) {", "    for (int chunk = 0; chunk < ((ABL & 128) ? 0 : nch); chunk += 2) {")
     return _sub(s, "__builtin_amdgcn_sched_barrier(0);", "if (!(ABL & 16)) __builtin_amdgcn_sched_barrier(0);", 0)
+
+
+def patch_wino6(s):
+    """F(2x4,3x3): 1 no patch staging, 2 no LDS reads, 4 no transform arithmetic (row combination + column transform), 8 no barrier,
+    32 no weight loads, 64 no epilogue, 128 no main loop."""
+    s = _sub(s, '#include "conv_wino_common.hpp"\n',
+             '#include "conv_wino_common.hpp"\n#ifndef ABL\n#define ABL 0\n#endif\n#define OPQ4(QQ) asm volatile("" : "+v"((QQ).x), "+v"((QQ).y), "+v"((QQ).z), "+v"((QQ).w))\n'
+             '#define OPQ1(QQ) asm volatile("" : "+v"(QQ))\n')
+    s = _sub(s, """                if (!(s & 1)) qa[s >> 1] = ld4(pnext + pra + (s >> 1) * 4);
+                else qb[s >> 1] = ld4(pnext + prb + (s >> 1) * 4);""",
+             """                if (ABL & 2) { if (!(s & 1)) OPQ4(qa[s >> 1]); else OPQ4(qb[s >> 1]); }
+                else if (!(s & 1)) qa[s >> 1] = ld4(pnext + pra + (s >> 1) * 4);
+                else qb[s >> 1] = ld4(pnext + prb + (s >> 1) * 4);""")
+    s = _sub(s, "                tn[j][c] = fmaf(sb, y, x);\n", "                if (ABL & 4) tn[j][c] = x; else tn[j][c] = fmaf(sb, y, x);\n")
+    s = _sub(s, "            if (g + LD < 6) colop(g + LD, (g + LD + 2 * PAR) & 3, i, tc);\n            else colop(g + LD - 6, (g + LD - 6 + 2 * (PAR ^ 1)) & 3, i, tn);",
+             "            if (ABL & 4) { if (i >= 4) { OPQ1(vb[(g + LD + 2 * PAR) & 3][i - 4]); } }\n"
+             "            else if (g + LD < 6) colop(g + LD, (g + LD + 2 * PAR) & 3, i, tc);\n            else colop(g + LD - 6, (g + LD - 6 + 2 * (PAR ^ 1)) & 3, i, tn);")
+    s = _sub(s, "            if (s >= 28 && s < 31) pr.store_slot(pfree, q.src, c2, s - 28);\n            if (s == 33 || s == 35 || s == 37) pr.load_slot(q.src, c3, (s - 33) >> 1, clast);",
+             "            if (!(ABL & 1)) { if (s >= 28 && s < 31) pr.store_slot(pfree, q.src, c2, s - 28);\n            if (s == 33 || s == 35 || s == 37) pr.load_slot(q.src, c3, (s - 33) >> 1, clast); }")
+    s = _sub(s, "            if ((s & 15) == 15) breg[g - 1][0] = wload(cw, (g - 1) * 2), breg[g][0] = wload(cw, g * 2);",
+             "            if ((s & 15) == 15) { if (ABL & 32) { OPQ4(breg[g - 1][0]); OPQ4(breg[g][0]); } else breg[g - 1][0] = wload(cw, (g - 1) * 2), breg[g][0] = wload(cw, g * 2); }")
+    s = _sub(s, "        __syncthreads();                           // patch(i+2) visible; patch(i+1) free", "        if (!(ABL & 8)) __syncthreads();")
+    s = _sub(s, "    } while (chunk < nch);", "    } while (chunk < ((ABL & 128) ? 0 : nch));")
+    s = _sub(s, "    // ---- exchange: column transform of the wave's row (M A4: 4 of 6 columns), all waves -> LDS.",
+             "    if (ABL & 64) { float t = 0.f; for (int i = 0; i < 6; ++i) for (int r = 0; r < 16; ++r) t += acc[i][0][r]; if (t == 123.456f) p.out[0] = t; return; }\n"
+             "    // ---- exchange: column transform of the wave's row (M A4: 4 of 6 columns), all waves -> LDS.")
+    return s
 
 
 def patch_wino24(s):
@@ -114,7 +145,9 @@ def build():
     os.makedirs(os.path.join(SCRATCH, "include"))
     shutil.copytree(B.CSRC, src)
     shutil.copy(os.path.join(ROOT, "include", "ramnet_hip.h"), os.path.join(SCRATCH, "include"))
-    for stem, fn in (("conv_wgrad_wino", patch_wgrad), ("conv_wino", patch_wino), ("conv_wino24", patch_wino24)):
+    for stem, fn in (("conv_wgrad_wino", patch_wgrad), ("conv_wino", patch_wino), ("conv_wino24", patch_wino24), ("conv_wino6", patch_wino6)):
+        if stem not in MASKS:
+            continue
         p = os.path.join(src, stem + ".hip")
         with open(p) as f:
             s = f.read()
@@ -126,7 +159,7 @@ def build():
     def one(job):
         stem, m = job
         obj = os.path.join(SCRATCH, "%s_%d.o" % (stem, m))
-        subprocess.run([hipcc] + B.FLAGS + ["-DABL=%d" % m, "-c", os.path.join(src, stem + ".hip"), "-o", obj], check=True)
+        subprocess.run([hipcc] + B.FLAGS + B.EXTRA_FLAGS.get(stem + ".hip", []) + ["-DABL=%d" % m, "-c", os.path.join(src, stem + ".hip"), "-o", obj], check=True)
         others = [os.path.join(B.OBJ, f) for f in os.listdir(B.OBJ) if f.endswith(".o") and f != stem + ".o"]
         lib = os.path.join(OUT, "%s_%d.so" % (stem, m))
         subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + others + [obj], check=True)
