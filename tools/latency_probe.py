@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from rpg_ramnet_amd import ops  # noqa: E402
-from rpg_ramnet_amd.graph import GraphedStream  # noqa: E402
+from rpg_ramnet_amd.graph import GraphedStream, TimeBatchedStream  # noqa: E402
 from rpg_ramnet_amd.model.model import ERGB2DepthRecurrent  # noqa: E402
 
 
@@ -56,6 +56,8 @@ def main():
     for pipelined in (False,):
         g = GraphedStream(m, 1, H, W, pipelined=pipelined)
         print("hipGraph replays (update, decode), serial: %.3f ms" % timed(lambda: g.wait(g.update_events(ev))))
+    tb = TimeBatchedStream(m, 1, H, W, max_events=1)      # groups of ONE measurement: encoder chain, then the three scales' updates side by side, then the decode
+    print("hipGraph chains, per-scale updates side by side (TimeBatchedStream, groups of 1): %.3f ms" % timed(lambda: tb.wait(tb.push_events(ev))))
 
 
 if __name__ == "__main__":
