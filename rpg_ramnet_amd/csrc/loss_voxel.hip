@@ -961,11 +961,13 @@ static double *si_scratch(hipStream_t st) {
     static std::map<std::pair<int, hipStream_t>, double *> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    // never handed to a CAPTURING stream, existing buffer or not: a hipGraph would bake the pointer and the self-resetting ticket in, and
+    // graphs replayed concurrently (torch's captures share one stream handle) would share them — captures use memset + atomics
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     auto it = bufs.find({dev, st});
     if (it != bufs.end()) return it->second;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
     void *p = nullptr;
     const size_t bytes = (3 * 256 + 1) * sizeof(double);
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
@@ -981,11 +983,11 @@ static unsigned char *voxel_id_scratch(hipStream_t st, size_t bytes) {
     static std::map<std::pair<int, hipStream_t>, std::pair<unsigned char *, size_t>> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // (a capture never sees library scratch: it could be freed / regrown under the graph)
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     auto &b = bufs[{dev, st}];
     if (b.second >= bytes) return b.first;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
     if (b.first) {
         if (hipStreamSynchronize(st) != hipSuccess) return nullptr;      // launches that still read the old buffer
         (void)hipFree(b.first);

@@ -58,14 +58,16 @@ def stream_dataset(model, dataset, every_x_rgb_frame, output_folder=None, settle
                 sequence_idx = 0
             package = {k: v[None, :] for k, v in item[0].items()}
             if use_tb:
-                if tb is None:
-                    from .graph import TimeBatchedStream
-                    tb = TimeBatchedStream(model, 1, package['image'].shape[2], package['image'].shape[3], max_events=K + 1)
+                hw = tuple(package['image'].shape[2:])
+                if tb is None or (tb.H, tb.W) != hw:                # a ConcatDatasetCustom may mix recordings of different resolution:
+                    from .graph import TimeBatchedStream          # the runtime's static buffers are per resolution -> a new one
+                    tb = TimeBatchedStream(model, 1, hw[0], hw[1], max_events=K + 1)
                 if sequence_idx == 0:
                     tb.reset()                                    # a new recording starts from the zero state
                 for k in range(K):
                     tb.push_events(package['events{}'.format(k)])
-                out = tb.wait(tb.push_image(package['image']))    # [K + 1, 1, 1, H, W]
+                out = tb.wait(tb.push_image(package['image']))    # [K + 1, 1, 1, H, W]: views of a static buffer, valid until the second-next
+                #                                                   group of this shape (they are written to disk right below)
                 preds = {'events{}'.format(k): out[k] for k in range(K)}
                 preds['image'] = out[K]
                 new_super, new_lstm = prev_super, prev_lstm        # (the runtime carries the state)
