@@ -139,7 +139,9 @@ typedef struct ramnet_wgrad_desc {
 
 /* Process-wide A/B options (they replace the RAMNET_* environment knobs of rounds 1-3): "voxel_sorted" (1; 0 = row-band / atomic
  * voxelizer forms), "fold_pair" (1; 0 = 32-channel folded decoders as 64 tiles x 32 channels — changes the layout ramnet_pack_weight_fold_wino
- * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel).  ramnet_get_option: -1 if unknown.  */
+ * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel), "wgrad_wino_blocks" (384, <= 384: the same for the
+ * Winograd backward-weights kernel — measured with F(2x4) in place: 384 -> 215.9, 320 -> 210.7, 256 -> 209.7, 192 -> 193.6 samples/s).
+ * ramnet_get_option: -1 if unknown.  */
 int ramnet_set_option(const char *name, int value);
 int ramnet_get_option(const char *name);
 const char *ramnet_last_error(void);

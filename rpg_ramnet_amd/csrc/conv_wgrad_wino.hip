@@ -440,7 +440,7 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
     // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room (measured
     // 256 ... 512: profiles/r03_h_tuning_notes.md)
-    int splits = WGRAD_WINO_TARGET / (gy * gz);
+    int splits = g_opt_wgrad_wino_blocks / (gy * gz);            // (<= WGRAD_WINO_TARGET: the slabs are sized for that)
     if (splits > q.nbatch) splits = q.nbatch;
     if (d.dw_slabs > 0 && splits > d.dw_slabs) splits = d.dw_slabs;
     if (splits < 1) splits = 1;
