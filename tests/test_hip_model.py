@@ -57,6 +57,18 @@ def test_reference_golden_forward(tag):
     run_fixture(tag)
 
 
+@pytest.mark.parametrize("tag", ["seeded_ramnet", "seeded_ramnet_bins10", "seeded_base_rgb"])
+def test_reference_golden_forward_f2x4(tag):
+    """The same reference-generated fixtures with every eligible 3x3 launch forced onto the F(2x4,3x3) kernel (csrc/conv_wino6.hip; the
+    library's size test would keep these small maps on F(2x2,3x3)): 1e-3 max-norm and element-wise, ragged 2 x 4 tilings included."""
+    from rpg_ramnet_amd import ops
+    ops.set_winograd_2x4("force")
+    try:
+        run_fixture(tag)
+    finally:
+        ops.set_winograd_2x4("auto")
+
+
 @pytest.mark.parametrize("tag", ["small_gru", "small_lstm", "small_gru_enclstm", "small_tconv", "small_base_rgb",
                                  "small_base_e", "small_base_ergb0"])
 def test_reference_golden_explicit_weights(tag):
