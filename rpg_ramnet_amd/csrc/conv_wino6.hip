@@ -1,6 +1,6 @@
-// Winograd F(2x4, 3x3) convolution for gfx950 (MI355X): forward and backward-data of the 3x3 stride-1 layers of the RAM-Net path on
-// the two FINE scales — ConvGRU gates / candidate (submodules.py:447-452) and every backward-data launch of those layers — exact-fp32
-// arithmetic on v_mfma_f32_32x32x2_f32.
+// Winograd F(2x4, 3x3) convolution for gfx950 (MI355X): forward and backward-data of the 3x3 stride-1 layers of the RAM-Net path at the
+// training batch — ConvGRU gates / candidate (submodules.py:447-452), residual blocks (:200-215) and every backward-data launch of those
+// layers (launches of >= 150 64-channel x 256-pixel output blocks: wino6_eligible) — exact-fp32 arithmetic on v_mfma_f32_32x32x2_f32.
 //
 //   Y = A2^T [ sum_ci (G2 g G4^T) .* (B2^T d B4) ] A4        F(2,3) down the rows, F(4,3) along the columns (Lavin & Gray 2016)
 //
