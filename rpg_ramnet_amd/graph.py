@@ -165,7 +165,11 @@ class TimeBatchedStream:
         T = max_events + 1
         self.in_ev = [torch.zeros(max_events * B, model.num_bins_events, H, W, device=dev) for _ in range(2)]
         self.in_im = [torch.zeros(B, model.num_bins_rgb, H, W, device=dev) for _ in range(2)]
-        self.carry = model.init_states(B, H, W)
+        # full-frame mode (model.set_full_frame(): raw 260 x 346 frames): the inputs are reflect-padded inside the repack, the states and
+        # the decoders run at the padded size, the returned predictions are the cropped window of the static buffer
+        self.crop = model._crop_for(H, W)
+        Hs, Ws = (H, W) if self.crop is None else (self.crop.height_crop_size, self.crop.width_crop_size)
+        self.carry = model.init_states(B, Hs, Ws)
         self.pair = isinstance(self.carry[0], (list, tuple))
 
         def batched(s_):
@@ -184,13 +188,13 @@ class TimeBatchedStream:
         fe = fi = None
         with torch.no_grad():
             if n:
-                x = net.head_events(ops.pack_input(self.in_ev[p][:n * B], dev))
+                x = net.head_events(ops.pack_input(self.in_ev[p][:n * B], dev, self.crop))
                 fe = []
                 for e in net.encoders_events:
                     x = e(x)
                     fe.append(x)
             if f:
-                x = net.head_rgb(ops.pack_input(self.in_im[p], dev))
+                x = net.head_rgb(ops.pack_input(self.in_im[p], dev, self.crop))
                 fi = []
                 for e in net.encoders_rgb:
                     x = e(x)
@@ -330,6 +334,9 @@ class TimeBatchedStream:
             gd.replay()
             self.d_done[p] = D.record_event()
         self.p, self.n, self.opened = 1 - p, 0, False
+        if self.crop is not None:
+            c = self.crop
+            return c.crop(self.pred[key].view(n + f, self.B, 1, c.height_crop_size, c.width_crop_size))
         return self.pred[key].view(n + f, self.B, 1, self.H, self.W)
 
     def wait(self, pred=None):

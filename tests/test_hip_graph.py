@@ -306,3 +306,33 @@ def test_time_batched_stream_follows_weight_updates():
     assert not torch.equal(after[-1], before[-1])
     for a, b in zip(after, eager()):
         assert torch.equal(a, b)
+
+
+def test_time_batched_stream_full_frame_equals_eager_primitives():
+    """Full-frame mode through the streaming runtime (what inference.stream_dataset runs on raw 260 x 346 recordings): a 26 x 35 stream
+    with model.set_full_frame() — inputs reflect-padded in the repack, states at 32 x 40, predictions cropped — gives bit-identical
+    predictions to update_events / update_image / decode(frame_hw=) called one by one."""
+    from rpg_ramnet_amd.graph import TimeBatchedStream
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval().set_full_frame(True)
+    rng = np.random.default_rng(5)
+    Hh, W = 26, 35
+    groups = [[torch.from_numpy(rng.standard_normal((1, 5, Hh, W)).astype(np.float32)) for _ in range(n)] for n in (2, 1, 3)]
+    frames = [torch.from_numpy(rng.random((1, 1, Hh, W)).astype(np.float32)) for _ in groups]
+    tb = TimeBatchedStream(model, 1, Hh, W, max_events=4)
+    st = model.init_states(1, 32, 40)
+    with torch.no_grad():
+        for evs, fr in zip(groups, frames):
+            want = []
+            for e in evs:
+                st, _ = model.update_events(e, st)
+                want.append(model.decode(st, frame_hw=(Hh, W)).clone())
+            st, _ = model.update_image(fr, st)
+            want.append(model.decode(st, frame_hw=(Hh, W)).clone())
+            for e in evs:
+                tb.push_events(e)
+            got = tb.wait(tb.push_image(fr))
+            torch.cuda.synchronize()
+            assert got.shape == (len(evs) + 1, 1, 1, Hh, W)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
