@@ -130,6 +130,22 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             for (int c = 0; c < 5; ++c)
                 raw[r * 5 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(rowo[r] + colo[c]), soff, 0));
     };
+    // one window row at a time (the main loop requests row i as soon as tr_row(i) has consumed the previous window's row i: five loads per
+    // slot instead of 25 in one)
+    int lr_soff = 0;
+    auto load_row_begin = [&](int chunk) {
+        lr_soff = chunk * (W24_K * 4);
+        if (DG) {
+            const int c = chunk / q.cpc;
+            if (c != cur_cls) set_class(c);
+            lr_soff = (chunk - c * q.cpc) * (W24_K * 4);
+        }
+    };
+    auto load_row = [&](int r) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+            raw[r * 5 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(rowo[r] + colo[c]), lr_soff, 0));
+    };
     // B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1]
     auto tr_col = [&](int c) {
         const float d0 = raw[c], d1 = raw[5 + c], d2 = raw[10 + c], d3 = raw[15 + c], d4 = raw[20 + c];
@@ -227,14 +243,22 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
                 acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[pos], 0, 0, 0);
                 if (two) acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[pos + 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (pp == 6) W24_STAMP(chunk, 1);
-                if (pp == 6) tr_col(0), tr_col(1);
-                if (pp == 7) tr_col(2);
-                if (pp == 8) tr_col(4);
-                if (pp == 9) tr_row(vn, 0);
-                if (pp == 10) tr_row(vn, 2);
-                if (pp == 11) tr_row(vn, 4);
-                if (pp == 8) W24_STAMP(chunk, 2);
+                // The side work of the chunk in SLOTS (slot = 2 pp + side), one piece behind every group of four MFMAs instead of blocks of
+                // 24-34 VALU in three gaps and 25 loads in one: column transform c in slots 4..8, row transform i (+ its 5 LDS stores) in
+                // slots 9, 11, .., 17, and the five window loads of row i of chunk + 2 right behind it (slots 10, 12, .., 18: the row's
+                // registers are free, and the loads have six position pairs + the barrier to land before the next chunk's slot 4).
+                auto slot = [&](int sl) {
+                    if (sl == 4) W24_STAMP(chunk, 1);
+                    if (sl >= 4 && sl <= 8) tr_col(sl - 4);
+                    if (sl == 9) W24_STAMP(chunk, 2);
+                    if (sl >= 9 && sl <= 17 && (sl & 1)) tr_row(vn, (sl - 9) >> 1);
+#if !defined(W24_ABLATE) || !(W24_ABLATE & 1)      // timing experiments (tools/wino24_trace.hip): 1 = no window loads, 2 = no weight loads
+                    if (sl == 10) load_row_begin(cnext2);
+                    if (sl >= 10 && sl <= 18 && !(sl & 1)) load_row((sl - 10) >> 1);
+#endif
+                    if (sl == 18) W24_STAMP(chunk, 3);
+                };
+                slot(2 * pp);
                 __builtin_amdgcn_sched_barrier(0);
                 if (VEC == 4) {
                     acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[pos], 0, 0, 0);
@@ -243,14 +267,8 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
                     if (two) acc[pos + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[pos + 1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (pp == 7) tr_col(3);
-                if (pp == 9) tr_row(vn, 1);
-                if (pp == 10) tr_row(vn, 3);
-                if (pp == 11) W24_STAMP(chunk, 3);
+                slot(2 * pp + 1);
                 __builtin_amdgcn_sched_barrier(0);
-#if !defined(W24_ABLATE) || !(W24_ABLATE & 1)      // timing experiments (tools/wino24_trace.hip): 1 = no window loads, 2 = no weight loads
-                if (pp == 11) load_raw(cnext2);
-#endif
             }
             W24_STAMP(chunk, 4);
             __syncthreads();
