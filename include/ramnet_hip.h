@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 15      /* 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 16      /* 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -105,6 +105,13 @@ typedef struct ramnet_conv_desc {
                                      * view is that of a 5x5 stride-2 layer — its slices (dy = +1, row parity 1) and (dx = +1, column
                                      * parity 1) are zero (11 of 36) — and the kernel skips the Winograd positions those zeros annihilate
                                      * (12.25 instead of 16 multiplies per tile and channel on average).  0: dense filter.              */
+    float *splitk_ws;               /* RAMNET_ALGO_WINOGRAD, optional (ABI 16): workspace of splitk_floats >= ramnet_conv_splitk_floats(d) floats,
+                                     * 16-byte aligned, ZERO when first handed over and owned by this layer (launches that share it must be
+                                     * ordered on one stream).  A launch far below one workgroup per CU (batch-1 streaming on the coarse
+                                     * scales) then splits its channel reduction over 2-4 workgroups per output tile; the partial tiles meet
+                                     * here, the last arrival sums them in split order (bit-reproducible) and runs the epilogue, and leaves
+                                     * the arrival counters at zero.  NULL: never split.                                               */
+    size_t splitk_floats;
 } ramnet_conv_desc;
 
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
@@ -141,6 +148,8 @@ typedef struct ramnet_wgrad_desc {
  * voxelizer forms), "fold_pair" (1; 0 = 32-channel folded decoders as 64 tiles x 32 channels — changes the layout ramnet_pack_weight_fold_wino
  * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel), "wgrad_wino_blocks" (384, <= 384: the same for the
  * Winograd backward-weights kernel — measured with F(2x4) in place: 384 -> 215.9, 320 -> 210.7, 256 -> 209.7, 192 -> 193.6 samples/s).
+ * "wino_ksplit" (1 = the library's heuristic; 0 = ramnet_conv_splitk_floats answers 0: no launch splits its reduction; 2..16 = that many
+ * splits for every launch whose epilogue can join partials: tuning runs).
  * ramnet_get_option: -1 if unknown.  */
 int ramnet_set_option(const char *name, int value);
 int ramnet_get_option(const char *name);
@@ -191,6 +200,9 @@ int ramnet_pack_weight_wino2x4(const float *w_oihw, float *wp, int Cout, int Cin
 /* 1 when a launch that qualifies for RAMNET_ALGO_WINOGRAD (d->algo set so, every other field final) runs faster as
  * RAMNET_ALGO_WINOGRAD_2X4 — the caller then sets d->algo and d->w (ramnet_pack_weight_wino2x4) accordingly; else 0.              */
 int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force);   /* force: skip the size heuristics (tests) */
+/* Floats of split-reduction workspace a RAMNET_ALGO_WINOGRAD launch of this descriptor (every other field final) would use, 0 when it
+ * would not split (enough workgroups, epilogue kinds that do not join partials, option "wino_ksplit" = 0).                              */
+size_t ramnet_conv_splitk_floats(const ramnet_conv_desc *d);
 /* Process-wide tuning of the F(2x4,3x3) selection (tests, A/B runs): min_wgs = 64-channel x 256-pixel blocks of output a launch must
  * have (default 150; < 0 keeps the current value).                                                                              */
 int ramnet_wino2x4_config(int min_wgs);

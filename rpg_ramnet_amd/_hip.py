@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("out_s2d", C.c_int),
         ("head_cin", C.c_int),
         ("s2d_5x5", C.c_int),
+        ("splitk_ws", C.c_void_p), ("splitk_floats", C.c_size_t),
     ]
 
 
@@ -78,6 +79,7 @@ _SIGS = {
     "ramnet_pack_weight_wino2x4": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_wino2x4_config": (C.c_int, [C.c_int]),
     "ramnet_conv_wino_variant": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "ramnet_conv_splitk_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
     "ramnet_head_supported": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_pack_weight_head": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
@@ -183,7 +185,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 15:
+        if l.ramnet_abi_version() != 16:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     const int pra = hq * RP_PLANE + ((2 * tty + ra) * RPW + 2 * ttx) * 4;
     const int prb = hq * RP_PLANE + ((2 * tty + rb) * RPW + 2 * ttx) * 4;
     // weights: [chunk][block64][wave 4][position-in-row 4][n-block 2][lane 64][channel j 4]
-    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + wave * 2048 + fh * 256 + lane * 4;
+    const float *wsrc = p.w + (size_t)nblk_i * WU_FLOATS + wave * 2048 + fh * 256 + lane * 4;     // (+ the split's first chunk, below)
     const size_t wchunk = (size_t)q.nblk * WU_FLOATS;
 
     f32x16 acc[4][NF];
@@ -106,8 +106,15 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
-    const int nch = q.nchunks;
-    const int clast = (nch - 1) * WK;
+    // Split reduction (q.ksplit > 1; NF = 1 launches far below one workgroup per CU — batch-1 streaming on the coarse maps): workgroup
+    // blockIdx.y reduces chunks [ch0, ch0 + nch) only; the partial OUTPUT tiles (the inverse transform is linear) meet in a workspace
+    // and the last workgroup to arrive sums them in split order and runs the epilogue (below).  cb = first channel of the range.
+    const int ksp = NF == 1 ? q.ksplit : 1;
+    const int cps = (q.nchunks + ksp - 1) / ksp, ch0 = NF == 1 ? (int)blockIdx.y * cps : 0;
+    const int nch = NF == 1 ? min(cps, q.nchunks - ch0) : q.nchunks;
+    const int cb = ch0 * WK;
+    const int clast = cb + (nch - 1) * WK;
+    if (NF == 1) wsrc += (size_t)ch0 * wchunk;
     WinoPatch<MODE> pr;
     pr.template init<G::PH, G::PW>(q.src, b, iy0, ix0, tid, clast, 2 * RP_FLOATS);
     float4 breg[4][NF];
@@ -115,17 +122,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     auto te = [&](float4 x, float4 y) { return make_float4(x.x + sb * y.x, x.y + sb * y.y, x.z + sb * y.z, x.w + sb * y.w); };
     auto f4sub = [](float4 x, float4 y) { return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w); };
 
-    pr.load(q.src, 0, clast);
+    pr.load(q.src, cb, clast);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if (NF == 2 || !(i & 1)) breg[i >> 1][NF == 2 ? i & 1 : 0] = ld4(wsrc + i * 256);
-    pr.store(patch, q.src, 0);
-    pr.load(q.src, min(WK, clast), clast);
+    pr.store(patch, q.src, cb);
+    pr.load(q.src, min(cb + WK, clast), clast);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c) tcur[c] = te(ld4(patch + pra + c * 4), ld4(patch + prb + c * 4));
-    pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
-    pr.load(q.src, min(2 * WK, clast), clast);
+    pr.store(patch + RP_FLOATS, q.src, min(cb + WK, clast));
+    pr.load(q.src, min(cb + 2 * WK, clast), clast);
     __syncthreads();
     // one chunk: MFMAs on the transformed rows in `tc`, while the rows of the next chunk are built in `tn` (the loop below
     // alternates the two register sets instead of copying them)
@@ -144,13 +151,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
     }
     auto body = [&](int chunk, const float4 (&tc)[4], float4 (&tn)[4]) {
         if (SP == 1) {
-            const int g = (chunk * WK) >> q.src.ld1;
+            const int g = (cb + chunk * WK) >> q.src.ld1;
             runm = ((g & 2) && wave == 3) ? 0u : (g & 1) ? 0x3fu : 0xffu;
         }
         const float *pnext = patch + ((chunk + 1) & 1) * RP_FLOATS;     // patch(i+1)
         float *pfree = patch + (chunk & 1) * RP_FLOATS;                 // patch(i), consumed during chunk i-1 -> patch(i+2)
         const float *wnext = wsrc + (size_t)min(chunk + 1, nch - 1) * wchunk;
-        const int c2 = min((chunk + 2) * WK, clast), c3 = min((chunk + 3) * WK, clast);
+        const int c2 = min(cb + (chunk + 2) * WK, clast), c3 = min(cb + (chunk + 3) * WK, clast);
         auto side = [&](int k) {                    // compile-time constant after unrolling: one slice behind every MFMA
             if (k < 8) {
                 if (!(k & 1)) ta = ld4(pnext + pra + (k >> 1) * 4), tb = ld4(pnext + prb + (k >> 1) * 4);
@@ -282,6 +289,37 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
             ok[i] = nok && oy < p.Ho && ox < p.Wo;
             pix[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;     // (a valid address either way)
         }
+        // Split reduction: this workgroup's partial quads -> its slab of the tile's workspace [split][128 pixels x 32 channels]; the LAST
+        // arrival (a counter per tile, left at zero for the next launch) adds the slabs in split order — every sum has a fixed order
+        // whoever arrives last: bit-reproducible — and goes on to the epilogue, the others are done.  The partials cross XCDs (private
+        // L2s): they are written and read with device-scope accesses (write-through / L2-bypassing), ordered around the counter by the
+        // wave's own s_waitcnt — a device-scope FENCE instead writes back and invalidates the whole L2 (measured: +30-50 us per launch).
+        float4 joined[NI];
+        if (NF == 1 && ksp > 1) {
+            // (16-byte buffer accesses with the sc1 cache-policy bit = what the compiler emits for device-scope atomics, four floats at a
+            // time: as 4-byte atomic stores / loads at a 16-byte lane stride the join cost 12 us per launch)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            constexpr int AUX_SC1 = 16;
+            const auto wr = wino_rsrc(q.ws + (size_t)blockIdx.x * ksp * 4096, (unsigned)(ksp * 4096 * 4));
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out4(pxl[i], qd * 4)), wr, (tid + i * 256) * 16, (int)blockIdx.y * 16384, AUX_SC1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the wave's stores have left (s_waitcnt), no cache maintenance
+            __syncthreads();                           // (also: every out4 read of P is done, P[0] can carry the verdict)
+            if (tid == 0) {
+                const int arrived = __hip_atomic_fetch_add(q.cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived == ksp - 1) __hip_atomic_store(q.cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                reinterpret_cast<int *>(P)[0] = arrived == ksp - 1;
+            }
+            __syncthreads();
+            if (!reinterpret_cast<int *>(P)[0]) return;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) joined[i] = f4zero();
+            for (int s = 0; s < ksp; ++s)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    joined[i] = f4add(joined[i], __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, (tid + i * 256) * 16, s * 16384, AUX_SC1)));
+        }
         auto run = [&](auto kind) {
             constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend
             float4 ea[NI], eb[NI];
@@ -293,7 +331,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if (!ok[i]) continue;
-                float4 v = f4add(out4(pxl[i], qd * 4), bias4);
+                float4 v = f4add((NF == 1 && ksp > 1) ? joined[i] : out4(pxl[i], qd * 4), bias4);
                 if (K == 0) {
                     if (addold) v = make_float4(v.x + p.beta * ea[i].x, v.y + p.beta * ea[i].y, v.z + p.beta * ea[i].z, v.w + p.beta * ea[i].w);
                     if (epi == RAMNET_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -381,7 +419,9 @@ static void wino_geometry(int Cout, int Cin, int transposed, int gates, int &R, 
     nblk = gates > 1 ? cdiv(N / gates, 16) : cdiv(N, WBN);
 }
 
-int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
+// Geometry and variant of a launch: everything launch_wino needs, and what ramnet_conv_splitk_bytes sizes the workspace from.
+// ksplit = the split of the reduction the launch WANTS (1 = none); it is used when the descriptor carries a workspace.
+static int wino_plan(const ramnet_conv_desc &d, WinoParams &q, bool &tall, int &nf, int &ksplit, unsigned &gridx) {
     RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1);
     RAMNET_CHECK_ARG(d.in_mode != RAMNET_IN_UP2X && d.in_mode != RAMNET_IN_UP2X_SKIP);
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
@@ -401,7 +441,6 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     }
     RAMNET_CHECK_ARG(seen == 0x1ffu);
     const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
-    WinoParams q;
     q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
@@ -410,7 +449,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = d.epi == RAMNET_EPI_LSTM ? cdiv(d.Cout, 16) : cdiv(d.Cout, WBN);
     q.tiles_x = cdiv(d.Wo, WTW), q.tiles_y = cdiv(d.Ho, WTH);
     // 8 x 16 or 32 x 4 output pixels per workgroup, whichever pads the map less
-    const bool tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
+    tall = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32 < (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
     if (tall) q.tiles_x = cdiv(d.Wo, 4), q.tiles_y = cdiv(d.Ho, 32);
     q.dy0 = dymin, q.dx0 = dxmin;
     auto al16 = [](const void *ptr) { return ptr == nullptr || ((uintptr_t)ptr & 15) == 0; };
@@ -445,19 +484,52 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
     // ConvGRU candidate at 32 x 43 0.177 -> 0.163 ms, training step 202.2 -> 203.4 / 204.0 samples/s)
     // threshold sweep at B = 8 (same box): 512 -> 204.6 / 204.5 samples/s, 1024 -> 203.5 (ConvGRU gates at 32 x 43: 0.258 -> 0.276 ms),
     // 1536 -> 201.6, everything -> 198.7: beyond the partial first round the doubled transform work costs more than the fill buys
-    const int nf = (wgs2 < 512 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && nf1_mode && d.Cout % 64 == 0) ? 1 : 2;
+    nf = (wgs2 < 512 && d.epi != RAMNET_EPI_LSTM && q.sparse != 2 && nf1_mode && d.Cout % 64 == 0) ? 1 : 2;
     // a launch of fewer workgroups than CUs is latency-bound: skipping the MFMAs of the zero slices buys nothing there, the
     // wave-uniform tests around them cost (enc2 at batch 1: 1.7 instead of 0.9 us per chunk) -> dense
     if (nf == 1 && q.sparse == 1 && wgs2 < 256) q.sparse = 0;
-    dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
-    const size_t lds = (size_t)(nf == 1 ? 4 * 2 * 32 * (32 + 4) : RO_FLOATS) * sizeof(float);       // (the two patch buffers, 2 x 2 planes, and the scratch cells are smaller)
-    // one instantiation per (tile shape, sparse mode, input mode) that occurs: the kernel body has no run-time mode branches
+    gridx = cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg);
+    // Split reduction: a launch of 32-channel workgroups that does not fill the chip's 512 workgroup slots (batch-1 streaming on the two
+    // coarse scales: 88-352 workgroups of 32-64 chunks each) is bound by the length of ONE workgroup's chunk chain (0.65 us per chunk) —
+    // split it 2-4 ways towards ~704 workgroups, not below 8 chunks per split.  Only the channel-quad epilogue joins partials.
+    // Same-box sweep (tools/bench_split.py, us per launch unsplit / 2 / 4 splits): residual conv 32x43 256->256 29.6 / - / 19.8, ConvGRU
+    // candidate 32x43 512->256 48.1 / 29.7 / 28.8, gates 512->512 51.7 / 49.2 / 41.0, gates 64x86 256->256 (352 workgroups) 47.3 / 39.9 /
+    // 42.4, encoder-2 view 52.0 / 30.2 / 29.3; 16-chunk launches gain nothing (the join costs about what 5 chunks do).
+    ksplit = 1;
+    if (nf == 1 && q.vec4 && !q.s2d_shift && g_opt_wino_ksplit) {
+        const int wgs1 = 2 * wgs2;
+        ksplit = 704 / wgs1 < 4 ? 704 / wgs1 : 4;
+        if (q.nchunks / 8 < ksplit) ksplit = q.nchunks / 8;
+        if (q.nchunks < 32) ksplit = 1;                 // the join costs about what 5 chunks do
+        if (g_opt_wino_ksplit > 1) ksplit = g_opt_wino_ksplit < q.nchunks ? g_opt_wino_ksplit : q.nchunks;      // (forced: tuning runs)
+        if (ksplit < 1) ksplit = 1;
+        while (ksplit > 1 && (ksplit - 1) * cdiv(q.nchunks, ksplit) >= q.nchunks) --ksplit;      // (every split owns at least one chunk)
+    }
     {
         const unsigned long long px = (unsigned long long)d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1);
         int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
         ldmax = ldmax > d.ldm ? ldmax : d.ldm;
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
     }
+    return 0;
+}
+
+// workspace of a split launch: [gridx counters, padded to 64][gridx][ksplit][128 pixels x 32 channels]
+static size_t wino_ksplit_floats(unsigned gridx, int ksplit) { return (size_t)cdiv((int)gridx, 64) * 64 + (size_t)gridx * ksplit * 4096; }
+
+int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
+    WinoParams q;
+    bool tall;
+    int nf, ksplit;
+    unsigned gridx;
+    if (int rc = wino_plan(d, q, tall, nf, ksplit, gridx)) return rc;
+    q.ksplit = d.splitk_ws ? ksplit : 1;
+    q.cnt = reinterpret_cast<int *>(d.splitk_ws);
+    q.ws = d.splitk_ws ? d.splitk_ws + cdiv((int)gridx, 64) * 64 : nullptr;
+    if (q.ksplit > 1) RAMNET_CHECK_ARG(d.splitk_floats >= wino_ksplit_floats(gridx, ksplit) && ((uintptr_t)d.splitk_ws & 15) == 0);
+    dim3 grid(gridx, q.ksplit);
+    const size_t lds = (size_t)(nf == 1 ? 4 * 2 * 32 * (32 + 4) : RO_FLOATS) * sizeof(float);       // (the two patch buffers, 2 x 2 planes, and the scratch cells are smaller)
+    // one instantiation per (tile shape, sparse mode, input mode) that occurs: the kernel body has no run-time mode branches
     const int key = (tall ? 0 : 1000) + q.sparse * 100 + d.in_mode + (nf == 1 ? 10000 : 0);
     note_kernel("conv_wino_r_kernel<%d,%d,%d,%d>", tall ? 2 : 8, q.sparse, d.in_mode, nf);
 #define RAMNET_GO(TXv, SPv, MDv)                                                                        \
@@ -492,6 +564,16 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
 }  // namespace ramnet
 
 using namespace ramnet;
+
+extern "C" size_t ramnet_conv_splitk_floats(const ramnet_conv_desc *d) {
+    if (!d || d->algo != RAMNET_ALGO_WINOGRAD) return 0;
+    WinoParams q;
+    bool tall;
+    int nf, ksplit;
+    unsigned gridx;
+    if (wino_plan(*d, q, tall, nf, ksplit, gridx) != 0 || ksplit <= 1) return 0;
+    return wino_ksplit_floats(gridx, ksplit);
+}
 
 extern "C" size_t ramnet_packed_weight_elems_wino(int Cout, int Cin, int transposed, int gates) {
     int R, N, nchunks, nblk;

@@ -16,6 +16,9 @@ struct WinoParams {
     int s2d_shift;          // log2(out_s2d) or 0
     int xg;                 // log2 of the number of XCD-pinned channel-block groups
     int sparse;             // ramnet_conv_desc.s2d_5x5: 1 = zero slices by input parity group (forward), 2 = by output group (backward-data)
+    int ksplit;             // F(2x2) kernel, 32-channel workgroups: gridDim.y = splits of the channel reduction (1 = none)
+    float *ws;              // ksplit > 1: partial output tiles [gridDim.x][ksplit][128 pixels][32 channels]
+    int *cnt;               //             arrival counters [gridDim.x], zero between launches
 };
 
 // Patch prefetcher of the Winograd kernel, MODE = ramnet_in_mode of the launch as a compile-time constant (run-time, wave-uniform

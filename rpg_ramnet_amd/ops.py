@@ -80,6 +80,12 @@ def set_fold_pair(on):
     invalidate_packs()
 
 
+def set_winograd_split(on):
+    """Split channel reduction of latency-bound F(2x2,3x3) launches (batch-1 streaming on the coarse scales; csrc/conv_wino.hip): on by
+    default, off for A/B runs.  Descriptors are built per launch, graphs captured before the call keep what they captured."""
+    H.check(H.lib().ramnet_set_option(b"wino_ksplit", int(on)), "set_option")         # (2..16: that many splits, tuning runs)
+
+
 def _fold_pair(Cout, Cin):
     """32-channel layers (the last decoder): both column parities of a row parity in one 64-column workgroup that shares the
     transformed input (conv_wino24_kernel<.., PAIR>); RAMNET_FOLD_PAIR=0 keeps the 64-tile x 32-channel form."""
@@ -230,6 +236,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
     d.algo = H.ALGO_DIRECT
     ref = None
+    cp = w.cp if isinstance(w, PackRef) else None
     if isinstance(w, PackRef) and beta == 0.0 and frame == 0 and os == (1, 1, 0, 0) and uses_head(taps, w, stride, epi, in_mode):
         d.algo, d.head_cin = H.ALGO_HEAD, w.cp.Cin
         w = w.cp.pack(0, "head")
@@ -259,6 +266,12 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     if ref is not None and _WINO_2X4 != "off" and H.lib().ramnet_conv_wino_variant(C.byref(d), int(_WINO_2X4 == "force")):
         # F(2x4,3x3) on the fine scales (csrc/conv_wino6.hip): its own Winograd-domain pack of the same parameters
         d.algo, d.w = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4"))
+    if d.algo == H.ALGO_WINOGRAD and cp is not None:
+        # latency-bound launches (batch-1 streaming on the coarse scales) split their channel reduction: the library says how much
+        # workspace the launch would use, the layer owns it (csrc/conv_wino.hip, ramnet_conv_desc.splitk_ws)
+        n = H.lib().ramnet_conv_splitk_floats(C.byref(d))
+        if n:
+            d.splitk_ws, d.splitk_floats = _p(cp.splitk_ws(n, x0.device)), n
     return d
 
 
@@ -608,6 +621,17 @@ class ConvParam:
         self._vbias = None
         self._packs = {}
         self._dirty = False
+
+    def splitk_ws(self, n, device):
+        """Workspace of this layer's split-reduction launches (ramnet_conv_desc.splitk_ws): zero once — the kernel leaves the arrival
+        counters at zero —, one buffer per size; the launches of ONE layer are ordered on one stream everywhere in this package
+        (per-scale update chains, decoder stream and backward-weights stream run different layers).  First use inside a graph capture
+        would record the zero-fill into the graph: the streaming runtimes warm up eagerly before they capture."""
+        pool = self.__dict__.setdefault("_splitk", {})       # (derived parameter views — S2DConvParam — build themselves)
+        ws = pool.get(n)
+        if ws is None or ws.device != device:
+            ws = pool[n] = torch.zeros(n, device=device, dtype=torch.float32)
+        return ws
 
     def _versions(self, ts):
         return (_PACK_EPOCH,) + tuple((t._version, t.data_ptr()) for t in ts)

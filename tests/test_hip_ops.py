@@ -317,6 +317,86 @@ def test_winograd_conv3x3_raw(B, H, W, cin, cout):
     assert_close(outs[True][0].cpu().numpy(), outs[False][0].cpu().numpy(), 2e-5, "winograd vs direct")
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 32, 43), (1, 16, 22), (2, 9, 20), (1, 8, 43)])
+@pytest.mark.parametrize("cin,cout", [(256, 256), (128, 64), (512, 128), (200, 64)])
+def test_winograd_split_reduction(B, H, W, cin, cout):
+    """Latency-bound F(2x2,3x3) launches (batch-1 streaming on the coarse scales) split their channel reduction over 2-4 workgroups per
+    output tile (ramnet_conv_desc.splitk_ws): forward RES_RELU, backward-data RELUMASK and LINEAR + beta against float64 and against the
+    unsplit launch; the partials are joined in split order — bit-reproducible —, the arrival counters return to zero (the workspace is
+    reused by every repetition), and the library reports a workspace for at least one launch of every case."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops, _hip as Hh
+    torch.manual_seed(12)
+    w = torch.randn(cout, cin, 3, 3) * 0.05
+    b = torch.randn(cout) * 0.1
+    cp = ops.ConvParam([torch.nn.Parameter(w.to(dev()))], [torch.nn.Parameter(b.to(dev()))])
+    x = torch.randn(B, cin, H, W)
+    xg = nhwc(x).to(dev()).contiguous()
+    res = torch.randn(B, cout, H, W)
+    resg = nhwc(res).to(dev()).contiguous()
+    taps, tapsd = ops.Taps.get("conv", 3, 1), ops.Taps.get("dgrad1", 3, 1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    outs, split = {}, []
+    for on in (True, True, False):
+        ops.set_winograd_split(on)
+        try:
+            y = torch.full((B, H, W, cout), float("nan"), device=dev())
+            d = ops._conv_desc(xg, taps, cp.fwd(), y, cout, bias=cp.bias(), epi=Hh.EPI_RES_RELU, e0=resg)
+            split.append(int(d.splitk_floats))
+            Hh.check(Hh.lib().ramnet_conv_launch(C.byref(d), ops._st()), "ramnet_conv_launch")
+            dx = torch.full((B, H, W, cin), float("nan"), device=dev())
+            d = ops._conv_desc(y, tapsd, cp.bwd(), dx, cin, xm=resg, in_mode=Hh.IN_RELUMASK)
+            split.append(int(d.splitk_floats))
+            Hh.check(Hh.lib().ramnet_conv_launch(C.byref(d), ops._st()), "ramnet_conv_launch")
+            acc = xg.clone()
+            ops.conv_launch(y, tapsd, cp.bwd(), acc, cin, beta=1.0)
+        finally:
+            ops.set_winograd_split(True)
+        outs.setdefault(on, []).append((y, dx, acc))
+    assert (max(split[:4]) > 0 or cin < 256) and split[4:] == [0, 0], split          # (reductions of 32 chunks and more split)
+    yref = torch.relu(ref + res.double())
+    dy = torch.where(res > 0, yref, torch.zeros_like(yref))
+    dxref = F.conv_transpose2d(dy, w.double(), None, 1, 1)
+    accref = x.double() + F.conv_transpose2d(yref, w.double(), None, 1, 1)
+    for on in (True, False):
+        y, dx, acc = outs[on][0]
+        assert_close(nchw(y).cpu().numpy(), yref.numpy(), TOL, "forward split=%s" % on)
+        assert_close(nchw(dx).cpu().numpy(), dxref.numpy(), TOL, "dgrad split=%s" % on)
+        assert_close(nchw(acc).cpu().numpy(), accref.numpy(), TOL, "dgrad beta split=%s" % on)
+    for a, c in zip(outs[True][0], outs[True][1]):
+        assert torch.equal(a, c), "split launches are bit-reproducible"
+    assert_close(outs[True][0][0].cpu().numpy(), outs[False][0][0].cpu().numpy(), 2e-5, "split vs unsplit")
+    for ws in cp.__dict__.get("_splitk", {}).values():      # counters (first floats of the workspace) back at zero
+        assert int(ws[:64].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 32, 43, 256), (1, 16, 22, 128)])
+def test_conv_gru_and_encoder_split_reduction_equals_unsplit(B, H, W, C):
+    """The other loaders / epilogues that split at batch 1 — ConvGRU gates (concatenation + sigmoid), candidate (h * r product + GRU
+    blend) and a stride-2 5x5 encoder over its space-to-depth view: split on against off (2e-5), and the oracle runs of test_conv_gru /
+    test_conv_layer at (2, 4, 43, 256) / (128, 128, 2) execute the split launches against float64."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvGRU, ConvLayer
+    torch.manual_seed(6)
+    gru, enc = ConvGRU(C, C, 3).to(dev()), ConvLayer(C // 2, C, 5, stride=2, padding=2).to(dev())
+    xin = torch.randn(B, 2 * H, 2 * W, C // 2, device=dev())
+    h0 = torch.tanh(torch.randn(B, H, W, C, device=dev()))
+    outs = {}
+    for on in (True, False):
+        ops.set_winograd_split(on)
+        try:
+            with torch.no_grad():
+                e = enc(xin)
+                outs[on] = (e, gru(e, h0))
+        finally:
+            ops.set_winograd_split(True)
+    used = {k: bool(cp.__dict__.get("_splitk")) for m in (gru, enc) for k, cp in m._cps.items()}
+    assert used["ur"] or used["o"], used
+    for a, c in zip(outs[True], outs[False]):
+        assert_close(a.cpu().numpy(), c.cpu().numpy(), 2e-5, "split vs unsplit")
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (3, 32, 48)])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
 def test_winograd_wgrad_raw(B, H, W, cin, cout):
