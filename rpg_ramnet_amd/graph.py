@@ -62,11 +62,8 @@ class GraphedStream:
         for src in (0, 1):
             for kind, buf, update in (("events", self.ev_in, model.update_events), ("image", self.im_in, model.update_image)):
                 def run(buf=buf, update=update, src=src):
-                    with torch.no_grad():
-                        new, _ = update(buf, self.sets[src])
-                        for dst, s_ in zip(self.sets[1 - src], new):
-                            for d, t in zip(self._flat(dst), self._flat(s_)):
-                                d.copy_(t)
+                    with torch.no_grad():                         # the cells write the other set themselves: no copy kernels in the chain
+                        update(buf, self.sets[src], out=self.sets[1 - src])
                 _warm(run)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

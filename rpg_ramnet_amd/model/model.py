@@ -143,19 +143,20 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                        else torch.zeros(shp, device=self.gpu))
         return out
 
-    def update_events(self, events, states, lstm_state=None):
+    def update_events(self, events, states, lstm_state=None, out=None):
         """Asynchronous primitive (irregular schedules, BASELINE configs[3]): fold ONE event voxel grid [B,Ce,H,W] into the
         shared multi-scale state.  `states`: list returned by init_states()/a previous update (NHWC buffers or the
         NCHW-shaped views forward() returns).  Returns (new_states, lstm_state); nothing is modified in place.
-        Equivalent to one iteration of the k-loop of model.py:176-195 without the decode."""
+        Equivalent to one iteration of the k-loop of model.py:176-195 without the decode.  out: optional per-scale NHWC buffers (a second
+        init_states() set, never the one passed as `states`) that receive — and are returned as — the new state."""
         assert not bool(self.baseline), "baselines have no event branch (model.py:181-185)"
         st = [_state_nhwc(s, self.base_num_channels * 2 ** (i + 1)) for i, s in enumerate(states)]
-        return self.statenetphasedrecurrent.forward_events(ops.pack_input(events, self.gpu, self._crop_for(*events.shape[2:])), st, lstm_state)
+        return self.statenetphasedrecurrent.forward_events(ops.pack_input(events, self.gpu, self._crop_for(*events.shape[2:])), st, lstm_state, out=out)
 
-    def update_image(self, image, states, lstm_state=None):
+    def update_image(self, image, states, lstm_state=None, out=None):
         """Fold ONE frame [B,Cr,H,W] into the shared state (model.py:196-213 without the decode)."""
         st = [_state_nhwc(s, self.base_num_channels * 2 ** (i + 1)) for i, s in enumerate(states)]
-        return self.statenetphasedrecurrent.forward_images(ops.pack_input(image, self.gpu, self._crop_for(*image.shape[2:])), st, lstm_state)
+        return self.statenetphasedrecurrent.forward_images(ops.pack_input(image, self.gpu, self._crop_for(*image.shape[2:])), st, lstm_state, out=out)
 
     def decode(self, states, frame_hw=None):
         """Depth prediction [B,1,H,W] in [0,1] from the current state (statenet.py:290-315).  frame_hw (full-frame mode): the (height,

@@ -70,8 +70,11 @@ class StateNetPhasedRecurrent(nn.Module):
         self.pred = ConvLayer(base_num_channels, num_output_channels, 1, activation=None, norm=norm)
 
     # ---------------------------------------------------------------------------------------------- encoders
-    def _encode(self, x, head, encoders, combs, prev_super_state, prev_states_lstm, feed_state_forward):
+    def _encode(self, x, head, encoders, combs, prev_super_state, prev_states_lstm, feed_state_forward, out=None):
+        """out (RAM-Net state updates only): per-scale NHWC buffers — (h, c) pairs for convlstm — that receive the new state (the
+        streaming runtimes' static buffers; none of them may alias the state being read)."""
         n = self.num_encoders
+        assert out is None or not feed_state_forward
         x = head(x)
         if prev_states_lstm is None:
             prev_states_lstm = {'encoders': [None] * n, 'state_comb': [None] * n}
@@ -90,7 +93,7 @@ class StateNetPhasedRecurrent(nn.Module):
                     main, side = torch.cuda.current_stream(), ops.branch_stream(x.device, i)
                     side.wait_stream(main)                                  # x_i (and the state) are ready
                     with torch.cuda.stream(side):
-                        _, super_state = combs[i](x, prev_super_state[i])
+                        _, super_state = combs[i](x, prev_super_state[i], None if out is None else out[i])
                     if not torch.cuda.is_current_stream_capturing():       # (a capture orders its private pool by the graph's own edges;
                         x.record_stream(side)                               # record_stream there left later captures crashing at replay)
                         for t in (prev_super_state[i] if isinstance(prev_super_state[i], (list, tuple)) else (prev_super_state[i],)):
@@ -99,7 +102,7 @@ class StateNetPhasedRecurrent(nn.Module):
                             t.record_stream(main)                           # consumed on the caller's stream after the join
                     joins.append(side)
                 else:
-                    _, super_state = combs[i](x, prev_super_state[i])       # convlstm: h and c both from the shared state
+                    _, super_state = combs[i](x, prev_super_state[i], None if out is None else out[i])       # convlstm: h and c both from the shared state
                 state_comb = super_state
                 super_states.append(super_state)
             else:
@@ -115,13 +118,13 @@ class StateNetPhasedRecurrent(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
         return super_states, states_lstm
 
-    def forward_events(self, x, prev_super_state, prev_states_lstm, times=None):
+    def forward_events(self, x, prev_super_state, prev_states_lstm, times=None, out=None):
         return self._encode(x, self.head_events, self.encoders_events, self.state_combination_events,
-                            prev_super_state, prev_states_lstm, False)
+                            prev_super_state, prev_states_lstm, False, out)
 
-    def forward_images(self, x, prev_super_state, prev_states_lstm, times=None):
+    def forward_images(self, x, prev_super_state, prev_states_lstm, times=None, out=None):
         return self._encode(x, self.head_rgb, self.encoders_rgb, self.state_combination_images,
-                            prev_super_state, prev_states_lstm, bool(self.baseline))
+                            prev_super_state, prev_states_lstm, bool(self.baseline), out)
 
     # ---------------------------------------------------------------------------------------------- decoder
     def forward_decoder(self, super_states):
