@@ -18,6 +18,7 @@ extern int g_opt_voxel_sorted, g_opt_fold_pair, g_opt_wgrad_blocks, g_opt_wgrad_
 void set_error(const char *fmt, ...);
 void note_kernel(const char *fmt, ...);   // symbol (template arguments included) of the MFMA kernel a launcher enqueued: ramnet_last_kernel()
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st);   // conv_wino.hip
+size_t wino24_splitk_floats(const ramnet_conv_desc &d);      // conv_wino24.hip
 int launch_wino6(const ramnet_conv_desc &d, hipStream_t st);  // conv_wino6.hip: F(2x4,3x3)
 int launch_head(const ramnet_conv_desc &d, hipStream_t st);   // conv_head.hip
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st); // conv_wino24.hip

@@ -566,6 +566,7 @@ int launch_wino(const ramnet_conv_desc &d, hipStream_t st) {
 using namespace ramnet;
 
 extern "C" size_t ramnet_conv_splitk_floats(const ramnet_conv_desc *d) {
+    if (d && d->algo == RAMNET_ALGO_WINOGRAD24) return wino24_splitk_floats(*d);
     if (!d || d->algo != RAMNET_ALGO_WINOGRAD) return 0;
     WinoParams q;
     bool tall;

@@ -53,6 +53,9 @@ struct Wino24Params {
     int Hp, Wp, ldx, nchunks, nblk, tiles_x, tiles_y, Hc, Wc;
     int cpc;                  // backward-data (DG): chunks per parity class = Cout_fwd / chunk size
     unsigned xbytes, wbytes;  // extents of x and wp (buffer addressing: both below 4 GB)
+    int ksplit;               // forward: gridDim.y = splits of the channel reduction (1 = none; an even number of chunks each)
+    float *ws;                // ksplit > 1: partial outputs [gridDim.x][ksplit][512 threads x 16]
+    int *cnt;                 //             arrival counters [gridDim.x], zero between launches
 };
 
 // NCQ = 16-channel groups of output channels per workgroup: 4 (32 tiles, chunks of 16) or 2 (64 tiles, chunks of 8)
@@ -113,7 +116,11 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
         for (int r = 0; r < 5; ++r)
             rowo[r] = 4u * (unsigned)((b * q.Hp + min(iy0 + r, q.Hp - 1)) * q.Wp * q.ldx), colo[r] = 4u * (unsigned)(min(ix0 + r, q.Wp - 1) * q.ldx + ik);
     }
-    const auto xrs = make_rsrc(q.x, q.xbytes);
+    // Split reduction (forward launches far below one workgroup per CU: the first decoders at batch 1): workgroup blockIdx.y reduces
+    // chunks [cbeg, cbeg + nch) and the partial outputs are joined in front of the epilogue (as in conv_wino.hip)
+    const int ksp = DG ? 1 : q.ksplit;
+    const int cps = ((q.nchunks / 2 + ksp - 1) / ksp) * 2, cbeg = DG ? 0 : (int)blockIdx.y * cps;
+    const auto xrs = make_rsrc(q.x + cbeg * W24_K, q.xbytes - (unsigned)cbeg * W24_K * 4u);
     // operand reads are VEC floats per lane; the XOR swizzle spreads the 16 tiles of a read over all banks
     const int vdst = NCQ == 4 ? it * 16 + (((ik >> 2) ^ ((it >> 2) & 3)) << 2) + (ik & 3) : it * 8 + (((ik >> 1) ^ ((it >> 3) & 1)) << 1) + (ik & 1);
     float raw[25];
@@ -170,7 +177,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
     const int aoff = NCQ == 4 ? tile * 16 + ((ks ^ ((tile >> 2) & 3)) << 2) : tile * 8 + ((ks ^ ((tile >> 3) & 1)) << 1);
     constexpr int WPOS = NCQ * 64 * VEC;              // packed floats per position
     const auto wrs = make_rsrc(q.wp, q.wbytes);
-    const int wsrc = (((cls * q.nchunks) * q.nblk + nb) * W24_U + cq * (64 * VEC)) * 4;     // uniform byte offset; lane part below
+    const int wsrc = (((cls * q.nchunks + cbeg) * q.nblk + nb) * W24_U + cq * (64 * VEC)) * 4;     // uniform byte offset; lane part below
     const int wlane = lane * VEC * 4;
     auto ldv = [&](const float *ptr) {                // VEC floats -> float4 (upper half unused for VEC = 2)
         if (VEC == 4) return ld4(ptr);
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
 #pragma unroll
     for (int i = 0; i < 25; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nch = q.nchunks;
+    const int nch = DG ? q.nchunks : min(cps, q.nchunks - cbeg);
     W24_STAMP(16, 0);
     load_raw(0);
     // Weight ring: 10 slots, prefetch distance 9 positions.  Vector loads return in order, so a weight load issued after the
@@ -299,25 +306,58 @@ __global__ void __launch_bounds__(512, 1) conv_wino24_kernel(const ramnet_conv_d
             s[0][j] = m0 + m1 + m2 + m3;
             s[1][j] = m1 - m2 + 2.f * m3 + m4;
         }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            ov[(r * 2 + a2) * 2] = s[a2][0] + s[a2][1] + s[a2][2] + s[a2][3];
+            ov[(r * 2 + a2) * 2 + 1] = s[a2][1] - s[a2][2] + 2.f * s[a2][3] + s[a2][4];
+        }
+    }
+    if (!DG && ksp > 1) {
+        // join of the split reduction: partial outputs -> slab blockIdx.y of this tile's workspace, the last arrival adds the slabs in
+        // split order (device-scope 16-byte accesses, no fences: see conv_wino.hip) and goes on; no lane has left (Cout fills the block)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int AUX_SC1 = 16;
+        const auto wr = make_rsrc(q.ws + (size_t)blockIdx.x * ksp * 8192, (unsigned)(ksp * 8192 * 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_float4(ov[4 * i], ov[4 * i + 1], ov[4 * i + 2], ov[4 * i + 3])), wr,
+                                                   (i * 512 + tid) * 16, (int)blockIdx.y * 32768, AUX_SC1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (tid == 0) {
+            const int arrived = __hip_atomic_fetch_add(q.cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived == ksp - 1) __hip_atomic_store(q.cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            reinterpret_cast<int *>(smem)[0] = arrived == ksp - 1;
+        }
+        __syncthreads();
+        if (!reinterpret_cast<int *>(smem)[0]) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ov[i] = 0.f;
+        for (int sp = 0; sp < ksp; ++sp)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, (i * 512 + tid) * 16, sp * 32768, AUX_SC1));
+                ov[4 * i] += t.x, ov[4 * i + 1] += t.y, ov[4 * i + 2] += t.z, ov[4 * i + 3] += t.w;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
         const int t = th * 16 + 4 * ks + r;
         const int oy0 = 2 * (tby * W24_TY + t / W24_TX), ox0 = 2 * (tbx * W24_TX + t % W24_TX) - (PAIR ? pxc : 0);
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
-            const float y0 = s[a2][0] + s[a2][1] + s[a2][2] + s[a2][3];
-            const float y1 = s[a2][1] - s[a2][2] + 2.f * s[a2][3] + s[a2][4];
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const int oy = oy0 + a2, ox = ox0 + c2, idx = (r * 2 + a2) * 2 + c2;
                 if (DG) {                           // dense output grid, plain store
                     oo[idx] = oy < p.Ho && ox < p.Wo;
                     op[idx] = (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.ldo + n;
-                    ov[idx] = c2 ? y1 : y0;
                     continue;
                 }
                 oo[idx] = !(oy >= q.Hc || ox >= q.Wc || (PAIR && ox < 0));
                 const int oyF = 2 * oy + py, oxF = 2 * ox + pxc;
                 op[idx] = (((size_t)b * p.HoF + oyF) * p.WoF + oxF) * p.ldo + n;
-                float v = (c2 ? y1 : y0) + bias_n;
+                float v = ov[idx] + bias_n;
                 if (oo[idx]) v += epilogue_side(p, epi, b, oyF, oxF, n);
                 ov[idx] = relu ? fmaxf(v, 0.f) : v;
             }
@@ -390,6 +430,7 @@ static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
     Wino24Params q;
     q.x = d.x0, q.wp = d.w, q.Hp = d.Hin, q.Wp = d.Win, q.ldx = d.ld0;
     q.cpc = d.C0 / 16, q.nchunks = 4 * q.cpc, q.nblk = d.Cout / 64;
+    q.ksplit = 1, q.ws = nullptr, q.cnt = nullptr;
     q.Hc = d.Hin / 2, q.Wc = d.Win / 2;
     const size_t xb = (size_t)d.B * d.Hin * d.Win * d.ld0 * sizeof(float), wb = (size_t)100 * d.C0 * d.Cout * sizeof(float);
     RAMNET_CHECK_ARG(xb < 0x40000000ull && wb < 0x7fffffffull);          // invalid window elements use offsets >= 2^30
@@ -412,6 +453,38 @@ static int launch_wino24_dgrad(const ramnet_conv_desc &d, hipStream_t st) {
     return 0;
 }
 
+// Split of the channel reduction a forward launch wants (1 = none): workgroups of 512 threads, one per CU — a launch that leaves more than
+// half of the CUs empty (decoder 0 at batch 1: 96 workgroups of 16 chunks) splits towards one full round of 256 workgroups, at least four
+// chunks (an even number) per split; every lane of a workgroup must own an output channel (the join has barriers).  Measured
+// (tools/bench_split.py, whole layer): decoder 0 87.0 -> 65.8 us with 2 splits (4: 67.5); decoder 1 (176 workgroups) 63.9 -> 64.8 with 2: a
+// second round of workgroups costs what the shorter chains save — not split.
+static int wino24_ksplit(const ramnet_conv_desc &d, int gridx, int nchunks) {
+    if (!g_opt_wino_ksplit || d.in_mode != RAMNET_IN_PLAIN) return 1;
+    const bool pair = fold_wino_pair(d.Cout, d.C0), wide = pair || (d.Cout % 64 == 0 && d.C0 % 16 == 0);
+    if (!pair && d.Cout % (wide ? 64 : 32) != 0) return 1;
+    int ks = 256 / gridx < 4 ? 256 / gridx : 4;
+    if (nchunks / 4 < ks) ks = nchunks / 4;
+    if (g_opt_wino_ksplit > 1) ks = g_opt_wino_ksplit < nchunks / 2 ? g_opt_wino_ksplit : nchunks / 2;
+    if (ks < 1) ks = 1;
+    while (ks > 1 && (ks - 1) * (cdiv(nchunks / 2, ks) * 2) >= nchunks) --ks;        // every split owns chunks
+    return ks;
+}
+static size_t wino24_ksplit_floats(unsigned gridx, int ks) { return (size_t)cdiv((int)gridx, 64) * 64 + (size_t)gridx * ks * 8192; }
+
+// ramnet_conv_splitk_floats() for RAMNET_ALGO_WINOGRAD24 descriptors (same geometry as launch_wino24 below)
+size_t wino24_splitk_floats(const ramnet_conv_desc &d) {
+    if (d.in_mode != RAMNET_IN_PLAIN || d.C0 % 16 != 0 || d.Cout % 32 != 0) return 0;
+    const bool pair = fold_wino_pair(d.Cout, d.C0), wide = pair || (d.Cout % 64 == 0 && d.C0 % 16 == 0);
+    if (d.C0 % (wide ? 32 : 16) != 0) return 0;
+    const int nchunks = d.C0 / (wide ? 16 : 8), nblk = pair ? 1 : d.Cout / (wide ? 64 : 32);
+    const int Wt = pair ? d.Wo + 2 : d.Wo;
+    const bool flat = wide && cdiv(Wt, 16) * cdiv(d.Ho, 8) < cdiv(Wt, 8) * cdiv(d.Ho, 16);
+    const int tiles_x = cdiv(Wt, wide && !flat ? 8 : 16), tiles_y = cdiv(d.Ho, flat ? 8 : 16);
+    const unsigned gridx = (unsigned)(tiles_x * tiles_y * d.B * nblk * (pair ? 2 : 4));
+    const int ks = wino24_ksplit(d, (int)gridx, nchunks);
+    return ks > 1 ? wino24_ksplit_floats(gridx, ks) : 0;
+}
+
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     if (d.in_mode == RAMNET_IN_PARITY4) return launch_wino24_dgrad(d, st);
     // d.x0 = replicate-padded low-res input [B][Hin = H+4][Win = W+4][C0]; Ho, Wo = the parity grid (H, W); HoF = 2H, WoF = 2W
@@ -432,7 +505,13 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st) {
     const bool flat = wide && cdiv(Wt, 16) * cdiv(d.Ho, 8) < cdiv(Wt, 8) * cdiv(d.Ho, 16);      // 8 x 16 instead of 16 x 8 pixels
     q.tiles_x = cdiv(Wt, wide && !flat ? 8 : 16), q.tiles_y = cdiv(d.Ho, flat ? 8 : 16);
     const size_t lds = (size_t)2 * W24_V * sizeof(float);
-    const dim3 grid((unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * (pair ? 2 : 4)));
+    const unsigned gridx = (unsigned)(q.tiles_x * q.tiles_y * d.B * q.nblk * (pair ? 2 : 4));
+    const int want = wino24_ksplit(d, (int)gridx, q.nchunks);
+    q.ksplit = d.splitk_ws ? want : 1;
+    q.cnt = reinterpret_cast<int *>(d.splitk_ws);
+    q.ws = d.splitk_ws ? d.splitk_ws + cdiv((int)gridx, 64) * 64 : nullptr;
+    if (q.ksplit > 1) RAMNET_CHECK_ARG(d.splitk_floats >= wino24_ksplit_floats(gridx, want) && ((uintptr_t)d.splitk_ws & 15) == 0);
+    const dim3 grid(gridx, q.ksplit);
     if (pair && flat) {
         RAMNET_FULL_LDS((conv_wino24_kernel<4, false, 8, true>));
         note_kernel("conv_wino24_kernel<4,0,8,1>");

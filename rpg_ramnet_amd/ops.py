@@ -228,7 +228,7 @@ def uses_head(taps, w, stride, epi, in_mode):
 
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
                 C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
-                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0, wino24=False):
+                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0, wino24=False, ws_owner=None):
     B = x0.shape[0]
     d = H.ConvDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
@@ -236,7 +236,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     d.C0, d.C1, d.in_mode = (x0.shape[3] if C0 is None else C0), C1, in_mode
     d.algo = H.ALGO_DIRECT
     ref = None
-    cp = w.cp if isinstance(w, PackRef) else None
+    cp = w.cp if isinstance(w, PackRef) else ws_owner            # the layer that owns the split-reduction workspace
     if isinstance(w, PackRef) and beta == 0.0 and frame == 0 and os == (1, 1, 0, 0) and uses_head(taps, w, stride, epi, in_mode):
         d.algo, d.head_cin = H.ALGO_HEAD, w.cp.Cin
         w = w.cp.pack(0, "head")
@@ -266,7 +266,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     if ref is not None and _WINO_2X4 != "off" and H.lib().ramnet_conv_wino_variant(C.byref(d), int(_WINO_2X4 == "force")):
         # F(2x4,3x3) on the fine scales (csrc/conv_wino6.hip): its own Winograd-domain pack of the same parameters
         d.algo, d.w = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4"))
-    if d.algo == H.ALGO_WINOGRAD and cp is not None:
+    if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD24) and cp is not None:
         # latency-bound launches (batch-1 streaming on the coarse scales) split their channel reduction: the library says how much
         # workspace the launch would use, the layer owns it (csrc/conv_wino.hip, ramnet_conv_desc.splitk_ws)
         n = H.lib().ramnet_conv_splitk_floats(C.byref(d))
@@ -1013,7 +1013,7 @@ def _folded_upsample_conv(x, skip, cp, y, epi):
             g_rows.record_stream(main), g_cols.record_stream(main)
     desc_kw = dict(bias=cp.bias(), epi=epi, frame=2, e0=g_cols.view(2 * B, H2, 1, 2 * cp.Cout), e1=g_rows.view(2 * B, W2, 1, 2 * cp.Cout))
     if _FOLD_WINO and _fold_wino_ok(Cc, cp.Cout):   # Winograd F(2x2,4x4) over the four parities
-        conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, **desc_kw)
+        conv_launch(xpad, Taps.get("fold", 4, 0, 0, 0), cp.pack_fold_wino(), y, cp.Cout, Ho=Hh, Wo=W, wino24=True, ws_owner=cp, **desc_kw)
         return xpad
     conv_launch_multi(xpad, cp.pack_fold(), y, cp.Cout,
                       [(Taps.get("fold", 4, 0, py, px), Hh, W, (2, 2, py, px)) for py in range(2) for px in range(2)], **desc_kw)

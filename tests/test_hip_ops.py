@@ -397,6 +397,33 @@ def test_conv_gru_and_encoder_split_reduction_equals_unsplit(B, H, W, C):
         assert_close(a.cpu().numpy(), c.cpu().numpy(), 2e-5, "split vs unsplit")
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(1, 32, 43, 256, 128), (1, 32, 43, 128, 64), (1, 16, 22, 256, 128), (2, 8, 12, 128, 64)])
+def test_folded_decoder_split_reduction_equals_unsplit(B, H, W, cin, cout):
+    """The folded upsample-conv decoders split their channel reduction at batch 1 as well (csrc/conv_wino24.hip; decoder 0: 96 workgroups
+    of 16 chunks -> 192 of 8): split against unsplit (2e-5), repeated launches bit-identical, counters back at zero; test_upsample_conv at
+    (1, 32, 43) x (256, 128) runs the split launch against the float64 oracle."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import UpsampleConvLayer
+    torch.manual_seed(9)
+    m = UpsampleConvLayer(cin, cout, 5, padding=2).to(dev())
+    x, sk = torch.randn(B, H, W, cin, device=dev()), torch.randn(B, H, W, cin, device=dev())
+    outs = []
+    for on in (True, True, False):
+        ops.set_winograd_split(on)
+        try:
+            with torch.no_grad():
+                outs.append(m(x, sk))
+        finally:
+            ops.set_winograd_split(True)
+    pools = [cp.__dict__.get("_splitk", {}) for cp in m._cps.values()]
+    assert any(pools), "the launch did not split"
+    assert torch.equal(outs[0], outs[1])
+    assert_close(outs[0].cpu().numpy(), outs[2].cpu().numpy(), 2e-5, "split vs unsplit")
+    for pool in pools:
+        for ws in pool.values():
+            assert int(ws[:64].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (3, 32, 48)])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
 def test_winograd_wgrad_raw(B, H, W, cin, cout):

@@ -35,6 +35,20 @@ def main():
         ops.set_winograd_2x4("auto")
         tiles = min(-(-Ww // 4) * -(-Hh // 32), -(-Ww // 16) * -(-Hh // 8))
         print("%-34s %5d | %s   us" % (name, tiles * cout // 32, "  ".join("%8.1f" % v for v in t)))
+    # the folded decoders (csrc/conv_wino24.hip): the whole layer (padded sum + border GEMM + Winograd launch), only the last one splits
+    from rpg_ramnet_amd.model.submodules import UpsampleConvLayer
+    for name, Hh, Ww, cin, cout in (("decoder 0 32x43 256->128", 32, 43, 256, 128), ("decoder 1 64x86 128->64", 64, 86, 128, 64)):
+        m = UpsampleConvLayer(cin, cout, 5, padding=2).to(dev)
+        x, sk = torch.randn(1, Hh, Ww, cin, device=dev), torch.randn(1, Hh, Ww, cin, device=dev)
+        t = []
+        for s in (0, 1, 2, 3, 4, 6, 8):
+            ops.set_winograd_split(s)
+            with torch.no_grad():
+                fn = lambda: m(x, sk)      # noqa: E731
+                timeit(fn, reps=5)
+                t.append(1e3 * min(timeit(fn, reps=50) for _ in range(3)))
+        ops.set_winograd_split(1)
+        print("%-34s %5s | %s   us (whole layer)" % (name, "", "  ".join("%8.1f" % v for v in t)))
 
 
 if __name__ == "__main__":
