@@ -15,7 +15,9 @@ LIB = os.path.join(PKG, "librpg_ramnet_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # per-file additions.  conv_wino6.hip: its main loop places single scalar fp32 operations between MFMAs by hand; the SLP vectoriser
 # pairs neighbours into 2-wide vectors that the backend scalarises again through v_mov shuffles (4 moves per 2 v_fma)
-EXTRA_FLAGS = {"conv_wino6.hip": ["-fno-slp-vectorize"]}
+# (the SLP vectorizer pairs the fp32 transform arithmetic of these kernels into <2 x float> values that the backend takes apart again with
+# v_mov shuffles: 29 of 303 instructions per 32 MFMAs in the backward-weights loop)
+EXTRA_FLAGS = {"conv_wino6.hip": ["-fno-slp-vectorize"], "conv_wgrad_wino.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -19,6 +19,7 @@
 // Measured against the previous formulation (V[16][ci][8] / Z[16][64][8] in LDS, a transform phase between two barriers per
 // batch; same-box A/B, round 2): the six ConvGRU backward-weights launches of a pass 1.596 -> 1.468 ms.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 
 namespace ramnet {
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
     const int xa_off = (ra * PW + 2 * kk) * 32 + l31, xb_off = (rb * PW + 2 * kk) * 32 + l31;      // + st * G::SX
     const int y_off = (2 * kk) * GW_CO + l31;                                                       // + st * G::SY pixels
     float da[4], db[4], g0[NF][2], g1[NF][2];    // raw operands of the tile pair being prepared
-    float an[4], bn[NF][4];
+    float an[2][4], bn[2][NF][4];               // operand sets of tile pairs st & 1 = 0 / 1 (four pairs per batch: the parity carries over)
     auto fetch_x = [&](const float *xc, int st) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) da[c] = xc[xa_off + st * G::SX + c * 32], db[c] = xc[xb_off + st * G::SX + c * 32];
@@ -211,13 +212,13 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
             for (int c = 0; c < 2; ++c)
                 g0[f][c] = yc[y_off + (yr0 + st * G::SY + c) * GW_CO + f * 32], g1[f][c] = yc[y_off + (YW + st * G::SY + c) * GW_CO + f * 32];
     };
-    auto finish_x = [&]() {
+    auto finish_x = [&](int o) {
         const float t0 = da[0] + sb * db[0], t1 = da[1] + sb * db[1], t2 = da[2] + sb * db[2], t3 = da[3] + sb * db[3];
-        an[0] = t0 - t2, an[1] = t1 + t2, an[2] = t2 - t1, an[3] = t1 - t3;
+        an[o][0] = t0 - t2, an[o][1] = t1 + t2, an[o][2] = t2 - t1, an[o][3] = t1 - t3;
     };
-    auto finish_y = [&](int f) {
+    auto finish_y = [&](int o, int f) {
         const float r0 = g0[f][0] + cb * g1[f][0], r1 = g0[f][1] + cb * g1[f][1];
-        bn[f][0] = r0, bn[f][1] = r0 + r1, bn[f][2] = r0 - r1, bn[f][3] = r1;       // (position 3 and wave 3: sign applied at the end)
+        bn[o][f][0] = r0, bn[o][f][1] = r0 + r1, bn[o][f][2] = r0 - r1, bn[o][f][3] = r1;       // (position 3 and wave 3: sign applied at the end)
     };
 
     const int step = gridDim.x;
@@ -232,11 +233,11 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
         for (int i = 0; i < NYS; ++i) store_y(i, Yp);
         load_raw(min(batch + step, last));
         __syncthreads();
-        int cur = 0;
         fetch_x(Xp, 0), fetch_y(Yp, 0, 0, NF);      // operands of the first tile pair (later batches: prepared under the previous one)
-        finish_x();
+        finish_x(0);
 #pragma unroll
-        for (int f = 0; f < NF; ++f) finish_y(f);
+        for (int f = 0; f < NF; ++f) finish_y(0, f);
+        int cur = 0;
         for (; batch <= last; batch += step, cur ^= 1) {
             bias_on = batch + step <= last ? 1.f : 0.f;
             const int b2 = min(batch + 2 * step, last);
@@ -255,13 +256,7 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
             };
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                float a[4], bv[NF][4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    a[j] = an[j];
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) bv[f][j] = bn[f][j];
-                }
+                const int o = st & 1, on = o ^ 1;       // operand set in use / being prepared (no register copies)
                 // the operands of the next tile pair are fetched / finished in the gaps; for the last pair of a batch that is the
                 // first pair of the NEXT batch, whose raw strip is complete in the other buffer since the barrier behind pair 2
                 auto gap = [&](int gidx) {          // compile-time constant after unrolling
@@ -270,9 +265,9 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
                         if (gidx == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 0, 2);
                         if (gidx == 2) stage(st * 3);
                         if (gidx == 3) stage(st * 3 + 1);
-                        if (gidx == 4) finish_x();
-                        if (gidx == 5) finish_y(0);
-                        if (gidx == 6) finish_y(1);
+                        if (gidx == 4) finish_x(on);
+                        if (gidx == 5) finish_y(on, 0);
+                        if (gidx == 6) finish_y(on, 1);
                         if (gidx == 7) stage(st * 3 + 2);
                     } else {
                         if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
@@ -280,12 +275,12 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
                         if (gidx == 2) fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 2, 4);
                         if (gidx == 3) stage(st * 4);
                         if (gidx == 5) stage(st * 4 + 1);
-                        if (gidx == 7) finish_x();
-                        if (gidx == 8) finish_y(0);
-                        if (gidx == 9) finish_y(1);
+                        if (gidx == 7) finish_x(on);
+                        if (gidx == 8) finish_y(on, 0);
+                        if (gidx == 9) finish_y(on, 1);
                         if (gidx == 10) stage(st * 4 + 2);
-                        if (gidx == 11) finish_y(2);
-                        if (gidx == 12) finish_y(3);
+                        if (gidx == 11) finish_y(on, 2);
+                        if (gidx == 12) finish_y(on, 3);
                         if (gidx == 14) stage(st * 4 + 3);
                     }
                 };
@@ -294,7 +289,7 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
                         __builtin_amdgcn_sched_barrier(0);
-                        acc[pl][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[pl], bv[f][pl], acc[pl][f], 0, 0, 0);
+                        acc[pl][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[o][pl], bn[o][f][pl], acc[pl][f], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                         gap(pl * NF + f);
                     }
