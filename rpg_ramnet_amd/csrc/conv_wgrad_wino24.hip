@@ -23,6 +23,7 @@ struct Wgrad24Params {
     const float *x, *g, *gm;
     float *dw, *dbias;
     int ldx, ldg, ldgm, Hp, Wp, H2, W2, Hc, Wc, Cin, Cout, tiles_x, tiles_y, ntiles, nbatch, ncob;
+    size_t xbytes, gbytes, gmbytes;       // extents of x / g / gm (buffer addressing: < WOOB, checked on the host)
 };
 
 template <bool GM, bool WCI>
@@ -52,42 +53,66 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
 
     float vraw[25], zraw[4];
     float bsum = 0.f;
-    auto load_v = [&](int batch) {
-        const int T = batch * G24_T + vt;
-        const bool ok = T < p.ntiles && c0 + vc < p.Cin;
-        int t = min(T, p.ntiles - 1);
-        const int tx = t % p.tiles_x;
+    // Loaders (round 4: 670 -> see the header; two run-time integer divisions, 64-bit pointer arithmetic, ten clamps and a select per value
+    // before): the (image, tile row, tile column) of the thread's tile is divided out ONCE and then walks by the pre-divided grid stride
+    // with carries; a value is one buffer load at lane offset + scalar offset.  The window of a tile that overhangs the grid, or lies past
+    // the last tile, reads whatever finite data (or the zeros past the tensor) the offset finds: it only meets gradient entries that are
+    // zero — the Winograd row / column that contains window line 4 multiplies A g's last line, which is the out-of-grid gradient itself.
+    struct Walk { int tx, ty, b, T; };
+    const int dT = G24_T * (int)gridDim.x;
+    const int d_tx = dT % p.tiles_x, d_ty = (dT / p.tiles_x) % p.tiles_y, d_b = (dT / p.tiles_x) / p.tiles_y;
+    auto walk_init = [&](Walk &w, int batch, int tile) {
+        w.T = batch * G24_T + tile;
+        int t = w.T;
+        w.tx = t % p.tiles_x;
         t /= p.tiles_x;
-        const int ty = t % p.tiles_y, b = t / p.tiles_y;
-        const float *src = p.x + (size_t)b * p.Hp * p.Wp * p.ldx + min(c0 + vc, p.Cin - 1);
-        int rowo[5], colo[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) rowo[r] = min(2 * ty + py + r, p.Hp - 1) * p.Wp * p.ldx, colo[r] = min(2 * tx + px + r, p.Wp - 1) * p.ldx;
+        w.ty = t % p.tiles_y, w.b = t / p.tiles_y;
+    };
+    auto walk_step = [&](Walk &w, int adv) {            // adv = 1: the next batch of this workgroup, 0: the same one again (clamped tail)
+        w.T += adv * dT;
+        w.tx += adv * d_tx;
+        const int cx = w.tx >= p.tiles_x ? 1 : 0;
+        w.tx -= cx * p.tiles_x;
+        w.ty += adv * d_ty + cx;
+        const int cy = w.ty >= p.tiles_y ? 1 : 0;
+        w.ty -= cy * p.tiles_y;
+        w.b += adv * d_b + cy;
+    };
+    Walk wv, wz;
+    int lbv = 0, lbz = 0;                               // batch the walks stand at
+    const auto rx = wino_rsrc(p.x, (unsigned)min((size_t)p.xbytes, (size_t)WOOB));
+    const auto rg = wino_rsrc(p.g, (unsigned)min((size_t)p.gbytes, (size_t)WOOB));
+    const auto rgm = GM ? wino_rsrc(p.gm, (unsigned)min((size_t)p.gmbytes, (size_t)WOOB)) : rg;
+    const bool vch_ok = c0 + vc < p.Cin, zch_ok = n0 + zc < p.Cout;
+    const unsigned zch = (unsigned)(n0 + zc);
+    const int rowB = p.Wp * p.ldx * 4, colB = p.ldx * 4;                              // bytes per window row / column
+    auto load_v = [&](int batch) {
+        walk_step(wv, batch != lbv ? 1 : 0);
+        lbv = batch;
+        const unsigned base = (unsigned)(((wv.b * p.Hp + 2 * wv.ty + py) * p.Wp + 2 * wv.tx + px) * p.ldx + c0 + vc) * 4u;
+        const unsigned lane_off = ((wv.T < p.ntiles) & vch_ok) ? base : WOOB;
 #pragma unroll
         for (int r = 0; r < 5; ++r)
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                const float v = src[rowo[r] + colo[c]];
-                vraw[r * 5 + c] = ok ? v : 0.f;
-            }
+            for (int c = 0; c < 5; ++c)
+                vraw[r * 5 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(lane_off + (unsigned)(r * rowB)), c * colB, 0));
     };
     auto load_z = [&](int batch, bool count) {
-        const int T = batch * G24_T + zt;
-        int t = min(T, p.ntiles - 1);
-        const int tx = t % p.tiles_x;
-        t /= p.tiles_x;
-        const int ty = t % p.tiles_y, b = t / p.tiles_y;
-        const int n = min(n0 + zc, p.Cout - 1);
+        walk_step(wz, batch != lbz ? 1 : 0);
+        lbz = batch;
+        const bool tok = (wz.T < p.ntiles) & zch_ok;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int oy = 2 * ty + a, ox = 2 * tx + c;
-                const bool ok = T < p.ntiles && oy < p.Hc && ox < p.Wc && n0 + zc < p.Cout;
-                const size_t pix = ((size_t)b * p.H2 + min(2 * oy + py, p.H2 - 1)) * p.W2 + min(2 * ox + px, p.W2 - 1);
-                float v = p.g[pix * p.ldg + n];
-                if (GM) v = p.gm[pix * p.ldgm + n] > 0.f ? v : 0.f;
-                v = ok ? v : 0.f;
+                const int oy = 2 * wz.ty + a, ox = 2 * wz.tx + c;
+                const bool ok = tok & (oy < p.Hc) & (ox < p.Wc);
+                const unsigned pix = (unsigned)((wz.b * p.H2 + 2 * oy + py) * p.W2 + 2 * ox + px);
+                float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)(ok ? (pix * p.ldg + zch) * 4u : WOOB), 0, 0));
+                if (GM) {
+                    const float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rgm, (int)(ok ? (pix * p.ldgm + zch) * 4u : WOOB), 0, 0));
+                    v = m > 0.f ? v : 0.f;
+                }
                 zraw[a * 2 + c] = v;
                 if (count) bsum += v;
             }
@@ -134,6 +159,8 @@ __global__ void __launch_bounds__(512, 1) conv_wgrad_wino24_kernel(const Wgrad24
     if (batch < p.nbatch) {
         const int last = batch + ((p.nbatch - 1 - batch) / step) * step;
         // prologue: batch -> buffer 0; raw data of the next batch in registers
+        walk_init(wv, batch, vt), walk_init(wz, batch, zt);
+        lbv = lbz = batch;
         if (zrole) load_z(batch, true);
         if (vrole) load_v(batch);
         if (zrole) {
@@ -224,6 +251,10 @@ int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.x = d.x0, q.g = d.dout, q.gm = d.gmask, q.dw = d.dw, q.dbias = d.dbias;
     q.ldx = d.ld0, q.ldg = d.ldg, q.ldgm = d.ldgm, q.Hp = d.Hin, q.Wp = d.Win, q.H2 = d.HoG, q.W2 = d.WoG, q.Hc = d.Ho, q.Wc = d.Wo;
     q.Cin = d.C0, q.Cout = d.Cout;
+    q.xbytes = (size_t)d.B * d.Hin * d.Win * d.ld0 * 4, q.gbytes = (size_t)d.B * d.HoG * d.WoG * d.ldg * 4;
+    q.gmbytes = d.gmask ? (size_t)d.B * d.HoG * d.WoG * d.ldgm * 4 : 0;
+    // per-lane 32-bit byte offsets; a tile past the last one may stand up to one grid stride of images beyond the tensor
+    RAMNET_CHECK_ARG(2 * q.xbytes < WOOB && 2 * q.gbytes < WOOB && 2 * q.gmbytes < WOOB);
     q.tiles_x = cdiv(d.Wo, 2), q.tiles_y = cdiv(d.Ho, 2), q.ntiles = q.tiles_x * q.tiles_y * d.B, q.nbatch = cdiv(q.ntiles, G24_T);
     q.ncob = cdiv(d.Cout, G24_CO);
     const int gy = d.C0 / G24_CI, gz = q.ncob * 4;
