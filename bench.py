@@ -247,9 +247,16 @@ class KernelTimer:
             nclass = 4 if kw.get("wino24") else 1
             cin = getattr(dw, "head_cin", 0) or cin_of(x0, kw)
             alg = 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout
+            # operand bytes of a backward-weights launch: input (+ its mask / product operand) and output gradient (+ ReLU mask) read once,
+            # the gradient workspace — [16] (Winograd), [taps] (direct) or [4][25] (folded decoder) x Cin x Cout — read and written once
+            px_in, px_out = x0.shape[0] * x0.shape[1] * x0.shape[2], dout.shape[0] * ho * wo * nclass
+            mode, c1 = kw.get("in_mode", 0), kw.get("C1", 0)
+            rd = px_in * ((kw.get("C0") or x0.shape[3]) + c1) * (2 if mode == Hh.IN_RELUMASK else 1) + (px_in * c1 if mode == Hh.IN_CAT_MUL else 0)
+            rd += px_out * Cout * (2 if kw.get("gmask") is not None else 1)
+            npos = 100 if kw.get("wino24") else 16 if getattr(dw, "wino", False) else taps.n
             timer._bracket(lambda: wgrad0(x0, taps, dout, dw, Cout, **kw), last,
                            sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "head_cin", 0)),
-                           alg, taps.n / float(taps.flop_taps))
+                           alg, taps.n / float(taps.flop_taps), None, 4.0 * (rd + 2 * npos * cin * Cout))
 
         def multi(x0, w, out, Cout, classes, **kw):
             if not timer.on:
@@ -909,6 +916,11 @@ def main():
                "final_loss": loss_val, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
                "rccl_ranks_seen": ranks_seen, "backend": ((backend_note or args.backend) if (world > 1 or args.force_collective) else None),
                "loss_semantics": LOSS_SEMANTICS[bool(args.dp_exact_loss and args.mode == "train")]}
+        if args.mode == "train" and (world > 1 or args.force_collective):
+            out["grad_allreduce"] = {"buckets": len(reducer.buckets), "mb": reducer.flat.numel() * 4 / 1e6,
+                                     "buckets_issued_during_the_fold": reducer.early_buckets, "steps_run": args.steps + args.warmup,
+                                     "note": "parallel.FlatGradReducer: bucket k goes to the side stream as soon as the end-of-backward fold "
+                                             "has finalised the last parameter of buckets 0..k (SURVEY 8e); the rest in all_reduce()"}
         if args.mode == "stream":
             out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
                              "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "
@@ -944,7 +956,8 @@ def main():
                         "= same launches on one stream.  algorithmic_achieved = layer-level rate (SURVEY 8d count).  traffic = HBM bytes "
                         "per launch, (2*FETCH_SIZE + WRITE_SIZE), launch-weighted over the kernel's grids (gfx950 FETCH_SIZE counts 1/2 "
                         "of wide reads, MI355X_MICROARCH.md); operand_bytes_per_launch = inputs, masks and epilogue operands read once + outputs "
-                        "written once + weights once, averaged over the same launches"}
+                        "written once + weights once (backward-weights: input, gradient and their masks read once + the gradient workspace read and written "
+                        "once; its per-split slabs repeat that last term per split), averaged over the same launches"}
             if warm and args.warmup > 0:      # overlap-proof view: all MFMA FLOP of a step over the step's wall time
                 step_alg = sum(v[2] for v in warm.values()) / args.warmup
                 step_ex = sum(v[3] for v in warm.values()) / args.warmup

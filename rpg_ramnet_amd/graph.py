@@ -398,7 +398,7 @@ class GraphedTrainStep:
 
         def zero():
             if reducer is not None:
-                reducer.zero()
+                reducer.zero(arm=False)          # (the collectives stay outside the graph: all_reduce() after the replay)
             else:
                 for p in model.parameters():
                     if p.grad is None:

@@ -448,8 +448,15 @@ class _Engine:
     def flush(cls):
         cls._join()
         dirty, cls.dirty, cls.task = cls.dirty, [], -1
+        # data-parallel runs: parallel.FlatGradReducer watches the folds and sends a gradient bucket off as soon as its last
+        # parameter is final — not while a hipGraph is being captured (collectives stay outside the training graph)
+        hook = _FINALIZE_HOOK if (_FINALIZE_HOOK is not None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())) else None
+        if hook is not None:
+            hook.begin(dirty)
         for cp in dirty:
             cp.finalize()
+            if hook is not None:
+                hook.finalized(cp)
 
     @classmethod
     def reset(cls):
@@ -458,6 +465,15 @@ class _Engine:
         dirty, cls.dirty, cls.task = cls.dirty, [], -1
         for cp in dirty:
             cp.discard()
+
+
+_FINALIZE_HOOK = None
+
+
+def set_finalize_hook(hook):
+    """hook.begin(list of ConvParam about to be folded) / hook.finalized(cp) are called by the end-of-backward fold; None removes it."""
+    global _FINALIZE_HOOK
+    _FINALIZE_HOOK = hook
 
 
 def ensure_grad(p):

@@ -4,9 +4,14 @@ gradients averaged with RCCL (torch.distributed backend "nccl" on ROCm) over xGM
 The reference is single-GPU (no collective anywhere); this module ADDS data parallelism.
 Design for xGMI (point-to-point links, per-link bound rings): all 68-77 gradient tensors live in ONE flat fp32 buffer
 (59.5 MB for RAM-Net) whose views are the parameters' ``.grad``; it is all-reduced in a few large buckets on a side
-HIP stream.  Every weight is used at every time step of the BPTT pass, so no gradient is final before the pass ends
-and its fold (ops._Engine.flush) has run: all_reduce() is therefore called AFTER backward() returns and overlaps only
-host-side work (loss read-back, optimizer bookkeeping); Adam waits on the event recorded behind the last bucket.
+HIP stream.  Every weight is used at every time step of the BPTT pass, so no gradient is final before the backward of time
+step 0 has run; what CAN overlap is the end of the pass: the weight gradients accumulate in kernel-side workspaces that are
+folded into ``.grad`` layer by layer when the autograd engine finishes (ops._Engine.flush: slab joins, Winograd-domain
+un-transforms, the decoders' fold).  With ``overlap=True`` (default on GPUs) the reducer watches those folds and enqueues bucket
+k on the side stream as soon as the last parameter of buckets 0..k is final — decoder / prediction layers first, then the
+recurrent cells, then encoders and heads — so the collectives run under the remaining folds; all_reduce() after
+backward() sends whatever is left (everything, when the pass had no kernel-side folds) and Adam waits on the event recorded
+behind the last bucket.  Buckets are always issued in index order: every rank enqueues the same sequence of collectives.
 Loss semantics: each rank's loss is the mean over ITS batch (standard DDP); gradients are averaged over ranks.
 """
 import torch
@@ -14,9 +19,10 @@ import torch.distributed as dist
 
 
 class FlatGradReducer:
-    def __init__(self, model, process_group=None, num_buckets=3, always_collective=False):
+    def __init__(self, model, process_group=None, num_buckets=3, always_collective=False, overlap=True):
         """always_collective: issue the bucketed collectives even at world size 1 (an initialised process group is required) — the
-        RCCL path of a single-GPU box is then the very code an 8-GPU run executes."""
+        RCCL path of a single-GPU box is then the very code an 8-GPU run executes.  overlap: buckets leave during the end-of-backward
+        fold (see the module text); False = everything in all_reduce()."""
         self.always_collective = bool(always_collective)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
@@ -42,6 +48,15 @@ class FlatGradReducer:
         self.side = torch.cuda.Stream(device=dev) if self.cuda else None
         self.done = None
         self.attach()
+        # early issue during the fold: parameter -> bucket, buckets issued so far in this pass, folds still pending per bucket
+        self._bucket_of, off = {}, 0
+        for p in order:
+            self._bucket_of[p] = next(i for i, (lo, hi) in enumerate(self.buckets) if lo <= off < hi)
+            off += p.numel()
+        self._issued, self._pending, self.early_buckets, self._armed = 0, None, 0, False
+        if overlap and self.cuda:
+            from . import ops
+            ops.set_finalize_hook(self)
 
     @property
     def world(self):
@@ -53,9 +68,16 @@ class FlatGradReducer:
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v
 
-    def zero(self):
+    def zero(self, arm=True):
+        """Start of a step: gradients to zero; arms the early issue for the ONE backward pass that follows (a second pass before
+        all_reduce() — gradient accumulation — finds it disarmed and everything leaves in all_reduce()).  arm=False: the pass that
+        follows is NOT a collective one (a rank computing something on its own): nothing may leave early."""
+        if self._issued:                  # buckets of a pass whose all_reduce() never came: let them finish before the buffer is reused
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._issued, self._pending = 0, None
         self.flat.zero_()
         self.attach()
+        self._armed = bool(arm)
 
     def all_reduce(self):
         """Average gradients over ranks; asynchronous on the side stream (wait() before the optimizer)."""
@@ -64,22 +86,66 @@ class FlatGradReducer:
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():      # fresh .grad outside the flat buffer
                 v.copy_(p.grad)
                 p.grad = v
-        if w == 1 and not (self.always_collective and dist.is_available() and dist.is_initialized()):
+        if not self._collective():
             return
         if self.cuda:
-            ready = torch.cuda.current_stream().record_event()
-            self.side.wait_event(ready)
-            with torch.cuda.stream(self.side):
-                for lo, hi in self.buckets:
-                    chunk = self.flat[lo:hi]
-                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
-                    chunk.mul_(1.0 / w)
-                self.done = self.side.record_event()
+            self._issue(len(self.buckets))
+            self.done = self.side.record_event()
+            self._issued, self._pending = 0, None
         else:
             for lo, hi in self.buckets:
                 chunk = self.flat[lo:hi]
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
                 chunk.mul_(1.0 / w)
+
+    def _collective(self):
+        return self.world > 1 or (self.always_collective and dist.is_available() and dist.is_initialized())
+
+    def _issue(self, upto):
+        """Enqueue buckets [_issued, upto) on the side stream, behind everything the current stream has done so far."""
+        if upto <= self._issued:
+            return
+        w = self.world
+        self.side.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(self.side):
+            for lo, hi in self.buckets[self._issued:upto]:
+                chunk = self.flat[lo:hi]
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                chunk.mul_(1.0 / w)
+        self._issued = upto
+
+    # ---- ops.set_finalize_hook protocol (called by ops._Engine.flush at the end of a backward pass)
+    def begin(self, dirty):
+        self._pending = None
+        armed, self._armed = self._armed, False
+        if not armed or self._issued or not self._collective():
+            return
+        for p, v in self.views.items():             # a .grad outside the flat buffer (set_to_none between steps): all_reduce() repairs it
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                return
+        self._pending = [0] * len(self.buckets)
+        for cp in dirty:
+            for b in self._buckets_of(cp):
+                self._pending[b] += 1
+        self._ready()
+
+    def _buckets_of(self, cp):
+        ps = list(cp.weights) + [b for b in cp.biases if b is not None]
+        return {self._bucket_of[p] for p in ps if p in self._bucket_of}
+
+    def finalized(self, cp):
+        if self._pending is None:
+            return
+        for b in self._buckets_of(cp):
+            self._pending[b] -= 1
+        self._ready()
+
+    def _ready(self):
+        k = self._issued
+        while k < len(self.buckets) and self._pending[k] == 0:
+            k += 1
+        self.early_buckets += k - self._issued
+        self._issue(k)
 
     def wait(self):
         if self.done is not None:

@@ -22,7 +22,7 @@ def main():
     dist.init_process_group("gloo")
     cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
     model = build_hip_model("ERGB2DepthRecurrent", cfg).train()          # torch.manual_seed(0): identical weights on every rank
-    red = FlatGradReducer(model)
+    red = FlatGradReducer(model, overlap="--overlap" in sys.argv)      # (the plain mode reads the LOCAL gradients between backward and all_reduce)
     rng = np.random.default_rng(21)
     n_seq, L = 4, 2                                                      # 4 sequences of 2 packages, sharded r, r + world, ...
     data = [[make_item(rng, 1, 32, 48, 2, 5, 1, True, 0.1) for _ in range(L)] for _ in range(n_seq)]
@@ -31,7 +31,7 @@ def main():
         return [{k: torch.cat([data[i][l][k] for i in idx]) for k in data[0][l]} for l in range(L)]
 
     def local_grads(idx):
-        red.zero()
+        red.zero(arm=False)
         total, _ = sequence_loss(model, batch(idx), cfg["loss_composition"], [1, 1])
         total.backward()
         torch.cuda.synchronize()
@@ -88,7 +88,7 @@ def exact_mode(model, red, cfg, batch, mine, n_seq, rank, world):
     dist.all_gather_object(losses, loss_dp)
     if rank == 0:
         full = [i for r in range(world) for i in range(r, n_seq, world)]      # concatenation in rank order (order is irrelevant to the loss)
-        red.zero()
+        red.zero(arm=False)                                                    # (rank 0 alone: no collective may leave during this backward)
         t1, _ = sequence_loss(model, batch(full), lc, [1, 1])
         t1.backward()
         torch.cuda.synchronize()
@@ -107,7 +107,8 @@ def exact_mode(model, red, cfg, batch, mine, n_seq, rank, world):
         print(json.dumps({"rank": rank, "losses": losses, "loss_single": float(t1.detach()), "loss_oracle": float(ref.detach()),
                           "err_vs_single_rank_concat": float((avg - single).abs().max()) / scale,
                           "ddp_vs_single_rank_concat": float((ddp - single).abs().max()) / scale,
-                          "err_vs_oracle_concat": worst, "n": int(avg.numel())}))
+                          "err_vs_oracle_concat": worst, "n": int(avg.numel()), "early_buckets": red.early_buckets,
+                          "buckets": len(red.buckets)}))
     dist.barrier()
     dist.destroy_process_group()
 
