@@ -436,6 +436,19 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
     dt = clock(run_tb)
     dt2 = clock(runner(GraphedStream(model, 1, H, W, pipelined=True)))
     dt1 = clock(runner(GraphedStream(model, 1, H, W, pipelined=False)))
+
+    def live(g):                                        # a live sensor: the host waits for every depth map before the next measurement
+        def run():
+            for l, item in enumerate(items):
+                for k in range(sched[l]):
+                    g.update_events(item["events%d" % (k % K)])
+                    torch.cuda.synchronize()
+                g.update_image(item["image"])
+                torch.cuda.synchronize()
+        return run
+    from rpg_ramnet_amd.graph import LatencyStream
+    dtl = clock(live(LatencyStream(model, 1, H, W)))
+    dtl1 = clock(live(GraphedStream(model, 1, H, W, pipelined=False)))
     dte = clock(eager)
     model.train(was_training)
     out = {"workload": "configs[3]: batch 1, %dx%d, persistent ConvGRU state, %d event grids + %d frames per pass (grids per frame %s), "
@@ -443,11 +456,15 @@ def stream_b1_measure(model, seq, K, H, W, timer, frames=8, reps=3):
            "ms_per_update_and_decode": 1e3 * dt / n_upd, "updates_per_s": n_upd / dt, "runtime": "graph.TimeBatchedStream: the event grids "
            "up to the next frame form a group — encoders at batch n and decoders at batch n+1 in one launch chain each (they do not depend "
            "on the order of the updates), state updates one by one per scale; groups pipelined (hipGraph replays, four streams)",
-           "latency_ms_update_then_decode": 1e3 * dt1 / n_upd, "two_stage_ms_per_update_and_decode": 1e3 * dt2 / n_upd,
+           "latency_ms_update_then_decode": 1e3 * dtl / n_upd, "latency_ms_serial_graph_replays": 1e3 * dtl1 / n_upd,
+           "serial_ms_per_update_and_decode": 1e3 * dt1 / n_upd, "two_stage_ms_per_update_and_decode": 1e3 * dt2 / n_upd,
 
            "eager_ms_per_update_and_decode": 1e3 * dte / n_upd, "mfma_launches_per_update": nl / float(n_upd),
            "note": "ms_per_update_and_decode = period of the pipelined stream (throughput over a recorded stream, test.py:205-232); "
-                   "latency_ms_update_then_decode = one update followed by its decode as serial graph replays (what a live sensor sees); "
+                   "latency_ms_update_then_decode = what a live sensor sees: one measurement in, the host synchronises on its depth map "
+                   "(graph.LatencyStream: the fine scales' state updates on a second stream beside the coarse update, the residual blocks "
+                   "and decoder 0); latency_ms_serial_graph_replays = the same with one update graph + one decode graph on one stream "
+                   "(graph.GraphedStream); serial_ms = those replays back to back without the host wait; "
                    "two_stage = decode of update k beside update k+1 (graph.GraphedStream, the round-2 runtime)"}
     if ex > 0:
         out["roofline"] = {"bound": "mfma", "kernel": "whole update+decode chain (%d MFMA launches per update)" % round(nl / float(n_upd)),

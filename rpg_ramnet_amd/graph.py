@@ -36,6 +36,116 @@ def _warm(fn, n=2):
     torch.cuda.synchronize()
 
 
+class LatencyStream:
+    """Live batch-1 streaming with the shortest path from a measurement to its depth map (BASELINE configs[3], one measurement in, one
+    prediction out, the caller waits for it): the state updates of the two FINE scales are not on that path — the decoder needs them
+    only for its last two skip connections — so they run on a second HIP stream beside the coarse scale's update, the residual blocks
+    and the first decoder.  Four hipGraph replays per measurement on two real streams (no forks inside a capture):
+
+        main:  A  = head, encoder 0, encoder 1                 C1 = encoder 2, update of scale 2, residual blocks, decoder 0
+        side:        B  = updates of scales 0 and 1            C2 = decoders 1, 2 + prediction   (main, after B)
+
+    Same kernels, same arithmetic as ``GraphedStream`` (bit-identical predictions and states); state in two buffer sets used in
+    ping-pong.  RAM-Net wiring only (shared state, plain convolutional encoders: statenet.py:215-237)."""
+
+    def __init__(self, model, B, H, W):
+        net = model.statenetphasedrecurrent
+        assert not bool(model.baseline) and net.recurrent_block_type == 'conv' and net.num_encoders == 3
+        self.model, dev = model, model.gpu
+        self.ev_in = torch.zeros(B, model.num_bins_events, H, W, device=dev)
+        self.im_in = torch.zeros(B, model.num_bins_rgb, H, W, device=dev)
+        crop = model._crop_for(H, W)                 # full-frame mode: states at the reflect-padded size, predictions cropped back
+        Hs, Ws = (crop.height_crop_size, crop.width_crop_size) if crop is not None else (H, W)
+        self.sets = [model.init_states(B, Hs, Ws), model.init_states(B, Hs, Ws)]
+        self.cur = 0
+        self.side = torch.cuda.Stream(device=dev)
+        # (the critical chain on a high-priority stream of its own was measured: 0.54 -> 0.93 ms, profiles/r04_h_tuning_notes.md)
+        self.gA, self.gB, self.gC1, self.gC2, self.pred = {}, {}, {}, {}, {}
+        pair = net.state_combination == 'convlstm'
+        pick = (lambda s: s[0]) if pair else (lambda s: s)
+        was_training = model.training
+        model.eval()
+        feats = {}
+
+        def capture(fn):
+            _warm(fn)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            return g, out
+        for kind, buf, head, encs, combs in (("events", self.ev_in, net.head_events, net.encoders_events, net.state_combination_events),
+                                             ("image", self.im_in, net.head_rgb, net.encoders_rgb, net.state_combination_images)):
+            def part_a(buf=buf, head=head, encs=encs):
+                with torch.no_grad():
+                    x0 = encs[0](head(ops.pack_input(buf, dev, model._crop_for(H, W))))
+                    return x0, encs[1](x0)
+            self.gA[kind], feats[kind] = capture(part_a)
+            for src in (0, 1):
+                def part_b(kind=kind, combs=combs, src=src):
+                    with torch.no_grad():
+                        for i in (0, 1):
+                            combs[i](feats[kind][i], self.sets[src][i], self.sets[1 - src][i])
+                self.gB[(kind, src)], _ = capture(part_b)
+
+                def part_c1(kind=kind, encs=encs, combs=combs, src=src):
+                    with torch.no_grad():
+                        combs[2](encs[2](feats[kind][1]), self.sets[src][2], self.sets[1 - src][2])
+                        x = pick(self.sets[1 - src][2])
+                        for rb in net.resblocks:
+                            x = rb(x)
+                        return net.decoders[0](x)
+                self.gC1[(kind, src)], d0 = capture(part_c1)
+
+                def part_c2(d0=d0, dst=1 - src):     # (one per (modality, parity): it reads decoder 0's output out of THAT C1 graph's pool)
+                    with torch.no_grad():
+                        x = net.decoders[1](d0, pick(self.sets[dst][1]))
+                        x = net.decoders[2](x, pick(self.sets[dst][0]))
+                        if net.norm in ('BN', 'IN'):
+                            p = net.pred(x, act='sigmoid').permute(0, 3, 1, 2)
+                        else:
+                            p = ops.PredSigmoid.apply(x, net.pred.conv2d.weight, net.pred.conv2d.bias)
+                        crop = model._crop_for(H, W)
+                        return p if crop is None else crop.crop(p)
+                self.gC2[(kind, src)], self.pred[(kind, src)] = capture(part_c2)
+        self.reset()
+        model.train(was_training)
+
+    @property
+    def states(self):
+        return self.sets[self.cur]
+
+    def reset(self):
+        torch.cuda.synchronize(self.model.gpu)
+        for st in self.sets:
+            for s in st:
+                for t in (list(s) if isinstance(s, (list, tuple)) else [s]):
+                    t.zero_()
+        self.cur = 0
+
+    def _step(self, kind, buf, data):
+        src, dst = self.cur, 1 - self.cur
+        main = torch.cuda.current_stream()
+        buf.copy_(data, non_blocking=True)
+        self.gA[kind].replay()
+        self.side.wait_event(main.record_event())
+        with torch.cuda.stream(self.side):
+            self.gB[(kind, src)].replay()
+            done_b = self.side.record_event()
+        self.gC1[(kind, src)].replay()
+        main.wait_event(done_b)
+        self.gC2[(kind, src)].replay()
+        self.cur = dst
+        return self.pred[(kind, src)]
+
+    def update_events(self, grid):
+        """grid [B, Ce, H, W] (device or pinned host) -> prediction [B,1,H,W] (a static buffer, valid on the caller's stream until the
+        second-next measurement)."""
+        return self._step("events", self.ev_in, grid)
+
+    def update_image(self, frame):
+        return self._step("image", self.im_in, frame)
+
+
 class GraphedStream:
     """Streaming inference (batch B, persistent state): ``update_events(grid)`` / ``update_image(frame)`` fold one measurement
     into the shared state and return the depth prediction decoded from it — hipGraph replays, no per-kernel host work.

@@ -12,6 +12,34 @@ from util import assert_close, build_hip_model, ref_cfg
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("B,H,W,full_frame", [(1, 32, 48, False), (1, 64, 88, False), (2, 36, 50, True)])
+def test_latency_stream_equals_eager_primitives(B, H, W, full_frame):
+    """graph.LatencyStream (live batch-1 latency: the two fine scales' state updates on a second stream beside the coarse update,
+    the residual blocks and decoder 0; four graph replays per measurement) == update_events / update_image / decode launch by launch,
+    bit for bit, over an irregular schedule — predictions, final state, after a reset, and with full-frame padding."""
+    from rpg_ramnet_amd.graph import LatencyStream
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz")
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
+    model.set_full_frame(full_frame)
+    ls = LatencyStream(model, B, H, W)
+    rng = np.random.default_rng(4)
+    for rnd in range(2):
+        st = model.init_states(B, *((H, W) if not full_frame else (model._crop_for(H, W).height_crop_size, model._crop_for(H, W).width_crop_size)))
+        for n_ev in [2, 1, 3]:
+            item = make_item(rng, B, H, W, n_ev, 5, 1)
+            for k in range(n_ev + 1):
+                key = "events%d" % k if k < n_ev else "image"
+                with torch.no_grad():
+                    st, _ = (model.update_events if k < n_ev else model.update_image)(item[key], st)
+                    want = model.decode(st, frame_hw=(H, W) if full_frame else None)
+                got = (ls.update_events if k < n_ev else ls.update_image)(item[key].to(model.gpu)).clone()
+                assert torch.equal(got, want), "LatencyStream differs from the eager launches (%s, round %d)" % (key, rnd)
+        for a, b in zip(ls.states, st):
+            assert torch.equal(a, b)
+        ls.reset()
+    model.set_full_frame(False)
+
+
 @pytest.mark.parametrize("pipelined", [False, True])
 def test_graphed_stream_equals_eager_primitives_and_oracle(pipelined):
     """Irregular asynchronous schedule (1..3 event grids between frames), batch 1, persistent state: one hipGraph replay per

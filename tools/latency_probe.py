@@ -56,6 +56,9 @@ def main():
     for pipelined in (False,):
         g = GraphedStream(m, 1, H, W, pipelined=pipelined)
         print("hipGraph replays (update, decode), serial: %.3f ms" % timed(lambda: g.wait(g.update_events(ev))))
+    from rpg_ramnet_amd.graph import LatencyStream
+    ls = LatencyStream(m, 1, H, W)
+    print("graph.LatencyStream (fine-scale updates on a second stream, 4 replays): %.3f ms" % timed(lambda: ls.update_events(ev)))
     tb = TimeBatchedStream(m, 1, H, W, max_events=1)      # groups of ONE measurement: encoder chain, then the three scales' updates side by side, then the decode
     print("hipGraph chains, per-scale updates side by side (TimeBatchedStream, groups of 1): %.3f ms" % timed(lambda: tb.wait(tb.push_events(ev))))
 

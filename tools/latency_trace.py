@@ -25,7 +25,13 @@ def run(eager):
     m = m.to(m.gpu).eval()
     H, W = 256, 344
     ev = torch.randn(1, 5, H, W, device=m.gpu)
-    if eager:
+    if "--latency-stream" in sys.argv:
+        from rpg_ramnet_amd.graph import LatencyStream
+        ls = LatencyStream(m, 1, H, W)
+
+        def one():
+            ls.update_events(ev)
+    elif eager:
         st = [m.init_states(1, H, W)]
 
         def one():
@@ -62,14 +68,14 @@ def table(path):
     g = same[-1]
     t0 = int(g[0]["Start_Timestamp"])
     print("%d measurements of %d launches in the trace; the last one:" % (len(same), n))
-    print("%9s %8s %8s %6s  %s" % ("start us", "dur us", "gap us", "WGs", "kernel"))
+    print("%9s %8s %8s %6s %5s  %s" % ("start us", "dur us", "gap us", "WGs", "queue", "kernel"))
     prev_end, busy = t0, 0.0
     for r in g:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         wg = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)) // max(
             1, int(r["Workgroup_Size_X"]) * int(r.get("Workgroup_Size_Y", 1)) * int(r.get("Workgroup_Size_Z", 1)))
         name = r["Kernel_Name"].replace("ramnet::", "").replace("void ", "").split("(")[0]
-        print("%9.1f %8.1f %8.1f %6d  %s" % ((s - t0) * 1e-3, (e - s) * 1e-3, (s - prev_end) * 1e-3, wg, name[:90]))
+        print("%9.1f %8.1f %8.1f %6d %5s  %s" % ((s - t0) * 1e-3, (e - s) * 1e-3, (s - prev_end) * 1e-3, wg, r.get("Queue_Id", "")[-3:], name[:90]))
         busy += (e - s) * 1e-3
         prev_end = max(prev_end, e)
     span = [(int(x[-1]["End_Timestamp"]) - int(x[0]["Start_Timestamp"])) * 1e-3 for x in same[2:]]
