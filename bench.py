@@ -87,6 +87,7 @@ def parse():
                          "JSON line (value null) and exit before any GPU work: the launch contract alone (CPU test)")
     ap.add_argument("--wino2x4", default="auto", help="F(2x4,3x3) kernel selection for A/B runs: auto (library heuristics) | off | force, "
                     "optionally ,min_wgs (ops.set_winograd_2x4)")
+    ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384, the default)")
     ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
     ap.add_argument("--graph", action="store_true",
@@ -646,6 +647,8 @@ def main():
     ops.set_wgrad_overlap(args.overlap_wgrad)
     ops.set_decoder_overlap(args.overlap_decoder)
     ops.set_wgrad_slabs(not args.wgrad_atomic)
+    if args.wgrad_wino_nf:
+        Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", args.wgrad_wino_nf), "set_option")
     if args.wgrad_wino_blocks:
         Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_blocks", args.wgrad_wino_blocks), "set_option")
     w24 = args.wino2x4.split(",")

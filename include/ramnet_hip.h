@@ -148,6 +148,9 @@ typedef struct ramnet_wgrad_desc {
  * voxelizer forms), "fold_pair" (1; 0 = 32-channel folded decoders as 64 tiles x 32 channels — changes the layout ramnet_pack_weight_fold_wino
  * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel), "wgrad_wino_blocks" (384, <= 384: the same for the
  * Winograd backward-weights kernel — measured with F(2x4) in place: 384 -> 215.9, 320 -> 210.7, 256 -> 209.7, 192 -> 193.6 samples/s).
+ * "wgrad_wino_nf" (1; 2: 32-channel output blocks per workgroup of the Winograd backward-weights kernel — 1 = 32 x 32 channels, 168 registers, three
+ * workgroups per CU: six ConvGRU launches 1.54 -> 1.31 ms on their own; 2 = 32 x 64 channels, two per CU: what a caller that co-schedules these
+ * launches with a backward-data chain on another stream wants (training step 217 vs 211 samples/s) —
  * "wino_ksplit" (1 = the library's heuristic; 0 = ramnet_conv_splitk_floats answers 0: no launch splits its reduction; 2..16 = that many
  * splits for every launch whose epilogue can join partials: tuning runs).
  * ramnet_get_option: -1 if unknown.  */

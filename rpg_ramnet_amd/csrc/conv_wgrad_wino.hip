@@ -51,7 +51,7 @@ template <int TXB, int NF = 2> struct GrGeom {
 };
 
 template <int XMK, bool GM, int TXB, int NF>
-__global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
+__global__ void __launch_bounds__(256, NF == 4 ? 1 : NF == 1 ? 3 : 2) conv_wgrad_wino_r_kernel(const ramnet_wgrad_desc p, const WgradWinoParams q) {
     using G = GrGeom<TXB, NF>;
     constexpr int NT = 256, XQ = 8, GW_CI = 32, NXS = G::NXS, NYS = NF, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
     constexpr int GW_CO = G::GW_CO, YQ = GW_CO / 4;          // channel quads per gradient pixel
@@ -260,7 +260,12 @@ __global__ void __launch_bounds__(256, NF == 4 ? 1 : 2) conv_wgrad_wino_r_kernel
                 // the operands of the next tile pair are fetched / finished in the gaps; for the last pair of a batch that is the
                 // first pair of the NEXT batch, whose raw strip is complete in the other buffer since the barrier behind pair 2
                 auto gap = [&](int gidx) {          // compile-time constant after unrolling
-                    if (NF == 2) {
+                    if (NF == 1) {
+                        if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3), fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 0, 1);
+                        if (gidx == 1) stage(st * 3), stage(st * 3 + 1);
+                        if (gidx == 2) finish_x(on);
+                        if (gidx == 3) finish_y(on, 0), stage(st * 3 + 2);
+                    } else if (NF == 2) {
                         if (gidx == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
                         if (gidx == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3, 0, 2);
                         if (gidx == 2) stage(st * 3);
@@ -431,11 +436,11 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     // (A 128-channel workgroup — NF = 4: 256 accumulators, one workgroup per CU, 7.25 instead of 11 instructions per MFMA — was built in
     // round 3: six ConvGRU launches 1.522 -> 1.434 ms alone, training step 200.2 -> 190.5 samples/s co-scheduled; its launch path and
     // environment knob were removed in round 4, the kernel template keeps the parameter.)
-    const int nf = 2;
+    const int nf = g_opt_wgrad_wino_nf;
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32 * nf);
     // co-scheduled with the backward-data chain on another stream (the training step): 384 workgroups leave it room (measured
     // 256 ... 512: profiles/r03_h_tuning_notes.md)
-    int splits = g_opt_wgrad_wino_blocks / (gy * gz);            // (<= WGRAD_WINO_TARGET: the slabs are sized for that)
+    int splits = g_opt_wgrad_wino_blocks * (2 / nf) / (gy * gz);            // (<= WGRAD_WINO_TARGET: the slabs are sized for that)
     if (splits > q.nbatch) splits = q.nbatch;
     if (d.dw_slabs > 0 && splits > d.dw_slabs) splits = d.dw_slabs;
     if (splits < 1) splits = 1;
@@ -451,7 +456,9 @@ int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st) {
     note_kernel("conv_wgrad_wino_r_kernel<%d,%d,%d,%d>", xmk, (int)gm, tall ? 2 : 8, nf);
 #define RAMNET_GO(XMv, GMv)                                                                                                  \
     do {                                                                                                                     \
-    if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 2>), grid, dim3(256), lds, st, d, q);            \
+    if (tall && nf == 1) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 1>), grid, dim3(256), lds, st, d, q); \
+    else if (nf == 1) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8, 1>), grid, dim3(256), lds, st, d, q);    \
+    else if (tall) hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 2, 2>), grid, dim3(256), lds, st, d, q);       \
     else hipLaunchKernelGGL((conv_wgrad_wino_r_kernel<XMv, GMv, 8, 2>), grid, dim3(256), lds, st, d, q);                 \
     } while (0)
     if (xmk == 1 && gm) RAMNET_GO(1, true);

@@ -601,13 +601,14 @@ extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
 
 // Process-wide A/B options (tests and tuning runs; the environment variables they replace are gone since round 4)
 namespace ramnet {
-int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1;
+int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1;
 }
 extern "C" int ramnet_set_option(const char *name, int value) {
     RAMNET_CHECK_ARG(name != nullptr);
     if (!strcmp(name, "voxel_sorted")) ramnet::g_opt_voxel_sorted = value != 0;
     else if (!strcmp(name, "fold_pair")) ramnet::g_opt_fold_pair = value != 0;
     else if (!strcmp(name, "wgrad_blocks")) { RAMNET_CHECK_ARG(value >= 1); ramnet::g_opt_wgrad_blocks = value; }
+    else if (!strcmp(name, "wgrad_wino_nf")) { RAMNET_CHECK_ARG(value == 1 || value == 2); ramnet::g_opt_wgrad_wino_nf = value; }
     else if (!strcmp(name, "wino_ksplit")) { RAMNET_CHECK_ARG(value >= 0 && value <= 16); ramnet::g_opt_wino_ksplit = value; }
     else if (!strcmp(name, "wgrad_wino_blocks")) { RAMNET_CHECK_ARG(value >= 1 && value <= 384); ramnet::g_opt_wgrad_wino_blocks = value; }
     else RAMNET_CHECK_ARG(!"ramnet_set_option: unknown option");
@@ -620,6 +621,7 @@ extern "C" int ramnet_get_option(const char *name) {
     if (!strcmp(name, "wgrad_blocks")) return ramnet::g_opt_wgrad_blocks;
     if (!strcmp(name, "wgrad_wino_blocks")) return ramnet::g_opt_wgrad_wino_blocks;
     if (!strcmp(name, "wino_ksplit")) return ramnet::g_opt_wino_ksplit;
+    if (!strcmp(name, "wgrad_wino_nf")) return ramnet::g_opt_wgrad_wino_nf;
     return -1;
 }
 

@@ -317,6 +317,10 @@ def set_wgrad_overlap(on):
     MI355X; per-kernel timings then include co-scheduled time, so profiling runs keep it off)."""
     global _USE_SIDE
     _USE_SIDE = bool(on)
+    # the Winograd backward-weights kernel in the shape that suits the schedule: 32 x 64-channel workgroups (two per CU) share the CUs
+    # with the backward-data chain of the other stream; 32 x 32-channel workgroups (168 registers: three per CU) are 13-20 % faster on
+    # their own and 3 % slower in the co-scheduled step, where three of them leave a CU no room for a backward-data workgroup
+    H.check(H.lib().ramnet_set_option(b"wgrad_wino_nf", 2 if _USE_SIDE else 1), "set_option")
 
 
 # The decoder of update k (prediction for that measurement) and the state update k+1 both depend only on the state after

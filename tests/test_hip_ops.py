@@ -424,9 +424,18 @@ def test_folded_decoder_split_reduction_equals_unsplit(B, H, W, cin, cout):
             assert int(ws[:64].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.fixture(params=[1, 2])
+def wgrad_nf(request):
+    """Both workgroup shapes of the Winograd backward-weights kernel: 32 x 32 channels (three per CU: launches on their own stream order) and
+    32 x 64 (two per CU: the co-scheduled training step, ops.set_wgrad_overlap(True))."""
+    Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", request.param), "set_option")
+    yield request.param
+    Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", 1), "set_option")
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (3, 32, 48)])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
-def test_winograd_wgrad_raw(B, H, W, cin, cout):
+def test_winograd_wgrad_raw(B, H, W, cin, cout, wgrad_nf):
     """Winograd backward-weights (+bias, + ReLU mask on the gradient) against float64 autograd and the direct kernel."""
     import torch.nn.functional as F
     from rpg_ramnet_amd import ops
@@ -457,7 +466,7 @@ def test_winograd_wgrad_raw(B, H, W, cin, cout):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(4, 32, 48, 64, 128), (2, 9, 43, 96, 64)])
-def test_winograd_wgrad_slabs_bit_reproducible(B, H, W, cin, cout):
+def test_winograd_wgrad_slabs_bit_reproducible(B, H, W, cin, cout, wgrad_nf):
     """the tile splits of the Winograd backward-weights launch join per-split slabs by plain read-modify-write
     (ramnet_wgrad_desc.dw_slabs) instead of atomic adds.  Two passes over the same data — three accumulating launches each, as over
     BPTT time steps — give BIT-IDENTICAL weight and bias gradients, equal to float64 autograd; the atomic form (one workspace) still

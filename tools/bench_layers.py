@@ -30,8 +30,12 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=344)
     ap.add_argument("--only", default="")
+    ap.add_argument("--wgrad-wino-nf", type=int, default=0)
     ap.add_argument("--wino2x4", default="auto", help="auto | off | force[,min_wgs]: F(2x4,3x3) selection (ops.set_winograd_2x4)")
     a = ap.parse_args()
+    if a.wgrad_wino_nf:
+        from rpg_ramnet_amd import _hip as H_
+        H_.check(H_.lib().ramnet_set_option(b"wgrad_wino_nf", a.wgrad_wino_nf), "set_option")
     w24 = a.wino2x4.split(",")
     ops.set_winograd_2x4(w24[0], min_wgs=int(w24[1]) if len(w24) > 1 else None)
     dev = torch.device("cuda:0")
