@@ -107,8 +107,28 @@ class LatencyStream:
                         crop = model._crop_for(H, W)
                         return p if crop is None else crop.crop(p)
                 self.gC2[(kind, src)], self.pred[(kind, src)] = capture(part_c2)
+        self._pick_side_stream()
         self.reset()
         model.train(was_training)
+
+    def _pick_side_stream(self, candidates=4, reps=8):
+        """HIP maps streams onto a few hardware queues; a side stream that lands on the caller's queue runs the fine updates IN ORDER
+        with the critical chain (measured: 0.62 instead of 0.54 ms).  Time a few measurements with each of `candidates` streams, keep the best."""
+        import time
+        best = None
+        for i in range(candidates):
+            cand = self.side if i == 0 else torch.cuda.Stream(device=self.model.gpu)
+            self.side = cand
+            for r in range(reps + 2):
+                if r == 2:
+                    torch.cuda.synchronize(self.model.gpu)
+                    t = time.perf_counter()
+                self._step("events", self.ev_in, self.ev_in)
+                torch.cuda.synchronize(self.model.gpu)
+            dt = time.perf_counter() - t
+            if best is None or dt < best[0]:
+                best = (dt, cand)
+        self.side = best[1]
 
     @property
     def states(self):
