@@ -87,6 +87,7 @@ def parse():
                          "JSON line (value null) and exit before any GPU work: the launch contract alone (CPU test)")
     ap.add_argument("--wino2x4", default="auto", help="F(2x4,3x3) kernel selection for A/B runs: auto (library heuristics) | off | force, "
                     "optionally ,min_wgs (ops.set_winograd_2x4)")
+    ap.add_argument("--wgrad-2x4", default="auto", choices=["auto", "off", "force"], help="A/B: F(2x4,3x3) backward-weights (ops.set_wgrad_winograd_2x4)")
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384, the default)")
     ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
@@ -134,7 +135,7 @@ def winograd_factor(kernel):
     F(2x2,4x4) 25 per 64; direct kernels 1."""
     if kernel.startswith(("conv_wino_kernel", "conv_wino_r_kernel", "conv_wgrad_wino_kernel", "conv_wgrad_wino_r_kernel")):
         return 16.0 / 36.0
-    if kernel.startswith("conv_wino_r6_kernel"):      # F(2x4,3x3): a 4 x 6 grid of products per 2 x 4 outputs x 9 taps
+    if kernel.startswith(("conv_wino_r6_kernel", "conv_wgrad_wino_r6_kernel")):      # F(2x4,3x3): a 4 x 6 grid of products per 2 x 4 outputs x 9 taps
         return 24.0 / 72.0
     if kernel.startswith(("conv_wino24_kernel", "conv_wgrad_wino24_kernel")):
         return 25.0 / 64.0
@@ -254,9 +255,9 @@ class KernelTimer:
             mode, c1 = kw.get("in_mode", 0), kw.get("C1", 0)
             rd = px_in * ((kw.get("C0") or x0.shape[3]) + c1) * (2 if mode == Hh.IN_RELUMASK else 1) + (px_in * c1 if mode == Hh.IN_CAT_MUL else 0)
             rd += px_out * Cout * (2 if kw.get("gmask") is not None else 1)
-            npos = 100 if kw.get("wino24") else 16 if getattr(dw, "wino", False) else taps.n
+            npos = 100 if kw.get("wino24") else 24 if getattr(dw, "wino6", False) else 16 if getattr(dw, "wino", False) else taps.n
             timer._bracket(lambda: wgrad0(x0, taps, dout, dw, Cout, **kw), last,
-                           sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "head_cin", 0)),
+                           sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "head_cin", 0)),
                            alg, taps.n / float(taps.flop_taps), None, 4.0 * (rd + 2 * npos * cin * Cout))
 
         def multi(x0, w, out, Cout, classes, **kw):
@@ -647,6 +648,7 @@ def main():
     ops.set_wgrad_overlap(args.overlap_wgrad)
     ops.set_decoder_overlap(args.overlap_decoder)
     ops.set_wgrad_slabs(not args.wgrad_atomic)
+    ops.set_wgrad_winograd_2x4(args.wgrad_2x4)
     if args.wgrad_wino_nf:
         Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", args.wgrad_wino_nf), "set_option")
     if args.wgrad_wino_blocks:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 16      /* 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 17      /* 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -130,6 +130,8 @@ typedef struct ramnet_wgrad_desc {
     float *dbias;                   /* [Cout] or NULL                                               */
     int algo;                       /* RAMNET_ALGO_DIRECT, or RAMNET_ALGO_WINOGRAD: dense 3x3 stride-1 taps in kh*3+kw order; dw then
                                      * accumulates the transformed-domain gradient dU, folded by ramnet_unpack_wgrad_wino();
+                                     * or RAMNET_ALGO_WINOGRAD_2X4 (same launches, plain / concatenated / masked inputs): dw = dU [24][Cin][Cout]
+                                     * of F(2x4,3x3) (24 multiplies per 8 outputs instead of 32), folded by ramnet_unpack_wgrad_wino2x4();
                                      * or RAMNET_ALGO_WINOGRAD24 (folded upsample-conv): x0 = [B][Hin = Ho+4][Win = Wo+4][C0] as for the
                                      * forward launch, dout / gmask = the full-resolution [B][HoG = 2*Ho][WoG = 2*Wo][Cout] tensors,
                                      * dw = dU [4 classes][25 positions][C0][Cout] (dW4 = G^T dU G per class); C0 % 32 == 0 and Cout % 64 == 0, or C0 % 64 == 0 and Cout % 32 == 0 */
@@ -188,6 +190,7 @@ int ramnet_reflect_pad(const float *src, float *dst, int B, int C, int H, int W,
 /* Slabs the Winograd backward-weights launches of a Cin -> Cout layer use at most (ramnet_wgrad_desc.dw_slabs), and the ordered fold
  * slab 0 += slab 1 + ... + slab S-1 (n floats each, n % 4 == 0; slabs 1.. are zeroed) at the end of a backward pass.            */
 int ramnet_wgrad_wino_slabs(int Cin, int Cout);
+int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout);      /* the same for RAMNET_ALGO_WINOGRAD_2X4 launches (slabs of [24][Cin][Cout]) */
 int ramnet_reduce_slabs(float *ws, int slabs, size_t n, void *stream);
 /* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
 size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
@@ -246,6 +249,9 @@ int ramnet_unpack_wgrad(const float *ws, float *grad_oihw, int Cout, int Cin, in
 /* Winograd backward-weights workspace [16][CinWs][CoutWs] (dU) -> OIHW 3x3: grad += G^T dU G.                 */
 int ramnet_unpack_wgrad_wino(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
                              void *stream);
+/* F(2x4,3x3) backward-weights workspace [24 = 4 rows x 6 columns][CinWs][CoutWs] -> OIHW 3x3: grad += G_r^T dU G_c (ABI 17).  */
+int ramnet_unpack_wgrad_wino2x4(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
+                                void *stream);
 
 /* ---- the two MFMA kernels ----------------------------------------------------------------------- */
 int ramnet_conv_launch(const ramnet_conv_desc *d, void *stream);    /* forward and backward-data   */

@@ -70,6 +70,7 @@ _SIGS = {
     "ramnet_nchw_to_nhwc_pad": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_reflect_pad": (C.c_int, [_fp, _fp] + [C.c_int] * 10 + [_fp]),
     "ramnet_wgrad_wino_slabs": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_wgrad_wino2x4_slabs": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_reduce_slabs": (C.c_int, [_fp, C.c_int, C.c_size_t, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -98,6 +99,7 @@ _SIGS = {
     "ramnet_frame_gather": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_unpack_wgrad": (C.c_int, [_fp, _fp] + [C.c_int] * 7 + [_fp]),
     "ramnet_unpack_wgrad_wino": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp]),
+    "ramnet_unpack_wgrad_wino2x4": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp]),
     "ramnet_conv_launch": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ramnet_conv_launch_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _fp]),
     "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),
@@ -185,7 +187,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 16:
+        if l.ramnet_abi_version() != 17:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

@@ -25,6 +25,7 @@ int launch_wino24(const ramnet_conv_desc &d, hipStream_t st); // conv_wino24.hip
 int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino24.hip
 int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st);
 int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino.hip
+int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st);  // conv_wgrad_wino6.hip: F(2x4,3x3)
 
 #define RAMNET_CHECK_ARG(cond)                                                        \
     do {                                                                              \

@@ -1,0 +1,410 @@
+// Winograd F(2x4, 3x3) backward-weights for gfx950 (MI355X): the 3x3 stride-1 layers of the RAM-Net path at the training batch (ConvGRU
+// gates / candidate, residual blocks: submodules.py:447-452, 200-215), exact-fp32 arithmetic on v_mfma_f32_32x32x2_f32.
+//
+//   y = A_r^T [ (G_r g G_c^T) .* (B_r^T d B_c) ] A_c   (F(2,3) along rows, F(4,3) along columns: csrc/conv_wino6.hip)
+//   =>  dU_p[ci][co] = sum_tiles V_p[tile][ci] * Z_p[tile][co],  V = B_r^T d B_c (4 x 6 window -> 4 x 6),  Z = A_r dy A_c^T (2 x 4 -> 4 x 6),
+//       dg = G_r^T dU G_c (ramnet_unpack_wgrad_wino2x4): 24 multiplies per 8 outputs and channel pair instead of the 32 of F(2x2,3x3).
+//
+// Same formulation as csrc/conv_wgrad_wino.hip — the four waves own the four ROWS of the transform grid, one MFMA step reduces over two
+// tiles, lane (channel, tile parity) forms row `wave` of both transforms in registers out of raw LDS strips, and those are the A / B
+// operands — with six column positions per wave instead of four: a workgroup owns 32 input x 32 output channels (6 x 16 = 96 accumulators,
+// two workgroups per CU: the shape the co-scheduled training step wants), a batch is 8 tiles = 64 output pixels (a 4 x 16,
+// 8 x 8 or 16 x 4 pixel strip, whichever pads the map least), raw strips double-buffered with one barrier per batch, the tile splits of a
+// launch own per-split slabs of a [S][24][Cin][Cout] workspace (plain read-modify-write: bit-reproducible).
+#include <stdlib.h>
+#include "common.hpp"
+
+namespace ramnet {
+
+constexpr int WG6_TARGET = 384;      // workgroups per launch the tile splits aim at
+
+struct WgradWino6Params {
+    InSrc src;
+    int bx_n, ty_n, nbatch;     // strips per row, strip rows per image, total
+    int dy0, dx0;               // offset of the first filter tap
+};
+
+// TXB = tile columns per strip: 4 (4 x 16 output pixels), 2 (8 x 8) or 1 (16 x 4)
+template <int TXB> struct G6Geom {
+    static constexpr int TYB = 8 / TXB, YH = 2 * TYB, YW = 4 * TXB, PH = YH + 2, PW = YW + 2;
+    static constexpr int XPIX = PH * PW, XSLOTS = XPIX * 8, NXS = (XSLOTS + 255) / 256;
+    static constexpr int XP = XPIX * 32;           // raw input strip [PH x PW pixels][32 channels]
+    static constexpr int YP = YH * YW * 32;        // raw gradient strip [64 pixels][32 channels]
+    // tile pair st (tiles 2 st, 2 st + 1; the lane's tile = 2 st + kk): offsets of its window / output origin that do not depend on the lane
+    static constexpr int sx(int st) { return (TXB == 4 ? (st >> 1) * 2 * PW + (st & 1) * 8 : TXB == 2 ? st * 2 * PW : st * 4 * PW) * 32; }
+    static constexpr int sy(int st) { return TXB == 4 ? (st >> 1) * 2 * YW + (st & 1) * 8 : TXB == 2 ? st * 2 * YW : st * 4 * YW; }
+};
+
+// XMK: second operand of the input loader — 0 none, 1 ReLU mask (x * (xm > 0)), 2 product (the h*r half of a CAT_MUL input); GM: ReLU mask on dy
+template <int XMK, bool GM, int TXB>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet_wgrad_desc p, const WgradWino6Params q) {
+    using G = G6Geom<TXB>;
+    constexpr int NT = 256, XQ = 8, YQ = 8, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
+    constexpr int PW = G::PW, YW = G::YW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xp = smem;                   // [2][XPIX][32]
+    float *Yp = smem + 2 * GR_XP;       // [2][64][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int c0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+    const InSrc &s = q.src;
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- raw-data prefetch (as in conv_wgrad_wino.hip: buffer loads at lane + scalar offsets, out-of-image = out-of-range offset)
+    float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
+    const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
+    const bool use_m = XMK == 1 || (XMK == 2 && second);
+    const float m_one = use_m ? 0.f : 1.f;
+    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
+    const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
+    const int ldS = second ? s.ld1 : s.ld0;
+    int xpy[NXS], xpx[NXS], ypx[NYS], ypy[NYS], xdst[NXS];
+    unsigned xoff[NXS], xmoff[NXS], yoff[NYS], ymoff[NYS];
+    bool xslot[NXS], yslot[NYS];
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) {
+        const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
+        xpy[i] = pix / PW, xpx[i] = pix - xpy[i] * PW;
+        xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
+        xoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * ldS + qd * 4) * 4u;
+        xmoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4) * 4u;
+        xdst[i] = sl < XSLOTS ? (sl / XQ) * 32 + (sl % XQ) * 4 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NYS; ++i) {
+        const int sl = tid + i * NT, qd = sl % YQ, pix = sl / YQ;
+        ypx[i] = pix % YW, ypy[i] = pix / YW;
+        yslot[i] = n0 + qd * 4 < p.Cout;
+        yoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4) * 4u;
+        ymoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4) * 4u;
+    }
+    int lb_ty = 0, lb_bx = 0, lb_b = 0, lb_batch = 0;
+    const int pad_m = -(q.dy0 * s.Win + q.dx0);
+    const int padS = pad_m > 0 ? pad_m : 0;
+    unsigned so_x = 0, so_m = 0, so_g = 0, so_gm = 0;
+    const int st_bx = (int)gridDim.x % q.bx_n, st_ty = ((int)gridDim.x / q.bx_n) % q.ty_n, st_b = ((int)gridDim.x / q.bx_n) / q.ty_n;
+    auto load_first = [&](int batch) {          // (once, in front of the loop: the two integer divisions)
+        int tt = batch;
+        lb_bx = tt % q.bx_n;
+        tt /= q.bx_n;
+        lb_ty = tt % q.ty_n;
+        lb_b = tt / q.ty_n;
+        lb_batch = batch;
+    };
+    auto load_begin = [&](int batch) {
+        {                                       // batch == lb_batch (first call, clamped tail) or lb_batch + gridDim.x: branch-free walk with carries
+            const int adv = batch != lb_batch ? 1 : 0;
+            lb_bx += adv * st_bx;
+            const int cx = lb_bx >= q.bx_n ? 1 : 0;
+            lb_bx -= cx * q.bx_n;
+            lb_ty += adv * st_ty + cx;
+            const int cy = lb_ty >= q.ty_n ? 1 : 0;
+            lb_ty -= cy * q.ty_n;
+            lb_b += adv * st_b + cy;
+        }
+        lb_batch = batch;
+        const int pix = (lb_b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
+        const int corner = pix + q.dy0 * s.Win + q.dx0;
+        so_x = (unsigned)((corner + padS) * ldS) * 4u;
+        if (XMK) so_m = (unsigned)((corner + padS) * s.ldm) * 4u;
+        so_g = (unsigned)(pix * p.ldg) * 4u;
+        if (GM) so_gm = (unsigned)(pix * p.ldgm) * 4u;
+    };
+    const auto rx = wino_rsrc(xsrc - (long)padS * ldS, WOOB);
+    const auto rmk = XMK ? wino_rsrc(msrc - (long)padS * s.ldm, WOOB) : rx;
+    const auto rg = wino_rsrc(p.dout, WOOB);
+    const auto rgm = GM ? wino_rsrc(p.gmask, WOOB) : rg;
+    auto bload = [](decltype(rx) r, unsigned vo, unsigned so) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
+    };
+    auto load_x = [&](int i) {
+        const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
+        const bool ok = xslot[i] & ((unsigned)iy < (unsigned)s.Hin) & ((unsigned)ix < (unsigned)s.Win);
+        xr[i] = bload(rx, ok ? xoff[i] : WOOB, so_x);
+        if (XMK) xm[i] = bload(rmk, (ok & use_m) ? xmoff[i] : WOOB, so_m);
+    };
+    auto load_y = [&](int i) {
+        const bool ok = yslot[i] & (G::YH * lb_ty + ypy[i] < p.Ho) & (YW * lb_bx + ypx[i] < p.Wo);
+        yr[i] = bload(rg, ok ? yoff[i] : WOOB, so_g);
+        if (GM) ym[i] = bload(rgm, ok ? ymoff[i] : WOOB, so_gm);
+    };
+    auto load_raw = [&](int batch) {
+        load_begin(batch);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) load_x(i);
+#pragma unroll
+        for (int i = 0; i < NYS; ++i) load_y(i);
+    };
+    float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid % YQ)
+    float *scratch = smem + 2 * (GR_XP + GR_YP) + tid * 4;          // 256 spare 16-byte cells behind the strips
+    auto store_x = [&](int i, float *xb) {
+        float4 r = xr[i];
+        if (XMK == 1)
+            r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
+        if (XMK == 2) r = make_float4(r.x * (xm[i].x + m_one), r.y * (xm[i].y + m_one), r.z * (xm[i].z + m_one), r.w * (xm[i].w + m_one));
+        st4(xdst[i] >= 0 ? xb + xdst[i] : scratch, r);
+    };
+    float bias_on = 1.f;                          // 0 for the clamped re-store of the last batch
+    auto store_y = [&](int i, float *yb) {
+        const int sl = tid + i * NT;
+        float4 r = yr[i];
+        if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
+        st4(yb + (sl / YQ) * 32 + (sl % YQ) * 4, r);
+        bsum = make_float4(bsum.x + bias_on * r.x, bsum.y + bias_on * r.y, bsum.z + bias_on * r.z, bsum.w + bias_on * r.w);
+    };
+
+    // ---- row `wave` of the two transforms.  B_r^T d: rows (ra, rb) of the window, te = d[ra] + sb * d[rb]; A_r dy: g[0][.] + cb * g[1][.]
+    // ((1,0), (1,1), (1,-1), (0,-1): wave 3 reads row 1 in the place of row 0 with cb = 0, its sign is applied to the accumulators at the end)
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sb = wave == 1 ? 1.f : -1.f;
+    const float cb = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+    const int yr0 = wave == 3 ? YW : 0;
+    // the lane's tile of a pair: TXB >= 2: the next tile column (4 pixels), TXB = 1: the next tile row (2 pixel rows)
+    const int kx = TXB == 1 ? kk * 2 * PW : kk * 4, ky = TXB == 1 ? kk * 2 * YW : kk * 4;
+    const int xa_off = (ra * PW + kx) * 32 + l31, xb_off = (rb * PW + kx) * 32 + l31;
+    const int y_off = ky * 32 + l31;
+    float da[6], db[6], g0[4], g1[4];             // raw operands of the tile pair being prepared
+    float an[2][6], bn[2][6];                     // operand sets of tile pairs st & 1 = 0 / 1
+    auto fetch_x = [&](const float *xc, int st) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) da[c] = xc[xa_off + G::sx(st) + c * 32], db[c] = xc[xb_off + G::sx(st) + c * 32];
+    };
+    auto fetch_y = [&](const float *yc, int st) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) g0[c] = yc[y_off + (yr0 + G::sy(st) + c) * 32], g1[c] = yc[y_off + (YW + G::sy(st) + c) * 32];
+    };
+    // B_c^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (conv_wino6.hip)
+    float tt[6];
+    auto finish_x0 = [&](int o) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) tt[c] = da[c] + sb * db[c];
+        an[o][0] = fmaf(4.f, tt[0], fmaf(-5.f, tt[2], tt[4]));
+        an[o][5] = fmaf(4.f, tt[1], fmaf(-5.f, tt[3], tt[5]));
+    };
+    auto finish_x1 = [&](int o) {
+        const float sa = fmaf(-4.f, tt[2], tt[4]), sd = fmaf(-4.f, tt[1], tt[3]), ua = tt[4] - tt[2], ud = tt[3] - tt[1];
+        an[o][1] = sa + sd, an[o][2] = sa - sd, an[o][3] = fmaf(2.f, ud, ua), an[o][4] = fmaf(-2.f, ud, ua);
+    };
+    // Z row = A_c w, A_c^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+    auto finish_y = [&](int o) {
+        const float w0 = g0[0] + cb * g1[0], w1 = g0[1] + cb * g1[1], w2 = g0[2] + cb * g1[2], w3 = g0[3] + cb * g1[3];
+        const float e = w0 + w2, f = w1 + w3, e4 = fmaf(4.f, w2, w0), f4 = fmaf(4.f, w3, w1);
+        bn[o][0] = w0, bn[o][1] = e + f, bn[o][2] = e - f, bn[o][3] = fmaf(2.f, f4, e4), bn[o][4] = fmaf(-2.f, f4, e4), bn[o][5] = w3;
+    };
+
+    const int step = gridDim.x;
+    int batch = blockIdx.x;
+    if (batch < q.nbatch) {
+        const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
+        load_first(batch);
+        load_raw(batch);
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) store_x(i, Xp);
+#pragma unroll
+        for (int i = 0; i < NYS; ++i) store_y(i, Yp);
+        load_raw(min(batch + step, last));
+        __syncthreads();
+        fetch_x(Xp, 0), fetch_y(Yp, 0);
+        finish_x0(0), finish_x1(0), finish_y(0);
+        int cur = 0;
+        for (; batch <= last; batch += step, cur ^= 1) {
+            bias_on = batch + step <= last ? 1.f : 0.f;
+            const int b2 = min(batch + 2 * step, last);
+            const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
+            float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
+            // staging slices: the raw strips of the next batch (in registers) -> the other LDS buffer (k = 0..5, all in front of the barrier
+            // behind tile pair 2), then the loads of the batch after it (k = 6..12)
+            auto stage = [&](int k) {
+                if (k < 4) { if (k < NXS) store_x(k, xn); }
+                else if (k < 6) store_y(k - 4, yn);
+                else if (k == 6) load_begin(b2);
+                else if (k < 11) { if (k - 7 < NXS) load_x(k - 7); }
+                else if (k < 13) load_y(k - 11);
+            };
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int o = st & 1, on = o ^ 1;       // operand set in use / being prepared
+                // the next tile pair is fetched / finished in the gaps; for the last pair of a batch that is the first pair of the NEXT batch,
+                // whose raw strips are complete in the other buffer since the barrier behind pair 2
+                auto gap = [&](int g) {
+                    if (g == 0) fetch_x(st < 3 ? xc : xn, (st + 1) & 3);
+                    if (g == 1) fetch_y(st < 3 ? yc : yn, (st + 1) & 3), stage(st * 3);
+                    if (g == 2) finish_x0(on);
+                    if (g == 3) finish_x1(on), stage(st * 3 + 1);
+                    if (g == 4) finish_y(on);
+                    if (g == 5) { stage(st * 3 + 2); if (st == 3) stage(12); }
+                };
+#pragma unroll
+                for (int pl = 0; pl < 6; ++pl) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[o][pl], bn[o][pl], acc[pl], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    gap(pl);
+                }
+                if (st == 2) __syncthreads();
+            }
+        }
+    }
+
+    // D[row = input channel][col = output channel] of position 6 * wave + pl -> slab[(pos * Cin + c) * Cout + n]
+    const int Cin = s.Cin;
+    const bool slabs = p.dw_slabs > 0;
+    float *dwb = p.dw + (slabs ? (size_t)blockIdx.x * 24 * Cin * p.Cout : 0);
+    const int n = n0 + l31;
+    const bool neg = wave == 3;
+    if (slabs) {                // pipelined read-modify-write of the split's own slab (conv_wgrad_wino.hip)
+        float old[2][16];
+        auto grp_load = [&](int pl, float (&o)[16]) {
+            const float *col = dwb + (size_t)(6 * wave + pl) * Cin * p.Cout + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                o[r] = (c < Cin && n < p.Cout) ? col[(size_t)c * p.Cout] : 0.f;
+            }
+        };
+        grp_load(0, old[0]);
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl) {
+            if (pl + 1 < 6) grp_load(pl + 1, old[(pl + 1) & 1]);
+            float *col = dwb + (size_t)(6 * wave + pl) * Cin * p.Cout + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (c < Cin && n < p.Cout) col[(size_t)c * p.Cout] = old[pl & 1][r] + (neg ? -acc[pl][r] : acc[pl][r]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl) {
+            float *col = dwb + (size_t)(6 * wave + pl) * Cin * p.Cout + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (c < Cin && n < p.Cout) atomicAdd(col + (size_t)c * p.Cout, neg ? -acc[pl][r] : acc[pl][r]);
+            }
+        }
+    }
+    if (p.dbias != nullptr && blockIdx.y == 0) {
+        __syncthreads();
+        float *red = smem;                        // [NT / YQ][32]
+        st4(red + (tid / YQ) * 32 + (tid % YQ) * 4, bsum);
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+            for (int g = 0; g < NT / YQ; ++g) t += red[g * 32 + tid];
+            if (n0 + tid < p.Cout) {
+                if (slabs) p.dbias[(size_t)blockIdx.x * p.Cout + n0 + tid] += t;
+                else atomicAdd(p.dbias + n0 + tid, t);
+            }
+        }
+    }
+}
+
+// ws [24][CinWs][CoutWs] (dU, position = 6 * row + column) -> grad OIHW [Cout][Cin][3][3] (+=): dg = G_r^T dU G_c
+__global__ void unpack_wgrad_wino2x4_kernel(const float *__restrict__ ws, float *__restrict__ g, int Cout, int Cin, int CinWs, int CoutWs,
+                                            int n_off, size_t total) {
+    const float G2[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cin), n = (int)(i / Cin);
+        double u[4][6];
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 6; ++b) u[a][b] = ws[((size_t)(a * 6 + b) * CinWs + c) * CoutWs + n_off + n];
+        for (int ka = 0; ka < 3; ++ka)
+            for (int kb = 0; kb < 3; ++kb) {
+                double sum = 0;
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 6; ++b) sum += G2[a][ka] * u[a][b] * G4[b][kb];
+                g[((size_t)n * Cin + c) * 9 + ka * 3 + kb] += (float)sum;
+            }
+    }
+}
+
+bool wgrad_wino6_eligible(const ramnet_wgrad_desc &d) {
+    return d.ntaps == 9 && d.stride == 1 && d.Ho == d.Hin && d.Wo == d.Win &&
+           (d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK);
+}
+
+int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
+    RAMNET_CHECK_ARG(wgrad_wino6_eligible(d));
+    if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % 32 == 0);   // a workgroup's channels come from one tensor
+    int dymin = 127, dxmin = 127;
+    for (int t = 0; t < 9; ++t) {
+        dymin = d.dy[t] < dymin ? d.dy[t] : dymin;
+        dxmin = d.dx[t] < dxmin ? d.dx[t] : dxmin;
+    }
+    for (int t = 0; t < 9; ++t) RAMNET_CHECK_ARG(d.dy[t] - dymin == t / 3 && d.dx[t] - dxmin == t % 3);      // the forward tap order kh*3 + kw
+    const bool cat = d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL;
+    WgradWino6Params q;
+    q.src.x0 = d.x0, q.src.x1 = d.x1, q.src.xm = d.xm;
+    q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
+    q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
+    q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    q.dy0 = dymin, q.dx0 = dxmin;
+    // strips of 8 tiles: 4 x 16, 8 x 8 or 16 x 4 output pixels, whichever pads the map least (ties: the widest)
+    long best = -1;
+    int txb = 4;
+    for (int t = 4; t >= 1; t >>= 1) {
+        const long a = (long)cdiv(d.Wo, 4 * t) * 4 * t * cdiv(d.Ho, 16 / t) * (16 / t);
+        if (best < 0 || a < best) best = a, txb = t;
+    }
+    q.bx_n = cdiv(d.Wo, 4 * txb), q.ty_n = cdiv(d.Ho, 16 / txb), q.nbatch = q.bx_n * q.ty_n * d.B;
+    const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32);
+    int splits = g_opt_wgrad_wino_blocks / (gy * gz);
+    if (splits > q.nbatch) splits = q.nbatch;
+    if (d.dw_slabs > 0 && splits > d.dw_slabs) splits = d.dw_slabs;
+    if (splits < 1) splits = 1;
+    const dim3 grid(splits, gy, gz);
+    const int xp = txb == 4 ? G6Geom<4>::XP : txb == 2 ? G6Geom<2>::XP : G6Geom<1>::XP;
+    const size_t lds = ((size_t)2 * (xp + G6Geom<4>::YP) + 256 * 4) * sizeof(float);
+    const int xmk = d.in_mode == RAMNET_IN_RELUMASK ? 1 : d.in_mode == RAMNET_IN_CAT_MUL ? 2 : 0;
+    const bool gm = d.gmask != nullptr;
+    {
+        const unsigned long long px = (unsigned long long)d.Hin * d.Win, ldx = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
+        RAMNET_CHECK_ARG(d.B * px * ldx * 4ull < WOOB && d.B * px * d.ldm * 4ull < WOOB &&
+                         (unsigned long long)d.B * d.Ho * d.Wo * d.ldg * 4ull < WOOB && (unsigned long long)d.B * d.Ho * d.Wo * d.ldgm * 4ull < WOOB);
+    }
+    note_kernel("conv_wgrad_wino_r6_kernel<%d,%d,%d>", xmk, (int)gm, txb);
+#define RAMNET_GO(XMv, GMv)                                                                                               \
+    do {                                                                                                                  \
+        if (txb == 4) hipLaunchKernelGGL((conv_wgrad_wino_r6_kernel<XMv, GMv, 4>), grid, dim3(256), lds, st, d, q);       \
+        else if (txb == 2) hipLaunchKernelGGL((conv_wgrad_wino_r6_kernel<XMv, GMv, 2>), grid, dim3(256), lds, st, d, q);  \
+        else hipLaunchKernelGGL((conv_wgrad_wino_r6_kernel<XMv, GMv, 1>), grid, dim3(256), lds, st, d, q);                \
+    } while (0)
+    if (xmk == 1 && gm) RAMNET_GO(1, true);
+    else if (xmk == 1) RAMNET_GO(1, false);
+    else if (xmk == 2 && gm) RAMNET_GO(2, true);
+    else if (xmk == 2) RAMNET_GO(2, false);
+    else if (gm) RAMNET_GO(0, true);
+    else RAMNET_GO(0, false);
+#undef RAMNET_GO
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ramnet
+
+using namespace ramnet;
+
+extern "C" int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout) {
+    const int s = WG6_TARGET / (cdiv(Cin, 32) * cdiv(Cout, 32));
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int ramnet_unpack_wgrad_wino2x4(const float *ws, float *grad, int Cout, int Cin, int CinWs, int CoutWs, int n_off, void *stream) {
+    RAMNET_CHECK_ARG(ws && grad && Cout > 0 && Cin > 0 && CinWs >= Cin && n_off >= 0 && CoutWs >= n_off + Cout);
+    const size_t total = (size_t)Cout * Cin;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(unpack_wgrad_wino2x4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ws, grad, Cout, Cin, CinWs, CoutWs, n_off, total);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}

@@ -30,6 +30,7 @@ def set_winograd(on):
 
 _WINO_2X4 = "auto"
 _WGRAD_SLABS = True
+_WGRAD_2X4 = "auto"       # F(2x4,3x3) backward-weights (csrc/conv_wgrad_wino6.hip): "auto" (with set_wgrad_overlap(True)) | "off" | "force"
 
 
 def set_wgrad_slabs(on):
@@ -78,6 +79,16 @@ def set_fold_pair(on):
     """32-channel folded decoders in the pair form (default) or as 64 tiles x 32 channels; the library option and the packs follow."""
     H.check(H.lib().ramnet_set_option(b"fold_pair", int(bool(on))), "set_option")
     invalidate_packs()
+
+
+def set_wgrad_winograd_2x4(mode):
+    """F(2x4,3x3) backward-weights for the plain 3x3 layers (ConvGRU / ConvLSTM / residual layers of >= 64 reduction channels): "auto"
+    (default) = when the backward-weights launches are co-scheduled with the backward-data chain (set_wgrad_overlap(True): training step
+    +1.1 % same-box; in stream order the 32 x 32-channel F(2x2) workgroups are faster: 200.4 vs 196.5 samples/s), "force" = always (tests),
+    "off" = F(2x2,3x3) everywhere.  Takes effect at the next backward pass (a pass uses one workspace layout per layer)."""
+    global _WGRAD_2X4
+    assert mode in ("auto", "off", "force")
+    _WGRAD_2X4 = mode
 
 
 def set_winograd_split(on):
@@ -291,13 +302,15 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     if gview is not None:      # dout / gmask addressed as (oy*gsy + goy, ox*gsx + gox) of [B, HoG, WoG]
         d.gsy, d.gsx, d.goy, d.gox, d.HoG, d.WoG = gview
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
-    d.dw_slabs = getattr(dw, "slabs", 0) if (d.algo == H.ALGO_WINOGRAD and _WGRAD_SLABS) else 0     # per-split slabs (read-modify-write joins)
+    if getattr(dw, "wino6", False):          # F(2x4,3x3): dw = [slabs][24][Cin][Cout] (csrc/conv_wgrad_wino6.hip)
+        d.algo = H.ALGO_WINOGRAD_2X4
+    d.dw_slabs = getattr(dw, "slabs", 0) if (d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4) and _WGRAD_SLABS) else 0     # per-split slabs (read-modify-write joins)
     if wino24:          # folded upsample-conv in the Winograd F(2x2,4x4) domain: dw = [4][25][C0][Cout]
         d.algo = H.ALGO_WINOGRAD24
     hc = getattr(dw, "head_cin", 0)
     if hc and _HEAD and taps.head and stride == 1 and in_mode == H.IN_PLAIN and gview is None and dw_off == 0:
         d.algo, d.head_cin = H.ALGO_HEAD, hc
-    if d.algo == H.ALGO_WINOGRAD and C1 and d.C0 % 32:
+    if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4) and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
 
@@ -777,7 +790,7 @@ class ConvParam:
         Winograd backward-weights kernel, whose workspace holds the transformed-domain gradient [16][CinWs][Cout]."""
         if self._ws is None:
             dev = self.weights[0].device
-            slots = 16 if self.k == 3 else self.k * self.k       # 3x3: room for the Winograd-domain gradient dU
+            slots = 24 if self.k == 3 else self.k * self.k       # 3x3: room for the Winograd-domain gradient dU (F(2x4): 24, F(2x2): 16 positions)
             # 3x3 layers: one slab per tile split of the Winograd backward-weights launch (joined by plain read-modify-write: no atomics,
             # bit-reproducible sums; ramnet_wgrad_desc.dw_slabs) — folded into slab 0 by finalize(); other layers: one slab
             self._slabs = H.lib().ramnet_wgrad_wino_slabs(self.CinWs, self.Cout) if self.k == 3 else 1
@@ -788,6 +801,14 @@ class ConvParam:
         if not self._dirty:     # one algorithm per backward pass: every launch of the pass accumulates into the same layout
             self._ws.wino = bool(wino_ok and _WINOGRAD and self.k == 3
                                  and self.CinWs >= _WINO_MIN_CIN)
+            # F(2x4,3x3) for the plain 3x3 layers (not the space-to-depth views): slabs of [24][Cin][Cout], half as many as F(2x2)'s
+            self._ws.wino6 = bool(self._ws.wino and (_WGRAD_2X4 == "force" or (_WGRAD_2X4 == "auto" and _USE_SIDE))
+                                  and type(self) is ConvParam and self.CinWs >= 64)
+            if self._ws.wino6:
+                self._ws.wino = False
+                self._ws.slabs = min(self._slabs, H.lib().ramnet_wgrad_wino2x4_slabs(self.CinWs, self.Cout))
+            else:
+                self._ws.slabs = self._slabs
             # head layers: the launch may run the head kernel (same [tap][CinWs][Cout] layout as the direct kernel)
             self._ws.head_cin = self.Cin if (self.k == 5 and self.gates == 1 and len(self.weights) == 1
                                              and H.lib().ramnet_head_supported(self.Cin, self.Cout)) else 0
@@ -838,9 +859,11 @@ class ConvParam:
 
     def _join_slabs(self):
         """Winograd backward-weights slabs -> slab 0 (fixed order), weights and bias."""
-        if getattr(self, "_slabs", 1) > 1 and getattr(self._ws, "wino", False):
-            H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), self._slabs, self._ws.numel() // self._slabs, _st()), "ramnet_reduce_slabs")
-            H.check(H.lib().ramnet_reduce_slabs(_p(self._bws), self._slabs, self.Cout, _st()), "ramnet_reduce_slabs")
+        w6 = getattr(self._ws, "wino6", False)
+        ns = getattr(self._ws, "slabs", 1)
+        if ns > 1 and (w6 or getattr(self._ws, "wino", False)):
+            H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), ns, (24 if w6 else 16) * self.CinWs * self.Cout, _st()), "ramnet_reduce_slabs")
+            H.check(H.lib().ramnet_reduce_slabs(_p(self._bws), ns, self.Cout, _st()), "ramnet_reduce_slabs")
 
     def finalize(self):
         if self._fold_used:
@@ -857,7 +880,10 @@ class ConvParam:
         for w, b in zip(self.weights, self.biases):
             n = w.shape[0]
             g = ensure_grad(w)
-            if getattr(self._ws, "wino", False):
+            if getattr(self._ws, "wino6", False):
+                H.check(H.lib().ramnet_unpack_wgrad_wino2x4(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
+                        "ramnet_unpack_wgrad_wino2x4")
+            elif getattr(self._ws, "wino", False):
                 H.check(H.lib().ramnet_unpack_wgrad_wino(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
                         "ramnet_unpack_wgrad_wino")
             else:

@@ -35,6 +35,16 @@ def bench_schedule():
     ops.set_decoder_overlap(False)
 
 
+@pytest.fixture(params=["f2x4", "f2x2"])
+def wgrad_algo(request):
+    """Both backward-weights kernels of the plain 3x3 layers at the real shapes: F(2x4,3x3) (what the co-scheduled step selects) and
+    F(2x2,3x3) in its 32 x 64-channel shape."""
+    from rpg_ramnet_amd import ops
+    ops.set_wgrad_winograd_2x4("auto" if request.param == "f2x4" else "off")
+    yield request.param
+    ops.set_wgrad_winograd_2x4("auto")
+
+
 def run_pair64(module, oracle_fn, inputs, input_grads=True, seed=0):
     """module: rpg_ramnet_amd layer (NHWC, cuda); oracle_fn(sd64, *nchw float64 inputs) -> tensor.  Compares the output, every
     input gradient and every parameter gradient for a random upstream gradient."""
@@ -99,7 +109,7 @@ def test_encoder_layer_full_size(cin, cout, div, bench_schedule):
 
 
 @pytest.mark.parametrize("C,div", [(64, 2), (128, 4), (256, 8)])
-def test_conv_gru_full_size(C, div, bench_schedule):
+def test_conv_gru_full_size(C, div, bench_schedule, wgrad_algo):
     """ConvGRU state update (update|reset launch, candidate launch) at the three scales: C=64 @128x172 ... C=256 @32x43."""
     from rpg_ramnet_amd.model.submodules import ConvGRU
     torch.manual_seed(30 + div)
@@ -112,7 +122,7 @@ def test_conv_gru_full_size(C, div, bench_schedule):
     run_pair64(m, lambda sd, a, hh: ramnet_ref.conv_gru(_pre(sd), "L", a, hh), [x, h])
 
 
-def test_residual_block_full_size(bench_schedule):
+def test_residual_block_full_size(bench_schedule, wgrad_algo):
     """ResidualBlock 256 @ 32x43 (submodules.py:200-215), its two launches checked separately: the block hides a ReLU between
     them, and among 2.8 M hidden activations a few sit within fp32 rounding of the kink, where the float64 checker takes the
     other branch (derivative 0 vs 1) — a property of comparing across precisions, not of the kernels.  Each half exposes its

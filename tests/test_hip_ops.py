@@ -216,9 +216,11 @@ def algo3x3(request):
     ops.set_winograd(request.param != "direct")
     if request.param == "winograd2x4":
         ops.set_winograd_2x4("force")
+        ops.set_wgrad_winograd_2x4("force")         # ... and the F(2x4,3x3) backward-weights kernel (csrc/conv_wgrad_wino6.hip)
     yield request.param
     ops.set_winograd(old)
     ops.set_winograd_2x4("auto")
+    ops.set_wgrad_winograd_2x4("auto")
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (1, 32, 8), (2, 8, 32), (1, 64, 86)])
@@ -433,7 +435,7 @@ def wgrad_nf(request):
     Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", 1), "set_option")
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (3, 32, 48)])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (3, 32, 48), (2, 24, 10), (1, 64, 86)])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (32, 96), (40, 20), (128, 256)])
 def test_winograd_wgrad_raw(B, H, W, cin, cout, wgrad_nf):
     """Winograd backward-weights (+bias, + ReLU mask on the gradient) against float64 autograd and the direct kernel."""
@@ -449,15 +451,19 @@ def test_winograd_wgrad_raw(B, H, W, cin, cout, wgrad_nf):
     (F.conv2d(x.double(), w, bias, 1, 1) * g).sum().backward()
     xg, dyg, yg = (nhwc(t).to(dev()).contiguous() for t in (x, dy, y))
     taps = ops.Taps.get("conv", 3, 1)
-    for wino in (True, False):
-        ws = torch.zeros(16 * cin * cout, device=dev())
-        ws.wino = wino
+    for wino in (True, False, "2x4"):                   # F(2x2,3x3), direct, F(2x4,3x3) (csrc/conv_wgrad_wino6.hip)
+        ws = torch.zeros(24 * cin * cout, device=dev())
+        ws.wino, ws.wino6 = wino is True, wino == "2x4"
         bws = torch.zeros(cout, device=dev())
         for _ in range(2):                              # accumulates over launches (BPTT time steps)
             ops.wgrad_launch(xg, taps, dyg, ws, cout, gmask=yg, dbias=bws)
+        assert Hh.lib().ramnet_last_kernel().decode().startswith(
+            {True: "conv_wgrad_wino_r_kernel", False: "conv_wgrad_kernel", "2x4": "conv_wgrad_wino_r6_kernel"}[wino])
         grad = torch.zeros(cout, cin, 3, 3, device=dev())
         L = Hh.lib()
-        if wino:
+        if wino == "2x4":
+            Hh.check(L.ramnet_unpack_wgrad_wino2x4(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, ops._st()), "unpack")
+        elif wino:
             Hh.check(L.ramnet_unpack_wgrad_wino(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, ops._st()), "unpack")
         else:
             Hh.check(L.ramnet_unpack_wgrad(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, 3, 3, ops._st()), "unpack")

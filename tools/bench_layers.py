@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--width", type=int, default=344)
     ap.add_argument("--only", default="")
     ap.add_argument("--wgrad-wino-nf", type=int, default=0)
+    ap.add_argument("--wgrad-2x4", type=int, default=1)
     ap.add_argument("--wino2x4", default="auto", help="auto | off | force[,min_wgs]: F(2x4,3x3) selection (ops.set_winograd_2x4)")
     a = ap.parse_args()
     if a.wgrad_wino_nf:
@@ -71,8 +72,10 @@ def main():
         cp = ops.ConvParam([wp], [bp], gates=4 if kind == "lstm" else 1)
         taps, tapsd = ops.Taps.get("conv", k, pad), ops.Taps.get("dgrad1", k, pad)
         gfl = 2.0 * B * Ho * Wo * k * k * cin * cout / 1e9
-        ws = torch.zeros((16 if k == 3 else k * k) * cin_p * cout, device=dev)
+        ws = torch.zeros((24 if k == 3 else k * k) * cin_p * cout, device=dev)
         ws.wino = k == 3 and stride == 1 and kind != "up" and ops.get_winograd()      # Winograd backward-weights workspace
+        if ws.wino and a.wgrad_2x4 and kind != "s2d" and cin_p >= 64:
+            ws.wino, ws.wino6 = False, True                                            # F(2x4,3x3) backward-weights
         ws.head_cin = cin if (kind == "conv" and k == 5 and stride == 1 and H.lib().ramnet_head_supported(cin, cout)) else 0
         bws = torch.zeros(cout, device=dev)
         if kind == "conv":
