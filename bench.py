@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--wino2x4", default="auto", help="F(2x4,3x3) kernel selection for A/B runs: auto (library heuristics) | off | force, "
                     "optionally ,min_wgs (ops.set_winograd_2x4)")
     ap.add_argument("--wgrad-2x4", default="auto", choices=["auto", "off", "force"], help="A/B: F(2x4,3x3) backward-weights (ops.set_wgrad_winograd_2x4)")
+    ap.add_argument("--no-gru-bwd-fused", action="store_true", help="A/B: ConvGRU backward stage B as its own launch (ops.set_gru_bwd_fused(False))")
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384, the default)")
     ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
@@ -152,6 +153,7 @@ HBM_CALLS = {
     "ramnet_pred_sigmoid_fwd": lambda a: (4.0 * a[2] + 4.0) * a[6],
     "ramnet_pred_sigmoid_bwd": lambda a: (8.0 * a[2] + 8.0) * a[10],
     "ramnet_gru_bwd_a": lambda a: 28.0 * a[8] * a[7],      # (a[9] = leading dimension of dh')
+    "ramnet_gru_bwd_a2": lambda a: 28.0 * a[8] * a[7],     # (stage B runs in the epilogue of the candidate convolution's backward-data launch)
     "ramnet_gru_bwd_b": lambda a: 24.0 * a[6] * a[5],
     "ramnet_pad2_sum": lambda a: 4.0 * a[6] * a[3] * ((2 if a[1] else 1) * a[4] * a[5] + (a[4] + 4) * (a[5] + 4)),
     "ramnet_relu_bwd": lambda a: 12.0 * a[3],
@@ -649,6 +651,7 @@ def main():
     ops.set_decoder_overlap(args.overlap_decoder)
     ops.set_wgrad_slabs(not args.wgrad_atomic)
     ops.set_wgrad_winograd_2x4(args.wgrad_2x4)
+    ops.set_gru_bwd_fused(not args.no_gru_bwd_fused)
     if args.wgrad_wino_nf:
         Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", args.wgrad_wino_nf), "set_option")
     if args.wgrad_wino_blocks:

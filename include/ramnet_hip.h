@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 17      /* 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 18      /* 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -66,7 +66,12 @@ enum ramnet_epilogue {
     RAMNET_EPI_SIGMOID = 2,   /* sigmoid(acc + bias)                 GRU gates submodules.py:448-449 */
     RAMNET_EPI_RES_RELU = 3,  /* relu(acc + bias + e0)               ResidualBlock submodules.py:212-214 */
     RAMNET_EPI_GRU_BLEND = 4, /* o=tanh(acc+bias); out=h*(1-u)+o*u   submodules.py:450-452; e0=u, e1=h, o1<-o */
-    RAMNET_EPI_LSTM = 5       /* i,f,o,g -> c'=f*c+i*g, h'=o*tanh(c') submodules.py:346-358; e1=c, out<-h', o1<-c', o2<-gates */
+    RAMNET_EPI_LSTM = 5,      /* i,f,o,g -> c'=f*c+i*g, h'=o*tanh(c') submodules.py:346-358; e1=c, out<-h', o1<-c', o2<-gates */
+    RAMNET_EPI_GRU_BWD = 6    /* backward-data of the candidate convolution W_o*[x, h.r] (ABI 18; Cout = 2C, no bias, beta = 0): channels n < C
+                               * (dx) are stored as they are; channels n >= C carry g = d(h.r): with r = e0[pix*lde0 + n] (e0 = [u|r]),
+                               * h = e1[pix*lde1 + n - C] (NULL: 0): o1[pix*ldo1 + n] <- g*h*r*(1-r) (the reset gate's pre-activation gradient)
+                               * and out <- out_old + g*r, out_old = dh'*(1-u) left there by ramnet_gru_bwd_a2 — ramnet_gru_bwd_b without
+                               * its launch.  Winograd kernels: C % 64 == 0                                                        */
 };
 
 /* One convolution launch.  out(a,b) = epi( sum_t sum_c in(a*stride+dy[t], b*stride+dx[t], c) * W[wtap[t]][c][n] ).
@@ -302,6 +307,9 @@ int ramnet_upsample2x_bwd(const float *dup, float *dx, int B, int H, int W, int 
 int ramnet_gru_bwd_a(const float *dhn, const float *ur, const float *o, const float *h, float *dpo,
                      float *dpur, float *dh, size_t npix, int C, int ld_dhn /* floats per pixel of dhn (>= C: channel slices) */,
                      void *stream);
+int ramnet_gru_bwd_a2(const float *dhn, const float *ur, const float *o, const float *h, float *dpo,
+                      float *dpur, float *dh, size_t npix, int C, int ld_dhn, int ld_dh /* floats per pixel of dh (ABI 18) */,
+                      void *stream);
 int ramnet_gru_bwd_b(const float *dxhr, const float *ur, const float *h, float *dpur, float *dh,
                      size_t npix, int C, void *stream);
 /* ConvLSTM backward point-wise: gates [npix,4C] (activated i,f,o,g), c_prev, c_new, dh', dc' ->

@@ -40,8 +40,21 @@ __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int ep
         const float h = p.e1 ? p.e1[pix * p.lde1 + n] : 0.f;
         if (p.o1) p.o1[pix * p.ldo1 + n] = o;
         v = h * (1.0f - u) + o * u;
+    } else if (epi == RAMNET_EPI_GRU_BWD && n >= p.Cout / 2) {     // stage B of the ConvGRU backward (ramnet_hip.h)
+        const float r = p.e0[pix * p.lde0 + n];
+        const float h = p.e1 ? p.e1[pix * p.lde1 + n - p.Cout / 2] : 0.f;
+        p.o1[pix * p.ldo1 + n] = v * h * r * (1.0f - r);
+        v = p.out[pix * p.ldo + n] + v * r;
     }
     p.out[pix * p.ldo + n] = v;
+}
+
+// RAMNET_EPI_GRU_BWD, channels of the d(h.r) half: g = the convolution's result, r, h, old = the direct path already in `out`;
+// writes the reset gate's pre-activation gradient and returns the completed dh.
+__device__ __forceinline__ float4 gru_bwd_quad(float4 g, float4 r, float4 h, float4 old, float *dpr) {
+    st4(dpr, make_float4(g.x * h.x * r.x * (1.0f - r.x), g.y * h.y * r.y * (1.0f - r.y), g.z * h.z * r.z * (1.0f - r.z),
+                         g.w * h.w * r.w * (1.0f - r.w)));
+    return make_float4(old.x + g.x * r.x, old.y + g.y * r.y, old.z + g.z * r.z, old.w + g.w * r.w);
 }
 
 // Four consecutive output channels n..n+3 of one pixel (all pointers 16-byte aligned, Cout % 4 == 0: checked on the host).
@@ -65,6 +78,9 @@ __device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int e
         if (p.o1) st4(p.o1 + pix * p.ldo1 + n, o);
         v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
                         h.w * (1.0f - u.w) + o.w * u.w);
+    } else if (epi == RAMNET_EPI_GRU_BWD && n >= p.Cout / 2) {     // (Cout / 2 % 4 == 0: a quad lies in one half)
+        v = gru_bwd_quad(v, ld4(p.e0 + pix * p.lde0 + n), p.e1 ? ld4(p.e1 + pix * p.lde1 + n - p.Cout / 2) : f4zero(),
+                         ld4(p.out + pix * p.ldo + n), p.o1 + pix * p.ldo1 + n);
     }
     st4(p.out + pix * p.ldo + n, v);
 }

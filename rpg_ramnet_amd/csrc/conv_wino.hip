@@ -321,12 +321,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                     joined[i] = f4add(joined[i], __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, (tid + i * 256) * 16, s * 16384, AUX_SC1)));
         }
         auto run = [&](auto kind) {
-            constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend
-            float4 ea[NI], eb[NI];
+            constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
+            float4 ea[NI], eb[NI], ec[K == 3 ? NI : 1];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 ea[i] = K >= 1 ? ld4(p.e0 + pix[i] * p.lde0 + nqs) : addold ? ld4(p.out + pix[i] * p.ldo + nqs) : f4zero();
-                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : f4zero();
+                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : (K == 3 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs - p.Cout / 2) : f4zero();
+                if (K == 3) ec[i] = ld4(p.out + pix[i] * p.ldo + nqs);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -338,6 +339,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                     else if (epi == RAMNET_EPI_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
                 } else if (K == 1) {
                     v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
+                } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD)
+                    v = gru_bwd_quad(v, ea[i], eb[i], ec[K == 3 ? i : 0], p.o1 + pix[i] * p.ldo1 + nq);
                 } else {
                     const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
                     if (p.o1) st4(p.o1 + pix[i] * p.ldo1 + nq, o);
@@ -349,6 +352,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         };
         if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
         else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
+        else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
         else run(std::integral_constant<int, 0>{});
         return;
     }
@@ -457,6 +461,7 @@ static int wino_plan(const ramnet_conv_desc &d, WinoParams &q, bool &tall, int &
              (!d.e0 || (d.lde0 % 4 == 0 && al16(d.e0))) && (!d.e1 || (d.lde1 % 4 == 0 && al16(d.e1))) &&
              (!d.o2 || (d.ldo2 % 4 == 0 && al16(d.o2)));
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(q.vec4);      // the cell epilogue works on channel quads of the staged tile
+    if (d.epi == RAMNET_EPI_GRU_BWD) RAMNET_CHECK_ARG(q.vec4 && d.Cout % 128 == 0);      // a 64-channel block lies in one half of [dx | d(h.r)]
     q.s2d_shift = 0;
     q.sparse = 0;
     if (d.s2d_5x5) {

@@ -260,13 +260,13 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     const float4 bias4 = p.bias ? ld4(p.bias + nqs) : f4zero();
     const bool addold = p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
     auto run = [&](auto kind) {
-        constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend
+        constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             bool ok[NI];
             size_t pix[NI];
             int pxl[NI];
-            float4 ea[NI], eb[NI];
+            float4 ea[NI], eb[NI], ec[K == 3 ? NI : 1];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int sl = tid + (half * NI + i) * 256;
@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
                 ok[i] = nok && oy < p.Ho && ox < p.Wo;
                 pix[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;     // (a valid address either way)
                 ea[i] = K >= 1 ? ld4(p.e0 + pix[i] * p.lde0 + nqs) : addold ? ld4(p.out + pix[i] * p.ldo + nqs) : f4zero();
-                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : f4zero();
+                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : (K == 3 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs - p.Cout / 2) : f4zero();
+                if (K == 3) ec[i] = ld4(p.out + pix[i] * p.ldo + nqs);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -287,6 +288,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
                     else if (epi == RAMNET_EPI_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
                 } else if (K == 1) {
                     v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
+                } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD)
+                    v = gru_bwd_quad(v, ea[i], eb[i], ec[K == 3 ? i : 0], p.o1 + pix[i] * p.ldo1 + nq);
                 } else {
                     const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
                     if (p.o1) st4(p.o1 + pix[i] * p.ldo1 + nq, o);
@@ -299,6 +302,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     };
     if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
     else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
+    else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
     else run(std::integral_constant<int, 0>{});
 }
 
@@ -372,6 +376,7 @@ int wino6_eligible(const ramnet_conv_desc &d, int force) {
     if (d.ntaps != 9 || d.stride != 1 || d.s2d_5x5 || d.out_s2d || d.frame) return 0;
     if (d.in_mode != RAMNET_IN_PLAIN && d.in_mode != RAMNET_IN_CAT && d.in_mode != RAMNET_IN_CAT_MUL && d.in_mode != RAMNET_IN_RELUMASK) return 0;
     if (d.epi == RAMNET_EPI_LSTM || d.Cout % 64 != 0 || !wino6_vec4(d)) return 0;
+    if (d.epi == RAMNET_EPI_GRU_BWD && d.Cout % 128 != 0) return 0;          // a 64-channel block lies in one half of [dx | d(h.r)]
     int txg;
     const long a6 = wino6_tile(d.Ho, d.Wo, txg);
     const long a4t = (long)cdiv(d.Wo, 4) * 4 * cdiv(d.Ho, 32) * 32, a4w = (long)cdiv(d.Wo, 16) * 16 * cdiv(d.Ho, 8) * 8;
@@ -387,6 +392,7 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
     RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK);
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
     RAMNET_CHECK_ARG(wino6_vec4(d) && d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0);
+    if (d.epi == RAMNET_EPI_GRU_BWD) RAMNET_CHECK_ARG(d.Cout % 128 == 0);
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
     for (int t = 0; t < 9; ++t) {

@@ -517,7 +517,7 @@ __global__ void space_to_depth2_kernel(const float *__restrict__ x, float *__res
 // ur = [u | r] (2C per pixel).  dpur = [dpu | dpr].
 __global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__restrict__ ur, const float *__restrict__ o,
                                  const float *__restrict__ h, float *__restrict__ dpo, float *__restrict__ dpur,
-                                 float *__restrict__ dh, size_t npix, int C, int ldg) {
+                                 float *__restrict__ dh, size_t npix, int C, int ldg, int lddh) {
     const int C4 = C / 4;
     const size_t total = npix * C4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -534,7 +534,7 @@ __global__ void gru_bwd_a_kernel(const float *__restrict__ dhn, const float *__r
 #undef RN_ONE
         st4(dpo + pix * C + c, a);
         st4(dpur + pix * 2 * C + c, bq);
-        st4(dh + pix * C + c, d);
+        st4(dh + pix * lddh + c, d);
     }
 }
 
@@ -813,7 +813,18 @@ extern "C" int ramnet_gru_bwd_a(const float *dhn, const float *ur, const float *
                                 float *dh, size_t npix, int C, int ld_dhn, void *stream) {
     RAMNET_CHECK_ARG(dhn && ur && o && dpo && dpur && dh && C % 4 == 0 && ld_dhn >= C && ld_dhn % 4 == 0);
     hipLaunchKernelGGL(gru_bwd_a_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ur, o, h, dpo, dpur, dh, npix, C,
-                       ld_dhn);
+                       ld_dhn, C);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same with dh written through its own leading dimension: into the [.., C:] half of the [dx | dh] tensor that the candidate
+// convolution's backward-data launch then completes in its epilogue (RAMNET_EPI_GRU_BWD) — stage B without a launch of its own
+extern "C" int ramnet_gru_bwd_a2(const float *dhn, const float *ur, const float *o, const float *h, float *dpo, float *dpur,
+                                 float *dh, size_t npix, int C, int ld_dhn, int ld_dh, void *stream) {
+    RAMNET_CHECK_ARG(dhn && ur && o && dpo && dpur && dh && C % 4 == 0 && ld_dhn >= C && ld_dhn % 4 == 0 && ld_dh >= C && ld_dh % 4 == 0);
+    hipLaunchKernelGGL(gru_bwd_a_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ur, o, h, dpo, dpur, dh, npix, C,
+                       ld_dhn, ld_dh);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -81,6 +81,16 @@ def set_fold_pair(on):
     invalidate_packs()
 
 
+_GRU_BWD_FUSED = True
+
+
+def set_gru_bwd_fused(on):
+    """Stage B of the ConvGRU backward (ramnet_gru_bwd_b) in the epilogue of the candidate convolution's backward-data launch
+    (RAMNET_EPI_GRU_BWD; hidden sizes that are multiples of 64): on by default, off for A/B runs and the unfused path's tests."""
+    global _GRU_BWD_FUSED
+    _GRU_BWD_FUSED = bool(on)
+
+
 def set_wgrad_winograd_2x4(mode):
     """F(2x4,3x3) backward-weights for the plain 3x3 layers (ConvGRU / ConvLSTM / residual layers of >= 64 reduction channels): "auto"
     (default) = when the backward-weights launches are co-scheduled with the backward-data chain (set_wgrad_overlap(True): training step
@@ -1490,14 +1500,23 @@ class GRUCell(Function):
         L = H.lib()
         dpo = torch.empty_like(o)
         dpur = torch.empty_like(ur)
-        dhd = torch.empty_like(o)
-        H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, ld(dhn), _st()), "gru_bwd_a")
+        dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)       # [dx | dh]
         taps, tapsd = Taps.get("conv", 3, 1), Taps.get("dgrad1", 3, 1)
+        # stage B (dpr = d(h.r) h r (1-r), dh = dh'(1-u) + d(h.r) r) in the epilogue of the launch that produces d(h.r): stage A leaves
+        # dh'(1-u) in the [.., C:] half of dxh (RAMNET_EPI_GRU_BWD; a 64-channel output block must lie in one half)
+        fused = _GRU_BWD_FUSED and Cc % 64 == 0
+        if fused:
+            H.check(L.ramnet_gru_bwd_a2(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dxh, Cc), npix, Cc, ld(dhn), 2 * Cc, _st()), "gru_bwd_a2")
+        else:
+            dhd = torch.empty_like(o)
+            H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, ld(dhn), _st()), "gru_bwd_a")
         ws, bws = cp_o.grad_ws(wino_ok=Cc % 32 == 0)
         wgrad_side([x, h, ur, dpo], x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
-        dxh = torch.empty(B, Hh, W, 2 * Cc, device=x.device)       # [dx | dh]
-        conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
-        H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
+        if fused:
+            conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc, epi=H.EPI_GRU_BWD, e0=ur, e1=h, o1=dpur)
+        else:
+            conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
+            H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
         ws, bws = cp_ur.grad_ws(wino_ok=Cc % 32 == 0)
         wgrad_side([x, h, dpur], x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)

@@ -589,6 +589,32 @@ def test_conv_gru(B, H, W, C, algo3x3):
              [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W))])
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 33, 45, 128), (8, 5, 43, 256)])
+def test_conv_gru_backward_stage_b_fused_equals_unfused(B, H, W, C, algo3x3):
+    """Stage B of the ConvGRU backward (dpr = d(h.r) h r (1-r), dh = dh'(1-u) + d(h.r) r; submodules.py:448-452 differentiated) runs in
+    the epilogue of the candidate convolution's backward-data launch (RAMNET_EPI_GRU_BWD) for hidden sizes that are multiples of 64 and
+    as its own launch (ramnet_gru_bwd_b) otherwise: both forms against each other on every 3x3 algorithm (the same sums in the same
+    order up to the fused multiply-adds of the last step: 1e-5), and test_conv_gru compares each with the float64 oracle."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvGRU
+    torch.manual_seed(11)
+    m = ConvGRU(C, C, 3).to(dev())
+    x0, h0 = torch.randn(B, H, W, C, device=dev()), torch.tanh(torch.randn(B, H, W, C, device=dev()))
+    wgt = torch.randn(B, H, W, C, device=dev())
+    res = {}
+    for on in (True, False):
+        ops.set_gru_bwd_fused(on)
+        try:
+            m.zero_grad()
+            x, h = x0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+            (m(x, h) * wgt).sum().backward()
+            res[on] = [x.grad.clone(), h.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+        finally:
+            ops.set_gru_bwd_fused(True)
+    for a, c in zip(res[True], res[False]):
+        assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-5, "fused vs unfused stage B")
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_conv_lstm(B, H, W, C):
     from rpg_ramnet_amd.model.submodules import ConvLSTM
