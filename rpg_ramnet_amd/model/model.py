@@ -63,6 +63,18 @@ def _state_nhwc(s, C):
     return _to_nhwc(s)
 
 
+def _cat_batch(ts):
+    """Concatenate along the batch axis; tensors that already lie one behind the other in one allocation (the K grids of a package out
+    of the batched voxelizer) become a view instead of a copy."""
+    t0 = ts[0]
+    step = t0.numel() * t0.element_size()
+    if all(t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and t.device == t0.device and not t.requires_grad
+           and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() and t.data_ptr() == t0.data_ptr() + i * step
+           for i, t in enumerate(ts)):
+        return t0.as_strided((len(ts) * t0.shape[0],) + tuple(t0.shape[1:]), t0.stride(), t0.storage_offset())
+    return torch.cat(ts, 0)
+
+
 class BaseERGB2Depth(BaseModel):
     def __init__(self, config):
         super().__init__(config)
@@ -165,6 +177,67 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         crop = self._crop_for(*frame_hw) if frame_hw is not None else None
         return pred if crop is None else crop.crop(pred)
 
+    def _forward_time_batched(self, item, states, crop, decode, emit):
+        """One package (model.py:176-213) with everything that does not depend on the ORDER of the state updates batched over time
+        (the training-step form of graph.TimeBatchedStream): RAM-Net's wiring (statenet.py:215-237) chains the ENCODER
+        feature through the scales and only updates the shared state, and the decoder of measurement k reads the state after update k
+        and nothing else.  So the K event grids go through head + encoders as ONE chain at batch K x B, the K + 1 state updates run one
+        by one — each cell writes its new state into slot k of a [K + 1, B, h, w, C] buffer per scale — and the K + 1 decodes run as
+        (at most) two chains over slots of those buffers: the measurements `loss_composition` supervises in one group, the others in
+        another, so that the backward pass only walks the decodes that carry a gradient (every prediction keeps its autograd path: a
+        caller that differentiates an unsupervised one is merely slower).  Per sample the arithmetic is what the pass-by-pass path does
+        (the launches pick their tiling by grid size, so results agree to rounding, not bit for bit).  ConvGRU state, plain-conv
+        encoders, no batch-statistics norm; anything else takes the pass-by-pass path."""
+        net, K, n = self.statenetphasedrecurrent, self.every_x_rgb_frame, self.num_encoders
+        keys = ['events{}'.format(k) for k in range(K)] + ['image']
+        ev = _cat_batch([item[k].to(device=self.gpu, dtype=torch.float32) for k in keys[:K]])
+        x = net.head_events(ops.pack_input(ev, self.gpu, crop))
+        B = x.shape[0] // K
+        feats = []
+        for enc in net.encoders_events:
+            x = enc(x)
+            feats.append(ops.TimeSplit.apply(x, K))
+        # slot k of arena[i] = the state of scale i after update k (slot K: after the frame); written by the cells, never by a torch op
+        arena = [torch.empty((K + 1,) + tuple(s.shape), device=self.gpu) for s in states]
+        lc = self.loss_composition
+        sup = [k for k in range(K + 1) if keys[k] in lc] if isinstance(lc, (list, tuple)) else None
+        if not torch.is_grad_enabled():
+            groups = [list(range(K + 1))]
+        elif sup is None:
+            groups = [[k] for k in range(K + 1)]              # unknown supervision: one decode per measurement, as in the reference
+        else:
+            groups = [g for g in ([k for k in range(K + 1) if k not in sup], sup) if g]
+        per_slot, preds = [], {}
+
+        def decode_group(g):
+            runs = [[g[0]]]                                    # maximal runs of consecutive slots (joined without a copy)
+            for k in g[1:]:
+                if k == runs[-1][-1] + 1:
+                    runs[-1].append(k)
+                else:
+                    runs.append([k])
+            joined = []
+            for i in range(n):
+                parts = [ops.TimeJoin.apply(arena[i][r[0]:r[-1] + 1].view((len(r) * B,) + tuple(arena[i].shape[2:])),
+                                            *[per_slot[k][i] for k in r]) if len(r) > 1 else per_slot[r[0]][i] for r in runs]
+                joined.append(parts[0] if len(parts) == 1 else torch.cat(parts, 0))
+            pred = decode(joined)
+            for j, k in enumerate([k for r in runs for k in r]):
+                preds[k] = pred[j * B:(j + 1) * B]
+
+        for k in range(K + 1):
+            if k < K:
+                states = [net.state_combination_events[i](feats[i][k], states[i], arena[i][k])[1] for i in range(n)]
+            else:
+                ximg = ops.pack_input(item['image'], self.gpu, crop)
+                states, _ = net.forward_images(ximg, states, None, out=[a[K] for a in arena])
+            per_slot.append(states)
+            for g in groups:                                   # a group is decoded as soon as its last update exists
+                if g[-1] == k:
+                    decode_group(g)
+        for k in range(K + 1):
+            emit(keys[k], preds[k], per_slot[k], {'encoders': [None] * n, 'state_comb': per_slot[k]})
+
     def forward(self, item, prev_super_states, prev_states_lstm):
         net = self.statenetphasedrecurrent
         predictions_dict, super_state_dict, states_lstm_dict = {}, {}, {}
@@ -206,6 +279,16 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
 
         events_as_image = baseline == "ergb0" or (baseline == "e" and lc == "image")
         last = None
+        if (ops.time_batching() and not bool(baseline) and K >= 2 and net.recurrent_block_type == 'conv'
+                and net.state_combination == 'convgru' and net.norm not in ('BN', 'IN')
+                and all(item['events{}'.format(k)].shape == item['events0'].shape for k in range(K))):
+            self._forward_time_batched(item, states, crop, decode, emit)
+            if side is not None:                       # predictions are consumed on the caller's stream
+                torch.cuda.current_stream().wait_stream(side)
+                if not torch.cuda.is_current_stream_capturing():
+                    for pred in predictions_dict.values():
+                        pred.record_stream(torch.cuda.current_stream())
+            return predictions_dict, super_state_dict, states_lstm_dict
         if not bool(baseline) or events_as_image:
             if events_as_image:
                 loop_range, last = K - 1, lstm_in(prev_states_lstm['image'])

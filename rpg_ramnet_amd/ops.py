@@ -1523,6 +1523,57 @@ class GRUCell(Function):
         return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None, None
 
 
+_TIME_BATCH = True
+
+
+def set_time_batching(on):
+    """ERGB2DepthRecurrent.forward batches over TIME what does not depend on the order of the state updates (the event encoders of a
+    package as ONE chain at batch K x B, the decodes of a package in groups: model/model.py) — on by default, off for A/B runs and the
+    pass-by-pass path's tests."""
+    global _TIME_BATCH
+    _TIME_BATCH = bool(on)
+
+
+def time_batching():
+    return _TIME_BATCH
+
+
+class TimeSplit(Function):
+    """[n * B, ...] -> n views [B, ...] (the features of n measurements that went through a layer chain as one batch); backward
+    concatenates the n gradients (ONE launch) instead of autograd's n zero-fills + n slice copies."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        B = x.shape[0] // n
+        ctx.meta = (n, B, tuple(x.shape[1:]))
+        return tuple(x[k * B:(k + 1) * B] for k in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return torch.cat(grads, 0), None
+
+
+class TimeJoin(Function):
+    """n state tensors [B, h, w, C] that already ARE consecutive slots of one buffer (the cells wrote them there: GRUCell `out=`)
+    -> the buffer's [n * B, h, w, C] view, without a copy; backward hands each cell its slice of the batched gradient."""
+
+    @staticmethod
+    def forward(ctx, joined, *parts):
+        B = parts[0].shape[0]
+        step = parts[0].numel() * parts[0].element_size()
+        for i, t in enumerate(parts):
+            if t.data_ptr() != joined.data_ptr() + i * step or not t.is_contiguous():
+                raise RuntimeError("TimeJoin: part %d is not slot %d of the joined buffer" % (i, i))
+        ctx.meta = (len(parts), B)
+        return joined.view(joined.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, B = ctx.meta
+        g = dense(g)
+        return (None,) + tuple(g[i * B:(i + 1) * B] for i in range(n))
+
+
 class LSTMCell(Function):
     """ConvLSTM (submodules.py:318-358): one launch; the gate non-linearities and the cell update are the epilogue."""
 

@@ -316,6 +316,58 @@ def test_bptt_gradients_vs_oracle(mode):
         assert_close(p.grad.cpu().numpy(), sd[k].grad.numpy(), 2e-3, "grad " + k, floor=1e-2 * gmax)
 
 
+@pytest.mark.parametrize("lc", [["image", "events2"], ["events0", "image"], ["events1"], False])
+@pytest.mark.parametrize("full_frame", [False, True])
+def test_time_batched_forward_equals_pass_by_pass(lc, full_frame):
+    """ERGB2DepthRecurrent.forward batches over time what does not depend on the order of the state updates (the K event grids through
+    head + encoders as one chain at batch K x B, the decodes in a supervised and an unsupervised group over slots of per-scale state
+    buffers; model/model.py:_forward_time_batched) — against the pass-by-pass loop of model.py:176-213 (ops.set_time_batching(False)):
+    every prediction, every returned state, the loss and every gradient, for supervised sets that are a run of slots, that are not,
+    a single key, and no `loss_composition` in the config (one decode per measurement); two packages (state carry), training and
+    no_grad, with and without full-frame padding.  Per sample the arithmetic is the same; the launches pick tilings by grid size, so
+    the comparison is 2e-5 / 2e-4 (gradients), not bit for bit.  test_bptt_gradients_vs_oracle etc. run the batched path against float64."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    K = 3
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=K, loss_composition=lc)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    model.set_full_frame(full_frame)
+    rng = np.random.default_rng(21)
+    B, H, W, L = 2, (26 if full_frame else 32), (35 if full_frame else 48), 2
+    seq = [make_item(rng, B, H, W, K, 5, 1, True, 0.2) for _ in range(L)]
+    keys = lc if lc else ["image", "events0"]
+    for it in seq:
+        for k in keys:
+            it.setdefault("depth_" + k, it["depth_image"].clone())
+    res = {}
+    for on in (True, False):
+        ops.set_time_batching(on)
+        try:
+            model.zero_grad()
+            total, _ = sequence_loss(model, seq, keys, [1, 1])
+            total.backward()
+            grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+            with torch.no_grad():
+                prev, lstm, outs = None, ramnet_ref.empty_states_lstm(K), []
+                for it in seq:
+                    preds, supers, lstm = model(it, prev, lstm)
+                    prev = supers["image"]
+                    assert list(preds.keys()) == ["events%d" % k for k in range(K)] + ["image"]
+                    outs.append(([preds[k].clone() for k in preds], [s.clone() for k in supers for s in supers[k]],
+                                 [s.clone() for k in lstm for s in lstm[k]["state_comb"]]))
+            res[on] = (float(total.detach()), grads, outs)
+        finally:
+            ops.set_time_batching(True)
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-5)
+    for (pa, sa, la), (pb, sb, lb) in zip(res[True][2], res[False][2]):
+        for a, c in zip(pa + sa + la, pb + sb + lb):
+            assert a.shape == c.shape
+            assert_close(a.cpu().numpy(), c.cpu().numpy(), 2e-5, "time-batched vs pass-by-pass forward")
+    gmax = max(float(g.abs().max()) for g in res[False][1].values())
+    for k, g in res[False][1].items():
+        assert_close(res[True][1][k].cpu().numpy(), g.cpu().numpy(), 2e-4, "grad " + k, floor=1e-2 * gmax)     # (pred.bias: a sum that cancels to ~0)
+
+
 def test_bench_two_ranks_share_one_gpu_gloo(tmp_path):
     """The N>1 path of bench.py end to end on a 1-GPU box: 2 ranks (gloo, both on cuda:0), tiny problem.  Checks the
     launch contract (torch.distributed.run env), the flat-bucket gradient all-reduce on CUDA tensors and the JSON line."""
