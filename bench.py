@@ -89,6 +89,7 @@ def parse():
                     "optionally ,min_wgs (ops.set_winograd_2x4)")
     ap.add_argument("--wgrad-2x4", default="auto", choices=["auto", "off", "force"], help="A/B: F(2x4,3x3) backward-weights (ops.set_wgrad_winograd_2x4)")
     ap.add_argument("--no-time-batching", action="store_true", help="A/B: the pass-by-pass package loop instead of the time-batched forward (ops.set_time_batching(False))")
+    ap.add_argument("--time-batch-max-decodes", type=int, default=0, help="A/B: decodes per chain of the time-batched forward (0 = a whole group)")
     ap.add_argument("--no-gru-bwd-fused", action="store_true", help="A/B: ConvGRU backward stage B as its own launch (ops.set_gru_bwd_fused(False))")
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384, the default)")
@@ -653,7 +654,7 @@ def main():
     ops.set_wgrad_slabs(not args.wgrad_atomic)
     ops.set_wgrad_winograd_2x4(args.wgrad_2x4)
     ops.set_gru_bwd_fused(not args.no_gru_bwd_fused)
-    ops.set_time_batching(not args.no_time_batching)
+    ops.set_time_batching(not args.no_time_batching, max_decodes=args.time_batch_max_decodes)
     if args.wgrad_wino_nf:
         Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", args.wgrad_wino_nf), "set_option")
     if args.wgrad_wino_blocks:

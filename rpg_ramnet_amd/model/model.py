@@ -186,8 +186,8 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         (at most) two chains over slots of those buffers: the measurements `loss_composition` supervises in one group, the others in
         another, so that the backward pass only walks the decodes that carry a gradient (every prediction keeps its autograd path: a
         caller that differentiates an unsupervised one is merely slower).  Per sample the arithmetic is what the pass-by-pass path does
-        (the launches pick their tiling by grid size, so results agree to rounding, not bit for bit).  ConvGRU state, plain-conv
-        encoders, no batch-statistics norm; anything else takes the pass-by-pass path."""
+        (the launches pick their tiling by grid size, so results agree to rounding, not bit for bit).  ConvGRU or ConvLSTM state,
+        plain-conv encoders, no batch-statistics norm; anything else takes the pass-by-pass path."""
         net, K, n = self.statenetphasedrecurrent, self.every_x_rgb_frame, self.num_encoders
         keys = ['events{}'.format(k) for k in range(K)] + ['image']
         ev = _cat_batch([item[k].to(device=self.gpu, dtype=torch.float32) for k in keys[:K]])
@@ -198,7 +198,14 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
             x = enc(x)
             feats.append(ops.TimeSplit.apply(x, K))
         # slot k of arena[i] = the state of scale i after update k (slot K: after the frame); written by the cells, never by a torch op
-        arena = [torch.empty((K + 1,) + tuple(s.shape), device=self.gpu) for s in states]
+        pair = net.state_combination == 'convlstm'           # (h, c) per scale: the decoders read h
+        if pair:
+            arena = [[torch.empty((K + 1,) + tuple(t.shape), device=self.gpu) for t in s] for s in states]
+        else:
+            arena = [torch.empty((K + 1,) + tuple(s.shape), device=self.gpu) for s in states]
+        slot = (lambda i, k: [a[k] for a in arena[i]]) if pair else (lambda i, k: arena[i][k])
+        hbuf = (lambda i: arena[i][0]) if pair else (lambda i: arena[i])
+        hof = (lambda s: s[0]) if pair else (lambda s: s)
         lc = self.loss_composition
         sup = [k for k in range(K + 1) if keys[k] in lc] if isinstance(lc, (list, tuple)) else None
         if not torch.is_grad_enabled():
@@ -207,6 +214,9 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
             groups = [[k] for k in range(K + 1)]              # unknown supervision: one decode per measurement, as in the reference
         else:
             groups = [g for g in ([k for k in range(K + 1) if k not in sup], sup) if g]
+        md = ops.time_batch_max_decodes()
+        if md > 0:
+            groups = [g[j:j + md] for g in groups for j in range(0, len(g), md)]
         per_slot, preds = [], {}
 
         def decode_group(g):
@@ -218,19 +228,21 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                     runs.append([k])
             joined = []
             for i in range(n):
-                parts = [ops.TimeJoin.apply(arena[i][r[0]:r[-1] + 1].view((len(r) * B,) + tuple(arena[i].shape[2:])),
-                                            *[per_slot[k][i] for k in r]) if len(r) > 1 else per_slot[r[0]][i] for r in runs]
-                joined.append(parts[0] if len(parts) == 1 else torch.cat(parts, 0))
+                buf = hbuf(i)
+                parts = [ops.TimeJoin.apply(buf[r[0]:r[-1] + 1].view((len(r) * B,) + tuple(buf.shape[2:])),
+                                            *[hof(per_slot[k][i]) for k in r]) if len(r) > 1 else hof(per_slot[r[0]][i]) for r in runs]
+                h = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+                joined.append((h,) if pair else h)
             pred = decode(joined)
             for j, k in enumerate([k for r in runs for k in r]):
                 preds[k] = pred[j * B:(j + 1) * B]
 
         for k in range(K + 1):
             if k < K:
-                states = [net.state_combination_events[i](feats[i][k], states[i], arena[i][k])[1] for i in range(n)]
+                states = [net.state_combination_events[i](feats[i][k], states[i], slot(i, k))[1] for i in range(n)]
             else:
                 ximg = ops.pack_input(item['image'], self.gpu, crop)
-                states, _ = net.forward_images(ximg, states, None, out=[a[K] for a in arena])
+                states, _ = net.forward_images(ximg, states, None, out=[slot(i, K) for i in range(n)])
             per_slot.append(states)
             for g in groups:                                   # a group is decoded as soon as its last update exists
                 if g[-1] == k:
@@ -280,7 +292,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         events_as_image = baseline == "ergb0" or (baseline == "e" and lc == "image")
         last = None
         if (ops.time_batching() and not bool(baseline) and K >= 2 and net.recurrent_block_type == 'conv'
-                and net.state_combination == 'convgru' and net.norm not in ('BN', 'IN')
+                and net.state_combination in ('convgru', 'convlstm') and net.norm not in ('BN', 'IN')
                 and all(item['events{}'.format(k)].shape == item['events0'].shape for k in range(K))):
             self._forward_time_batched(item, states, crop, decode, emit)
             if side is not None:                       # predictions are consumed on the caller's stream

@@ -1526,12 +1526,21 @@ class GRUCell(Function):
 _TIME_BATCH = True
 
 
-def set_time_batching(on):
+_TIME_BATCH_MAX_DECODES = 0      # decodes per chain of the time-batched forward (0: a whole group)
+
+
+def set_time_batching(on, max_decodes=None):
     """ERGB2DepthRecurrent.forward batches over TIME what does not depend on the order of the state updates (the event encoders of a
     package as ONE chain at batch K x B, the decodes of a package in groups: model/model.py) — on by default, off for A/B runs and the
-    pass-by-pass path's tests."""
-    global _TIME_BATCH
+    pass-by-pass path's tests.  max_decodes: split a decode group into chains of at most that many measurements (0 = no split)."""
+    global _TIME_BATCH, _TIME_BATCH_MAX_DECODES
     _TIME_BATCH = bool(on)
+    if max_decodes is not None:
+        _TIME_BATCH_MAX_DECODES = int(max_decodes)
+
+
+def time_batch_max_decodes():
+    return _TIME_BATCH_MAX_DECODES
 
 
 def time_batching():

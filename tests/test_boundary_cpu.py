@@ -579,3 +579,43 @@ def test_epoch_trainer_matches_the_reference_base_trainer_fixture(tmp_path):
     assert t2.start_epoch == 8 and t2.monitor_best == z["monitor_best_final"]
     t2.train()
     assert len(t2.train_logger.entries) == 8
+
+
+def test_time_split_join_autograd_plumbing_cpu():
+    """Host logic of the time-batched forward (model._forward_time_batched; no kernels): ops.TimeSplit hands out views of a batched
+    tensor and concatenates the gradients, ops.TimeJoin declares cell outputs that already ARE consecutive slots of one buffer to be
+    its [n B, ...] view (no copy; refuses anything else), model._cat_batch turns adjacent tensors into a view and copies otherwise."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.model import _cat_batch
+
+    class Cell(torch.autograd.Function):          # stand-in for GRUCell(out=): writes the slot through a raw pointer (no version bump)
+        @staticmethod
+        def forward(ctx, x, out):
+            out.numpy()[...] = (2.0 * x).numpy()
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            return 2.0 * g, None
+
+    n, B = 3, 2
+    x = torch.randn(n * B, 4, 5, 8, requires_grad=True)
+    parts = ops.TimeSplit.apply(x * 1.0, n)
+    assert all(p.shape == (B, 4, 5, 8) for p in parts)
+    arena = torch.empty(n, B, 4, 5, 8)
+    hs = [Cell.apply(p, arena[k]) for k, p in enumerate(parts)]
+    assert all(h.data_ptr() == arena[k].data_ptr() and h.requires_grad for k, h in enumerate(hs))
+    joined = ops.TimeJoin.apply(arena[0:n].view(n * B, 4, 5, 8), *hs)
+    assert joined.data_ptr() == arena.data_ptr() and joined.requires_grad
+    w = torch.randn(n * B, 4, 5, 8)
+    (joined * w).sum().backward()
+    torch.testing.assert_close(x.grad, 2.0 * w)
+    with pytest.raises(RuntimeError):             # parts that are not the buffer's slots, in order
+        ops.TimeJoin.apply(arena[0:2].view(2 * B, 4, 5, 8), hs[1].detach(), hs[0].detach())
+    g = torch.randn(5, B, 3, 4, 6)
+    a = _cat_batch([g[k] for k in range(5)])
+    assert a.data_ptr() == g.data_ptr() and torch.equal(a, g.view(5 * B, 3, 4, 6))
+    b = _cat_batch([g[1], g[3]])
+    assert b.data_ptr() != g[1].data_ptr() and torch.equal(b, torch.cat([g[1], g[3]], 0))
+    c = _cat_batch([g[2].clone(), g[3].clone()])
+    assert torch.equal(c, g[2:4].reshape(2 * B, 3, 4, 6))
