@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--wgrad-2x4", default="auto", choices=["auto", "off", "force"], help="A/B: F(2x4,3x3) backward-weights (ops.set_wgrad_winograd_2x4)")
     ap.add_argument("--no-time-batching", action="store_true", help="A/B: the pass-by-pass package loop instead of the time-batched forward (ops.set_time_batching(False))")
     ap.add_argument("--time-batch-max-decodes", type=int, default=0, help="A/B: decodes per chain of the time-batched forward (0 = a whole group)")
+    ap.add_argument("--no-configs4-extra", action="store_true", help="skip extras.configs4_shape (a ~20 s run of the 480x640 / 10-bin / B=4 / L=16 workload in a process of its own)")
     ap.add_argument("--no-gru-bwd-fused", action="store_true", help="A/B: ConvGRU backward stage B as its own launch (ops.set_gru_bwd_fused(False))")
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384, the default)")
@@ -99,6 +100,25 @@ def parse():
                          "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
                          "unavailable (no roofline object).  stream / infer modes always report both eager and graph replay")
     return ap.parse_args()
+
+
+def configs4_measure():
+    """BASELINE configs[4]'s per-GPU workload (480 x 640, 10-bin grids, batch 4, sequence length 16: ~100 GB of HBM) as a short run of
+    this script in a process of its own, so that the default line carries a driver-timed number for it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+           "--no-kernel-timing", "--height", "480", "--width", "640", "--bins", "10", "--batch", "4", "--seq-len", "16"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["WORLD_SIZE"] = "1"
+    t = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "peak_hbm_gb": d["peak_hbm_gb"],
+                "workload": d["config"]["workload"], "wall_s": time.perf_counter() - t,
+                "note": "configs[4] shape on ONE GPU (its 8-GPU form shards sequences like configs[2]); same binary, a separate process"}
+    except Exception as ex:     # noqa: BLE001
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
 
 def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
@@ -908,6 +928,8 @@ def main():
                                               "loss, BPTT backward, gradient fold) + eager Adam; rpg_ramnet_amd.graph.GraphedTrainStep")
             except Exception as ex:     # noqa: BLE001 — an extra must not take the headline measurement down
                 extras["graph_replay"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            if (H, W, bins, B, L) == (256, 344, 5, 8, 8) and not args.full_frame and not args.no_configs4_extra:
+                extras["configs4_shape"] = configs4_measure()
 
     stream_roof = None
     if args.mode in ("stream", "infer") and not args.no_kernel_timing and "eager" in graphed:
