@@ -23,7 +23,7 @@ def timeit(fn, reps=10):
 
 
 dev = torch.device("cuda:0")
-B = 8
+B = int(os.environ.get("S2D_B", "8"))
 for cin, cout, Hh, W in [(32, 64, 256, 344), (64, 128, 128, 172), (128, 256, 64, 86)]:
     w = torch.nn.Parameter(torch.randn(cout, cin, 5, 5, device=dev) * 0.05)
     b = torch.nn.Parameter(torch.randn(cout, device=dev) * 0.1)
