@@ -1008,6 +1008,10 @@ def main():
                         "of wide reads, MI355X_MICROARCH.md); operand_bytes_per_launch = inputs, masks and epilogue operands read once + outputs "
                         "written once + weights once (backward-weights: input, gradient and their masks read once + the gradient workspace read and written "
                         "once; its per-split slabs repeat that last term per split), averaged over the same launches"}
+            iso_k = extras.get("single_stream", {}).get("dominant_kernel") if extras else None
+            if iso_k:       # the same launches with nothing else on the chip (one-stream pass of the same process)
+                out["roofline"]["one_stream"] = {"avg_launch_ms": iso_k["avg_launch_ms"], "frac_executed": iso_k["frac"],
+                                                 "frac_algorithmic": iso_k["algorithmic_achieved"] / F32_MFMA_PEAK_TFLOPS, "launches": iso_k["launches"]}
             if warm and args.warmup > 0:      # overlap-proof view: all MFMA FLOP of a step over the step's wall time
                 step_alg = sum(v[2] for v in warm.values()) / args.warmup
                 step_ex = sum(v[3] for v in warm.values()) / args.warmup
