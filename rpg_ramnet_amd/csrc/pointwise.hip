@@ -678,6 +678,38 @@ extern "C" int ramnet_unpack_wgrad(const float *ws, float *grad, int Cout, int C
     return 0;
 }
 
+// out [n * npix][C] = parts[0..n-1] [npix][ld] one behind the other along the batch axis (+ base): gradient of a time-batched feature
+struct CatParts {
+    const float *p[8];
+};
+__global__ void cat_batch_add_kernel(const CatParts parts, int n, size_t npix, int C, int ld, const float *__restrict__ base,
+                                     float *__restrict__ out) {
+    const int C4 = C / 4;
+    const size_t per = npix * C4, total = per * n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / per);
+        const size_t r = i - (size_t)k * per, pix = r / C4;
+        const int c = (int)(r - pix * C4) * 4;
+        const float *src = k == 0 ? parts.p[0] : k == 1 ? parts.p[1] : k == 2 ? parts.p[2] : k == 3 ? parts.p[3] : k == 4 ? parts.p[4]
+                           : k == 5 ? parts.p[5] : k == 6 ? parts.p[6] : parts.p[7];
+        float4 v = ld4(src + pix * ld + c);
+        if (base) v = f4add(v, ld4(base + i * 4));
+        st4(out + i * 4, v);
+    }
+}
+
+extern "C" int ramnet_cat_batch_add(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, float *out, void *stream) {
+    RAMNET_CHECK_ARG(parts && out && n >= 1 && n <= 8 && npix > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0);
+    CatParts q;
+    for (int k = 0; k < 8; ++k) {
+        q.p[k] = k < n ? parts[k] : nullptr;
+        if (k < n) RAMNET_CHECK_ARG(parts[k] && ((uintptr_t)parts[k] & 15) == 0);
+    }
+    hipLaunchKernelGGL(cat_batch_add_kernel, dim3(grid_for((size_t)n * npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, q, n, npix, C, ld, base, out);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *stream) {
     RAMNET_CHECK_ARG(dy && y && dx);
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);

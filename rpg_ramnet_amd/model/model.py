@@ -194,9 +194,14 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         x = net.head_events(ops.pack_input(ev, self.gpu, crop))
         B = x.shape[0] // K
         feats = []
-        for enc in net.encoders_events:
+        for i, enc in enumerate(net.encoders_events):
             x = enc(x)
-            feats.append(ops.TimeSplit.apply(x, K))
+            if i + 1 < n:          # feeds the next encoder as a whole and the K cells of its scale slice by slice
+                fan = ops.TimeFan.apply(x, K)
+                x, parts = fan[0], fan[1:]
+            else:
+                parts = ops.TimeSplit.apply(x, K)
+            feats.append(parts)
         # slot k of arena[i] = the state of scale i after update k (slot K: after the frame); written by the cells, never by a torch op
         pair = net.state_combination == 'convlstm'           # (h, c) per scale: the decoders read h
         if pair:

@@ -1547,6 +1547,27 @@ def time_batching():
     return _TIME_BATCH
 
 
+def _cat_batch_add(grads, base, shape, device):
+    """cat(grads, 0) [+ base] as ONE launch (ramnet_cat_batch_add): the slices' gradients are channel slices of wider tensors (the
+    [dx | dh] of a ConvGRU backward: ld = 2C), `base` the gradient that arrived through the batched consumer."""
+    n = len(grads)
+    ok = (len(shape) == 4 and n <= 8 and shape[3] % 4 == 0 and all(g is not None and g.is_cuda and g.dim() == 4 and g.dtype == torch.float32 for g in grads)
+          and (base is None or base.dtype == torch.float32))
+    if ok:
+        gs = [dense(g) for g in grads]
+        ok = all(ld(g) == ld(gs[0]) and g.stride(1) == g.shape[2] * g.stride(2) and g.stride(0) == g.shape[1] * g.stride(1)
+                 and tuple(g.shape) == (shape[0] // n,) + tuple(shape[1:]) for g in gs)
+    if not ok:
+        filled = [g if g is not None else torch.zeros((shape[0] // n,) + tuple(shape[1:]), device=device) for g in grads]
+        out = torch.cat(filled, 0)
+        return out if base is None else out + base
+    out = torch.empty(shape, device=device)
+    arr = (C.c_void_p * n)(*[g.data_ptr() for g in gs])
+    b = None if base is None else base.contiguous()
+    H.check(H.lib().ramnet_cat_batch_add(arr, n, shape[1] * shape[2] * (shape[0] // n), shape[3], ld(gs[0]), _p(b), _p(out), _st()), "ramnet_cat_batch_add")
+    return out
+
+
 class TimeSplit(Function):
     """[n * B, ...] -> n views [B, ...] (the features of n measurements that went through a layer chain as one batch); backward
     concatenates the n gradients (ONE launch) instead of autograd's n zero-fills + n slice copies."""
@@ -1554,12 +1575,34 @@ class TimeSplit(Function):
     @staticmethod
     def forward(ctx, x, n):
         B = x.shape[0] // n
-        ctx.meta = (n, B, tuple(x.shape[1:]))
+        ctx.meta = (n, tuple(x.shape), x.device)
+        ctx.set_materialize_grads(False)
         return tuple(x[k * B:(k + 1) * B] for k in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
-        return torch.cat(grads, 0), None
+        n, shape, dev = ctx.meta
+        return _cat_batch_add(list(grads), None, shape, dev), None
+
+
+class TimeFan(Function):
+    """TimeSplit for a feature that ALSO feeds the next layer of the batched chain: returns (x itself, n views).  Backward gets the
+    gradient of the batched consumer and the n slice gradients in ONE call and forms their sum in one launch — autograd's fan-in add
+    (and the concatenation) as library work."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        B = x.shape[0] // n
+        ctx.meta = (n, tuple(x.shape), x.device)
+        ctx.set_materialize_grads(False)
+        return (x.view_as(x),) + tuple(x[k * B:(k + 1) * B] for k in range(n))
+
+    @staticmethod
+    def backward(ctx, g_all, *grads):
+        n, shape, dev = ctx.meta
+        if all(g is None for g in grads):
+            return g_all, None
+        return _cat_batch_add(list(grads), g_all, shape, dev), None
 
 
 class TimeJoin(Function):

@@ -619,3 +619,24 @@ def test_time_split_join_autograd_plumbing_cpu():
     assert b.data_ptr() != g[1].data_ptr() and torch.equal(b, torch.cat([g[1], g[3]], 0))
     c = _cat_batch([g[2].clone(), g[3].clone()])
     assert torch.equal(c, g[2:4].reshape(2 * B, 3, 4, 6))
+
+
+def test_time_fan_autograd_plumbing_cpu():
+    """ops.TimeFan (a batched feature that feeds the next layer of the chain as a whole AND n cells slice by slice): the gradient is
+    the batched consumer's plus the concatenation of the slices' — with unused slices, and with an unused batched consumer."""
+    from rpg_ramnet_amd import ops
+    n, B = 3, 2
+    x = torch.randn(n * B, 4, 5, 8, requires_grad=True)
+    w_all, w = torch.randn(n * B, 4, 5, 8), [torch.randn(B, 4, 5, 8) for _ in range(n)]
+    out = ops.TimeFan.apply(x * 1.0, n)
+    assert out[0].shape == x.shape and all(p.shape == (B, 4, 5, 8) for p in out[1:])
+    ((out[0] * w_all).sum() + sum((p * wk).sum() for p, wk in zip(out[1:], w))).backward()
+    torch.testing.assert_close(x.grad, w_all + torch.cat(w, 0))
+    x.grad = None
+    out = ops.TimeFan.apply(x * 1.0, n)
+    ((out[0] * w_all).sum() + (out[2] * w[1]).sum()).backward()                # slices 0 and 2 unused
+    torch.testing.assert_close(x.grad, w_all + torch.cat([torch.zeros_like(w[0]), w[1], torch.zeros_like(w[2])], 0))
+    x.grad = None
+    out = ops.TimeFan.apply(x * 1.0, n)
+    sum((p * wk).sum() for p, wk in zip(out[1:], w)).backward()                # the batched consumer unused
+    torch.testing.assert_close(x.grad, torch.cat(w, 0))

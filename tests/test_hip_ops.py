@@ -615,6 +615,26 @@ def test_conv_gru_backward_stage_b_fused_equals_unfused(B, H, W, C, algo3x3):
         assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-5, "fused vs unfused stage B")
 
 
+@pytest.mark.parametrize("n,B,H,W,C,wide", [(5, 2, 8, 12, 64, True), (3, 1, 7, 13, 32, False), (8, 1, 4, 6, 8, True), (2, 3, 5, 9, 128, True)])
+def test_time_fan_gradient_kernel(n, B, H, W, C, wide):
+    """ramnet_cat_batch_add behind ops.TimeFan / ops.TimeSplit: the gradient of a time-batched feature = the gradients of its n slices
+    (channel slices of wider tensors, as the [dx | dh] of a ConvGRU backward hands them over: ld = 2C) one behind the other along the batch
+    axis, plus the gradient of the batched consumer — bit-equal to torch.cat + add (one addition per element)."""
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(n)
+    x = torch.randn(n * B, H, W, C, device=dev(), requires_grad=True)
+    wide_g = [torch.randn(B, H, W, 2 * C if wide else C, device=dev()) for _ in range(n)]
+    g_all = torch.randn(n * B, H, W, C, device=dev())
+    out = ops.TimeFan.apply(x * 1.0, n)
+    torch.autograd.backward([out[0]] + list(out[1:]), [g_all] + [g[..., :C] for g in wide_g])
+    ref = g_all + torch.cat([g[..., :C] for g in wide_g], 0)
+    assert torch.equal(x.grad, ref)
+    x.grad = None
+    parts = ops.TimeSplit.apply(x * 1.0, n)
+    torch.autograd.backward(list(parts), [g[..., :C] for g in wide_g])
+    assert torch.equal(x.grad, torch.cat([g[..., :C] for g in wide_g], 0))
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_conv_lstm(B, H, W, C):
     from rpg_ramnet_amd.model.submodules import ConvLSTM
