@@ -298,7 +298,9 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         last = None
         if (ops.time_batching() and not bool(baseline) and K >= 2 and net.recurrent_block_type == 'conv'
                 and net.state_combination in ('convgru', 'convlstm') and net.norm not in ('BN', 'IN')
-                and all(item['events{}'.format(k)].shape == item['events0'].shape for k in range(K))):
+                and all(item['events{}'.format(k)].shape == item['events0'].shape for k in range(K))
+                # (the kernels address a tensor with 32-bit element offsets: the K x B head output must stay below 2^32 elements)
+                and (K + 1) * item['events0'].shape[0] * (states[0].shape[1] * 2) * (states[0].shape[2] * 2) * self.base_num_channels < (1 << 32)):
             self._forward_time_batched(item, states, crop, decode, emit)
             if side is not None:                       # predictions are consumed on the caller's stream
                 torch.cuda.current_stream().wait_stream(side)
