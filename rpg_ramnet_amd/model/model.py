@@ -63,6 +63,11 @@ def _state_nhwc(s, C):
     return _to_nhwc(s)
 
 
+def _leaf(s):
+    """The h tensor of a per-scale state (ConvLSTM states are (h, c) pairs)."""
+    return s[0] if isinstance(s, (list, tuple)) else s
+
+
 def _cat_batch(ts):
     """Concatenate along the batch axis; tensors that already lie one behind the other in one allocation (the K grids of a package out
     of the batched voxelizer) become a view instead of a copy."""
@@ -300,7 +305,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                 and net.state_combination in ('convgru', 'convlstm') and net.norm not in ('BN', 'IN')
                 and all(item['events{}'.format(k)].shape == item['events0'].shape for k in range(K))
                 # (the kernels address a tensor with 32-bit element offsets: the K x B head output must stay below 2^32 elements)
-                and (K + 1) * item['events0'].shape[0] * (states[0].shape[1] * 2) * (states[0].shape[2] * 2) * self.base_num_channels < (1 << 32)):
+                and (K + 1) * item['events0'].shape[0] * 4 * _leaf(states[0]).shape[1] * _leaf(states[0]).shape[2] * self.base_num_channels < (1 << 32)):
             self._forward_time_batched(item, states, crop, decode, emit)
             if side is not None:                       # predictions are consumed on the caller's stream
                 torch.cuda.current_stream().wait_stream(side)
