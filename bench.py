@@ -325,11 +325,29 @@ class KernelTimer:
 
 
 def newest_pmc_traffic():
-    """The newest tracked PMC summary (tools/pmc_traffic.py): {kernel: {grid: {launches, hbm_bytes_per_launch}}}."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_hbm_traffic.json")))
+    """The PMC summary (tools/pmc_traffic.py) that belongs to this tree: profiles/CURRENT_PMC names it (tools/profile_round.sh's copy step
+    writes that one line); without the pointer, the file of the highest (round, then modification time) — never plain lexicographic order,
+    in which `r04_zzzz` beats the newer `r04_final`.  {kernel: {grid: {launches, hbm_bytes_per_launch}}}."""
+    ptr = os.path.join(ROOT, "profiles", "CURRENT_PMC")
+    if os.path.exists(ptr):
+        name = open(ptr).read().split()[0]
+        return name, json.load(open(os.path.join(ROOT, "profiles", name)))
+    files = glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_hbm_traffic.json"))
     if not files:
         raise FileNotFoundError("no profiles/r*_pmc_hbm_traffic.json: run the rocprofv3 --pmc passes (tools/pmc_traffic.py) and commit it")
-    return os.path.basename(files[-1]), json.load(open(files[-1]))
+    best = max(files, key=lambda f: (os.path.basename(f)[:3], os.path.getmtime(f)))
+    return os.path.basename(best), json.load(open(best))
+
+
+def pmc_launches_of(pmc, name):
+    """Launches of kernel symbol `name` in the PMC pass (ONE step, no warm-up: tools/profile_round.sh)."""
+    want = name.replace(" ", "")
+    n = 0
+    for k, ent in pmc.items():
+        kk = k.replace(" ", "").replace("(bool)", "").replace("true", "1").replace("false", "0")
+        if kk == want or kk.split("<")[0] == want:
+            n += sum(v["launches"] for v in ent.values())
+    return n
 
 
 def traffic_of(pmc, name):
@@ -847,18 +865,35 @@ def main():
         # co-scheduled event durations of the warm-up inflate forward and backward launches differently and would make the
         # choice flip between the instantiations of the same kernel from run to run
         timer.only = max(warm.items(), key=lambda kv: kv[1][3])[0]
+    collective = args.mode == "train" and (world > 1 or args.force_collective)
+    if collective:
+        reducer.timing = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0     # this rank's own time to finish its K steps (before the barrier)
     fence()
     dt = time.perf_counter() - t0
     timer.on = False
     agg_timed = timer.summary()          # dominant kernel over the timed region (the extras below reuse the timer)
     timer.rec = []
+    per_rank = None
     if world > 1 or args.force_collective:
         t = torch.tensor([dt], device=model.gpu, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        # where a non-ideal scaling curve would come from: every rank's own step time and the span of its gradient collectives
+        span = reducer.span_ms() if collective else None
+        mine = torch.tensor([1e3 * dt_local / args.steps, span if span is not None else -1.0], device=model.gpu, dtype=torch.float64)
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        ms = [float(g[0]) for g in got]
+        per_rank = {"step_ms": [round(v, 3) for v in ms], "step_ms_max": max(ms), "step_ms_min": min(ms),
+                    "grad_allreduce_span_ms_last_step": [round(float(g[1]), 3) if float(g[1]) >= 0 else None for g in got],
+                    "note": "step_ms = each rank's own wall time per step up to ITS device synchronisation, before the barrier; the "
+                            "all-reduce span (side stream, first collective issued -> last done, last timed step) includes the wait of "
+                            "early buckets for later folds"}
     loss_val = float(last.detach())
     assert np.isfinite(loss_val), "non-finite loss"
 
@@ -972,6 +1007,8 @@ def main():
                                      "buckets_issued_during_the_fold": reducer.early_buckets, "steps_run": args.steps + args.warmup,
                                      "note": "parallel.FlatGradReducer: bucket k goes to the side stream as soon as the end-of-backward fold "
                                              "has finalised the last parameter of buckets 0..k (SURVEY 8e); the rest in all_reduce()"}
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if args.mode == "stream":
             out["stream"] = {"updates_per_s": updates / dt, "ms_per_update_and_decode": 1e3 * dt / (updates / (world * B)),
                              "grids_per_frame": sched, "note": "one update = fold one event grid or frame into the persistent "
@@ -988,6 +1025,15 @@ def main():
             name, (n, secs, alg, ex, opb) = max(agg_timed.items(), key=lambda kv: kv[1][1])
             pmc_file, pmc = newest_pmc_traffic()
             traffic = traffic_of(pmc, name)
+            # a summary recorded for another build (different launches per step of the kernels it is quoted for) is refused, not quoted
+            pmc_stale = []
+            if warm and args.warmup > 0:
+                for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])[:3]:
+                    have, want = pmc_launches_of(pmc, k), v[0] / args.warmup
+                    if have and abs(have - want) > 0.01 * want:
+                        pmc_stale.append("%s: %d launches per step in %s, %d now" % (k, have, pmc_file, want))
+            if pmc_stale:
+                traffic = None
             out["roofline"] = {
                 "bound": "mfma", "kernel": name, "achieved": ex / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS, "frac_executed": ex / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
@@ -1009,6 +1055,17 @@ def main():
                         "of wide reads, MI355X_MICROARCH.md); operand_bytes_per_launch = inputs, masks and epilogue operands read once + outputs "
                         "written once + weights once (backward-weights: input, gradient and their masks read once + the gradient workspace read and written "
                         "once; its per-split slabs repeat that last term per split), averaged over the same launches"}
+            if pmc_stale:
+                out["roofline"]["traffic_refused"] = pmc_stale
+            if warm and args.warmup > 0:      # the three kernels with the most GPU time: what they have to move against what the counters saw
+                top = []
+                for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])[:3]:
+                    tr = None if pmc_stale else traffic_of(pmc, k)
+                    top.append({"kernel": k, "launches_per_step": v[0] / args.warmup, "avg_launch_ms": 1e3 * v[1] / v[0],
+                                "mfma_frac_executed": v[3] / v[1] / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                "operand_bytes_per_launch": v[4] / v[0], "traffic": tr,
+                                "traffic_over_operand_bytes": (tr / (v[4] / v[0])) if (tr and v[4]) else None})
+                out["roofline"]["top3"] = top
             iso_k = extras.get("single_stream", {}).get("dominant_kernel") if extras else None
             if iso_k:       # the same launches with nothing else on the chip (one-stream pass of the same process)
                 out["roofline"]["one_stream"] = {"avg_launch_ms": iso_k["avg_launch_ms"], "frac_executed": iso_k["frac"],

@@ -484,6 +484,8 @@ class _Engine:
             cp.finalize()
             if hook is not None:
                 hook.finalized(cp)
+        if hook is not None and hasattr(hook, "end"):
+            hook.end()
 
     @classmethod
     def reset(cls):
@@ -503,18 +505,22 @@ def set_finalize_hook(hook):
     _FINALIZE_HOOK = hook
 
 
+def get_finalize_hook():
+    return _FINALIZE_HOOK
+
+
 def ensure_grad(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p)
     return p.grad
 
 
-# ---- folded upsample-conv: weight algebra (pure torch, device-agnostic; tests/test_boundary_cpu.py checks it against F.conv2d)
+# ---- folded upsample-conv: weight algebra of the direct-kernel pack (pure torch; the plain-torch restatements of the HIP pack / unpack
+# kernels that the tests compare against live in tests/torch_restatements.py)
 # high-res row 2i + p + k - 2 (k = 0..4) of the x2 bilinear upsample is a 0.25 / 0.75 blend of two low-res rows;
 # FOLD_A[p][t][k] = weight of low-res row i + p - 2 + t (t = 0..3) in tap k of output parity p.
 FOLD_A = ([[.25, 0, 0, 0, 0], [.75, .75, .25, 0, 0], [0, .25, .75, .75, .25], [0, 0, 0, .25, .75]],
           [[.75, .25, 0, 0, 0], [.25, .75, .75, .25, 0], [0, 0, .25, .75, .75], [0, 0, 0, 0, .25]])
-FOLD_LOST = [[(0, 1), (0,)], [(4,), (3, 4)]]    # [side: near / far edge][slot: distance into the band] -> taps outside the image
 
 
 _CONSTS = {}
@@ -529,77 +535,10 @@ def _const(name, values, device, dtype):
     return t
 
 
-# Winograd F(2x2,4x4) of the four parity filters (csrc/conv_wino24.hip; Toom-Cook points 0, 1, -1, 2, inf)
-W24_G = [[0.5, 0, 0, 0], [-0.5, -0.5, -0.5, -0.5], [-1 / 6, 1 / 6, -1 / 6, 1 / 6], [1 / 6, 1 / 3, 2 / 3, 4 / 3], [0, 0, 0, 1]]
-W24_BT = [[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]]
-W24_AT = [[1, 1, 1, 1, 0], [0, 1, -1, 2, 1]]
-
-
-def fold_weights_wino(w):
-    """OIHW 5x5 -> U[class = py*2+px][pos = a*5+b][Cin][Cout] = G W4 G^T of the four 4x4 parity filters (float64)."""
-    G = _const("W24_G", W24_G, w.device, torch.float64)
-    u = torch.einsum("at,bs,oipqts->pqabio", G, G, fold_weights(w))
-    return u.reshape(4, 25, w.shape[1], w.shape[0])
-
-
-def pack_fold_wino(w):
-    """fold_weights_wino() in the lane order of conv_wino24_kernel's B operand (layout: include/ramnet_hip.h)."""
-    Cout, Cin = w.shape[0], w.shape[1]
-    if _fold_pair(Cout, Cin):       # class = row parity py, the workgroup's 64 columns = (column parity px, 32 channels)
-        u = fold_weights_wino(w).float().view(2, 2, 25, Cin, 32).permute(0, 2, 3, 1, 4).reshape(2, 25, Cin // 16, 4, 4, 1, 4, 16)
-        return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)
-    kc, ncq = (16, 4) if (Cout % 64 == 0 and Cin % 16 == 0) else (8, 2)     # chunk size, 16-channel groups per workgroup
-    u = fold_weights_wino(w).float().view(4, 25, Cin // kc, 4, kc // 4, Cout // (16 * ncq), ncq, 16)      # cls pos chunk ks j nb cq l15
-    return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)                                       # cls chunk nb pos cq ks l15 j
-
-
-def pack_fold_wino_dgrad(w):
-    """Backward-data of the folded layer on conv_wino24_kernel (RAMNET_IN_PARITY4): Winograd weights of the FLIPPED parity filters
-    with the roles of the channels swapped — reduce over (parity class, output channel), produce input channels."""
-    Cout, Cin = w.shape[0], w.shape[1]
-    G = _const("W24_G", W24_G, w.device, torch.float64)
-    u = torch.einsum("at,bs,ncpqts->abpqnc", G, G, fold_weights(w).flip(4, 5)).reshape(1, 25, 4 * Cout, Cin).float()
-    u = u.view(1, 25, 4 * Cout // 16, 4, 4, Cin // 64, 4, 16)                   # cls pos chunk ks j nb cq l15
-    return u.permute(0, 2, 5, 1, 6, 3, 7, 4).contiguous().view(-1)
-
-
 def fold_weights(w):
     """OIHW 5x5 -> [O][I][py][px][ty][tx]: the 4x4 filter of every output parity, W4 = A_py w A_px^T (float64)."""
     A = _const("FOLD_A", FOLD_A, w.device, torch.float64)
     return torch.einsum("ptk,qsl,oikl->oipqts", A, A, w.double())
-
-
-def fold_unpack_torch(w4, dU, wr, wc, Cout, Cin, CinWs):
-    """Plain-torch statement of ramnet_fold_unpack_wgrad (the product path runs the kernel; tests compare the two): the OIHW 5x5 gradient
-    that the workspaces of a folded decoder's backward pass stand for."""
-    A = _const("FOLD_A", FOLD_A, w4.device, torch.float32)                        # [p][t][k]
-    d4 = w4.view(2, 2, 4, 4, CinWs, Cout)[:, :, :, :, :Cin]
-    if dU is not None:        # dW4 += G^T dU G
-        G = _const("W24_G", W24_G, w4.device, torch.float32)
-        d4 = d4 + torch.einsum("at,bs,pqabio->pqtsio", G, G, dU.view(2, 2, 5, 5, CinWs, Cout))[:, :, :, :, :Cin]
-    g = torch.einsum("ptk,qsl,pqtsio->oikl", A, A, d4).contiguous()
-    r = wr.view(2, 5, Cin, 2, Cout)          # [side][kx][ci][slot][co]
-    c = wc.view(2, 5, Cin, 2, Cout)          # [side][ky][ci][slot][co]
-    for side in range(2):
-        for slot in range(2):
-            for a in FOLD_LOST[side][slot]:
-                g[:, :, a, :].sub_(r[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][kx]
-                g[:, :, :, a].sub_(c[side, :, :, slot, :].permute(2, 1, 0))        # [co][ci][ky]
-    return g
-
-
-def border_matrices(w):
-    """(Wrows, Wcols), each [2 sides][5*Cin][2*Cout]: MINUS the sums of the taps the zero padding removes at the image border.
-    Rows: K index = (kx, ci), N index = (slot, co), lost direction ky; columns the same with ky <-> kx."""
-    Cout, Cin = w.shape[0], w.shape[1]
-
-    def mats(wk):                                                          # wk[co][ci][a][b]: `a` is the lost direction
-        out = []
-        for side in range(2):
-            slots = [-sum(wk[:, :, a, :] for a in FOLD_LOST[side][slot]) for slot in range(2)]          # [co][ci][b]
-            out.append(torch.stack(slots, 0).permute(3, 2, 0, 1).reshape(5 * Cin, 2 * Cout))              # [b][ci][slot][co]
-        return torch.stack(out, 0).contiguous()
-    return mats(w), mats(w.transpose(2, 3))
 
 
 # ---- stride-2 5x5 convolution == stride-1 3x3 convolution of the space-to-depth input (4*Cin channels): tap ky of the 5x5
@@ -754,7 +693,7 @@ class ConvParam:
         return hit[1]
 
     def _border_pack(self):
-        """(rows, cols, rows^T, cols^T) of the border matrices (border_matrices() is the plain-torch statement of the same; one launch of
+        """(rows, cols, rows^T, cols^T) of the border matrices (tests/torch_restatements.border_matrices is the plain-torch statement; one launch of
         ramnet_pack_border_weights), cached per parameter version."""
         v = (self._versions(self.weights), "border")
         hit = self._packs.get("border")

@@ -54,9 +54,30 @@ class FlatGradReducer:
             self._bucket_of[p] = next(i for i, (lo, hi) in enumerate(self.buckets) if lo <= off < hi)
             off += p.numel()
         self._issued, self._pending, self.early_buckets, self._armed = 0, None, 0, False
+        self._hooked = False
+        self.timing = False               # bench: bracket the collectives of a step with events on the side stream (span_ms())
+        self._t0 = self._t1 = None
+        self.issue_log = []               # (first bucket, one past the last) of every _issue() since the last zero(): the order buckets left in
         if overlap and self.cuda:
             from . import ops
+            prev = ops.get_finalize_hook()
+            if prev is not None and prev is not self:
+                import warnings
+                warnings.warn("FlatGradReducer: replacing the end-of-backward hook of another reducer (close() the old one first)")
             ops.set_finalize_hook(self)
+            self._hooked = True
+
+    def close(self):
+        """Detach from the end-of-backward fold (the process-global ops hook keeps the reducer, its flat buffer and the model alive
+        otherwise).  The hook is removed only if it still is this reducer; pending early buckets are waited for."""
+        if self._hooked:
+            from . import ops
+            if ops.get_finalize_hook() is self:
+                ops.set_finalize_hook(None)
+            self._hooked = False
+        if self.cuda and self._issued:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._issued, self._pending, self._armed = 0, None, False
 
     @property
     def world(self):
@@ -69,15 +90,24 @@ class FlatGradReducer:
                 p.grad = v
 
     def zero(self, arm=True):
-        """Start of a step: gradients to zero; arms the early issue for the ONE backward pass that follows (a second pass before
-        all_reduce() — gradient accumulation — finds it disarmed and everything leaves in all_reduce()).  arm=False: the pass that
-        follows is NOT a collective one (a rank computing something on its own): nothing may leave early."""
+        """Start of a step: gradients to zero; arms the early issue for the ONE backward pass that follows.  A further pass before
+        all_reduce() (gradient accumulation, two losses) is safe: the armed pass's early collectives are complete before anything later
+        on the stream runs (end()), and begin() of the unarmed pass schedules every bucket for reduction again — the early buckets hold
+        the rank AVERAGE of pass 1 on every rank, so averaging (that + the local gradients of pass 2) gives avg 1 + avg 2.  For
+        accumulation loops prefer zero(arm=False) and arm() right before the last backward: the overlap then goes to the pass that
+        completes the gradients.  arm=False: the pass that follows is NOT a collective one: nothing may leave early."""
         if self._issued:                  # buckets of a pass whose all_reduce() never came: let them finish before the buffer is reused
             torch.cuda.current_stream().wait_stream(self.side)
             self._issued, self._pending = 0, None
         self.flat.zero_()
         self.attach()
         self._armed = bool(arm)
+        self.issue_log = []
+        self._t0 = self._t1 = None
+
+    def arm(self):
+        """Arm the early issue for the NEXT backward pass (the last one of a gradient-accumulation step)."""
+        self._armed = True
 
     def all_reduce(self):
         """Average gradients over ranks; asynchronous on the side stream (wait() before the optimizer)."""
@@ -90,9 +120,13 @@ class FlatGradReducer:
             return
         if self.cuda:
             self._issue(len(self.buckets))
+            if self.timing:
+                self._t1 = torch.cuda.Event(enable_timing=True)
+                self._t1.record(self.side)
             self.done = self.side.record_event()
             self._issued, self._pending = 0, None
         else:
+            self.issue_log.append((0, len(self.buckets)))
             for lo, hi in self.buckets:
                 chunk = self.flat[lo:hi]
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
@@ -107,7 +141,11 @@ class FlatGradReducer:
             return
         w = self.world
         self.side.wait_event(torch.cuda.current_stream().record_event())
+        self.issue_log.append((self._issued, upto))
         with torch.cuda.stream(self.side):
+            if self.timing and self._t0 is None:
+                self._t0 = torch.cuda.Event(enable_timing=True)
+                self._t0.record()
             for lo, hi in self.buckets[self._issued:upto]:
                 chunk = self.flat[lo:hi]
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
@@ -117,8 +155,17 @@ class FlatGradReducer:
     # ---- ops.set_finalize_hook protocol (called by ops._Engine.flush at the end of a backward pass)
     def begin(self, dirty):
         self._pending = None
+        if not any(self._buckets_of(cp) for cp in dirty):      # a pass over another model: not this reducer's business
+            return
         armed, self._armed = self._armed, False
-        if not armed or self._issued or not self._collective():
+        if self._issued:
+            # a pass AFTER one that already sent buckets early (gradient accumulation with overlap): this pass's folds add local
+            # gradients into buckets that hold rank averages — every bucket is reduced again by all_reduce() (linear: avg1 + avg2);
+            # the collectives in flight are complete before the folds write (end() of the earlier pass made the stream wait)
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._issued = 0
+            return
+        if not armed or not self._collective():
             return
         for p, v in self.views.items():             # a .grad outside the flat buffer (set_to_none between steps): all_reduce() repairs it
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
@@ -140,12 +187,27 @@ class FlatGradReducer:
             self._pending[b] -= 1
         self._ready()
 
+    def end(self):
+        """End of the fold: everything enqueued on the stream afterwards (a second backward pass writing .grad directly — the
+        prediction layer's backward does —, the optimizer) is ordered behind the early collectives.  The overlap that matters, bucket
+        k's collective under the folds of the later layers, has happened by now."""
+        if self._issued:
+            torch.cuda.current_stream().wait_stream(self.side)
+
     def _ready(self):
         k = self._issued
         while k < len(self.buckets) and self._pending[k] == 0:
             k += 1
         self.early_buckets += k - self._issued
         self._issue(k)
+
+    def span_ms(self):
+        """timing=True: milliseconds on the side stream from the start of this step's first collective to the end of its last (after
+        a device synchronisation); includes the time the early buckets waited for later folds."""
+        if self._t0 is None or self._t1 is None:
+            return None
+        self._t1.synchronize()
+        return self._t0.elapsed_time(self._t1)
 
     def wait(self):
         if self.done is not None:

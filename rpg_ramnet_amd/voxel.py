@@ -47,6 +47,36 @@ def normalize_nonzero(grid):
     return out
 
 
+def pack_event_lists(event_lists, device):
+    """A batch of event lists -> (one [sum N, 4] float64 device tensor, int64 offsets [G + 1] on the device, the longest list): the form a
+    loader uploads once and events_to_voxel_grids_packed() consumes without a concatenation copy per call."""
+    device = torch.device(device)
+    evs = [_events(e, device) for e in event_lists]
+    counts = [int(e.shape[0]) for e in evs]
+    off = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int64).to(device)
+    cat = torch.cat(evs) if sum(counts) else None
+    return cat, off, max(counts)
+
+
+def events_to_voxel_grids_packed(cat, off, max_count, num_bins, width, height, out=None, normalize=False, scratch=None):
+    """events_to_voxel_grids() on lists that are already packed (pack_event_lists): ONE scatter-add launch + one batched nonzero
+    normalisation on the current stream, no allocation when `out` ([G, num_bins, height, width] fp32) and `scratch` (3 G doubles) are given
+    — the per-step form of an input pipeline that prepares the next step's grids on a side stream."""
+    G, n = int(off.shape[0]) - 1, num_bins * int(height) * int(width)
+    device = off.device
+    grids = out if out is not None else torch.empty(G, num_bins, int(height), int(width), device=device, dtype=torch.float32)
+    assert tuple(grids.shape) == (G, num_bins, int(height), int(width)) and grids.is_contiguous() and grids.dtype == torch.float32
+    L = H.lib()
+    H.check(L.ramnet_voxelize_batch(_p(cat), _p(off), G, int(max_count), num_bins, int(width), int(height), _p(grids), _st()),
+            "ramnet_voxelize_batch")
+    if normalize:
+        assert n % 4 == 0, "batched normalisation: bins * height * width must be a multiple of 4"
+        if scratch is None:
+            scratch = torch.empty(3 * G, device=device, dtype=torch.float64)
+        H.check(L.ramnet_normalize_nonzero_batch(_p(grids), G, n, _p(scratch), _st()), "ramnet_normalize_nonzero_batch")
+    return grids
+
+
 def events_to_voxel_grids(event_lists, num_bins, width, height, device=None, normalize=False):
     """A batch of event lists -> [G, num_bins, height, width] in ONE scatter-add launch (+ one batched nonzero normalisation):
     the B x K grids of a batch of data packages.  Per grid identical to events_to_voxel_grid / normalize_nonzero."""

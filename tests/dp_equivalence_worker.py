@@ -40,6 +40,8 @@ def main():
     mine = shard_indices(n_seq, rank, world)
     if "--exact" in sys.argv:
         return exact_mode(model, red, cfg, batch, mine, n_seq, rank, world)
+    if "--accum" in sys.argv:
+        return accum_mode(model, red, cfg, batch, mine, rank)
     own = local_grads(mine)
     assert all(p.grad.data_ptr() == red.views[p].data_ptr() for p in model.parameters())
     red.all_reduce()
@@ -109,6 +111,41 @@ def exact_mode(model, red, cfg, batch, mine, n_seq, rank, world):
                           "ddp_vs_single_rank_concat": float((ddp - single).abs().max()) / scale,
                           "err_vs_oracle_concat": worst, "n": int(avg.numel()), "early_buckets": red.early_buckets,
                           "buckets": len(red.buckets)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def accum_mode(model, red, cfg, batch, mine, rank):
+    """two backward passes per optimizer step with the early bucket issue on.  The armed first pass sends buckets from the
+    fold; the second pass must neither race with them nor leave its share of those buckets un-reduced."""
+    from rpg_ramnet_amd.trainer import sequence_loss
+    lc = cfg["loss_composition"]
+    halves = [mine[:len(mine) // 2], mine[len(mine) // 2:]]
+
+    def run(arm_first, arm_last):
+        red.zero(arm=arm_first)
+        for j, idx in enumerate(halves):
+            if arm_last and j == len(halves) - 1:
+                red.arm()
+            total, _ = sequence_loss(model, batch(idx), lc, [1, 1])
+            total.backward()
+        red.all_reduce()
+        red.wait()
+        torch.cuda.synchronize()
+        return red.flat.clone()
+
+    e0 = red.early_buckets
+    got_first = run(True, False)          # zero() arms the FIRST pass (the pattern the advisor flagged)
+    e1 = red.early_buckets
+    got_last = run(False, True)           # the recommended form: arm() right before the last pass
+    e2 = red.early_buckets
+    want = run(False, False)              # nothing leaves early
+    e3 = red.early_buckets
+    if rank == 0:
+        scale = float(want.abs().max())
+        print(json.dumps({"err_armed_first": float((got_first - want).abs().max()) / scale,
+                          "err_armed_last": float((got_last - want).abs().max()) / scale,
+                          "early": [e1 - e0, e2 - e1, e3 - e2], "gmax": scale}))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from util import load_golden, ref_cfg
+import torch_restatements as tr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -205,6 +206,105 @@ def test_data_parallel_gradient_average_gloo_world2():
     np.testing.assert_allclose(res[0][2], ((grads[0] + grads[1]) / 2).numpy(), rtol=1e-5, atol=1e-8)
 
 
+def _dp8_worker(rank, world, port, q):
+    """World-8 readiness, everything a node run relies on that does not need a device."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import loss_ref
+    from rpg_ramnet_amd.data import ShardedSequenceSampler
+    from rpg_ramnet_amd.parallel import FlatGradReducer, shard_indices
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 4, 3), torch.nn.Conv2d(4, 1, 1))
+    red = FlatGradReducer(net, num_buckets=3)
+    sent = []
+    real = dist.all_reduce
+
+    def spy(t, *a, **kw):                                # the order in which collectives leave this rank (sizes identify the buckets)
+        sent.append(int(t.numel()))
+        return real(t, *a, **kw)
+    dist.all_reduce = spy
+    n_seq = 67                                           # not a multiple of 8: the tail is dropped, every rank runs the same number of steps
+    mine = shard_indices(n_seq, rank, world)
+    samp = ShardedSequenceSampler(list(range(n_seq)), rank, world, shuffle=True, seed=3, batch_size=2)
+    samp.set_epoch(5)
+    picked = list(samp)
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(n_seq, 3, 8, 8, generator=g)
+    target = torch.rand(n_seq, 1, 4, 4, generator=g)
+    target[target < 0.1] = float("nan")                  # invalid pixels: the valid count differs between ranks
+    # two backward passes per step (gradient accumulation), then ONE bucketed all-reduce
+    red.zero()
+    half = len(mine) // 2
+    for idx in (mine[:half], mine[half:]):
+        pred = torch.sigmoid(net(data[idx]))
+        loss_ref.scale_invariant_loss(pred, target[idx]).backward()
+    red.all_reduce()
+    red.wait()
+    # exact global-batch SI loss (trainer._sequence_loss_dp_exact's protocol): (sum d, sum d^2, n) all-reduced, loss from the global sums
+    with torch.no_grad():
+        pred = torch.sigmoid(net(data[mine]))
+        d = (pred - target[mine]).double()
+        ok = ~torch.isnan(d)
+        table = torch.tensor([[float(d[ok].sum()), float((d[ok] ** 2).sum()), float(ok.sum()), 0.0]], dtype=torch.float64)
+    dist.all_reduce = real
+    dist.all_reduce(table)
+    S1, S2, n = (float(v) for v in table[0, :3])
+    q.put((rank, mine, picked, len(samp), sent, list(red.issue_log), red.flat.clone().numpy(), S2 / n - (S1 / n) ** 2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_world8_gloo():
+    """SURVEY 8e at the world size of the node (8 ranks over gloo): rank r owns sequences r, r + 8, ...; the sharded sampler gives all
+    ranks the same number of steps over disjoint items; every rank sends the same buckets in the same order; the bucketed all-reduce
+    after TWO backward passes (gradient accumulation) is the mean over ranks of the accumulated gradients; the exact-loss table
+    reproduces the single-process loss of the concatenated 8-shard batch (invalid pixels included)."""
+    import torch.multiprocessing as mp
+    from oracle import loss_ref
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_seq = 67
+    for r, (rank, mine, picked, nsteps, sent, log, flat, loss) in enumerate(res):
+        assert rank == r and mine == list(range(r, n_seq, world))
+        assert nsteps == res[0][3] == (n_seq // (world * 2)) * 2 and len(picked) == nsteps
+        assert sent == res[0][4] and len(sent) >= 2 and log == res[0][5] == [(0, len(sent))]        # same buckets, same order, on every rank
+        np.testing.assert_allclose(flat, res[0][6], rtol=1e-6, atol=1e-9)                    # every rank holds the same average
+        assert loss == res[0][7]
+    allp = [i for t in res for i in t[2]]
+    assert len(set(allp)) == len(allp)                                                       # the sampler's shards are disjoint
+    # reference: ONE process — mean over the ranks of each rank's two accumulated passes; loss on the concatenated batch
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Conv2d(4, 4, 3), torch.nn.Conv2d(4, 1, 1))
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(n_seq, 3, 8, 8, generator=g)
+    target = torch.rand(n_seq, 1, 4, 4, generator=g)
+    target[target < 0.1] = float("nan")
+    acc = None
+    for r in range(world):
+        mine = list(range(r, n_seq, world))
+        half = len(mine) // 2
+        net.zero_grad()
+        for idx in (mine[:half], mine[half:]):
+            loss_ref.scale_invariant_loss(torch.sigmoid(net(data[idx])), target[idx]).backward()
+        gr = torch.cat([p.grad.flatten() for p in reversed(list(net.parameters()))])
+        acc = gr.clone() if acc is None else acc + gr
+    np.testing.assert_allclose(res[0][6], (acc / world).numpy(), rtol=2e-5, atol=1e-8)
+    with torch.no_grad():
+        order = [i for r in range(world) for i in range(r, n_seq, world)]
+        want = float(loss_ref.scale_invariant_loss(torch.sigmoid(net(data[order])).double(), target[order].double()))
+    assert abs(res[0][7] - want) < 1e-9 * max(1.0, abs(want))
+
+
 def test_crop_parameters_match_the_reference():
     """Full-frame helper: ops.CropParameters reproduces every field of the reference's CropParameters (utils/inference_utils.py:287-314;
     fixture produced by the reference class itself) — the raw DAVIS frame 260 x 346 -> 264 x 352 with a (2, 2, 3, 3) reflection border
@@ -397,7 +497,7 @@ def test_cabi_argument_errors_and_host_only_entry_points():
 
 def test_folded_upsample_conv_algebra_cpu():
     """conv5x5_zero_padded(bilinear_x2(x)) == four 4x4 parity convolutions of the replicate-padded input (ops.fold_weights)
-    + the border GEMMs (ops.border_matrices): the factorisation the HIP path runs, checked in float64 with torch ops only."""
+    + the border GEMMs (tr.border_matrices): the factorisation the HIP path runs, checked in float64 with torch ops only."""
     import torch.nn.functional as F
     from rpg_ramnet_amd import ops
     torch.manual_seed(0)
@@ -415,7 +515,7 @@ def test_folded_upsample_conv_algebra_cpu():
             y[:, :, py::2, px::2] = full[:, :, py:py + H, px:px + W]   # tap t reads padded row i + py + t
     H2, W2 = 2 * H, 2 * W
     assert torch.allclose(y[:, :, 2:H2 - 2, 2:W2 - 2], ref[:, :, 2:H2 - 2, 2:W2 - 2], atol=1e-12)          # interior: exact as is
-    wr, wc = ops.border_matrices(w)
+    wr, wc = tr.border_matrices(w)
     idx = torch.arange(W2)
     for side, row in enumerate((0, H2 - 1)):                          # rows: A[(b, ox)][(kx, ci)] = u[row][clamp(ox + kx - 2)]
         A = torch.stack([u[:, :, row, (idx + kx - 2).clamp(0, W2 - 1)] for kx in range(5)], 1)              # [B][5][Cin][W2]
@@ -490,7 +590,7 @@ def test_space_to_depth_weight_maps_cpu():
 
 
 def test_winograd_f2x2_4x4_algebra_cpu():
-    """The matrices of csrc/conv_wino24.hip / ops.fold_weights_wino: Y = A^T[(G g G^T) .* (B^T d B)]A equals the 4x4 stride-1
+    """The matrices of csrc/conv_wino24.hip / tr.fold_weights_wino: Y = A^T[(G g G^T) .* (B^T d B)]A equals the 4x4 stride-1
     correlation of every parity class of the folded upsample-conv, and the four classes together equal the 5x5 convolution of the
     bilinear upsample away from the border."""
     import torch.nn.functional as F
@@ -500,9 +600,9 @@ def test_winograd_f2x2_4x4_algebra_cpu():
     w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64)
     x = torch.randn(1, Cin, Hh, W, dtype=torch.float64)
     xpad = F.pad(x, (2, 2, 2, 2), mode="replicate")
-    U = ops.fold_weights_wino(w)                                   # [4][25][Cin][Cout]
-    BT = torch.tensor(ops.W24_BT, dtype=torch.float64)
-    AT = torch.tensor(ops.W24_AT, dtype=torch.float64)
+    U = tr.fold_weights_wino(w)                                   # [4][25][Cin][Cout]
+    BT = torch.tensor(tr.W24_BT, dtype=torch.float64)
+    AT = torch.tensor(tr.W24_AT, dtype=torch.float64)
     W4 = ops.fold_weights(w)                                       # [O][I][py][px][4][4]
     up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
     ref = F.conv2d(up, w, None, 1, 2)
@@ -522,18 +622,18 @@ def test_winograd_f2x2_4x4_algebra_cpu():
     assert torch.allclose(y[:, :, 2:-2, 2:-2], ref[:, :, 2:-2, 2:-2], atol=1e-10)
     # packed layout: element (cls, pos, k, n) sits where include/ramnet_hip.h says
     w2 = torch.randn(64, 32, 5, 5)
-    packed, U2 = ops.pack_fold_wino(w2), ops.fold_weights_wino(w2).float()
+    packed, U2 = tr.pack_fold_wino(w2), tr.fold_weights_wino(w2).float()
     for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 31, 63), (2, 7, 21, 37), (1, 13, 6, 50)]:
         idx = ((((cls * 2 + k // 16) * 1 + n // 64) * 25 + pos) * 4 + (n % 64) // 16) * 256 + (((k % 16) // 4) * 16 + n % 16) * 4 + k % 4
         assert packed[idx] == U2[cls, pos, k, n]
     w4 = torch.randn(32, 64, 5, 5)                                 # 32-channel layer, Cin % 32 == 0: pair layout — class = row parity,
-    packed, U4 = ops.pack_fold_wino(w4), ops.fold_weights_wino(w4).float()      # column = (column parity, channel), chunks of 16
+    packed, U4 = tr.pack_fold_wino(w4), tr.fold_weights_wino(w4).float()      # column = (column parity, channel), chunks of 16
     for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 63, 31), (2, 7, 21, 17), (1, 13, 38, 5)]:
         py, col = cls >> 1, (cls & 1) * 32 + n
         idx = (((py * 4 + k // 16) * 25 + pos) * 4 + col // 16) * 256 + (((k % 16) // 4) * 16 + col % 16) * 4 + k % 4
         assert packed[idx] == U4[cls, pos, k, n]
     w3 = torch.randn(32, 24, 5, 5)                                 # 32-channel layers: chunks of 8, two 16-channel groups
-    packed, U3 = ops.pack_fold_wino(w3), ops.fold_weights_wino(w3).float()
+    packed, U3 = tr.pack_fold_wino(w3), tr.fold_weights_wino(w3).float()
     for cls, pos, k, n in [(0, 0, 0, 0), (3, 24, 23, 31), (2, 7, 13, 17)]:
         idx = ((((cls * 3 + k // 8) * 1 + n // 32) * 25 + pos) * 2 + (n % 32) // 16) * 128 + (((k % 8) // 2) * 16 + n % 16) * 2 + k % 2
         assert packed[idx] == U3[cls, pos, k, n]

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from rpg_ramnet_amd import _hip
+import torch_restatements as tr
 
 pytestmark = pytest.mark.gpu
 
@@ -301,7 +302,7 @@ def test_folded_upsample_conv_winograd_through_raw_descriptors(Cin, Cout):
     assert L.ramnet_fold_wino_supported(Cout, Cin) == 1 and L.ramnet_fold_wino_supported(48, Cin) == 0
     wp = torch.empty(L.ramnet_packed_weight_elems_fold_wino(Cout, Cin), device=dev)
     assert L.ramnet_pack_weight_fold_wino(ptr(w), ptr(wp), Cout, Cin, st) == 0
-    assert float((wp - ops.pack_fold_wino(w)).abs().max()) < 1e-6
+    assert float((wp - tr.pack_fold_wino(w)).abs().max()) < 1e-6
     xpad = torch.empty(B, H + 4, W + 4, Cin, device=dev)
     assert L.ramnet_pad2_sum(ptr(x), None, ptr(xpad), B, H, W, Cin, st) == 0
     y = torch.zeros(B, 2 * H, 2 * W, Cout, device=dev)
@@ -330,7 +331,7 @@ def test_folded_upsample_conv_winograd_through_raw_descriptors(Cin, Cout):
     g.dout, g.ldg, g.Cout, g.Ho, g.Wo, g.HoG, g.WoG = ptr(dy), Cout, Cout, H, W, 2 * H, 2 * W
     g.dw, g.dbias, g.algo = ptr(ws), ptr(dbias), _hip.ALGO_WINOGRAD24
     assert L.ramnet_wgrad_launch(C.byref(g), st) == 0, L.ramnet_last_error()
-    G = torch.tensor(ops.W24_G, dtype=torch.float64)
+    G = torch.tensor(tr.W24_G, dtype=torch.float64)
     d4 = torch.einsum("at,bs,pqabio->pqtsio", G, G, ws.view(2, 2, 5, 5, Cin, Cout).cpu().double())
     xp = xpad.permute(0, 3, 1, 2).cpu().double()
     dyr = dy.permute(0, 3, 1, 2).cpu().double()

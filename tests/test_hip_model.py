@@ -447,6 +447,53 @@ def test_data_parallel_exact_global_batch_loss(overlap):
     assert (out["early_buckets"] > 0) == overlap and out["buckets"] >= 2, out
 
 
+def test_data_parallel_gradient_accumulation_with_early_buckets():
+    """zero() -> backward() -> backward() -> all_reduce() with the overlapped reducer.  The first (armed) pass sends
+    buckets from the end-of-backward fold; the second pass adds its gradients into buckets that already hold rank averages and every
+    bucket is reduced again (linear: avg 1 + avg 2) — the result equals the run in which nothing leaves early, also with arm() called
+    right before the last pass."""
+    import json as js
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29200 + os.getpid() % 90), os.path.join(root, "tests", "dp_equivalence_worker.py"), "--accum", "--overlap"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = js.loads(lines[0])
+    assert out["gmax"] > 0 and out["early"][0] > 0 and out["early"][1] > 0 and out["early"][2] == 0, out
+    assert out["err_armed_first"] < 1e-4 and out["err_armed_last"] < 1e-4, out           # atomic order only
+
+
+def test_bench_eight_ranks_on_one_device():
+    """the driver's 8-GPU command `python bench.py --gpus 8` at a tiny shape with the 8 ranks sharing this box's one
+    device (collectives over gloo, declared): all 8 ranks report in, the line carries the per-rank step times and the span of every
+    rank's gradient all-reduce, and with --dp-exact-loss every rank trains on the global-batch loss."""
+    import json as js
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--height", "32", "--width", "48",
+           "--batch", "1", "--seq-len", "2", "--events-per-grid", "2000", "--no-cpu-baseline", "--no-extras", "--dp-exact-loss"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    out = js.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks_seen"] == list(range(8)) and out["config"]["global_batch"] == 8
+    assert out["backend"].startswith("gloo") and "exact global batch" in out["loss_semantics"]
+    pr = out["per_rank"]
+    assert len(pr["step_ms"]) == 8 and pr["step_ms_min"] > 0 and pr["step_ms_max"] >= pr["step_ms_min"]
+    assert len(pr["grad_allreduce_span_ms_last_step"]) == 8 and all(v is not None and v > 0 for v in pr["grad_allreduce_span_ms_last_step"])
+    ga = out["grad_allreduce"]
+    assert ga["buckets"] >= 2 and ga["buckets_issued_during_the_fold"] >= 1
+    assert out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
 def test_bench_plain_command_self_launches_two_ranks():
     """`python bench.py --gpus 2` the way the driver types it — no torch.distributed.run, no WORLD_SIZE in the
     environment — starts its two ranks itself.  On this 1-GPU box both ranks share cuda:0 and the collectives go over gloo (RCCL

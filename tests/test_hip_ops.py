@@ -8,6 +8,7 @@ import torch
 from oracle import loss_ref, ramnet_ref, voxel_ref
 from rpg_ramnet_amd import _hip as Hh
 from util import assert_close, load_golden, nchw, nhwc
+import torch_restatements as tr
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4   # exact-fp32 MFMA vs PyTorch CPU; summation order differs
@@ -140,18 +141,18 @@ def test_upsample_conv(B, H, W, cin, cout, skip, upsample_algo):
 def test_fold_weight_algebra_kernels_equal_their_torch_statements(cin, cout):
     """The folded decoder's once-per-step weight algebra runs as library kernels since round 4 (torch.einsum chains
     before): backward-data Winograd pack, border matrices (+ transposes), and the fold of the pass's gradient workspaces into the 5x5
-    `.grad` — each against the plain-torch statement it replaced (ops.pack_fold_wino_dgrad / border_matrices / fold_unpack_torch)."""
+    `.grad` — each against the plain-torch statement it replaced (tr.pack_fold_wino_dgrad / border_matrices / fold_unpack_torch)."""
     from rpg_ramnet_amd import ops
     torch.manual_seed(3)
     w = (torch.randn(cout, cin, 5, 5) * 0.1).to(dev())
     L = Hh.lib()
     out = torch.empty(100 * cout * cin, device=dev())
     Hh.check(L.ramnet_pack_weight_fold_wino_dgrad(ops._p(w), ops._p(out), cout, cin, ops._st()), "pack dgrad")
-    assert_close(out.cpu().numpy(), ops.pack_fold_wino_dgrad(w).cpu().numpy(), 1e-6, "fold dgrad pack")
+    assert_close(out.cpu().numpy(), tr.pack_fold_wino_dgrad(w).cpu().numpy(), 1e-6, "fold dgrad pack")
     rows, cols = (torch.empty(2, 5 * cin, 2 * cout, device=dev()) for _ in range(2))
     rows_t, cols_t = (torch.empty(2, 2 * cout, 5 * cin, device=dev()) for _ in range(2))
     Hh.check(L.ramnet_pack_border_weights(ops._p(w), ops._p(rows), ops._p(cols), ops._p(rows_t), ops._p(cols_t), cout, cin, ops._st()), "border")
-    r_ref, c_ref = ops.border_matrices(w)
+    r_ref, c_ref = tr.border_matrices(w)
     assert_close(rows.cpu().numpy(), r_ref.cpu().numpy(), 1e-6, "border rows")
     assert_close(cols.cpu().numpy(), c_ref.cpu().numpy(), 1e-6, "border cols")
     assert torch.equal(rows_t, rows.transpose(1, 2)) and torch.equal(cols_t, cols.transpose(1, 2))
@@ -159,7 +160,7 @@ def test_fold_weight_algebra_kernels_equal_their_torch_statements(cin, cout):
     dU = torch.randn(100 * cin * cout, device=dev())
     wr, wc = torch.randn(2, 5 * cin, 2 * cout, device=dev()), torch.randn(2, 5 * cin, 2 * cout, device=dev())
     for use_du in (True, False):
-        ref = ops.fold_unpack_torch(w4, dU if use_du else None, wr, wc, cout, cin, cin)
+        ref = tr.fold_unpack_torch(w4, dU if use_du else None, wr, wc, cout, cin, cin)
         g = torch.full((cout, cin, 5, 5), 0.5, device=dev())
         a4, aU, ar, ac = w4.clone(), dU.clone(), wr.clone(), wc.clone()
         Hh.check(L.ramnet_fold_unpack_wgrad(ops._p(a4), ops._p(aU) if use_du else None, ops._p(ar), ops._p(ac), ops._p(g), cout, cin, cin, ops._st()), "unfold")
