@@ -95,6 +95,12 @@ def parse():
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384; default 320)")
     ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
+    ap.add_argument("--wgrad-defer", type=int, default=-1, help="ConvGRU cell updates per deferred multi-segment backward-weights launch "
+                    "(ops.set_wgrad_defer; 0 = every update launches its own; default: the trainer's)")
+    ap.add_argument("--resident-inputs", action="store_true",
+                    help="train: time the step on input tensors that are already resident in HBM (the definition of `value` up to round 4) "
+                         "instead of the default, which voxelises fresh event lists and uploads frames / targets every step beside the compute "
+                         "(InputSide); the default line carries the resident-input number as extras.resident_inputs")
     ap.add_argument("--graph", action="store_true",
                     help="train: the timed step replays ONE hipGraph (gradient zero-fill, forward, loss, BPTT backward, gradient fold; "
                          "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
@@ -121,9 +127,10 @@ def configs4_measure():
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
 
-def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
+def synth_sequence(model, B, L, H, W, K, bins, n_events, seed, keep_events=None):
     """SURVEY section 8d recipe, generated on device; returns a list of L item dicts (NCHW device tensors).  The B x K event
-    lists of a package go through ONE batched scatter-add launch and one batched nonzero normalisation."""
+    lists of a package go through ONE batched scatter-add launch and one batched nonzero normalisation.  keep_events: a list that
+    receives the packed event lists of every package (voxel.pack_event_lists) — the raw input of the per-step input pipeline."""
     from rpg_ramnet_amd import voxel
     dev = model.gpu
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -137,7 +144,12 @@ def synth_sequence(model, B, L, H, W, K, bins, n_events, seed):
             ev[:, 2] = torch.randint(0, H, (n_events,), device=dev, generator=g).double()
             ev[:, 3] = torch.randint(0, 2, (n_events,), device=dev, generator=g).double()
             lists.append(ev)
-        grids = voxel.events_to_voxel_grids(lists, bins, W, H, dev, normalize=True).view(K, B, bins, H, W)
+        if keep_events is not None:
+            packed = voxel.pack_event_lists(lists, dev)
+            keep_events.append(packed)
+            grids = voxel.events_to_voxel_grids_packed(*packed, bins, W, H, normalize=True).view(K, B, bins, H, W)
+        else:
+            grids = voxel.events_to_voxel_grids(lists, bins, W, H, dev, normalize=True).view(K, B, bins, H, W)
         for k in range(K):
             item["events%d" % k] = grids[k]
         item["image"] = torch.rand(B, 1, H, W, device=dev, generator=g)
@@ -228,7 +240,7 @@ class KernelTimer:
 
         def sig_of(kind, x0, taps, Cout, kw):
             return (kind, tuple(x0.shape), id(taps), Cout) + tuple(kw.get(k) if not torch.is_tensor(kw.get(k)) else 1 for k in
-                                                                  ("stride", "in_mode", "C0", "C1", "epi", "Ho", "Wo", "wino24", "out_s2d", "beta", "frame", "gview"))
+                                                                  ("stride", "in_mode", "C0", "C1", "epi", "Ho", "Wo", "wino24", "out_s2d", "beta", "frame", "gview")) + (len(kw["segs"]) if kw.get("segs") is not None else 0,)
 
         def conv_bytes(x0, taps, Cout, kw, cin, Ho, Wo, nout, nclass):
             """Operand bytes of one forward / backward-data launch: every input, mask and epilogue operand read once, every
@@ -273,10 +285,11 @@ class KernelTimer:
             ho, wo = kw.get("Ho") or dout.shape[1], kw.get("Wo") or dout.shape[2]     # (parity sub-grid of a folded decoder)
             nclass = 4 if kw.get("wino24") else 1
             cin = getattr(dw, "head_cin", 0) or cin_of(x0, kw)
-            alg = 2.0 * nclass * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout
+            nseg = len(kw["segs"]) if kw.get("segs") is not None else 1       # a multi-segment launch covers nseg launches' tensors
+            alg = 2.0 * nclass * nseg * dout.shape[0] * ho * wo * taps.flop_taps * cin * Cout
             # operand bytes of a backward-weights launch: input (+ its mask / product operand) and output gradient (+ ReLU mask) read once,
             # the gradient workspace — [16] (Winograd), [taps] (direct) or [4][25] (folded decoder) x Cin x Cout — read and written once
-            px_in, px_out = x0.shape[0] * x0.shape[1] * x0.shape[2], dout.shape[0] * ho * wo * nclass
+            px_in, px_out = nseg * x0.shape[0] * x0.shape[1] * x0.shape[2], nseg * dout.shape[0] * ho * wo * nclass
             mode, c1 = kw.get("in_mode", 0), kw.get("C1", 0)
             rd = px_in * ((kw.get("C0") or x0.shape[3]) + c1) * (2 if mode == Hh.IN_RELUMASK else 1) + (px_in * c1 if mode == Hh.IN_CAT_MUL else 0)
             rd += px_out * Cout * (2 if kw.get("gmask") is not None else 1)
@@ -571,6 +584,72 @@ def input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank, n=2):
                     (L, K * B, n_ev, L * B, 2 * L * B)}
 
 
+class InputSide:
+    """The input side of a training step INSIDE the timed loop (reference: utils/event_tensor_utils.py:120-187,
+    data_loader/dataset.py:254-415): per step, the L x (B*K) event lists of the NEXT step's sequences — resident in HBM, as the loader's
+    raw `*_events.npy` are after their upload; two alternating sets — go through L batched voxel scatter-adds + L batched nonzero
+    normalisations on an input stream of their own, and the frames / target maps of the next step come up from pinned host memory on a copy
+    stream (data.DevicePrefetcher), all beside the compute of the current step; the step then trains on tensors that did not exist one step
+    earlier.  Grid buffers alternate between two sets: set p is rewritten only after the step that read it has finished (event wait)."""
+
+    def __init__(self, model, seq, events_a, events_b, K, B, bins, H, W):
+        from rpg_ramnet_amd.data import DevicePrefetcher
+        self.dev, self.K, self.B, self.bins, self.H, self.W, self.L = model.gpu, K, B, bins, H, W, len(seq)
+        self.events = [events_a, events_b]
+        # the input stream at the LOWEST priority the device offers: its workgroups (up to 160 KB of LDS each) should take the CUs the three
+        # compute streams leave idle, not displace their workgroups
+        try:
+            prio = int(os.environ.get("RAMNET_INPUT_PRIORITY", max(torch.cuda.Stream.priority_range())))
+        except Exception:      # noqa: BLE001
+            prio = 0
+        self.priority = prio
+        self.stream = torch.cuda.Stream(device=self.dev, priority=prio)
+        self.grids = [[torch.empty(K * B, bins, H, W, device=self.dev) for _ in range(self.L)] for _ in range(2)]
+        self.scratch = [[torch.empty(3 * K * B, device=self.dev, dtype=torch.float64) for _ in range(self.L)] for _ in range(2)]
+        self.ready, self.free = [None, None], [None, None]
+        self.static = [{k: v for k, v in item.items() if not k.startswith("events")} for item in seq]
+        host = [{k: v.cpu().pin_memory() for k, v in item.items()} for item in self.static]
+
+        def host_sequences():               # the loader's side: the same pinned host sequence over and over
+            while True:
+                yield host
+        self.uploads = iter(DevicePrefetcher(host_sequences(), self.dev))
+        self.n = 0
+        self.prepare(0)
+
+    def prepare(self, p):
+        """Enqueue the voxelisation of one step's inputs into grid set p on the input stream."""
+        from rpg_ramnet_amd import voxel
+        if self.free[p] is not None:
+            self.stream.wait_event(self.free[p])
+        with torch.cuda.stream(self.stream):
+            for l in range(self.L):
+                voxel.events_to_voxel_grids_packed(*self.events[p][l], self.bins, self.W, self.H, out=self.grids[p][l], normalize=True,
+                                                   scratch=self.scratch[p][l])
+            self.ready[p] = self.stream.record_event()
+
+    def next_sequence(self):
+        """The sequence of this step (grids of set p, fresh uploads of frames / targets); starts the next step's input work."""
+        p = self.n & 1
+        self.n += 1
+        torch.cuda.current_stream().wait_event(self.ready[p])
+        frames = next(self.uploads)
+        seq = []
+        for l in range(self.L):
+            item = dict(frames[l])
+            g = self.grids[p][l].view(self.K, self.B, self.bins, self.H, self.W)
+            for k in range(self.K):
+                item["events%d" % k] = g[k]
+            seq.append(item)
+        self.prepare(p ^ 1)
+        self._cur = p
+        return seq
+
+    def done(self):
+        """The step that read the current grid set has been enqueued completely: the set may be rewritten behind it."""
+        self.free[self._cur] = torch.cuda.current_stream().record_event()
+
+
 class ClockSampler:
     """Best-effort effective shader clock during the timed region: a background thread polls `rocm-smi --showclocks
     --json` and keeps the sclk readings; the roofline keeps the 2.4 GHz spec peak, `clock_ghz` says what the chip really ran at
@@ -693,6 +772,8 @@ def main():
     ops.set_wgrad_slabs(not args.wgrad_atomic)
     ops.set_wgrad_winograd_2x4(args.wgrad_2x4)
     ops.set_gru_bwd_fused(not args.no_gru_bwd_fused)
+    if args.wgrad_defer >= 0:
+        ops.set_wgrad_defer(args.wgrad_defer)
     ops.set_time_batching(not args.no_time_batching, max_decodes=args.time_batch_max_decodes)
     if args.wgrad_wino_nf:
         Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_nf", args.wgrad_wino_nf), "set_option")
@@ -720,10 +801,18 @@ def main():
     synth_sequence(model, B, 1, H, W, K, bins, args.events_per_grid, seed=999)      # untimed: the library allocates its sort scratch on first use
     torch.cuda.synchronize()
     timer.on = timer.hbm = not args.no_kernel_timing
-    seq = synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=1000 + rank)
+    want_input_side = args.mode == "train" and not args.resident_inputs and not args.graph
+    events_a = [] if want_input_side else None
+    seq = synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=1000 + rank, keep_events=events_a)
     torch.cuda.synchronize()
     vox = timer.summary().get("ramnet_voxelize_batch")
     timer.rec, timer.on, timer.hbm = [], False, False
+    inp, use_inp = None, {"on": want_input_side}
+    if want_input_side:
+        events_b = []
+        synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=5000 + rank, keep_events=events_b)
+        inp = InputSide(model, seq, events_a, events_b, K, B, bins, H, W)
+        torch.cuda.synchronize()
 
     ranks_seen = [0]
     if world > 1 or args.force_collective:      # every rank reports in over the collective backend: the driver's SCALE run can confirm N ranks took part
@@ -741,9 +830,13 @@ def main():
         opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=0, fused=True)
 
         def step():
+            live = inp is not None and use_inp["on"]
+            s_ = inp.next_sequence() if live else seq         # (live: grids voxelised / frames uploaded beside the previous step)
             reducer.zero()
-            total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1], dp_exact=args.dp_exact_loss)
+            total, _ = sequence_loss(model, s_, cfg["loss_composition"], [1, 1], dp_exact=args.dp_exact_loss)
             total.backward()
+            if live:
+                inp.done()
             reducer.all_reduce()
             reducer.wait()
             opt.step()
@@ -903,6 +996,7 @@ def main():
     if not args.no_extras and args.mode == "train" and world == 1 and (args.overlap_wgrad or args.overlap_decoder):
         ops.set_wgrad_overlap(False)
         ops.set_decoder_overlap(False)
+        use_inp["on"] = False                 # (ONE stream: inputs resident, no input stream beside it)
         step()
         fence()
         timer.only, only = None, timer.only
@@ -926,6 +1020,7 @@ def main():
                 "algorithmic_achieved": iso[2] / iso[1] / 1e12}
         ops.set_wgrad_overlap(args.overlap_wgrad)
         ops.set_decoder_overlap(args.overlap_decoder)
+        use_inp["on"] = want_input_side
 
     def measure(fn, n=2):
         fn()
@@ -951,10 +1046,16 @@ def main():
                 extras["graph_two_stage"] = dict(measure(graphed["graph_two_stage"]), note="decode of update k on a second stream beside "
                                                  "update k+1 (graph.GraphedStream pipelined, the round-2 runtime)")
         elif args.mode == "train" and not args.graph:
-            try:
-                extras["with_input_side"] = input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank)
-            except Exception as ex:     # noqa: BLE001
-                extras["with_input_side"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            if inp is not None:          # the definition of `value` up to round 4: the same step on tensors resident in HBM
+                use_inp["on"] = False
+                extras["resident_inputs"] = dict(measure(step, n=3), note="the step on input tensors already resident in HBM (no voxelisation, "
+                                                 "no uploads in the loop): `value` of rounds 1-4; `value` now includes the input side")
+                use_inp["on"] = True
+            else:
+                try:
+                    extras["with_input_side"] = input_side_measure(model, step, seq, args, K, bins, B, L, H, W, rank)
+                except Exception as ex:     # noqa: BLE001
+                    extras["with_input_side"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             try:
                 extras["stream_b1"] = stream_b1_measure(model, seq, K, H, W, timer)
             except Exception as ex:     # noqa: BLE001
@@ -994,6 +1095,10 @@ def main():
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
+               "input_side": ("in the timed loop: per step %d batched voxel scatter-adds of %d fresh on-device event lists (%d events each) + nonzero "
+                              "normalisation on an input stream, H2D of %d frames + %d target maps from pinned memory on a copy stream, both beside the "
+                              "previous step's compute (bench.InputSide)" % (L, K * B, args.events_per_grid, L * B, 2 * L * B)) if (inp is not None) else
+                             "resident: the step's input tensors are in HBM before the timed region",
                "config": {"workload": "EventScape-shaped %s, %d event bins, K=5, batch %d/GPU, seq-len %d, "
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam, backward-weights %s"
                                       % (("346x260 -> 256x344 crop" if (H, W) == (256, 344) else geom), bins, B, L, args.mode, args.state, "co-scheduled on a side stream" if args.overlap_wgrad else "on the main stream") +

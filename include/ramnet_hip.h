@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 19      /* 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 20      /* 20: ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -122,6 +122,14 @@ typedef struct ramnet_conv_desc {
 /* Weight-gradient launch: dW[t][c][n] += sum_{b,a,b'} in(a*stride+dy[t], b'*stride+dx[t], c) * g(a,b',n)
  * where g = dout (optionally * (gmask > 0)).  Accumulates (atomically) into a [ntaps][Cin][Cout] fp32
  * workspace and, when dbias != NULL, sum_pixels g into dbias[Cout].                               */
+/* One segment of a multi-segment backward-weights launch (ABI 20): the tensors of ONE of several launches of the same layer whose
+ * weight gradients are accumulated in a single launch — the K deferred ConvGRU cell updates of a data package (submodules.py:436-454:
+ * the same three convolutions at every update).  Shapes, leading dimensions, channel counts and modes are the descriptor's. */
+#define RAMNET_WGRAD_MAX_SEGMENTS 48
+typedef struct ramnet_wgrad_seg {
+    const float *x0, *x1, *xm, *dout, *gmask;
+} ramnet_wgrad_seg;
+
 typedef struct ramnet_wgrad_desc {
     const float *x0, *x1, *xm;
     int ld0, ld1, ldm, C0, C1, in_mode;
@@ -135,8 +143,8 @@ typedef struct ramnet_wgrad_desc {
     float *dbias;                   /* [Cout] or NULL                                               */
     int algo;                       /* RAMNET_ALGO_DIRECT, or RAMNET_ALGO_WINOGRAD: dense 3x3 stride-1 taps in kh*3+kw order; dw then
                                      * accumulates the transformed-domain gradient dU, folded by ramnet_unpack_wgrad_wino();
-                                     * or RAMNET_ALGO_WINOGRAD_2X4 (same launches, plain / concatenated / masked inputs): dw = dU [24][Cin][Cout]
-                                     * of F(2x4,3x3) (24 multiplies per 8 outputs instead of 32), folded by ramnet_unpack_wgrad_wino2x4();
+                                     * or RAMNET_ALGO_WINOGRAD_2X4 (same launches, plain / concatenated / masked inputs): dw = dU, 24 positions in the blocked
+                                     * layout of ramnet_wgrad_wino2x4_ws_floats(), of F(2x4,3x3) (24 multiplies per 8 outputs instead of 32), folded by ramnet_unpack_wgrad_wino2x4();
                                      * or RAMNET_ALGO_WINOGRAD24 (folded upsample-conv): x0 = [B][Hin = Ho+4][Win = Wo+4][C0] as for the
                                      * forward launch, dout / gmask = the full-resolution [B][HoG = 2*Ho][WoG = 2*Wo][Cout] tensors,
                                      * dw = dU [4 classes][25 positions][C0][Cout] (dW4 = G^T dU G per class); C0 % 32 == 0 and Cout % 64 == 0, or C0 % 64 == 0 and Cout % 32 == 0 */
@@ -149,6 +157,11 @@ typedef struct ramnet_wgrad_desc {
                                      * split s owns slab s and joins it by plain read-modify-write — no atomics, and with the launches of
                                      * a layer serialised on one stream the gradient is bit-reproducible; ramnet_reduce_slabs() folds the
                                      * slabs into slab 0 before ramnet_unpack_wgrad_wino().  Other algorithms ignore it.           */
+    int nseg;                       /* 0: one launch over x0 / x1 / xm / dout / gmask above.  1..RAMNET_WGRAD_MAX_SEGMENTS (RAMNET_ALGO_WINOGRAD_2X4
+                                     * and RAMNET_ALGO_WINOGRAD only): `segs` (HOST memory, copied into the kernel arguments by the launch) lists nseg tensor
+                                     * sets of B images each; the launch reduces over all of them (one prologue / one join of the tile splits'
+                                     * partial sums instead of nseg).  x0 ... gmask above must still be non-NULL where the mode uses them.   */
+    const ramnet_wgrad_seg *segs;
 } ramnet_wgrad_desc;
 
 /* Process-wide A/B options (they replace the RAMNET_* environment knobs of rounds 1-3): "voxel_sorted" (1; 0 = row-band / atomic
@@ -195,7 +208,11 @@ int ramnet_reflect_pad(const float *src, float *dst, int B, int C, int H, int W,
 /* Slabs the Winograd backward-weights launches of a Cin -> Cout layer use at most (ramnet_wgrad_desc.dw_slabs), and the ordered fold
  * slab 0 += slab 1 + ... + slab S-1 (n floats each, n % 4 == 0; slabs 1.. are zeroed) at the end of a backward pass.            */
 int ramnet_wgrad_wino_slabs(int Cin, int Cout);
-int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout);      /* the same for RAMNET_ALGO_WINOGRAD_2X4 launches (slabs of [24][Cin][Cout]) */
+int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout);      /* the same for RAMNET_ALGO_WINOGRAD_2X4 launches */
+/* Floats of ONE slab of the RAMNET_ALGO_WINOGRAD_2X4 workspace (ABI 20): blocked [24 positions][ceil(Cin/32)][ceil(Cout/32)][64 lanes][16] —
+ * element (position, c, n) at ((position * nCiB + c/32) * nCoB + n/32) * 1024 + ((n%32) + 32 * ((c%32 >> 2) & 1)) * 16 + (c%4) + 4 * (c%32 >> 3):
+ * the accumulator registers of one lane of the 32 x 32 MFMA are 64 contiguous bytes (16-byte read-modify-write joins).                */
+size_t ramnet_wgrad_wino2x4_ws_floats(int Cin, int Cout);
 int ramnet_reduce_slabs(float *ws, int slabs, size_t n, void *stream);
 /* Number of floats of a packed weight (forward: reduce over Cin; transposed: reduce over Cout).    */
 size_t ramnet_packed_weight_elems(int Cout, int Cin, int KH, int KW, int transposed, int gates);
@@ -254,7 +271,7 @@ int ramnet_unpack_wgrad(const float *ws, float *grad_oihw, int Cout, int Cin, in
 /* Winograd backward-weights workspace [16][CinWs][CoutWs] (dU) -> OIHW 3x3: grad += G^T dU G.                 */
 int ramnet_unpack_wgrad_wino(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
                              void *stream);
-/* F(2x4,3x3) backward-weights workspace [24 = 4 rows x 6 columns][CinWs][CoutWs] -> OIHW 3x3: grad += G_r^T dU G_c (ABI 17).  */
+/* F(2x4,3x3) backward-weights workspace (blocked: ramnet_wgrad_wino2x4_ws_floats(CinWs, CoutWs)) -> OIHW 3x3: grad += G_r^T dU G_c.  */
 int ramnet_unpack_wgrad_wino2x4(const float *ws, float *grad_oihw, int Cout, int Cin, int CinWs, int CoutWs, int n_off,
                                 void *stream);
 
@@ -272,6 +289,20 @@ int ramnet_pred_sigmoid_fwd(const float *x, int ldx, int C, const float *w, cons
 /* backward of the above: dx[npix,C] = dz*w, dw[C] += sum dz*x, db += sum dz, dz = dy*y*(1-y).      */
 int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy,
                             float *dx, int lddx, float *dw, float *db, size_t npix, void *stream);
+/* The prediction layer TOGETHER with the scale-invariant loss of the maps it supervises (ABI 20; model/loss.py:6-9 on the output of
+ * statenet.py:313): the batch is nseg (<= RAMNET_PRED_SI_MAX_SEGMENTS) segments of seg_pix pixels, targets[i] (HOST array of device pointers)
+ * = the seg_pix target values of segment i (NaN = invalid).  fwd: y as ramnet_pred_sigmoid_fwd, stats[i][0..3] = (sum d, sum d^2, n, 0) in
+ * double, loss[i] = weight * (mean d^2 - lambda * mean(d)^2); scratch = ramnet_pred_si_scratch_doubles(seg_pix, nseg) doubles, ZERO before the
+ * first use (the kernel leaves the tickets at zero; the partial sums are joined in a fixed order: bit-reproducible).  bwd: the gradient of
+ * sum_i gscale[i] * loss[i] (+ dy . y when dy != NULL) w.r.t. x, w and b — ramnet_si_loss_bwd and ramnet_pred_sigmoid_bwd in one pass. */
+#define RAMNET_PRED_SI_MAX_SEGMENTS 8
+size_t ramnet_pred_si_scratch_doubles(size_t seg_pix, int nseg);
+int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t seg_pix, int nseg,
+                               const float *const *targets, float weight, float lambda, double *scratch, double *stats, float *loss,
+                               void *stream);
+int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, size_t seg_pix, int nseg,
+                               const float *const *targets, const double *stats, const float *gscale, float weight, float lambda,
+                               float *dx, int lddx, float *dw, float *db, void *stream);
 /* The same layer WITHOUT the sigmoid (a normalisation follows: `norm` BN / IN, submodules.py:29-33): z = conv1x1(x) [+ b] (b may be
  * NULL) and its backward dx = dz*w, dw += sum dz*x, db += sum dz (db may be NULL).                                       */
 int ramnet_pred_linear_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *z, size_t npix, void *stream);

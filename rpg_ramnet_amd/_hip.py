@@ -40,6 +40,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WgradSeg(C.Structure):
+    _fields_ = [("x0", _fp), ("x1", _fp), ("xm", _fp), ("dout", _fp), ("gmask", _fp)]
+
+
+WGRAD_MAX_SEGMENTS = 48
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x0", _fp), ("x1", _fp), ("xm", _fp),
@@ -55,6 +62,7 @@ class WgradDesc(C.Structure):
         ("gsy", C.c_int), ("gsx", C.c_int), ("goy", C.c_int), ("gox", C.c_int), ("HoG", C.c_int), ("WoG", C.c_int),
         ("head_cin", C.c_int),
         ("dw_slabs", C.c_int),
+        ("nseg", C.c_int), ("segs", C.POINTER(WgradSeg)),
     ]
 
 
@@ -71,6 +79,7 @@ _SIGS = {
     "ramnet_reflect_pad": (C.c_int, [_fp, _fp] + [C.c_int] * 10 + [_fp]),
     "ramnet_wgrad_wino_slabs": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_wgrad_wino2x4_slabs": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_wgrad_wino2x4_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ramnet_reduce_slabs": (C.c_int, [_fp, C.c_int, C.c_size_t, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
     "ramnet_pack_weight": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
@@ -105,6 +114,11 @@ _SIGS = {
     "ramnet_wgrad_launch": (C.c_int, [C.POINTER(WgradDesc), _fp]),
     "ramnet_pred_sigmoid_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_pred_sigmoid_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
+    "ramnet_pred_si_scratch_doubles": (C.c_size_t, [C.c_size_t, C.c_int]),
+    "ramnet_pred_sigmoid_si_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float,
+                                             _fp, _fp, _fp, _fp]),
+    "ramnet_pred_sigmoid_si_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), _fp, _fp, C.c_float,
+                                             C.c_float, _fp, C.c_int, _fp, _fp, _fp]),
     "ramnet_pred_linear_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_pred_linear_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_cat_batch_add": (C.c_int, [_fp, C.c_int, C.c_size_t, C.c_int, C.c_int, _fp, _fp, _fp]),
@@ -189,7 +203,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 19:
+        if l.ramnet_abi_version() != 20:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

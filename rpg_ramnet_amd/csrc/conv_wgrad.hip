@@ -201,6 +201,7 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
     if (d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK) RAMNET_CHECK_ARG(d.xm && d.ldm % 4 == 0);
     if (d.in_mode == RAMNET_IN_UP2X_SKIP) RAMNET_CHECK_ARG(d.x1 && d.ld1 % 4 == 0);
     if (d.gmask) RAMNET_CHECK_ARG(d.ldgm % 4 == 0);
+    RAMNET_CHECK_ARG(d.nseg >= 0 && (d.nseg == 0 || d.algo == RAMNET_ALGO_WINOGRAD_2X4));       // multi-segment launches: F(2x4,3x3) only
     if (d.algo == RAMNET_ALGO_WINOGRAD24) return launch_wgrad_wino24(d, (hipStream_t)stream);
     const bool gdense = d.gsy == 0 && d.gsx == 0 && d.goy == 0 && d.gox == 0 && d.HoG == 0 && d.WoG == 0;
     if (!gdense) RAMNET_CHECK_ARG(d.gsy >= 1 && d.gsx >= 1 && d.goy >= 0 && d.gox >= 0 && (d.Ho - 1) * d.gsy + d.goy < d.HoG &&

@@ -14,14 +14,26 @@
 #include <stdlib.h>
 #include "common.hpp"
 
+// Tuning builds only (tools/abl_wgrad6.sh): RAMNET_ABL is a bit mask that removes one ingredient of the main loop — 1 staging (global loads,
+// LDS stores, batch walk), 2 LDS reads of the raw strips, 4 transform arithmetic, 8 barrier, 128 the whole loop, 256 the join.  Such a build
+// computes WRONG results; only its duration means something.  The product is built with RAMNET_ABL = 0.
+#ifndef RAMNET_ABL
+#define RAMNET_ABL 0
+#endif
+#define RAMNET_OPQ(QQ) asm volatile("" : "+v"(QQ))
+
 namespace ramnet {
 
 constexpr int WG6_TARGET = 384;      // workgroups per launch the tile splits aim at
 
+constexpr int WG6_MAXSEG = RAMNET_WGRAD_MAX_SEGMENTS;
+
 struct WgradWino6Params {
     InSrc src;
-    int bx_n, ty_n, nbatch;     // strips per row, strip rows per image, total
+    int bx_n, ty_n, nbatch;     // strips per row, strip rows per image, total (all segments)
     int dy0, dx0;               // offset of the first filter tap
+    int nseg, seg_images;       // segments of the launch (ramnet_wgrad_desc.segs; 1: the descriptor's own tensors), images per segment
+    ramnet_wgrad_seg seg[WG6_MAXSEG];
 };
 
 // TXB = tile columns per strip: 4 (4 x 16 output pixels), 2 (8 x 8) or 1 (16 x 4)
@@ -61,8 +73,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
     const bool use_m = XMK == 1 || (XMK == 2 && second);
     const float m_one = use_m ? 0.f : 1.f;
-    const float *xsrc = second ? s.x1 + (c0 - s.C0) : s.x0 + c0;
-    const float *msrc = s.mode == RAMNET_IN_RELUMASK ? s.xm + c0 : s.xm + (c0 - s.C0);
     const int ldS = second ? s.ld1 : s.ld0;
     int xpy[NXS], xpx[NXS], ypx[NYS], ypy[NYS], xdst[NXS];
     unsigned xoff[NXS], xmoff[NXS], yoff[NYS], ymoff[NYS];
@@ -84,29 +94,49 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         yoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldg + n0 + qd * 4) * 4u;
         ymoff[i] = (unsigned)((ypy[i] * p.Wo + ypx[i]) * p.ldgm + n0 + qd * 4) * 4u;
     }
-    int lb_ty = 0, lb_bx = 0, lb_b = 0, lb_batch = 0;
+    // A workgroup (tile split blockIdx.x) walks a CONTIGUOUS range of batches [lo, hi) of the launch's segments x images x strips, one
+    // batch at a time: the walk is an increment with carries, and the segment — the tensors of one deferred ConvGRU cell update
+    // (ramnet_wgrad_desc.segs) — changes at most a few times per workgroup: a real, almost never taken branch rebuilds the descriptors.
+    int lb_ty = 0, lb_bx = 0, lb_b = 0, lb_seg = 0, lb_batch = 0;
     const int pad_m = -(q.dy0 * s.Win + q.dx0);
     const int padS = pad_m > 0 ? pad_m : 0;
     unsigned so_x = 0, so_m = 0, so_g = 0, so_gm = 0;
-    const int st_bx = (int)gridDim.x % q.bx_n, st_ty = ((int)gridDim.x / q.bx_n) % q.ty_n, st_b = ((int)gridDim.x / q.bx_n) / q.ty_n;
-    auto load_first = [&](int batch) {          // (once, in front of the loop: the two integer divisions)
+    auto rx = wino_rsrc(nullptr, 0u);
+    auto rmk = rx, rg = rx, rgm = rx;
+    auto set_seg = [&](int sg) {
+        const ramnet_wgrad_seg &g = q.seg[sg];
+        const float *xsrc = second ? g.x1 + (c0 - s.C0) : g.x0 + c0;
+        const float *msrc = s.mode == RAMNET_IN_RELUMASK ? g.xm + c0 : g.xm + (c0 - s.C0);
+        rx = wino_rsrc(xsrc - (long)padS * ldS, WOOB);
+        rmk = XMK ? wino_rsrc(msrc - (long)padS * s.ldm, WOOB) : rx;
+        rg = wino_rsrc(g.dout, WOOB);
+        rgm = GM ? wino_rsrc(g.gmask, WOOB) : rg;
+    };
+    auto load_first = [&](int batch) {          // (once, in front of the loop: the integer divisions)
         int tt = batch;
         lb_bx = tt % q.bx_n;
         tt /= q.bx_n;
         lb_ty = tt % q.ty_n;
-        lb_b = tt / q.ty_n;
+        tt /= q.ty_n;
+        lb_b = tt % q.seg_images;
+        lb_seg = tt / q.seg_images;
         lb_batch = batch;
+        set_seg(lb_seg);
     };
     auto load_begin = [&](int batch) {
-        {                                       // batch == lb_batch (first call, clamped tail) or lb_batch + gridDim.x: branch-free walk with carries
+        {                                       // batch == lb_batch (first call, clamped tail) or lb_batch + 1
             const int adv = batch != lb_batch ? 1 : 0;
-            lb_bx += adv * st_bx;
+            lb_bx += adv;
             const int cx = lb_bx >= q.bx_n ? 1 : 0;
             lb_bx -= cx * q.bx_n;
-            lb_ty += adv * st_ty + cx;
+            lb_ty += cx;
             const int cy = lb_ty >= q.ty_n ? 1 : 0;
             lb_ty -= cy * q.ty_n;
-            lb_b += adv * st_b + cy;
+            lb_b += cy;
+            if (lb_b >= q.seg_images) {         // (uniform; the loads already in flight keep the descriptors they were issued with)
+                lb_b = 0;
+                set_seg(++lb_seg);
+            }
         }
         lb_batch = batch;
         const int pix = (lb_b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
@@ -116,10 +146,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         so_g = (unsigned)(pix * p.ldg) * 4u;
         if (GM) so_gm = (unsigned)(pix * p.ldgm) * 4u;
     };
-    const auto rx = wino_rsrc(xsrc - (long)padS * ldS, WOOB);
-    const auto rmk = XMK ? wino_rsrc(msrc - (long)padS * s.ldm, WOOB) : rx;
-    const auto rg = wino_rsrc(p.dout, WOOB);
-    const auto rgm = GM ? wino_rsrc(p.gmask, WOOB) : rg;
     auto bload = [](decltype(rx) r, unsigned vo, unsigned so) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
     };
@@ -174,54 +200,63 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     float an[2][6], bn[2][6];                     // operand sets of tile pairs st & 1 = 0 / 1
     auto fetch_x = [&](const float *xc, int st) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) da[c] = xc[xa_off + G::sx(st) + c * 32], db[c] = xc[xb_off + G::sx(st) + c * 32];
+        for (int c = 0; c < 6; ++c) {
+            if (RAMNET_ABL & 2) { RAMNET_OPQ(da[c]); RAMNET_OPQ(db[c]); }
+            else da[c] = xc[xa_off + G::sx(st) + c * 32], db[c] = xc[xb_off + G::sx(st) + c * 32];
+        }
     };
     auto fetch_y = [&](const float *yc, int st) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) g0[c] = yc[y_off + (yr0 + G::sy(st) + c) * 32], g1[c] = yc[y_off + (YW + G::sy(st) + c) * 32];
+        for (int c = 0; c < 4; ++c) {
+            if (RAMNET_ABL & 2) { RAMNET_OPQ(g0[c]); RAMNET_OPQ(g1[c]); }
+            else g0[c] = yc[y_off + (yr0 + G::sy(st) + c) * 32], g1[c] = yc[y_off + (YW + G::sy(st) + c) * 32];
+        }
     };
     // B_c^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (conv_wino6.hip)
     float tt[6];
     auto finish_x0 = [&](int o) {
+        if (RAMNET_ABL & 4) { RAMNET_OPQ(an[o][0]); RAMNET_OPQ(an[o][5]); return; }
 #pragma unroll
         for (int c = 0; c < 6; ++c) tt[c] = da[c] + sb * db[c];
         an[o][0] = fmaf(4.f, tt[0], fmaf(-5.f, tt[2], tt[4]));
         an[o][5] = fmaf(4.f, tt[1], fmaf(-5.f, tt[3], tt[5]));
     };
     auto finish_x1 = [&](int o) {
+        if (RAMNET_ABL & 4) { RAMNET_OPQ(an[o][1]); RAMNET_OPQ(an[o][2]); RAMNET_OPQ(an[o][3]); RAMNET_OPQ(an[o][4]); return; }
         const float sa = fmaf(-4.f, tt[2], tt[4]), sd = fmaf(-4.f, tt[1], tt[3]), ua = tt[4] - tt[2], ud = tt[3] - tt[1];
         an[o][1] = sa + sd, an[o][2] = sa - sd, an[o][3] = fmaf(2.f, ud, ua), an[o][4] = fmaf(-2.f, ud, ua);
     };
     // Z row = A_c w, A_c^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
     auto finish_y = [&](int o) {
+        if (RAMNET_ABL & 4) { for (int c = 0; c < 6; ++c) RAMNET_OPQ(bn[o][c]); return; }
         const float w0 = g0[0] + cb * g1[0], w1 = g0[1] + cb * g1[1], w2 = g0[2] + cb * g1[2], w3 = g0[3] + cb * g1[3];
         const float e = w0 + w2, f = w1 + w3, e4 = fmaf(4.f, w2, w0), f4 = fmaf(4.f, w3, w1);
         bn[o][0] = w0, bn[o][1] = e + f, bn[o][2] = e - f, bn[o][3] = fmaf(2.f, f4, e4), bn[o][4] = fmaf(-2.f, f4, e4), bn[o][5] = w3;
     };
 
-    const int step = gridDim.x;
-    int batch = blockIdx.x;
-    if (batch < q.nbatch) {
-        const int last = batch + ((q.nbatch - 1 - batch) / step) * step;
+    int batch = (int)((long long)q.nbatch * blockIdx.x / gridDim.x);
+    const int last = (int)((long long)q.nbatch * (blockIdx.x + 1) / gridDim.x) - 1;
+    if (batch <= last) {
         load_first(batch);
         load_raw(batch);
 #pragma unroll
         for (int i = 0; i < NXS; ++i) store_x(i, Xp);
 #pragma unroll
         for (int i = 0; i < NYS; ++i) store_y(i, Yp);
-        load_raw(min(batch + step, last));
+        load_raw(min(batch + 1, last));
         __syncthreads();
         fetch_x(Xp, 0), fetch_y(Yp, 0);
         finish_x0(0), finish_x1(0), finish_y(0);
         int cur = 0;
-        for (; batch <= last; batch += step, cur ^= 1) {
-            bias_on = batch + step <= last ? 1.f : 0.f;
-            const int b2 = min(batch + 2 * step, last);
+        for (; batch <= ((RAMNET_ABL & 128) ? -1 : last); ++batch, cur ^= 1) {
+            bias_on = batch + 1 <= last ? 1.f : 0.f;
+            const int b2 = min(batch + 2, last);
             const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
             float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
             // staging slices: the raw strips of the next batch (in registers) -> the other LDS buffer (k = 0..5, all in front of the barrier
             // behind tile pair 2), then the loads of the batch after it (k = 6..12)
             auto stage = [&](int k) {
+                if (RAMNET_ABL & 1) return;
                 if (k < 4) { if (k < NXS) store_x(k, xn); }
                 else if (k < 6) store_y(k - 4, yn);
                 else if (k == 6) load_begin(b2);
@@ -248,47 +283,50 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
                     __builtin_amdgcn_sched_barrier(0);
                     gap(pl);
                 }
-                if (st == 2) __syncthreads();
+                if (st == 2 && !(RAMNET_ABL & 8)) __syncthreads();
             }
         }
     }
 
-    // D[row = input channel][col = output channel] of position 6 * wave + pl -> slab[(pos * Cin + c) * Cout + n]
-    const int Cin = s.Cin;
+    // D of position 6 * wave + pl -> the BLOCKED workspace [24 positions][Cin / 32][Cout / 32][64 lanes][16 accumulator registers]: a lane's
+    // 16 values (rows c = (r & 3) + 8 (r >> 2) + 4 kk of column n = lane & 31) are 64 contiguous bytes, a wave's block 4 KB — the join of
+    // a split's partial sums with its slab is 4 + 4 16-byte accesses per position instead of 16 + 16 4-byte ones at a Cout-float stride
+    // (the join is ~12 % of a launch at the training batch: every workgroup runs it at the same time, behind the last MFMA).  Channels
+    // beyond Cin / Cout inside a block hold zeros (their strips load as zeros).  ramnet_unpack_wgrad_wino2x4 reads the same layout.
+    const int nCiB = gridDim.y, nCoB = gridDim.z;
     const bool slabs = p.dw_slabs > 0;
-    float *dwb = p.dw + (slabs ? (size_t)blockIdx.x * 24 * Cin * p.Cout : 0);
-    const int n = n0 + l31;
+    const size_t slab_floats = (size_t)24 * nCiB * nCoB * 1024;
+    float *dwb = p.dw + (slabs ? (size_t)blockIdx.x * slab_floats : 0) + ((size_t)blockIdx.y * nCoB + blockIdx.z) * 1024 + lane * 16;
+    const size_t pos_stride = (size_t)nCiB * nCoB * 1024;
     const bool neg = wave == 3;
-    if (slabs) {                // pipelined read-modify-write of the split's own slab (conv_wgrad_wino.hip)
-        float old[2][16];
-        auto grp_load = [&](int pl, float (&o)[16]) {
-            const float *col = dwb + (size_t)(6 * wave + pl) * Cin * p.Cout + n;
+    if (RAMNET_ABL & 256) {
+        if (acc[0][0] == 123.456f) dwb[0] = acc[1][0] + acc[2][0] + acc[3][0] + acc[4][0] + acc[5][0];
+    } else if (slabs) {                // pipelined read-modify-write of the split's own slab: position pl + 1 is requested before pl is stored
+        float4 old[2][4];
+        auto grp_load = [&](int pl, float4 (&o)[4]) {
+            const float *b = dwb + (size_t)(6 * wave + pl) * pos_stride;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                o[r] = (c < Cin && n < p.Cout) ? col[(size_t)c * p.Cout] : 0.f;
-            }
+            for (int v = 0; v < 4; ++v) o[v] = ld4(b + 4 * v);
         };
         grp_load(0, old[0]);
 #pragma unroll
         for (int pl = 0; pl < 6; ++pl) {
             if (pl + 1 < 6) grp_load(pl + 1, old[(pl + 1) & 1]);
-            float *col = dwb + (size_t)(6 * wave + pl) * Cin * p.Cout + n;
+            float *b = dwb + (size_t)(6 * wave + pl) * pos_stride;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (c < Cin && n < p.Cout) col[(size_t)c * p.Cout] = old[pl & 1][r] + (neg ? -acc[pl][r] : acc[pl][r]);
+            for (int v = 0; v < 4; ++v) {
+                const float4 o = old[pl & 1][v];
+                const float sg = neg ? -1.f : 1.f;
+                st4(b + 4 * v, make_float4(fmaf(sg, acc[pl][4 * v], o.x), fmaf(sg, acc[pl][4 * v + 1], o.y), fmaf(sg, acc[pl][4 * v + 2], o.z),
+                                            fmaf(sg, acc[pl][4 * v + 3], o.w)));
             }
         }
     } else {
 #pragma unroll
         for (int pl = 0; pl < 6; ++pl) {
-            float *col = dwb + (size_t)(6 * wave + pl) * Cin * p.Cout + n;
+            float *b = dwb + (size_t)(6 * wave + pl) * pos_stride;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (c < Cin && n < p.Cout) atomicAdd(col + (size_t)c * p.Cout, neg ? -acc[pl][r] : acc[pl][r]);
-            }
+            for (int r = 0; r < 16; ++r) atomicAdd(b + r, neg ? -acc[pl][r] : acc[pl][r]);
         }
     }
     if (p.dbias != nullptr && blockIdx.y == 0) {
@@ -307,17 +345,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     }
 }
 
-// ws [24][CinWs][CoutWs] (dU, position = 6 * row + column) -> grad OIHW [Cout][Cin][3][3] (+=): dg = G_r^T dU G_c
+// blocked ws [24][CinWs / 32][CoutWs / 32][64][16] (dU, position = 6 * row + column; layout: the kernel's join above) -> grad OIHW
+// [Cout][Cin][3][3] (+=): dg = G_r^T dU G_c
 __global__ void unpack_wgrad_wino2x4_kernel(const float *__restrict__ ws, float *__restrict__ g, int Cout, int Cin, int CinWs, int CoutWs,
                                             int n_off, size_t total) {
     const float G2[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
     const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                              {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nCiB = (CinWs + 31) / 32, nCoB = (CoutWs + 31) / 32;
+    const size_t pos_stride = (size_t)nCiB * nCoB * 1024;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cin), n = (int)(i / Cin);
+        const int nn = n_off + n, c32 = c & 31;
+        const size_t at = ((size_t)(c >> 5) * nCoB + (nn >> 5)) * 1024 + ((nn & 31) + 32 * ((c32 >> 2) & 1)) * 16 + (c32 & 3) + 4 * (c32 >> 3);
         double u[4][6];
         for (int a = 0; a < 4; ++a)
-            for (int b = 0; b < 6; ++b) u[a][b] = ws[((size_t)(a * 6 + b) * CinWs + c) * CoutWs + n_off + n];
+            for (int b = 0; b < 6; ++b) u[a][b] = ws[(size_t)(a * 6 + b) * pos_stride + at];
         for (int ka = 0; ka < 3; ++ka)
             for (int kb = 0; kb < 3; ++kb) {
                 double sum = 0;
@@ -356,7 +399,16 @@ int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
         const long a = (long)cdiv(d.Wo, 4 * t) * 4 * t * cdiv(d.Ho, 16 / t) * (16 / t);
         if (best < 0 || a < best) best = a, txb = t;
     }
-    q.bx_n = cdiv(d.Wo, 4 * txb), q.ty_n = cdiv(d.Ho, 16 / txb), q.nbatch = q.bx_n * q.ty_n * d.B;
+    // segments: the tensors of several launches of the same layer (deferred ConvGRU cell updates) walked as one batch dimension
+    q.nseg = d.nseg > 0 ? d.nseg : 1, q.seg_images = d.B;
+    RAMNET_CHECK_ARG(q.nseg <= WG6_MAXSEG && (d.nseg == 0 || d.segs != nullptr));
+    for (int i = 0; i < q.nseg; ++i) {
+        if (d.nseg > 0) q.seg[i] = d.segs[i];
+        else q.seg[i].x0 = d.x0, q.seg[i].x1 = d.x1, q.seg[i].xm = d.xm, q.seg[i].dout = d.dout, q.seg[i].gmask = d.gmask;
+        RAMNET_CHECK_ARG(q.seg[i].x0 && q.seg[i].dout && (!cat || q.seg[i].x1) && (d.xm == nullptr) == (q.seg[i].xm == nullptr) &&
+                         (d.gmask == nullptr) == (q.seg[i].gmask == nullptr));
+    }
+    q.bx_n = cdiv(d.Wo, 4 * txb), q.ty_n = cdiv(d.Ho, 16 / txb), q.nbatch = q.bx_n * q.ty_n * d.B * q.nseg;
     const int gy = cdiv(q.src.Cin, 32), gz = cdiv(d.Cout, 32);
     int splits = g_opt_wgrad_wino_blocks / (gy * gz);
     if (splits > q.nbatch) splits = q.nbatch;
@@ -398,6 +450,8 @@ extern "C" int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout) {
     const int s = WG6_TARGET / (cdiv(Cin, 32) * cdiv(Cout, 32));
     return s < 1 ? 1 : s;
 }
+
+extern "C" size_t ramnet_wgrad_wino2x4_ws_floats(int Cin, int Cout) { return (size_t)24 * cdiv(Cin, 32) * cdiv(Cout, 32) * 1024; }
 
 extern "C" int ramnet_unpack_wgrad_wino2x4(const float *ws, float *grad, int Cout, int Cin, int CinWs, int CoutWs, int n_off, void *stream) {
     RAMNET_CHECK_ARG(ws && grad && Cout > 0 && Cin > 0 && CinWs >= Cin && n_off >= 0 && CoutWs >= n_off + Cout);

@@ -282,6 +282,156 @@ __global__ void pred_sigmoid_bwd_kernel(const float *__restrict__ x, int ldx, in
     }
 }
 
+// ------------------------------------------------------------------------------------------ prediction head + scale-invariant loss
+// pred = sigmoid(conv1x1(x) + b) (statenet.py:116-117, 313) AND the statistics of scale_invariant_loss (model/loss.py:6-9) of the maps it
+// supervises, in the pass that produces them: the prediction is read where it is made instead of once more by a loss launch.  The batch is
+// `nseg` segments of seg_pix pixels (one supervised measurement each: events4 and image of a package decoded as one chain), blockIdx.y =
+// segment.  Sums in double; every workgroup leaves its three partial sums in part[segment][workgroup][3], the LAST one of a segment to
+// arrive (ticket) adds them in workgroup order — bit-reproducible — and writes stats[segment] = (sum d, sum d^2, n, 0) and the loss.
+struct PredSiTargets {
+    const float *t[RAMNET_PRED_SI_MAX_SEGMENTS];
+};
+
+__device__ __forceinline__ double pw_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
+                                                                  const float *__restrict__ bias, float *__restrict__ y, size_t seg_pix,
+                                                                  PredSiTargets tg, float weight, float lambda, double *__restrict__ part,
+                                                                  unsigned long long *__restrict__ ticket, double *__restrict__ stats,
+                                                                  float *__restrict__ loss) {
+    const int sub = threadIdx.x & 7, seg = blockIdx.y;
+    const size_t stride = (size_t)gridDim.x * blockDim.x / 8, base = (size_t)seg * seg_pix;
+    const float b0 = bias ? bias[0] : 0.f;
+    const float *__restrict__ tgt = tg.t[seg];
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (size_t p = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) / 8; p < seg_pix; p += stride) {
+        const size_t pix = base + p;
+        float s = 0.f;
+        for (int c = sub * 4; c < C; c += 32) {
+            const float4 v = ld4(x + pix * ldx + c), ww = ld4(w + c);
+            s += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (sub == 0) {
+            const float yy = sigmoidf_(s + b0);
+            y[pix] = yy;
+            const float d = yy - tgt[p];
+            if (d == d) {
+                s1 += (double)d;
+                s2 += (double)d * (double)d;
+                cnt += 1.0;
+            }
+        }
+    }
+    __shared__ double red[3][4];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s1 = pw_wave_sum(s1), s2 = pw_wave_sum(s2), cnt = pw_wave_sum(cnt);
+    if (lane == 0) red[0][wave] = s1, red[1][wave] = s2, red[2][wave] = cnt;
+    __syncthreads();
+    double *mine = part + ((size_t)seg * gridDim.x) * 3;
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 3; ++k) mine[blockIdx.x * 3 + k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        __threadfence();                                        // the partials are visible before the ticket
+        is_last = atomicAdd(ticket + seg, 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)         // (fixed assignment of partials to threads: a fixed order)
+        for (int k = 0; k < 3; ++k) v[k] += __hip_atomic_load(mine + i * 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 3; ++k) v[k] = pw_wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) red[0][wave] = v[0], red[1][wave] = v[1], red[2][wave] = v[2];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S[3];
+        for (int k = 0; k < 3; ++k) S[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]), stats[seg * 4 + k] = S[k];
+        stats[seg * 4 + 3] = 0.0;
+        const double m = S[0] / S[2];
+        loss[seg] = (float)((double)weight * (S[1] / S[2] - (double)lambda * m * m));
+        atomicExch(ticket + seg, 0ull);
+    }
+}
+
+// Backward of the same: the gradient w.r.t. the prediction is what arrives densely (dy, may be NULL) PLUS, per segment, the scale-invariant
+// term gscale[seg] * weight * 2 (d - lambda * mean) / n over the valid pixels (si_bwd_kernel's arithmetic, formed in double) — no dense
+// gradient map of the loss exists; then the sigmoid's derivative, dx = dz * w and the [C] + 1 weight / bias partials as in pred_sigmoid_bwd_kernel.
+__global__ void pred_sigmoid_si_bwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w, const float *__restrict__ y,
+                                           const float *__restrict__ dy, PredSiTargets tg, const double *__restrict__ stats,
+                                           const float *__restrict__ gscale, float weight, float lambda, float *__restrict__ dx, int lddx,
+                                           float *__restrict__ dw, float *__restrict__ db, size_t seg_pix) {
+    __shared__ float red[32 * 4 * 8 + 32];
+    const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3, seg = blockIdx.y;
+    const size_t stride = (size_t)gridDim.x * (blockDim.x / 8), base = (size_t)seg * seg_pix;
+    const float *__restrict__ tgt = tg.t[seg];
+    const double cnt = stats[seg * 4 + 2], mean = stats[seg * 4] / cnt;
+    const double s2 = 2.0 * (double)(gscale[seg] * weight) / cnt, lm = (double)lambda * mean;
+    float4 dwp[4] = {f4zero(), f4zero(), f4zero(), f4zero()};   // C <= 128
+    float4 ww[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ww[k] = sub * 4 + 32 * k < C ? ld4(w + sub * 4 + 32 * k) : f4zero();
+    float dbp = 0.f;
+    for (size_t p0 = blockIdx.x * (size_t)(blockDim.x / 8) + slot; p0 < seg_pix; p0 += 4 * stride) {
+        float dz[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = p0 + u * stride, pix = base + p;
+            const bool ok = p < seg_pix;
+            const float yy = ok ? y[pix] : 0.f;
+            const float d = ok ? yy - tgt[p] : 0.f;
+            float g = (ok && dy) ? dy[pix] : 0.f;
+            if (ok && d == d) g += (float)(s2 * ((double)d - lm));
+            dz[u] = g * yy * (1.0f - yy);
+            v[u] = ok && sub * 4 < C ? ld4(x + pix * ldx + sub * 4) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = p0 + u * stride, pix = base + p;
+            if (p >= seg_pix) break;
+            if (sub == 0) dbp += dz[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = sub * 4 + 32 * k;
+                if (c < C) {
+                    const float4 xv = k == 0 ? v[u] : ld4(x + pix * ldx + c);
+                    if (dx) st4(dx + pix * lddx + c, f4scale(ww[k], dz[u]));
+                    dwp[k] = f4add(dwp[k], f4scale(xv, dz[u]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k * 32 >= C) break;
+        __syncthreads();
+        st4(red + (slot * 8 + sub) * 4, dwp[k]);
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int c = k * 32 + threadIdx.x;
+            float s = 0.f;
+            for (int g = 0; g < 32; ++g) s += red[g * 32 + threadIdx.x];
+            if (c < C) atomicAdd(dw + c, s);
+        }
+    }
+    __syncthreads();
+    if (sub == 0) red[slot] = dbp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int g = 0; g < 32; ++g) s += red[g];
+        if (db) atomicAdd(db, s);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ upsample adjoint
 __device__ __forceinline__ float up2x_weight(int dst, int src, int n_src) {
     int i0, i1;
@@ -766,6 +916,51 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
     RAMNET_CHECK_ARG(x && w && y && dy && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0);
     return pred_bwd(x, ldx, C, w, y, dy, dx, lddx, dw, db, npix, stream);
 }
+static int pred_si_grid(size_t seg_pix, int nseg) {
+    int g = grid_for(seg_pix * 8);
+    const int cap = 512 / (nseg > 0 ? nseg : 1);      // the partial sums of a segment meet in its last workgroup: a few hundred workgroups over all segments
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : g;
+}
+
+extern "C" size_t ramnet_pred_si_scratch_doubles(size_t seg_pix, int nseg) {
+    // [nseg][workgroups][3] partial sums + [nseg] tickets (zero before the first use; the kernel leaves them at zero)
+    return nseg > 0 ? (size_t)nseg * pred_si_grid(seg_pix, nseg) * 3 + nseg : 0;
+}
+
+extern "C" int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t seg_pix, int nseg,
+                                          const float *const *targets, float weight, float lambda, double *scratch, double *stats, float *loss,
+                                          void *stream) {
+    RAMNET_CHECK_ARG(x && w && y && C > 0 && C % 4 == 0 && ldx % 4 == 0 && seg_pix > 0);
+    RAMNET_CHECK_ARG(nseg >= 1 && nseg <= RAMNET_PRED_SI_MAX_SEGMENTS && targets && scratch && stats && loss);
+    PredSiTargets tg;
+    for (int i = 0; i < RAMNET_PRED_SI_MAX_SEGMENTS; ++i) tg.t[i] = i < nseg ? targets[i] : nullptr;
+    for (int i = 0; i < nseg; ++i) RAMNET_CHECK_ARG(tg.t[i] != nullptr);
+    const int g = pred_si_grid(seg_pix, nseg);
+    hipLaunchKernelGGL(pred_sigmoid_si_fwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, y, seg_pix, tg, weight, lambda,
+                       scratch, reinterpret_cast<unsigned long long *>(scratch + (size_t)nseg * g * 3), stats, loss);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, size_t seg_pix, int nseg,
+                                          const float *const *targets, const double *stats, const float *gscale, float weight, float lambda,
+                                          float *dx, int lddx, float *dw, float *db, void *stream) {
+    RAMNET_CHECK_ARG(x && w && y && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0 && seg_pix > 0);
+    RAMNET_CHECK_ARG(nseg >= 1 && nseg <= RAMNET_PRED_SI_MAX_SEGMENTS && targets && stats && gscale);
+    if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
+    PredSiTargets tg;
+    for (int i = 0; i < RAMNET_PRED_SI_MAX_SEGMENTS; ++i) tg.t[i] = i < nseg ? targets[i] : nullptr;
+    for (int i = 0; i < nseg; ++i) RAMNET_CHECK_ARG(tg.t[i] != nullptr);
+    int g = grid_for(seg_pix * 8);
+    if (g > 512 / nseg) g = 512 / nseg;      // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(pred_sigmoid_si_bwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, tg, stats, gscale, weight,
+                       lambda, dx, lddx, dw, db, seg_pix);
+    RAMNET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int ramnet_pred_linear_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *z, size_t npix, void *stream) {
     RAMNET_CHECK_ARG(x && w && z && C > 0 && C % 4 == 0 && ldx % 4 == 0);
     hipLaunchKernelGGL(pred_sigmoid_fwd_kernel<false>, dim3(grid_for(npix * 8)), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, z, npix);

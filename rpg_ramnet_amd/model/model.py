@@ -228,6 +228,7 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         if md > 0:
             groups = [g[j:j + md] for g in groups for j in range(0, len(g), md)]
         per_slot, preds = [], {}
+        fuse = self._si_request(item, keys, crop)
 
         def decode_group(g):
             runs = [[g[0]]]                                    # maximal runs of consecutive slots (joined without a copy)
@@ -243,8 +244,17 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                                             *[hof(per_slot[k][i]) for k in r]) if len(r) > 1 else hof(per_slot[r[0]][i]) for r in runs]
                 h = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
                 joined.append((h,) if pair else h)
+            order = [k for r in runs for k in r]
+            if fuse is not None and all(keys[k] in fuse[2] for k in order):
+                # every measurement of this chain is supervised and its target is at hand: the scale-invariant loss rides in the
+                # prediction layer's launches (ops.PredSigmoidSI); trainer.sequence_loss picks the terms up from the predictions
+                pred, losses = decode(joined, (fuse[0], fuse[1], [fuse[2][keys[k]] for k in order]))
+                for j, k in enumerate(order):
+                    preds[k] = pred[j * B:(j + 1) * B]
+                    preds[k]._si_fused = (losses[j], fuse[2][keys[k]].data_ptr(), (fuse[0], fuse[1]))
+                return
             pred = decode(joined)
-            for j, k in enumerate([k for r in runs for k in r]):
+            for j, k in enumerate(order):
                 preds[k] = pred[j * B:(j + 1) * B]
 
         for k in range(K + 1):
@@ -259,6 +269,25 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                     decode_group(g)
         for k in range(K + 1):
             emit(keys[k], preds[k], per_slot[k], {'encoders': [None] * n, 'state_comb': per_slot[k]})
+
+    def _si_request(self, item, keys, crop):
+        """(weight, n_lambda, {key: device target}) when this package's trainer asked for the scale-invariant loss of the supervised
+        predictions to be formed inside the prediction layer (`self._si_fuse`, set around the call by trainer.sequence_loss) and it can be:
+        gradients on, plain prediction layer, no full-frame crop, a [B, 1, H, W] target per requested key in the item."""
+        req = getattr(self, "_si_fuse", None)
+        if req is None or not torch.is_grad_enabled() or crop is not None or self.statenetphasedrecurrent.norm in ('BN', 'IN'):
+            return None
+        tg = {}
+        shape = tuple(item['image'].shape[:1]) + (1,) + tuple(item['image'].shape[2:])
+        for k in req["keys"]:
+            t = item.get('depth_' + k) if k in keys else None
+            if t is None:
+                continue
+            t = t.to(device=self.gpu, dtype=torch.float32)
+            if tuple(t.shape) != shape:
+                return None
+            tg[k] = t.contiguous()
+        return (float(req["weight"]), float(req["n_lambda"]), tg) if tg else None
 
     def forward(self, item, prev_super_states, prev_states_lstm):
         net = self.statenetphasedrecurrent
@@ -286,13 +315,14 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
 
         side = ops.decode_stream(self.gpu) if ops.decoder_overlap() else None
 
-        def decode(ss):
-            """Prediction from the state after this update; optionally on the decode stream, concurrent with the next update."""
+        def decode(ss, si=None):
+            """Prediction from the state after this update; optionally on the decode stream, concurrent with the next update.
+            si: see StateNetPhasedRecurrent.forward_decoder — returns (prediction, losses) then."""
             if side is None:
-                return net.forward_decoder(ss)
+                return net.forward_decoder(ss, si)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                pred = net.forward_decoder(ss)
+                pred = net.forward_decoder(ss, si)
             if not torch.cuda.is_current_stream_capturing():       # (inside a capture the graph's edges order the private pool)
                 for t in ss:
                     for u in (t if isinstance(t, (list, tuple)) else (t,)):

@@ -127,7 +127,10 @@ class StateNetPhasedRecurrent(nn.Module):
                             prev_super_state, prev_states_lstm, bool(self.baseline), out)
 
     # ---------------------------------------------------------------------------------------------- decoder
-    def forward_decoder(self, super_states):
+    def forward_decoder(self, super_states, si=None):
+        """si (training step of this package's own trainer): (weight, n_lambda, [target per equal batch segment]) — the scale-invariant loss
+        of the decoded maps is formed inside the prediction layer's launches (ops.PredSigmoidSI) and returned beside the prediction:
+        (pred, [loss per segment]).  Default: the prediction alone, as in the reference (statenet.py:290-315)."""
         pair = (not bool(self.baseline)) and self.state_combination == 'convlstm'
         pick = (lambda s: s[0]) if pair else (lambda s: s)
         x = pick(super_states[-1])
@@ -136,5 +139,9 @@ class StateNetPhasedRecurrent(nn.Module):
         for i, dec in enumerate(self.decoders):
             x = dec(x) if i == 0 else dec(x, pick(super_states[self.num_encoders - i - 1]))   # no skip into decoder 0
         if self.norm in ('BN', 'IN'):          # conv1x1 -> norm -> sigmoid (statenet.py:116-117, 313)
+            assert si is None, "fused SI loss: plain prediction layer only"
             return self.pred(x, act='sigmoid').permute(0, 3, 1, 2)           # NHWC [B,H,W,1] -> NCHW view
+        if si is not None:
+            out = ops.PredSigmoidSI.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias, float(si[0]), float(si[1]), *si[2])
+            return out[0], list(out[1:])
         return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

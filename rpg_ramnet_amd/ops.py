@@ -16,6 +16,7 @@ from torch.autograd import Function
 from . import _hip as H
 
 _NULL = None
+_ABL_SKIP_WGRAD = _os.environ.get("RAMNET_ABL_SKIP_WGRAD") == "1"
 
 # 3x3 stride-1 layers (ConvGRU gates / candidate, residual blocks) run Winograd F(2x2,3x3) in fp32 — 2.25x fewer
 # multiplies, rounding error ~1e-6 relative (tests/test_hip_ops.py) — unless switched off (RAMNET_WINOGRAD=0).
@@ -297,7 +298,9 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
 
 
 def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
-                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0, wino24=False):
+                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0, wino24=False, segs=None):
+    """segs: a ctypes array of H.WgradSeg (ramnet_wgrad_desc.segs) — the tensors of several launches of the SAME layer and shape reduced
+    in one launch (deferred ConvGRU cell updates, _wgrad_cell); x0 ... gmask then describe the first segment."""
     d = H.WgradDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
@@ -322,6 +325,10 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
         d.algo, d.head_cin = H.ALGO_HEAD, hc
     if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4) and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
+    if segs is not None:
+        d.nseg, d.segs = len(segs), C.cast(segs, C.POINTER(H.WgradSeg))
+    if _ABL_SKIP_WGRAD:        # tuning runs only (RAMNET_ABL_SKIP_WGRAD=1: how much of the step the backward-weights launches cost; gradients are WRONG)
+        return
     H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
 
 
@@ -435,6 +442,43 @@ def wgrad_side(tensors, *args, **kw):
     _Engine.side_used = dev
 
 
+# Deferred backward-weights of the recurrent cells.  Every update of a ConvGRU scale runs the same two convolutions, so the weight
+# gradients of several updates can be reduced by ONE launch over the updates' tensors (ramnet_wgrad_desc.segs) instead of one launch per
+# update: a launch pays its prologue and — more — the join of every tile split's partial sums with the layer's workspace once (24 x 32 x 32
+# floats read and written per workgroup: ~40 us of a ~250 us launch at the training batch) whatever its length.  The cell's backward
+# queues its tensors on the layer (ConvParam._defer) and goes on with the backward-data chain; the queue is launched on the
+# backward-weights stream when it holds `_WGRAD_DEFER` updates and, for what is left, when the engine finishes the pass.
+_WGRAD_DEFER = 0
+
+
+def set_wgrad_defer(n):
+    """Cell updates per deferred multi-segment backward-weights launch of a ConvGRU layer (0 / 1: every update launches its own;
+    <= 48).  The queued tensors (x, h, [u|r], the gate gradients: ~0.24 GB per update at the bench shape) stay alive until the launch."""
+    global _WGRAD_DEFER
+    n = int(n)
+    assert 0 <= n <= H.WGRAD_MAX_SEGMENTS
+    _WGRAD_DEFER = n
+
+
+def wgrad_defer():
+    return _WGRAD_DEFER
+
+
+def _wgrad_cell(cp, dw, tensors, x0, taps, dout, Cout, **kw):
+    """Backward-weights of one recurrent-cell convolution: launched now (wgrad_side) or queued on the layer for a multi-segment launch."""
+    if _WGRAD_DEFER <= 1 or not getattr(dw, "wino6", False) or not _WGRAD_SLABS:
+        return wgrad_side(tensors, x0, taps, dout, dw, Cout, **kw)
+    x1, xm = kw.get("x1"), kw.get("xm")
+    key = (id(dw), tuple(x0.shape), ld(x0), ld(x1) if x1 is not None else 0, ld(xm) if xm is not None else 0, ld(dout), Cout,
+           kw.get("in_mode"), kw.get("C1"), kw.get("xm_off", 0), x0.device)
+    q = cp._defer
+    if q and q[0][0] != key:
+        cp.flush_deferred()
+    cp._defer.append((key, tensors, x0, taps, dout, dw, Cout, kw))
+    if len(cp._defer) >= _WGRAD_DEFER:
+        cp.flush_deferred()
+
+
 # ------------------------------------------------------------------------------------------------ parameters
 class _Engine:
     """Per-backward-pass bookkeeping: fold weight-gradient workspaces into .grad when the autograd engine finishes the pass.
@@ -473,6 +517,8 @@ class _Engine:
 
     @classmethod
     def flush(cls):
+        for cp in cls.dirty:               # queued cell updates go to the backward-weights stream before it is joined
+            cp.flush_deferred()
         cls._join()
         dirty, cls.dirty, cls.task = cls.dirty, [], -1
         # data-parallel runs: parallel.FlatGradReducer watches the folds and sends a gradient bucket off as soon as its last
@@ -490,6 +536,8 @@ class _Engine:
     @classmethod
     def reset(cls):
         """Drop the partial weight-gradient sums of an aborted backward pass (nothing reaches .grad)."""
+        for cp in cls.dirty:
+            cp._defer = []
         cls._join()
         dirty, cls.dirty, cls.task = cls.dirty, [], -1
         for cp in dirty:
@@ -603,6 +651,23 @@ class ConvParam:
         self._vbias = None
         self._packs = {}
         self._dirty = False
+        self._defer = []                 # queued backward-weights launches of a recurrent cell (_wgrad_cell)
+
+    def flush_deferred(self):
+        """Launch the queued cell updates as ONE multi-segment backward-weights launch (ramnet_wgrad_desc.segs)."""
+        q, self._defer = self._defer, []
+        if not q:
+            return
+        _, _, x0, taps, dout, dw, Cout, kw = q[0]
+        if len(q) == 1:
+            return wgrad_side(q[0][1], x0, taps, dout, dw, Cout, **kw)
+        segs = (H.WgradSeg * len(q))()
+        keep = []
+        for i, (_, tensors, xi, _, di, _, _, kwi) in enumerate(q):
+            segs[i].x0, segs[i].x1, segs[i].xm = _p(xi), _p(kwi.get("x1")), _p(kwi.get("xm"), kwi.get("xm_off", 0))
+            segs[i].dout, segs[i].gmask = _p(di), _p(kwi.get("gmask"))
+            keep += list(tensors)
+        wgrad_side(keep, x0, taps, dout, dw, Cout, segs=segs, **kw)
 
     def splitk_ws(self, n, device):
         """Workspace of this layer's split-reduction launches (ramnet_conv_desc.splitk_ws): zero once — the kernel leaves the arrival
@@ -743,7 +808,10 @@ class ConvParam:
             # 3x3 layers: one slab per tile split of the Winograd backward-weights launch (joined by plain read-modify-write: no atomics,
             # bit-reproducible sums; ramnet_wgrad_desc.dw_slabs) — folded into slab 0 by finalize(); other layers: one slab
             self._slabs = H.lib().ramnet_wgrad_wino_slabs(self.CinWs, self.Cout) if self.k == 3 else 1
-            self._ws = torch.zeros(self._slabs * slots * self.CinWs * self.Cout, device=dev)
+            # (F(2x4): blocked layout padded to 32 x 32-channel blocks, half as many slabs as F(2x2): never larger than the dense 24-slot slabs
+            # of F(2x2)'s count unless the channel counts are ragged — take the maximum)
+            n6 = H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout) * H.lib().ramnet_wgrad_wino2x4_slabs(self.CinWs, self.Cout) if self.k == 3 else 0
+            self._ws = torch.zeros(max(self._slabs * slots * self.CinWs * self.Cout, n6), device=dev)
             self._bws = torch.zeros(self._slabs * self.Cout, device=dev)
             self._ws.slabs = self._slabs
         _Engine.enter()         # (a new pass after an aborted one resets _dirty first)
@@ -811,7 +879,8 @@ class ConvParam:
         w6 = getattr(self._ws, "wino6", False)
         ns = getattr(self._ws, "slabs", 1)
         if ns > 1 and (w6 or getattr(self._ws, "wino", False)):
-            H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), ns, (24 if w6 else 16) * self.CinWs * self.Cout, _st()), "ramnet_reduce_slabs")
+            n = H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout) if w6 else 16 * self.CinWs * self.Cout
+            H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), ns, n, _st()), "ramnet_reduce_slabs")
             H.check(H.lib().ramnet_reduce_slabs(_p(self._bws), ns, self.Cout, _st()), "ramnet_reduce_slabs")
 
     def finalize(self):
@@ -863,6 +932,7 @@ class S2DConvParam(ConvParam):
         self._fold_used = self._ws_used = False
         self._packs = {}
         self._dirty = False
+        self._defer = []
 
     def _cat_w(self):
         return s2d_weights(self.parent.weights[0].detach()).contiguous()
@@ -1450,14 +1520,14 @@ class GRUCell(Function):
             dhd = torch.empty_like(o)
             H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, ld(dhn), _st()), "gru_bwd_a")
         ws, bws = cp_o.grad_ws(wino_ok=Cc % 32 == 0)
-        wgrad_side([x, h, ur, dpo], x, taps, dpo, ws, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
+        _wgrad_cell(cp_o, ws, [x, h, ur, dpo], x, taps, dpo, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
         if fused:
             conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc, epi=H.EPI_GRU_BWD, e0=ur, e1=h, o1=dpur)
         else:
             conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc)
             H.check(L.ramnet_gru_bwd_b(_p(dxh), _p(ur), _p(h), _p(dpur), _p(dhd), npix, Cc, _st()), "gru_bwd_b")
         ws, bws = cp_ur.grad_ws(wino_ok=Cc % 32 == 0)
-        wgrad_side([x, h, dpur], x, taps, dpur, ws, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
+        _wgrad_cell(cp_ur, ws, [x, h, dpur], x, taps, dpur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
         conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * Cc, beta=1.0)
         return dxh[..., :Cc], dxh[..., Cc:], None, None, None, None, None, None, None, None, None
 
@@ -1628,6 +1698,66 @@ class PredSigmoid(Function):
         H.check(H.lib().ramnet_pred_sigmoid_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), _p(dx), Cc,
                                                 _p(ensure_grad(w)), _p(ensure_grad(b)), B * Hh * W, _st()), "pred_bwd")
         return dx, None, None
+
+
+_SI_FUSION = True
+
+
+def set_si_fusion(on):
+    """Scale-invariant loss of the supervised predictions inside the prediction layer's launches (PredSigmoidSI; trainer.sequence_loss
+    asks the model for it): on by default, off for A/B runs and the separate-launch path's tests."""
+    global _SI_FUSION
+    _SI_FUSION = bool(on)
+
+
+def si_fusion():
+    return _SI_FUSION
+
+
+class PredSigmoidSI(Function):
+    """PredSigmoid + scale_invariant_loss (model/loss.py:6-9) of the `len(targets)` equal batch segments of its output against their
+    target maps, statistics formed in the forward launch and the loss gradient in the backward launch (ramnet_pred_sigmoid_si_fwd / _bwd):
+    returns (pred NCHW [B,1,H,W], loss_0, ..., loss_{n-1}).  pred stays differentiable for other consumers (a dense gradient is added)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, weight, n_lambda, *targets):
+        x = dense(x)
+        B, Hh, W, Cc = x.shape
+        n = len(targets)
+        assert 1 <= n <= 8 and B % n == 0
+        seg_pix = (B // n) * Hh * W
+        tg = [t.contiguous() for t in targets]
+        for t in tg:
+            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == seg_pix, "PredSigmoidSI: one [B/n, 1, H, W] fp32 target per segment"
+        L = H.lib()
+        y = torch.empty(B, 1, Hh, W, device=x.device)
+        scratch = torch.zeros(L.ramnet_pred_si_scratch_doubles(seg_pix, n), device=x.device, dtype=torch.float64)
+        stats = torch.empty(n, 4, device=x.device, dtype=torch.float64)
+        loss = torch.empty(n, device=x.device)
+        arr = (C.c_void_p * n)(*[t.data_ptr() for t in tg])
+        H.check(L.ramnet_pred_sigmoid_si_fwd(_p(x), ld(x), Cc, _p(w.detach()), _p(b.detach()), _p(y), seg_pix, n, arr, weight, n_lambda,
+                                             _p(scratch), _p(stats), _p(loss), _st()), "pred_si_fwd")
+        ctx.save_for_backward(x, w, b, y, stats, *tg)
+        ctx.meta = (weight, n_lambda, n, seg_pix)
+        ctx.set_materialize_grads(False)
+        return (y,) + tuple(loss[i] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, dy, *dloss):
+        x, w, b, y, stats = ctx.saved_tensors[:5]
+        tg = ctx.saved_tensors[5:]
+        weight, n_lambda, n, seg_pix = ctx.meta
+        B, Hh, W, Cc = x.shape
+        dy = dy.contiguous() if dy is not None else None
+        if all(g is None for g in dloss):
+            gs = torch.zeros(n, device=x.device)
+        else:
+            gs = torch.stack([g.float().reshape(()) if g is not None else torch.zeros((), device=x.device) for g in dloss])
+        dx = torch.empty(B, Hh, W, Cc, device=x.device) if ctx.needs_input_grad[0] else None
+        arr = (C.c_void_p * n)(*[t.data_ptr() for t in tg])
+        H.check(H.lib().ramnet_pred_sigmoid_si_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), seg_pix, n, arr, _p(stats), _p(gs), weight,
+                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _st()), "pred_si_bwd")
+        return (dx, None, None, None, None) + (None,) * n
 
 
 class PredLinear(Function):

@@ -66,13 +66,27 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
     K = model.every_x_rgb_frame
     prev_super, prev_lstm = None, empty_states_lstm(K)
     terms, keys_seen = [], []
+    # the scale-invariant loss of the supervised predictions inside the prediction layer's own launches (ops.PredSigmoidSI): the model is
+    # told which keys and parameters for the duration of its forward call and hangs the loss term on the prediction it returns
+    si_par = (float(loss_params.get("weight", 1.0)), float(loss_params.get("n_lambda", 1.0))) if loss_type == "scale_invariant_loss" else None
+    ask = si_par is not None and ops.si_fusion() and isinstance(loss_composition, (list, tuple)) and hasattr(model, "_si_request")
     for item in sequence:
-        preds, supers, lstms = model(item, prev_super, prev_lstm)
+        if ask:
+            model._si_fuse = {"weight": si_par[0], "n_lambda": si_par[1], "keys": list(loss_composition)}
+        try:
+            preds, supers, lstms = model(item, prev_super, prev_lstm)
+        finally:
+            if ask:
+                model._si_fuse = None
         for key, value in preds.items():
             if not loss_composition or key in loss_composition:
                 w = loss_weights[loss_composition.index(key)]
                 target = item['depth_' + key].to(model.gpu)
-                terms.append(w * _nominal_loss(loss_type, value, target, loss_params))
+                fused = getattr(value, "_si_fused", None)
+                if fused is not None and ask and fused[2] == si_par and target.dtype == torch.float32 and fused[1] == target.data_ptr():
+                    terms.append(w * fused[0])
+                else:
+                    terms.append(w * _nominal_loss(loss_type, value, target, loss_params))
                 if grad_loss_weight is not None:
                     gterms.append(w * ops.multi_scale_grad_loss(value, target))
                 if mse_loss is not None:

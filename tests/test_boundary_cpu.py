@@ -39,7 +39,7 @@ def test_desc_struct_layout_matches_header_field_order():
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r"^(const\s+)?(float|int|int8_t|uint8_t|size_t)\s+", "", decl)
+            decl = re.sub(r"^(const\s+)?(float|int|int8_t|uint8_t|size_t|ramnet_wgrad_seg)\s+", "", decl)
             names += [re.sub(r"[\*\s]|\[\d+\]", "", n) for n in decl.split(",")]
         assert names == [f[0] for f in cls._fields_], cname
 

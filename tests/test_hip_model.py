@@ -447,6 +447,53 @@ def test_data_parallel_exact_global_batch_loss(overlap):
     assert (out["early_buckets"] > 0) == overlap and out["buckets"] >= 2, out
 
 
+@pytest.mark.parametrize("lc,nan,gw", [(["image", "events2"], 0.2, None), (["image"], 0.0, None), (["events0", "image"], 0.3, 0.25),
+                                       (["events1", "events2", "image"], 0.1, None)])
+def test_scale_invariant_loss_inside_the_prediction_layer(lc, nan, gw):
+    """trainer.sequence_loss asks the model for the scale-invariant loss (model/loss.py:6-9) of the supervised
+    predictions to be formed inside the prediction layer's launches (ops.PredSigmoidSI: statistics in the forward pass that writes the
+    prediction, the loss gradient in the backward pass that reads it) — against the separate ramnet_si_loss_fwd / _bwd launches
+    (ops.set_si_fusion(False), themselves pinned to the reference's loss.py by test_si_loss_golden_and_grad): loss values to 1e-6, every
+    gradient to 1e-5 of its maximum; NaN targets, one / two / three supervised keys (runs of slots and not), with the multi-scale
+    gradient loss sending a dense gradient into the same prediction; and no si_loss launch is left in the fused step."""
+    from rpg_ramnet_amd import ops, _hip as Hh
+    from rpg_ramnet_amd.trainer import sequence_loss
+    K = 3
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=K, loss_composition=lc)
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(5)
+    B, H, W, L = 2, 32, 48, 2
+    seq = [{k: v.to(model.gpu) for k, v in make_item(rng, B, H, W, K, 5, 1, True, nan).items()} for _ in range(L)]
+    for it in seq:
+        for k in lc:
+            it.setdefault("depth_" + k, (it["depth_image"] * 0.9 + 0.05).clone())
+    calls = []
+    Hh.set_tracer(lambda name, fn, args: (calls.append(name), fn(*args))[1])
+    res = {}
+    try:
+        for on in (True, False):
+            ops.set_si_fusion(on)
+            calls.clear()
+            model.zero_grad()
+            total, rep = sequence_loss(model, seq, lc, [1.0, 0.5, 2.0][:len(lc)], grad_loss_weight=gw)
+            total.backward()
+            torch.cuda.synchronize()
+            res[on] = (float(total.detach()), float(rep), {k: p.grad.clone() for k, p in model.named_parameters()}, list(calls))
+    finally:
+        ops.set_si_fusion(True)
+        Hh.set_tracer(None)
+    assert not any(c.startswith("ramnet_si_loss") for c in res[True][3]) and "ramnet_pred_sigmoid_si_fwd" in res[True][3]
+    assert sum(c == "ramnet_si_loss_fwd" for c in res[False][3]) == L * len(lc)
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-6)
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=1e-6)
+    gmax = max(float(g.abs().max()) for g in res[False][2].values())
+    for k, g in res[False][2].items():
+        # (the last bias: its SI-loss gradient is a sum over all pixels that cancels to ~1e-6 of the largest gradient — what is left is the
+        # rounding of the per-pixel terms, which the two paths form differently: fp32 map times y(1-y) against one double expression)
+        tol = 2e-3 if k.endswith("pred.conv2d.bias") else 1e-5
+        assert_close(res[True][2][k].cpu().numpy(), g.cpu().numpy(), tol, "fused SI loss: grad " + k, floor=1e-2 * gmax)
+
+
 def test_data_parallel_gradient_accumulation_with_early_buckets():
     """zero() -> backward() -> backward() -> all_reduce() with the overlapped reducer.  The first (armed) pass sends
     buckets from the end-of-backward fold; the second pass adds its gradients into buckets that already hold rank averages and every

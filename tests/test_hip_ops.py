@@ -453,7 +453,7 @@ def test_winograd_wgrad_raw(B, H, W, cin, cout, wgrad_nf):
     xg, dyg, yg = (nhwc(t).to(dev()).contiguous() for t in (x, dy, y))
     taps = ops.Taps.get("conv", 3, 1)
     for wino in (True, False, "2x4"):                   # F(2x2,3x3), direct, F(2x4,3x3) (csrc/conv_wgrad_wino6.hip)
-        ws = torch.zeros(24 * cin * cout, device=dev())
+        ws = torch.zeros(max(24 * cin * cout, Hh.lib().ramnet_wgrad_wino2x4_ws_floats(cin, cout)), device=dev())
         ws.wino, ws.wino6 = wino is True, wino == "2x4"
         bws = torch.zeros(cout, device=dev())
         for _ in range(2):                              # accumulates over launches (BPTT time steps)
@@ -614,6 +614,41 @@ def test_conv_gru_backward_stage_b_fused_equals_unfused(B, H, W, C, algo3x3):
             ops.set_gru_bwd_fused(True)
     for a, c in zip(res[True], res[False]):
         assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-5, "fused vs unfused stage B")
+
+
+@pytest.mark.parametrize("n,defer,B,H,W,C", [(5, 5, 2, 8, 16, 64), (5, 3, 1, 33, 45, 64), (6, 48, 2, 16, 22, 128), (3, 2, 8, 5, 43, 256)])
+def test_conv_gru_deferred_backward_weights_equal_per_update_launches(n, defer, B, H, W, C):
+    """ops.set_wgrad_defer: the backward-weights launches of n chained updates of ONE ConvGRU cell (submodules.py:436-454) queued and
+    reduced by multi-segment launches (ramnet_wgrad_desc.segs; F(2x4,3x3) kernel, per-split slabs) — queues that fill during the pass and a
+    remainder flushed when the engine finishes — against one launch per update: the same sums in another order (1e-5 of the tensor's
+    maximum), repeated runs bit-identical, input gradients untouched (they do not depend on the weight-gradient launches)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvGRU
+    torch.manual_seed(13)
+    m = ConvGRU(C, C, 3).to(dev())
+    xs = [torch.randn(B, H, W, C, device=dev()) for _ in range(n)]
+    h0 = torch.tanh(torch.randn(B, H, W, C, device=dev()))
+    wgt = torch.randn(B, H, W, C, device=dev())
+    res = []
+    ops.set_wgrad_winograd_2x4("force")
+    try:
+        for d in (defer, defer, 0):
+            ops.set_wgrad_defer(d)
+            m.zero_grad()
+            h = h0.clone().requires_grad_(True)
+            st = h
+            for x in xs:
+                st = m(x, st)
+            (st * wgt).sum().backward()
+            res.append([h.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    finally:
+        ops.set_wgrad_defer(0)
+        ops.set_wgrad_winograd_2x4("auto")
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c), "deferred launches are bit-reproducible"
+    assert torch.equal(res[0][0], res[2][0])
+    for a, c in zip(res[0][1:], res[2][1:]):
+        assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-5, "deferred vs per-update backward-weights")
 
 
 @pytest.mark.parametrize("n,B,H,W,C,wide", [(5, 2, 8, 12, 64, True), (3, 1, 7, 13, 32, False), (8, 1, 4, 6, 8, True), (2, 3, 5, 9, 128, True)])
