@@ -209,7 +209,7 @@ class KernelTimer:
         self.hbm = False        # also bracket the HBM-bound calls (warm-up steps only)
         self.names = {}         # launch signature -> kernel symbol
 
-    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None, nbytes=0.0):
+    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None, nbytes=0.0, sparse=1.0):
         """sig: hashable launch signature -> kernel symbol, learnt while every launch is bracketed (warm-up); with `only` set,
         launches whose signature maps to another symbol run un-bracketed.  tap_ratio = taps in the launch's list / taps of
         the layer it stands for (16/25 folded decoder, 36/25 space-to-depth encoder, else 1)."""
@@ -222,7 +222,9 @@ class KernelTimer:
         name = self.names[sig] = name_of()
         if self.only is not None and name != self.only:
             return
-        self.rec.append((name, s, e, alg, alg * tap_ratio * winograd_factor(name), nbytes, tag))
+        if name.startswith("conv_wino_r6_kernel"):      # the F(2x4) kernel runs the space-to-depth views dense (no skipped zero slices)
+            sparse = 1.0
+        self.rec.append((name, s, e, alg, alg * tap_ratio * sparse * winograd_factor(name), nbytes, tag))
 
     def install(self):
         from rpg_ramnet_amd import ops, _hip as Hh
@@ -266,8 +268,9 @@ class KernelTimer:
             nclass = 4 if (kw.get("wino24") and not parity4) else 1
             cin, nout = cin_of(x0, kw, w), Cout * (4 if kw.get("epi") == Hh.EPI_LSTM else 1)
             ratio = taps.n / float(taps.flop_taps)
+            sparse = 1.0
             if ops._S2D_SPARSE and (kw.get("in_mode", 0) == Hh.IN_S2D or kw.get("out_s2d")):
-                ratio *= S2D_SPARSE_FACTOR      # positions of the zero slices are not issued (ramnet_conv_desc.s2d_5x5)
+                sparse = S2D_SPARSE_FACTOR      # positions of the zero slices are not issued (ramnet_conv_desc.s2d_5x5; F(2x2) kernel only)
             if parity4:     # decoder backward-data: stands for a 5x5 convolution over the full-resolution gradient; runs 16 taps
                 alg = 2.0 * x0.shape[0] * x0.shape[1] * x0.shape[2] * 25 * x0.shape[3] * Cout      # over 4*C0 channels on the
                 ratio = 16.0 * 4 * Ho * Wo / (25.0 * x0.shape[1] * x0.shape[2])                    # padded low-resolution grid
@@ -277,7 +280,7 @@ class KernelTimer:
             if kw.get("epi") in (Hh.EPI_SIGMOID, Hh.EPI_GRU_BLEND) and kw.get("in_mode", 0) in (Hh.IN_CAT, Hh.IN_CAT_MUL):
                 tag = "gru_fwd_C%d" % (kw.get("C1") or 0)
             timer._bracket(lambda: conv0(x0, taps, w, out, Cout, **kw), last, sig_of("c", x0, taps, Cout, kw) + (isinstance(w, ops.PackRef),),
-                           alg, ratio, tag, conv_bytes(x0, taps, Cout, kw, cin, Ho, Wo, nout, nclass))
+                           alg, ratio, tag, conv_bytes(x0, taps, Cout, kw, cin, Ho, Wo, nout, nclass), sparse)
 
         def wgrad(x0, taps, dout, dw, Cout, **kw):
             if not timer.on:

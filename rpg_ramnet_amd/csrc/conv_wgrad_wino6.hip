@@ -71,6 +71,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     // ---- raw-data prefetch (as in conv_wgrad_wino.hip: buffer loads at lane + scalar offsets, out-of-image = out-of-range offset)
     float4 xr[NXS], xm[NXS], yr[NYS], ym[NYS];
     const bool second = (s.mode == RAMNET_IN_CAT || s.mode == RAMNET_IN_CAT_MUL) && c0 >= s.C0;
+    // space-to-depth view of a stride-2 5x5 encoder's input (RAMNET_IN_S2D, s.ld1 = log2 C0): the workgroup's 32 channels lie in ONE parity
+    // group g = (a, b) — logical pixel (iy, ix) is stored pixel (2 iy + a, 2 ix + b) of the [2 Hin][2 Win][C0] image: doubled pixel strides,
+    // (a, b) and the channel base folded into the buffer's base pointer
+    const bool s2d = s.mode == RAMNET_IN_S2D;
+    const int s2g = s2d ? c0 >> s.ld1 : 0, pxs = s2d ? 2 : 1, WinS = pxs * s.Win;
     const bool use_m = XMK == 1 || (XMK == 2 && second);
     const float m_one = use_m ? 0.f : 1.f;
     const int ldS = second ? s.ld1 : s.ld0;
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         const int sl = tid + i * NT, qd = sl % XQ, pix = sl / XQ;
         xpy[i] = pix / PW, xpx[i] = pix - xpy[i] * PW;
         xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
-        xoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * ldS + qd * 4) * 4u;
+        xoff[i] = (unsigned)((pxs * xpy[i] * WinS + pxs * xpx[i]) * ldS + qd * 4) * 4u;
         xmoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4) * 4u;
         xdst[i] = sl < XSLOTS ? (sl / XQ) * 32 + (sl % XQ) * 4 : -1;
     }
@@ -98,14 +103,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     // batch at a time: the walk is an increment with carries, and the segment — the tensors of one deferred ConvGRU cell update
     // (ramnet_wgrad_desc.segs) — changes at most a few times per workgroup: a real, almost never taken branch rebuilds the descriptors.
     int lb_ty = 0, lb_bx = 0, lb_b = 0, lb_seg = 0, lb_batch = 0;
-    const int pad_m = -(q.dy0 * s.Win + q.dx0);
+    const int pad_m = -(pxs * q.dy0 * WinS + pxs * q.dx0);
     const int padS = pad_m > 0 ? pad_m : 0;
     unsigned so_x = 0, so_m = 0, so_g = 0, so_gm = 0;
     auto rx = wino_rsrc(nullptr, 0u);
     auto rmk = rx, rg = rx, rgm = rx;
     auto set_seg = [&](int sg) {
         const ramnet_wgrad_seg &g = q.seg[sg];
-        const float *xsrc = second ? g.x1 + (c0 - s.C0) : g.x0 + c0;
+        const float *xsrc = second ? g.x1 + (c0 - s.C0) : s2d ? g.x0 + (c0 - (s2g << s.ld1)) + (long)((s2g >> 1) * WinS + (s2g & 1)) * ldS : g.x0 + c0;
         const float *msrc = s.mode == RAMNET_IN_RELUMASK ? g.xm + c0 : g.xm + (c0 - s.C0);
         rx = wino_rsrc(xsrc - (long)padS * ldS, WOOB);
         rmk = XMK ? wino_rsrc(msrc - (long)padS * s.ldm, WOOB) : rx;
@@ -140,7 +145,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         }
         lb_batch = batch;
         const int pix = (lb_b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
-        const int corner = pix + q.dy0 * s.Win + q.dx0;
+        const int corner = s2d ? ((lb_b * 2 * s.Hin + 2 * (G::YH * lb_ty + q.dy0)) * WinS + 2 * (YW * lb_bx + q.dx0))
+                               : pix + q.dy0 * s.Win + q.dx0;
         so_x = (unsigned)((corner + padS) * ldS) * 4u;
         if (XMK) so_m = (unsigned)((corner + padS) * s.ldm) * 4u;
         so_g = (unsigned)(pix * p.ldg) * 4u;
@@ -373,7 +379,8 @@ __global__ void unpack_wgrad_wino2x4_kernel(const float *__restrict__ ws, float 
 
 bool wgrad_wino6_eligible(const ramnet_wgrad_desc &d) {
     return d.ntaps == 9 && d.stride == 1 && d.Ho == d.Hin && d.Wo == d.Win &&
-           (d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK);
+           (d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK ||
+            (d.in_mode == RAMNET_IN_S2D && d.C0 >= 32 && (d.C0 & (d.C0 - 1)) == 0));
 }
 
 int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
@@ -391,6 +398,11 @@ int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
     q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    if (d.in_mode == RAMNET_IN_S2D) {       // Cin = the four parity groups; ld1 carries log2 C0
+        int sh = 0;
+        while ((1 << sh) < d.C0) ++sh;
+        q.src.Cin = 4 * d.C0, q.src.ld1 = sh;
+    }
     q.dy0 = dymin, q.dx0 = dxmin;
     // strips of 8 tiles: 4 x 16, 8 x 8 or 16 x 4 output pixels, whichever pads the map least (ties: the widest)
     long best = -1;
@@ -420,7 +432,7 @@ int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
     const int xmk = d.in_mode == RAMNET_IN_RELUMASK ? 1 : d.in_mode == RAMNET_IN_CAT_MUL ? 2 : 0;
     const bool gm = d.gmask != nullptr;
     {
-        const unsigned long long px = (unsigned long long)d.Hin * d.Win, ldx = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
+        const unsigned long long px = (unsigned long long)d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1), ldx = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
         RAMNET_CHECK_ARG(d.B * px * ldx * 4ull < WOOB && d.B * px * d.ldm * 4ull < WOOB &&
                          (unsigned long long)d.B * d.Ho * d.Wo * d.ldg * 4ull < WOOB && (unsigned long long)d.B * d.Ho * d.Wo * d.ldgm * 4ull < WOOB);
     }

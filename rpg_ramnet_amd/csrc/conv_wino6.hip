@@ -138,6 +138,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
         }
     };
 
+    // (requesting the patches of the first TWO chunks together — one memory round trip per workgroup instead of two — measured no
+    // difference, round 5: 281.0-281.5 against 280.7-280.8 ms per step; the other workgroup of the CU covers the prologue)
     pr.load(q.src, 0, clast);
 #pragma unroll
     for (int i = 0; i < 12; ++i)
@@ -300,6 +302,20 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
             }
         }
     };
+    if (q.s2d_shift) {
+        // out_s2d (backward-data of a stride-2 5x5 encoder over its space-to-depth view; LINEAR, no bias: checked on the host): output channel
+        // quad nq of logical pixel (oy, ox) is channel quad nq - g * C of full-resolution pixel (2 oy + (g >> 1), 2 ox + (g & 1)), g = nq / C
+        const int g = nq >> q.s2d_shift;
+#pragma unroll
+        for (int i = 0; i < 2 * NI; ++i) {
+            const int sl = tid + i * 256, pxl = NF == 2 ? sl >> 4 : sl >> 3;
+            const int oy = oy0 + pxl / RTW, ox = ox0 + pxl % RTW;
+            if (!nok || oy >= p.Ho || ox >= p.Wo) continue;
+            const size_t pix = ((size_t)b * p.HoF + 2 * oy + (g >> 1)) * p.WoF + 2 * ox + (g & 1);
+            st4(p.out + pix * p.ldo + (nq - (g << q.s2d_shift)), out4(pxl, qd * 4));
+        }
+        return;
+    }
     if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
     else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
     else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
@@ -373,8 +389,14 @@ static bool wino6_vec4(const ramnet_conv_desc &d) {
 static int g_w6_min_wgs = 150;                  // ramnet_wino2x4_config(): launch-size threshold (64-channel workgroups of 256 pixels)
 
 int wino6_eligible(const ramnet_conv_desc &d, int force) {
-    if (d.ntaps != 9 || d.stride != 1 || d.s2d_5x5 || d.out_s2d || d.frame) return 0;
-    if (d.in_mode != RAMNET_IN_PLAIN && d.in_mode != RAMNET_IN_CAT && d.in_mode != RAMNET_IN_CAT_MUL && d.in_mode != RAMNET_IN_RELUMASK) return 0;
+    if (d.ntaps != 9 || d.stride != 1 || d.frame) return 0;
+    // (space-to-depth views of the stride-2 5x5 encoders, round 5: dense — the zero slices of the view are not skipped here; 3.0 products per
+    // output against the 3.5 the F(2x2) kernel realises with its column masks)
+    if (d.in_mode != RAMNET_IN_PLAIN && d.in_mode != RAMNET_IN_CAT && d.in_mode != RAMNET_IN_CAT_MUL && d.in_mode != RAMNET_IN_RELUMASK &&
+        d.in_mode != RAMNET_IN_S2D) return 0;
+    if (d.in_mode == RAMNET_IN_S2D && (d.C0 < WK || (d.C0 & (d.C0 - 1)) != 0)) return 0;
+    if (d.out_s2d && (d.out_s2d < 8 || (d.out_s2d & (d.out_s2d - 1)) != 0 || d.Cout != 4 * d.out_s2d || d.epi != RAMNET_EPI_LINEAR || d.bias || d.beta != 0.f ||
+                      d.HoF != 2 * d.Ho || d.WoF != 2 * d.Wo || (d.in_mode != RAMNET_IN_PLAIN && d.in_mode != RAMNET_IN_RELUMASK))) return 0;
     if (d.epi == RAMNET_EPI_LSTM || d.Cout % 64 != 0 || !wino6_vec4(d)) return 0;
     if (d.epi == RAMNET_EPI_GRU_BWD && d.Cout % 128 != 0) return 0;          // a 64-channel block lies in one half of [dx | d(h.r)]
     int txg;
@@ -388,10 +410,15 @@ int wino6_eligible(const ramnet_conv_desc &d, int force) {
 }
 
 int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
-    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && !d.s2d_5x5 && !d.out_s2d && !d.frame && d.epi != RAMNET_EPI_LSTM);
-    RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK);
+    RAMNET_CHECK_ARG(d.ntaps == 9 && d.stride == 1 && !d.frame && d.epi != RAMNET_EPI_LSTM);
+    RAMNET_CHECK_ARG(d.in_mode == RAMNET_IN_PLAIN || d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL || d.in_mode == RAMNET_IN_RELUMASK ||
+                     d.in_mode == RAMNET_IN_S2D);
+    auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return (1 << sh) == v ? sh : -1; };
+    if (d.in_mode == RAMNET_IN_S2D) RAMNET_CHECK_ARG(d.C0 >= WK && log2_exact(d.C0) > 0);                 // a chunk lies in one parity group
     if (d.in_mode == RAMNET_IN_CAT || d.in_mode == RAMNET_IN_CAT_MUL) RAMNET_CHECK_ARG(d.C0 % WK == 0);   // chunks do not straddle the concatenation
     RAMNET_CHECK_ARG(wino6_vec4(d) && d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0);
+    if (d.out_s2d) RAMNET_CHECK_ARG(d.out_s2d >= 8 && log2_exact(d.out_s2d) > 0 && d.Cout == 4 * d.out_s2d && d.epi == RAMNET_EPI_LINEAR && !d.bias &&
+                                    d.beta == 0.f && d.HoF == 2 * d.Ho && d.WoF == 2 * d.Wo);
     if (d.epi == RAMNET_EPI_GRU_BWD) RAMNET_CHECK_ARG(d.Cout % 128 == 0);
     int dymin = 127, dxmin = 127;
     unsigned seen = 0;
@@ -411,12 +438,13 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
     q.src.ld0 = d.ld0, q.src.ld1 = d.ld1, q.src.ldm = d.ldm;
     q.src.C0 = d.C0, q.src.Cin = d.C0 + (cat ? d.C1 : 0);
     q.src.mode = d.in_mode, q.src.Hin = d.Hin, q.src.Win = d.Win;
+    if (d.in_mode == RAMNET_IN_S2D) q.src.Cin = 4 * d.C0, q.src.ld1 = log2_exact(d.C0);
     q.nchunks = cdiv(q.src.Cin, WK), q.nblk = cdiv(d.Cout, W6_BN);
     int txg;
     wino6_tile(d.Ho, d.Wo, txg);
     q.tiles_x = cdiv(d.Wo, 4 * txg), q.tiles_y = cdiv(d.Ho, 2 * (32 / txg));
     q.dy0 = dymin, q.dx0 = dxmin;
-    q.vec4 = 1, q.s2d_shift = 0, q.sparse = 0;
+    q.vec4 = 1, q.s2d_shift = d.out_s2d ? log2_exact(d.out_s2d) : 0, q.sparse = 0;
     // XCD-pinned channel groups for weights that do not fit an L2 (conv_wino.hip)
     const size_t wbytes = (size_t)q.nchunks * q.nblk * W6_U_FLOATS * sizeof(float);
     q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
@@ -426,7 +454,7 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
     const size_t ex = (size_t)4 * 4 * 32 * (nf * 32 + 4) * sizeof(float);
     {
-        const unsigned long long px = (unsigned long long)d.Hin * d.Win;
+        const unsigned long long px = (unsigned long long)d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1);
         int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
         ldmax = ldmax > d.ldm ? ldmax : d.ldm;
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
@@ -439,7 +467,8 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
         hipLaunchKernelGGL((conv_wino_r6_kernel<TXv, MDv>), grid, dim3(256), ex > pf ? ex : pf, st, d, q);          \
     } break;
 #define RAMNET_GO6_TX(TXv)                                                                                          \
-    RAMNET_GO6(TXv, RAMNET_IN_PLAIN) RAMNET_GO6(TXv, RAMNET_IN_CAT) RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL) RAMNET_GO6(TXv, RAMNET_IN_RELUMASK)
+    RAMNET_GO6(TXv, RAMNET_IN_PLAIN) RAMNET_GO6(TXv, RAMNET_IN_CAT) RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL) RAMNET_GO6(TXv, RAMNET_IN_RELUMASK) \
+    RAMNET_GO6(TXv, RAMNET_IN_S2D)
     switch (txg * 100 + d.in_mode) {
         RAMNET_GO6_TX(4)
         RAMNET_GO6_TX(2)

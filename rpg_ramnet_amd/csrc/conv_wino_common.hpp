@@ -69,23 +69,24 @@ struct WinoPatch {
     static __device__ __forceinline__ float4 bload(decltype(wino_rsrc(nullptr, 0u)) r, unsigned vo, int so) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, so, 0));
     }
-    // issue the loads of slot i for the 8 channels starting at c0 (wave-uniform)
-    __device__ __forceinline__ void load_slot(const InSrc &s, int c0, int i, int clast) {
+    // issue the loads of slot i for the 8 channels starting at c0 (wave-uniform) into (vo, mo)
+    __device__ __forceinline__ void load_slot_to(float4 &vo, float4 &mo, const InSrc &s, int c0, int i, int clast) {
         const unsigned last = c0 == clast ? 0xffffffffu : 0u;           // (scalar)
         if (MODE == RAMNET_IN_S2D) {            // ld1 = log2(C0): parity group g = (a*2 + c) of the chunk -> pixel (2i+a, 2j+c)
             const int g = c0 >> s.ld1;
-            v[i] = bload(r0, vo0[i] | (bad[i] & last), (((g >> 1) * 2 * s.Win + (g & 1)) * s.ld0 + (c0 - (g << s.ld1))) * 4);
+            vo = bload(r0, vo0[i] | (bad[i] & last), (((g >> 1) * 2 * s.Win + (g & 1)) * s.ld0 + (c0 - (g << s.ld1))) * 4);
         } else if (CAT) {
             // second (uniform; C0 % 8 == 0: a chunk lies in one tensor) selects descriptor and offsets — no branch, so that the
             // number of loads in flight is the same on every path (a join would force the compiler to drain them)
             const bool second = c0 >= s.C0;
-            v[i] = bload(second ? r1 : r0, second ? (vo1[i] | (bad[i] & last)) : vo0[i], (second ? c0 - s.C0 : c0) * 4);
-            if (MODE == RAMNET_IN_CAT_MUL) m[i] = bload(rm, second ? (vom[i] | (bad[i] & last)) : WOOB, (second ? c0 - s.C0 : 0) * 4);
+            vo = bload(second ? r1 : r0, second ? (vo1[i] | (bad[i] & last)) : vo0[i], (second ? c0 - s.C0 : c0) * 4);
+            if (MODE == RAMNET_IN_CAT_MUL) mo = bload(rm, second ? (vom[i] | (bad[i] & last)) : WOOB, (second ? c0 - s.C0 : 0) * 4);
         } else {
-            v[i] = bload(r0, vo0[i] | (bad[i] & last), c0 * 4);
-            if (MODE == RAMNET_IN_RELUMASK) m[i] = bload(rm, vom[i] | (bad[i] & last), c0 * 4);
+            vo = bload(r0, vo0[i] | (bad[i] & last), c0 * 4);
+            if (MODE == RAMNET_IN_RELUMASK) mo = bload(rm, vom[i] | (bad[i] & last), c0 * 4);
         }
     }
+    __device__ __forceinline__ void load_slot(const InSrc &s, int c0, int i, int clast) { load_slot_to(v[i], m[i], s, c0, i, clast); }
     __device__ __forceinline__ void load(const InSrc &s, int c0, int clast) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) load_slot(s, c0, i, clast);

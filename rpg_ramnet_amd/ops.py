@@ -267,7 +267,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
         d.algo = H.ALGO_WINOGRAD if wino else H.ALGO_DIRECT
         # the 3x3 view of a 5x5 stride-2 layer read / written in place: 11 of its 36 slices are zero by construction (s2d_weights)
         d.s2d_5x5 = int(wino and isinstance(w.cp, S2DConvParam) and _S2D_SPARSE and (in_mode == H.IN_S2D or out_s2d > 0))
-        if wino and w.cp.gates == 1 and os == (1, 1, 0, 0) and not isinstance(w.cp, S2DConvParam):
+        if wino and w.cp.gates == 1 and os == (1, 1, 0, 0) and (_S2D_2X4 or not isinstance(w.cp, S2DConvParam)):
             ref = w                      # candidate for F(2x4,3x3): the library decides once the descriptor is complete (below)
         w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
@@ -287,7 +287,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
         d.algo = H.ALGO_WINOGRAD24
     if ref is not None and _WINO_2X4 != "off" and H.lib().ramnet_conv_wino_variant(C.byref(d), int(_WINO_2X4 == "force")):
         # F(2x4,3x3) on the fine scales (csrc/conv_wino6.hip): its own Winograd-domain pack of the same parameters
-        d.algo, d.w = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4"))
+        d.algo, d.w, d.s2d_5x5 = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4")), 0      # (dense: the F(2x4) kernel skips no zero slices)
     if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD24) and cp is not None:
         # latency-bound launches (batch-1 streaming on the coarse scales) split their channel reduction: the library says how much
         # workspace the launch would use, the layer owns it (csrc/conv_wino.hip, ramnet_conv_desc.splitk_ws)
@@ -820,7 +820,7 @@ class ConvParam:
                                  and self.CinWs >= _WINO_MIN_CIN)
             # F(2x4,3x3) for the plain 3x3 layers (not the space-to-depth views): slabs of [24][Cin][Cout], half as many as F(2x2)'s
             self._ws.wino6 = bool(self._ws.wino and (_WGRAD_2X4 == "force" or (_WGRAD_2X4 == "auto" and _USE_SIDE))
-                                  and type(self) is ConvParam and self.CinWs >= 64)
+                                  and (type(self) is ConvParam or (_S2D_2X4 and self.Cin >= 128)) and self.CinWs >= 64)
             if self._ws.wino6:
                 self._ws.wino = False
                 self._ws.slabs = min(self._slabs, H.lib().ramnet_wgrad_wino2x4_slabs(self.CinWs, self.Cout))
@@ -942,7 +942,9 @@ class S2DConvParam(ConvParam):
         g3 = torch.zeros(self.Cout, self.Cin, 3, 3, device=w.device)
         L = H.lib()
         self._join_slabs()
-        if getattr(self._ws, "wino", False):
+        if getattr(self._ws, "wino6", False):
+            H.check(L.ramnet_unpack_wgrad_wino2x4(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino2x4")
+        elif getattr(self._ws, "wino", False):
             H.check(L.ramnet_unpack_wgrad_wino(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino")
         else:
             H.check(L.ramnet_unpack_wgrad(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, 3, 3, _st()), "ramnet_unpack_wgrad")
@@ -1109,6 +1111,13 @@ def _s2d_eligible(x, cp, k, stride, up):
 _S2D_FUSED = True
 # ... and skip the Winograd positions that the zero slices of that view annihilate (ramnet_conv_desc.s2d_5x5)
 _S2D_SPARSE = True
+# ... or run the view on the F(2x4,3x3) kernel (dense) where the library's size heuristics select it (the training batch)
+_S2D_2X4 = _os.environ.get("RAMNET_S2D_2X4", "1") != "0"      # (environment: A/B runs of bench.py)
+
+
+def set_space_to_depth_2x4(on):
+    global _S2D_2X4
+    _S2D_2X4 = bool(on)
 
 
 def set_space_to_depth_fused(on):

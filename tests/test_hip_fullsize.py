@@ -2,7 +2,9 @@
 (B=8, 256x344 crop, the 13 distinct layers of one pass) on the bench schedule (backward-weights on a side stream), against
 the oracle in float64 on the CPU — the grid-size dependent code paths (pixel-range splits joined by atomics, XCD remap,
 tile-shape choices, persistent workgroups) only run at these sizes.  Plus whole training steps at full resolution
-(configs[1] at B=2, L=2 and the configs[4] shape 480x640 with 10 bins) against the oracle.
+(configs[1] at B=2, L=2, the bench batch at L = 1 and L = 8, the configs[4] shape 480x640 with 10 bins) and the two long-horizon
+runs against the oracle's results on the same seeded inputs, which tests/golden/make_golden_fullsize.py computed once
+(tests/golden/fullsize.npz, round 5: the float64 oracle of these runs is ~6 minutes of host time per suite run otherwise).
 
 Reference semantics: RAM_Net/model/submodules.py:26-35 (ConvLayer), :87-97 (UpsampleConvLayer), :200-215 (ResidualBlock),
 :436-454 (ConvGRU); statenet.py:160-202 for the layer shapes.
@@ -11,9 +13,10 @@ import numpy as np
 import pytest
 import torch
 
+import fullsize_cases as fc
 from oracle import ramnet_ref
 from recipe import make_item
-from util import assert_close, build_hip_model, nchw, nhwc, ref_cfg
+from util import ELEM_FLOOR, assert_close, build_hip_model, load_golden, nchw, nhwc, ref_cfg
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -215,33 +218,36 @@ def test_pred_layer_full_size():
     assert_close(bg.grad.cpu().numpy(), bc.grad.numpy(), TOL, "pred db")
 
 
-def _training_step_vs_oracle(cfg, Bn, Hn, Wn, L, nan_frac):
-    """Loss and every parameter gradient of one BPTT step vs the float64 oracle.  Error of a tensor = max |difference| over its
-    largest entry (floored at 1 % of the largest gradient in the model).  Bounds: median over the 70 tensors <= 2e-3 (the
-    network-level bar of tests/test_hip_model.py), worst tensor <= 1e-2.  At this size (10^5 pixels x 10^2 layers x 12 passes)
-    every fp32 evaluation carries that much noise: bias gradients are cancelling sums of ~10^6 terms, and a few hidden ReLU
+def _training_step_vs_oracle(tag):
+    """Loss and every parameter gradient of one BPTT step (fullsize_cases.STEP_CASES[tag]) vs the float64 oracle's
+    (tests/golden/fullsize.npz: the loss, and per tensor its largest magnitude + 1024 seeded entries).  Error of a tensor = max
+    |difference| over the held entries / its largest entry (floored at 1 % of the largest gradient in the model).  Bounds: median over the
+    70 tensors <= 2e-3 (the network-level bar of tests/test_hip_model.py), worst tensor <= 1e-2.  At this size (10^5 pixels x 10^2 layers x
+    12 passes) every fp32 evaluation carries that much noise: bias gradients are cancelling sums of ~10^6 terms, and a few hidden ReLU
     pre-activations sit within rounding of zero.  Measured with tools/grad_noise_probe.py (profiles/r02_b_grad_noise_probe.txt):
     HIP Winograd median 6.6e-4 / worst 5.6e-3, HIP direct exact-fp32 kernels 4.8e-4 / 5.2e-3, the oracle itself in float32
     (PyTorch CPU) 2.5e-4 / 1.8e-2."""
     from rpg_ramnet_amd.trainer import sequence_loss
+    fx, over, Bn, Hn, Wn, L, nan_frac = fc.STEP_CASES[tag]
+    cfg, _ = ref_cfg(fx, **over)
+    z = load_golden("fullsize.npz")
     model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
-    K, lc = cfg["every_x_rgb_frame"], cfg["loss_composition"]
-    rng = np.random.default_rng(11)
-    seq = [make_item(rng, Bn, Hn, Wn, K, cfg["num_bins_events"], cfg["num_bins_rgb"], True, nan_frac) for _ in range(L)]
+    seq = fc.step_sequence(cfg, Bn, Hn, Wn, L, nan_frac)
     model.zero_grad()
-    total, _ = sequence_loss(model, seq, lc, [1, 1])
+    total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
     total.backward()
     torch.cuda.synchronize()
-    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
-    ref_total, _ = ramnet_ref.sequence_loss(sd, cfg, [{k: v.double() for k, v in it.items()} for it in seq], lc, [1, 1])
-    ref_total.backward()
-    np.testing.assert_allclose(float(total.detach()), float(ref_total.detach()), rtol=1e-4)
-    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+    np.testing.assert_allclose(float(total.detach()), float(z["step.%s.loss" % tag]), rtol=1e-4)
+    names = [k for k, _ in model.named_parameters()]
+    gmax = max(float(z["step.%s.g.%s.absmax" % (tag, k)]) for k in names)
     errs = []
     for k, p in model.named_parameters():
         assert p.grad is not None, k
-        scale = max(float(sd[k].grad.abs().max()), 1e-2 * gmax)
-        errs.append((float((p.grad.cpu().double() - sd[k].grad).abs().max()) / scale, k))
+        key = "step.%s.g.%s" % (tag, k)
+        ref = z[key + ".val"].astype(np.float64)
+        got = p.grad.detach().cpu().double().numpy().ravel()[fc.sample_idx(key, p.numel(), fc.N_GRAD)]
+        scale = max(float(z[key + ".absmax"]), 1e-2 * gmax)
+        errs.append((float(np.abs(got - ref).max()) / scale, k))
     errs.sort(reverse=True)
     print("gradient errors: worst", ["%s %.1e" % (k, e) for e, k in errs[:3]], "median %.1e" % errs[len(errs) // 2][0])
     assert errs[0][0] <= 1e-2, "grad %s: rel err %.3e" % (errs[0][1], errs[0][0])
@@ -249,28 +255,27 @@ def _training_step_vs_oracle(cfg, Bn, Hn, Wn, L, nan_frac):
 
 
 def test_config1_training_step_full_resolution_vs_oracle(bench_schedule):
-    """BASELINE configs[1] at reduced batch / length only (B=2, L=2; K=5, 5 bins, 256x344, SI loss on [image, events4]):
+    """BASELINE configs[1] at reduced batch / length (B=2, L=2; K=5, 5 bins, 256x344, SI loss on [image, events4]):
     loss and all 70 parameter gradients of one BPTT step on the bench's three-stream schedule vs the float64 oracle."""
-    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=5, loss_composition=["image", "events4"])
-    _training_step_vs_oracle(cfg, 2, H, W, 2, 0.0)
+    _training_step_vs_oracle("config1_B2_L2")
 
 
 def test_bench_batch_training_step_vs_oracle(bench_schedule):
     """VERDICT r3 weak #1b: gradients at the BENCH BATCH (B = 8, 256x344, K = 5, 5 bins — the grids, tile shapes and the F(2x4,3x3) kernel
-    selection of the measured step) against the float64 oracle, not only as properties: one data package per sequence (L = 1: six state
-    updates and decodes through BPTT; the oracle's float64 step at L = 8 would take ~15 minutes of the suite), loss and all 70 gradients."""
-    from rpg_ramnet_amd import _hip as Hh
-    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=5, loss_composition=["image", "events4"])
-    _training_step_vs_oracle(cfg, 8, H, W, 1, 0.0)
-    assert Hh.lib().ramnet_last_kernel() is not None
+    selection of the measured step) against the float64 oracle: one data package per sequence (L = 1)."""
+    _training_step_vs_oracle("bench_B8_L1")
+
+
+def test_bench_step_B8_L8_vs_oracle(bench_schedule):
+    """VERDICT r4 weak #1c / item 9: THE bench step — B = 8, L = 8, K = 5: 48 state updates and 16 supervised decodes through BPTT — loss
+    and all 70 gradients against the float64 oracle (ten minutes and ~200 GB of host memory when the fixture was made)."""
+    _training_step_vs_oracle("bench_B8_L8")
 
 
 def test_config4_shape_training_step_vs_oracle(bench_schedule):
     """BASELINE configs[4] shape: 640x480, 10-bin voxel grids (the 10-channel head runs conv_head_*<10> since round 3), 20 % NaN targets;
-    B=1, K=2, L=2 keeps the oracle to seconds."""
-    cfg, _ = ref_cfg("net_seeded_ramnet_bins10.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
-    assert cfg["num_bins_events"] == 10
-    _training_step_vs_oracle(cfg, 1, 480, 640, 2, 0.2)
+    B=1, K=2, L=2."""
+    _training_step_vs_oracle("config4_B1_L2")
 
 
 def test_config4_shape_forward_properties():
@@ -339,12 +344,6 @@ def test_backward_recovers_after_an_aborted_pass():
             assert_close(after[k].cpu().numpy(), clean[k].cpu().numpy(), 1e-5, "after aborted pass: " + k, floor=1e-2 * gmax)
 
 
-def _report(tag, got, ref):
-    from util import elem_rel_err, rel_err
-    return "%s max-norm %.2e elem(floor 1e-2) %.2e elem(floor 1e-3) %.2e" % (tag, rel_err(got, ref), elem_rel_err(got, ref, 1e-2),
-                                                                          elem_rel_err(got, ref, 1e-3))
-
-
 @pytest.fixture(params=["auto", "f2x4"])
 def wino_variant(request):
     """auto: the library's selection (batch 1 -> F(2x2,3x3)); f2x4: every eligible 3x3 launch on the F(2x4,3x3) kernel — the kernel the
@@ -355,99 +354,63 @@ def wino_variant(request):
     ops.set_winograd_2x4("auto")
 
 
-_ORACLE_RUNS = {}      # the float64 / fp32 oracle trajectories of the two long runs: computed once, shared by the two kernel variants
-
-
-def _oracle_long_horizon(sd, cfg, K, L):
-    """Items and oracle results of the 48-update run (the checker's 45 s of CPU time are spent once for both `wino_variant`s: the
-    seeded weights, the seeded inputs and therefore the oracle's outputs are the same)."""
-    if "long" not in _ORACLE_RUNS:
-        rng = np.random.default_rng(21)
-        rprev, rlstm, out = None, ramnet_ref.empty_states_lstm(K), []
-        with torch.no_grad():
-            for _ in range(L):
-                item = make_item(rng, 1, H, W, K, 5, 1)
-                rpreds, rsupers, rlstm = ramnet_ref.forward_recurrent(sd, cfg, {k: v.double() for k, v in item.items()}, rprev, rlstm)
-                rprev = rsupers["image"]
-                out.append((item, {k: v.numpy() for k, v in rpreds.items()}, [r.numpy() for r in rprev]))
-        _ORACLE_RUNS["long"] = out
-    return _ORACLE_RUNS["long"]
+def _close_to_fixture(z, key, got, tol, what):
+    """The max-norm and the element-wise relative error (tests/util.py) of `got` against the oracle tensor `key` of fullsize.npz over the
+    entries the fixture holds (8192 seeded positions; <key>.absmax = the largest magnitude of the WHOLE reference tensor)."""
+    ref = z[key + ".val"].astype(np.float64)
+    g = np.asarray(got, dtype=np.float64).ravel()[fc.sample_idx(key, int(np.asarray(got).size), fc.N_MAP)]
+    amax = max(float(z[key + ".absmax"]), 1e-30)
+    e = float(np.abs(g - ref).max()) / amax
+    ee = float((np.abs(g - ref) / np.maximum(np.abs(ref), ELEM_FLOOR * amax)).max())
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+    assert ee <= tol, "%s: element-wise rel err %.3e > %.1e (floor %.0e of max|ref| %.3e)" % (what, ee, tol, ELEM_FLOOR, amax)
+    return "%s max-norm %.2e elem %.2e" % (what, e, ee)
 
 
 def test_long_horizon_forward_full_resolution(wino_variant):
     """48 consecutive Winograd-fp32 state updates at the real resolution (B=1, 256x344, K=5, L=8 packages
     through ERGB2DepthRecurrent.forward, model/model.py:141-219) against the float64 oracle: every prediction of every package
-    and the three carried states, max-norm AND element-wise relative error <= 1e-3 (north star bar).  Round 4: also with every eligible
-    launch forced onto F(2x4,3x3) ("prove it end to end")."""
+    and the three carried states, max-norm AND element-wise relative error <= 1e-3 (north star bar) over 8192 seeded entries per map, the
+    last frame prediction over all of its pixels.  Round 4: also with every eligible launch forced onto F(2x4,3x3)."""
     cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=5)
     model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
-    sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
-    K, L = 5, 8
+    z = load_golden("fullsize.npz")
+    K = 5
     prev, lstm = None, ramnet_ref.empty_states_lstm(K)
     lines = []
     with torch.no_grad():
-        for l, (item, rpreds, rprev) in enumerate(_oracle_long_horizon(sd, cfg, K, L)):
+        for l, item in enumerate(fc.long_horizon_items()):
             preds, supers, lstm = model(item, prev, lstm)
             prev = supers["image"]
-            for k in rpreds:
-                assert_close(preds[k].cpu().numpy(), rpreds[k], 1e-3, "package %d pred %s" % (l, k), elem_tol=1e-3)
-            for i, (s, r) in enumerate(zip(prev, rprev)):
-                assert_close(s.cpu().numpy(), r, 1e-3, "package %d state %d" % (l, i), elem_tol=1e-3)
-            lines.append(_report("package %d image" % l, preds["image"].cpu().numpy(), rpreds["image"]) + " | " +
-                         _report("state2", prev[2].cpu().numpy(), rprev[2]))
-    print("\n".join(lines))
-
-
-def _oracle_stream_200(sd, ncfg):
-    """The 200-update irregular stream: its measurements in order, the oracle's decodes at the checkpoints and its final states (shared
-    by the two `wino_variant`s like the run above)."""
-    if "stream" not in _ORACLE_RUNS:
-        rng = np.random.default_rng(33)
-        ref_states = [torch.zeros(1, 64 * 2 ** i, H >> (i + 1), W >> (i + 1)) for i in range(3)]
-        n, steps = 0, []               # steps: ("events" | "rgb", tensor) or ("check", tag, reference decode)
-        with torch.no_grad():
-            while n < 200:
-                for _ in range(int(rng.integers(1, 9))):
-                    ev = torch.from_numpy(rng.standard_normal((1, 5, H, W)).astype(np.float32))
-                    ref_states, _ = ramnet_ref._encode(sd, ncfg, "events", ev, ref_states, None)
-                    steps.append(("events", ev))
-                    n += 1
-                img = torch.from_numpy(rng.random((1, 1, H, W)).astype(np.float32))
-                ref_states, _ = ramnet_ref._encode(sd, ncfg, "rgb", img, ref_states, None)
-                steps.append(("rgb", img))
-                n += 1
-                if n % 40 < 9:
-                    steps.append(("check", "after %d updates" % n, ramnet_ref._decode(sd, ncfg, ref_states).numpy()))
-            steps.append(("check", "after %d updates (end)" % n, ramnet_ref._decode(sd, ncfg, ref_states).numpy()))
-        _ORACLE_RUNS["stream"] = (steps, [r.numpy() for r in ref_states])
-    return _ORACLE_RUNS["stream"]
+            for k in preds:
+                lines.append(_close_to_fixture(z, "long.%d.pred.%s" % (l, k), preds[k].cpu().numpy(), 1e-3, "package %d pred %s" % (l, k)))
+            for i, s in enumerate(prev):
+                lines.append(_close_to_fixture(z, "long.%d.state%d" % (l, i), s.cpu().numpy(), 1e-3, "package %d state %d" % (l, i)))
+    assert_close(preds["image"].cpu().numpy(), z["long.last_image_full"], 1e-3, "last frame prediction, every pixel", elem_tol=1e-3)
+    print("\n".join(lines[-9:]))
 
 
 def test_streaming_200_updates_full_resolution(wino_variant):
     """configs[3]: batch-1 asynchronous streaming with a persistent state, 200 updates at 256x344 on an irregular schedule
     (1..8 event grids per frame, test.py:212-232 call pattern through update_events / update_image / decode), against the
-    oracle: predictions at checkpoints along the stream and the final states, max-norm and element-wise <= 1e-3.  (The oracle runs in
-    float32 here — its own error is ~4e-7 of a tensor's maximum, tests/test_oracle_golden.py — to keep 200 CPU updates at this size to
-    under a minute; the 48-update run above uses float64.)"""
+    oracle (float32: its own error is ~4e-7 of a tensor's maximum, tests/test_oracle_golden.py): predictions at checkpoints along the
+    stream and the final states, max-norm and element-wise <= 1e-3."""
     cfg, _ = ref_cfg("net_seeded_ramnet.npz")
     model = build_hip_model("ERGB2DepthRecurrent", cfg).eval()
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    steps, ref_final = _oracle_stream_200(sd, ramnet_ref.normalize_config(cfg))
+    z = load_golden("fullsize.npz")
     states = model.init_states(1, H, W)
-    lines = []
+    lines, c = [], 0
     with torch.no_grad():
-        for st in steps:
+        for st in fc.stream_200_schedule():
             if st[0] == "events":
                 states, _ = model.update_events(st[1], states)
             elif st[0] == "rgb":
                 states, _ = model.update_image(st[1], states)
             else:
-                got = model.decode(states).cpu().numpy()
-                assert_close(got, st[2], 1e-3, st[1], elem_tol=1e-3)
-                lines.append(_report(st[1], got, st[2]))
-    for i, (s, r) in enumerate(zip(states, ref_final)):
-        assert_close(s.permute(0, 3, 1, 2).cpu().numpy(), r, 1e-3, "final state %d" % i, elem_tol=1e-3)
-        lines.append(_report("final state %d" % i, s.permute(0, 3, 1, 2).cpu().numpy(), r))
+                lines.append(_close_to_fixture(z, "stream.check%d" % c, model.decode(states).cpu().numpy(), 1e-3, st[1]))
+                c += 1
+    for i, s in enumerate(states):
+        lines.append(_close_to_fixture(z, "stream.final_state%d" % i, s.permute(0, 3, 1, 2).cpu().numpy(), 1e-3, "final state %d" % i))
     print("\n".join(lines))
 
 

@@ -822,6 +822,12 @@ def test_voxel_grid_golden(name):
     gl, gr = voxel.voxel_indices(torch.from_numpy(ev).to(dev()), bins, W, H)
     assert np.array_equal(gl.cpu().numpy(), np.where(okl, il, -1)), "left indices must be bit-exact"
     assert np.array_equal(gr.cpu().numpy(), np.where(okr, ir, -1)), "right indices must be bit-exact"
+    # ... and against the REFERENCE's own index arrays: what events_to_voxel_grid_pytorch handed to its two index_add_ calls
+    # (event_tensor_utils.py:170-181), recorded by tests/golden/make_golden_voxel_indices.py — the valid votes in event order
+    zi = load_golden("voxel_indices.npz")
+    gln, grn = gl.cpu().numpy(), gr.cpu().numpy()
+    assert np.array_equal(gln[gln >= 0], zi["%s.ref_idx_left" % name]), "left indices vs the reference's"
+    assert np.array_equal(grn[grn >= 0], zi["%s.ref_idx_right" % name]), "right indices vs the reference's"
     g = voxel.events_to_voxel_grid(torch.from_numpy(ev).to(dev()), bins, W, H).cpu().numpy()
     ref = z["%s.grid_torch" % name]
     assert np.array_equal(g != 0, ref != 0) or np.abs(g - ref).max() < 1e-5

@@ -235,6 +235,10 @@ def test_voxel_grid(golden_dir, name):
     assert np.array_equal(g, ref), np.abs(g - ref).max()
     assert np.array_equal(g != 0, ref != 0)
     np.testing.assert_allclose(g, z["%s.grid_numpy" % name], atol=2e-6)
+    # the oracle's int64 indices == the reference's own (what its two index_add_ calls received: make_golden_voxel_indices.py)
+    il, _, okl, ir, _, okr = voxel_ref.voxel_votes(ev, bins, W, H)
+    zi = load(golden_dir, "voxel_indices.npz")
+    assert np.array_equal(il[okl], zi["%s.ref_idx_left" % name]) and np.array_equal(ir[okr], zi["%s.ref_idx_right" % name])
 
 
 def test_voxel_normalisation(golden_dir):
