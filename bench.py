@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--no-configs4-extra", action="store_true", help="skip extras.configs4_shape (a ~20 s run of the 480x640 / 10-bin / B=4 / L=16 workload in a process of its own)")
     ap.add_argument("--no-gru-bwd-fused", action="store_true", help="A/B: ConvGRU backward stage B as its own launch (ops.set_gru_bwd_fused(False))")
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
-    ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384; default 320)")
+    ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384; default 384)")
     ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
     ap.add_argument("--wgrad-defer", type=int, default=-1, help="ConvGRU cell updates per deferred multi-segment backward-weights launch "
                     "(ops.set_wgrad_defer; 0 = every update launches its own; default: the trainer's)")

@@ -166,7 +166,7 @@ typedef struct ramnet_wgrad_desc {
 
 /* Process-wide A/B options (they replace the RAMNET_* environment knobs of rounds 1-3): "voxel_sorted" (1; 0 = row-band / atomic
  * voxelizer forms), "fold_pair" (1; 0 = 32-channel folded decoders as 64 tiles x 32 channels — changes the layout ramnet_pack_weight_fold_wino
- * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel), "wgrad_wino_blocks" (320, <= 384: the same for the
+ * writes: re-pack), "wgrad_blocks" (512: workgroups per launch of the DIRECT backward-weights kernel), "wgrad_wino_blocks" (384 since round 5 — with the splits dealt to the XCDs: 279.7 ms per step against 281.0 at 320 —, <= 384: the same for the
  * Winograd backward-weights kernel — measured with F(2x4) in place: 384 -> 215.9, 320 -> 210.7, 256 -> 209.7, 192 -> 193.6 samples/s).
  * "wgrad_wino_nf" (1; 2: 32-channel output blocks per workgroup of the Winograd backward-weights kernel — 1 = 32 x 32 channels, 168 registers, three
  * workgroups per CU: six ConvGRU launches 1.54 -> 1.31 ms on their own; 2 = 32 x 64 channels, two per CU: what a caller that co-schedules these

@@ -33,6 +33,7 @@ struct WgradWino6Params {
     int bx_n, ty_n, nbatch;     // strips per row, strip rows per image, total (all segments)
     int dy0, dx0;               // offset of the first filter tap
     int nseg, seg_images;       // segments of the launch (ramnet_wgrad_desc.segs; 1: the descriptor's own tensors), images per segment
+    int splits, gy, gz, xcd_map; // tile splits, 32-channel input / output blocks; xcd_map: the 1-D grid deals the splits to the 8 XCDs
     ramnet_wgrad_seg seg[WG6_MAXSEG];
 };
 
@@ -59,7 +60,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
-    const int c0 = blockIdx.y * 32, n0 = blockIdx.z * 32;
+    // Workgroup -> (tile split, input block, output block).  The gy x gz workgroups of one split read the SAME strips (every input block
+    // the split's dy strips, every output block its x strips): consecutive workgroup ids go round-robin to the 8 XCDs (private L2s), so
+    // with splits % 8 == 0 XCD x is dealt the splits x, x + 8, ... and the workgroups of one split sit in consecutive slots of ONE XCD —
+    // a strip is fetched into one L2 instead of up to eight (L2 hit rate of the scale-0 launches 55-61 % before: profiles/r05_l2_*).
+    int sp_i, by_i, bz_i;
+    if (q.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = q.gy * q.gz;
+        sp_i = (slot / per) * 8 + xcd;
+        const int rem = slot % per;
+        by_i = rem % q.gy, bz_i = rem / q.gy;
+    } else {
+        sp_i = blockIdx.x % q.splits;
+        const int rem = blockIdx.x / q.splits;
+        by_i = rem % q.gy, bz_i = rem / q.gy;
+    }
+    const int c0 = by_i * 32, n0 = bz_i * 32;
     const InSrc &s = q.src;
 
     f32x16 acc[6];
@@ -240,8 +256,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         bn[o][0] = w0, bn[o][1] = e + f, bn[o][2] = e - f, bn[o][3] = fmaf(2.f, f4, e4), bn[o][4] = fmaf(-2.f, f4, e4), bn[o][5] = w3;
     };
 
-    int batch = (int)((long long)q.nbatch * blockIdx.x / gridDim.x);
-    const int last = (int)((long long)q.nbatch * (blockIdx.x + 1) / gridDim.x) - 1;
+    int batch = (int)((long long)q.nbatch * sp_i / q.splits);
+    const int last = (int)((long long)q.nbatch * (sp_i + 1) / q.splits) - 1;
     if (batch <= last) {
         load_first(batch);
         load_raw(batch);
@@ -299,10 +315,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     // a split's partial sums with its slab is 4 + 4 16-byte accesses per position instead of 16 + 16 4-byte ones at a Cout-float stride
     // (the join is ~12 % of a launch at the training batch: every workgroup runs it at the same time, behind the last MFMA).  Channels
     // beyond Cin / Cout inside a block hold zeros (their strips load as zeros).  ramnet_unpack_wgrad_wino2x4 reads the same layout.
-    const int nCiB = gridDim.y, nCoB = gridDim.z;
+    const int nCiB = q.gy, nCoB = q.gz;
     const bool slabs = p.dw_slabs > 0;
     const size_t slab_floats = (size_t)24 * nCiB * nCoB * 1024;
-    float *dwb = p.dw + (slabs ? (size_t)blockIdx.x * slab_floats : 0) + ((size_t)blockIdx.y * nCoB + blockIdx.z) * 1024 + lane * 16;
+    float *dwb = p.dw + (slabs ? (size_t)sp_i * slab_floats : 0) + ((size_t)by_i * nCoB + bz_i) * 1024 + lane * 16;
     const size_t pos_stride = (size_t)nCiB * nCoB * 1024;
     const bool neg = wave == 3;
     if (RAMNET_ABL & 256) {
@@ -335,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
             for (int r = 0; r < 16; ++r) atomicAdd(b + r, neg ? -acc[pl][r] : acc[pl][r]);
         }
     }
-    if (p.dbias != nullptr && blockIdx.y == 0) {
+    if (p.dbias != nullptr && by_i == 0) {
         __syncthreads();
         float *red = smem;                        // [NT / YQ][32]
         st4(red + (tid / YQ) * 32 + (tid % YQ) * 4, bsum);
@@ -344,7 +360,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
             float t = 0.f;
             for (int g = 0; g < NT / YQ; ++g) t += red[g * 32 + tid];
             if (n0 + tid < p.Cout) {
-                if (slabs) p.dbias[(size_t)blockIdx.x * p.Cout + n0 + tid] += t;
+                if (slabs) p.dbias[(size_t)sp_i * p.Cout + n0 + tid] += t;
                 else atomicAdd(p.dbias + n0 + tid, t);
             }
         }
@@ -426,7 +442,17 @@ int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
     if (splits > q.nbatch) splits = q.nbatch;
     if (d.dw_slabs > 0 && splits > d.dw_slabs) splits = d.dw_slabs;
     if (splits < 1) splits = 1;
-    const dim3 grid(splits, gy, gz);
+    // splits dealt to the XCDs (kernel): from 8 splits up, a multiple of 8 (the nearest the slabs and the batches allow)
+    q.xcd_map = 0;
+#ifndef RAMNET_NO_XCD_MAP
+    if (splits >= 8) {
+        int s8 = (splits + 4) / 8 * 8;
+        if (s8 > q.nbatch || (d.dw_slabs > 0 && s8 > d.dw_slabs)) s8 = splits / 8 * 8;
+        splits = s8, q.xcd_map = 1;
+    }
+#endif
+    q.splits = splits, q.gy = gy, q.gz = gz;
+    const dim3 grid(splits * gy * gz);
     const int xp = txb == 4 ? G6Geom<4>::XP : txb == 2 ? G6Geom<2>::XP : G6Geom<1>::XP;
     const size_t lds = ((size_t)2 * (xp + G6Geom<4>::YP) + 256 * 4) * sizeof(float);
     const int xmk = d.in_mode == RAMNET_IN_RELUMASK ? 1 : d.in_mode == RAMNET_IN_CAT_MUL ? 2 : 0;

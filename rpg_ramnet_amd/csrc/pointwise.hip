@@ -751,7 +751,7 @@ extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
 
 // Process-wide A/B options (tests and tuning runs; the environment variables they replace are gone since round 4)
 namespace ramnet {
-int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 320, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1;
+int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1;
 }
 extern "C" int ramnet_set_option(const char *name, int value) {
     RAMNET_CHECK_ARG(name != nullptr);
