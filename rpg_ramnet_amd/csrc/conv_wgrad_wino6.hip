@@ -41,10 +41,17 @@ struct WgradWino6Params {
 template <int TXB> struct G6Geom {
     static constexpr int TYB = 8 / TXB, YH = 2 * TYB, YW = 4 * TXB, PH = YH + 2, PW = YW + 2;
     static constexpr int XPIX = PH * PW, XSLOTS = XPIX * 8, NXS = (XSLOTS + 255) / 256;
-    static constexpr int XP = XPIX * 32;           // raw input strip [PH x PW pixels][32 channels]
-    static constexpr int YP = YH * YW * 32;        // raw gradient strip [64 pixels][32 channels]
+    // LDS strips are CHANNEL-major (round 5): [32 channels][rows][row pitch] floats.  The MFMA operands put the lanes along the channels, so
+    // a lane's window row (6 consecutive pixels) / gradient row (4) is contiguous: one ds_read_b128 + one ds_read_b64 / one ds_read_b128
+    // instead of 6 / 4 ds_read_b32 at a 32-float stride (20 -> 6 LDS reads per tile pair and wave, and no address arithmetic: the offsets
+    // are immediates).  RPX: row pitch (a multiple of 4 >= PW: 16-byte aligned tile origins); CPX / CPY: channel pitch with CP / 4 ODD — the 16
+    // lanes a ds_read_b128 serves per cycle then fall on 16 distinct 4-bank groups (conflict-free); the staging stores become four
+    // ds_write_b32 per 16-byte slot (immediate offsets j * CP), two-way conflicts between channel quads q and q + 4.
+    static constexpr int RPX = (PW + 3) / 4 * 4, CPX = ((PH * RPX / 4) | 1) * 4, CPY = ((YH * YW / 4) | 1) * 4;
+    static constexpr int XP = 32 * CPX;            // raw input strip [32 channels][PH rows][RPX]
+    static constexpr int YP = 32 * CPY;            // raw gradient strip [32 channels][YH x YW pixels]
     // tile pair st (tiles 2 st, 2 st + 1; the lane's tile = 2 st + kk): offsets of its window / output origin that do not depend on the lane
-    static constexpr int sx(int st) { return (TXB == 4 ? (st >> 1) * 2 * PW + (st & 1) * 8 : TXB == 2 ? st * 2 * PW : st * 4 * PW) * 32; }
+    static constexpr int sx(int st) { return TXB == 4 ? (st >> 1) * 2 * RPX + (st & 1) * 8 : TXB == 2 ? st * 2 * RPX : st * 4 * RPX; }
     static constexpr int sy(int st) { return TXB == 4 ? (st >> 1) * 2 * YW + (st & 1) * 8 : TXB == 2 ? st * 2 * YW : st * 4 * YW; }
 };
 
@@ -53,10 +60,10 @@ template <int XMK, bool GM, int TXB>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet_wgrad_desc p, const WgradWino6Params q) {
     using G = G6Geom<TXB>;
     constexpr int NT = 256, XQ = 8, YQ = 8, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
-    constexpr int PW = G::PW, YW = G::YW;
+    constexpr int PW = G::PW, YW = G::YW, RPX = G::RPX, CPX = G::CPX, CPY = G::CPY;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xp = smem;                   // [2][XPIX][32]
-    float *Yp = smem + 2 * GR_XP;       // [2][64][32]
+    float *Xp = smem;                   // [2][32][CPX]
+    float *Yp = smem + 2 * GR_XP;       // [2][32][CPY]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
         xoff[i] = (unsigned)((pxs * xpy[i] * WinS + pxs * xpx[i]) * ldS + qd * 4) * 4u;
         xmoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4) * 4u;
-        xdst[i] = sl < XSLOTS ? (sl / XQ) * 32 + (sl % XQ) * 4 : -1;
+        xdst[i] = sl < XSLOTS ? (qd * 4) * CPX + xpy[i] * RPX + xpx[i] : -1;
     }
 #pragma unroll
     for (int i = 0; i < NYS; ++i) {
@@ -169,7 +176,9 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         if (GM) so_gm = (unsigned)(pix * p.ldgm) * 4u;
     };
     auto bload = [](decltype(rx) r, unsigned vo, unsigned so) {
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, (int)so, 0));
+        // (the batch offset is wave-uniform; when the register allocator parks it in a VGPR — this kernel runs at the SGPR limit — the
+        // compiler otherwise wraps every load in a waterfall loop: 9 instructions and an exec-mask round trip per load)
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, __builtin_amdgcn_readfirstlane((int)so), 0));
     };
     auto load_x = [&](int i) {
         const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
@@ -196,14 +205,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         if (XMK == 1)
             r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
         if (XMK == 2) r = make_float4(r.x * (xm[i].x + m_one), r.y * (xm[i].y + m_one), r.z * (xm[i].z + m_one), r.w * (xm[i].w + m_one));
-        st4(xdst[i] >= 0 ? xb + xdst[i] : scratch, r);
+        float *d = xdst[i] >= 0 ? xb + xdst[i] : scratch;
+        const int cp = xdst[i] >= 0 ? CPX : 1;          // (threads without a slot: four floats of their scratch cell)
+        d[0] = r.x, d[cp] = r.y, d[2 * cp] = r.z, d[3 * cp] = r.w;
     };
     float bias_on = 1.f;                          // 0 for the clamped re-store of the last batch
     auto store_y = [&](int i, float *yb) {
         const int sl = tid + i * NT;
         float4 r = yr[i];
         if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
-        st4(yb + (sl / YQ) * 32 + (sl % YQ) * 4, r);
+        float *d = yb + ((sl % YQ) * 4) * CPY + sl / YQ;
+        d[0] = r.x, d[CPY] = r.y, d[2 * CPY] = r.z, d[3 * CPY] = r.w;
         bsum = make_float4(bsum.x + bias_on * r.x, bsum.y + bias_on * r.y, bsum.z + bias_on * r.z, bsum.w + bias_on * r.w);
     };
 
@@ -215,23 +227,30 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     const float cb = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
     const int yr0 = wave == 3 ? YW : 0;
     // the lane's tile of a pair: TXB >= 2: the next tile column (4 pixels), TXB = 1: the next tile row (2 pixel rows)
-    const int kx = TXB == 1 ? kk * 2 * PW : kk * 4, ky = TXB == 1 ? kk * 2 * YW : kk * 4;
-    const int xa_off = (ra * PW + kx) * 32 + l31, xb_off = (rb * PW + kx) * 32 + l31;
-    const int y_off = ky * 32 + l31;
+    const int kx = TXB == 1 ? kk * 2 * RPX : kk * 4, ky = TXB == 1 ? kk * 2 * YW : kk * 4;
+    const int xa_off = l31 * CPX + ra * RPX + kx, xb_off = l31 * CPX + rb * RPX + kx;
+    const int y_off = l31 * CPY + ky;
     float da[6], db[6], g0[4], g1[4];             // raw operands of the tile pair being prepared
     float an[2][6], bn[2][6];                     // operand sets of tile pairs st & 1 = 0 / 1
     auto fetch_x = [&](const float *xc, int st) {
+        if (RAMNET_ABL & 2) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            if (RAMNET_ABL & 2) { RAMNET_OPQ(da[c]); RAMNET_OPQ(db[c]); }
-            else da[c] = xc[xa_off + G::sx(st) + c * 32], db[c] = xc[xb_off + G::sx(st) + c * 32];
+            for (int c = 0; c < 6; ++c) { RAMNET_OPQ(da[c]); RAMNET_OPQ(db[c]); }
+        } else {
+            const float4 a4 = ld4(xc + xa_off + G::sx(st)), b4 = ld4(xc + xb_off + G::sx(st));
+            const float2 a2 = *reinterpret_cast<const float2 *>(xc + xa_off + G::sx(st) + 4), b2 = *reinterpret_cast<const float2 *>(xc + xb_off + G::sx(st) + 4);
+            da[0] = a4.x, da[1] = a4.y, da[2] = a4.z, da[3] = a4.w, da[4] = a2.x, da[5] = a2.y;
+            db[0] = b4.x, db[1] = b4.y, db[2] = b4.z, db[3] = b4.w, db[4] = b2.x, db[5] = b2.y;
         }
     };
     auto fetch_y = [&](const float *yc, int st) {
+        if (RAMNET_ABL & 2) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (RAMNET_ABL & 2) { RAMNET_OPQ(g0[c]); RAMNET_OPQ(g1[c]); }
-            else g0[c] = yc[y_off + (yr0 + G::sy(st) + c) * 32], g1[c] = yc[y_off + (YW + G::sy(st) + c) * 32];
+            for (int c = 0; c < 4; ++c) { RAMNET_OPQ(g0[c]); RAMNET_OPQ(g1[c]); }
+        } else {
+            const float4 a4 = ld4(yc + y_off + yr0 + G::sy(st)), b4 = ld4(yc + y_off + YW + G::sy(st));
+            g0[0] = a4.x, g0[1] = a4.y, g0[2] = a4.z, g0[3] = a4.w;
+            g1[0] = b4.x, g1[1] = b4.y, g1[2] = b4.z, g1[3] = b4.w;
         }
     };
     // B_c^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]   (conv_wino6.hip)

@@ -29,8 +29,11 @@ def test_full_size_conv_is_positively_homogeneous_and_shift_consistent():
         # translation by one output pixel (= 2 input pixels) away from the border
         xs = torch.roll(x, shifts=(2, 2), dims=(1, 2))
         ys = m(xs)
+        # (a shift by one output pixel moves every pixel to another position of its Winograd tile — 2 x 4 since the encoders' views run the
+        # F(2x4,3x3) kernel (round 5; column-transform coefficients up to 8): the two evaluations round differently, 1.9e-6 measured; 1e-6 held
+        # for the 2 x 2 tiles of F(2x2))
         assert_close(ys[:, 4:-4, 4:-4].cpu().numpy(), torch.roll(y1, shifts=(1, 1), dims=(1, 2))[:, 4:-4, 4:-4].cpu().numpy(),
-                     1e-6, "shift equivariance")
+                     4e-6, "shift equivariance")
 
 
 def test_full_size_network_is_batch_permutation_equivariant_and_deterministic():
