@@ -186,6 +186,9 @@ HBM_CALLS = {
     "ramnet_si_loss_bwd": lambda a: 12.0 * a[2],
     "ramnet_pred_sigmoid_fwd": lambda a: (4.0 * a[2] + 4.0) * a[6],
     "ramnet_pred_sigmoid_bwd": lambda a: (8.0 * a[2] + 8.0) * a[10],
+    # prediction layer + SI loss in one pass (round 5): x read, y written, target read / x read, dx written, y and target read
+    "ramnet_pred_sigmoid_si_fwd": lambda a: (4.0 * a[2] + 8.0) * a[6] * a[7],
+    "ramnet_pred_sigmoid_si_bwd": lambda a: (8.0 * a[2] + 8.0) * a[6] * a[7],
     "ramnet_gru_bwd_a": lambda a: 28.0 * a[8] * a[7],      # (a[9] = leading dimension of dh')
     "ramnet_gru_bwd_a2": lambda a: 28.0 * a[8] * a[7],     # (stage B runs in the epilogue of the candidate convolution's backward-data launch)
     "ramnet_gru_bwd_b": lambda a: 24.0 * a[6] * a[5],

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     // Workgroup -> (tile split, input block, output block).  The gy x gz workgroups of one split read the SAME strips (every input block
     // the split's dy strips, every output block its x strips): consecutive workgroup ids go round-robin to the 8 XCDs (private L2s), so
     // with splits % 8 == 0 XCD x is dealt the splits x, x + 8, ... and the workgroups of one split sit in consecutive slots of ONE XCD —
-    // a strip is fetched into one L2 instead of up to eight (L2 hit rate of the scale-0 launches 55-61 % before: profiles/r05_l2_*).
+    // a strip is fetched into one L2 instead of up to eight (L2 hit rate of the scale-0 launches 55-61 % before: profiles/r05_z_pmc_l2.txt).
     int sp_i, by_i, bz_i;
     if (q.xcd_map) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = q.gy * q.gz;
