@@ -136,7 +136,15 @@ def get_fold_upsample():
     return _FOLD_UP
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _st():
+    """The current HIP stream of the current device as a void* — through torch's C entry points (0.3 us): torch.cuda.current_stream() builds
+    a Stream object behind three Python wrappers (~10 us, ~600 calls per training step on the launch path)."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -406,7 +414,9 @@ def branch_stream(dev, i):
 def _side_stream(dev):
     st = _SIDE.get(dev)
     if st is None:
-        st = _SIDE[dev] = torch.cuda.Stream(device=dev)       # (a lower stream priority measured no effect)
+        # (a lower stream priority measured no effect; a second side stream for the decoders' backward-weights path neither: 280.9 / 280.7
+        # against 280.9 / 280.5 ms per step, round 5)
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
     return st
 
 
