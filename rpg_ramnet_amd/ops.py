@@ -893,6 +893,21 @@ class ConvParam:
             H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), ns, n, _st()), "ramnet_reduce_slabs")
             H.check(H.lib().ramnet_reduce_slabs(_p(self._bws), ns, self.Cout, _st()), "ramnet_reduce_slabs")
 
+    def _zero_ws(self):
+        """Zero what the pass used of the gradient workspace for the next one: slab 0 only where the slabs were joined
+        (ramnet_reduce_slabs leaves slabs 1.. zeroed), not the whole buffer sized for the largest layout."""
+        w6, wn = getattr(self._ws, "wino6", False), getattr(self._ws, "wino", False)
+        ns = getattr(self._ws, "slabs", 1)
+        if w6:
+            n = H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout)
+        elif wn:
+            n = 16 * self.CinWs * self.Cout
+        else:
+            n, ns = self.k * self.k * self.CinWs * self.Cout, 1
+        joined = ns > 1 and (w6 or wn)
+        self._ws[:n if joined else min(self._ws.numel(), n * max(ns, 1))].zero_()
+        self._bws[:self.Cout if joined else self._bws.numel()].zero_()
+
     def finalize(self):
         if self._fold_used:
             self._finalize_fold()
@@ -920,8 +935,7 @@ class ConvParam:
             if b is not None and b.shape[0] == n:      # (transposed conv: bias has Cout_t entries, handled by its op)
                 ensure_grad(b).add_(self._bws[off:off + n])
             off += n
-        self._ws.zero_()
-        self._bws.zero_()
+        self._zero_ws()
         self._dirty = self._ws_used = False
 
 
@@ -961,8 +975,7 @@ class S2DConvParam(ConvParam):
         ensure_grad(w).add_(s2d_weights_adjoint(g3, self.parent.Cin))
         if b is not None:
             ensure_grad(b).add_(self._bws[:self.Cout])
-        self._ws.zero_()
-        self._bws.zero_()
+        self._zero_ws()
         self._dirty = self._ws_used = False
 
 

@@ -519,6 +519,66 @@ def test_winograd_wgrad_slabs_bit_reproducible(B, H, W, cin, cout, wgrad_nf):
     assert_close(g1.cpu().numpy(), res[0][0], 1e-5, "atomic form vs slabs")
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 32, 48, 64, 128), (2, 9, 43, 96, 64), (8, 16, 22, 128, 128)])
+def test_winograd2x4_wgrad_slabs_bit_reproducible(B, H, W, cin, cout):
+    """The F(2x4,3x3) backward-weights kernel (csrc/conv_wgrad_wino6.hip) with per-split slabs in the BLOCKED layout of round 5
+    (ramnet_wgrad_wino2x4_ws_floats: one MFMA lane's 16 accumulators = 64 contiguous bytes, 16-byte read-modify-write joins, tile splits dealt
+    to the XCDs from 8 splits up): two passes of three accumulating launches give BIT-IDENTICAL weight and bias gradients, equal to float64
+    autograd; the atomic form (one slab) agrees to rounding; a 2-segment launch (ramnet_wgrad_desc.segs) equals two launches to rounding."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(14)
+    x = torch.randn(B, cin, H, W)
+    dy = torch.randn(B, cout, H, W)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, bias, 1, 1) * dy.double()).sum().backward()
+    xg, dyg = (nhwc(t).to(dev()).contiguous() for t in (x, dy))
+    taps = ops.Taps.get("conv", 3, 1)
+    L = Hh.lib()
+    slabs, n = L.ramnet_wgrad_wino2x4_slabs(cin, cout), L.ramnet_wgrad_wino2x4_ws_floats(cin, cout)
+    assert slabs > 1
+
+    def unpack(ws):
+        grad = torch.zeros(cout, cin, 3, 3, device=dev())
+        Hh.check(L.ramnet_unpack_wgrad_wino2x4(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, ops._st()), "unpack")
+        return grad.cpu().numpy()
+    res = []
+    for _ in range(2):
+        ws = torch.zeros(slabs * n, device=dev())
+        ws.wino, ws.wino6, ws.slabs = False, True, slabs
+        bws = torch.zeros(slabs * cout, device=dev())
+        for _k in range(3):
+            ops.wgrad_launch(xg, taps, dyg, ws, cout, dbias=bws)
+        assert Hh.lib().ramnet_last_kernel().decode().startswith("conv_wgrad_wino_r6_kernel")
+        assert float(ws[n:].abs().max()) > 0                        # more than one slab really is in use
+        Hh.check(L.ramnet_reduce_slabs(ops._p(ws), slabs, n, ops._st()), "reduce")
+        Hh.check(L.ramnet_reduce_slabs(ops._p(bws), slabs, cout, ops._st()), "reduce")
+        res.append((unpack(ws), bws[:cout].cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert_close(res[0][0], 3 * w.grad.numpy(), TOL, "dW slabs")
+    assert_close(res[0][1], 3 * bias.grad.numpy(), TOL, "db slabs")
+    ws1 = torch.zeros(n, device=dev())
+    ws1.wino, ws1.wino6 = False, True
+    b1 = torch.zeros(cout, device=dev())
+    for _k in range(3):
+        ops.wgrad_launch(xg, taps, dyg, ws1, cout, dbias=b1)
+    assert_close(unpack(ws1), res[0][0], 1e-5, "atomic form vs slabs")
+    # two segments in one launch (the same tensors twice) + one plain launch == three launches
+    ws2 = torch.zeros(slabs * n, device=dev())
+    ws2.wino, ws2.wino6, ws2.slabs = False, True, slabs
+    b2 = torch.zeros(slabs * cout, device=dev())
+    segs = (Hh.WgradSeg * 2)()
+    for sg in segs:
+        sg.x0, sg.dout = ops._p(xg), ops._p(dyg)
+    ops.wgrad_launch(xg, taps, dyg, ws2, cout, dbias=b2, segs=segs)
+    ops.wgrad_launch(xg, taps, dyg, ws2, cout, dbias=b2)
+    Hh.check(L.ramnet_reduce_slabs(ops._p(ws2), slabs, n, ops._st()), "reduce")
+    Hh.check(L.ramnet_reduce_slabs(ops._p(b2), slabs, cout, ops._st()), "reduce")
+    assert_close(unpack(ws2), res[0][0], 1e-5, "two segments + one launch vs three launches")
+    assert_close(b2[:cout].cpu().numpy(), res[0][1], 1e-5, "bias: two segments + one launch vs three launches")
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_residual_block(B, H, W, C, algo3x3):
     from rpg_ramnet_amd.model.submodules import ResidualBlock
