@@ -211,17 +211,24 @@ class KernelTimer:
         self.only = None        # when set: bracket only launches of this kernel symbol (keeps the timed region unperturbed)
         self.hbm = False        # also bracket the HBM-bound calls (warm-up steps only)
         self.names = {}         # launch signature -> kernel symbol
+        self.ext = {}           # raw stream handle -> torch.cuda.ExternalStream (event brackets on explicitly named launch streams)
 
-    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None, nbytes=0.0, sparse=1.0):
+    def _bracket(self, fn, name_of, sig, alg, tap_ratio, tag=None, nbytes=0.0, sparse=1.0, stream=None):
         """sig: hashable launch signature -> kernel symbol, learnt while every launch is bracketed (warm-up); with `only` set,
         launches whose signature maps to another symbol run un-bracketed.  tap_ratio = taps in the launch's list / taps of
         the layer it stands for (16/25 folded decoder, 36/25 space-to-depth encoder, else 1)."""
         if self.only is not None and self.names.get(sig, self.only) != self.only:
             return fn()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        st = None
+        if stream is not None:            # the launch names its stream (backward-weights on the side stream): bracket it THERE
+            raw = getattr(stream, "value", stream)
+            st = self.ext.get(raw)
+            if st is None:
+                st = self.ext[raw] = torch.cuda.ExternalStream(raw)
+        s.record(st) if st is not None else s.record()
         fn()
-        e.record()
+        e.record(st) if st is not None else e.record()
         name = self.names[sig] = name_of()
         if self.only is not None and name != self.only:
             return
@@ -302,7 +309,7 @@ class KernelTimer:
             npos = 100 if kw.get("wino24") else 24 if getattr(dw, "wino6", False) else 16 if getattr(dw, "wino", False) else taps.n
             timer._bracket(lambda: wgrad0(x0, taps, dout, dw, Cout, **kw), last,
                            sig_of("w", x0, taps, Cout, kw) + (getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "head_cin", 0)),
-                           alg, taps.n / float(taps.flop_taps), None, 4.0 * (rd + 2 * npos * cin * Cout))
+                           alg, taps.n / float(taps.flop_taps), None, 4.0 * (rd + 2 * npos * cin * Cout), stream=kw.get("stream"))
 
         def multi(x0, w, out, Cout, classes, **kw):
             if not timer.on:

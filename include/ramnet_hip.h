@@ -181,6 +181,9 @@ int ramnet_abi_version(void);
 /* Symbol (template arguments included, as rocprofv3 prints it without spaces) of the MFMA kernel the calling thread's most
  * recent ramnet_conv_launch / ramnet_conv_launch_multi / ramnet_wgrad_launch enqueued; "" before the first launch.  For profilers. */
 const char *ramnet_last_kernel(void);
+/* Stream `to` waits for the work enqueued on stream `from` so far (one reused event per calling thread and device; legal inside a stream
+ * capture, where it joins `to` to the capture) — the fork of the backward-weights stream off the backward-data chain (ABI 20).        */
+int ramnet_stream_fork(void *from, void *to);
 
 /* ---- small fp32 GEMMs (border corrections of the folded upsample-conv and their gradients; csrc/gemm_skinny.hip) ----
  * trans_a = 0:  C[M][N] (=, or += when accumulate) A[M][K] * B[K][N]       (K % 4 == 0, rows of A 16-byte aligned)

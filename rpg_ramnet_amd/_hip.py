@@ -72,6 +72,7 @@ _SIGS = {
     "ramnet_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "ramnet_get_option": (C.c_int, [C.c_char_p]),
     "ramnet_last_kernel": (C.c_char_p, []),
+    "ramnet_stream_fork": (C.c_int, [_fp, _fp]),
     "ramnet_gemm": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 9 + [C.c_long] * 3 + [_fp]),
     "ramnet_gemm2": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long, C.c_int, _fp, _fp, _fp, C.c_int, C.c_long, C.c_long, C.c_long,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),

@@ -42,6 +42,24 @@ hipError_t allow_full_lds(const void *kernel) {
     return e;
 }
 
+}  // namespace ramnet
+
+// `to` waits for everything enqueued on `from` so far — hipEventRecord + hipStreamWaitEvent on ONE reused event per (thread, device): a wait
+// refers to the record that precedes it, so the event can be re-recorded at once.  The host cost of forking the backward-weights stream off
+// the backward-data chain ~400 times per training step (torch: a Stream object, an Event object and a context manager per fork: ~30 us).
+extern "C" int ramnet_stream_fork(void *from, void *to) {
+    static thread_local hipEvent_t ev[16] = {};
+    int dev = 0;
+    RAMNET_HIP(hipGetDevice(&dev));
+    hipEvent_t &e = ev[dev & 15];
+    if (!e) RAMNET_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    RAMNET_HIP(hipEventRecord(e, (hipStream_t)from));
+    RAMNET_HIP(hipStreamWaitEvent((hipStream_t)to, e, 0));
+    return 0;
+}
+
+namespace ramnet {
+
 static inline int grid_for(size_t n_items, int block = 256) {
     size_t g = (n_items + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;   // 256 CUs x 8 workgroups, grid-stride the rest

@@ -51,6 +51,7 @@ def set_winograd_2x4(mode, min_wgs=None):
     _WINO_2X4 = mode
     if min_wgs is not None:
         H.check(H.lib().ramnet_wino2x4_config(int(min_wgs)), "wino2x4_config")
+        invalidate_descs()
 
 
 def get_winograd():
@@ -80,6 +81,7 @@ def set_fold_pair(on):
     """32-channel folded decoders in the pair form (default) or as 64 tiles x 32 channels; the library option and the packs follow."""
     H.check(H.lib().ramnet_set_option(b"fold_pair", int(bool(on))), "set_option")
     invalidate_packs()
+    invalidate_descs()
 
 
 _GRU_BWD_FUSED = True
@@ -106,6 +108,7 @@ def set_winograd_split(on):
     """Split channel reduction of latency-bound F(2x2,3x3) launches (batch-1 streaming on the coarse scales; csrc/conv_wino.hip): on by
     default, off for A/B runs.  Descriptors are built per launch, graphs captured before the call keep what they captured."""
     H.check(H.lib().ramnet_set_option(b"wino_ksplit", int(on)), "set_option")         # (2..16: that many splits, tuning runs)
+    invalidate_descs()
 
 
 def _fold_pair(Cout, Cin):
@@ -256,10 +259,69 @@ def uses_head(taps, w, stride, epi, in_mode):
                 and H.lib().ramnet_head_supported(w.cp.Cin, w.cp.Cout))
 
 
+# Launch descriptors are cached per call site (round 5): everything of a ramnet_conv_desc but its pointers is a function of the layer,
+# the shapes / strides and the kernel-selection switches — filling ~45 ctypes fields and asking the library twice (F(2x4) variant, split
+# reduction) cost ~17 us per launch, ~1100 launches per training step on the two host threads.  A hit copies the template and sets the
+# pointers (~5 us).  The key holds every argument that is not a tensor's address, the strides, the 16-byte alignment of the epilogue
+# operands (the library's variant choice looks at it) and the switches; _DESC_EPOCH covers library-side options.
+_DESC_CACHE = {}
+_DESC_EPOCH = 0
+_DESC_CACHE_ON = _os.environ.get("RAMNET_DESC_CACHE", "1") != "0"
+
+
+def invalidate_descs():
+    global _DESC_EPOCH
+    _DESC_EPOCH += 1
+    _DESC_CACHE.clear()
+    _WDESC_CACHE.clear()
+
+
+def _sd(t):
+    return -1 if t is None else t.stride(2)
+
+
 def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
-                C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
-                o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0, wino24=False, ws_owner=None):
+               C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
+               o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0, wino24=False, ws_owner=None):
+    is_ref = isinstance(w, PackRef)
+    al = out.data_ptr() | (4 * out_off)
+    for t in (e0, e1, o1, o2, bias):
+        if t is not None:
+            al |= t.data_ptr()
+    key = (id(taps), id(w.cp) if is_ref else 0, w.transposed if is_ref else -1, id(ws_owner), Cout, stride, in_mode, C0, C1, Hin, Win, epi, beta, Ho,
+           Wo, os, out_off, frame, out_s2d, wino24, xm_off, tuple(x0.shape), x0.stride(2), _sd(x1), _sd(xm), out.shape[1], out.shape[2],
+           out.stride(2), _sd(e0), _sd(e1), _sd(o1), _sd(o2), bias is None, al & 15, _WINOGRAD, _WINO_2X4, _HEAD, _S2D_SPARSE, _S2D_2X4,
+           _DESC_EPOCH, x0.device.index)
+    hit = _DESC_CACHE.get(key) if _DESC_CACHE_ON else None
+    if hit is not None and (not is_ref or hit[3]() is w.cp) and (ws_owner is None or hit[4]() is ws_owner):
+        tmpl, kind, nsplit = hit[0], hit[1], hit[2]
+        d = H.ConvDesc.from_buffer_copy(tmpl)
+        d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
+        d.bias, d.e0, d.e1 = _p(bias), _p(e0), _p(e1)
+        d.out, d.o1, d.o2 = _p(out, out_off), _p(o1), _p(o2)
+        d.w = _p(w) if kind is None else _p(w.cp.pack(0, "head") if kind == "head" else w.cp.pack(w.transposed, kind))
+        if nsplit:
+            d.splitk_ws = _p((w.cp if is_ref else ws_owner).splitk_ws(nsplit, x0.device))
+        return d
+    meta = []
+    d = _conv_desc_build(x0, taps, w, out, Cout, meta, stride=stride, x1=x1, xm=xm, xm_off=xm_off, in_mode=in_mode, C0=C0, C1=C1, Hin=Hin, Win=Win,
+                         bias=bias, epi=epi, beta=beta, e0=e0, e1=e1, o1=o1, o2=o2, Ho=Ho, Wo=Wo, os=os, out_off=out_off, frame=frame,
+                         out_s2d=out_s2d, wino24=wino24, ws_owner=ws_owner)
+    import weakref
+    if len(_DESC_CACHE) > 4096:
+        _DESC_CACHE.clear()
+    _DESC_CACHE[key] = (H.ConvDesc.from_buffer_copy(d), meta[0], meta[1], weakref.ref(w.cp) if is_ref else None,
+                        weakref.ref(ws_owner) if ws_owner is not None else None)
+    return d
+
+
+def _conv_desc_build(x0, taps, w, out, Cout, meta, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN,
+                     C0=None, C1=0, Hin=None, Win=None, bias=None, epi=H.EPI_LINEAR, beta=0.0, e0=None, e1=None,
+                     o1=None, o2=None, Ho=None, Wo=None, os=(1, 1, 0, 0), out_off=0, frame=0, out_s2d=0, wino24=False, ws_owner=None):
+    """The descriptor from scratch; meta <- [which pack of the layer d.w points at (None: `w` is a packed tensor itself; "head"; False /
+    True / "2x4": ConvParam.pack(transposed, kind)), floats of the split-reduction workspace (0: none)]."""
     B = x0.shape[0]
+    kind, nsplit = None, 0
     d = H.ConvDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
@@ -269,6 +331,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     cp = w.cp if isinstance(w, PackRef) else ws_owner            # the layer that owns the split-reduction workspace
     if isinstance(w, PackRef) and beta == 0.0 and frame == 0 and os == (1, 1, 0, 0) and uses_head(taps, w, stride, epi, in_mode):
         d.algo, d.head_cin = H.ALGO_HEAD, w.cp.Cin
+        kind = "head"
         w = w.cp.pack(0, "head")
     elif isinstance(w, PackRef):
         wino = uses_winograd(taps, w, stride, epi, in_mode, d.C0, C1)
@@ -277,6 +340,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
         d.s2d_5x5 = int(wino and isinstance(w.cp, S2DConvParam) and _S2D_SPARSE and (in_mode == H.IN_S2D or out_s2d > 0))
         if wino and w.cp.gates == 1 and os == (1, 1, 0, 0) and (_S2D_2X4 or not isinstance(w.cp, S2DConvParam)):
             ref = w                      # candidate for F(2x4,3x3): the library decides once the descriptor is complete (below)
+        kind = bool(wino)
         w = w.cp.pack(w.transposed, wino)
     d.B, d.Hin, d.Win = B, (x0.shape[1] if Hin is None else Hin), (x0.shape[2] if Win is None else Win)
     d.ntaps, d.stride = taps.n, stride
@@ -296,19 +360,22 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
     if ref is not None and _WINO_2X4 != "off" and H.lib().ramnet_conv_wino_variant(C.byref(d), int(_WINO_2X4 == "force")):
         # F(2x4,3x3) on the fine scales (csrc/conv_wino6.hip): its own Winograd-domain pack of the same parameters
         d.algo, d.w, d.s2d_5x5 = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4")), 0      # (dense: the F(2x4) kernel skips no zero slices)
+        kind = "2x4"
     if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD24) and cp is not None:
         # latency-bound launches (batch-1 streaming on the coarse scales) split their channel reduction: the library says how much
         # workspace the launch would use, the layer owns it (csrc/conv_wino.hip, ramnet_conv_desc.splitk_ws)
         n = H.lib().ramnet_conv_splitk_floats(C.byref(d))
         if n:
             d.splitk_ws, d.splitk_floats = _p(cp.splitk_ws(n, x0.device)), n
+            nsplit = n
+    meta[:] = [kind, nsplit]
     return d
 
 
-def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
-                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0, wino24=False, segs=None):
-    """segs: a ctypes array of H.WgradSeg (ramnet_wgrad_desc.segs) — the tensors of several launches of the SAME layer and shape reduced
-    in one launch (deferred ConvGRU cell updates, _wgrad_cell); x0 ... gmask then describe the first segment."""
+_WDESC_CACHE = {}
+
+
+def _wgrad_desc_build(x0, taps, dout, dw, Cout, stride, x1, xm, xm_off, in_mode, C0, C1, Hin, Win, gmask, dbias, Ho, Wo, gview, dw_off, wino24):
     d = H.WgradDesc()
     d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
     d.ld0, d.ld1, d.ldm = ld(x0), (ld(x1) if x1 is not None else 0), (ld(xm) if xm is not None else 0)
@@ -333,11 +400,33 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
         d.algo, d.head_cin = H.ALGO_HEAD, hc
     if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4) and C1 and d.C0 % 32:
         raise RuntimeError("Winograd backward-weights needs the concatenation boundary at a multiple of 32 channels")
+    return d
+
+
+def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off=0, in_mode=H.IN_PLAIN, C0=None,
+                 C1=0, Hin=None, Win=None, gmask=None, dbias=None, Ho=None, Wo=None, gview=None, dw_off=0, wino24=False, segs=None, stream=None):
+    """segs: a ctypes array of H.WgradSeg (ramnet_wgrad_desc.segs) — the tensors of several launches of the SAME layer and shape reduced
+    in one launch (deferred ConvGRU cell updates, _wgrad_cell); x0 ... gmask then describe the first segment."""
+    # (descriptor cache as for _conv_desc: the template holds everything but the six pointers)
+    key = (id(taps), id(dw), getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "slabs", 0), getattr(dw, "head_cin", 0), Cout, stride,
+           in_mode, C0, C1, Hin, Win, Ho, Wo, gview, dw_off, wino24, xm_off, tuple(x0.shape), x0.stride(2), _sd(x1), _sd(xm), dout.shape[1],
+           dout.shape[2], dout.stride(2), _sd(gmask), _WGRAD_SLABS, _HEAD, x0.device.index)
+    tmpl = _WDESC_CACHE.get(key) if _DESC_CACHE_ON else None
+    if tmpl is not None:
+        d = H.WgradDesc.from_buffer_copy(tmpl)
+        d.x0, d.x1, d.xm = _p(x0), _p(x1), _p(xm, xm_off)
+        d.dout, d.gmask = _p(dout), _p(gmask)
+        d.dw, d.dbias = _p(dw, dw_off), _p(dbias)
+    else:
+        d = _wgrad_desc_build(x0, taps, dout, dw, Cout, stride, x1, xm, xm_off, in_mode, C0, C1, Hin, Win, gmask, dbias, Ho, Wo, gview, dw_off, wino24)
+        if len(_WDESC_CACHE) > 4096:
+            _WDESC_CACHE.clear()
+        _WDESC_CACHE[key] = H.WgradDesc.from_buffer_copy(d)
     if segs is not None:
         d.nseg, d.segs = len(segs), C.cast(segs, C.POINTER(H.WgradSeg))
     if _ABL_SKIP_WGRAD:        # tuning runs only (RAMNET_ABL_SKIP_WGRAD=1: how much of the step the backward-weights launches cost; gradients are WRONG)
         return
-    H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st()), "ramnet_wgrad_launch")
+    H.check(H.lib().ramnet_wgrad_launch(C.byref(d), _st() if stream is None else stream), "ramnet_wgrad_launch")
 
 
 # ------------------------------------------------------------------------------------------------ side stream
@@ -443,9 +532,11 @@ def wgrad_side(tensors, *args, **kw):
         return wgrad_launch(*args, **kw)
     dev = args[0].device
     side = _side_stream(dev)
-    side.wait_event(torch.cuda.current_stream().record_event())
-    with torch.cuda.stream(side):
-        wgrad_launch(*args, **kw)
+    # (the launch takes the side stream explicitly and the fork is ONE library call: no Stream / Event objects, no context manager —
+    # ~30 us of host time per launch less on the autograd thread)
+    raw = C.c_void_p(side.cuda_stream)
+    H.check(H.lib().ramnet_stream_fork(_st(), raw), "ramnet_stream_fork")
+    wgrad_launch(*args, stream=raw, **kw)
     for t in tensors:
         if t is not None:
             t.record_stream(side)
