@@ -133,6 +133,22 @@ def prepare_depth_data(target, prediction, clip_distance, reg_factor):
     return target, prediction
 
 
+def evaluation_table(target, prediction, mask, eps=1e-5):
+    """The ten rows one frame adds to the evaluation table (evaluation.py:201-241: `add_to_metrics` on metric depths).  The delta
+    thresholds, RMS_log and median_diff are plain numpy means / medians over the mask (a NaN target inside makes the last two NaN,
+    and counts as a miss of every threshold); the other six are the NaN-skipping functions of model/metric.py."""
+    t, p = target[mask], prediction[mask]
+    with np.errstate(invalid="ignore"):
+        ratio = np.maximum(t / (p + eps), p / (t + eps))
+        out = {"threshold_delta_1.25": np.mean(ratio <= 1.25), "threshold_delta_1.25^2": np.mean(ratio <= 1.25 ** 2),
+               "threshold_delta_1.25^3": np.mean(ratio <= 1.25 ** 3)}
+        lt, lp = np.log(t + eps), np.log(p + eps)
+        out.update({"abs_rel_diff": abs_rel_diff(p, t), "squ_rel_diff": squ_rel_diff(p, t), "RMS_linear": rms_linear(p, t),
+                    "RMS_log": np.sqrt(((lt - lp) ** 2).mean()), "SILog": scale_invariant_error(lp, lt), "mean_depth_error": mean_error(p, t),
+                    "median_diff": np.abs(np.median(t) - np.median(p))})
+    return out
+
+
 def depth_to_normalised_log(depth, clip_distance, reg_factor):
     """Target normalisation of data_loader/dataset.py:296-305."""
     f = np.clip(depth, 0.0, clip_distance) / clip_distance

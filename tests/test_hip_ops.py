@@ -1082,4 +1082,27 @@ def test_depth_metrics_vs_reference_golden():
     want, n = reference_sums(t.astype(np.float64), p.astype(np.float64), np.nan_to_num(t) < 30.0)     # strict <, NaN -> inside
     assert m["n"] == n
     for k, v in want.items():
+        if k == "RMS_log":                      # plain np.mean over the mask in the reference: a NaN target inside -> NaN
+            assert np.isnan(m[k]) and np.isnan(m["median_diff"])
+            continue
         np.testing.assert_allclose(m[k], v, rtol=5e-5, atol=1e-7, err_msg=k)
+
+
+def test_depth_metrics_table_vs_reference_add_to_metrics():
+    """All ten rows of the reference's evaluation table (evaluation.py:201-241) against ITS `add_to_metrics`, run on seeded maps by
+    tests/golden/make_golden_eval_metrics.py: `median_diff`, and `RMS_log` / `median_diff` NaN as soon as the mask holds a NaN target."""
+    from rpg_ramnet_amd import metrics
+    z = load_golden("eval_metrics.npz")
+    keys = ("abs_rel_diff", "squ_rel_diff", "RMS_linear", "RMS_log", "SILog", "mean_depth_error", "median_diff", "threshold_delta_1.25",
+            "threshold_delta_1.25^2", "threshold_delta_1.25^3")
+    for tag in ("plain", "cut30", "nan", "nan_cut20", "mvsec"):
+        clip, reg, cutoff = (float(v) for v in z[tag + ".params"])
+        m = metrics.depth_metrics(torch.from_numpy(z[tag + ".pred_in"]).to(dev()), torch.from_numpy(z[tag + ".target_in"]).to(dev()),
+                                  clip, reg, cutoff=cutoff)
+        for k in keys:
+            want = float(z["%s.%s" % (tag, k)])
+            if np.isnan(want):
+                assert k in ("RMS_log", "median_diff") and np.isnan(m[k]), (tag, k, m[k])
+            else:
+                np.testing.assert_allclose(m[k], want, rtol=1e-4, atol=2e-5, err_msg="%s %s" % (tag, k))
+        assert np.isnan(float(z[tag + ".RMS_log"])) == tag.startswith("nan")

@@ -190,6 +190,19 @@ def test_si_loss_and_metrics(golden_dir):
         np.testing.assert_allclose(loss_ref.abs_rel_diff(p2, t2), z["depth%d.abs_rel" % clip], rtol=1e-6)
 
 
+def test_evaluation_table_vs_reference_add_to_metrics(golden_dir):
+    """oracle evaluation_table == the reference's add_to_metrics (evaluation.py:201-241) on its seeded maps: ten rows, NaN rows NaN."""
+    z = load(golden_dir, "eval_metrics.npz")
+    for tag in ("plain", "cut30", "nan", "nan_cut20", "mvsec"):
+        clip, reg, cutoff = (float(v) for v in z[tag + ".params"])
+        t, p = loss_ref.prepare_depth_data(z[tag + ".target_in"], z[tag + ".pred_in"], clip, reg)
+        got = loss_ref.evaluation_table(t, p, np.nan_to_num(t) < cutoff)
+        assert len(got) == 10
+        for k, v in got.items():
+            np.testing.assert_allclose(v, float(z["%s.%s" % (tag, k)]), rtol=1e-6, err_msg="%s %s" % (tag, k), equal_nan=True)
+        assert np.isnan(got["median_diff"]) == np.isnan(got["RMS_log"]) == tag.startswith("nan")
+
+
 def test_log_and_mse_losses_and_trainer_assembly(golden_dir):
     """scale_invariant_log_loss (model/loss.py:12-15), mse_loss at full / half resolution and the trainer's assembly with the mse
     term (lstm_trainer.py:152-226) against vectors produced by the reference's own functions and LSTMTrainer methods
