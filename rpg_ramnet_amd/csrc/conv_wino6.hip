@@ -24,8 +24,18 @@
 #include "conv_wino_common.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace ramnet {
+
+// Tuning builds only (tools/probe_wino6.sh, -DRAMNET_PROBE): thread 0 of every workgroup stamps the shader clock at the phase boundaries of
+// its life into g_probe6[workgroup][16] (+ the 100 MHz wall counter at entry: slot 7, HW_ID / XCC_ID registers: slots 8 / 9); ramnet_probe6_read copies the table out.
+#ifdef RAMNET_PROBE
+__device__ unsigned long long g_probe6[16384 * 16];
+#define RAMNET_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_probe6[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RAMNET_STAMP(k) do { } while (0)
+#endif
 
 constexpr int W6_BN = 64;                        // output channels per 64-channel block of the packed weights
 constexpr int W6_U_FLOATS = 24 * W6_BN * WK;     // weights of one (chunk, 64-channel block): 24 positions x 64 x 8 = 48 KB
@@ -57,6 +67,14 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hq = lane >> 5;
+    RAMNET_STAMP(0);
+#ifdef RAMNET_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        g_probe6[blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memrealtime();
+        g_probe6[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        g_probe6[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    }
+#endif
 
     // XCD-aware order as in conv_wino.hip: the channel blocks of ONE spatial tile are consecutive on one XCD
     const int xslot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
@@ -140,6 +158,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
 
     // (requesting the patches of the first TWO chunks together — one memory round trip per workgroup instead of two — measured no
     // difference, round 5: 281.0-281.5 against 280.7-280.8 ms per step; the other workgroup of the CU covers the prologue)
+    RAMNET_STAMP(1);
     pr.load(q.src, 0, clast);
 #pragma unroll
     for (int i = 0; i < 12; ++i)
@@ -147,6 +166,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     pr.store(patch, q.src, 0);
     pr.load(q.src, min(WK, clast), clast);
     __syncthreads();
+    RAMNET_STAMP(2);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const float4 x = ld4(patch + pra + c * 4), y = ld4(patch + prb + c * 4);
@@ -159,6 +179,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     pr.store(patch + RP_FLOATS, q.src, min(WK, clast));
     pr.load(q.src, min(2 * WK, clast), clast);
     __syncthreads();
+    RAMNET_STAMP(3);
     // One chunk = 6 positions x 4 K steps of MFMAs.  Everything else of the chunk is cut into 48 SLOTS, two behind every MFMA, each a
     // handful of instructions: a block of 12 VALU between two MFMAs is a bubble in the pipe, so no gap carries more than ~6:
     //   slots  0..11   LDS reads of the NEXT chunk's two window rows (column j = slot >> 1)
@@ -220,6 +241,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
         if (chunk + 1 < nch) body(std::integral_constant<int, 1>{}, chunk + 1, tB, tA);      // (uniform over the workgroup)
         chunk += 2;
     } while (chunk < nch);
+    RAMNET_STAMP(4);
 
     // ---- exchange: column transform of the wave's row (M A4: 4 of 6 columns), all waves -> LDS.
     // A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
@@ -239,87 +261,132 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
             dst[3 * 32 * RO_LD] = d12 + 8.f * d34 + m5;
         }
     __syncthreads();
-    // row transform A2^T (.) across the waves for output pixel pxl (0..255 of the TH x TW tile) and channels col .. col+3
-    auto out4 = [&](int pxl, int col) {
-        const int py = pxl / RTW, px = pxl % RTW;
-        const float *base = P + ((px & 3) * 32 + (py >> 1) * TXG + (px >> 2)) * RO_LD + col;
-        const float4 t1 = ld4(base + 1 * 128 * RO_LD), t2 = ld4(base + 2 * 128 * RO_LD);
-        if (py & 1) {
-            const float4 t3 = ld4(base + 3 * 128 * RO_LD);
-            return make_float4(t1.x - t2.x - t3.x, t1.y - t2.y - t3.y, t1.z - t2.z - t3.z, t1.w - t2.w - t3.w);
-        }
-        const float4 t0 = ld4(base);
-        return make_float4(t0.x + t1.x + t2.x, t0.y + t1.y + t2.y, t0.z + t1.z + t2.z, t0.w + t1.w + t2.w);
-    };
+    RAMNET_STAMP(5);
+    // ---- channel-quad epilogue.  Thread (tid >> 3, qd = tid & 7) owns channel quad qd of the 8 output pixels pxl = (tid >> 3) + 32 j of the
+    // TH x TW tile: one column, rows py0 + j * (32 / TW).  Straight-line code (round 5: a workgroup spent 4.3 us alone / 7.2 us beside its CU
+    // partner here, a fifth of its life, in 8 x 4 serial chains of LDS read -> activation -> 64-bit address -> predicated store;
+    // tools/probe_wino6.py): every tensor is addressed through a buffer resource over image b with 32-bit byte offsets — a pixel outside the
+    // map or a quad beyond Cout gets the offset WOOB, its loads return zero and its stores are dropped, no branch —, and per half (4 pixels)
+    // all global operands, then all 12 LDS reads are requested before the first value is used.  The row transform A2^T over the waves:
+    // even rows t0 + t1 + t2, odd rows t1 - t2 - t3 = r0 + s r1 + s r2 with the first row and the sign selected by the parity (same sums,
+    // same order).  The launcher only selects this kernel for 16-byte-accessible operands (q.vec4), unit output strides and images < 2 GB.
     const int epi = p.epi;
-    // Channel-quad epilogue in two phases (conv_wino.hip): every global operand of the thread's 8 * NF output quads is REQUESTED first —
-    // in two halves of 4 * NF, so that the GRU blend's three operands per quad stay in registers —, then the quads are transformed out
-    // of LDS, activated and stored.  The launcher only selects this kernel for 16-byte-accessible operands (q.vec4) and no s2d output.
-    constexpr int NI = 4 * NF;
-    const int qd = NF == 2 ? tid & 15 : tid & 7, nq = n0 + qd * 4;       // (the same quad for all i: 256 threads = 16 x 16 quads)
+    constexpr int NI = 4, RSTEP = 32 / RTW;                   // pixels per half; rows between consecutive pixels of a thread
+    const int qd = tid & 7, nq = n0 + qd * 4;
     const bool nok = nq < p.Cout;
-    const int nqs = nok ? nq : 0;
-    const float4 bias4 = p.bias ? ld4(p.bias + nqs) : f4zero();
-    const bool addold = p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
+    const float4 bias4 = p.bias ? ld4(p.bias + (nok ? nq : 0)) : f4zero();
+    const int px0 = (tid >> 3) % RTW, py0 = (tid >> 3) / RTW;
+    const bool colok = nok && ox0 + px0 < p.Wo;
+    const unsigned pix0 = (unsigned)((oy0 + py0) * p.WoF + ox0 + px0);      // inside image b (osy = osx = 1, no offsets: launcher)
+    const size_t img = (size_t)b * p.HoF * p.WoF;
+    const float *lbase = P + ((px0 & 3) * 32 + (px0 >> 2)) * RO_LD + qd * 4;
+    auto rsrc_of = [&](const float *ptr, int ld) { return wino_rsrc(ptr ? ptr + img * ld : nullptr, WOOB); };
+    auto bld = [](decltype(wino_rsrc(nullptr, 0u)) r, unsigned off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
+    auto bst = [](decltype(wino_rsrc(nullptr, 0u)) r, unsigned off, float4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0); };
+    // byte offset of the thread's quad at pixel j of a tensor with row stride ld: the offset at j = 0 (WOOB: no such tensor; uniform) + j
+    // uniform steps, OR-ed with the pixel's own WOOB when it has nothing to do (selects of constants: no branch, no per-pixel multiply)
+    unsigned bad[2 * NI];
+#pragma unroll
+    for (int j = 0; j < 2 * NI; ++j) bad[j] = (colok && oy0 + py0 + j * RSTEP < p.Ho) ? 0u : WOOB;
+    auto off0_of = [&](int ld, bool have, int dn = 0) { return have ? (pix0 * (unsigned)ld + (unsigned)(nq + dn)) * 4u : WOOB; };
+    auto step_of = [&](int ld) { return (unsigned)(RSTEP * p.WoF * ld * 4); };
+    const auto r_out = rsrc_of(p.out, p.ldo);
     auto run = [&](auto kind) {
-        constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
+        // 0: linear / ReLU (+ beta * old), 4: sigmoid, 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
+        constexpr int K = decltype(kind)::value;
+        const bool addold = K == 0 && p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
+        const bool relu = epi == RAMNET_EPI_RELU;
+        const auto r_e0 = (K >= 1 && K <= 3) ? rsrc_of(p.e0, p.lde0) : r_out;
+        const auto r_e1 = (K == 2 || K == 3) ? rsrc_of(p.e1, p.lde1) : r_out;
+        const auto r_o1 = (K == 2 || K == 3) ? rsrc_of(p.o1, p.ldo1) : r_out;
+        const unsigned o_out = off0_of(p.ldo, true), s_out = step_of(p.ldo);
+        const unsigned o_e0 = off0_of(p.lde0, K >= 1 && K <= 3), s_e0 = step_of(p.lde0);
+        const unsigned o_e1 = off0_of(p.lde1, (K == 2 || K == 3) && p.e1 != nullptr, K == 3 ? -(p.Cout / 2) : 0), s_e1 = step_of(p.lde1);
+        const unsigned o_o1 = off0_of(p.ldo1, (K == 2 || K == 3) && p.o1 != nullptr), s_o1 = step_of(p.ldo1);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            bool ok[NI];
-            size_t pix[NI];
-            int pxl[NI];
-            float4 ea[NI], eb[NI], ec[K == 3 ? NI : 1];
+            unsigned oo[NI];
+            float4 ea[NI], eb[NI], ec[NI], t0[NI], t1[NI], t2[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int sl = tid + (half * NI + i) * 256;
-                pxl[i] = NF == 2 ? sl >> 4 : sl >> 3;
-                const int oy = oy0 + pxl[i] / RTW, ox = ox0 + pxl[i] % RTW;
-                ok[i] = nok && oy < p.Ho && ox < p.Wo;
-                pix[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;     // (a valid address either way)
-                ea[i] = K >= 1 ? ld4(p.e0 + pix[i] * p.lde0 + nqs) : addold ? ld4(p.out + pix[i] * p.ldo + nqs) : f4zero();
-                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : (K == 3 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs - p.Cout / 2) : f4zero();
-                if (K == 3) ec[i] = ld4(p.out + pix[i] * p.ldo + nqs);
+                const int j = half * NI + i;
+                oo[i] = (o_out + j * s_out) | bad[j];
+                if (K == 0) ea[i] = addold ? bld(r_out, oo[i]) : f4zero();      // (uniform)
+                if (K >= 1 && K <= 3) ea[i] = bld(r_e0, (o_e0 + j * s_e0) | bad[j]);
+                if (K == 2 || K == 3) eb[i] = bld(r_e1, (o_e1 + j * s_e1) | bad[j]);
+                if (K == 3) ec[i] = bld(r_out, oo[i]);
+            }
+            RAMNET_STAMP(11 + 2 * half);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int py = py0 + (half * NI + i) * RSTEP;
+                const float *bb = lbase + ((py >> 1) * TXG + (py & 1) * 128) * RO_LD;
+                t0[i] = ld4(bb), t1[i] = ld4(bb + 128 * RO_LD), t2[i] = ld4(bb + 256 * RO_LD);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                if (!ok[i]) continue;
-                float4 v = f4add(out4(pxl[i], qd * 4), bias4);
+                const float sg = ((py0 + (half * NI + i) * RSTEP) & 1) ? -1.f : 1.f;
+                float4 v = make_float4(fmaf(sg, t2[i].x, fmaf(sg, t1[i].x, t0[i].x)), fmaf(sg, t2[i].y, fmaf(sg, t1[i].y, t0[i].y)),
+                                       fmaf(sg, t2[i].z, fmaf(sg, t1[i].z, t0[i].z)), fmaf(sg, t2[i].w, fmaf(sg, t1[i].w, t0[i].w)));
+                v = f4add(v, bias4);
                 if (K == 0) {
                     if (addold) v = make_float4(v.x + p.beta * ea[i].x, v.y + p.beta * ea[i].y, v.z + p.beta * ea[i].z, v.w + p.beta * ea[i].w);
-                    if (epi == RAMNET_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                    else if (epi == RAMNET_EPI_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+                    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                } else if (K == 4) {
+                    v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
                 } else if (K == 1) {
                     v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
-                } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD)
-                    v = gru_bwd_quad(v, ea[i], eb[i], ec[K == 3 ? i : 0], p.o1 + pix[i] * p.ldo1 + nq);
+                } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD; conv_epilogue.hpp: gru_bwd_quad)
+                    const float4 g = v, r = ea[i], h = eb[i], old = ec[i];
+                    bst(r_o1, (o_o1 + (half * NI + i) * s_o1) | bad[half * NI + i], make_float4(g.x * h.x * r.x * (1.0f - r.x), g.y * h.y * r.y * (1.0f - r.y),
+                                                                                g.z * h.z * r.z * (1.0f - r.z), g.w * h.w * r.w * (1.0f - r.w)));
+                    v = make_float4(old.x + g.x * r.x, old.y + g.y * r.y, old.z + g.z * r.z, old.w + g.w * r.w);
                 } else {
                     const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
-                    if (p.o1) st4(p.o1 + pix[i] * p.ldo1 + nq, o);
+                    bst(r_o1, (o_o1 + (half * NI + i) * s_o1) | bad[half * NI + i], o);
                     v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
                                     h.w * (1.0f - u.w) + o.w * u.w);
                 }
-                st4(p.out + pix[i] * p.ldo + nq, v);
+                bst(r_out, oo[i], v);
             }
+            RAMNET_STAMP(12 + 2 * half);
         }
     };
     if (q.s2d_shift) {
         // out_s2d (backward-data of a stride-2 5x5 encoder over its space-to-depth view; LINEAR, no bias: checked on the host): output channel
         // quad nq of logical pixel (oy, ox) is channel quad nq - g * C of full-resolution pixel (2 oy + (g >> 1), 2 ox + (g & 1)), g = nq / C
         const int g = nq >> q.s2d_shift;
+        const unsigned fp0 = (unsigned)((2 * (oy0 + py0) + (g >> 1)) * p.WoF + 2 * (ox0 + px0) + (g & 1));
 #pragma unroll
-        for (int i = 0; i < 2 * NI; ++i) {
-            const int sl = tid + i * 256, pxl = NF == 2 ? sl >> 4 : sl >> 3;
-            const int oy = oy0 + pxl / RTW, ox = ox0 + pxl % RTW;
-            if (!nok || oy >= p.Ho || ox >= p.Wo) continue;
-            const size_t pix = ((size_t)b * p.HoF + 2 * oy + (g >> 1)) * p.WoF + 2 * ox + (g & 1);
-            st4(p.out + pix * p.ldo + (nq - (g << q.s2d_shift)), out4(pxl, qd * 4));
+        for (int half = 0; half < 2; ++half) {
+            float4 t0[NI], t1[NI], t2[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int py = py0 + (half * NI + i) * RSTEP;
+                const float *bb = lbase + ((py >> 1) * TXG + (py & 1) * 128) * RO_LD;
+                t0[i] = ld4(bb), t1[i] = ld4(bb + 128 * RO_LD), t2[i] = ld4(bb + 256 * RO_LD);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int j = half * NI + i;
+                const float sg = ((py0 + j * RSTEP) & 1) ? -1.f : 1.f;
+                const unsigned off = ((fp0 * (unsigned)p.ldo + (unsigned)(nq - (g << q.s2d_shift))) * 4u + j * 2 * step_of(p.ldo)) | bad[j];
+                bst(r_out, off, make_float4(fmaf(sg, t2[i].x, fmaf(sg, t1[i].x, t0[i].x)), fmaf(sg, t2[i].y, fmaf(sg, t1[i].y, t0[i].y)),
+                                            fmaf(sg, t2[i].z, fmaf(sg, t1[i].z, t0[i].z)), fmaf(sg, t2[i].w, fmaf(sg, t1[i].w, t0[i].w))));
+            }
         }
         return;
     }
     if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
     else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
     else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
+    else if (epi == RAMNET_EPI_SIGMOID) run(std::integral_constant<int, 4>{});
     else run(std::integral_constant<int, 0>{});
+#ifdef RAMNET_PROBE
+    __builtin_amdgcn_s_waitcnt(0);          // (the stores have left the wave)
+    RAMNET_STAMP(6);
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_probe6[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // OIHW 3x3 -> U = G2 g G4^T (evaluated in double) in the lane order of the kernel's B operand:
@@ -458,13 +525,21 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
         int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
         ldmax = ldmax > d.ldm ? ldmax : d.ldm;
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
+        int lo = d.ldo > d.ldo1 ? d.ldo : d.ldo1;                              // ... of the epilogue's tensors too
+        lo = lo > d.lde0 ? lo : d.lde0;
+        lo = lo > d.lde1 ? lo : d.lde1;
+        RAMNET_CHECK_ARG((unsigned long long)d.HoF * d.WoF * lo * 4ull < (unsigned long long)WOOB);
     }
     note_kernel("conv_wino_r6_kernel<%d,%d>", txg, d.in_mode);
+    size_t probe_pad = 0;                       // (probe builds: RAMNET_PROBE_LDS_KB pads the allocation — 90: ONE workgroup per CU)
+#ifdef RAMNET_PROBE
+    if (const char *e = getenv("RAMNET_PROBE_LDS_KB")) probe_pad = (size_t)atoi(e) * 1024;
+#endif
 #define RAMNET_GO6(TXv, MDv)                                                                                        \
     case (TXv) * 100 + (MDv): {                                                                                     \
         const size_t pf = (size_t)(2 * R6Geom<TXv>::PFLOATS + 256 * 4) * sizeof(float);                             \
         RAMNET_FULL_LDS((conv_wino_r6_kernel<TXv, MDv>));                                                           \
-        hipLaunchKernelGGL((conv_wino_r6_kernel<TXv, MDv>), grid, dim3(256), ex > pf ? ex : pf, st, d, q);          \
+        hipLaunchKernelGGL((conv_wino_r6_kernel<TXv, MDv>), grid, dim3(256), (ex > pf ? ex : pf) + probe_pad, st, d, q); \
     } break;
 #define RAMNET_GO6_TX(TXv)                                                                                          \
     RAMNET_GO6(TXv, RAMNET_IN_PLAIN) RAMNET_GO6(TXv, RAMNET_IN_CAT) RAMNET_GO6(TXv, RAMNET_IN_CAT_MUL) RAMNET_GO6(TXv, RAMNET_IN_RELUMASK) \
@@ -485,6 +560,12 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
 }  // namespace ramnet
 
 using namespace ramnet;
+
+#ifdef RAMNET_PROBE
+extern "C" int ramnet_probe6_read(unsigned long long *dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ramnet::g_probe6), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int ramnet_wino2x4_config(int min_wgs) {
     if (min_wgs >= 0) g_w6_min_wgs = min_wgs;

@@ -1,5 +1,4 @@
-python -m pytest tests/test_hip_ops.py tests/test_hip_model.py tests/test_cabi_direct.py tests/test_hip_fullsize.py -x -q -m gpu 2>&1 | tail -3
-for i in 1 2 3; do
-echo cache on; python tools/host_profile.py 2>/dev/null | head -1
-echo cache off; RAMNET_DESC_CACHE=0 python tools/host_profile.py 2>/dev/null | head -1
+for i in 1 2; do
+echo OLD; RAMNET_HIP_LIB=rpg_ramnet_amd/abl/lib_old.so python bench.py --steps 10 --warmup 3 --resident-inputs --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
+echo NEW; python bench.py --steps 10 --warmup 3 --resident-inputs --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
 done

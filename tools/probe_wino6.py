@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Where does a workgroup of conv_wino_r6_kernel spend its life?  Needs the probe build (tools/probe_wino6.sh):
+    RAMNET_HIP_LIB=rpg_ramnet_amd/abl/lib_probe6.so python tools/probe_wino6.py
+Thread 0 of every workgroup stamps the shader clock at: 0 entry, 1 descriptors / prefetcher set up, 2 first patch in LDS (first barrier),
+3 prologue done (first transforms, second barrier), 4 main loop done, 5 exchange written (barrier), 6 epilogue stores retired; plus the 100 MHz
+wall counter at entry and exit and the CU the workgroup ran on.  ConvGRU gate / candidate shapes of the training step (B = 8), F(2x4) forced."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rpg_ramnet_amd import ops, _hip as H  # noqa: E402
+
+NWG, NS = 16384, 16
+NAMES = ["setup", "first patch -> LDS", "first transforms", "main loop", "exchange", "epilogue"]
+
+
+def read():
+    buf = np.zeros(NWG * NS, dtype=np.uint64)
+    fn = H.lib().ramnet_probe6_read
+    fn.argtypes, fn.restype = [C.c_void_p, C.c_size_t], C.c_int
+    assert fn(buf.ctypes.data, buf.size) == 0
+    return buf.reshape(NWG, NS).astype(np.int64)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    taps = ops.Taps.get("conv", 3, 1)
+    ops.set_winograd(True)
+    ops.set_winograd_2x4("force")
+    B = 8
+    for (Hh, Ww, cin, cout, epi) in ((128, 172, 128, 128, H.EPI_SIGMOID), (128, 172, 128, 64, H.EPI_LINEAR), (64, 86, 256, 256, H.EPI_SIGMOID),
+                                      (32, 43, 512, 512, H.EPI_SIGMOID), (128, 172, 64, 64, H.EPI_RELU), (128, 172, 32, 64, H.EPI_RELU)):
+        w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+        b = torch.nn.Parameter(torch.randn(cout, device=dev) * 0.1)
+        cp = ops.ConvParam([w], [b])
+        x = torch.randn(B, Hh, Ww, cin, device=dev)
+        y = torch.empty(B, Hh, Ww, cout, device=dev)
+
+        def launch():
+            ops.conv_launch(x, taps, cp.fwd(), y, cout, bias=cp.bias(), epi=epi)
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            launch()
+        e.record()
+        torch.cuda.synchronize()
+        t_ms = s.elapsed_time(e) / 10
+        before = read()
+        launch()
+        torch.cuda.synchronize()
+        t = read()
+        ran = t[:, 0] != before[:, 0]
+        full = ran & (t[:, 6] != before[:, 6])
+        t = t[full]
+        n, nch = int(full.sum()), cin // 8
+        d = np.diff(t[:, :7], axis=1).astype(np.float64)              # cycles per phase
+        life = (t[:, 6] - t[:, 0]).astype(np.float64)
+        wall = (t[:, 10] - t[:, 7]) * 10.0                            # ns
+        ghz = float(np.median(life / np.maximum(wall, 1.0)))
+        start = (t[:, 7] - t[:, 7].min()) * 0.01                      # us
+        end = (t[:, 10] - t[:, 7].min()) * 0.01
+        cu = (t[:, 9] & 0xf) * 1000 + ((t[:, 8] >> 13) & 7) * 100 + ((t[:, 8] >> 8) & 0xf)      # (xcc, se, cu)
+        print("\n%dx%d Cin %d -> Cout %d, B %d: %.1f us per launch (events), %d workgroups (%d launched) on %d CUs, shader clock %.2f GHz" % (
+            Hh, Ww, cin, cout, B, t_ms * 1e3, n, int(ran.sum()), len(np.unique(cu)), ghz))
+        print("  workgroup starts %.1f .. %.1f us, last end %.1f us; life of a workgroup: median %.1f us (%.0f cycles), p10 %.1f, p90 %.1f" % (
+            start.min(), start.max(), end.max(), np.median(life) / ghz * 1e-3, np.median(life), np.percentile(life, 10) / ghz * 1e-3,
+            np.percentile(life, 90) / ghz * 1e-3))
+        order = np.argsort(start)
+        first, rest = order[:min(512, n)], order[min(512, n):]
+        for label, idx in (("all", order), ("the first 512 started", first), ("the later ones", rest)):
+            if len(idx) == 0:
+                continue
+            print("  %-22s" % label + "  ".join("%s %.2f us" % (NAMES[k], np.median(d[idx, k]) / ghz * 1e-3) for k in range(6)))
+        e5 = t[:, 5].astype(np.float64)
+        ep = [np.median(t[:, k] - (e5 if k == 11 else t[:, k - 1])) / ghz * 1e-3 for k in (11, 12, 13, 14)] + [np.median(t[:, 6] - t[:, 14]) / ghz * 1e-3]
+        print("  epilogue: operands of half 0 requested %.2f us, its 4 quads out of LDS / activated / stores issued %.2f, half 1: %.2f + %.2f, "
+              "stores retired %.2f" % tuple(ep))
+        ml = np.median(d[:, 3])
+        print("  main loop: %.0f cycles per chunk (%d chunks; 24 MFMAs = 1536 cycles of the pipe per wave, two waves per SIMD); fixed part of a "
+              "workgroup's life: %.2f us of %.2f" % (ml / nch, nch, (np.median(life) - ml) / ghz * 1e-3, np.median(life) / ghz * 1e-3))
+        # occupancy over time: how many workgroups are alive at 20 points of the launch
+        ts = np.linspace(0, end.max(), 21)[1:-1]
+        alive = [(int(((start <= x) & (end > x)).sum())) for x in ts]
+        print("  workgroups alive at 5 %% steps of the launch: %s" % " ".join(str(a) for a in alive))
+
+
+if __name__ == "__main__":
+    main()
