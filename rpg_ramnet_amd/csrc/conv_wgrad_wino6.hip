@@ -22,6 +22,15 @@
 #endif
 #define RAMNET_OPQ(QQ) asm volatile("" : "+v"(QQ))
 
+// Probe builds (tools/probe_wino6.sh, -DRAMNET_PROBE): thread 0 of every workgroup stamps the shader clock at the phase boundaries of its life
+// (csrc/conv_wino6.hip has the forward kernel's); ramnet_probe_w6_read copies the table out.
+#ifdef RAMNET_PROBE
+namespace ramnet { __device__ unsigned long long g_probe_w6[16384 * 16]; }
+#define RAMNET_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) ramnet::g_probe_w6[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RAMNET_STAMP(k) do { } while (0)
+#endif
+
 namespace ramnet {
 
 constexpr int WG6_TARGET = 384;      // workgroups per launch the tile splits aim at
@@ -67,6 +76,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
+    RAMNET_STAMP(0);
+#ifdef RAMNET_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        g_probe_w6[blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memrealtime();
+        g_probe_w6[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_probe_w6[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     // Workgroup -> (tile split, input block, output block).  The gy x gz workgroups of one split read the SAME strips (every input block
     // the split's dy strips, every output block its x strips): consecutive workgroup ids go round-robin to the 8 XCDs (private L2s), so
     // with splits % 8 == 0 XCD x is dealt the splits x, x + 8, ... and the workgroups of one split sit in consecutive slots of ONE XCD —
@@ -112,7 +129,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
         xoff[i] = (unsigned)((pxs * xpy[i] * WinS + pxs * xpx[i]) * ldS + qd * 4) * 4u;
         xmoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4) * 4u;
-        xdst[i] = sl < XSLOTS ? (qd * 4) * CPX + xpy[i] * RPX + xpx[i] : -1;
+        // (threads without a slot write the pad float behind the rows of their four channels: never read, and the stores keep immediate offsets)
+        xdst[i] = (qd * 4) * CPX + (sl < XSLOTS ? xpy[i] * RPX + xpx[i] : G::PH * RPX);
     }
 #pragma unroll
     for (int i = 0; i < NYS; ++i) {
@@ -140,6 +158,24 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         rg = wino_rsrc(g.dout, WOOB);
         rgm = GM ? wino_rsrc(g.gmask, WOOB) : rg;
     };
+    // Byte offsets of the thread's slots with the ROW half of the in-image test folded in (WOOB: the slot's row of this strip row lies outside
+    // the map, or the thread has no slot): they change with the strip row only — once per bx_n batches, a real, rarely taken branch — so a
+    // batch tests the columns alone (one add, one compare, one select per slot instead of two of each and a mask combination).
+    unsigned xov[NXS], xmv[XMK ? NXS : 1], yov[NYS], ymv[GM ? NYS : 1];
+    auto rows_update = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXS; ++i) {
+            const bool ok = xslot[i] & ((unsigned)(G::YH * lb_ty + q.dy0 + xpy[i]) < (unsigned)s.Hin);
+            xov[i] = ok ? xoff[i] : WOOB;
+            if (XMK) xmv[i] = (ok & use_m) ? xmoff[i] : WOOB;
+        }
+#pragma unroll
+        for (int i = 0; i < NYS; ++i) {
+            const bool ok = yslot[i] & (G::YH * lb_ty + ypy[i] < p.Ho);
+            yov[i] = ok ? yoff[i] : WOOB;
+            if (GM) ymv[i] = ok ? ymoff[i] : WOOB;
+        }
+    };
     auto load_first = [&](int batch) {          // (once, in front of the loop: the integer divisions)
         int tt = batch;
         lb_bx = tt % q.bx_n;
@@ -150,6 +186,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         lb_seg = tt / q.seg_images;
         lb_batch = batch;
         set_seg(lb_seg);
+        rows_update();
     };
     auto load_begin = [&](int batch) {
         {                                       // batch == lb_batch (first call, clamped tail) or lb_batch + 1
@@ -165,6 +202,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
                 lb_b = 0;
                 set_seg(++lb_seg);
             }
+            if (cx) rows_update();              // (uniform)
         }
         lb_batch = batch;
         const int pix = (lb_b * p.Ho + G::YH * lb_ty) * p.Wo + YW * lb_bx;
@@ -180,16 +218,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         // compiler otherwise wraps every load in a waterfall loop: 9 instructions and an exec-mask round trip per load)
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo, __builtin_amdgcn_readfirstlane((int)so), 0));
     };
-    auto load_x = [&](int i) {
-        const int iy = G::YH * lb_ty + q.dy0 + xpy[i], ix = YW * lb_bx + q.dx0 + xpx[i];
-        const bool ok = xslot[i] & ((unsigned)iy < (unsigned)s.Hin) & ((unsigned)ix < (unsigned)s.Win);
-        xr[i] = bload(rx, ok ? xoff[i] : WOOB, so_x);
-        if (XMK) xm[i] = bload(rmk, (ok & use_m) ? xmoff[i] : WOOB, so_m);
+    auto load_x = [&](int i) {              // (the row half of the in-image test lives in xov / xmv: rows_update)
+        const bool ok = (unsigned)(YW * lb_bx + q.dx0 + xpx[i]) < (unsigned)s.Win;
+        xr[i] = bload(rx, ok ? xov[i] : WOOB, so_x);
+        if (XMK) xm[i] = bload(rmk, ok ? xmv[i] : WOOB, so_m);
     };
     auto load_y = [&](int i) {
-        const bool ok = yslot[i] & (G::YH * lb_ty + ypy[i] < p.Ho) & (YW * lb_bx + ypx[i] < p.Wo);
-        yr[i] = bload(rg, ok ? yoff[i] : WOOB, so_g);
-        if (GM) ym[i] = bload(rgm, ok ? ymoff[i] : WOOB, so_gm);
+        const bool ok = YW * lb_bx + ypx[i] < p.Wo;
+        yr[i] = bload(rg, ok ? yov[i] : WOOB, so_g);
+        if (GM) ym[i] = bload(rgm, ok ? ymv[i] : WOOB, so_gm);
     };
     auto load_raw = [&](int batch) {
         load_begin(batch);
@@ -199,15 +236,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         for (int i = 0; i < NYS; ++i) load_y(i);
     };
     float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid % YQ)
-    float *scratch = smem + 2 * (GR_XP + GR_YP) + tid * 4;          // 256 spare 16-byte cells behind the strips
+    static_assert(CPX > G::PH * RPX, "a pad float per channel behind the rows of the strip");
     auto store_x = [&](int i, float *xb) {
         float4 r = xr[i];
         if (XMK == 1)
             r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
         if (XMK == 2) r = make_float4(r.x * (xm[i].x + m_one), r.y * (xm[i].y + m_one), r.z * (xm[i].z + m_one), r.w * (xm[i].w + m_one));
-        float *d = xdst[i] >= 0 ? xb + xdst[i] : scratch;
-        const int cp = xdst[i] >= 0 ? CPX : 1;          // (threads without a slot: four floats of their scratch cell)
-        d[0] = r.x, d[cp] = r.y, d[2 * cp] = r.z, d[3 * cp] = r.w;
+        float *d = xb + xdst[i];
+        d[0] = r.x, d[CPX] = r.y, d[2 * CPX] = r.z, d[3 * CPX] = r.w;
     };
     float bias_on = 1.f;                          // 0 for the clamped re-store of the last batch
     auto store_y = [&](int i, float *yb) {
@@ -277,6 +313,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
 
     int batch = (int)((long long)q.nbatch * sp_i / q.splits);
     const int last = (int)((long long)q.nbatch * (sp_i + 1) / q.splits) - 1;
+    RAMNET_STAMP(1);
     if (batch <= last) {
         load_first(batch);
         load_raw(batch);
@@ -286,9 +323,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         for (int i = 0; i < NYS; ++i) store_y(i, Yp);
         load_raw(min(batch + 1, last));
         __syncthreads();
+        RAMNET_STAMP(2);
         fetch_x(Xp, 0), fetch_y(Yp, 0);
         finish_x0(0), finish_x1(0), finish_y(0);
         int cur = 0;
+        RAMNET_STAMP(3);
         for (; batch <= ((RAMNET_ABL & 128) ? -1 : last); ++batch, cur ^= 1) {
             bias_on = batch + 1 <= last ? 1.f : 0.f;
             const int b2 = min(batch + 2, last);
@@ -329,6 +368,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         }
     }
 
+    RAMNET_STAMP(4);
     // D of position 6 * wave + pl -> the BLOCKED workspace [24 positions][Cin / 32][Cout / 32][64 lanes][16 accumulator registers]: a lane's
     // 16 values (rows c = (r & 3) + 8 (r >> 2) + 4 kk of column n = lane & 31) are 64 contiguous bytes, a wave's block 4 KB — the join of
     // a split's partial sums with its slab is 4 + 4 16-byte accesses per position instead of 16 + 16 4-byte ones at a Cout-float stride
@@ -370,6 +410,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
             for (int r = 0; r < 16; ++r) atomicAdd(b + r, neg ? -acc[pl][r] : acc[pl][r]);
         }
     }
+#ifdef RAMNET_PROBE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    RAMNET_STAMP(5);
     if (p.dbias != nullptr && by_i == 0) {
         __syncthreads();
         float *red = smem;                        // [NT / YQ][32]
@@ -384,6 +428,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
             }
         }
     }
+#ifdef RAMNET_PROBE
+    __builtin_amdgcn_s_waitcnt(0);
+    RAMNET_STAMP(6);
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_probe_w6[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // blocked ws [24][CinWs / 32][CoutWs / 32][64][16] (dU, position = 6 * row + column; layout: the kernel's join above) -> grad OIHW
@@ -502,6 +551,12 @@ int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
 }  // namespace ramnet
 
 using namespace ramnet;
+
+#ifdef RAMNET_PROBE
+extern "C" int ramnet_probe_w6_read(unsigned long long *dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ramnet::g_probe_w6), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout) {
     const int s = WG6_TARGET / (cdiv(Cin, 32) * cdiv(Cout, 32));

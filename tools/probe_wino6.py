@@ -18,15 +18,72 @@ NWG, NS = 16384, 16
 NAMES = ["setup", "first patch -> LDS", "first transforms", "main loop", "exchange", "epilogue"]
 
 
-def read():
+def read(which="ramnet_probe6_read"):
     buf = np.zeros(NWG * NS, dtype=np.uint64)
-    fn = H.lib().ramnet_probe6_read
+    fn = getattr(H.lib(), which)
     fn.argtypes, fn.restype = [C.c_void_p, C.c_size_t], C.c_int
     assert fn(buf.ctypes.data, buf.size) == 0
     return buf.reshape(NWG, NS).astype(np.int64)
 
 
+WNAMES = ["setup", "first strips -> LDS", "first transforms", "main loop", "slab join", "bias"]
+
+
+def wgrad():
+    """conv_wgrad_wino_r6_kernel on the six ConvGRU backward-weights launches of one cell update (B = 8): stamps 0 entry, 1 set up, 2 first strips
+    in LDS, 3 first transforms, 4 main loop done, 5 slab join retired, 6 bias partials done."""
+    dev = torch.device("cuda:0")
+    ops.set_wgrad_winograd_2x4("force")
+    taps = ops.Taps.get("conv", 3, 1)
+    B = 8
+    for i, Cc in enumerate([64, 128, 256]):
+        Hh, Ww = 256 >> (i + 1), 344 >> (i + 1)
+        for kind, cout in (("gates", 2 * Cc), ("candidate", Cc)):
+            w = torch.nn.Parameter(torch.randn(cout, 2 * Cc, 3, 3, device=dev) * 0.01)
+            b = torch.nn.Parameter(torch.zeros(cout, device=dev))
+            cp = ops.ConvParam([w], [b])
+            x, h = torch.randn(B, Hh, Ww, Cc, device=dev), torch.randn(B, Hh, Ww, Cc, device=dev)
+            ur, g = torch.rand(B, Hh, Ww, 2 * Cc, device=dev), torch.randn(B, Hh, Ww, cout, device=dev)
+            ws, bws = cp.grad_ws(wino_ok=True)
+            kw = dict(x1=h, in_mode=H.IN_CAT, C1=Cc, dbias=bws) if kind == "gates" else dict(x1=h, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws, xm=ur, xm_off=Cc)
+
+            def launch():
+                ops.wgrad_launch(x, taps, g, ws, cout, **kw)
+            for _ in range(3):
+                launch()
+            torch.cuda.synchronize()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(10):
+                launch()
+            e_.record()
+            torch.cuda.synchronize()
+            t_ms = s_.elapsed_time(e_) / 10
+            before = read("ramnet_probe_w6_read")
+            launch()
+            torch.cuda.synchronize()
+            t = read("ramnet_probe_w6_read")
+            full = (t[:, 0] != before[:, 0]) & (t[:, 6] != before[:, 6])
+            t = t[full]
+            n = int(full.sum())
+            d = np.diff(t[:, :7], axis=1).astype(np.float64)
+            life = (t[:, 6] - t[:, 0]).astype(np.float64)
+            wall = (t[:, 10] - t[:, 7]) * 10.0
+            ghz = float(np.median(life / np.maximum(wall, 1.0)))
+            start, end = (t[:, 7] - t[:, 7].min()) * 0.01, (t[:, 10] - t[:, 7].min()) * 0.01
+            print("\ngru%d %s (%dx%d, Cin %d -> Cout %d): %.1f us per launch (events), %d workgroups, shader clock %.2f GHz; starts %.1f .. %.1f us, "
+                  "last end %.1f us" % (i, kind, Hh, Ww, 2 * Cc, cout, t_ms * 1e3, n, ghz, start.min(), start.max(), end.max()))
+            print("  life of a workgroup: median %.1f us (p10 %.1f, p90 %.1f): " % (np.median(life) / ghz * 1e-3, np.percentile(life, 10) / ghz * 1e-3,
+                                                                                  np.percentile(life, 90) / ghz * 1e-3) +
+                  "  ".join("%s %.2f us" % (WNAMES[k], np.median(d[:, k]) / ghz * 1e-3) for k in range(6)))
+            ts = np.linspace(0, end.max(), 21)[1:-1]
+            print("  workgroups alive at 5 %% steps of the launch: %s" % " ".join(str(int(((start <= x_) & (end > x_)).sum())) for x_ in ts))
+            cp.discard()
+
+
 def main():
+    if "--wgrad" in sys.argv:
+        return wgrad()
     dev = torch.device("cuda:0")
     taps = ops.Taps.get("conv", 3, 1)
     ops.set_winograd(True)
