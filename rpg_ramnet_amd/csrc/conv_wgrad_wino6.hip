@@ -12,6 +12,7 @@
 // 8 x 8 or 16 x 4 pixel strip, whichever pads the map least), raw strips double-buffered with one barrier per batch, the tile splits of a
 // launch own per-split slabs of a [S][24][Cin][Cout] workspace (plain read-modify-write: bit-reproducible).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 
 // Tuning builds only (tools/abl_wgrad6.sh): RAMNET_ABL is a bit mask that removes one ingredient of the main loop — 1 staging (global loads,
@@ -326,9 +327,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         RAMNET_STAMP(2);
         fetch_x(Xp, 0), fetch_y(Yp, 0);
         finish_x0(0), finish_x1(0), finish_y(0);
-        int cur = 0;
         RAMNET_STAMP(3);
-        for (; batch <= ((RAMNET_ABL & 128) ? -1 : last); ++batch, cur ^= 1) {
+        // One batch; CUR = the LDS buffer holding it, a compile-time constant (the loop below alternates two instantiations): every strip
+        // address is then the thread's base + an immediate — with a run-time buffer index the loop carried 15 address additions per batch.
+        auto iter = [&](auto cur_c) {
+            constexpr int cur = decltype(cur_c)::value;
             bias_on = batch + 1 <= last ? 1.f : 0.f;
             const int b2 = min(batch + 2, last);
             const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
@@ -365,6 +368,16 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
                 }
                 if (st == 2 && !(RAMNET_ABL & 8)) __syncthreads();
             }
+        };
+        if (!(RAMNET_ABL & 128)) {
+            do {                                        // (batch <= last here; ONE exit, at the bottom: a second path into the join makes the
+                iter(std::integral_constant<int, 0>{}); //  allocator copy the 96 accumulators — 256 VGPRs and 144-392 bytes of scratch)
+                ++batch;
+                if (batch <= last) {                    // (uniform)
+                    iter(std::integral_constant<int, 1>{});
+                    ++batch;
+                }
+            } while (batch <= last);
         }
     }
 
