@@ -41,7 +41,7 @@ __device__ __forceinline__ auto make_rsrc(const void *p, unsigned bytes) {
 __device__ unsigned long long *g_w24_trace;
 #define W24_STAMP(chunk_, slot)                                                                                          \
     do {                                                                                                                 \
-        if (lane == 0 && (chunk_) < 16) g_w24_trace[(((size_t)blockIdx.x * 8 + wave) * 17 + (chunk_)) * 6 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0 && (chunk_) <= 16) g_w24_trace[(((size_t)blockIdx.x * 8 + wave) * 17 + (chunk_)) * 6 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define W24_STAMP(chunk_, slot)

@@ -243,6 +243,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     } while (chunk < nch);
     RAMNET_STAMP(4);
 
+    // (the epilogue's bias quad is requested here: its round trip passes under the exchange instead of in front of the first output)
+    const int qd = tid & 7, nq = n0 + qd * 4;
+    const bool nok = nq < p.Cout;
+    const float4 bias4 = p.bias ? ld4(p.bias + (nok ? nq : 0)) : f4zero();
     // ---- exchange: column transform of the wave's row (M A4: 4 of 6 columns), all waves -> LDS.
     // A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
     // D of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile)
@@ -272,9 +276,6 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     // same order).  The launcher only selects this kernel for 16-byte-accessible operands (q.vec4), unit output strides and images < 2 GB.
     const int epi = p.epi;
     constexpr int NI = 4, RSTEP = 32 / RTW;                   // pixels per half; rows between consecutive pixels of a thread
-    const int qd = tid & 7, nq = n0 + qd * 4;
-    const bool nok = nq < p.Cout;
-    const float4 bias4 = p.bias ? ld4(p.bias + (nok ? nq : 0)) : f4zero();
     const int px0 = (tid >> 3) % RTW, py0 = (tid >> 3) / RTW;
     const bool colok = nok && ox0 + px0 < p.Wo;
     const unsigned pix0 = (unsigned)((oy0 + py0) * p.WoF + ox0 + px0);      // inside image b (osy = osx = 1, no offsets: launcher)
