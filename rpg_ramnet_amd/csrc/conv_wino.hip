@@ -268,27 +268,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         return;
     }
     if (q.vec4 && !q.s2d_shift) {
-        // Channel-quad epilogue in two phases: every global operand of the thread's 4 * NF output quads (bias, residual / update gate,
-        // previous state, accumulated output) is REQUESTED first, then the quads are transformed out of LDS, activated and stored.
-        // One epilogue kind per straight-line instantiation: the former per-quad `switch (epi)` around the loads made every quad wait
-        // for its own round trips (2-3 serialized L2 / HBM latencies x 8 quads per thread, 5500 instructions of branches).
-        constexpr int NI = 4 * NF;
+        // Channel-quad epilogue, straight-line (as in conv_wino6.hip, round 5): the thread owns channel quad qd of the NI output pixels
+        // pxl = p0 + PSTEP i of the TH x TW tile — one column, rows RS apart.  Every tensor is addressed through a buffer resource over image
+        // b with 32-bit byte offsets (a pixel outside the map or a quad beyond Cout: WOOB — its loads return zero, its stores are dropped; no
+        // branch, no 64-bit address arithmetic); all global operands, then all LDS reads of the quads are requested before the first value is
+        // used.  Row transform A^T over the waves: even rows t0 + t1 + t2, odd rows t1 - t2 - t3 = r0 + s r1 + s r2 (same sums, same order).
+        // One epilogue kind per instantiation.  The launcher checks 16-byte-accessible operands (q.vec4) and images < 2 GB.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NI = 4 * NF, PSTEP = 256 / (8 * NF), RS = PSTEP / RTW;
+        static_assert(PSTEP % RTW == 0, "a thread's pixels lie in one column of the tile");
         const int qd = NF == 2 ? tid & 15 : tid & 7, nq = n0 + qd * 4;       // (the same quad for all i: 256 threads = 16 x 16 quads)
         const bool nok = nq < p.Cout;
-        const int nqs = nok ? nq : 0;
-        const float4 bias4 = p.bias ? ld4(p.bias + nqs) : f4zero();
-        const bool addold = p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
-        bool ok[NI];
-        size_t pix[NI];
-        int pxl[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int sl = tid + i * 256;
-            pxl[i] = NF == 2 ? sl >> 4 : sl >> 3;
-            const int oy = oy0 + pxl[i] / RTW, ox = ox0 + pxl[i] % RTW;
-            ok[i] = nok && oy < p.Ho && ox < p.Wo;
-            pix[i] = ok[i] ? ((size_t)b * p.HoF + (oy * p.osy + p.ooy)) * p.WoF + (ox * p.osx + p.oox) : 0;     // (a valid address either way)
-        }
+        const float4 bias4 = p.bias ? ld4(p.bias + (nok ? nq : 0)) : f4zero();
+        const int p0 = NF == 2 ? tid >> 4 : tid >> 3, px0 = p0 % RTW, py0 = p0 / RTW;
         // Split reduction: this workgroup's partial quads -> its slab of the tile's workspace [split][128 pixels x 32 channels]; the LAST
         // arrival (a counter per tile, left at zero for the next launch) adds the slabs in split order — every sum has a fixed order
         // whoever arrives last: bit-reproducible — and goes on to the epilogue, the others are done.  The partials cross XCDs (private
@@ -298,12 +290,11 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         if (NF == 1 && ksp > 1) {
             // (16-byte buffer accesses with the sc1 cache-policy bit = what the compiler emits for device-scope atomics, four floats at a
             // time: as 4-byte atomic stores / loads at a 16-byte lane stride the join cost 12 us per launch)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             constexpr int AUX_SC1 = 16;
             const auto wr = wino_rsrc(q.ws + (size_t)blockIdx.x * ksp * 4096, (unsigned)(ksp * 4096 * 4));
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out4(pxl[i], qd * 4)), wr, (tid + i * 256) * 16, (int)blockIdx.y * 16384, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out4(p0 + PSTEP * i, qd * 4)), wr, (tid + i * 256) * 16, (int)blockIdx.y * 16384, AUX_SC1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the wave's stores have left (s_waitcnt), no cache maintenance
             __syncthreads();                           // (also: every out4 read of P is done, P[0] can carry the verdict)
             if (tid == 0) {
@@ -320,39 +311,87 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                 for (int i = 0; i < NI; ++i)
                     joined[i] = f4add(joined[i], __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, (tid + i * 256) * 16, s * 16384, AUX_SC1)));
         }
+        const bool colok = nok && ox0 + px0 < p.Wo;
+        const unsigned pix0 = (unsigned)(((oy0 + py0) * p.osy + p.ooy) * p.WoF + (ox0 + px0) * p.osx + p.oox);      // inside image b
+        const size_t img = (size_t)b * p.HoF * p.WoF;
+        const float *lbase = P + ((px0 & 1) * 32 + (px0 >> 1)) * RO_LD + qd * 4;
+        auto rsrc_of = [&](const float *ptr, int ld) { return wino_rsrc(ptr ? ptr + img * ld : nullptr, WOOB); };
+        auto bld = [](decltype(wino_rsrc(nullptr, 0u)) r, unsigned off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
+        auto bst = [](decltype(wino_rsrc(nullptr, 0u)) r, unsigned off, float4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0); };
+        unsigned bad[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bad[i] = (colok && oy0 + py0 + i * RS < p.Ho) ? 0u : WOOB;
+        auto off0_of = [&](int ld, bool have, int dn = 0) { return have ? (pix0 * (unsigned)ld + (unsigned)(nq + dn)) * 4u : WOOB; };
+        auto step_of = [&](int ld) { return (unsigned)(RS * p.osy * p.WoF * ld * 4); };
+        const auto r_out = rsrc_of(p.out, p.ldo);
         auto run = [&](auto kind) {
-            constexpr int K = decltype(kind)::value;        // 0: linear / ReLU / sigmoid (+ beta * old), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
-            float4 ea[NI], eb[NI], ec[K == 3 ? NI : 1];
+            // 0: linear / ReLU (+ beta * old), 4: sigmoid, 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
+            constexpr int K = decltype(kind)::value;
+            const bool addold = K == 0 && p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
+            const bool relu = epi == RAMNET_EPI_RELU;
+            const auto r_e0 = (K >= 1 && K <= 3) ? rsrc_of(p.e0, p.lde0) : r_out;
+            const auto r_e1 = (K == 2 || K == 3) ? rsrc_of(p.e1, p.lde1) : r_out;
+            const auto r_o1 = (K == 2 || K == 3) ? rsrc_of(p.o1, p.ldo1) : r_out;
+            const unsigned o_out = off0_of(p.ldo, true), s_out = step_of(p.ldo);
+            const unsigned o_e0 = off0_of(p.lde0, K >= 1 && K <= 3), s_e0 = step_of(p.lde0);
+            const unsigned o_e1 = off0_of(p.lde1, (K == 2 || K == 3) && p.e1 != nullptr, K == 3 ? -(p.Cout / 2) : 0), s_e1 = step_of(p.lde1);
+            const unsigned o_o1 = off0_of(p.ldo1, (K == 2 || K == 3) && p.o1 != nullptr), s_o1 = step_of(p.ldo1);
+            constexpr int HN = 4;                        // quads per half (NF = 2: two halves, the GRU blend's operands stay in registers)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                ea[i] = K >= 1 ? ld4(p.e0 + pix[i] * p.lde0 + nqs) : addold ? ld4(p.out + pix[i] * p.ldo + nqs) : f4zero();
-                eb[i] = (K == 2 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs) : (K == 3 && p.e1) ? ld4(p.e1 + pix[i] * p.lde1 + nqs - p.Cout / 2) : f4zero();
-                if (K == 3) ec[i] = ld4(p.out + pix[i] * p.ldo + nqs);
-            }
+            for (int half = 0; half < NI / HN; ++half) {
+                unsigned oo[HN];
+                float4 ea[HN], eb[HN], ec[HN], t0[HN], t1[HN], t2[HN];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                if (!ok[i]) continue;
-                float4 v = f4add((NF == 1 && ksp > 1) ? joined[i] : out4(pxl[i], qd * 4), bias4);
-                if (K == 0) {
-                    if (addold) v = make_float4(v.x + p.beta * ea[i].x, v.y + p.beta * ea[i].y, v.z + p.beta * ea[i].z, v.w + p.beta * ea[i].w);
-                    if (epi == RAMNET_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-                    else if (epi == RAMNET_EPI_SIGMOID) v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
-                } else if (K == 1) {
-                    v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
-                } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD)
-                    v = gru_bwd_quad(v, ea[i], eb[i], ec[K == 3 ? i : 0], p.o1 + pix[i] * p.ldo1 + nq);
-                } else {
-                    const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
-                    if (p.o1) st4(p.o1 + pix[i] * p.ldo1 + nq, o);
-                    v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
-                                    h.w * (1.0f - u.w) + o.w * u.w);
+                for (int i = 0; i < HN; ++i) {
+                    const int j = half * HN + i;
+                    oo[i] = (o_out + j * s_out) | bad[j];
+                    if (K == 0) ea[i] = addold ? bld(r_out, oo[i]) : f4zero();      // (uniform)
+                    if (K >= 1 && K <= 3) ea[i] = bld(r_e0, (o_e0 + j * s_e0) | bad[j]);
+                    if (K == 2 || K == 3) eb[i] = bld(r_e1, (o_e1 + j * s_e1) | bad[j]);
+                    if (K == 3) ec[i] = bld(r_out, oo[i]);
                 }
-                st4(p.out + pix[i] * p.ldo + nq, v);
+                if (!(NF == 1 && ksp > 1)) {
+#pragma unroll
+                    for (int i = 0; i < HN; ++i) {
+                        const int py = py0 + (half * HN + i) * RS;
+                        const float *bb = lbase + ((py >> 1) * TX + (py & 1) * 64) * RO_LD;
+                        t0[i] = ld4(bb), t1[i] = ld4(bb + 64 * RO_LD), t2[i] = ld4(bb + 128 * RO_LD);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < HN; ++i) {
+                    const int j = half * HN + i;
+                    const float sg = ((py0 + j * RS) & 1) ? -1.f : 1.f;
+                    float4 v = (NF == 1 && ksp > 1) ? joined[j]
+                                                    : make_float4(fmaf(sg, t2[i].x, fmaf(sg, t1[i].x, t0[i].x)), fmaf(sg, t2[i].y, fmaf(sg, t1[i].y, t0[i].y)),
+                                                                  fmaf(sg, t2[i].z, fmaf(sg, t1[i].z, t0[i].z)), fmaf(sg, t2[i].w, fmaf(sg, t1[i].w, t0[i].w)));
+                    v = f4add(v, bias4);
+                    if (K == 0) {
+                        if (addold) v = make_float4(v.x + p.beta * ea[i].x, v.y + p.beta * ea[i].y, v.z + p.beta * ea[i].z, v.w + p.beta * ea[i].w);
+                        if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    } else if (K == 4) {
+                        v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+                    } else if (K == 1) {
+                        v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
+                    } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD; conv_epilogue.hpp: gru_bwd_quad)
+                        const float4 g = v, r = ea[i], h = eb[i], old = ec[i];
+                        bst(r_o1, (o_o1 + j * s_o1) | bad[j], make_float4(g.x * h.x * r.x * (1.0f - r.x), g.y * h.y * r.y * (1.0f - r.y),
+                                                                          g.z * h.z * r.z * (1.0f - r.z), g.w * h.w * r.w * (1.0f - r.w)));
+                        v = make_float4(old.x + g.x * r.x, old.y + g.y * r.y, old.z + g.z * r.z, old.w + g.w * r.w);
+                    } else {
+                        const float4 o = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)), u = ea[i], h = eb[i];
+                        bst(r_o1, (o_o1 + j * s_o1) | bad[j], o);
+                        v = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
+                                        h.w * (1.0f - u.w) + o.w * u.w);
+                    }
+                    bst(r_out, oo[i], v);
+                }
             }
         };
         if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
         else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
         else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
+        else if (epi == RAMNET_EPI_SIGMOID) run(std::integral_constant<int, 4>{});
         else run(std::integral_constant<int, 0>{});
         return;
     }
@@ -515,6 +554,10 @@ static int wino_plan(const ramnet_conv_desc &d, WinoParams &q, bool &tall, int &
         int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
         ldmax = ldmax > d.ldm ? ldmax : d.ldm;
         RAMNET_CHECK_ARG(px * ldmax * 4ull < (unsigned long long)WOOB);        // per-image 32-bit byte offsets
+        int lo = d.ldo > d.ldo1 ? d.ldo : d.ldo1;                              // ... of the epilogue's tensors too
+        lo = lo > d.lde0 ? lo : d.lde0;
+        lo = lo > d.lde1 ? lo : d.lde1;
+        RAMNET_CHECK_ARG((unsigned long long)d.HoF * d.WoF * lo * 4ull < (unsigned long long)WOOB);
     }
     return 0;
 }
