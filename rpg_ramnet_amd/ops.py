@@ -778,6 +778,11 @@ class ConvParam:
         pool = self.__dict__.setdefault("_splitk", {})       # (derived parameter views — S2DConvParam — build themselves)
         ws = pool.get(n)
         if ws is None or ws.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                # (the zero-fill would be recorded into the graph and the buffer would come out of the graph's private pool while eager
+                #  launches of the same layer share it: ADVICE r4)
+                raise RuntimeError("split-reduction workspace of a layer first used inside a graph capture: run the launch eagerly once "
+                                   "before capturing (graph._warm)")
             ws = pool[n] = torch.zeros(n, device=device, dtype=torch.float32)
         return ws
 
