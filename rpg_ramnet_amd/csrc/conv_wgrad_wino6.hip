@@ -51,29 +51,32 @@ struct WgradWino6Params {
 template <int TXB> struct G6Geom {
     static constexpr int TYB = 8 / TXB, YH = 2 * TYB, YW = 4 * TXB, PH = YH + 2, PW = YW + 2;
     static constexpr int XPIX = PH * PW, XSLOTS = XPIX * 8, NXS = (XSLOTS + 255) / 256;
-    // LDS strips are CHANNEL-major (round 5): [32 channels][rows][row pitch] floats.  The MFMA operands put the lanes along the channels, so
-    // a lane's window row (6 consecutive pixels) / gradient row (4) is contiguous: one ds_read_b128 + one ds_read_b64 / one ds_read_b128
-    // instead of 6 / 4 ds_read_b32 at a 32-float stride (20 -> 6 LDS reads per tile pair and wave, and no address arithmetic: the offsets
-    // are immediates).  RPX: row pitch (a multiple of 4 >= PW: 16-byte aligned tile origins); CPX / CPY: channel pitch with CP / 4 ODD — the 16
-    // lanes a ds_read_b128 serves per cycle then fall on 16 distinct 4-bank groups (conflict-free); the staging stores become four
-    // ds_write_b32 per 16-byte slot (immediate offsets j * CP), two-way conflicts between channel quads q and q + 4.
-    static constexpr int RPX = (PW + 3) / 4 * 4, CPX = ((PH * RPX / 4) | 1) * 4, CPY = ((YH * YW / 4) | 1) * 4;
-    static constexpr int XP = 32 * CPX;            // raw input strip [32 channels][PH rows][RPX]
-    static constexpr int YP = 32 * CPY;            // raw gradient strip [32 channels][YH x YW pixels]
+    // LDS strips: [row][32 channels][2 buffers][row pitch] floats.  The MFMA operands put the lanes along the channels, so a lane's window row
+    // (6 consecutive pixels) / gradient row (4) is contiguous: one ds_read_b128 + one ds_read_b64 / one ds_read_b128 at immediate offsets
+    // (round 5: 20 -> 6 LDS reads per tile pair and wave).  RPX: row pitch of the input strip (a multiple of 4 >= PW: 16-byte aligned tile
+    // origins).  The two buffers of the double-buffered strips sit side by side inside a channel's row, so that EVERY address of the loop is
+    // a per-thread base + an immediate small enough for ds_write2_b32's 8-bit offsets — the four channels of a staged 16-byte slot lie
+    // CH, 2 CH, 3 CH floats apart, the other buffer RPX / YW further: no address arithmetic in the loop at all.  CHX / CHY = channel pitch,
+    // 2 x row pitch + 4 so that CH / 4 is ODD: the 16 lanes a ds_read_b128 serves per cycle fall on 16 distinct 4-bank groups.
+    static constexpr int RPX = (PW + 3) / 4 * 4, CHX = 2 * RPX + 4, CHY = 2 * YW + 4;
+    static constexpr int ROWX = 32 * CHX, ROWY = 32 * CHY;
+    static constexpr int XTOT = PH * ROWX;         // raw input strips, both buffers
+    static constexpr int YTOT = YH * ROWY;         // raw gradient strips, both buffers
+    static_assert(RPX > PW && 3 * CHX + RPX < 256 && 3 * CHY + YW < 256, "pad pixel per row; ds_write2_b32 offsets");
     // tile pair st (tiles 2 st, 2 st + 1; the lane's tile = 2 st + kk): offsets of its window / output origin that do not depend on the lane
-    static constexpr int sx(int st) { return TXB == 4 ? (st >> 1) * 2 * RPX + (st & 1) * 8 : TXB == 2 ? st * 2 * RPX : st * 4 * RPX; }
-    static constexpr int sy(int st) { return TXB == 4 ? (st >> 1) * 2 * YW + (st & 1) * 8 : TXB == 2 ? st * 2 * YW : st * 4 * YW; }
+    static constexpr int sx(int st) { return TXB == 4 ? (st >> 1) * 2 * ROWX + (st & 1) * 8 : TXB == 2 ? st * 2 * ROWX : st * 4 * ROWX; }
+    static constexpr int sy(int st) { return TXB == 4 ? (st >> 1) * 2 * ROWY + (st & 1) * 8 : TXB == 2 ? st * 2 * ROWY : st * 4 * ROWY; }
 };
 
 // XMK: second operand of the input loader — 0 none, 1 ReLU mask (x * (xm > 0)), 2 product (the h*r half of a CAT_MUL input); GM: ReLU mask on dy
 template <int XMK, bool GM, int TXB>
 __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet_wgrad_desc p, const WgradWino6Params q) {
     using G = G6Geom<TXB>;
-    constexpr int NT = 256, XQ = 8, YQ = 8, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS, GR_XP = G::XP, GR_YP = G::YP;
-    constexpr int PW = G::PW, YW = G::YW, RPX = G::RPX, CPX = G::CPX, CPY = G::CPY;
+    constexpr int NT = 256, XQ = 8, YQ = 8, NXS = G::NXS, NYS = 2, XSLOTS = G::XSLOTS;
+    constexpr int PW = G::PW, YW = G::YW, RPX = G::RPX, CHX = G::CHX, CHY = G::CHY, ROWX = G::ROWX, ROWY = G::ROWY;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xp = smem;                   // [2][32][CPX]
-    float *Yp = smem + 2 * GR_XP;       // [2][32][CPY]
+    float *Xp = smem;                   // [PH][32][2][RPX] (+ 4 pad floats per channel)
+    float *Yp = smem + G::XTOT;         // [YH][32][2][YW]  (+ 4)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
@@ -130,8 +133,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         xslot[i] = sl < XSLOTS && c0 + qd * 4 < s.Cin;
         xoff[i] = (unsigned)((pxs * xpy[i] * WinS + pxs * xpx[i]) * ldS + qd * 4) * 4u;
         xmoff[i] = (unsigned)((xpy[i] * s.Win + xpx[i]) * s.ldm + qd * 4) * 4u;
-        // (threads without a slot write the pad float behind the rows of their four channels: never read, and the stores keep immediate offsets)
-        xdst[i] = (qd * 4) * CPX + (sl < XSLOTS ? xpy[i] * RPX + xpx[i] : G::PH * RPX);
+        // (threads without a slot write the pad pixel PW of row 0 of their four channels: never read, and the stores keep immediate offsets)
+        xdst[i] = (qd * 4) * CHX + (sl < XSLOTS ? xpy[i] * ROWX + xpx[i] : PW);
     }
 #pragma unroll
     for (int i = 0; i < NYS; ++i) {
@@ -237,22 +240,21 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
         for (int i = 0; i < NYS; ++i) load_y(i);
     };
     float4 bsum = f4zero();                      // bias gradient partial of channel quad (tid % YQ)
-    static_assert(CPX > G::PH * RPX, "a pad float per channel behind the rows of the strip");
     auto store_x = [&](int i, float *xb) {
         float4 r = xr[i];
         if (XMK == 1)
             r = make_float4(xm[i].x > 0.f ? r.x : 0.f, xm[i].y > 0.f ? r.y : 0.f, xm[i].z > 0.f ? r.z : 0.f, xm[i].w > 0.f ? r.w : 0.f);
         if (XMK == 2) r = make_float4(r.x * (xm[i].x + m_one), r.y * (xm[i].y + m_one), r.z * (xm[i].z + m_one), r.w * (xm[i].w + m_one));
         float *d = xb + xdst[i];
-        d[0] = r.x, d[CPX] = r.y, d[2 * CPX] = r.z, d[3 * CPX] = r.w;
+        d[0] = r.x, d[CHX] = r.y, d[2 * CHX] = r.z, d[3 * CHX] = r.w;
     };
     float bias_on = 1.f;                          // 0 for the clamped re-store of the last batch
     auto store_y = [&](int i, float *yb) {
         const int sl = tid + i * NT;
         float4 r = yr[i];
         if (GM) r = make_float4(ym[i].x > 0.f ? r.x : 0.f, ym[i].y > 0.f ? r.y : 0.f, ym[i].z > 0.f ? r.z : 0.f, ym[i].w > 0.f ? r.w : 0.f);
-        float *d = yb + ((sl % YQ) * 4) * CPY + sl / YQ;
-        d[0] = r.x, d[CPY] = r.y, d[2 * CPY] = r.z, d[3 * CPY] = r.w;
+        float *d = yb + ((sl % YQ) * 4) * CHY + ((sl / YQ) / YW) * ROWY + (sl / YQ) % YW;
+        d[0] = r.x, d[CHY] = r.y, d[2 * CHY] = r.z, d[3 * CHY] = r.w;
         bsum = make_float4(bsum.x + bias_on * r.x, bsum.y + bias_on * r.y, bsum.z + bias_on * r.z, bsum.w + bias_on * r.w);
     };
 
@@ -262,11 +264,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sb = wave == 1 ? 1.f : -1.f;
     const float cb = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
-    const int yr0 = wave == 3 ? YW : 0;
+    const int yr0 = wave == 3 ? ROWY : 0;
     // the lane's tile of a pair: TXB >= 2: the next tile column (4 pixels), TXB = 1: the next tile row (2 pixel rows)
-    const int kx = TXB == 1 ? kk * 2 * RPX : kk * 4, ky = TXB == 1 ? kk * 2 * YW : kk * 4;
-    const int xa_off = l31 * CPX + ra * RPX + kx, xb_off = l31 * CPX + rb * RPX + kx;
-    const int y_off = l31 * CPY + ky;
+    const int kx = TXB == 1 ? kk * 2 * ROWX : kk * 4, ky = TXB == 1 ? kk * 2 * ROWY : kk * 4;
+    const int xa_off = l31 * CHX + ra * ROWX + kx, xb_off = l31 * CHX + rb * ROWX + kx;
+    const int y_off = l31 * CHY + ky;
     float da[6], db[6], g0[4], g1[4];             // raw operands of the tile pair being prepared
     float an[2][6], bn[2][6];                     // operand sets of tile pairs st & 1 = 0 / 1
     auto fetch_x = [&](const float *xc, int st) {
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
 #pragma unroll
             for (int c = 0; c < 4; ++c) { RAMNET_OPQ(g0[c]); RAMNET_OPQ(g1[c]); }
         } else {
-            const float4 a4 = ld4(yc + y_off + yr0 + G::sy(st)), b4 = ld4(yc + y_off + YW + G::sy(st));
+            const float4 a4 = ld4(yc + y_off + yr0 + G::sy(st)), b4 = ld4(yc + y_off + ROWY + G::sy(st));
             g0[0] = a4.x, g0[1] = a4.y, g0[2] = a4.z, g0[3] = a4.w;
             g1[0] = b4.x, g1[1] = b4.y, g1[2] = b4.z, g1[3] = b4.w;
         }
@@ -334,8 +336,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
             constexpr int cur = decltype(cur_c)::value;
             bias_on = batch + 1 <= last ? 1.f : 0.f;
             const int b2 = min(batch + 2, last);
-            const float *xc = Xp + cur * GR_XP, *yc = Yp + cur * GR_YP;
-            float *xn = Xp + (cur ^ 1) * GR_XP, *yn = Yp + (cur ^ 1) * GR_YP;
+            const float *xc = Xp + cur * RPX, *yc = Yp + cur * YW;                  // (the buffers interleave inside a channel's row)
+            float *xn = Xp + (cur ^ 1) * RPX, *yn = Yp + (cur ^ 1) * YW;
             // staging slices: the raw strips of the next batch (in registers) -> the other LDS buffer (k = 0..5, all in front of the barrier
             // behind tile pair 2), then the loads of the batch after it (k = 6..12)
             auto stage = [&](int k) {
@@ -534,8 +536,8 @@ int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st) {
 #endif
     q.splits = splits, q.gy = gy, q.gz = gz;
     const dim3 grid(splits * gy * gz);
-    const int xp = txb == 4 ? G6Geom<4>::XP : txb == 2 ? G6Geom<2>::XP : G6Geom<1>::XP;
-    const size_t lds = ((size_t)2 * (xp + G6Geom<4>::YP) + 256 * 4) * sizeof(float);
+    const int strips = txb == 4 ? G6Geom<4>::XTOT + G6Geom<4>::YTOT : txb == 2 ? G6Geom<2>::XTOT + G6Geom<2>::YTOT : G6Geom<1>::XTOT + G6Geom<1>::YTOT;
+    const size_t lds = (size_t)(strips > 1024 ? strips : 1024) * sizeof(float);         // (the bias reduction reuses 32 x 32 floats)
     const int xmk = d.in_mode == RAMNET_IN_RELUMASK ? 1 : d.in_mode == RAMNET_IN_CAT_MUL ? 2 : 0;
     const bool gm = d.gmask != nullptr;
     {
