@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 20      /* 20: ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 21      /* 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20: ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -67,11 +67,15 @@ enum ramnet_epilogue {
     RAMNET_EPI_RES_RELU = 3,  /* relu(acc + bias + e0)               ResidualBlock submodules.py:212-214 */
     RAMNET_EPI_GRU_BLEND = 4, /* o=tanh(acc+bias); out=h*(1-u)+o*u   submodules.py:450-452; e0=u, e1=h, o1<-o */
     RAMNET_EPI_LSTM = 5,      /* i,f,o,g -> c'=f*c+i*g, h'=o*tanh(c') submodules.py:346-358; e1=c, out<-h', o1<-c', o2<-gates */
-    RAMNET_EPI_GRU_BWD = 6    /* backward-data of the candidate convolution W_o*[x, h.r] (ABI 18; Cout = 2C, no bias, beta = 0): channels n < C
+    RAMNET_EPI_GRU_BWD = 6,   /* backward-data of the candidate convolution W_o*[x, h.r] (ABI 18; Cout = 2C, no bias, beta = 0): channels n < C
                                * (dx) are stored as they are; channels n >= C carry g = d(h.r): with r = e0[pix*lde0 + n] (e0 = [u|r]),
                                * h = e1[pix*lde1 + n - C] (NULL: 0): o1[pix*ldo1 + n] <- g*h*r*(1-r) (the reset gate's pre-activation gradient)
                                * and out <- out_old + g*r, out_old = dh'*(1-u) left there by ramnet_gru_bwd_a2 — ramnet_gru_bwd_b without
                                * its launch.  Winograd kernels: C % 64 == 0                                                        */
+    RAMNET_EPI_SIGMOID_HR = 7 /* ConvGRU gates [u | r] = sigmoid(acc + bias) (ABI 21; Cout = 2C, beta = 0): as RAMNET_EPI_SIGMOID, and for the
+                               * channels n >= C (the reset gate r) also o1[pix*ldo1 + n - C] <- e1[pix*lde1 + n - C] * r, the h.r operand of
+                               * the candidate convolution W_o*[x, h.r] (submodules.py:450) — that launch, and the backward-weights launch of
+                               * W_o, then read a plain concatenation [x | h.r] instead of forming the product in their loaders.  e1 = h, o1 = h.r */
 };
 
 /* One convolution launch.  out(a,b) = epi( sum_t sum_c in(a*stride+dy[t], b*stride+dx[t], c) * W[wtap[t]][c][n] ).

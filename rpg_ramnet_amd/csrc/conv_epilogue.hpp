@@ -32,6 +32,9 @@ __device__ __forceinline__ void epilogue_store(const ramnet_conv_desc &p, int ep
         v = fmaxf(v, 0.f);
     } else if (epi == RAMNET_EPI_SIGMOID) {
         v = sigmoidf_(v);
+    } else if (epi == RAMNET_EPI_SIGMOID_HR) {      // gates [u | r]; the r half also writes h.r (ramnet_hip.h)
+        v = sigmoidf_(v);
+        if (n >= p.Cout / 2) p.o1[pix * p.ldo1 + n - p.Cout / 2] = p.e1[pix * p.lde1 + n - p.Cout / 2] * v;
     } else if (epi == RAMNET_EPI_RES_RELU) {
         v = fmaxf(v + p.e0[pix * p.lde0 + n], 0.f);
     } else if (epi == RAMNET_EPI_GRU_BLEND) {
@@ -68,6 +71,12 @@ __device__ __forceinline__ void epilogue_store4(const ramnet_conv_desc &p, int e
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     } else if (epi == RAMNET_EPI_SIGMOID) {
         v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+    } else if (epi == RAMNET_EPI_SIGMOID_HR) {      // (Cout / 2 % 4 == 0: a quad lies in one half)
+        v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+        if (n >= p.Cout / 2) {
+            const float4 h = ld4(p.e1 + pix * p.lde1 + n - p.Cout / 2);
+            st4(p.o1 + pix * p.ldo1 + n - p.Cout / 2, make_float4(h.x * v.x, h.y * v.y, h.z * v.z, h.w * v.w));
+        }
     } else if (epi == RAMNET_EPI_RES_RELU) {
         const float4 e = ld4(p.e0 + pix * p.lde0 + n);
         v = make_float4(fmaxf(v.x + e.x, 0.f), fmaxf(v.y + e.y, 0.f), fmaxf(v.z + e.z, 0.f), fmaxf(v.w + e.w, 0.f));

@@ -224,6 +224,8 @@ static int check_desc(const ramnet_conv_desc &d) {
     if (d.epi == RAMNET_EPI_GRU_BLEND) RAMNET_CHECK_ARG(d.e0);
     if (d.epi == RAMNET_EPI_LSTM) RAMNET_CHECK_ARG(d.o1 && d.bias);
     if (d.epi == RAMNET_EPI_GRU_BWD) RAMNET_CHECK_ARG(d.e0 && d.o1 && d.Cout % 8 == 0 && !d.bias && d.beta == 0.f && d.frame == 0 && d.out_s2d == 0);
+    if (d.epi == RAMNET_EPI_SIGMOID_HR) RAMNET_CHECK_ARG(d.e1 && d.o1 && d.Cout % 8 == 0 && d.beta == 0.f && d.frame == 0 && d.out_s2d == 0 &&
+                                                         d.algo != RAMNET_ALGO_WINOGRAD24 && d.algo != RAMNET_ALGO_HEAD);
     // the patch loaders address their source tensors with 32-bit element offsets (16 GB per tensor: batch ~45 at 256x344x32)
     {
         unsigned long long ld = (unsigned long long)d.ld0;

@@ -325,17 +325,18 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         auto step_of = [&](int ld) { return (unsigned)(RS * p.osy * p.WoF * ld * 4); };
         const auto r_out = rsrc_of(p.out, p.ldo);
         auto run = [&](auto kind) {
-            // 0: linear / ReLU (+ beta * old), 4: sigmoid, 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
+            // 0: linear / ReLU (+ beta * old), 4: sigmoid, 5: sigmoid + h.r (gates), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
             constexpr int K = decltype(kind)::value;
             const bool addold = K == 0 && p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
             const bool relu = epi == RAMNET_EPI_RELU;
             const auto r_e0 = (K >= 1 && K <= 3) ? rsrc_of(p.e0, p.lde0) : r_out;
-            const auto r_e1 = (K == 2 || K == 3) ? rsrc_of(p.e1, p.lde1) : r_out;
-            const auto r_o1 = (K == 2 || K == 3) ? rsrc_of(p.o1, p.ldo1) : r_out;
+            const auto r_e1 = (K == 2 || K == 3 || K == 5) ? rsrc_of(p.e1, p.lde1) : r_out;
+            const auto r_o1 = (K == 2 || K == 3 || K == 5) ? rsrc_of(p.o1, p.ldo1) : r_out;
             const unsigned o_out = off0_of(p.ldo, true), s_out = step_of(p.ldo);
             const unsigned o_e0 = off0_of(p.lde0, K >= 1 && K <= 3), s_e0 = step_of(p.lde0);
-            const unsigned o_e1 = off0_of(p.lde1, (K == 2 || K == 3) && p.e1 != nullptr, K == 3 ? -(p.Cout / 2) : 0), s_e1 = step_of(p.lde1);
-            const unsigned o_o1 = off0_of(p.ldo1, (K == 2 || K == 3) && p.o1 != nullptr), s_o1 = step_of(p.ldo1);
+            // (K = 5: the quads of the reset gate only — a per-thread condition, folded into the offset like every other predicate)
+            const unsigned o_e1 = off0_of(p.lde1, ((K == 2 || K == 3) && p.e1 != nullptr) || (K == 5 && nq >= p.Cout / 2), (K == 3 || K == 5) ? -(p.Cout / 2) : 0), s_e1 = step_of(p.lde1);
+            const unsigned o_o1 = off0_of(p.ldo1, ((K == 2 || K == 3) && p.o1 != nullptr) || (K == 5 && nq >= p.Cout / 2), K == 5 ? -(p.Cout / 2) : 0), s_o1 = step_of(p.ldo1);
             constexpr int HN = 4;                        // quads per half (NF = 2: two halves, the GRU blend's operands stay in registers)
 #pragma unroll
             for (int half = 0; half < NI / HN; ++half) {
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                     oo[i] = (o_out + j * s_out) | bad[j];
                     if (K == 0) ea[i] = addold ? bld(r_out, oo[i]) : f4zero();      // (uniform)
                     if (K >= 1 && K <= 3) ea[i] = bld(r_e0, (o_e0 + j * s_e0) | bad[j]);
-                    if (K == 2 || K == 3) eb[i] = bld(r_e1, (o_e1 + j * s_e1) | bad[j]);
+                    if (K == 2 || K == 3 || K == 5) eb[i] = bld(r_e1, (o_e1 + j * s_e1) | bad[j]);
                     if (K == 3) ec[i] = bld(r_out, oo[i]);
                 }
                 if (!(NF == 1 && ksp > 1)) {
@@ -371,6 +372,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
                         if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                     } else if (K == 4) {
                         v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+                    } else if (K == 5) {      // gates: the reset gate's quads also leave h.r (RAMNET_EPI_SIGMOID_HR; other quads: offset WOOB, h = 0)
+                        v = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+                        const float4 h = eb[i];
+                        bst(r_o1, (o_o1 + j * s_o1) | bad[j], make_float4(h.x * v.x, h.y * v.y, h.z * v.z, h.w * v.w));
                     } else if (K == 1) {
                         v = make_float4(fmaxf(v.x + ea[i].x, 0.f), fmaxf(v.y + ea[i].y, 0.f), fmaxf(v.z + ea[i].z, 0.f), fmaxf(v.w + ea[i].w, 0.f));
                     } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD; conv_epilogue.hpp: gru_bwd_quad)
@@ -392,6 +397,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r_kernel(const ramnet_conv_d
         else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
         else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
         else if (epi == RAMNET_EPI_SIGMOID) run(std::integral_constant<int, 4>{});
+        else if (epi == RAMNET_EPI_SIGMOID_HR) run(std::integral_constant<int, 5>{});
         else run(std::integral_constant<int, 0>{});
         return;
     }

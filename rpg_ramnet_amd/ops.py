@@ -94,6 +94,17 @@ def set_gru_bwd_fused(on):
     _GRU_BWD_FUSED = bool(on)
 
 
+_GRU_HR = _os.environ.get("RAMNET_GRU_HR", "1") != "0"
+
+
+def set_gru_materialize_hr(on):
+    """The ConvGRU gates launch also writes h.r (RAMNET_EPI_SIGMOID_HR): the candidate convolution and its backward-weights launch then read
+    the plain concatenation [x | h.r] instead of forming the product in their loaders (one more state-sized tensor per update, saved for the
+    backward; the same single-rounded products either way).  On by default; off for A/B runs and the loader path's tests."""
+    global _GRU_HR
+    _GRU_HR = bool(on)
+
+
 def set_wgrad_winograd_2x4(mode):
     """F(2x4,3x3) backward-weights for the plain 3x3 layers (ConvGRU / ConvLSTM / residual layers of >= 64 reduction channels): "auto"
     (default) = when the backward-weights launches are co-scheduled with the backward-data chain (set_wgrad_overlap(True): training step
@@ -1614,22 +1625,33 @@ class GRUCell(Function):
         B, Hh, W, Cc = x.shape
         taps = Taps.get("conv", 3, 1)
         ur = torch.empty(B, Hh, W, 2 * Cc, device=x.device)
-        conv_launch(x, taps, cp_ur.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp_ur.bias(), epi=H.EPI_SIGMOID)
+        hr = torch.empty(B, Hh, W, Cc, device=x.device) if (_GRU_HR and Cc % 4 == 0) else None
+        if hr is not None:
+            conv_launch(x, taps, cp_ur.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp_ur.bias(), epi=H.EPI_SIGMOID_HR, e1=h, o1=hr)
+        else:
+            conv_launch(x, taps, cp_ur.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp_ur.bias(), epi=H.EPI_SIGMOID)
         hn = torch.empty(B, Hh, W, Cc, device=x.device) if out is None else out
         if out is not None and (tuple(out.shape) != (B, Hh, W, Cc) or not out.is_contiguous() or out.dtype != torch.float32):
             raise RuntimeError("GRUCell: `out` must be a contiguous fp32 NHWC buffer of the state's shape")
         need = any(ctx.needs_input_grad)
         o = torch.empty_like(hn) if need else None
-        conv_launch(x, taps, cp_o.fwd(), hn, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, bias=cp_o.bias(),
-                    epi=H.EPI_GRU_BLEND, e0=ur, e1=h, o1=o)
+        if hr is not None:
+            conv_launch(x, taps, cp_o.fwd(), hn, Cc, x1=hr, in_mode=H.IN_CAT, C1=Cc, bias=cp_o.bias(), epi=H.EPI_GRU_BLEND, e0=ur, e1=h, o1=o)
+        else:
+            conv_launch(x, taps, cp_o.fwd(), hn, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, bias=cp_o.bias(),
+                        epi=H.EPI_GRU_BLEND, e0=ur, e1=h, o1=o)
         ctx.cps = (cp_ur, cp_o)
+        ctx.has_hr = hr is not None
         if need:
-            ctx.save_for_backward(x, h, ur, o)
+            ctx.save_for_backward(*((x, h, ur, o, hr) if hr is not None else (x, h, ur, o)))
         return hn
 
     @staticmethod
     def backward(ctx, dhn):
-        x, h, ur, o = ctx.saved_tensors
+        if ctx.has_hr:
+            x, h, ur, o, hr = ctx.saved_tensors
+        else:
+            (x, h, ur, o), hr = ctx.saved_tensors, None
         cp_ur, cp_o = ctx.cps
         B, Hh, W, Cc = x.shape
         npix = B * Hh * W
@@ -1648,7 +1670,10 @@ class GRUCell(Function):
             dhd = torch.empty_like(o)
             H.check(L.ramnet_gru_bwd_a(_p(dhn), _p(ur), _p(o), _p(h), _p(dpo), _p(dpur), _p(dhd), npix, Cc, ld(dhn), _st()), "gru_bwd_a")
         ws, bws = cp_o.grad_ws(wino_ok=Cc % 32 == 0)
-        _wgrad_cell(cp_o, ws, [x, h, ur, dpo], x, taps, dpo, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
+        if hr is not None:
+            _wgrad_cell(cp_o, ws, [x, hr, dpo], x, taps, dpo, Cc, x1=hr, in_mode=H.IN_CAT, C1=Cc, dbias=bws)
+        else:
+            _wgrad_cell(cp_o, ws, [x, h, ur, dpo], x, taps, dpo, Cc, x1=h, xm=ur, xm_off=Cc, in_mode=H.IN_CAT_MUL, C1=Cc, dbias=bws)
         if fused:
             conv_launch(dpo, tapsd, cp_o.bwd(), dxh, 2 * Cc, epi=H.EPI_GRU_BWD, e0=ur, e1=h, o1=dpur)
         else:

@@ -676,6 +676,36 @@ def test_conv_gru_backward_stage_b_fused_equals_unfused(B, H, W, C, algo3x3):
         assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-5, "fused vs unfused stage B")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 33, 45, 128), (8, 5, 43, 256), (1, 7, 13, 32), (2, 6, 9, 12)])
+def test_conv_gru_materialised_h_r_equals_the_loader_product(B, H, W, C, algo3x3):
+    """RAMNET_EPI_SIGMOID_HR (ABI 21): the gates launch also writes h.r, the candidate convolution W_o*[x, h.r] (submodules.py:450) and its
+    backward-weights launch read the plain concatenation [x | h.r] — against the loader form (RAMNET_IN_CAT_MUL: the product formed while
+    the patch is staged) on every 3x3 algorithm: the same single-rounded products enter the same sums, so state, input gradients and (Winograd
+    kernels: per-split slabs) weight gradients are BIT-identical; test_conv_gru compares either form with the float64 oracle."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvGRU
+    torch.manual_seed(17)
+    m = ConvGRU(C, C, 3).to(dev())
+    x0, h0 = torch.randn(B, H, W, C, device=dev()), torch.tanh(torch.randn(B, H, W, C, device=dev()))
+    wgt = torch.randn(B, H, W, C, device=dev())
+    res = {}
+    for on in (True, False):
+        ops.set_gru_materialize_hr(on)
+        try:
+            m.zero_grad()
+            x, h = x0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+            y = m(x, h)
+            (y * wgt).sum().backward()
+            res[on] = [y.detach().clone(), x.grad.clone(), h.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+        finally:
+            ops.set_gru_materialize_hr(True)
+    for k, (a, c) in enumerate(zip(res[True], res[False])):
+        if k >= 3 and algo3x3 == "direct":      # (the direct backward-weights kernel joins its tile splits with atomic adds: order-dependent sums)
+            assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-5, "materialised h.r vs loader product, weight gradients")
+        else:
+            assert torch.equal(a, c), "materialised h.r vs loader product (tensor %d)" % k
+
+
 @pytest.mark.parametrize("n,defer,B,H,W,C", [(5, 5, 2, 8, 16, 64), (5, 3, 1, 33, 45, 64), (6, 48, 2, 16, 22, 128), (3, 2, 8, 5, 43, 256)])
 def test_conv_gru_deferred_backward_weights_equal_per_update_launches(n, defer, B, H, W, C):
     """ops.set_wgrad_defer: the backward-weights launches of n chained updates of ONE ConvGRU cell (submodules.py:436-454) queued and
