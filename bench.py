@@ -265,7 +265,8 @@ class KernelTimer:
             elif mode == Hh.IN_CAT_MUL:
                 rd += px_in * c1
             epi = kw.get("epi", Hh.EPI_LINEAR)
-            extra = {Hh.EPI_GRU_BLEND: 3, Hh.EPI_RES_RELU: 1, Hh.EPI_LSTM: 2 + (4 if kw.get("o2") is not None else 0)}.get(epi, 0)
+            extra = {Hh.EPI_GRU_BLEND: 3, Hh.EPI_RES_RELU: 1, Hh.EPI_LSTM: 2 + (4 if kw.get("o2") is not None else 0),
+                     Hh.EPI_SIGMOID_HR: 1}.get(epi, 0)      # (h read and h.r written for the reset gate's half of the 2C outputs)
             extra += 1 if kw.get("beta") else 0
             wr = px_out * Cout * (1 + extra)
             return 4.0 * (rd + wr + nclass * taps.n * cin * nout)
@@ -287,7 +288,7 @@ class KernelTimer:
             else:
                 alg = 2.0 * nclass * x0.shape[0] * Ho * Wo * taps.flop_taps * cin * nout
             tag = None
-            if kw.get("epi") in (Hh.EPI_SIGMOID, Hh.EPI_GRU_BLEND) and kw.get("in_mode", 0) in (Hh.IN_CAT, Hh.IN_CAT_MUL):
+            if kw.get("epi") in (Hh.EPI_SIGMOID, Hh.EPI_SIGMOID_HR, Hh.EPI_GRU_BLEND) and kw.get("in_mode", 0) in (Hh.IN_CAT, Hh.IN_CAT_MUL):
                 tag = "gru_fwd_C%d" % (kw.get("C1") or 0)
             timer._bracket(lambda: conv0(x0, taps, w, out, Cout, **kw), last, sig_of("c", x0, taps, Cout, kw) + (isinstance(w, ops.PackRef),),
                            alg, ratio, tag, conv_bytes(x0, taps, Cout, kw, cin, Ho, Wo, nout, nclass), sparse)
