@@ -108,23 +108,34 @@ def parse():
     return ap.parse_args()
 
 
-def configs4_measure():
-    """BASELINE configs[4]'s per-GPU workload (480 x 640, 10-bin grids, batch 4, sequence length 16: ~100 GB of HBM) as a short run of
-    this script in a process of its own, so that the default line carries a driver-timed number for it."""
+def subprocess_measure(extra, note, steps=2, warmup=1, timeout=240):
+    """A short run of this script in a process of its own with `extra` arguments appended: the default line then carries a driver-timed
+    number for a second workload / variant without disturbing the timed region of the headline."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
-           "--no-kernel-timing", "--height", "480", "--width", "640", "--bins", "10", "--batch", "4", "--seq-len", "16"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--no-cpu-baseline", "--no-extras",
+           "--no-kernel-timing"] + list(extra)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["WORLD_SIZE"] = "1"
     t = time.perf_counter()
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "peak_hbm_gb": d["peak_hbm_gb"],
-                "workload": d["config"]["workload"], "wall_s": time.perf_counter() - t,
-                "note": "configs[4] shape on ONE GPU (its 8-GPU form shards sequences like configs[2]); same binary, a separate process"}
+                "final_loss": d.get("final_loss"), "workload": d["config"]["workload"], "wall_s": time.perf_counter() - t, "note": note}
     except Exception as ex:     # noqa: BLE001
         return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+
+
+def configs4_measure():
+    """BASELINE configs[4]'s per-GPU workload (480 x 640, 10-bin grids, batch 4, sequence length 16: ~100 GB of HBM)."""
+    return subprocess_measure(["--height", "480", "--width", "640", "--bins", "10", "--batch", "4", "--seq-len", "16"],
+                              "configs[4] shape on ONE GPU (its 8-GPU form shards sequences like configs[2]); same binary, a separate process")
+
+
+def full_frame_measure():
+    """SURVEY 8d config 2 'also report 264x352': the raw 260 x 346 frame, reflect-padded to 264 x 352 inside the input repack."""
+    return subprocess_measure(["--full-frame"], "the same training step on the raw 346x260 frame (reflect-padded to 264x352 in the input repack, "
+                              "predictions cropped back; utils/inference_utils.py:287-314); same binary, a separate process", steps=3)
 
 
 def synth_sequence(model, B, L, H, W, K, bins, n_events, seed, keep_events=None):
@@ -377,8 +388,12 @@ def pmc_launches_of(pmc, name):
     return n
 
 
-def traffic_of(pmc, name):
-    """Launch-weighted HBM bytes per launch of kernel symbol `name` (template arguments: rocprofv3 prints ", " separators)."""
+def traffic_of(pmc, name, fetch_x2=False):
+    """Launch-weighted HBM bytes per launch of kernel symbol `name` (template arguments: rocprofv3 prints ", " separators):
+    FETCH_SIZE + WRITE_SIZE as counted — FETCH_SIZE = TCC_EA0_RDREQ x 64 B (MI355X_MICROARCH.md), which profiles/r05_zx_pmc_l2.txt confirms
+    request by request for these kernels (118.9 MB per launch of the dominant kernel either way).  fetch_x2: the guide's correction for
+    128-byte streaming reads (2 x FETCH_SIZE + WRITE_SIZE) — it does not apply to the 32-byte-per-pixel patch loads of the convolution
+    kernels and is only kept as a second figure."""
     want = name.replace(" ", "")
     hit = None
     for k, ent in pmc.items():
@@ -388,7 +403,9 @@ def traffic_of(pmc, name):
     if not hit:
         return None
     n = sum(v["launches"] for v in hit.values())
-    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit.values()) / max(1, n)
+    if fetch_x2:
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit.values()) / max(1, n)
+    return sum((v["fetch_kb_raw"] + v["write_kb"]) * 1024.0 * v["launches"] for v in hit.values()) / max(1, n)
 
 
 def cpu_baseline(cfg, H, W, K, args, mode=None):
@@ -1080,6 +1097,7 @@ def main():
             except Exception as ex:     # noqa: BLE001 — an extra must not take the headline measurement down
                 extras["graph_replay"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             if (H, W, bins, B, L) == (256, 344, 5, 8, 8) and not args.full_frame and not args.no_configs4_extra:
+                extras["full_frame_264x352"] = full_frame_measure()
                 extras["configs4_shape"] = configs4_measure()
 
     stream_roof = None
@@ -1109,6 +1127,8 @@ def main():
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
+               "abs_rel": "unverifiable: no checkpoint/dataset in the image (README.md:59-68 are URLs); the Abs-Rel formula and depth post-processing are "
+                          "pinned against the reference's own outputs (tests/test_hip_ops.py::test_depth_metrics_*)",
                "input_side": ("in the timed loop: per step %d batched voxel scatter-adds of %d fresh on-device event lists (%d events each) + nonzero "
                               "normalisation on an input stream, H2D of %d frames + %d target maps from pinned memory on a copy stream, both beside the "
                               "previous step's compute (bench.InputSide)" % (L, K * B, args.events_per_grid, L * B, 2 * L * B)) if (inp is not None) else
@@ -1159,19 +1179,21 @@ def main():
                 "frac_algorithmic": alg / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
                 "clock_ghz": clock.ghz() if clock is not None else None, "clock_source": "rocm-smi --showclocks sclk, mean over the warm-up steps "
                 "(None: tool absent); peak = spec clock 2.4 GHz",
-                "traffic": traffic, "traffic_source": "profiles/" + pmc_file,
+                "traffic": traffic, "traffic_fetch_size_x2": None if pmc_stale else traffic_of(pmc, name, fetch_x2=True),
+                "traffic_source": "profiles/" + pmc_file,
                 "operand_bytes_per_launch": opb / n, "traffic_over_operand_bytes": (traffic / (opb / n)) if traffic and opb else None,
                 "launches": n, "avg_launch_ms": 1e3 * secs / n,
                 "executed_gflop_per_launch": ex / n / 1e9, "algorithmic_gflop_per_launch": alg / n / 1e9,
                 "algorithmic_achieved": alg / secs / 1e12,
                 "note": "frac_algorithmic = SURVEY 8d quantity (algorithmic FLOP per launch / average launch duration / peak; can exceed the "
-                        "executed fraction by the Winograd factor 36/16); frac = frac_executed = pipe utilisation.  "
-                        "achieved/frac = EXECUTED MFMA FLOP (Winograd: 16/36 of the 3x3 layer's, 12.25/25 for space-to-depth encoders) over "
+                        "executed fraction by the Winograd factor 72/24 = 3 of F(2x4,3x3)); frac = frac_executed = pipe utilisation.  "
+                        "achieved/frac = EXECUTED MFMA FLOP (F(2x4,3x3): 24/72 of the 3x3 layer's, F(2x2,3x3) 16/36, folded decoders 25/64) over "
                         "HIP-event durations of this kernel in the timed region, which co-schedules three streams (main, decoders, "
                         "backward-weights) — wall durations include time shared with other kernels; extras.single_stream.dominant_kernel "
                         "= same launches on one stream.  algorithmic_achieved = layer-level rate (SURVEY 8d count).  traffic = HBM bytes "
-                        "per launch, (2*FETCH_SIZE + WRITE_SIZE), launch-weighted over the kernel's grids (gfx950 FETCH_SIZE counts 1/2 "
-                        "of wide reads, MI355X_MICROARCH.md); operand_bytes_per_launch = inputs, masks and epilogue operands read once + outputs "
+                        "per launch, TCC_EA_RDREQ x 64 B + WRITE_SIZE (= FETCH_SIZE + WRITE_SIZE as counted), launch-weighted over the kernel's grids; traffic_fetch_size_x2 "
+                        "= 2*FETCH_SIZE + WRITE_SIZE, the guide's correction for 128-byte streaming reads, which these 32-byte-per-pixel patch loads are not (L2 hit rate "
+                        "90 %, nothing is fetched twice: profiles/r05_zx_pmc_l2.txt); operand_bytes_per_launch = inputs, masks and epilogue operands read once + outputs "
                         "written once + weights once (backward-weights: input, gradient and their masks read once + the gradient workspace read and written "
                         "once; its per-split slabs repeat that last term per split), averaged over the same launches"}
             if pmc_stale:

@@ -162,7 +162,7 @@ typedef struct ramnet_wgrad_desc {
                                      * a layer serialised on one stream the gradient is bit-reproducible; ramnet_reduce_slabs() folds the
                                      * slabs into slab 0 before ramnet_unpack_wgrad_wino().  Other algorithms ignore it.           */
     int nseg;                       /* 0: one launch over x0 / x1 / xm / dout / gmask above.  1..RAMNET_WGRAD_MAX_SEGMENTS (RAMNET_ALGO_WINOGRAD_2X4
-                                     * and RAMNET_ALGO_WINOGRAD only): `segs` (HOST memory, copied into the kernel arguments by the launch) lists nseg tensor
+                                     * only — ramnet_wgrad_launch rejects nseg > 0 for every other algorithm): `segs` (HOST memory, copied into the kernel arguments by the launch) lists nseg tensor
                                      * sets of B images each; the launch reduces over all of them (one prologue / one join of the tile splits'
                                      * partial sums instead of nseg).  x0 ... gmask above must still be non-NULL where the mode uses them.   */
     const ramnet_wgrad_seg *segs;

@@ -3,6 +3,7 @@
 // loops (coalesced 16 B per lane, 1 KiB per wavefront instruction).
 #include <stdarg.h>
 #include <mutex>
+#include <unordered_map>
 #include <unordered_set>
 #include <stdlib.h>
 #include <string.h>
@@ -48,11 +49,20 @@ hipError_t allow_full_lds(const void *kernel) {
 // refers to the record that precedes it, so the event can be re-recorded at once.  The host cost of forking the backward-weights stream off
 // the backward-data chain ~400 times per training step (torch: a Stream object, an Event object and a context manager per fork: ~30 us).
 extern "C" int ramnet_stream_fork(void *from, void *to) {
-    static thread_local hipEvent_t ev[16] = {};
-    int dev = 0;
-    RAMNET_HIP(hipGetDevice(&dev));
-    hipEvent_t &e = ev[dev & 15];
-    if (!e) RAMNET_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // one event per (thread, device that OWNS `from`): the current device need not be the streams' (wgrad_side passes the side stream of its
+    // operands' device), and an event recorded on a stream of another device is an invalid-handle error
+    static thread_local std::unordered_map<int, hipEvent_t> ev;
+    int dev = 0, cur = 0;
+    RAMNET_HIP(hipGetDevice(&cur));
+    dev = cur;
+    if (from && hipStreamGetDevice((hipStream_t)from, &dev) != hipSuccess) (void)hipGetLastError(), dev = cur;
+    hipEvent_t &e = ev[dev];
+    if (!e) {
+        if (dev != cur) RAMNET_HIP(hipSetDevice(dev));
+        const hipError_t ce = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (dev != cur) RAMNET_HIP(hipSetDevice(cur));
+        RAMNET_HIP(ce);
+    }
     RAMNET_HIP(hipEventRecord(e, (hipStream_t)from));
     RAMNET_HIP(hipStreamWaitEvent((hipStream_t)to, e, 0));
     return 0;

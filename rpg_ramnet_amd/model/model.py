@@ -209,12 +209,13 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
             feats.append(parts)
         # slot k of arena[i] = the state of scale i after update k (slot K: after the frame); written by the cells, never by a torch op
         pair = net.state_combination == 'convlstm'           # (h, c) per scale: the decoders read h
+        # (ops.arena_slots: the slots are aliases with version counters of their own, not views of the buffer)
         if pair:
-            arena = [[torch.empty((K + 1,) + tuple(t.shape), device=self.gpu) for t in s] for s in states]
+            arena = [[ops.arena_slots(K + 1, t.shape, self.gpu) for t in s] for s in states]
         else:
-            arena = [torch.empty((K + 1,) + tuple(s.shape), device=self.gpu) for s in states]
-        slot = (lambda i, k: [a[k] for a in arena[i]]) if pair else (lambda i, k: arena[i][k])
-        hbuf = (lambda i: arena[i][0]) if pair else (lambda i: arena[i])
+            arena = [ops.arena_slots(K + 1, s.shape, self.gpu) for s in states]
+        slot = (lambda i, k: [a[1][k] for a in arena[i]]) if pair else (lambda i, k: arena[i][1][k])
+        hbuf = (lambda i: arena[i][0][0]) if pair else (lambda i: arena[i][0])
         hof = (lambda s: s[0]) if pair else (lambda s: s)
         lc = self.loss_composition
         sup = [k for k in range(K + 1) if keys[k] in lc] if isinstance(lc, (list, tuple)) else None
@@ -342,6 +343,9 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
                 if not torch.cuda.is_current_stream_capturing():
                     for pred in predictions_dict.values():
                         pred.record_stream(torch.cuda.current_stream())
+                        fused = getattr(pred, "_si_fused", None)       # (the fused loss term was allocated on the decode stream too)
+                        if fused is not None and torch.is_tensor(fused[0]):
+                            fused[0].record_stream(torch.cuda.current_stream())
             return predictions_dict, super_state_dict, states_lstm_dict
         if not bool(baseline) or events_as_image:
             if events_as_image:

@@ -17,6 +17,10 @@ from . import _hip as H
 
 _NULL = None
 _ABL_SKIP_WGRAD = _os.environ.get("RAMNET_ABL_SKIP_WGRAD") == "1"
+if _ABL_SKIP_WGRAD:
+    import warnings as _warnings
+    _warnings.warn("RAMNET_ABL_SKIP_WGRAD=1: backward-weights launches are SKIPPED — every weight gradient of this process is zero "
+                   "(tuning runs only; unset the variable for anything else)", RuntimeWarning)
 
 # 3x3 stride-1 layers (ConvGRU gates / candidate, residual blocks) run Winograd F(2x2,3x3) in fp32 — 2.25x fewer
 # multiplies, rounding error ~1e-6 relative (tests/test_hip_ops.py) — unless switched off (RAMNET_WINOGRAD=0).
@@ -1631,8 +1635,12 @@ class GRUCell(Function):
         else:
             conv_launch(x, taps, cp_ur.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp_ur.bias(), epi=H.EPI_SIGMOID)
         hn = torch.empty(B, Hh, W, Cc, device=x.device) if out is None else out
-        if out is not None and (tuple(out.shape) != (B, Hh, W, Cc) or not out.is_contiguous() or out.dtype != torch.float32):
-            raise RuntimeError("GRUCell: `out` must be a contiguous fp32 NHWC buffer of the state's shape")
+        if out is not None:
+            if tuple(out.shape) != (B, Hh, W, Cc) or not out.is_contiguous() or out.dtype != torch.float32:
+                raise RuntimeError("GRUCell: `out` must be a contiguous fp32 NHWC buffer of the state's shape")
+            # the library writes `out` behind autograd's back: declared as an in-place modification, so that its version counter moves and
+            # a cell that saved the slot's previous content for its backward raises instead of differentiating the overwritten state
+            ctx.mark_dirty(out)
         need = any(ctx.needs_input_grad)
         o = torch.empty_like(hn) if need else None
         if hr is not None:
@@ -1730,6 +1738,17 @@ def _cat_batch_add(grads, base, shape, device):
     return out
 
 
+def arena_slots(n, shape, device):
+    """A [n, *shape] fp32 buffer and n tensors over its consecutive slots that are NOT autograd views of it (each has its own version counter):
+    a cell that writes slot k (GRUCell / LSTMCell `out=`, declared with mark_dirty) neither rebases the history of the other slots nor
+    invalidates what other cells saved of them, and overwriting a slot whose old content a backward still needs raises."""
+    buf = torch.empty((n,) + tuple(shape), device=device, dtype=torch.float32)
+    numel = buf[0].numel()
+    st = buf.untyped_storage()
+    slots = [torch.empty(0, device=device, dtype=torch.float32).set_(st, buf.storage_offset() + k * numel, tuple(shape)) for k in range(n)]
+    return buf, slots
+
+
 class TimeSplit(Function):
     """[n * B, ...] -> n views [B, ...] (the features of n measurements that went through a layer chain as one batch); backward
     concatenates the n gradients (ONE launch) instead of autograd's n zero-fills + n slice copies."""
@@ -1803,6 +1822,9 @@ class LSTMCell(Function):
         for t in (out_h, out_c):
             if t is not None and (tuple(t.shape) != (B, Hh, W, Cc) or not t.is_contiguous() or t.dtype != torch.float32):
                 raise RuntimeError("LSTMCell: `out_h` / `out_c` must be contiguous fp32 NHWC buffers of the state's shape")
+        dirty = [t for t in (out_h, out_c) if t is not None]
+        if dirty:
+            ctx.mark_dirty(*dirty)          # (as in GRUCell: written by the library, declared to autograd)
         need = any(ctx.needs_input_grad)
         gates = torch.empty(B, Hh, W, 4 * Cc, device=x.device) if need else None
         conv_launch(x, Taps.get("conv", 3, 1), cp.fwd(), hn, Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp.bias(),

@@ -73,6 +73,15 @@ def sequence_loss(model, sequence, loss_composition, loss_weights, loss_params=N
     for item in sequence:
         if ask:
             model._si_fuse = {"weight": si_par[0], "n_lambda": si_par[1], "keys": list(loss_composition)}
+            # the supervised targets move to the device ONCE (a DataLoader item holds CPU tensors): the model's fused loss and the term below
+            # then see the same tensor — a second copy would make the pointers differ, the fused term be dropped and its launches wasted
+            moved = {}
+            for key in loss_composition:
+                t = item.get('depth_' + key)
+                if torch.is_tensor(t) and (t.device != torch.device(model.gpu) or t.dtype != torch.float32 or not t.is_contiguous()):
+                    moved['depth_' + key] = t.to(device=model.gpu, dtype=torch.float32).contiguous()
+            if moved:
+                item = dict(item, **moved)
         try:
             preds, supers, lstms = model(item, prev_super, prev_lstm)
         finally:

@@ -460,3 +460,58 @@ def test_bench_shape_training_step_properties(bench_schedule):
                 terms_ref.append(float((d ** 2).mean() - d.mean() ** 2))
     np.testing.assert_allclose(terms_hip, terms_ref, rtol=1e-4)
     print("B=8 L=8 step: loss %.6f; first four SI terms hip %s ref %s" % (loss1, terms_hip, terms_ref))
+
+
+def test_config4_full_training_step_B4_L16(bench_schedule):
+    """BASELINE configs[4]'s per-GPU workload at its REAL size — 480 x 640, 10-bin voxel grids, B = 4, L = 16, K = 5
+    (96 state updates, 32 supervised decodes, ~100 GB of HBM; 20 % NaN targets as on MVSEC-like data) — as ONE training step on the bench
+    schedule.  As for configs[1] (test_bench_shape_training_step_properties): the first two packages against the fp32 oracle (forward is
+    causal: their predictions and SI terms at L = 16 equal those of an L = 2 run), then the whole step as properties — finite loss, every
+    parameter a finite non-zero gradient, a second run reproduces loss and gradients — and the memory the DESIGN quotes (< 288 GB)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    Bn, Hn, Wn, K, L, bins = 4, 480, 640, 5, 16, 10
+    cfg, _ = ref_cfg("net_seeded_ramnet_bins10.npz", every_x_rgb_frame=K, loss_composition=["image", "events4"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(44)
+    seq = [make_item(rng, Bn, Hn, Wn, K, bins, 1, True, 0.2) for _ in range(L)]
+    dseq = [{k: v.to(model.gpu) for k, v in it.items()} for it in seq]
+    torch.cuda.reset_peak_memory_stats()
+
+    def run():
+        model.zero_grad()
+        total, reported = sequence_loss(model, dseq, cfg["loss_composition"], [1, 1])
+        total.backward()
+        torch.cuda.synchronize()
+        assert abs(float(reported) - 2 * float(total.detach())) <= 1e-6 * abs(float(reported)), "reported loss = (#keys) x the differentiated one (a9 quirk)"
+        return float(total.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    loss1, g1 = run()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    loss2, g2 = run()
+    assert np.isfinite(loss1) and abs(loss1 - loss2) <= 1e-6 * abs(loss1)
+    assert peak < 288.0, "peak %.1f GB" % peak
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    for k, v in g1.items():
+        assert bool(torch.isfinite(v).all()), k
+        assert float(v.abs().max()) > 0, k
+        assert_close(g2[k].cpu().numpy(), v.cpu().numpy(), 1e-4, "second run: " + k, floor=1e-2 * gmax)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    terms_ref, terms_hip = [], []
+    with torch.no_grad():
+        prev, lstm = None, ramnet_ref.empty_states_lstm(K)
+        rprev, rlstm = None, ramnet_ref.empty_states_lstm(K)
+        for l in range(2):
+            preds, supers, lstm = model(dseq[l], prev, lstm)
+            rpreds, rsupers, rlstm = ramnet_ref.forward_recurrent(sd, cfg, seq[l], rprev, rlstm)
+            prev, rprev = supers["image"], rsupers["image"]
+            for key in cfg["loss_composition"]:
+                assert_close(preds[key].cpu().numpy(), rpreds[key].numpy(), 1e-3, "package %d pred %s" % (l, key), elem_tol=1e-3)
+                terms_hip.append(float(ops.scale_invariant_loss(preds[key], dseq[l]["depth_" + key])))
+                d = (rpreds[key].double() - seq[l]["depth_" + key].double()).flatten()
+                d = d[~torch.isnan(d)]                              # loss.py:7: the NaN pixels of the target are masked out
+                terms_ref.append(float((d ** 2).mean() - d.mean() ** 2))
+            for a, b_ in zip(supers["image"], rsupers["image"]):
+                assert_close(a.cpu().numpy(), b_.numpy(), 1e-3, "package %d state" % l, elem_tol=1e-3)
+    np.testing.assert_allclose(terms_hip, terms_ref, rtol=1e-4)
+    print("configs[4] B=4 L=16 step: loss %.6f, peak %.1f GB; first four SI terms hip %s ref %s" % (loss1, peak, terms_hip, terms_ref))

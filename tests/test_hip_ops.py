@@ -706,6 +706,45 @@ def test_conv_gru_materialised_h_r_equals_the_loader_product(B, H, W, C, algo3x3
             assert torch.equal(a, c), "materialised h.r vs loader product (tensor %d)" % k
 
 
+@pytest.mark.parametrize("cell", ["convgru", "convlstm"])
+def test_overwriting_a_state_slot_before_backward_raises(cell):
+    """The cells write their new state into a caller's buffer (`out=`: the slots of the time-batched forward, ops.arena_slots) behind
+    autograd's back; the write is declared (ctx.mark_dirty), so a later write to a slot whose OLD content a pending backward saved — the next
+    cell keeps its input state for its backward (submodules.py:436-454 differentiated) — raises instead of differentiating the overwritten
+    state.  Slots are aliases with version counters of their own: writing slot 1 does not invalidate what was saved of slot 0."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvGRU, ConvLSTM
+    torch.manual_seed(2)
+    B, H, W, C = 1, 8, 12, 32
+    m = (ConvGRU if cell == "convgru" else ConvLSTM)(C, C, 3).to(dev())
+    pair = cell == "convlstm"
+
+    def slots():
+        bufs = [ops.arena_slots(2, (B, H, W, C), dev()) for _ in range(2 if pair else 1)]
+        return bufs, (lambda k: tuple(b[1][k] for b in bufs) if pair else bufs[0][1][k])
+
+    def first(st):
+        return st[0] if pair else st
+
+    x = [torch.randn(B, H, W, C, device=dev(), requires_grad=True) for _ in range(3)]
+    h0 = torch.zeros(B, H, W, C, device=dev())
+    h0 = (h0, h0.clone()) if pair else h0
+    # (1) the legal pattern: slot 0, then slot 1 from slot 0 — backward runs, and the buffer holds both states consecutively
+    bufs, slot = slots()
+    s0 = m(x[0], h0, slot(0))
+    s1 = m(x[1], s0, slot(1))
+    assert first(s0).data_ptr() == bufs[0][0].data_ptr() and first(s1).data_ptr() == bufs[0][0][1].data_ptr()
+    first(s1).sum().backward()
+    assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) for t in x[:2])
+    # (2) slot 0 rewritten while the second cell's backward still needs its old content
+    bufs, slot = slots()
+    s0 = m(x[0], h0, slot(0))
+    s1 = m(x[1], s0, slot(1))
+    m(x[2], h0, slot(0))
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        first(s1).sum().backward()
+
+
 @pytest.mark.parametrize("n,defer,B,H,W,C", [(5, 5, 2, 8, 16, 64), (5, 3, 1, 33, 45, 64), (6, 48, 2, 16, 22, 128), (3, 2, 8, 5, 43, 256)])
 def test_conv_gru_deferred_backward_weights_equal_per_update_launches(n, defer, B, H, W, C):
     """ops.set_wgrad_defer: the backward-weights launches of n chained updates of ONE ConvGRU cell (submodules.py:436-454) queued and
