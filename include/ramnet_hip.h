@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 21      /* 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20: ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 22      /* 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -57,7 +57,11 @@ enum ramnet_in_mode {
  * G = [1/2 0 0 0; -1/2 -1/2 -1/2 -1/2; -1/6 1/6 -1/6 1/6; 1/6 1/3 2/3 4/3; 0 0 0 1] (Toom-Cook points 0, 1, -1, 2, inf).  */
 /* RAMNET_ALGO_WINOGRAD_2X4: F(2x4,3x3) — 2 x 4 output tiles, 3 instead of 4 multiplies per output (csrc/conv_wino6.hip); the same launches
  * as RAMNET_ALGO_WINOGRAD restricted to what ramnet_conv_wino_variant() accepts, w from ramnet_pack_weight_wino2x4()                 */
-enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3, RAMNET_ALGO_WINOGRAD_2X4 = 4 };
+/* RAMNET_ALGO_WINOGRAD_2X4_SPLIT (ABI 22): the launches of RAMNET_ALGO_WINOGRAD_2X4 with every Winograd-domain product evaluated on the bf16
+ * matrix pipe from three-term bf16 splits of BOTH operands (six of the nine partial products, fp32 accumulation: fp32-level accuracy;
+ * csrc/conv_wino6s.hip), where ramnet_conv_wino_split_ok() accepts the descriptor; w from ramnet_pack_weight_wino2x4_split()                */
+enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3, RAMNET_ALGO_WINOGRAD_2X4 = 4,
+                   RAMNET_ALGO_WINOGRAD_2X4_SPLIT = 5 };
 
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {
@@ -235,6 +239,12 @@ int ramnet_pack_weight_wino2x4(const float *w_oihw, float *wp, int Cout, int Cin
 /* 1 when a launch that qualifies for RAMNET_ALGO_WINOGRAD (d->algo set so, every other field final) runs faster as
  * RAMNET_ALGO_WINOGRAD_2X4 — the caller then sets d->algo and d->w (ramnet_pack_weight_wino2x4) accordingly; else 0.              */
 int ramnet_conv_wino_variant(const ramnet_conv_desc *d, int force);   /* force: skip the size heuristics (tests) */
+/* 1 when a launch that ramnet_conv_wino_variant() accepts can run as RAMNET_ALGO_WINOGRAD_2X4_SPLIT (16-channel chunks: the boundary of a
+ * concatenation at a multiple of 16 channels, space-to-depth views of >= 16 channels); the caller then sets d->algo and d->w
+ * (ramnet_pack_weight_wino2x4_split: three bf16 planes, 6 bytes per Winograd-domain weight; the size is returned in 4-byte units).           */
+int ramnet_conv_wino_split_ok(const ramnet_conv_desc *d, int force);
+size_t ramnet_packed_weight_elems_wino2x4_split(int Cout, int Cin, int transposed);
+int ramnet_pack_weight_wino2x4_split(const float *w_oihw, float *wp, int Cout, int Cin, int transposed, void *stream);
 /* Floats of split-reduction workspace a RAMNET_ALGO_WINOGRAD launch of this descriptor (every other field final) would use, 0 when it
  * would not split (enough workgroups, epilogue kinds that do not join partials, option "wino_ksplit" = 0).                              */
 size_t ramnet_conv_splitk_floats(const ramnet_conv_desc *d);

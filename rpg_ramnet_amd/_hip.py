@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet_hip.so")     # (override: A/B builds)
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D, IN_PARITY4 = range(8)
-ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24, ALGO_WINOGRAD_2X4 = 0, 1, 2, 3, 4
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24, ALGO_WINOGRAD_2X4, ALGO_WINOGRAD_2X4_SPLIT = 0, 1, 2, 3, 4, 5
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM, EPI_GRU_BWD, EPI_SIGMOID_HR = range(8)
 
 _fp = C.c_void_p
@@ -90,6 +90,9 @@ _SIGS = {
     "ramnet_pack_weight_wino2x4": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_wino2x4_config": (C.c_int, [C.c_int]),
     "ramnet_conv_wino_variant": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "ramnet_conv_wino_split_ok": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "ramnet_packed_weight_elems_wino2x4_split": (C.c_size_t, [C.c_int] * 3),
+    "ramnet_pack_weight_wino2x4_split": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_conv_splitk_floats": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "ramnet_packed_weight_elems_head": (C.c_size_t, [C.c_int]),
     "ramnet_head_supported": (C.c_int, [C.c_int, C.c_int]),
@@ -204,7 +207,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 21:
+        if l.ramnet_abi_version() != 22:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

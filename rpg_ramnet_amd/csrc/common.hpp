@@ -20,6 +20,7 @@ void note_kernel(const char *fmt, ...);   // symbol (template arguments included
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st);   // conv_wino.hip
 size_t wino24_splitk_floats(const ramnet_conv_desc &d);      // conv_wino24.hip
 int launch_wino6(const ramnet_conv_desc &d, hipStream_t st);  // conv_wino6.hip: F(2x4,3x3)
+int launch_wino6s(const ramnet_conv_desc &d, hipStream_t st); // conv_wino6s.hip: F(2x4,3x3), split bf16 operands
 int launch_head(const ramnet_conv_desc &d, hipStream_t st);   // conv_head.hip
 int launch_wino24(const ramnet_conv_desc &d, hipStream_t st); // conv_wino24.hip
 int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino24.hip

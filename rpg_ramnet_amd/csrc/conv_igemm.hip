@@ -325,6 +325,10 @@ extern "C" int ramnet_conv_launch(const ramnet_conv_desc *dp, void *stream) {
         const int rc = check_desc(*dp);
         return rc ? rc : launch_wino6(*dp, (hipStream_t)stream);
     }
+    if (dp->algo == RAMNET_ALGO_WINOGRAD_2X4_SPLIT) {
+        const int rc = check_desc(*dp);
+        return rc ? rc : launch_wino6s(*dp, (hipStream_t)stream);
+    }
     if (dp->algo == RAMNET_ALGO_WINOGRAD24) {
         const int rc = check_desc(*dp);
         return rc ? rc : launch_wino24(*dp, (hipStream_t)stream);

@@ -28,8 +28,11 @@ struct WinoParams {
 // over that image.  Per chunk a slot is ONE buffer load (+ one for the mask / h*r operand) with a scalar byte offset for the
 // channel (and, for the space-to-depth view, the parity pixel), and one 16-byte LDS store.
 // NS = (pixel, channel quad) slots per thread: 2 for the 128-pixel tiles of F(2x2,3x3), 3 for the 256-pixel tiles of F(2x4,3x3).
-template <int MODE, int NS = 2>
+// QPP = channel quads per pixel and chunk: 2 (8-channel chunks, fp32 MFMA K steps) or 4 (16-channel chunks of the split-operand kernel,
+// conv_wino6s.hip: one v_mfma_f32_32x32x16_bf16 reduces 16 channels).
+template <int MODE, int NS = 2, int QPP = 2>
 struct WinoPatch {
+    static_assert(QPP == 2 || QPP == 4, "quads per pixel");
     static constexpr bool CAT = MODE == RAMNET_IN_CAT || MODE == RAMNET_IN_CAT_MUL;
     float4 v[NS], m[NS];
     unsigned vo0[NS], vo1[NS], vom[NS];      // byte offsets of (pixel, quad) in image b of x0 / x1 / xm, or WOOB
@@ -37,7 +40,7 @@ struct WinoPatch {
     int ldst[NS];                         // LDS float offset of the slot (a scratch location for the threads without one)
     decltype(wino_rsrc(nullptr, 0u)) r0, r1, rm;
 
-    // LDS patch layout: [channel quad 2][PH x PW pixels][4]; scratch = float offset of 256 spare 16-byte cells
+    // LDS patch layout: [channel quad QPP][PH x PW pixels][4]; scratch = float offset of 256 spare 16-byte cells
     // PWS / PLANE / SKEW: row pitch in pixels, floats per quad plane, and a per-row column skew of ((row >> 1) & 3) pixels — the
     // bank-conflict-free layout of conv_wino6.hip (defaults: the dense layout of conv_wino.hip)
     template <int PH, int PW, int PWS = PW, int PLANE = PH * PW * 4, bool SKEW = false>
@@ -51,10 +54,10 @@ struct WinoPatch {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int sl = tid + i * 256;
-            const int pix = sl >> 1, qd = sl & 1;
+            const int pix = sl / QPP, qd = sl % QPP;
             const int py = pix / PW, px = pix - py * PW;
             const int iy = iy0 + py, ix = ix0 + px;
-            const bool slot = sl < PH * PW * 2;
+            const bool slot = sl < PH * PW * QPP;
             const bool in = slot && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
             // space-to-depth view: logical pixel (iy, ix) starts at full-resolution pixel (2iy, 2ix); the parity group of a
             // chunk only moves the (wave-uniform) scalar offset, see load_slot

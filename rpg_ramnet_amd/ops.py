@@ -109,6 +109,22 @@ def set_gru_materialize_hr(on):
     _GRU_HR = bool(on)
 
 
+_SPLIT_OPERANDS = False
+
+
+def set_split_operands(on):
+    """F(2x4,3x3) forward / backward-data launches with three-term bf16 splits of both operands on the bf16 matrix pipe (RAMNET_ALGO_WINOGRAD_2X4_SPLIT,
+    csrc/conv_wino6s.hip: six of the nine partial products, fp32 accumulation — fp32-level accuracy, the parity suites run it at unchanged
+    tolerances) instead of the exact-fp32 MFMA.  Off by default: the headline arithmetic is exact fp32."""
+    global _SPLIT_OPERANDS
+    _SPLIT_OPERANDS = bool(on)
+    invalidate_descs()
+
+
+def get_split_operands():
+    return _SPLIT_OPERANDS
+
+
 def set_wgrad_winograd_2x4(mode):
     """F(2x4,3x3) backward-weights for the plain 3x3 layers (ConvGRU / ConvLSTM / residual layers of >= 64 reduction channels): "auto"
     (default) = when the backward-weights launches are co-scheduled with the backward-data chain (set_wgrad_overlap(True): training step
@@ -305,7 +321,7 @@ def _conv_desc(x0, taps, w, out, Cout, *, stride=1, x1=None, xm=None, xm_off=0, 
             al |= t.data_ptr()
     key = (id(taps), id(w.cp) if is_ref else 0, w.transposed if is_ref else -1, id(ws_owner), Cout, stride, in_mode, C0, C1, Hin, Win, epi, beta, Ho,
            Wo, os, out_off, frame, out_s2d, wino24, xm_off, tuple(x0.shape), x0.stride(2), _sd(x1), _sd(xm), out.shape[1], out.shape[2],
-           out.stride(2), _sd(e0), _sd(e1), _sd(o1), _sd(o2), bias is None, al & 15, _WINOGRAD, _WINO_2X4, _HEAD, _S2D_SPARSE, _S2D_2X4,
+           out.stride(2), _sd(e0), _sd(e1), _sd(o1), _sd(o2), bias is None, al & 15, _WINOGRAD, _WINO_2X4, _SPLIT_OPERANDS, _HEAD, _S2D_SPARSE, _S2D_2X4,
            _DESC_EPOCH, x0.device.index)
     hit = _DESC_CACHE.get(key) if _DESC_CACHE_ON else None
     if hit is not None and (not is_ref or hit[3]() is w.cp) and (ws_owner is None or hit[4]() is ws_owner):
@@ -374,8 +390,11 @@ def _conv_desc_build(x0, taps, w, out, Cout, meta, *, stride=1, x1=None, xm=None
         d.algo = H.ALGO_WINOGRAD24
     if ref is not None and _WINO_2X4 != "off" and H.lib().ramnet_conv_wino_variant(C.byref(d), int(_WINO_2X4 == "force")):
         # F(2x4,3x3) on the fine scales (csrc/conv_wino6.hip): its own Winograd-domain pack of the same parameters
-        d.algo, d.w, d.s2d_5x5 = H.ALGO_WINOGRAD_2X4, _p(ref.cp.pack(ref.transposed, "2x4")), 0      # (dense: the F(2x4) kernel skips no zero slices)
+        d.algo, d.s2d_5x5 = H.ALGO_WINOGRAD_2X4, 0      # (dense: the F(2x4) kernel skips no zero slices)
         kind = "2x4"
+        if _SPLIT_OPERANDS and H.lib().ramnet_conv_wino_split_ok(C.byref(d), int(_WINO_2X4 == "force")):
+            d.algo, kind = H.ALGO_WINOGRAD_2X4_SPLIT, "2x4s"       # the same launch on the bf16 matrix pipe, split operands (csrc/conv_wino6s.hip)
+        d.w = _p(ref.cp.pack(ref.transposed, kind))
     if d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD24) and cp is not None:
         # latency-bound launches (batch-1 streaming on the coarse scales) split their channel reduction: the library says how much
         # workspace the launch would use, the layer owns it (csrc/conv_wino.hip, ramnet_conv_desc.splitk_ws)
@@ -819,6 +838,10 @@ class ConvParam:
             out = torch.empty(L.ramnet_packed_weight_elems_wino2x4(self.Cout, self.Cin, transposed), device=w.device, dtype=torch.float32)
             H.check(L.ramnet_pack_weight_wino2x4(_p(w), _p(out), self.Cout, self.Cin, transposed, _st()), "ramnet_pack_weight_wino2x4")
             return out
+        if wino == "2x4s":      # three bf16 planes of the same Winograd-domain weights (csrc/conv_wino6s.hip); the size is in 4-byte units
+            out = torch.empty(L.ramnet_packed_weight_elems_wino2x4_split(self.Cout, self.Cin, transposed), device=w.device, dtype=torch.float32)
+            H.check(L.ramnet_pack_weight_wino2x4_split(_p(w), _p(out), self.Cout, self.Cin, transposed, _st()), "ramnet_pack_weight_wino2x4_split")
+            return out
         if wino:
             n = L.ramnet_packed_weight_elems_wino(self.Cout, self.Cin, transposed, g)
             out = torch.empty(n, device=w.device, dtype=torch.float32)
@@ -832,7 +855,7 @@ class ConvParam:
     def pack(self, transposed, wino=False):
         """Packed weights for the forward (transposed=0) / backward-data (1) launch, re-packed when a parameter changes."""
         v = self._versions(self.weights)
-        wino = wino if wino in ("head", "2x4") else bool(wino)
+        wino = wino if wino in ("head", "2x4", "2x4s") else bool(wino)
         key = (transposed, wino)
         hit = self._packs.get(key)
         if hit is None or hit[0] != v:

@@ -208,20 +208,23 @@ def test_transposed_conv(B, H, W, cin, cout, skip):
     run_pair(m, oracle, [x, s] if skip else [x])
 
 
-@pytest.fixture(params=["winograd", "direct", "winograd2x4"])
+@pytest.fixture(params=["winograd", "direct", "winograd2x4", "winograd2x4_split"])
 def algo3x3(request):
-    """3x3 stride-1 layers: Winograd F(2x2,3x3) (default at these sizes), the direct implicit GEMM, and F(2x4,3x3) (the fine-scale
-    kernel of the training batch, forced here for every eligible launch), all against the oracle."""
+    """3x3 stride-1 layers: Winograd F(2x2,3x3) (default at these sizes), the direct implicit GEMM, F(2x4,3x3) (the fine-scale
+    kernel of the training batch, forced here for every eligible launch) and F(2x4,3x3) with split bf16 operands (csrc/conv_wino6s.hip),
+    all against the oracle at the same tolerances."""
     from rpg_ramnet_amd import ops
     old = ops.get_winograd()
     ops.set_winograd(request.param != "direct")
-    if request.param == "winograd2x4":
+    if request.param.startswith("winograd2x4"):
         ops.set_winograd_2x4("force")
         ops.set_wgrad_winograd_2x4("force")         # ... and the F(2x4,3x3) backward-weights kernel (csrc/conv_wgrad_wino6.hip)
+        ops.set_split_operands(request.param.endswith("_split"))
     yield request.param
     ops.set_winograd(old)
     ops.set_winograd_2x4("auto")
     ops.set_wgrad_winograd_2x4("auto")
+    ops.set_split_operands(False)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2), (1, 32, 8), (2, 8, 32), (1, 64, 86)])
@@ -229,7 +232,9 @@ def algo3x3(request):
 def test_winograd2x4_conv3x3_raw(B, H, W, cin, cout):
     """F(2x4,3x3) forward and backward-data launches (csrc/conv_wino6.hip; loaders PLAIN / RELUMASK, epilogues RES_RELU / LINEAR /
     beta accumulation; the three workgroup tile shapes 16x16, 32x8, 8x32; ragged maps and reduction depths that are not multiples
-    of 8) against float64 F.conv2d and against F(2x2,3x3); the library must report the r6 kernel for every launch."""
+    of 8) against float64 F.conv2d and against F(2x2,3x3); the library must report the r6 kernel for every launch.  "split": the same
+    launches with three-term bf16 splits of both operands on the bf16 matrix pipe (csrc/conv_wino6s.hip, ops.set_split_operands) at the
+    SAME tolerance; its error against float64 is printed beside the exact-fp32 kernel's."""
     import torch.nn.functional as F
     from rpg_ramnet_amd import ops, _hip as Hh
     torch.manual_seed(11)
@@ -243,8 +248,9 @@ def test_winograd2x4_conv3x3_raw(B, H, W, cin, cout):
     taps, tapsd = ops.Taps.get("conv", 3, 1), ops.Taps.get("dgrad1", 3, 1)
     ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
     outs = {}
-    for mode in ("force", "off"):
-        ops.set_winograd_2x4(mode)
+    for mode in ("force", "split", "off"):
+        ops.set_winograd_2x4("force" if mode == "split" else mode)
+        ops.set_split_operands(mode == "split")
         try:
             kern = []
             y = torch.full((B, H, W, cout), float("nan"), device=dev())
@@ -261,13 +267,17 @@ def test_winograd2x4_conv3x3_raw(B, H, W, cin, cout):
                 acc = None
         finally:
             ops.set_winograd_2x4("auto")
-        assert all(k.startswith("conv_wino_r6_kernel" if mode == "force" else "conv_wino_r_kernel") for k in kern), kern
+            ops.set_split_operands(False)
+        assert all(k.startswith({"force": "conv_wino_r6_kernel<", "split": "conv_wino_r6s_kernel<", "off": "conv_wino_r_kernel"}[mode]) for k in kern), kern
         outs[mode] = (y, dx, acc)
     yref = torch.relu(ref + res.double())
     dy = torch.where(res > 0, yref, torch.zeros_like(yref))                     # the RELUMASK loader of the backward pass
     dxref = F.conv_transpose2d(dy, w.double(), None, 1, 1)
     accref = x.double() + F.conv_transpose2d(yref, w.double(), None, 1, 1)
-    for mode in ("force", "off"):
+    err = lambda a, r: float((nchw(a).cpu().double() - r).abs().max() / r.abs().max())
+    print("max-norm error vs float64: forward exact-fp32 %.2e, split operands %.2e" % (err(outs["force"][0], yref), err(outs["split"][0], yref)) +
+          ("; backward-data %.2e / %.2e" % (err(outs["force"][1], dxref), err(outs["split"][1], dxref)) if outs["force"][2] is not None else ""))
+    for mode in ("force", "split", "off"):
         y, dx, acc = outs[mode]
         assert_close(nchw(y).cpu().numpy(), yref.numpy(), TOL, "forward 2x4=%s" % mode)
         if acc is not None:
@@ -275,6 +285,7 @@ def test_winograd2x4_conv3x3_raw(B, H, W, cin, cout):
             assert_close(nchw(acc).cpu().numpy(), accref.numpy(), TOL, "dgrad beta 2x4=%s" % mode)
     # rounding of F(2x4,3x3) in fp32 stays within a few ulp of F(2x2,3x3)
     assert_close(outs["force"][0].cpu().numpy(), outs["off"][0].cpu().numpy(), 2e-5, "F(2x4) vs F(2x2)")
+    assert_close(outs["split"][0].cpu().numpy(), outs["force"][0].cpu().numpy(), 2e-5, "F(2x4) split operands vs exact fp32")
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (1, 7, 13), (2, 9, 43), (1, 2, 2)])
