@@ -87,6 +87,10 @@ def parse():
                          "JSON line (value null) and exit before any GPU work: the launch contract alone (CPU test)")
     ap.add_argument("--wino2x4", default="auto", help="F(2x4,3x3) kernel selection for A/B runs: auto (library heuristics) | off | force, "
                     "optionally ,min_wgs (ops.set_winograd_2x4)")
+    ap.add_argument("--split-operands", action="store_true",
+                    help="F(2x4,3x3) forward / backward-data launches on the bf16 matrix pipe with three-term bf16 splits of both operands "
+                         "(ops.set_split_operands, csrc/conv_wino6s.hip: fp32-level accuracy, parity suites at unchanged tolerances).  The default "
+                         "line stays exact fp32 and carries this variant as extras.split_operands")
     ap.add_argument("--wgrad-2x4", default="auto", choices=["auto", "off", "force"], help="A/B: F(2x4,3x3) backward-weights (ops.set_wgrad_winograd_2x4)")
     ap.add_argument("--no-time-batching", action="store_true", help="A/B: the pass-by-pass package loop instead of the time-batched forward (ops.set_time_batching(False))")
     ap.add_argument("--time-batch-max-decodes", type=int, default=0, help="A/B: decodes per chain of the time-batched forward (0 = a whole group)")
@@ -130,6 +134,16 @@ def configs4_measure():
     """BASELINE configs[4]'s per-GPU workload (480 x 640, 10-bin grids, batch 4, sequence length 16: ~100 GB of HBM)."""
     return subprocess_measure(["--height", "480", "--width", "640", "--bins", "10", "--batch", "4", "--seq-len", "16"],
                               "configs[4] shape on ONE GPU (its 8-GPU form shards sequences like configs[2]); same binary, a separate process")
+
+
+def split_operands_measure():
+    """the same training step with the F(2x4,3x3) forward / backward-data launches on split bf16 operands."""
+    return subprocess_measure(["--split-operands"], "the same training step with the F(2x4,3x3) forward / backward-data launches (ConvGRU, residual blocks, "
+                              "space-to-depth encoders: 45.7 % of the GPU time) on v_mfma_f32_32x32x16_bf16 with three-term bf16 splits of both operands "
+                              "(six of nine partial products, fp32 accumulation; csrc/conv_wino6s.hip).  fp32-level accuracy: the operator, model, "
+                              "long-horizon and B=8 L=8 gradient parity tests run this variant at unchanged tolerances (tests/test_hip_ops.py "
+                              "algo3x3=winograd2x4_split, tests/test_hip_fullsize.py f2x4_split / test_bench_step_B8_L8_vs_oracle_split_operands).  "
+                              "NOT the headline: `value` is exact fp32 on v_mfma_f32_32x32x2_f32; backward-weights stays exact fp32 here too", steps=3)
 
 
 def full_frame_measure():
@@ -181,7 +195,8 @@ def winograd_factor(kernel):
     F(2x2,4x4) 25 per 64; direct kernels 1."""
     if kernel.startswith(("conv_wino_kernel", "conv_wino_r_kernel", "conv_wgrad_wino_kernel", "conv_wgrad_wino_r_kernel")):
         return 16.0 / 36.0
-    if kernel.startswith(("conv_wino_r6_kernel", "conv_wgrad_wino_r6_kernel")):      # F(2x4,3x3): a 4 x 6 grid of products per 2 x 4 outputs x 9 taps
+    # (conv_wino_r6s_kernel, --split-operands: the same 24 products, each as six bf16 partial products — counted here as fp32-equivalent FLOP)
+    if kernel.startswith(("conv_wino_r6_kernel", "conv_wino_r6s_kernel", "conv_wgrad_wino_r6_kernel")):      # F(2x4,3x3): a 4 x 6 grid of products per 2 x 4 outputs x 9 taps
         return 24.0 / 72.0
     if kernel.startswith(("conv_wino24_kernel", "conv_wgrad_wino24_kernel")):
         return 25.0 / 64.0
@@ -243,7 +258,7 @@ class KernelTimer:
         name = self.names[sig] = name_of()
         if self.only is not None and name != self.only:
             return
-        if name.startswith("conv_wino_r6_kernel"):      # the F(2x4) kernel runs the space-to-depth views dense (no skipped zero slices)
+        if name.startswith(("conv_wino_r6_kernel", "conv_wino_r6s_kernel")):      # the F(2x4) kernels run the space-to-depth views dense (no skipped zero slices)
             sparse = 1.0
         self.rec.append((name, s, e, alg, alg * tap_ratio * sparse * winograd_factor(name), nbytes, tag))
 
@@ -812,6 +827,7 @@ def main():
         Hh.check(Hh.lib().ramnet_set_option(b"wgrad_wino_blocks", args.wgrad_wino_blocks), "set_option")
     w24 = args.wino2x4.split(",")
     ops.set_winograd_2x4(w24[0], min_wgs=int(w24[1]) if len(w24) > 1 else None)
+    ops.set_split_operands(args.split_operands)
     if args.full_frame:
         assert args.mode == "train", "--full-frame: the training step (the graph runtimes of the other modes have static 8-aligned buffers)"
         args.height, args.width, args.no_extras = 260, 346, True
@@ -1097,6 +1113,7 @@ def main():
             except Exception as ex:     # noqa: BLE001 — an extra must not take the headline measurement down
                 extras["graph_replay"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             if (H, W, bins, B, L) == (256, 344, 5, 8, 8) and not args.full_frame and not args.no_configs4_extra:
+                extras["split_operands"] = split_operands_measure()
                 extras["full_frame_264x352"] = full_frame_measure()
                 extras["configs4_shape"] = configs4_measure()
 
@@ -1126,7 +1143,8 @@ def main():
                          % (geom, bins, {"train": "training step", "infer": "inference", "stream": "asynchronous streaming inference"}[args.mode]),
                "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "dtype": "f32" if not args.split_operands else "f32 (3x3 forward / backward-data products as 3-term bf16 splits on the bf16 MFMA, fp32 accumulation)",
+               "data": "synthetic",
                "abs_rel": "unverifiable: no checkpoint/dataset in the image (README.md:59-68 are URLs); the Abs-Rel formula and depth post-processing are "
                           "pinned against the reference's own outputs (tests/test_hip_ops.py::test_depth_metrics_*)",
                "input_side": ("in the timed loop: per step %d batched voxel scatter-adds of %d fresh on-device event lists (%d events each) + nonzero "

@@ -35,6 +35,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace ramnet {
 
+// Tuning builds only (tools/abl_wino6s.sh, -DRAMNET_ABL6S=<mask>): parts of the main loop removed to see what each costs (results are WRONG):
+// 1 patch global loads, 2 B-operand loads, 4 split, 8 column transform, 16 next row (LDS reads + combinations), 32 MFMAs, 64 patch LDS stores.
+// Such builds only instantiate the concatenation loader on the 16 x 16 and 32 x 8 tiles.
+#ifndef RAMNET_ABL6S
+#define RAMNET_ABL6S 0
+#endif
+#define ABL6S(bit) ((RAMNET_ABL6S & (bit)) != 0)
+#define ABL6S_KEEP(x) asm volatile("" : : "v"(x))
+
 constexpr int WKS = 16;                              // input channels per chunk = K of one v_mfma_f32_32x32x16_bf16
 constexpr int W6S_BN = 64;                           // output channels per workgroup
 constexpr int W6S_POS_BYTES = 2 * 3 * 1024;          // B operands of one (row, position): [32-channel half 2][plane 3][lane 64][8 bf16]
@@ -66,11 +75,49 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // {b
 // the six partial products in issue order: (term of A, term of B), smallest first
 __device__ constexpr int prod_a(int i) { return i == 0 ? 2 : i == 1 ? 1 : i == 2 ? 0 : i == 3 ? 1 : 0; }
 __device__ constexpr int prod_b(int i) { return i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 2 : i == 3 ? 0 : i == 4 ? 1 : 0; }
-// next chunk's row t = d[ra] + sb d[rb] is built while the positions of this chunk multiply: columns per position
-__device__ constexpr int tcols_n(int p) { return p == 0 ? 1 : p == 1 ? 2 : p == 2 ? 1 : p == 3 ? 2 : 0; }
-__device__ constexpr int tcols_0(int p) { return p == 0 ? 0 : p == 1 ? 1 : p == 2 ? 3 : 4; }
 // vector instructions of the column transform B4 of position q for 8 channels (positions (1, 2) and (3, 4) share sub-expressions)
 __device__ constexpr int colops_n(int q) { return (q == 0 || q == 5) ? 16 : (q == 1 || q == 3) ? 24 : 8; }
+
+// What a wave does BEHIND the twelve MFMAs of position P.  Memory instructions sit at fixed gaps, ONE per gap — the four waves of the workgroup run in
+// step (a barrier per chunk) and share the CU's address unit, which takes 16 cycles per 1 KB wave-load: a burst of six loads per wave holds it for
+// 384 cycles and stalls the issuing waves in front of their next MFMA (measured: B loads in one burst cost 17 % of the launch) —: gap 0, 2, .. 10
+// the six B loads of the position three ahead, gap 1 the patch store, gap 3 the patch reload.  The vector / LDS work is a list of segments
+// executed in order and cut into twelve equal slices.
+// The row t = d[ra] + sb d[rb] lives in ONE register set: the next chunk's column j replaces this chunk's as soon as its last reader — the
+// column transform that builds the A operands of position Q = P + 1 — is through with it: column 0 is only read by position 0 (built behind
+// position 5 of the previous chunk), columns 2 and 4 last by position 3 (built behind 2), columns 1, 3, 5 last by position 5 (built behind 4).
+enum { SEG_B = 0, SEG_PST, SEG_PLD, SEG_RD, SEG_COL, SEG_SPLIT, SEG_CMB };
+struct Seg { int kind, col, slot; };                 // SEG_RD / SEG_CMB: column of the next row, raw register slot
+struct OpRef { int kind, col, slot, idx; };
+__device__ constexpr int seg_count(int P) { return (P == 0 ? 5 : P == 1 ? 7 : P == 2 ? 5 : P == 3 ? 9 : P == 4 ? 9 : 7) - 3; }
+__device__ constexpr Seg seg_at(int P, int i0) {
+    const int i = i0 + 3;
+    if (P == 0 || P == 2) return i == 3 ? Seg{SEG_COL, 0, 0} : Seg{SEG_SPLIT, 0, 0};
+    if (P == 1) return i == 3 ? Seg{SEG_RD, 0, 0} : i == 4 ? Seg{SEG_COL, 0, 0} : i == 5 ? Seg{SEG_SPLIT, 0, 0} : Seg{SEG_CMB, 0, 0};
+    if (P == 3) return i == 3 ? Seg{SEG_RD, 2, 0} : i == 4 ? Seg{SEG_RD, 4, 1} : i == 5 ? Seg{SEG_COL, 0, 0} : i == 6 ? Seg{SEG_SPLIT, 0, 0}
+                     : i == 7 ? Seg{SEG_CMB, 2, 0} : Seg{SEG_CMB, 4, 1};
+    if (P == 4) return i == 3 ? Seg{SEG_COL, 0, 0} : i == 4 ? Seg{SEG_RD, 5, 0} : i == 5 ? Seg{SEG_RD, 1, 1} : i == 6 ? Seg{SEG_SPLIT, 0, 0}
+                     : i == 7 ? Seg{SEG_CMB, 5, 0} : Seg{SEG_CMB, 1, 1};
+    return i == 3 ? Seg{SEG_RD, 3, 0} : i == 4 ? Seg{SEG_COL, 0, 0} : i == 5 ? Seg{SEG_SPLIT, 0, 0} : Seg{SEG_CMB, 3, 0};
+}
+__device__ constexpr int seg_len(int P, Seg s) {
+    return s.kind == SEG_B ? 6 : s.kind == SEG_PST ? 1 : s.kind == SEG_PLD ? 1 : s.kind == SEG_RD ? 4 : s.kind == SEG_COL ? colops_n((P + 1) % 6)
+         : s.kind == SEG_SPLIT ? 44 : 8;
+}
+__device__ constexpr int ops_total(int P) {
+    int n = 0;
+    for (int i = 0; i < seg_count(P); ++i) n += seg_len(P, seg_at(P, i));
+    return n;
+}
+__device__ constexpr OpRef op_at(int P, int k) {
+    for (int i = 0; i < seg_count(P); ++i) {
+        const Seg s = seg_at(P, i);
+        const int n = seg_len(P, s);
+        if (k < n) return {s.kind, s.col, s.slot, k};
+        k -= n;
+    }
+    return {-1, 0, 0, 0};
+}
 
 template <int TXG, int MODE>
 __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv_desc p, const WinoParams q) {
@@ -122,15 +169,15 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
     const unsigned wvo = (unsigned)(wave * 6 * W6S_POS_BYTES + lane * 16);
     const int wblk = nblk_i * W6S_BLK_BYTES, wchunk = q.nblk * W6S_BLK_BYTES;          // bytes
     u32x4 Aop[2][3];                                 // A operands (hi, mid, lo) of the position in flight and the one being built
-    u32x4 Bop[3][2][3];                              // B operands [ring of three positions][32-channel half][plane]
-    float tA[6][8], tB[6][8];                        // row `wave` of B2^T d of the chunk in flight / the next one: [column][channel]
+    u32x4 Bop[4][2][3];                              // B operands [ring of four positions][32-channel half][plane]: requested three positions ahead
+    float t[6][8];                                   // row `wave` of B2^T d: [column][channel] (columns of the next chunk replace dead ones)
     float4 qa[2][2], qb[2][2];                       // raw window rows of the (up to two) columns being read: [column slot][quad]
     float v[8], hf[8], sa[8], sd[8];                 // column-transform outputs of a position, unpacked bf16 terms, shared sub-expressions
 
-    auto bload = [&](auto Pc, auto Kc, int chunk) {  // B operand k = half * 3 + plane of position P of `chunk` -> its ring slot
-        constexpr int P = decltype(Pc)::value, K = decltype(Kc)::value;
-        Bop[P % 3][K / 3][K % 3] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, (int)(wvo + (K % 3) * 1024), chunk * wchunk + wblk + P * W6S_POS_BYTES + (K / 3) * 3072, 0));
+    auto bload = [&](auto Pc, auto Rc, auto Kc, int chunk) {  // B operand k = plane * 2 + half (the order the MFMAs take them) of position P of `chunk` -> ring slot R
+        constexpr int P = decltype(Pc)::value, R = decltype(Rc)::value, K = decltype(Kc)::value;
+        Bop[R][K & 1][K >> 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            wrs, (int)(wvo + (K >> 1) * 1024), chunk * wchunk + wblk + P * W6S_POS_BYTES + (K & 1) * 3072, 0));
     };
     // t[j] of the NEXT chunk: 4 LDS reads (rows ra / rb x quads 2 hq, 2 hq + 1) and 8 combinations per column
     auto tread = [&](auto Jc, auto Sc, auto Kc, const float *pn) {
@@ -138,17 +185,19 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
         if (K < 2) qa[S][K] = ld4(pn + pra + K * PL + J * 4);
         else qb[S][K - 2] = ld4(pn + prb + (K - 2) * PL + J * 4);
     };
-    auto tcomb = [&](auto Jc, auto Sc, auto Ec, float (&tn)[6][8]) {
+    auto tcomb = [&](auto Jc, auto Sc, auto Ec) {
         constexpr int J = decltype(Jc)::value, S = decltype(Sc)::value, E = decltype(Ec)::value;
         const float4 x = qa[S][E >> 2], y = qb[S][E >> 2];
         const float xe = (E & 3) == 0 ? x.x : (E & 3) == 1 ? x.y : (E & 3) == 2 ? x.z : x.w;
         const float ye = (E & 3) == 0 ? y.x : (E & 3) == 1 ? y.y : (E & 3) == 2 ? y.z : y.w;
-        tn[J][E] = fmaf(sb, ye, xe);
+        t[J][E] = fmaf(sb, ye, xe);
+        if (ABL6S(8)) ABL6S_KEEP(t[J][E]);
     };
     // instruction k of the column transform of position Q from row t
     //   B4^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-    auto colop = [&](auto Qc, auto Kc, const float (&t)[6][8]) {
+    auto colop = [&](auto Qc, auto Kc) {
         constexpr int Q = decltype(Qc)::value, K = decltype(Kc)::value, E = K & 7;
+        struct Keep { float &x; __device__ ~Keep() { if (ABL6S(4) && K >= colops_n(Q) - 8) ABL6S_KEEP(x); } } keep{v[E]};
         if (Q == 0) {
             if (K < 8) v[E] = fmaf(-5.f, t[2][E], t[4][E]);
             else v[E] = fmaf(4.f, t[0][E], v[E]);
@@ -191,60 +240,64 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
 
     // ---- prologue: patch 0 -> LDS, B operands of the first two positions, row and first A operand of chunk 0
     pr.load(q.src, 0, clast);
-    sfor<6>([&](auto K) { bload(std::integral_constant<int, 0>{}, K, 0); });
-    sfor<6>([&](auto K) { bload(std::integral_constant<int, 1>{}, K, 0); });
+    sfor<3>([&](auto P) { sfor<6>([&](auto K) { bload(P, P, K, 0); }); });
     pr.store(patch, q.src, 0);
     pr.load(q.src, min(WKS, clast), clast);
     __syncthreads();
     sfor<6>([&](auto J) {
         sfor<4>([&](auto K) { tread(J, std::integral_constant<int, 0>{}, K, patch); });
-        sfor<8>([&](auto E) { tcomb(J, std::integral_constant<int, 0>{}, E, tA); });
+        sfor<8>([&](auto E) { tcomb(J, std::integral_constant<int, 0>{}, E); });
     });
-    sfor<16>([&](auto K) { colop(std::integral_constant<int, 0>{}, K, tA); });
+    sfor<16>([&](auto K) { colop(std::integral_constant<int, 0>{}, K); });
     sfor<44>([&](auto K) { split(std::integral_constant<int, 0>{}, K); });
     pr.store(patch + PF, q.src, min(WKS, clast));
     pr.load(q.src, min(2 * WKS, clast), clast);
     __syncthreads();
 
-    // ---- main loop.  One chunk = 6 positions x (6 products x 2 halves) MFMAs.  Behind every MFMA a slice of the position's OTHER work, in
-    // this order: the six B loads of the position two ahead; patch slot P of chunk + 2 (registers -> LDS) and its reload for chunk + 3; the
-    // LDS reads of this position's share of the next chunk's row; column transform and split of the NEXT position's A operands (position 0 of
-    // the next chunk behind position 5); the row combinations of what was read.
-    auto body = [&](auto par, int chunk, const float (&tc)[6][8], float (&tn)[6][8]) {
+    // ---- main loop.  One chunk = 6 positions x (6 products x 2 halves) MFMAs.  Behind every MFMA a slice of the position's OTHER work (seg_at):
+    // the six B loads of the position THREE ahead; patch slot P of chunk + 2 (registers -> LDS) and its reload for chunk + 3; column transform
+    // and split of the NEXT position's A operands (position 0 of the next chunk behind position 5); LDS reads and row combinations of the
+    // next chunk's columns that have just died.  PAR = chunk & 1: six positions do not divide the ring of four.
+    auto body = [&](auto par, int chunk) {
+        constexpr int PAR = decltype(par)::value;
         const float *pnext = patch + ((chunk + 1) & 1) * PF;            // patch(chunk + 1)
         float *pfree = patch + (chunk & 1) * PF;                        // patch(chunk): consumed during chunk - 1 -> patch(chunk + 2)
         const int cw = min(chunk + 1, nch - 1);
         const int c2 = min((chunk + 2) * WKS, clast), c3 = min((chunk + 3) * WKS, clast);
         sfor<6>([&](auto Pc) {
-            constexpr int P = decltype(Pc)::value, Q = (P + 1) % 6;
-            constexpr int NB = 6, NP = 2, NR = 4 * tcols_n(P), NC = colops_n(Q), NS = 44, NT = 8 * tcols_n(P);
-            constexpr int O_P = NB, O_R = O_P + NP, O_C = O_R + NR, O_S = O_C + NC, O_T = O_S + NS, N = O_T + NT;
+            constexpr int P = decltype(Pc)::value, Q = (P + 1) % 6, N = ops_total(P);
             auto op = [&](auto Kc) {
-                constexpr int K = decltype(Kc)::value;
-                if constexpr (K < O_P) {
-                    bload(std::integral_constant<int, (P + 2) % 6>{}, Kc, P + 2 < 6 ? chunk : cw);
-                } else if constexpr (K < O_R) {
-                    if (K == O_P) pr.store_slot(pfree, q.src, c2, P);
-                    else pr.load_slot(q.src, c3, P, clast);
-                } else if constexpr (K < O_C) {
-                    constexpr int S = (K - O_R) / 4;
-                    tread(std::integral_constant<int, tcols_0(P) + S>{}, std::integral_constant<int, S>{}, std::integral_constant<int, (K - O_R) % 4>{}, pnext);
-                } else if constexpr (K < O_S) {
-                    if constexpr (P == 5) colop(std::integral_constant<int, Q>{}, std::integral_constant<int, K - O_C>{}, tn);
-                    else colop(std::integral_constant<int, Q>{}, std::integral_constant<int, K - O_C>{}, tc);
-                } else if constexpr (K < O_T) {
-                    split(std::integral_constant<int, Q & 1>{}, std::integral_constant<int, K - O_S>{});
+                constexpr OpRef o = op_at(P, decltype(Kc)::value);
+                using I = std::integral_constant<int, o.idx>;
+                using J = std::integral_constant<int, o.col>;
+                using S = std::integral_constant<int, o.slot>;
+                if constexpr (o.kind == SEG_RD) {
+                    if (!ABL6S(16)) tread(J{}, S{}, I{}, pnext);
+                } else if constexpr (o.kind == SEG_COL) {
+                    if (!ABL6S(8)) {
+                        colop(std::integral_constant<int, Q>{}, I{});
+                    }
+                } else if constexpr (o.kind == SEG_SPLIT) {
+                    if (!ABL6S(4)) split(std::integral_constant<int, Q & 1>{}, I{});
                 } else {
-                    constexpr int S = (K - O_T) / 8;
-                    tcomb(std::integral_constant<int, tcols_0(P) + S>{}, std::integral_constant<int, S>{}, std::integral_constant<int, (K - O_T) % 8>{}, tn);
+                    if (!ABL6S(16)) tcomb(J{}, S{}, I{});
                 }
             };
             sfor<12>([&](auto Mc) {
                 constexpr int M = decltype(Mc)::value, PR = M >> 1, FH = M & 1;
                 __builtin_amdgcn_sched_barrier(0);
-                acc[P][FH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aop[P & 1][prod_a(PR)]),
-                                                                     __builtin_bit_cast(bf16x8, Bop[P % 3][FH][prod_b(PR)]), acc[P][FH], 0, 0, 0);
+                if (!ABL6S(32))
+                    acc[P][FH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aop[P & 1][prod_a(PR)]),
+                                                                         __builtin_bit_cast(bf16x8, Bop[(2 * PAR + P) & 3][FH][prod_b(PR)]), acc[P][FH], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((M & 1) == 0) {
+                    if (!ABL6S(2)) bload(std::integral_constant<int, (P + 3) % 6>{}, std::integral_constant<int, (2 * PAR + P + 3) & 3>{},
+                                         std::integral_constant<int, M / 2>{}, P + 3 < 6 ? chunk : cw);
+                } else if constexpr (M == 1) {
+                    if (!ABL6S(64)) pr.store_slot(pfree, q.src, c2, P);
+                } else if constexpr (M == 3) {
+                    if (!ABL6S(1)) pr.load_slot(q.src, c3, P, clast);
+                }
                 constexpr int LO = N * M / 12, HI = N * (M + 1) / 12;
                 sfor<HI - LO>([&](auto Kc) { op(std::integral_constant<int, LO + decltype(Kc)::value>{}); });
             });
@@ -254,8 +307,8 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
     };
     int chunk = 0;
     do {
-        body(std::integral_constant<int, 0>{}, chunk, tA, tB);
-        if (chunk + 1 < nch) body(std::integral_constant<int, 1>{}, chunk + 1, tB, tA);      // (uniform over the workgroup)
+        body(std::integral_constant<int, 0>{}, chunk);
+        if (chunk + 1 < nch) body(std::integral_constant<int, 1>{}, chunk + 1);      // (uniform over the workgroup)
         chunk += 2;
     } while (chunk < nch);
 
@@ -535,13 +588,19 @@ int launch_wino6s(const ramnet_conv_desc &d, hipStream_t st) {
         RAMNET_FULL_LDS((conv_wino_r6s_kernel<TXv, MDv>));                                                          \
         hipLaunchKernelGGL((conv_wino_r6s_kernel<TXv, MDv>), grid, dim3(256), (ex > pf ? ex : pf), st, d, q);       \
     } break;
+#if RAMNET_ABL6S
+#define RAMNET_GO6S_TX(TXv) RAMNET_GO6S(TXv, RAMNET_IN_CAT)
+#else
 #define RAMNET_GO6S_TX(TXv)                                                                                         \
     RAMNET_GO6S(TXv, RAMNET_IN_PLAIN) RAMNET_GO6S(TXv, RAMNET_IN_CAT) RAMNET_GO6S(TXv, RAMNET_IN_CAT_MUL) RAMNET_GO6S(TXv, RAMNET_IN_RELUMASK) \
     RAMNET_GO6S(TXv, RAMNET_IN_S2D)
+#endif
     switch (txg * 100 + d.in_mode) {
         RAMNET_GO6S_TX(4)
         RAMNET_GO6S_TX(2)
+#if !RAMNET_ABL6S
         RAMNET_GO6S_TX(8)
+#endif
     default:
         RAMNET_CHECK_ARG(!"conv_wino_r6s: unsupported (tile, input mode) combination");
     }

@@ -272,6 +272,17 @@ def test_bench_step_B8_L8_vs_oracle(bench_schedule):
     _training_step_vs_oracle("bench_B8_L8")
 
 
+def test_bench_step_B8_L8_vs_oracle_split_operands(bench_schedule):
+    """the bench step of test_bench_step_B8_L8_vs_oracle with the F(2x4,3x3) forward / backward-data launches on split bf16
+    operands (ops.set_split_operands; csrc/conv_wino6s.hip) — loss and all 70 gradients against the float64 oracle at the UNCHANGED bounds."""
+    from rpg_ramnet_amd import ops
+    ops.set_split_operands(True)
+    try:
+        _training_step_vs_oracle("bench_B8_L8")
+    finally:
+        ops.set_split_operands(False)
+
+
 def test_config4_shape_training_step_vs_oracle(bench_schedule):
     """BASELINE configs[4] shape: 640x480, 10-bin voxel grids (the 10-channel head runs conv_head_*<10> since round 3), 20 % NaN targets;
     B=1, K=2, L=2."""
@@ -344,14 +355,17 @@ def test_backward_recovers_after_an_aborted_pass():
             assert_close(after[k].cpu().numpy(), clean[k].cpu().numpy(), 1e-5, "after aborted pass: " + k, floor=1e-2 * gmax)
 
 
-@pytest.fixture(params=["auto", "f2x4"])
+@pytest.fixture(params=["auto", "f2x4", "f2x4_split"])
 def wino_variant(request):
     """auto: the library's selection (batch 1 -> F(2x2,3x3)); f2x4: every eligible 3x3 launch on the F(2x4,3x3) kernel — the kernel the
-    TRAINING batch runs, driven here through the long sequences that only fit the checker's time budget at batch 1."""
+    TRAINING batch runs, driven here through the long sequences that only fit the checker's time budget at batch 1; f2x4_split: the same
+    launches with split bf16 operands on the bf16 matrix pipe (csrc/conv_wino6s.hip) — at the SAME bounds, ELEM_FLOOR included."""
     from rpg_ramnet_amd import ops
-    ops.set_winograd_2x4("force" if request.param == "f2x4" else "auto")
+    ops.set_winograd_2x4("auto" if request.param == "auto" else "force")
+    ops.set_split_operands(request.param == "f2x4_split")
     yield request.param
     ops.set_winograd_2x4("auto")
+    ops.set_split_operands(False)
 
 
 def _close_to_fixture(z, key, got, tol, what):

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=344)
     ap.add_argument("--scales", default="0,1,2")
+    ap.add_argument("--quick", action="store_true", help="split-operand forward launches only, no reference (ablation builds: tools/abl_wino6s.sh)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
@@ -60,6 +61,12 @@ def main():
             "gates_bwd": lambda: ops.conv_launch(dpur, tapsd, cp_ur.bwd(), dxh, 2 * C, beta=0.0),
         }
         res, outs = {}, {}
+        if a.quick:
+            ops.set_split_operands(True)
+            tg, tc = timeit(launches["gates"], a.reps), timeit(launches["cand"], a.reps)
+            print("scale %d  gates %.4f ms  cand %.4f ms   [%s]" % (i, tg, tc, H.lib().ramnet_last_kernel().decode()))
+            tot[True] += tg + tc
+            continue
         for split in (False, True):
             ops.set_split_operands(split)
             for name, fn in launches.items():
@@ -84,6 +91,9 @@ def main():
         print("   gates max |err| vs float64 (sigmoid outputs): exact fp32 %.2e, split %.2e;  new state split vs exact: %.2e" % (e32, esp, dsp))
         for split in (False, True):
             tot[split] += res[("gates", split)] + res[("cand", split)]
+    if a.quick:
+        print("six forward launches, split operands: %.4f ms" % tot[True])
+        return
     print("six forward launches of one update: exact fp32 %.4f ms, split operands %.4f ms: x%.2f" % (tot[False], tot[True], tot[False] / tot[True]))
 
 
