@@ -41,6 +41,14 @@ namespace ramnet {
 #ifndef RAMNET_ABL6S
 #define RAMNET_ABL6S 0
 #endif
+// Probe builds (tools/probe_wino6.sh, -DRAMNET_PROBE): thread 0 of every workgroup stamps the shader clock at the phase boundaries of its life into
+// g_probe6s[workgroup][16] (slot 7 / 10: the 100 MHz wall counter at entry / exit, 8 / 9: HW_ID / XCC_ID); ramnet_probe6s_read copies the table out.
+#ifdef RAMNET_PROBE
+__device__ unsigned long long g_probe6s[16384 * 16];
+#define W6S_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_probe6s[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W6S_STAMP(k) do { } while (0)
+#endif
 #define ABL6S(bit) ((RAMNET_ABL6S & (bit)) != 0)
 #define ABL6S_KEEP(x) asm volatile("" : : "v"(x))
 
@@ -130,17 +138,34 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hq = lane >> 5;
+    W6S_STAMP(0);
+#ifdef RAMNET_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        g_probe6s[blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memrealtime();
+        g_probe6s[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        g_probe6s[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+    }
+#endif
 
     // XCD-aware order as in conv_wino6.hip: the 64-channel blocks of ONE spatial tile are consecutive on one XCD
+    // (quotients through the float reciprocals the launcher passes — the operands are far below 2^23, one correction step makes them exact —
+    // instead of three integer divisions: ~0.5 us of a workgroup's set-up, which nothing else on this CU covers)
+    auto fdiv = [](int n, int d, float inv) {
+        int qv = (int)((float)n * inv);
+        const int r = n - qv * d;
+        qv += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+        return qv;
+    };
     const int xslot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     const int nbl = q.nblk >> q.xg;
-    const int nblk_i = ((xslot % nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
-    int bid = (xslot / nbl) * (8 >> q.xg) + (xcd >> q.xg);
+    const int xq = fdiv(xslot, nbl, q.inv_nbl);
+    const int nblk_i = ((xslot - xq * nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
+    int bid = xq * (8 >> q.xg) + (xcd >> q.xg);
     if (bid >= q.tiles_x * q.tiles_y * p.B) return;
-    const int tx_i = bid % q.tiles_x;
-    bid /= q.tiles_x;
-    const int ty_i = bid % q.tiles_y;
-    const int b = bid / q.tiles_y;
+    const int bq = fdiv(bid, q.tiles_x, q.inv_tx);
+    const int tx_i = bid - bq * q.tiles_x;
+    const int b = fdiv(bq, q.tiles_y, q.inv_ty);
+    const int ty_i = bq - b * q.tiles_y;
     const int n0 = nblk_i * W6S_BN;
     const int oy0 = ty_i * G::TH, ox0 = tx_i * G::TW;
     const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
@@ -238,12 +263,16 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
         }
     };
 
-    // ---- prologue: patch 0 -> LDS, B operands of the first two positions, row and first A operand of chunk 0
+    // ---- prologue: patch 0 -> LDS, B operands of the first three positions, row and first A operand of chunk 0.  (Requesting the patches of the
+    // first TWO chunks together — one memory round trip instead of two — measured WORSE: first barrier 2.1 -> 2.6 us, the second 0.79 -> 0.72:
+    // profiles/r06_probe_split_*.txt.)
+    W6S_STAMP(1);
     pr.load(q.src, 0, clast);
     sfor<3>([&](auto P) { sfor<6>([&](auto K) { bload(P, P, K, 0); }); });
     pr.store(patch, q.src, 0);
     pr.load(q.src, min(WKS, clast), clast);
     __syncthreads();
+    W6S_STAMP(2);
     sfor<6>([&](auto J) {
         sfor<4>([&](auto K) { tread(J, std::integral_constant<int, 0>{}, K, patch); });
         sfor<8>([&](auto E) { tcomb(J, std::integral_constant<int, 0>{}, E); });
@@ -253,6 +282,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
     pr.store(patch + PF, q.src, min(WKS, clast));
     pr.load(q.src, min(2 * WKS, clast), clast);
     __syncthreads();
+    W6S_STAMP(3);
 
     // ---- main loop.  One chunk = 6 positions x (6 products x 2 halves) MFMAs.  Behind every MFMA a slice of the position's OTHER work (seg_at):
     // the six B loads of the position THREE ahead; patch slot P of chunk + 2 (registers -> LDS) and its reload for chunk + 3; column transform
@@ -287,8 +317,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
                 constexpr int M = decltype(Mc)::value, PR = M >> 1, FH = M & 1;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ABL6S(32))
-                    acc[P][FH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Aop[P & 1][prod_a(PR)]),
-                                                                         __builtin_bit_cast(bf16x8, Bop[(2 * PAR + P) & 3][FH][prod_b(PR)]), acc[P][FH], 0, 0, 0);
+                    // (weights as the MFMA's first operand: D = [channel][tile], a lane then holds FOUR CONSECUTIVE CHANNELS of its tile per
+                    // register quad and the exchange below writes 16-byte cells)
+                    acc[P][FH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bop[(2 * PAR + P) & 3][FH][prod_b(PR)]),
+                                                                         __builtin_bit_cast(bf16x8, Aop[P & 1][prod_a(PR)]), acc[P][FH], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr ((M & 1) == 0) {
                     if (!ABL6S(2)) bload(std::integral_constant<int, (P + 3) % 6>{}, std::integral_constant<int, (2 * PAR + P + 3) & 3>{},
@@ -311,13 +343,19 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
         if (chunk + 1 < nch) body(std::integral_constant<int, 1>{}, chunk + 1);      // (uniform over the workgroup)
         chunk += 2;
     } while (chunk < nch);
+    W6S_STAMP(4);
 
-    // ---- per 32-channel half: exchange (column transform M A4 of the wave's row, all waves -> LDS) and channel-quad epilogue, both as in
-    // conv_wino6.hip.  A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1];
-    // D of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile)
+    // ---- per 32-channel half: exchange (column transform M A4 of the wave's row, all waves -> LDS) and channel-quad epilogue as in conv_wino6.hip,
+    // with one difference that matters for a workgroup ALONE on its CU: the epilogue's global operands (state, gates, old output: up to three
+    // tensors x 8 pixels per thread) are requested BEFORE the exchange of their half, the second half's before the first half is finished — their
+    // round trips (1-2.5 us each at four exposed requests per workgroup: profiles/r06_probe_split_before.txt) pass under the exchange, the barrier
+    // and the other half's arithmetic instead of in front of every group of stores.
+    // A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1];
+    // D of the 32x32 MFMA (weights first): col = lane & 31 (TILE), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel of the 32-channel half):
+    // registers 4 g .. 4 g + 3 are channels 8 g + 4 hq .. + 3 of the lane's tile — 16 ds_write_b128 per half instead of 64 ds_write_b32
     float *Pb = smem;
     const int qd = tid & 7;
-    constexpr int NI = 4, RSTEP = 32 / RTW;                   // pixels per half-pass; rows between consecutive pixels of a thread
+    constexpr int NP = 8, RSTEP = 32 / RTW;                   // pixels per thread: one column, rows py0 + j * RSTEP
     const int px0 = (tid >> 3) % RTW, py0 = (tid >> 3) / RTW;
     const unsigned pix0 = (unsigned)((oy0 + py0) * p.WoF + ox0 + px0);      // inside image b (osy = osx = 1, no offsets: launcher)
     const size_t img = (size_t)b * p.HoF * p.WoF;
@@ -326,124 +364,165 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
     auto bld = [](decltype(wino_rsrc(nullptr, 0u)) r, unsigned off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
     auto bst = [](decltype(wino_rsrc(nullptr, 0u)) r, unsigned off, float4 x) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), r, (int)off, 0, 0); };
     const int epi = p.epi;
+    // 0: linear / ReLU (+ beta * old), 4: sigmoid, 5: sigmoid + h.r (gates), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B, 6: out_s2d scatter
+    const int kind = q.s2d_shift ? 6 : epi == RAMNET_EPI_GRU_BLEND ? 2 : epi == RAMNET_EPI_RES_RELU ? 1 : (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) ? 3
+                   : epi == RAMNET_EPI_SIGMOID ? 4 : epi == RAMNET_EPI_SIGMOID_HR ? 5 : 0;      // (GRU_BWD: a block lies in one half: launcher)
     const auto r_out = rsrc_of(p.out, p.ldo);
+    const auto r_e0 = (kind >= 1 && kind <= 3) ? rsrc_of(p.e0, p.lde0) : r_out;
+    const auto r_e1 = (kind == 2 || kind == 3 || kind == 5) ? rsrc_of(p.e1, p.lde1) : r_out;
+    const auto r_o1 = (kind == 2 || kind == 3 || kind == 5) ? rsrc_of(p.o1, p.ldo1) : r_out;
     auto step_of = [&](int ld) { return (unsigned)(RSTEP * p.WoF * ld * 4); };
-
-    sfor<2>([&](auto Fc) {
+    const bool addold = kind == 0 && p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
+    const bool relu = epi == RAMNET_EPI_RELU;
+    unsigned bad[NP];                                          // WOOB for the pixels of this thread outside the map (Cout % 64 == 0: every quad exists)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) bad[j] = (ox0 + px0 < p.Wo && oy0 + py0 + j * RSTEP < p.Ho) ? 0u : WOOB;
+    float4 ea[2][NP], eb[2][NP], ec[2][NP];                   // global operands of the two halves
+    float4 bias4[2];
+    auto nq_of = [&](int fh) { return n0 + fh * 32 + qd * 4; };
+    auto off0_of = [&](int fh, int ld, bool have, int dn = 0) { return have ? (pix0 * (unsigned)ld + (unsigned)(nq_of(fh) + dn)) * 4u : WOOB; };
+    // byte offsets at pixel 0 of the half's tensors: out, e0, e1, o1 (WOOB: no such operand for this thread)
+    auto o_out = [&](int fh) { return off0_of(fh, p.ldo, true); };
+    auto o_e0 = [&](int fh) { return off0_of(fh, p.lde0, kind >= 1 && kind <= 3); };
+    auto o_e1 = [&](int fh) {
+        return off0_of(fh, p.lde1, ((kind == 2 || kind == 3) && p.e1 != nullptr) || (kind == 5 && nq_of(fh) >= p.Cout / 2), (kind == 3 || kind == 5) ? -(p.Cout / 2) : 0);
+    };
+    auto o_o1 = [&](int fh) {
+        return off0_of(fh, p.ldo1, ((kind == 2 || kind == 3) && p.o1 != nullptr) || (kind == 5 && nq_of(fh) >= p.Cout / 2), kind == 5 ? -(p.Cout / 2) : 0);
+    };
+    auto eload = [&](auto Fc) {                                // request the half's global operands (uniform branches on `kind`)
         constexpr int FH = decltype(Fc)::value;
-        if (FH) __syncthreads();                      // the first half's epilogue has read the exchange buffer
-        const int nq = n0 + FH * 32 + qd * 4;
-        const bool nok = nq < p.Cout;
-        const float4 bias4 = p.bias ? ld4(p.bias + (nok ? nq : 0)) : f4zero();
+        bias4[FH] = p.bias ? ld4(p.bias + nq_of(FH)) : f4zero();
+        if (kind == 0 && addold) {
+            const unsigned o = o_out(FH), st = step_of(p.ldo);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][FH][r], m1 = acc[1][FH][r], m2 = acc[2][FH][r], m3 = acc[3][FH][r], m4 = acc[4][FH][r], m5 = acc[5][FH][r];
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
-            const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
-            float *dst = Pb + ((wave * 4) * 32 + m) * RO_LD + l31;
-            dst[0 * 32 * RO_LD] = m0 + a12 + a34;
-            dst[1 * 32 * RO_LD] = d12 + 2.f * d34;
-            dst[2 * 32 * RO_LD] = a12 + 4.f * a34;
-            dst[3 * 32 * RO_LD] = d12 + 8.f * d34 + m5;
+            for (int j = 0; j < NP; ++j) ea[FH][j] = bld(r_out, (o + j * st) | bad[j]);
         }
-        __syncthreads();
-        const bool colok = nok && ox0 + px0 < p.Wo;
-        unsigned bad[2 * NI];
+        if (kind >= 1 && kind <= 3) {
+            const unsigned o = o_e0(FH), st = step_of(p.lde0);
 #pragma unroll
-        for (int j = 0; j < 2 * NI; ++j) bad[j] = (colok && oy0 + py0 + j * RSTEP < p.Ho) ? 0u : WOOB;
-        auto off0_of = [&](int ld, bool have, int dn = 0) { return have ? (pix0 * (unsigned)ld + (unsigned)(nq + dn)) * 4u : WOOB; };
-        // the row transform A2^T over the waves: even rows t0 + t1 + t2, odd rows t1 - t2 - t3 (conv_wino6.hip)
-        auto rows = [&](int half, float4 (&t0)[NI], float4 (&t1)[NI], float4 (&t2)[NI]) {
+            for (int j = 0; j < NP; ++j) ea[FH][j] = bld(r_e0, (o + j * st) | bad[j]);
+        }
+        if (kind == 2 || kind == 3 || kind == 5) {
+            const unsigned o = o_e1(FH), st = step_of(p.lde1);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int py = py0 + (half * NI + i) * RSTEP;
+            for (int j = 0; j < NP; ++j) eb[FH][j] = bld(r_e1, (o + j * st) | bad[j]);
+        }
+        if (kind == 3) {
+            const unsigned o = o_out(FH), st = step_of(p.ldo);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) ec[FH][j] = bld(r_out, (o + j * st) | bad[j]);
+        }
+    };
+    auto exchange = [&](auto Fc) {
+        constexpr int FH = decltype(Fc)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float c0[4], c1[4], c2[4], c3[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const float m0 = acc[0][FH][r], m1 = acc[1][FH][r], m2 = acc[2][FH][r], m3 = acc[3][FH][r], m4 = acc[4][FH][r], m5 = acc[5][FH][r];
+                const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
+                c0[e] = m0 + a12 + a34, c1[e] = d12 + 2.f * d34, c2[e] = a12 + 4.f * a34, c3[e] = d12 + 8.f * d34 + m5;
+            }
+            float *dst = Pb + ((wave * 4) * 32 + l31) * RO_LD + 8 * g + 4 * hq;
+            st4(dst + 0 * 32 * RO_LD, make_float4(c0[0], c0[1], c0[2], c0[3]));
+            st4(dst + 1 * 32 * RO_LD, make_float4(c1[0], c1[1], c1[2], c1[3]));
+            st4(dst + 2 * 32 * RO_LD, make_float4(c2[0], c2[1], c2[2], c2[3]));
+            st4(dst + 3 * 32 * RO_LD, make_float4(c3[0], c3[1], c3[2], c3[3]));
+        }
+    };
+    // the row transform A2^T over the waves: even rows t0 + t1 + t2, odd rows t1 - t2 - t3 (conv_wino6.hip); then the activation of `kind`
+    auto efinish = [&](auto Fc, auto Kc) {
+        constexpr int FH = decltype(Fc)::value, K = decltype(Kc)::value;
+        const int nq = nq_of(FH);
+        const unsigned oo = o_out(FH), so = step_of(p.ldo), o1 = o_o1(FH), s1 = step_of(p.ldo1);
+        const int g = K == 6 ? nq >> q.s2d_shift : 0;
+        const unsigned fp0 = (unsigned)((2 * (oy0 + py0) + (g >> 1)) * p.WoF + 2 * (ox0 + px0) + (g & 1));      // (K = 6)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 t0[4], t1[4], t2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int py = py0 + (half * 4 + i) * RSTEP;
                 const float *bb = lbase + ((py >> 1) * TXG + (py & 1) * 128) * RO_LD;
                 t0[i] = ld4(bb), t1[i] = ld4(bb + 128 * RO_LD), t2[i] = ld4(bb + 256 * RO_LD);
             }
-        };
-        auto rowsum = [&](int half, int i, const float4 &t0, const float4 &t1, const float4 &t2) {
-            const float sg = ((py0 + (half * NI + i) * RSTEP) & 1) ? -1.f : 1.f;
-            return make_float4(fmaf(sg, t2.x, fmaf(sg, t1.x, t0.x)), fmaf(sg, t2.y, fmaf(sg, t1.y, t0.y)),
-                               fmaf(sg, t2.z, fmaf(sg, t1.z, t0.z)), fmaf(sg, t2.w, fmaf(sg, t1.w, t0.w)));
-        };
-        auto run = [&](auto kind) {
-            // 0: linear / ReLU (+ beta * old), 4: sigmoid, 5: sigmoid + h.r (gates), 1: residual + ReLU, 2: GRU blend, 3: GRU backward stage B
-            constexpr int K = decltype(kind)::value;
-            const bool addold = K == 0 && p.beta != 0.f && (epi == RAMNET_EPI_RELU || epi == RAMNET_EPI_LINEAR);
-            const bool relu = epi == RAMNET_EPI_RELU;
-            const auto r_e0 = (K >= 1 && K <= 3) ? rsrc_of(p.e0, p.lde0) : r_out;
-            const auto r_e1 = (K == 2 || K == 3 || K == 5) ? rsrc_of(p.e1, p.lde1) : r_out;
-            const auto r_o1 = (K == 2 || K == 3 || K == 5) ? rsrc_of(p.o1, p.ldo1) : r_out;
-            const unsigned o_out = off0_of(p.ldo, true), s_out = step_of(p.ldo);
-            const unsigned o_e0 = off0_of(p.lde0, K >= 1 && K <= 3), s_e0 = step_of(p.lde0);
-            const unsigned o_e1 = off0_of(p.lde1, ((K == 2 || K == 3) && p.e1 != nullptr) || (K == 5 && nq >= p.Cout / 2), (K == 3 || K == 5) ? -(p.Cout / 2) : 0), s_e1 = step_of(p.lde1);
-            const unsigned o_o1 = off0_of(p.ldo1, ((K == 2 || K == 3) && p.o1 != nullptr) || (K == 5 && nq >= p.Cout / 2), K == 5 ? -(p.Cout / 2) : 0), s_o1 = step_of(p.ldo1);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                unsigned oo[NI];
-                float4 ea[NI], eb[NI], ec[NI], t0[NI], t1[NI], t2[NI];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int j = half * NI + i;
-                    oo[i] = (o_out + j * s_out) | bad[j];
-                    if (K == 0) ea[i] = addold ? bld(r_out, oo[i]) : f4zero();      // (uniform)
-                    if (K >= 1 && K <= 3) ea[i] = bld(r_e0, (o_e0 + j * s_e0) | bad[j]);
-                    if (K == 2 || K == 3 || K == 5) eb[i] = bld(r_e1, (o_e1 + j * s_e1) | bad[j]);
-                    if (K == 3) ec[i] = bld(r_out, oo[i]);
+            for (int i = 0; i < 4; ++i) {
+                const int j = half * 4 + i;
+                const float sg = ((py0 + j * RSTEP) & 1) ? -1.f : 1.f;
+                float4 x = make_float4(fmaf(sg, t2[i].x, fmaf(sg, t1[i].x, t0[i].x)), fmaf(sg, t2[i].y, fmaf(sg, t1[i].y, t0[i].y)),
+                                       fmaf(sg, t2[i].z, fmaf(sg, t1[i].z, t0[i].z)), fmaf(sg, t2[i].w, fmaf(sg, t1[i].w, t0[i].w)));
+                if (K == 6) {     // out_s2d (backward-data of a stride-2 5x5 encoder over its space-to-depth view; LINEAR, no bias: checked on the host):
+                    // channel quad nq of logical pixel (oy, ox) is channel quad nq - g * C of full-resolution pixel (2 oy + (g >> 1), 2 ox + (g & 1))
+                    bst(r_out, ((fp0 * (unsigned)p.ldo + (unsigned)(nq - (g << q.s2d_shift))) * 4u + j * 2 * so) | bad[j], x);
+                    continue;
                 }
-                rows(half, t0, t1, t2);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    float4 x = f4add(rowsum(half, i, t0[i], t1[i], t2[i]), bias4);
-                    if (K == 0) {
-                        if (addold) x = make_float4(x.x + p.beta * ea[i].x, x.y + p.beta * ea[i].y, x.z + p.beta * ea[i].z, x.w + p.beta * ea[i].w);
-                        if (relu) x = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
-                    } else if (K == 4) {
-                        x = make_float4(sigmoidf_(x.x), sigmoidf_(x.y), sigmoidf_(x.z), sigmoidf_(x.w));
-                    } else if (K == 5) {      // gates: the reset gate's quads also leave h.r (RAMNET_EPI_SIGMOID_HR; other quads: offset WOOB, h = 0)
-                        x = make_float4(sigmoidf_(x.x), sigmoidf_(x.y), sigmoidf_(x.z), sigmoidf_(x.w));
-                        const float4 h = eb[i];
-                        bst(r_o1, (o_o1 + (half * NI + i) * s_o1) | bad[half * NI + i], make_float4(h.x * x.x, h.y * x.y, h.z * x.z, h.w * x.w));
-                    } else if (K == 1) {
-                        x = make_float4(fmaxf(x.x + ea[i].x, 0.f), fmaxf(x.y + ea[i].y, 0.f), fmaxf(x.z + ea[i].z, 0.f), fmaxf(x.w + ea[i].w, 0.f));
-                    } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD; conv_epilogue.hpp: gru_bwd_quad)
-                        const float4 g = x, r = ea[i], h = eb[i], old = ec[i];
-                        bst(r_o1, (o_o1 + (half * NI + i) * s_o1) | bad[half * NI + i], make_float4(g.x * h.x * r.x * (1.0f - r.x), g.y * h.y * r.y * (1.0f - r.y),
-                                                                                    g.z * h.z * r.z * (1.0f - r.z), g.w * h.w * r.w * (1.0f - r.w)));
-                        x = make_float4(old.x + g.x * r.x, old.y + g.y * r.y, old.z + g.z * r.z, old.w + g.w * r.w);
-                    } else {
-                        const float4 o = make_float4(tanhf_(x.x), tanhf_(x.y), tanhf_(x.z), tanhf_(x.w)), u = ea[i], h = eb[i];
-                        bst(r_o1, (o_o1 + (half * NI + i) * s_o1) | bad[half * NI + i], o);
-                        x = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
-                                        h.w * (1.0f - u.w) + o.w * u.w);
-                    }
-                    bst(r_out, oo[i], x);
+                x = f4add(x, bias4[FH]);
+                if (K == 0) {
+                    if (addold) x = make_float4(x.x + p.beta * ea[FH][j].x, x.y + p.beta * ea[FH][j].y, x.z + p.beta * ea[FH][j].z, x.w + p.beta * ea[FH][j].w);
+                    if (relu) x = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
+                } else if (K == 4) {
+                    x = make_float4(sigmoidf_(x.x), sigmoidf_(x.y), sigmoidf_(x.z), sigmoidf_(x.w));
+                } else if (K == 5) {      // gates: the reset gate's quads also leave h.r (RAMNET_EPI_SIGMOID_HR; other quads: offset WOOB, h = 0)
+                    x = make_float4(sigmoidf_(x.x), sigmoidf_(x.y), sigmoidf_(x.z), sigmoidf_(x.w));
+                    const float4 h = eb[FH][j];
+                    bst(r_o1, (o1 + j * s1) | bad[j], make_float4(h.x * x.x, h.y * x.y, h.z * x.z, h.w * x.w));
+                } else if (K == 1) {
+                    const float4 e = ea[FH][j];
+                    x = make_float4(fmaxf(x.x + e.x, 0.f), fmaxf(x.y + e.y, 0.f), fmaxf(x.z + e.z, 0.f), fmaxf(x.w + e.w, 0.f));
+                } else if (K == 3) {      // stage B of the ConvGRU backward on the d(h.r) half (RAMNET_EPI_GRU_BWD; conv_epilogue.hpp: gru_bwd_quad)
+                    const float4 gq = x, r = ea[FH][j], h = eb[FH][j], old = ec[FH][j];
+                    bst(r_o1, (o1 + j * s1) | bad[j], make_float4(gq.x * h.x * r.x * (1.0f - r.x), gq.y * h.y * r.y * (1.0f - r.y),
+                                                                   gq.z * h.z * r.z * (1.0f - r.z), gq.w * h.w * r.w * (1.0f - r.w)));
+                    x = make_float4(old.x + gq.x * r.x, old.y + gq.y * r.y, old.z + gq.z * r.z, old.w + gq.w * r.w);
+                } else if (K == 2) {
+                    const float4 o = make_float4(tanhf_(x.x), tanhf_(x.y), tanhf_(x.z), tanhf_(x.w)), u = ea[FH][j], h = eb[FH][j];
+                    bst(r_o1, (o1 + j * s1) | bad[j], o);
+                    x = make_float4(h.x * (1.0f - u.x) + o.x * u.x, h.y * (1.0f - u.y) + o.y * u.y, h.z * (1.0f - u.z) + o.z * u.z,
+                                    h.w * (1.0f - u.w) + o.w * u.w);
                 }
+                bst(r_out, (oo + j * so) | bad[j], x);
             }
-        };
-        if (q.s2d_shift) {
-            // out_s2d (backward-data of a stride-2 5x5 encoder over its space-to-depth view; LINEAR, no bias: checked on the host): output channel
-            // quad nq of logical pixel (oy, ox) is channel quad nq - g * C of full-resolution pixel (2 oy + (g >> 1), 2 ox + (g & 1)), g = nq / C
-            const int g = nq >> q.s2d_shift;
-            const unsigned fp0 = (unsigned)((2 * (oy0 + py0) + (g >> 1)) * p.WoF + 2 * (ox0 + px0) + (g & 1));
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float4 t0[NI], t1[NI], t2[NI];
-                rows(half, t0, t1, t2);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int j = half * NI + i;
-                    const unsigned off = ((fp0 * (unsigned)p.ldo + (unsigned)(nq - (g << q.s2d_shift))) * 4u + j * 2 * step_of(p.ldo)) | bad[j];
-                    bst(r_out, off, rowsum(half, i, t0[i], t1[i], t2[i]));
-                }
-            }
-        } else if (epi == RAMNET_EPI_GRU_BLEND) run(std::integral_constant<int, 2>{});
-        else if (epi == RAMNET_EPI_RES_RELU) run(std::integral_constant<int, 1>{});
-        else if (epi == RAMNET_EPI_GRU_BWD && n0 >= p.Cout / 2) run(std::integral_constant<int, 3>{});      // (a block lies in one half: launcher)
-        else if (epi == RAMNET_EPI_SIGMOID) run(std::integral_constant<int, 4>{});
-        else if (epi == RAMNET_EPI_SIGMOID_HR) run(std::integral_constant<int, 5>{});
-        else run(std::integral_constant<int, 0>{});
-    });
+        }
+    };
+    auto finish = [&](auto Fc) {
+        if (kind == 0) efinish(Fc, std::integral_constant<int, 0>{});
+        else if (kind == 1) efinish(Fc, std::integral_constant<int, 1>{});
+        else if (kind == 2) efinish(Fc, std::integral_constant<int, 2>{});
+        else if (kind == 3) efinish(Fc, std::integral_constant<int, 3>{});
+        else if (kind == 4) efinish(Fc, std::integral_constant<int, 4>{});
+        else if (kind == 5) efinish(Fc, std::integral_constant<int, 5>{});
+        else efinish(Fc, std::integral_constant<int, 6>{});
+    };
+#define W6S_KEEP_AGPR() asm volatile("" : "+a"(acc[0][1]), "+a"(acc[1][1]), "+a"(acc[2][1]), "+a"(acc[3][1]), "+a"(acc[4][1]), "+a"(acc[5][1]))
+    using F0 = std::integral_constant<int, 0>;
+    using F1 = std::integral_constant<int, 1>;
+    // (the second half's accumulators stay in their AGPRs until its exchange: left alone, the compiler copies all 192 to VGPRs at once and the
+    // operand registers requested below do not fit beside them)
+    W6S_KEEP_AGPR();
+    eload(F0{});
+    exchange(F0{});
+    __syncthreads();
+    W6S_STAMP(5);
+    W6S_KEEP_AGPR();
+    eload(F1{});
+    finish(F0{});
+    W6S_STAMP(6);
+    W6S_KEEP_AGPR();
+    __syncthreads();                                  // the first half's epilogue has read the exchange buffer
+    exchange(F1{});
+    __syncthreads();
+    W6S_STAMP(11);
+    finish(F1{});
+    W6S_STAMP(12);
+#ifdef RAMNET_PROBE
+    __builtin_amdgcn_s_waitcnt(0);          // (the stores have left the wave)
+    W6S_STAMP(13);
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_probe6s[blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // OIHW 3x3 -> U = G2 g G4^T (evaluated in double, rounded to fp32 like the pack of conv_wino6.hip) split into three bf16 planes in the
@@ -569,6 +648,7 @@ int launch_wino6s(const ramnet_conv_desc &d, hipStream_t st) {
     q.xg = wbytes > (12u << 20) ? 2 : wbytes > (3u << 20) ? 1 : 0;
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
+    q.inv_nbl = 1.0f / (float)(q.nblk >> q.xg), q.inv_tx = 1.0f / (float)q.tiles_x, q.inv_ty = 1.0f / (float)q.tiles_y;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));
     const size_t ex = (size_t)4 * 4 * 32 * (32 + 4) * sizeof(float);
     {
@@ -613,6 +693,12 @@ int launch_wino6s(const ramnet_conv_desc &d, hipStream_t st) {
 }  // namespace ramnet
 
 using namespace ramnet;
+
+#ifdef RAMNET_PROBE
+extern "C" int ramnet_probe6s_read(unsigned long long *dst, size_t n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(ramnet::g_probe6s), n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int ramnet_conv_wino_split_ok(const ramnet_conv_desc *d, int force) { return d ? wino6s_eligible(*d, force) : 0; }
 

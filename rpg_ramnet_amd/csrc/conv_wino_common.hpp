@@ -19,6 +19,7 @@ struct WinoParams {
     int ksplit;             // F(2x2) kernel, 32-channel workgroups: gridDim.y = splits of the channel reduction (1 = none)
     float *ws;              // ksplit > 1: partial output tiles [gridDim.x][ksplit][128 pixels][32 channels]
     int *cnt;               //             arrival counters [gridDim.x], zero between launches
+    float inv_nbl, inv_tx, inv_ty;      // conv_wino6s.hip: reciprocals of (nblk >> xg), tiles_x, tiles_y (workgroup index decomposition without integer division)
 };
 
 // Patch prefetcher of the Winograd kernel, MODE = ramnet_in_mode of the launch as a compile-time constant (run-time, wave-uniform
@@ -95,16 +96,17 @@ struct WinoPatch {
         for (int i = 0; i < NS; ++i) load_slot(s, c0, i, clast);
     }
     // registers of slot i (loaded for channel c0) -> LDS patch
-    __device__ __forceinline__ void store_slot(float *__restrict__ patch, const InSrc &s, int c0, int i) const {
-        float4 r = v[i];
+    // (r, mk) = what load_slot_to() left for slot i and channel c0 -> LDS patch
+    __device__ __forceinline__ void store_regs(float *__restrict__ patch, const InSrc &s, int c0, int i, float4 r, float4 mk) const {
         if (MODE == RAMNET_IN_RELUMASK)
-            r = make_float4(m[i].x > 0.f ? r.x : 0.f, m[i].y > 0.f ? r.y : 0.f, m[i].z > 0.f ? r.z : 0.f, m[i].w > 0.f ? r.w : 0.f);
+            r = make_float4(mk.x > 0.f ? r.x : 0.f, mk.y > 0.f ? r.y : 0.f, mk.z > 0.f ? r.z : 0.f, mk.w > 0.f ? r.w : 0.f);
         if (MODE == RAMNET_IN_CAT_MUL) {        // chunks of x0: the mask load returned zeros, scale by 1 instead (uniform select, no branch)
             const float one = c0 >= s.C0 ? 0.f : 1.f;
-            r = make_float4(r.x * (m[i].x + one), r.y * (m[i].y + one), r.z * (m[i].z + one), r.w * (m[i].w + one));
+            r = make_float4(r.x * (mk.x + one), r.y * (mk.y + one), r.z * (mk.z + one), r.w * (mk.w + one));
         }
         st4(patch + ldst[i], r);
     }
+    __device__ __forceinline__ void store_slot(float *__restrict__ patch, const InSrc &s, int c0, int i) const { store_regs(patch, s, c0, i, v[i], m[i]); }
     __device__ __forceinline__ void store(float *__restrict__ patch, const InSrc &s, int c0) const {
 #pragma unroll
         for (int i = 0; i < NS; ++i) store_slot(patch, s, c0, i);

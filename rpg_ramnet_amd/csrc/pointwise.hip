@@ -331,25 +331,45 @@ __global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *_
                                                                   PredSiTargets tg, float weight, float lambda, double *__restrict__ part,
                                                                   unsigned long long *__restrict__ ticket, double *__restrict__ stats,
                                                                   float *__restrict__ loss) {
+    // Eight lanes share a pixel's 128-byte channel row (one 16-byte load each per 32 channels) and take EIGHT pixels per trip: eight loads in
+    // flight per lane, then a transpose-reduction (7 shuffles: lane i of the group ends up with the dot product of pixel i) so that EVERY lane
+    // finishes one pixel — sigmoid, store, target, the three double-precision sums.  (Round 5 form: one pixel per trip, lane 0 of the group
+    // alone behind a 3-shuffle butterfly: 7 of 8 lanes idle through the double arithmetic, one load in flight: 0.22 of the HBM peak.)
     const int sub = threadIdx.x & 7, seg = blockIdx.y;
-    const size_t stride = (size_t)gridDim.x * blockDim.x / 8, base = (size_t)seg * seg_pix;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, base = (size_t)seg * seg_pix;        // pixels per trip of the whole grid (8 per group)
     const float b0 = bias ? bias[0] : 0.f;
     const float *__restrict__ tgt = tg.t[seg];
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    for (size_t p = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) / 8; p < seg_pix; p += stride) {
-        const size_t pix = base + p;
-        float s = 0.f;
-        for (int c = sub * 4; c < C; c += 32) {
-            const float4 v = ld4(x + pix * ldx + c), ww = ld4(w + c);
-            s += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+    for (size_t p0 = ((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3) << 3; p0 < seg_pix; p0 += stride) {
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t pj = p0 + j < seg_pix ? p0 + j : seg_pix - 1;          // (clamped: a valid address; its result is dropped below)
+            float a = 0.f;
+            for (int c = sub * 4; c < C; c += 32) {
+                const float4 v = ld4(x + (base + pj) * ldx + c), ww = ld4(w + c);
+                a += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            }
+            s[j] = a;
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (sub == 0) {
-            const float yy = sigmoidf_(s + b0);
-            y[pix] = yy;
-            const float d = yy - tgt[p];
+        float t4[4], t2[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {               // lanes with sub & 4 keep pixels 4..7, the others 0..3
+            const float keep = (sub & 4) ? s[j + 4] : s[j], give = (sub & 4) ? s[j] : s[j + 4];
+            t4[j] = keep + __shfl_xor(give, 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float keep = (sub & 2) ? t4[j + 2] : t4[j], give = (sub & 2) ? t4[j] : t4[j + 2];
+            t2[j] = keep + __shfl_xor(give, 2);
+        }
+        const float keep = (sub & 1) ? t2[1] : t2[0], give = (sub & 1) ? t2[0] : t2[1];
+        const float dot = keep + __shfl_xor(give, 1);                           // pixel p0 + sub
+        const size_t pm = p0 + sub;
+        if (pm < seg_pix) {
+            const float yy = sigmoidf_(dot + b0);
+            y[base + pm] = yy;
+            const float d = yy - tgt[pm];
             if (d == d) {
                 s1 += (double)d;
                 s2 += (double)d * (double)d;

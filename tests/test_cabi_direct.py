@@ -120,6 +120,48 @@ def test_winograd_conv_and_wgrad_through_raw_descriptors():
     assert float((dbias.cpu() - br.grad).abs().max() / br.grad.abs().max()) < 2e-4
 
 
+def test_split_operand_winograd_through_raw_descriptors():
+    """RAMNET_ALGO_WINOGRAD_2X4_SPLIT (ABI 22) with raw pointers: the library accepts the descriptor (ramnet_conv_wino_split_ok), packs the
+    three bf16 planes (ramnet_pack_weight_wino2x4_split: 6 bytes per Winograd-domain weight), runs conv_wino_r6s_kernel and matches float64 at the
+    bar of the exact-fp32 algorithms; a concatenation whose boundary is not a multiple of 16 channels is refused (16-channel chunks)."""
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(4)
+    B, H, W, C0, C1, Cout = 2, 18, 26, 32, 48, 128
+    Cin = C0 + C1
+    x0, x1 = torch.randn(B, H, W, C0, device=dev), torch.randn(B, H, W, C1, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.1
+    b = torch.randn(Cout, device=dev) * 0.1
+    n4 = L.ramnet_packed_weight_elems_wino2x4_split(Cout, Cin, 0)
+    assert n4 * 4 == ((Cin + 15) // 16) * (Cout // 64) * 24 * 2 * 3 * 1024          # [chunk][block][24 positions][2 halves][3 planes][64 lanes x 16 B]
+    wp = torch.empty(n4, device=dev)
+    assert L.ramnet_pack_weight_wino2x4_split(ptr(w), ptr(wp), Cout, Cin, 0, st) == 0
+    y = torch.full((B, H, W, Cout), float("nan"), device=dev)
+    d = _hip.ConvDesc()
+    d.x0, d.x1, d.ld0, d.ld1, d.C0, d.C1, d.in_mode = ptr(x0), ptr(x1), C0, C1, C0, C1, _hip.IN_CAT
+    d.B, d.Hin, d.Win, d.stride, d.ntaps = B, H, W, 1, 9
+    for i in range(9):
+        d.dy[i], d.dx[i], d.wtap[i] = i // 3 - 1, i % 3 - 1, i
+    d.w, d.bias, d.Cout = ptr(wp), ptr(b), Cout
+    d.Ho, d.Wo, d.HoF, d.WoF = H, W, H, W
+    d.osy, d.osx = 1, 1
+    d.epi, d.out, d.ldo, d.algo = _hip.EPI_RELU, ptr(y), Cout, _hip.ALGO_WINOGRAD
+    assert L.ramnet_conv_wino_split_ok(C.byref(d), 1) == 1
+    d.algo = _hip.ALGO_WINOGRAD_2X4_SPLIT
+    assert L.ramnet_conv_launch(C.byref(d), st) == 0, L.ramnet_last_error()
+    assert L.ramnet_last_kernel().decode().startswith("conv_wino_r6s_kernel<")
+    xr = torch.cat([x0, x1], 3).permute(0, 3, 1, 2).cpu().double()
+    ref = torch.relu(torch.nn.functional.conv2d(xr, w.cpu().double(), b.cpu().double(), 1, 1))
+    assert float((y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-4
+    # a chunk of 16 channels must lie in one tensor of the concatenation
+    d.C0, d.C1, d.ld0 = 24, 56, 24
+    d.algo = _hip.ALGO_WINOGRAD
+    assert L.ramnet_conv_wino_split_ok(C.byref(d), 1) == 0
+    d.algo = _hip.ALGO_WINOGRAD_2X4_SPLIT
+    assert L.ramnet_conv_launch(C.byref(d), st) == 10001
+
+
 def test_space_to_depth_view_through_raw_descriptors():
     """RAMNET_IN_S2D / out_s2d: the Winograd kernels read and write the space-to-depth view of a full-resolution NHWC
     tensor in place; checked against the materialised view (ramnet_space_to_depth2) fed to the same kernels and against

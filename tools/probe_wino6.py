@@ -81,9 +81,70 @@ def wgrad():
             cp.discard()
 
 
+def split():
+    """conv_wino_r6s_kernel (split bf16 operands, ONE workgroup per CU) on the six forward launches of a ConvGRU update (B = 8): stamps 0 entry, 1 set up,
+    2 first patch in LDS, 3 prologue done, 4 main loop done, 5 / 11 exchange of the first / second 32-channel half written, 6 / 12 its epilogue's stores
+    issued, 13 stores retired."""
+    dev = torch.device("cuda:0")
+    taps = ops.Taps.get("conv", 3, 1)
+    ops.set_winograd_2x4("force")
+    ops.set_split_operands(True)
+    B = 8
+    names = ["set-up", "first patch -> LDS", "row + first A operand", "main loop", "exchange 0", "epilogue 0", "exchange 1", "epilogue 1", "stores retired"]
+    for i, Cc in enumerate([64, 128, 256]):
+        Hh, Ww = 256 >> (i + 1), 344 >> (i + 1)
+        for kind, cout in (("gates", 2 * Cc), ("candidate", Cc)):
+            w = torch.nn.Parameter(torch.randn(cout, 2 * Cc, 3, 3, device=dev) * 0.02)
+            b = torch.nn.Parameter(torch.randn(cout, device=dev) * 0.1)
+            cp = ops.ConvParam([w], [b])
+            x, h = torch.randn(B, Hh, Ww, Cc, device=dev), torch.tanh(torch.randn(B, Hh, Ww, Cc, device=dev))
+            ur, hr, hn, o = (torch.rand(B, Hh, Ww, n, device=dev) for n in (2 * Cc, Cc, Cc, Cc))
+            if kind == "gates":
+                def launch():
+                    ops.conv_launch(x, taps, cp.fwd(), ur, 2 * Cc, x1=h, in_mode=H.IN_CAT, C1=Cc, bias=cp.bias(), epi=H.EPI_SIGMOID_HR, e1=h, o1=hr)
+            else:
+                def launch():
+                    ops.conv_launch(x, taps, cp.fwd(), hn, Cc, x1=hr, in_mode=H.IN_CAT, C1=Cc, bias=cp.bias(), epi=H.EPI_GRU_BLEND, e0=ur, e1=h, o1=o)
+            for _ in range(3):
+                launch()
+            torch.cuda.synchronize()
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            for _ in range(10):
+                launch()
+            e_.record()
+            torch.cuda.synchronize()
+            t_ms = s_.elapsed_time(e_) / 10
+            before = read("ramnet_probe6s_read")
+            launch()
+            torch.cuda.synchronize()
+            t = read("ramnet_probe6s_read")
+            full = (t[:, 0] != before[:, 0]) & (t[:, 13] != before[:, 13])
+            t = t[full]
+            n, nch = int(full.sum()), 2 * Cc // 16
+            seq = [0, 1, 2, 3, 4, 5, 6, 11, 12, 13]
+            d = np.diff(t[:, seq], axis=1).astype(np.float64)
+            life = (t[:, 13] - t[:, 0]).astype(np.float64)
+            wall = (t[:, 10] - t[:, 7]) * 10.0
+            ghz = float(np.median(life / np.maximum(wall, 1.0)))
+            start, end = (t[:, 7] - t[:, 7].min()) * 0.01, (t[:, 10] - t[:, 7].min()) * 0.01
+            print("\ngru%d %s (%dx%d, Cin %d -> Cout %d): %.1f us per launch (events; %s), %d workgroups, shader clock %.2f GHz; starts %.1f .. %.1f us, "
+                  "last end %.1f us" % (i, kind, Hh, Ww, 2 * Cc, cout, t_ms * 1e3, H.lib().ramnet_last_kernel().decode(), n, ghz, start.min(), start.max(), end.max()))
+            print("  life of a workgroup: median %.1f us (p10 %.1f, p90 %.1f):  " % (np.median(life) / ghz * 1e-3, np.percentile(life, 10) / ghz * 1e-3,
+                                                                                   np.percentile(life, 90) / ghz * 1e-3) +
+                  "  ".join("%s %.2f" % (names[k], np.median(d[:, k]) / ghz * 1e-3) for k in range(9)))
+            ml = np.median(d[:, 3])
+            print("  main loop: %.0f cycles per 16-channel chunk (%d chunks; 72 MFMAs = 2304 cycles of the pipe); fixed part %.2f us of %.2f" % (
+                ml / nch, nch, (np.median(life) - ml) / ghz * 1e-3, np.median(life) / ghz * 1e-3))
+            ts = np.linspace(0, end.max(), 21)[1:-1]
+            print("  workgroups alive at 5 %% steps of the launch: %s" % " ".join(str(int(((start <= x_) & (end > x_)).sum())) for x_ in ts))
+
+
 def main():
     if "--wgrad" in sys.argv:
         return wgrad()
+    if "--split" in sys.argv:
+        return split()
     dev = torch.device("cuda:0")
     taps = ops.Taps.get("conv", 3, 1)
     ops.set_winograd(True)
