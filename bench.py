@@ -105,6 +105,11 @@ def parse():
                     help="train: time the step on input tensors that are already resident in HBM (the definition of `value` up to round 4) "
                          "instead of the default, which voxelises fresh event lists and uploads frames / targets every step beside the compute "
                          "(InputSide); the default line carries the resident-input number as extras.resident_inputs")
+    ap.add_argument("--input-stream", dest="input_inline", action="store_false",
+                    help="A/B: the next step's voxelisation on a low-priority input stream beside the compute (round 5's schedule) instead of the "
+                         "step's own stream, in front of its forward pass (default since round 6: a fourth stream of 160 KB-LDS workgroups beside "
+                         "the three compute streams cost 1.6 % — 229.7 / 230.8 against 233.6 / 234.2 samples/s on one box, "
+                         "profiles/r06_sched_ab.txt — and 2.7 % with split operands, whose workgroups need a whole CU)")
     ap.add_argument("--graph", action="store_true",
                     help="train: the timed step replays ONE hipGraph (gradient zero-fill, forward, loss, BPTT backward, gradient fold; "
                          "rpg_ramnet_amd.graph.GraphedTrainStep) instead of ~7000 eager launches; per-kernel HIP events are then "
@@ -638,8 +643,9 @@ class InputSide:
     stream (data.DevicePrefetcher), all beside the compute of the current step; the step then trains on tensors that did not exist one step
     earlier.  Grid buffers alternate between two sets: set p is rewritten only after the step that read it has finished (event wait)."""
 
-    def __init__(self, model, seq, events_a, events_b, K, B, bins, H, W):
+    def __init__(self, model, seq, events_a, events_b, K, B, bins, H, W, inline=False):
         from rpg_ramnet_amd.data import DevicePrefetcher
+        self.inline = inline            # voxelise on the step's own stream, in front of its forward pass (A/B: --input-inline)
         self.dev, self.K, self.B, self.bins, self.H, self.W, self.L = model.gpu, K, B, bins, H, W, len(seq)
         self.events = [events_a, events_b]
         # the input stream at the LOWEST priority the device offers: its workgroups (up to 160 KB of LDS each) should take the CUs the three
@@ -666,13 +672,14 @@ class InputSide:
     def prepare(self, p):
         """Enqueue the voxelisation of one step's inputs into grid set p on the input stream."""
         from rpg_ramnet_amd import voxel
+        st = torch.cuda.current_stream() if self.inline else self.stream
         if self.free[p] is not None:
-            self.stream.wait_event(self.free[p])
-        with torch.cuda.stream(self.stream):
+            st.wait_event(self.free[p])
+        with torch.cuda.stream(st):
             for l in range(self.L):
                 voxel.events_to_voxel_grids_packed(*self.events[p][l], self.bins, self.W, self.H, out=self.grids[p][l], normalize=True,
                                                    scratch=self.scratch[p][l])
-            self.ready[p] = self.stream.record_event()
+            self.ready[p] = st.record_event()
 
     def next_sequence(self):
         """The sequence of this step (grids of set p, fresh uploads of frames / targets); starts the next step's input work."""
@@ -858,7 +865,7 @@ def main():
     if want_input_side:
         events_b = []
         synth_sequence(model, B, L, H, W, K, bins, args.events_per_grid, seed=5000 + rank, keep_events=events_b)
-        inp = InputSide(model, seq, events_a, events_b, K, B, bins, H, W)
+        inp = InputSide(model, seq, events_a, events_b, K, B, bins, H, W, inline=args.input_inline)
         torch.cuda.synchronize()
 
     ranks_seen = [0]
@@ -1148,8 +1155,9 @@ def main():
                "abs_rel": "unverifiable: no checkpoint/dataset in the image (README.md:59-68 are URLs); the Abs-Rel formula and depth post-processing are "
                           "pinned against the reference's own outputs (tests/test_hip_ops.py::test_depth_metrics_*)",
                "input_side": ("in the timed loop: per step %d batched voxel scatter-adds of %d fresh on-device event lists (%d events each) + nonzero "
-                              "normalisation on an input stream, H2D of %d frames + %d target maps from pinned memory on a copy stream, both beside the "
-                              "previous step's compute (bench.InputSide)" % (L, K * B, args.events_per_grid, L * B, 2 * L * B)) if (inp is not None) else
+                              "normalisation %s, H2D of %d frames + %d target maps from pinned memory on a copy stream beside the "
+                              "previous step's compute (bench.InputSide)" % (L, K * B, args.events_per_grid, "on the step's own stream in front of its forward pass"
+                                                                             if args.input_inline else "on a low-priority input stream beside the compute", L * B, 2 * L * B)) if (inp is not None) else
                              "resident: the step's input tensors are in HBM before the timed region",
                "config": {"workload": "EventScape-shaped %s, %d event bins, K=5, batch %d/GPU, seq-len %d, "
                                       "1xMI355X-per-rank %s, state=%s, SI loss on [image,events4], Adam, backward-weights %s"
