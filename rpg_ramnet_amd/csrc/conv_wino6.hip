@@ -220,11 +220,12 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
-                acc[p0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p0 + 2 * PAR) & 3][j], b0[j], acc[p0][0], 0, 0, 0);
+                // (weights first: D = [channel][tile] — a lane's register quad is four consecutive channels of its tile, see the exchange)
+                acc[p0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[j], vb[(p0 + 2 * PAR) & 3][j], acc[p0][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 slot(gp * 16 + j * 4), slot(gp * 16 + j * 4 + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[p1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[(p1 + 2 * PAR) & 3][j], b1[j], acc[p1][0], 0, 0, 0);
+                acc[p1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[j], vb[(p1 + 2 * PAR) & 3][j], acc[p1][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 slot(gp * 16 + j * 4 + 2), slot(gp * 16 + j * 4 + 3);
             }
@@ -249,20 +250,27 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
     const float4 bias4 = p.bias ? ld4(p.bias + (nok ? nq : 0)) : f4zero();
     // ---- exchange: column transform of the wave's row (M A4: 4 of 6 columns), all waves -> LDS.
     // A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-    // D of the 32x32 MFMA: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (tile)
+    // D of the 32x32 MFMA (weights first, round 6): col = lane & 31 (TILE), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel): registers
+    // 4 g .. 4 g + 3 are channels 8 g + 4 hq .. + 3 of the lane's tile — 16 ds_write_b128 instead of 64 ds_write_b32 (the same products in the
+    // same order: bit-identical results)
     float *P = smem;
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r], m4 = acc[4][f][r], m5 = acc[5][f][r];
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * hq;
-            const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
-            float *dst = P + ((wave * 4) * 32 + m) * RO_LD + f * 32 + l31;
-            dst[0 * 32 * RO_LD] = m0 + a12 + a34;
-            dst[1 * 32 * RO_LD] = d12 + 2.f * d34;
-            dst[2 * 32 * RO_LD] = a12 + 4.f * a34;
-            dst[3 * 32 * RO_LD] = d12 + 8.f * d34 + m5;
+        for (int g = 0; g < 4; ++g) {
+            float c0[4], c1[4], c2[4], c3[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const float m0 = acc[0][f][r], m1 = acc[1][f][r], m2 = acc[2][f][r], m3 = acc[3][f][r], m4 = acc[4][f][r], m5 = acc[5][f][r];
+                const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
+                c0[e] = m0 + a12 + a34, c1[e] = d12 + 2.f * d34, c2[e] = a12 + 4.f * a34, c3[e] = d12 + 8.f * d34 + m5;
+            }
+            float *dst = P + ((wave * 4) * 32 + l31) * RO_LD + f * 32 + 8 * g + 4 * hq;
+            st4(dst + 0 * 32 * RO_LD, make_float4(c0[0], c0[1], c0[2], c0[3]));
+            st4(dst + 1 * 32 * RO_LD, make_float4(c1[0], c1[1], c1[2], c1[3]));
+            st4(dst + 2 * 32 * RO_LD, make_float4(c2[0], c2[1], c2[2], c2[3]));
+            st4(dst + 3 * 32 * RO_LD, make_float4(c3[0], c3[1], c3[2], c3[3]));
         }
     __syncthreads();
     RAMNET_STAMP(5);

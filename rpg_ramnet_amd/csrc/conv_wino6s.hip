@@ -36,7 +36,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace ramnet {
 
 // Tuning builds only (tools/abl_wino6s.sh, -DRAMNET_ABL6S=<mask>): parts of the main loop removed to see what each costs (results are WRONG):
-// 1 patch global loads, 2 B-operand loads, 4 split, 8 column transform, 16 next row (LDS reads + combinations), 32 MFMAs, 64 patch LDS stores.
+// 1 patch global loads, 2 B-operand loads, 4 split, 8 column transform, 16 next row (LDS reads + combinations), 32 MFMAs, 64 patch LDS stores,
+// 256 the MFMAs of a position alternate between four accumulators instead of two.
 // Such builds only instantiate the concatenation loader on the 16 x 16 and 32 x 8 tiles.
 #ifndef RAMNET_ABL6S
 #define RAMNET_ABL6S 0
@@ -201,8 +202,21 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
 
     auto bload = [&](auto Pc, auto Rc, auto Kc, int chunk) {  // B operand k = plane * 2 + half (the order the MFMAs take them) of position P of `chunk` -> ring slot R
         constexpr int P = decltype(Pc)::value, R = decltype(Rc)::value, K = decltype(Kc)::value;
+        // byte offset inside the position: half * 3072 + plane * 1024; two scalar bases per position (+ 0 / + 4096) and the rest in the
+        // instruction's 12-bit immediate instead of one scalar addition per load
+        constexpr int OFF = (K & 1) * 3072 + (K >> 1) * 1024, HI = OFF >= 4096 ? 4096 : 0;
         Bop[R][K & 1][K >> 1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            wrs, (int)(wvo + (K >> 1) * 1024), chunk * wchunk + wblk + P * W6S_POS_BYTES + (K & 1) * 3072, 0));
+            wrs, (int)(wvo + (OFF - HI)), chunk * wchunk + wblk + P * W6S_POS_BYTES + HI, 0));
+    };
+    // ONE wait per position: the six B operands of ring slot r (requested three positions ago) pass through a common use in front of the
+    // position's first MFMA, so that the compiler waits for all of them there instead of once in front of each of six MFMAs
+    auto bready = [&](int r) {
+#define W6S_BUSE(R_) asm volatile("" : "+v"(Bop[R_][0][0]), "+v"(Bop[R_][0][1]), "+v"(Bop[R_][0][2]), "+v"(Bop[R_][1][0]), "+v"(Bop[R_][1][1]), "+v"(Bop[R_][1][2]))
+        if (r == 0) W6S_BUSE(0);
+        else if (r == 1) W6S_BUSE(1);
+        else if (r == 2) W6S_BUSE(2);
+        else W6S_BUSE(3);
+#undef W6S_BUSE
     };
     // t[j] of the NEXT chunk: 4 LDS reads (rows ra / rb x quads 2 hq, 2 hq + 1) and 8 combinations per column
     auto tread = [&](auto Jc, auto Sc, auto Kc, const float *pn) {
@@ -313,14 +327,16 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
                     if (!ABL6S(16)) tcomb(J{}, S{}, I{});
                 }
             };
+            if (!ABL6S(2)) bready((2 * PAR + P) & 3);
             sfor<12>([&](auto Mc) {
                 constexpr int M = decltype(Mc)::value, PR = M >> 1, FH = M & 1;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ABL6S(32))
                     // (weights as the MFMA's first operand: D = [channel][tile], a lane then holds FOUR CONSECUTIVE CHANNELS of its tile per
                     // register quad and the exchange below writes 16-byte cells)
-                    acc[P][FH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Bop[(2 * PAR + P) & 3][FH][prod_b(PR)]),
-                                                                         __builtin_bit_cast(bf16x8, Aop[P & 1][prod_a(PR)]), acc[P][FH], 0, 0, 0);
+                    acc[ABL6S(256) && (M & 2) ? (P + 3) % 6 : P][FH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, Bop[(2 * PAR + P) & 3][FH][prod_b(PR)]), __builtin_bit_cast(bf16x8, Aop[P & 1][prod_a(PR)]),
+                        acc[ABL6S(256) && (M & 2) ? (P + 3) % 6 : P][FH], 0, 0, 0);       // (256: a tuning build's FOUR accumulators in flight)
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr ((M & 1) == 0) {
                     if (!ABL6S(2)) bload(std::integral_constant<int, (P + 3) % 6>{}, std::integral_constant<int, (2 * PAR + P + 3) & 3>{},
