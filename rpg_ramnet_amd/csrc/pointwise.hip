@@ -340,17 +340,42 @@ __global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *_
     const float b0 = bias ? bias[0] : 0.f;
     const float *__restrict__ tgt = tg.t[seg];
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    for (size_t p0 = ((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3) << 3; p0 < seg_pix; p0 += stride) {
-        float s[8];
+    // (C = 32, the prediction layer of the network: one 16-byte load per lane and pixel, requested ONE TRIP AHEAD together with the lane's target
+    // value, so that a trip's arithmetic runs under the next trip's memory round trip; other channel counts take the plain loop)
+    const size_t first = ((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3) << 3;
+    const bool c32 = C == 32;
+    float4 xn[8];
+    float tn = 0.f;
+    auto request = [&](size_t p0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const size_t pj = p0 + j < seg_pix ? p0 + j : seg_pix - 1;          // (clamped: a valid address; its result is dropped below)
-            float a = 0.f;
-            for (int c = sub * 4; c < C; c += 32) {
-                const float4 v = ld4(x + (base + pj) * ldx + c), ww = ld4(w + c);
-                a += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+            xn[j] = ld4(x + (base + pj) * ldx + sub * 4);
+        }
+        tn = tgt[p0 + sub < seg_pix ? p0 + sub : seg_pix - 1];
+    };
+    const float4 w32 = c32 ? ld4(w + sub * 4) : f4zero();
+    if (c32 && first < seg_pix) request(first);
+    for (size_t p0 = first; p0 < seg_pix; p0 += stride) {
+        float s[8];
+        float tcur;
+        if (c32) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = xn[j].x * w32.x + xn[j].y * w32.y + xn[j].z * w32.z + xn[j].w * w32.w;
+            tcur = tn;
+            if (p0 + stride < seg_pix) request(p0 + stride);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t pj = p0 + j < seg_pix ? p0 + j : seg_pix - 1;
+                float a = 0.f;
+                for (int c = sub * 4; c < C; c += 32) {
+                    const float4 v = ld4(x + (base + pj) * ldx + c), ww = ld4(w + c);
+                    a += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+                }
+                s[j] = a;
             }
-            s[j] = a;
+            tcur = tgt[p0 + sub < seg_pix ? p0 + sub : seg_pix - 1];
         }
         float t4[4], t2[2];
 #pragma unroll
@@ -369,7 +394,7 @@ __global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *_
         if (pm < seg_pix) {
             const float yy = sigmoidf_(dot + b0);
             y[base + pm] = yy;
-            const float d = yy - tgt[pm];
+            const float d = yy - tcur;
             if (d == d) {
                 s1 += (double)d;
                 s2 += (double)d * (double)d;
@@ -965,11 +990,14 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
     return pred_bwd(x, ldx, C, w, y, dy, dx, lddx, dw, db, npix, stream);
 }
 static int pred_si_grid(size_t seg_pix, int nseg) {
-    int g = grid_for(seg_pix * 8);
-    const int cap = 2048 / (nseg > 0 ? nseg : 1);     // the partial sums of a segment meet in its last workgroup (3 doubles per workgroup: 8 per thread at
-                                                      // most); 512 over all segments left the chip at two waves per SIMD: 0.29 of the HBM peak
+    // Workgroups per segment: at most 1024 over all segments (their partial sums meet in the segment's last workgroup), and a count that gives
+    // every 8-lane group the SAME number of 8-pixel trips (a ragged last trip left a third of the chip idle: 0.21 of the HBM peak at 2048)
+    const size_t groups = (seg_pix + 7) / 8;
+    const size_t cap = 1024 / (size_t)(nseg > 0 ? nseg : 1);
+    const size_t trips = (groups + cap * 32 - 1) / (cap * 32);
+    size_t g = (groups + 32 * trips - 1) / (32 * trips);
     if (g > cap) g = cap;
-    return g < 1 ? 1 : g;
+    return g < 1 ? 1 : (int)g;
 }
 
 extern "C" size_t ramnet_pred_si_scratch_doubles(size_t seg_pix, int nseg) {
