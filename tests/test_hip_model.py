@@ -696,10 +696,24 @@ def test_raw_346x260_is_rejected_like_the_reference():
         model(dict(bad, **{"events%d" % k: bad["events0"] for k in range(1, 5)}), None, ramnet_ref.empty_states_lstm(5))
 
 
-def test_training_trajectory_matches_oracle():
+@pytest.mark.parametrize("arith", ["exact", "split_operands"])
+def test_training_trajectory_matches_oracle(arith):
     """End to end: 6 Adam steps (lr 1e-4) on one fixed batch through the HIP path and through the CPU oracle with
-    torch autograd — identical seeded weights and data.  The loss trajectories must coincide and fall."""
+    torch autograd — identical seeded weights and data.  The loss trajectories must coincide and fall.  split_operands: every eligible 3x3
+    launch forced onto F(2x4,3x3) with split bf16 operands (csrc/conv_wino6s.hip) — the same bound."""
+    from rpg_ramnet_amd import ops
     from rpg_ramnet_amd.trainer import sequence_loss
+    if arith == "split_operands":
+        ops.set_winograd_2x4("force")
+        ops.set_split_operands(True)
+    try:
+        _training_trajectory(sequence_loss)
+    finally:
+        ops.set_winograd_2x4("auto")
+        ops.set_split_operands(False)
+
+
+def _training_trajectory(sequence_loss):
     cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=2, loss_composition=["image", "events1"])
     model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
