@@ -130,7 +130,7 @@ __device__ constexpr OpRef op_at(int P, int k) {
 
 template <int TXG, int MODE>
 __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv_desc p, const WinoParams q) {
-    constexpr int RO_LD = 32 + 4;                    // row of the exchange buffer [wave 4][column 4][tile 32][channels + pad]
+    constexpr int RO_LD = 64 + 4;                    // row of the exchange buffer [wave 4][column 4][tile 32][64 channels + pad]: both halves at once
     using G = R6SGeom<TXG>;
     constexpr int PL = G::PLANE, PF = G::PFLOATS, RPW = G::PWS, RTW = G::TW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
                 const float a12 = m1 + m2, d12 = m1 - m2, a34 = m3 + m4, d34 = m3 - m4;
                 c0[e] = m0 + a12 + a34, c1[e] = d12 + 2.f * d34, c2[e] = a12 + 4.f * a34, c3[e] = d12 + 8.f * d34 + m5;
             }
-            float *dst = Pb + ((wave * 4) * 32 + l31) * RO_LD + 8 * g + 4 * hq;
+            float *dst = Pb + ((wave * 4) * 32 + l31) * RO_LD + FH * 32 + 8 * g + 4 * hq;
             st4(dst + 0 * 32 * RO_LD, make_float4(c0[0], c0[1], c0[2], c0[3]));
             st4(dst + 1 * 32 * RO_LD, make_float4(c1[0], c1[1], c1[2], c1[3]));
             st4(dst + 2 * 32 * RO_LD, make_float4(c2[0], c2[1], c2[2], c2[3]));
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int py = py0 + (half * 4 + i) * RSTEP;
-                const float *bb = lbase + ((py >> 1) * TXG + (py & 1) * 128) * RO_LD;
+                const float *bb = lbase + ((py >> 1) * TXG + (py & 1) * 128) * RO_LD + FH * 32;
                 t0[i] = ld4(bb), t1[i] = ld4(bb + 128 * RO_LD), t2[i] = ld4(bb + 256 * RO_LD);
             }
 #pragma unroll
@@ -513,24 +513,18 @@ __global__ void __launch_bounds__(256, 1) conv_wino_r6s_kernel(const ramnet_conv
         else if (kind == 5) efinish(Fc, std::integral_constant<int, 5>{});
         else efinish(Fc, std::integral_constant<int, 6>{});
     };
-#define W6S_KEEP_AGPR() asm volatile("" : "+a"(acc[0][1]), "+a"(acc[1][1]), "+a"(acc[2][1]), "+a"(acc[3][1]), "+a"(acc[4][1]), "+a"(acc[5][1]))
     using F0 = std::integral_constant<int, 0>;
     using F1 = std::integral_constant<int, 1>;
-    // (the second half's accumulators stay in their AGPRs until its exchange: left alone, the compiler copies all 192 to VGPRs at once and the
-    // operand registers requested below do not fit beside them)
-    W6S_KEEP_AGPR();
+    // ONE exchange for both 32-channel halves (136 KB of LDS: the workgroup is alone on its CU anyway): the operands of both halves are requested
+    // first, one barrier instead of three, and the second half's LDS reads run under the first half's stores.
     eload(F0{});
-    exchange(F0{});
-    __syncthreads();
-    W6S_STAMP(5);
-    W6S_KEEP_AGPR();
     eload(F1{});
-    finish(F0{});
-    W6S_STAMP(6);
-    W6S_KEEP_AGPR();
-    __syncthreads();                                  // the first half's epilogue has read the exchange buffer
+    exchange(F0{});
     exchange(F1{});
     __syncthreads();
+    W6S_STAMP(5);
+    finish(F0{});
+    W6S_STAMP(6);
     W6S_STAMP(11);
     finish(F1{});
     W6S_STAMP(12);
@@ -666,7 +660,7 @@ int launch_wino6s(const ramnet_conv_desc &d, hipStream_t st) {
     const int lanes = 8 >> q.xg;
     q.inv_nbl = 1.0f / (float)(q.nblk >> q.xg), q.inv_tx = 1.0f / (float)q.tiles_x, q.inv_ty = 1.0f / (float)q.tiles_y;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * (q.nblk >> q.xg));
-    const size_t ex = (size_t)4 * 4 * 32 * (32 + 4) * sizeof(float);
+    const size_t ex = (size_t)4 * 4 * 32 * (64 + 4) * sizeof(float);       // exchange buffer: both 32-channel halves
     {
         const unsigned long long px = (unsigned long long)d.Hin * d.Win * (d.in_mode == RAMNET_IN_S2D ? 4 : 1);
         int ldmax = d.ld0 > d.ld1 ? d.ld0 : d.ld1;
