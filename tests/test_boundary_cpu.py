@@ -740,3 +740,134 @@ def test_time_fan_autograd_plumbing_cpu():
     out = ops.TimeFan.apply(x * 1.0, n)
     sum((p * wk).sum() for p, wk in zip(out[1:], w)).backward()                # the batched consumer unused
     torch.testing.assert_close(x.grad, torch.cat(w, 0))
+
+
+def _bf16_rne(x):
+    """float32 tensor -> the nearest bf16 value (ties to even), as float32: what v_cvt_pk_bf16_f32 / the pack kernel's bf16_rne produce."""
+    u = x.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return (u - ((u >> 31) << 32)).to(torch.int32).view(torch.float32)
+
+
+def _split3(x):
+    h = _bf16_rne(x)
+    r1 = x - h
+    m = _bf16_rne(r1)
+    r2 = r1 - m
+    return h, m, _bf16_rne(r2), r2
+
+
+def test_split_operand_winograd_f2x4_algebra_cpu():
+    """The arithmetic hard-wired in csrc/conv_wino6s.hip, restated in torch on the CPU: F(2,3) down the rows x F(4,3) along the columns
+    (Y = A2^T [(G2 g G4^T) .* (B2^T d B4)] A4, the matrices of csrc/conv_wino6.hip) with BOTH Winograd-domain operands as three-term
+    bf16 splits (round-to-nearest terms, exact fp32 residuals) and six of the nine partial products accumulated in float32 — against
+    float64 F.conv2d: the split form must be as close to float64 as the plain fp32 evaluation of the same transform (the dropped products
+    are <= 2^-25 of a product), the residuals must be exact, and three terms must reproduce an fp32 value to <= 2^-24 relative."""
+    import torch.nn.functional as F
+    torch.manual_seed(2)
+    G2 = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                      dtype=torch.float64)
+    B2t = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    B4t = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+                       dtype=torch.float64)
+    A2t = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+    A4t = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+    Cin, Cout, H, W = 48, 8, 4, 8
+    x = torch.randn(1, Cin, H, W)
+    g = torch.randn(Cout, Cin, 3, 3) * 0.1
+    ref = F.conv2d(x.double(), g.double(), None, 1, 1)
+    # the transform algebra itself, in float64
+    xp = F.pad(x.double(), (1, 1, 1, 1))
+    U64 = torch.einsum("ia,ocab,jb->ocij", G2, g.double(), G4)                             # [co][ci][4][6]
+    U = U64.float()                                                                        # (the packs round U to fp32 first)
+    y64, y32, ysp = torch.zeros_like(ref), torch.zeros(ref.shape), torch.zeros(ref.shape)
+    Uh, Um, Ul, _ = _split3(U)
+    for ty in range(H // 2):
+        for tx in range(W // 4):
+            d = xp[0, :, 2 * ty:2 * ty + 4, 4 * tx:4 * tx + 6]
+            V64 = torch.einsum("ia,cab,jb->cij", B2t, d, B4t)                              # [ci][4][6]
+            y64[0, :, 2 * ty:2 * ty + 2, 4 * tx:4 * tx + 4] = torch.einsum("ai,oij,bj->oab", A2t, torch.einsum("ocij,cij->oij", U64, V64), A4t)
+            V = torch.einsum("ia,cab,jb->cij", B2t.float(), d.float(), B4t.float())        # fp32 transform (small integer coefficients)
+            M32 = torch.einsum("ocij,cij->oij", U, V)
+            Vh, Vm, Vl, r2 = _split3(V)
+            assert torch.equal((Vh.double() + Vm.double() + r2.double()).float(), V), "residuals are exact"
+            assert float(((Vh.double() + Vm.double() + Vl.double()) - V.double()).abs().max() / V.abs().max()) <= 2.0 ** -24
+            Msp = sum(torch.einsum("ocij,cij->oij", ub, va) for va, ub in ((Vl, Uh), (Vm, Um), (Vh, Ul), (Vm, Uh), (Vh, Um), (Vh, Uh)))
+            for M, y in ((M32, y32), (Msp, ysp)):
+                y[0, :, 2 * ty:2 * ty + 2, 4 * tx:4 * tx + 4] = torch.einsum("ai,oij,bj->oab", A2t.float(), M, A4t.float())
+    assert torch.allclose(y64, ref, atol=1e-12), "F(2x4,3x3) reproduces the convolution"
+    e32 = float((y32.double() - ref).abs().max() / ref.abs().max())
+    esp = float((ysp.double() - ref).abs().max() / ref.abs().max())
+    assert e32 < 1e-5 and esp < 1e-5 and esp <= 1.5 * e32 + 1e-7, (e32, esp)
+    # the pack's size entry point: [chunk of 16][64-channel block][24 positions][2 halves][3 planes][64 lanes x 16 bytes], in 4-byte units
+    from rpg_ramnet_amd import _hip
+    L = _hip.lib()
+    assert L.ramnet_packed_weight_elems_wino2x4_split(128, 128, 0) == 8 * 2 * 24 * 2 * 3 * 256
+    assert L.ramnet_packed_weight_elems_wino2x4_split(128, 40, 0) == 3 * 2 * 24 * 2 * 3 * 256          # ragged reduction depth: 3 chunks
+    assert L.ramnet_packed_weight_elems_wino2x4_split(128, 64, 1) == 8 * 1 * 24 * 2 * 3 * 256          # backward-data: reduce over Cout
+    assert L.ramnet_conv_wino_split_ok(None, 0) == 0
+
+
+def test_arena_slots_are_aliases_with_version_counters_of_their_own():
+    """ops.arena_slots (the state slots the cells of the time-batched forward write, GRUCell / LSTMCell `out=`): consecutive slots of ONE
+    buffer that are not autograd views of it — an in-place write to one slot (what ctx.mark_dirty declares for a cell's output) moves only
+    that slot's version counter, so what a backward saved of the neighbouring slots stays valid and a rewrite of the SAME slot is caught."""
+    from rpg_ramnet_amd import ops
+    buf, slots = ops.arena_slots(3, (2, 4, 5, 8), torch.device("cpu"))
+    assert buf.shape == (3, 2, 4, 5, 8) and len(slots) == 3
+    for k, s in enumerate(slots):
+        assert s.data_ptr() == buf[k].data_ptr() and s.is_contiguous() and not s._is_view() and tuple(s.shape) == (2, 4, 5, 8)
+    v = [s._version for s in slots]
+    slots[1].fill_(7.0)
+    assert slots[1]._version == v[1] + 1 and slots[0]._version == v[0] and slots[2]._version == v[2] and buf._version == 0
+    assert float(buf[1].min()) == 7.0 and float(buf[1].max()) == 7.0        # (the write landed in the shared storage)
+
+    class Write(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, out):
+            out.copy_(2 * x.detach())
+            ctx.mark_dirty(out)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            return 2 * g, None
+
+    class Keep(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, h):
+            ctx.save_for_backward(h)
+            return h * 3
+
+        @staticmethod
+        def backward(ctx, g):
+            (h,) = ctx.saved_tensors
+            return g * 3
+
+    x = torch.ones(2, 4, 5, 8, requires_grad=True)
+    _, slots = ops.arena_slots(2, (2, 4, 5, 8), torch.device("cpu"))
+    z = Keep.apply(Write.apply(x, slots[0]))
+    Write.apply(x, slots[1])                                                # another slot: harmless
+    z.sum().backward()
+    assert float(x.grad.min()) == 6.0
+    _, slots = ops.arena_slots(2, (2, 4, 5, 8), torch.device("cpu"))
+    z = Keep.apply(Write.apply(x, slots[0]))
+    Write.apply(x, slots[0])                                                # the same slot again: the saved state is gone
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        z.sum().backward()
+
+
+def test_bench_traffic_is_requests_times_64_bytes_plus_writes():
+    """bench.py's roofline.traffic: FETCH_SIZE + WRITE_SIZE as counted (= TCC_EA_RDREQ x 64 B + WRITE_SIZE), launch-weighted
+    over a kernel's grids; the doubled-FETCH figure only on request."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    pmc = {"conv_wino_r6_kernel<4,0>": {"720896": {"fetch_kb_raw": 100.0, "write_kb": 50.0, "hbm_bytes_per_launch": 250.0 * 1024, "launches": 3},
+                                        "196608": {"fetch_kb_raw": 40.0, "write_kb": 10.0, "hbm_bytes_per_launch": 90.0 * 1024, "launches": 1}},
+           "other_kernel": {"1": {"fetch_kb_raw": 1.0, "write_kb": 1.0, "hbm_bytes_per_launch": 3.0 * 1024, "launches": 7}}}
+    assert bench.traffic_of(pmc, "conv_wino_r6_kernel<4,0>") == pytest.approx((3 * 150.0 + 50.0) * 1024 / 4)
+    assert bench.traffic_of(pmc, "conv_wino_r6_kernel<4,0>", fetch_x2=True) == pytest.approx((3 * 250.0 + 90.0) * 1024 / 4)
+    assert bench.traffic_of(pmc, "no_such_kernel") is None
+    assert bench.pmc_launches_of(pmc, "conv_wino_r6_kernel<4,0>") == 4
