@@ -18,3 +18,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _split_operands_everywhere():
+    """RAMNET_TEST_SPLIT_OPERANDS=1: run the WHOLE suite with the F(2x4,3x3) forward / backward-data launches on split bf16 operands
+    (ops.set_split_operands; csrc/conv_wino6s.hip) — every tolerance unchanged.  Tests that pin kernel symbols or compare two exact-fp32
+    variants bit for bit are expected to differ; everything that compares with the oracle, a fixture or float64 must still pass
+    (profiles/r06_gputest_split_everywhere.log)."""
+    if os.environ.get("RAMNET_TEST_SPLIT_OPERANDS") != "1":
+        yield
+        return
+    from rpg_ramnet_amd import ops
+    ops.set_split_operands(True)
+    yield
+    ops.set_split_operands(True)
