@@ -1180,6 +1180,12 @@ def main():
                              "state + decode one depth map; samples/s counts frames"}
         if extras:
             out["extras"] = extras
+            sp = extras.get("split_operands")
+            if isinstance(sp, dict) and sp.get("value"):     # the optional second arithmetic, beside — never instead of — the exact-fp32 `value`
+                out["split_operands"] = {"value": sp["value"], "unit": sp["unit"], "ms_per_step": sp["ms_per_step"], "vs_exact_fp32": sp["value"] / (samples / dt),
+                                         "final_loss": sp.get("final_loss"),
+                                         "evidence": "parity suites at unchanged tolerances incl. the whole GPU suite with the variant forced on (profiles/"
+                                                     "r06_gputest_split_everywhere.log), error vs float64 beside the exact kernel's (profiles/r06_split_design.md)"}
         if stream_roof:
             out["roofline"] = stream_roof
             if args.mode == "stream":
