@@ -18,10 +18,14 @@
 //   * 192 accumulators + the operand rings need one wave per SIMD (512 registers): ONE 256-thread workgroup per CU; a wave interleaves
 //     its own vector work with its own MFMAs (bf16 MFMAs leave the issue port free, MI355X_MICROARCH.md);
 //   * the B operands stream from L2 at 0.5 KB per MFMA (3 planes x 1 KB per 6 MFMAs): ~45 B/clk per CU at the target rate, through a
-//     ring of three positions in registers (two positions = ~800 cycles ahead of their MFMAs).
+//     ring of four positions in registers (requested three positions ahead), ONE memory instruction per MFMA gap: the four waves run in
+//     step and share the CU's address unit — bursts of six loads cost 17 % of a launch.
+// Measured (profiles/r06_split_design.md, r06_probe_split_after.txt, r06_pmc_split_vs_exact.txt): x1.55 on the six forward launches of a
+// ConvGRU update, 3630-3990 cycles per 16-channel chunk for 2304 cycles of MFMAs (issue-bound: the wave issues 45-67 % of its cycles, a
+// lone wave adds its vector and memory instructions to its MFMA time), 10-15 us of a workgroup's 26-76 outside the main loop.
 // Everything around the main loop follows conv_wino6.hip: wave w owns ROW w of the 4 x 6 transform grid, only the raw patch goes
-// through LDS (skewed conflict-free layout, fused loaders), the waves meet once per 32-channel half in LDS for the output transform and
-// the straight-line channel-quad epilogue.
+// through LDS (skewed conflict-free layout, fused loaders), the waves meet once in LDS (both 32-channel halves: 136 KB) for the output
+// transform and the straight-line channel-quad epilogue.
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
