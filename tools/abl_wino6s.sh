@@ -1,6 +1,6 @@
 #!/bin/bash
 # Ablation builds of csrc/conv_wino6s.hip (RAMNET_ABL6S masks, see the file) -> rpg_ramnet_amd/abl/lib6s_<mask>.so (git-ignored, travels with
-# gpurun); time with:  RAMNET_HIP_LIB=rpg_ramnet_amd/abl/lib6s_<mask>.so python tools/bench_split_operands.py --fwd-only
+# gpurun); time with:  tools/abl_wino6s_run.sh <masks>   (= RAMNET_HIP_LIB=rpg_ramnet_amd/abl/lib6s_<mask>.so python tools/bench_split_operands.py --quick)
 # (mask 128 = the full loop in the same reduced build: the reference point)
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
