@@ -77,16 +77,25 @@ __global__ void __launch_bounds__(256, 2) conv_wino_r6_kernel(const ramnet_conv_
 #endif
 
     // XCD-aware order as in conv_wino.hip: the channel blocks of ONE spatial tile are consecutive on one XCD
+    // (round 6: quotients through the float reciprocals the launcher passes — operands far below 2^23, one correction step makes them exact —
+    // instead of three integer divisions in the workgroup's set-up)
+    auto fdiv = [](int n, int d, float inv) {
+        int qv = (int)((float)n * inv);
+        const int r = n - qv * d;
+        qv += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+        return qv;
+    };
     const int xslot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     const int nbl = (q.nblk * (2 / NF)) >> q.xg;
-    const int nblk_v = ((xslot % nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
+    const int xq = fdiv(xslot, nbl, q.inv_nbl);
+    const int nblk_v = ((xslot - xq * nbl) << q.xg) + (xcd & ((1 << q.xg) - 1));
     const int nblk_i = NF == 1 ? nblk_v >> 1 : nblk_v, fh = NF == 1 ? nblk_v & 1 : 0;
-    int bid = (xslot / nbl) * (8 >> q.xg) + (xcd >> q.xg);
+    int bid = xq * (8 >> q.xg) + (xcd >> q.xg);
     if (bid >= q.tiles_x * q.tiles_y * p.B) return;
-    const int tx_i = bid % q.tiles_x;
-    bid /= q.tiles_x;
-    const int ty_i = bid % q.tiles_y;
-    const int b = bid / q.tiles_y;
+    const int bq = fdiv(bid, q.tiles_x, q.inv_tx);
+    const int tx_i = bid - bq * q.tiles_x;
+    const int b = fdiv(bq, q.tiles_y, q.inv_ty);
+    const int ty_i = bq - b * q.tiles_y;
     const int n0 = nblk_i * W6_BN + fh * 32;
     const int oy0 = ty_i * G::TH, ox0 = tx_i * G::TW;
     const int iy0 = oy0 + q.dy0, ix0 = ox0 + q.dx0;
@@ -533,6 +542,7 @@ int launch_wino6(const ramnet_conv_desc &d, hipStream_t st) {
     while (q.xg > 0 && (q.nblk % (1 << q.xg)) != 0) --q.xg;
     const int lanes = 8 >> q.xg;
     const int nf = 1;                                               // 32-channel workgroups
+    q.inv_nbl = 1.0f / (float)((q.nblk * (2 / nf)) >> q.xg), q.inv_tx = 1.0f / (float)q.tiles_x, q.inv_ty = 1.0f / (float)q.tiles_y;
     dim3 grid(cdiv(q.tiles_x * q.tiles_y * d.B, lanes) * 8 * ((q.nblk * (2 / nf)) >> q.xg));
     const size_t ex = (size_t)4 * 4 * 32 * (nf * 32 + 4) * sizeof(float);
     {
