@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 22      /* 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 23      /* 23: ramnet_wgrad_desc.algo = RAMNET_ALGO_DIRECT_SPLIT (direct 3x3 backward-weights on the bf16 matrix pipe, split operands: csrc/conv_wgrad_dsplit.hip) + ramnet_wgrad_dsplit_slabs; 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -60,8 +60,13 @@ enum ramnet_in_mode {
 /* RAMNET_ALGO_WINOGRAD_2X4_SPLIT (ABI 22): the launches of RAMNET_ALGO_WINOGRAD_2X4 with every Winograd-domain product evaluated on the bf16
  * matrix pipe from three-term bf16 splits of BOTH operands (six of the nine partial products, fp32 accumulation: fp32-level accuracy;
  * csrc/conv_wino6s.hip), where ramnet_conv_wino_split_ok() accepts the descriptor; w from ramnet_pack_weight_wino2x4_split()                */
+/* RAMNET_ALGO_DIRECT_SPLIT (ABI 23; ramnet_wgrad_desc only): backward-weights of the launches RAMNET_ALGO_WINOGRAD_2X4 accepts (dense 3x3 stride-1
+ * taps; plain / concatenated / masked / space-to-depth inputs; nseg = 0) in DIRECT form on the bf16 matrix pipe: both operands split into three
+ * bf16 terms when a strip is staged, six of the nine partial products, fp32 accumulation (csrc/conv_wgrad_dsplit.hip); dw = the blocked
+ * layout of ramnet_wgrad_dsplit_ws_floats() (ramnet_unpack_wgrad_dsplit), dw_slabs as for the Winograd forms with at most
+ * ramnet_wgrad_dsplit_slabs() slabs.                                                                                                         */
 enum ramnet_algo { RAMNET_ALGO_DIRECT = 0, RAMNET_ALGO_WINOGRAD = 1, RAMNET_ALGO_HEAD = 2, RAMNET_ALGO_WINOGRAD24 = 3, RAMNET_ALGO_WINOGRAD_2X4 = 4,
-                   RAMNET_ALGO_WINOGRAD_2X4_SPLIT = 5 };
+                   RAMNET_ALGO_WINOGRAD_2X4_SPLIT = 5, RAMNET_ALGO_DIRECT_SPLIT = 6 };
 
 /* ---- fused epilogues ------------------------------------------------------------------------- */
 enum ramnet_epilogue {
@@ -220,6 +225,12 @@ int ramnet_reflect_pad(const float *src, float *dst, int B, int C, int H, int W,
  * slab 0 += slab 1 + ... + slab S-1 (n floats each, n % 4 == 0; slabs 1.. are zeroed) at the end of a backward pass.            */
 int ramnet_wgrad_wino_slabs(int Cin, int Cout);
 int ramnet_wgrad_wino2x4_slabs(int Cin, int Cout);      /* the same for RAMNET_ALGO_WINOGRAD_2X4 launches */
+int ramnet_wgrad_dsplit_slabs(int Cin, int Cout);       /* the same for RAMNET_ALGO_DIRECT_SPLIT launches (ABI 23) */
+/* Floats of ONE slab of the RAMNET_ALGO_DIRECT_SPLIT workspace (ABI 23): blocked [9 taps][ceil(Cin/32)][ceil(Cout/32)][64 lanes][16], element
+ * (tap, c, n) where ramnet_wgrad_wino2x4_ws_floats() puts (position, c, n); ramnet_unpack_wgrad_dsplit adds it into the OIHW gradient
+ * [Cout][Cin][3][3] of output channels n_off .. n_off + Cout - 1 of a [CinWs][CoutWs] workspace.                                    */
+size_t ramnet_wgrad_dsplit_ws_floats(int Cin, int Cout);
+int ramnet_unpack_wgrad_dsplit(const float *ws, float *grad, int Cout, int Cin, int CinWs, int CoutWs, int n_off, void *stream);
 /* Floats of ONE slab of the RAMNET_ALGO_WINOGRAD_2X4 workspace (ABI 20): blocked [24 positions][ceil(Cin/32)][ceil(Cout/32)][64 lanes][16] —
  * element (position, c, n) at ((position * nCiB + c/32) * nCoB + n/32) * 1024 + ((n%32) + 32 * ((c%32 >> 2) & 1)) * 16 + (c%4) + 4 * (c%32 >> 3):
  * the accumulator registers of one lane of the 32 x 32 MFMA are 64 contiguous bytes (16-byte read-modify-write joins).                */

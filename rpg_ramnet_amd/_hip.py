@@ -10,7 +10,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAMNET_HIP_LIB") or os.path.join(_PKG, "librpg_ramnet_hip.so")     # (override: A/B builds)
 
 IN_PLAIN, IN_CAT, IN_CAT_MUL, IN_UP2X, IN_UP2X_SKIP, IN_RELUMASK, IN_S2D, IN_PARITY4 = range(8)
-ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24, ALGO_WINOGRAD_2X4, ALGO_WINOGRAD_2X4_SPLIT = 0, 1, 2, 3, 4, 5
+ALGO_DIRECT, ALGO_WINOGRAD, ALGO_HEAD, ALGO_WINOGRAD24, ALGO_WINOGRAD_2X4, ALGO_WINOGRAD_2X4_SPLIT, ALGO_DIRECT_SPLIT = 0, 1, 2, 3, 4, 5, 6
 EPI_LINEAR, EPI_RELU, EPI_SIGMOID, EPI_RES_RELU, EPI_GRU_BLEND, EPI_LSTM, EPI_GRU_BWD, EPI_SIGMOID_HR = range(8)
 
 _fp = C.c_void_p
@@ -80,6 +80,9 @@ _SIGS = {
     "ramnet_reflect_pad": (C.c_int, [_fp, _fp] + [C.c_int] * 10 + [_fp]),
     "ramnet_wgrad_wino_slabs": (C.c_int, [C.c_int, C.c_int]),
     "ramnet_wgrad_wino2x4_slabs": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_wgrad_dsplit_slabs": (C.c_int, [C.c_int, C.c_int]),
+    "ramnet_wgrad_dsplit_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "ramnet_unpack_wgrad_dsplit": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_wgrad_wino2x4_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ramnet_reduce_slabs": (C.c_int, [_fp, C.c_int, C.c_size_t, _fp]),
     "ramnet_packed_weight_elems": (C.c_size_t, [C.c_int] * 6),
@@ -207,7 +210,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 22:
+        if l.ramnet_abi_version() != 23:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

@@ -27,6 +27,7 @@ int launch_wgrad_wino24(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_w
 int launch_head_wgrad(const ramnet_wgrad_desc &d, hipStream_t st);
 int launch_wgrad_wino(const ramnet_wgrad_desc &d, hipStream_t st);   // conv_wgrad_wino.hip
 int launch_wgrad_wino6(const ramnet_wgrad_desc &d, hipStream_t st);  // conv_wgrad_wino6.hip: F(2x4,3x3)
+int launch_wgrad_dsplit(const ramnet_wgrad_desc &d, hipStream_t st); // conv_wgrad_dsplit.hip: direct 3x3, split bf16 operands
 
 #define RAMNET_CHECK_ARG(cond)                                                        \
     do {                                                                              \

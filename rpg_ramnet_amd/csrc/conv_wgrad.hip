@@ -208,6 +208,10 @@ extern "C" int ramnet_wgrad_launch(const ramnet_wgrad_desc *dp, void *stream) {
                                   (d.Wo - 1) * d.gsx + d.gox < d.WoG && d.algo == RAMNET_ALGO_DIRECT);
     if (d.algo == RAMNET_ALGO_WINOGRAD) return launch_wgrad_wino(d, (hipStream_t)stream);
     if (d.algo == RAMNET_ALGO_WINOGRAD_2X4) return launch_wgrad_wino6(d, (hipStream_t)stream);
+    if (d.algo == RAMNET_ALGO_DIRECT_SPLIT) {
+        RAMNET_CHECK_ARG(gdense);
+        return launch_wgrad_dsplit(d, (hipStream_t)stream);
+    }
     if (d.algo == RAMNET_ALGO_HEAD) {
         RAMNET_CHECK_ARG(gdense);
         return launch_head_wgrad(d, (hipStream_t)stream);

@@ -125,6 +125,24 @@ def get_split_operands():
     return _SPLIT_OPERANDS
 
 
+_SPLIT_WGRAD = _os.environ.get("RAMNET_SPLIT_WGRAD", "0") == "1"
+
+
+def set_split_wgrad(on):
+    """With split operands on (set_split_operands): the backward-weights launches of the layers that would run F(2x4,3x3) run the DIRECT
+    3x3 form on the bf16 matrix pipe instead (RAMNET_ALGO_DIRECT_SPLIT, csrc/conv_wgrad_dsplit.hip: operands split once per element when a
+    strip is staged, no Winograd transform in the loop).  OFF by default — measured (profiles/r06_dsplit_notes.md): the six backward-weights
+    launches of a ConvGRU update 1.19 ms against 1.20 ms for the exact-fp32 F(2x4) kernel on their own, and the co-scheduled training step
+    LOSES 7 % (237 against 255 samples/s with split forward / backward-data launches): kept as a correct, tested algorithm and a record of
+    why its loop does not reach the matrix pipe's rate.  Takes effect at the next backward pass."""
+    global _SPLIT_WGRAD
+    _SPLIT_WGRAD = bool(on)
+
+
+def get_split_wgrad():
+    return _SPLIT_WGRAD
+
+
 def set_wgrad_winograd_2x4(mode):
     """F(2x4,3x3) backward-weights for the plain 3x3 layers (ConvGRU / ConvLSTM / residual layers of >= 64 reduction channels): "auto"
     (default) = when the backward-weights launches are co-scheduled with the backward-data chain (set_wgrad_overlap(True): training step
@@ -426,7 +444,9 @@ def _wgrad_desc_build(x0, taps, dout, dw, Cout, stride, x1, xm, xm_off, in_mode,
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
     if getattr(dw, "wino6", False):          # F(2x4,3x3): dw = [slabs][24][Cin][Cout] (csrc/conv_wgrad_wino6.hip)
         d.algo = H.ALGO_WINOGRAD_2X4
-    d.dw_slabs = getattr(dw, "slabs", 0) if (d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4) and _WGRAD_SLABS) else 0     # per-split slabs (read-modify-write joins)
+    if getattr(dw, "dsplit", False):         # direct 3x3, split bf16 operands: dw = [slabs][9][Cin][Cout] (csrc/conv_wgrad_dsplit.hip)
+        d.algo = H.ALGO_DIRECT_SPLIT
+    d.dw_slabs = getattr(dw, "slabs", 0) if (d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4, H.ALGO_DIRECT_SPLIT) and _WGRAD_SLABS) else 0     # per-split slabs (read-modify-write joins)
     if wino24:          # folded upsample-conv in the Winograd F(2x2,4x4) domain: dw = [4][25][C0][Cout]
         d.algo = H.ALGO_WINOGRAD24
     hc = getattr(dw, "head_cin", 0)
@@ -442,7 +462,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     """segs: a ctypes array of H.WgradSeg (ramnet_wgrad_desc.segs) — the tensors of several launches of the SAME layer and shape reduced
     in one launch (deferred ConvGRU cell updates, _wgrad_cell); x0 ... gmask then describe the first segment."""
     # (descriptor cache as for _conv_desc: the template holds everything but the six pointers)
-    key = (id(taps), id(dw), getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "slabs", 0), getattr(dw, "head_cin", 0), Cout, stride,
+    key = (id(taps), id(dw), getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "dsplit", False), getattr(dw, "slabs", 0), getattr(dw, "head_cin", 0), Cout, stride,
            in_mode, C0, C1, Hin, Win, Ho, Wo, gview, dw_off, wino24, xm_off, tuple(x0.shape), x0.stride(2), _sd(x1), _sd(xm), dout.shape[1],
            dout.shape[2], dout.stride(2), _sd(gmask), _WGRAD_SLABS, _HEAD, x0.device.index)
     tmpl = _WDESC_CACHE.get(key) if _DESC_CACHE_ON else None
@@ -965,7 +985,18 @@ class ConvParam:
             # F(2x4,3x3) for the plain 3x3 layers (not the space-to-depth views): slabs of [24][Cin][Cout], half as many as F(2x2)'s
             self._ws.wino6 = bool(self._ws.wino and (_WGRAD_2X4 == "force" or (_WGRAD_2X4 == "auto" and _USE_SIDE))
                                   and (type(self) is ConvParam or (_S2D_2X4 and self.Cin >= 128)) and self.CinWs >= 64)
-            if self._ws.wino6:
+            # ... and with split operands on, those layers' backward-weights in direct form on the bf16 matrix pipe: slabs of [9][Cin][Cout]
+            self._ws.dsplit = bool(self._ws.wino6 and _SPLIT_OPERANDS and _SPLIT_WGRAD)
+            if self._ws.dsplit:
+                ns, nf = H.lib().ramnet_wgrad_dsplit_slabs(self.CinWs, self.Cout), H.lib().ramnet_wgrad_dsplit_ws_floats(self.CinWs, self.Cout)
+                if self._ws.numel() < ns * nf or self._bws.numel() < ns * self.Cout:       # (between passes the workspaces hold zeros: grow them)
+                    old = self._ws
+                    self._ws = torch.zeros(max(ns * nf, old.numel()), device=old.device)
+                    self._ws.dsplit = True
+                    self._bws = torch.zeros(max(ns, self._slabs) * self.Cout, device=old.device)
+                self._ws.wino = self._ws.wino6 = False
+                self._ws.slabs = ns
+            elif self._ws.wino6:
                 self._ws.wino = False
                 self._ws.slabs = min(self._slabs, H.lib().ramnet_wgrad_wino2x4_slabs(self.CinWs, self.Cout))
             else:
@@ -1020,25 +1051,28 @@ class ConvParam:
 
     def _join_slabs(self):
         """Winograd backward-weights slabs -> slab 0 (fixed order), weights and bias."""
-        w6 = getattr(self._ws, "wino6", False)
+        w6, ds = getattr(self._ws, "wino6", False), getattr(self._ws, "dsplit", False)
         ns = getattr(self._ws, "slabs", 1)
-        if ns > 1 and (w6 or getattr(self._ws, "wino", False)):
-            n = H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout) if w6 else 16 * self.CinWs * self.Cout
+        if ns > 1 and (w6 or ds or getattr(self._ws, "wino", False)):
+            n = (H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout) if w6 else
+                 H.lib().ramnet_wgrad_dsplit_ws_floats(self.CinWs, self.Cout) if ds else 16 * self.CinWs * self.Cout)
             H.check(H.lib().ramnet_reduce_slabs(_p(self._ws), ns, n, _st()), "ramnet_reduce_slabs")
             H.check(H.lib().ramnet_reduce_slabs(_p(self._bws), ns, self.Cout, _st()), "ramnet_reduce_slabs")
 
     def _zero_ws(self):
         """Zero what the pass used of the gradient workspace for the next one: slab 0 only where the slabs were joined
         (ramnet_reduce_slabs leaves slabs 1.. zeroed), not the whole buffer sized for the largest layout."""
-        w6, wn = getattr(self._ws, "wino6", False), getattr(self._ws, "wino", False)
+        w6, wn, ds = getattr(self._ws, "wino6", False), getattr(self._ws, "wino", False), getattr(self._ws, "dsplit", False)
         ns = getattr(self._ws, "slabs", 1)
         if w6:
             n = H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout)
         elif wn:
             n = 16 * self.CinWs * self.Cout
+        elif ds:
+            n = H.lib().ramnet_wgrad_dsplit_ws_floats(self.CinWs, self.Cout)
         else:
             n, ns = self.k * self.k * self.CinWs * self.Cout, 1
-        joined = ns > 1 and (w6 or wn)
+        joined = ns > 1 and (w6 or wn or ds)
         self._ws[:n if joined else min(self._ws.numel(), n * max(ns, 1))].zero_()
         self._bws[:self.Cout if joined else self._bws.numel()].zero_()
 
@@ -1060,6 +1094,9 @@ class ConvParam:
             if getattr(self._ws, "wino6", False):
                 H.check(H.lib().ramnet_unpack_wgrad_wino2x4(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
                         "ramnet_unpack_wgrad_wino2x4")
+            elif getattr(self._ws, "dsplit", False):
+                H.check(H.lib().ramnet_unpack_wgrad_dsplit(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
+                        "ramnet_unpack_wgrad_dsplit")
             elif getattr(self._ws, "wino", False):
                 H.check(H.lib().ramnet_unpack_wgrad_wino(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
                         "ramnet_unpack_wgrad_wino")
@@ -1102,6 +1139,8 @@ class S2DConvParam(ConvParam):
         self._join_slabs()
         if getattr(self._ws, "wino6", False):
             H.check(L.ramnet_unpack_wgrad_wino2x4(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino2x4")
+        elif getattr(self._ws, "dsplit", False):
+            H.check(L.ramnet_unpack_wgrad_dsplit(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_dsplit")
         elif getattr(self._ws, "wino", False):
             H.check(L.ramnet_unpack_wgrad_wino(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino")
         else:

@@ -590,6 +590,67 @@ def test_winograd2x4_wgrad_slabs_bit_reproducible(B, H, W, cin, cout):
     assert_close(b2[:cout].cpu().numpy(), res[0][1], 1e-5, "bias: two segments + one launch vs three launches")
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 32, 48, 64, 128), (2, 9, 43, 96, 64), (8, 16, 22, 128, 128), (1, 5, 7, 64, 32), (3, 13, 20, 160, 192)])
+def test_direct_split_wgrad_raw(B, H, W, cin, cout):
+    """RAMNET_ALGO_DIRECT_SPLIT (csrc/conv_wgrad_dsplit.hip): the direct 3x3 backward-weights kernel on the bf16 matrix pipe — both operands
+    split into three bf16 terms when a strip is staged, six of the nine partial products — against float64 autograd at the tolerance of the
+    exact-fp32 kernels; per-split slabs in the blocked layout give BIT-IDENTICAL gradients over two passes of three accumulating launches, the
+    atomic form (one slab) agrees to rounding, and the error against float64 is printed beside the exact F(2x4,3x3) kernel's."""
+    import torch.nn.functional as F
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(15)
+    x = torch.randn(B, cin, H, W)
+    dy = torch.randn(B, cout, H, W)
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, bias, 1, 1) * dy.double()).sum().backward()
+    xg, dyg = (nhwc(t).to(dev()).contiguous() for t in (x, dy))
+    taps = ops.Taps.get("conv", 3, 1)
+    L = Hh.lib()
+    slabs, n = L.ramnet_wgrad_dsplit_slabs(cin, cout), L.ramnet_wgrad_dsplit_ws_floats(cin, cout)
+    assert slabs > 1
+
+    def unpack(ws):
+        grad = torch.zeros(cout, cin, 3, 3, device=dev())
+        Hh.check(L.ramnet_unpack_wgrad_dsplit(ops._p(ws), ops._p(grad), cout, cin, cin, cout, 0, ops._st()), "unpack")
+        return grad.cpu().numpy()
+    res = []
+    for _ in range(2):
+        ws = torch.zeros(slabs * n, device=dev())
+        ws.wino, ws.wino6, ws.dsplit, ws.slabs = False, False, True, slabs
+        bws = torch.zeros(slabs * cout, device=dev())
+        for _k in range(3):
+            ops.wgrad_launch(xg, taps, dyg, ws, cout, dbias=bws)
+        assert Hh.lib().ramnet_last_kernel().decode().startswith("conv_wgrad_dsplit_kernel")
+        Hh.check(L.ramnet_reduce_slabs(ops._p(ws), slabs, n, ops._st()), "reduce")
+        Hh.check(L.ramnet_reduce_slabs(ops._p(bws), slabs, cout, ops._st()), "reduce")
+        assert float(ws[n:].abs().max()) == 0.0
+        res.append((unpack(ws), bws[:cout].cpu().numpy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert_close(res[0][0], 3 * w.grad.numpy(), TOL, "dW slabs")
+    assert_close(res[0][1], 3 * bias.grad.numpy(), TOL, "db slabs")
+    ws1 = torch.zeros(n, device=dev())
+    ws1.wino, ws1.wino6, ws1.dsplit = False, False, True
+    b1 = torch.zeros(cout, device=dev())
+    for _k in range(3):
+        ops.wgrad_launch(xg, taps, dyg, ws1, cout, dbias=b1)
+    assert_close(unpack(ws1), res[0][0], 1e-5, "atomic form vs slabs")
+    # the exact-fp32 F(2x4,3x3) kernel on the same tensors: both errors against float64 side by side
+    n6 = L.ramnet_wgrad_wino2x4_ws_floats(cin, cout)
+    ws6 = torch.zeros(n6, device=dev())
+    ws6.wino, ws6.wino6, ws6.dsplit = False, True, False
+    b6 = torch.zeros(cout, device=dev())
+    ops.wgrad_launch(xg, taps, dyg, ws6, cout, dbias=b6)
+    assert Hh.lib().ramnet_last_kernel().decode().startswith("conv_wgrad_wino_r6_kernel")
+    g6 = torch.zeros(cout, cin, 3, 3, device=dev())
+    Hh.check(L.ramnet_unpack_wgrad_wino2x4(ops._p(ws6), ops._p(g6), cout, cin, cin, cout, 0, ops._st()), "unpack")
+    ref = w.grad.numpy()
+    e_split = np.abs(res[0][0] / 3 - ref).max() / np.abs(ref).max()
+    e_exact = np.abs(g6.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print("dW max-norm error vs float64: direct split %.3e, exact F(2x4,3x3) %.3e" % (e_split, e_exact))
+    assert e_split < 4 * max(e_exact, 1e-7)
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_residual_block(B, H, W, C, algo3x3):
     from rpg_ramnet_amd.model.submodules import ResidualBlock
