@@ -444,7 +444,7 @@ def _wgrad_desc_build(x0, taps, dout, dw, Cout, stride, x1, xm, xm_off, in_mode,
     d.algo = H.ALGO_WINOGRAD if getattr(dw, "wino", False) else H.ALGO_DIRECT      # set by ConvParam.grad_ws()
     if getattr(dw, "wino6", False):          # F(2x4,3x3): dw = [slabs][24][Cin][Cout] (csrc/conv_wgrad_wino6.hip)
         d.algo = H.ALGO_WINOGRAD_2X4
-    if getattr(dw, "dsplit", False):         # direct 3x3, split bf16 operands: dw = [slabs][9][Cin][Cout] (csrc/conv_wgrad_dsplit.hip)
+    if getattr(dw, "wg_dsplit", False):         # direct 3x3, split bf16 operands: dw = [slabs][9][Cin][Cout] (csrc/conv_wgrad_dsplit.hip)
         d.algo = H.ALGO_DIRECT_SPLIT
     d.dw_slabs = getattr(dw, "slabs", 0) if (d.algo in (H.ALGO_WINOGRAD, H.ALGO_WINOGRAD_2X4, H.ALGO_DIRECT_SPLIT) and _WGRAD_SLABS) else 0     # per-split slabs (read-modify-write joins)
     if wino24:          # folded upsample-conv in the Winograd F(2x2,4x4) domain: dw = [4][25][C0][Cout]
@@ -462,7 +462,7 @@ def wgrad_launch(x0, taps, dout, dw, Cout, *, stride=1, x1=None, xm=None, xm_off
     """segs: a ctypes array of H.WgradSeg (ramnet_wgrad_desc.segs) — the tensors of several launches of the SAME layer and shape reduced
     in one launch (deferred ConvGRU cell updates, _wgrad_cell); x0 ... gmask then describe the first segment."""
     # (descriptor cache as for _conv_desc: the template holds everything but the six pointers)
-    key = (id(taps), id(dw), getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "dsplit", False), getattr(dw, "slabs", 0), getattr(dw, "head_cin", 0), Cout, stride,
+    key = (id(taps), id(dw), getattr(dw, "wino", False), getattr(dw, "wino6", False), getattr(dw, "wg_dsplit", False), getattr(dw, "slabs", 0), getattr(dw, "head_cin", 0), Cout, stride,
            in_mode, C0, C1, Hin, Win, Ho, Wo, gview, dw_off, wino24, xm_off, tuple(x0.shape), x0.stride(2), _sd(x1), _sd(xm), dout.shape[1],
            dout.shape[2], dout.stride(2), _sd(gmask), _WGRAD_SLABS, _HEAD, x0.device.index)
     tmpl = _WDESC_CACHE.get(key) if _DESC_CACHE_ON else None
@@ -986,13 +986,13 @@ class ConvParam:
             self._ws.wino6 = bool(self._ws.wino and (_WGRAD_2X4 == "force" or (_WGRAD_2X4 == "auto" and _USE_SIDE))
                                   and (type(self) is ConvParam or (_S2D_2X4 and self.Cin >= 128)) and self.CinWs >= 64)
             # ... and with split operands on, those layers' backward-weights in direct form on the bf16 matrix pipe: slabs of [9][Cin][Cout]
-            self._ws.dsplit = bool(self._ws.wino6 and _SPLIT_OPERANDS and _SPLIT_WGRAD)
-            if self._ws.dsplit:
+            self._ws.wg_dsplit = bool(self._ws.wino6 and _SPLIT_OPERANDS and _SPLIT_WGRAD)
+            if self._ws.wg_dsplit:
                 ns, nf = H.lib().ramnet_wgrad_dsplit_slabs(self.CinWs, self.Cout), H.lib().ramnet_wgrad_dsplit_ws_floats(self.CinWs, self.Cout)
                 if self._ws.numel() < ns * nf or self._bws.numel() < ns * self.Cout:       # (between passes the workspaces hold zeros: grow them)
                     old = self._ws
                     self._ws = torch.zeros(max(ns * nf, old.numel()), device=old.device)
-                    self._ws.dsplit = True
+                    self._ws.wg_dsplit = True
                     self._bws = torch.zeros(max(ns, self._slabs) * self.Cout, device=old.device)
                 self._ws.wino = self._ws.wino6 = False
                 self._ws.slabs = ns
@@ -1051,7 +1051,7 @@ class ConvParam:
 
     def _join_slabs(self):
         """Winograd backward-weights slabs -> slab 0 (fixed order), weights and bias."""
-        w6, ds = getattr(self._ws, "wino6", False), getattr(self._ws, "dsplit", False)
+        w6, ds = getattr(self._ws, "wino6", False), getattr(self._ws, "wg_dsplit", False)
         ns = getattr(self._ws, "slabs", 1)
         if ns > 1 and (w6 or ds or getattr(self._ws, "wino", False)):
             n = (H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout) if w6 else
@@ -1062,7 +1062,7 @@ class ConvParam:
     def _zero_ws(self):
         """Zero what the pass used of the gradient workspace for the next one: slab 0 only where the slabs were joined
         (ramnet_reduce_slabs leaves slabs 1.. zeroed), not the whole buffer sized for the largest layout."""
-        w6, wn, ds = getattr(self._ws, "wino6", False), getattr(self._ws, "wino", False), getattr(self._ws, "dsplit", False)
+        w6, wn, ds = getattr(self._ws, "wino6", False), getattr(self._ws, "wino", False), getattr(self._ws, "wg_dsplit", False)
         ns = getattr(self._ws, "slabs", 1)
         if w6:
             n = H.lib().ramnet_wgrad_wino2x4_ws_floats(self.CinWs, self.Cout)
@@ -1094,7 +1094,7 @@ class ConvParam:
             if getattr(self._ws, "wino6", False):
                 H.check(H.lib().ramnet_unpack_wgrad_wino2x4(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
                         "ramnet_unpack_wgrad_wino2x4")
-            elif getattr(self._ws, "dsplit", False):
+            elif getattr(self._ws, "wg_dsplit", False):
                 H.check(H.lib().ramnet_unpack_wgrad_dsplit(_p(self._ws), _p(g), n, self.Cin, self.CinWs, self.Cout, off, _st()),
                         "ramnet_unpack_wgrad_dsplit")
             elif getattr(self._ws, "wino", False):
@@ -1139,7 +1139,7 @@ class S2DConvParam(ConvParam):
         self._join_slabs()
         if getattr(self._ws, "wino6", False):
             H.check(L.ramnet_unpack_wgrad_wino2x4(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino2x4")
-        elif getattr(self._ws, "dsplit", False):
+        elif getattr(self._ws, "wg_dsplit", False):
             H.check(L.ramnet_unpack_wgrad_dsplit(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_dsplit")
         elif getattr(self._ws, "wino", False):
             H.check(L.ramnet_unpack_wgrad_wino(_p(self._ws), _p(g3), self.Cout, self.Cin, self.CinWs, self.Cout, 0, _st()), "ramnet_unpack_wgrad_wino")

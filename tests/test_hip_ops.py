@@ -617,7 +617,7 @@ def test_direct_split_wgrad_raw(B, H, W, cin, cout):
     res = []
     for _ in range(2):
         ws = torch.zeros(slabs * n, device=dev())
-        ws.wino, ws.wino6, ws.dsplit, ws.slabs = False, False, True, slabs
+        ws.wino, ws.wino6, ws.wg_dsplit, ws.slabs = False, False, True, slabs
         bws = torch.zeros(slabs * cout, device=dev())
         for _k in range(3):
             ops.wgrad_launch(xg, taps, dyg, ws, cout, dbias=bws)
@@ -630,7 +630,7 @@ def test_direct_split_wgrad_raw(B, H, W, cin, cout):
     assert_close(res[0][0], 3 * w.grad.numpy(), TOL, "dW slabs")
     assert_close(res[0][1], 3 * bias.grad.numpy(), TOL, "db slabs")
     ws1 = torch.zeros(n, device=dev())
-    ws1.wino, ws1.wino6, ws1.dsplit = False, False, True
+    ws1.wino, ws1.wino6, ws1.wg_dsplit = False, False, True
     b1 = torch.zeros(cout, device=dev())
     for _k in range(3):
         ops.wgrad_launch(xg, taps, dyg, ws1, cout, dbias=b1)
@@ -638,7 +638,7 @@ def test_direct_split_wgrad_raw(B, H, W, cin, cout):
     # the exact-fp32 F(2x4,3x3) kernel on the same tensors: both errors against float64 side by side
     n6 = L.ramnet_wgrad_wino2x4_ws_floats(cin, cout)
     ws6 = torch.zeros(n6, device=dev())
-    ws6.wino, ws6.wino6, ws6.dsplit = False, True, False
+    ws6.wino, ws6.wino6, ws6.wg_dsplit = False, True, False
     b6 = torch.zeros(cout, device=dev())
     ops.wgrad_launch(xg, taps, dyg, ws6, cout, dbias=b6)
     assert Hh.lib().ramnet_last_kernel().decode().startswith("conv_wgrad_wino_r6_kernel")

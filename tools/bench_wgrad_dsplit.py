@@ -14,18 +14,18 @@ taps = ops.Taps.get("conv", 3, 1)
 B = int(os.environ.get("B", "8"))
 shapes = [("gru0 gates", 128, 172, 128, 128), ("gru0 cand", 128, 172, 128, 64), ("gru1 gates", 64, 86, 256, 256), ("gru1 cand", 64, 86, 256, 128),
           ("gru2 gates", 32, 43, 512, 512), ("gru2 cand", 32, 43, 512, 256)]
-tot = {"f2x4": 0.0, "dsplit": 0.0}
+tot = {"f2x4": 0.0, "wg_dsplit": 0.0}
 for name, H, W, cin, cout in shapes:
     x = torch.randn(B, H, W, cin, device=dev)
     dy = torch.randn(B, H, W, cout, device=dev)
     row = []
-    for kind in ("f2x4", "dsplit"):
+    for kind in ("f2x4", "wg_dsplit"):
         if kind == "f2x4":
             slabs, n = L.ramnet_wgrad_wino2x4_slabs(cin, cout), L.ramnet_wgrad_wino2x4_ws_floats(cin, cout)
         else:
             slabs, n = L.ramnet_wgrad_dsplit_slabs(cin, cout), L.ramnet_wgrad_dsplit_ws_floats(cin, cout)
         ws = torch.zeros(slabs * n, device=dev)
-        ws.wino, ws.wino6, ws.dsplit, ws.slabs = False, kind == "f2x4", kind == "dsplit", slabs
+        ws.wino, ws.wino6, ws.wg_dsplit, ws.slabs = False, kind == "f2x4", kind == "wg_dsplit", slabs
         bws = torch.zeros(slabs * cout, device=dev)
         for _ in range(3):
             ops.wgrad_launch(x, taps, dy, ws, cout, dbias=bws)
@@ -40,4 +40,4 @@ for name, H, W, cin, cout in shapes:
         tot[kind] += ms
         row.append("%s %.3f ms (%s, %d slabs)" % (kind, ms, L.ramnet_last_kernel().decode(), slabs))
     print("%-11s Cin %3d Cout %3d %3dx%3d: %s" % (name, cin, cout, H, W, " | ".join(row)), flush=True)
-print("six launches: f2x4 %.3f ms, dsplit %.3f ms (x%.2f)" % (tot["f2x4"], tot["dsplit"], tot["f2x4"] / tot["dsplit"]))
+print("six launches: f2x4 %.3f ms, dsplit %.3f ms (x%.2f)" % (tot["f2x4"], tot["wg_dsplit"], tot["f2x4"] / tot["wg_dsplit"]))
