@@ -722,6 +722,60 @@ def test_conv_gru(B, H, W, C, algo3x3):
              [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W))])
 
 
+@pytest.fixture
+def direct_split_wgrad():
+    """Split operands everywhere they exist: F(2x4,3x3) forward / backward-data with split operands (csrc/conv_wino6s.hip) AND the direct
+    split backward-weights kernel (csrc/conv_wgrad_dsplit.hip, ops.set_split_wgrad — off by default: profiles/r06_dsplit_notes.md)."""
+    from rpg_ramnet_amd import ops
+    ops.set_winograd_2x4("force")
+    ops.set_wgrad_winograd_2x4("force")
+    ops.set_split_operands(True)
+    ops.set_split_wgrad(True)
+    yield
+    ops.set_split_wgrad(False)
+    ops.set_split_operands(False)
+    ops.set_winograd_2x4("auto")
+    ops.set_wgrad_winograd_2x4("auto")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256), (1, 16, 32, 128)])
+def test_conv_gru_direct_split_backward_weights(B, H, W, C, direct_split_wgrad):
+    """ConvGRU (concatenated inputs, both gate convolutions and the candidate) with the direct split backward-weights kernel: state, input
+    and parameter gradients against the float64 oracle at the tolerance of the exact kernels; the launches really are that kernel."""
+    from rpg_ramnet_amd.model.submodules import ConvGRU
+    torch.manual_seed(5)
+    m = ConvGRU(C, C, 3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    run_pair(m, lambda sd, a, h: ramnet_ref.conv_gru({"L." + k: v for k, v in sd.items()}, "L", a, h),
+             [torch.randn(B, C, H, W), torch.tanh(torch.randn(B, C, H, W))])
+    if 2 * C >= 64:
+        assert Hh.lib().ramnet_last_kernel().decode().startswith("conv_wgrad_dsplit_kernel")
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (2, 4, 43, 256)])
+def test_residual_block_direct_split_backward_weights(B, H, W, C, direct_split_wgrad):
+    """Residual block (ReLU masks on the input of the second layer's backward-weights launch and on both gradients: the masked
+    instantiations of the kernel) against the float64 oracle."""
+    from rpg_ramnet_amd.model.submodules import ResidualBlock
+    torch.manual_seed(4)
+    m = ResidualBlock(C, C)
+    run_pair(m, lambda sd, a: ramnet_ref.residual_block({"L." + k: v for k, v in sd.items()}, "L", a), [torch.randn(B, C, H, W)])
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 32, 32, 64), (1, 18, 26, 64, 128)])
+def test_stride2_encoder_direct_split_backward_weights(B, H, W, cin, cout, direct_split_wgrad):
+    """Stride-2 5x5 encoder over its space-to-depth view (RAMNET_IN_S2D) with the direct split backward-weights kernel."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.model.submodules import ConvLayer
+    torch.manual_seed(1)
+    m = ConvLayer(cin, cout, 5, 2, 2)
+    assert ops.get_space_to_depth()
+    run_pair(m, lambda sd, a: torch.relu(torch.nn.functional.conv2d(a, sd["conv2d.weight"], sd["conv2d.bias"], 2, 2)), [torch.randn(B, cin, H, W)])
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 33, 45, 128), (8, 5, 43, 256)])
 def test_conv_gru_backward_stage_b_fused_equals_unfused(B, H, W, C, algo3x3):
     """Stage B of the ConvGRU backward (dpr = d(h.r) h r (1-r), dh = dh'(1-u) + d(h.r) r; submodules.py:448-452 differentiated) runs in
