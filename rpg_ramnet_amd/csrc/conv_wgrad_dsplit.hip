@@ -70,6 +70,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned ds_cvt_pk(float lo, float hi) {      // {bf16(lo), bf16(hi)}, round to nearest even: v_cvt_pk_bf16_f32
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{lo, hi}), bf16x2));
 }
+// a * b, rounded ONCE (HIP's __fmul_rn is a plain product: left to -ffp-contract=fast, the first residual of the split becomes fma(x, m, -x1))
+__device__ __forceinline__ float ds_mul_rn(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // three bf16 terms of the pixel pair (a, b): h[t] = {term t of a, term t of b}
 __device__ __forceinline__ void ds_split2(float a, float b, unsigned (&h)[3]) {
     h[0] = ds_cvt_pk(a, b);
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 
         if (ABLD(2)) return;
         float e = comp(xv[i][0], j), o = comp(xv[i][1], j);
         if (XMK == 1) e = comp(xmv[i & 1][0], j) > 0.f ? e : 0.f, o = comp(xmv[i & 1][1], j) > 0.f ? o : 0.f;
-        if (XMK == 2) e *= comp(xmv[i & 1][0], j) + m_one, o *= comp(xmv[i & 1][1], j) + m_one;
+        if (XMK == 2) e = ds_mul_rn(e, comp(xmv[i & 1][0], j) + m_one), o = ds_mul_rn(o, comp(xmv[i & 1][1], j) + m_one);
         unsigned h[3];
         ds_split2(e, o, h);
 #pragma unroll
@@ -293,7 +299,8 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 
                     if (kind == 0) {
                         se = comp(xv[i & 1][0], j), so = comp(xv[i & 1][1], j);
                         if (XMK == 1) se = comp(xmv[i & 1][0], j) > 0.f ? se : 0.f, so = comp(xmv[i & 1][1], j) > 0.f ? so : 0.f;
-                        if (XMK == 2) se *= comp(xmv[i & 1][0], j) + m_one, so *= comp(xmv[i & 1][1], j) + m_one;
+                        // (the SINGLE-rounded product the materialised h.r holds)
+                        if (XMK == 2) se = ds_mul_rn(se, comp(xmv[i & 1][0], j) + m_one), so = ds_mul_rn(so, comp(xmv[i & 1][1], j) + m_one);
                     } else {
                         se = comp(yv[0], j), so = comp(yv[1], j);
                         if (GM) se = comp(ymv[0], j) > 0.f ? se : 0.f, so = comp(ymv[1], j) > 0.f ? so : 0.f;
