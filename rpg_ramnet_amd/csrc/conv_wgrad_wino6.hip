@@ -359,12 +359,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_wino_r6_kernel(const ramnet
                     if (g == 2) finish_x0(on);
                     if (g == 3) finish_x1(on), stage(st * 3 + 1);
                     if (g == 4) finish_y(on);
+                    if (RAMNET_ABL & 1024) {      // (timing only: the vector work of the transforms once more — what a split of the operands would add)
+                        if (g == 3) { for (int c = 0; c < 6; ++c) RAMNET_OPQ(da[c]); finish_x0(on), finish_x1(on); }
+                        if (g == 5) { for (int c = 0; c < 4; ++c) RAMNET_OPQ(g0[c]); finish_y(on); }
+                    }
                     if (g == 5) { stage(st * 3 + 2); if (st == 3) stage(12); }
                 };
 #pragma unroll
                 for (int pl = 0; pl < 6; ++pl) {
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[o][pl], bn[o][pl], acc[pl], 0, 0, 0);
+                    if (!(RAMNET_ABL & 512) || pl < 2) acc[pl] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[o][pl], bn[o][pl], acc[pl], 0, 0, 0);
+                    else asm volatile("" : : "v"(an[o][pl]), "v"(bn[o][pl]));
                     __builtin_amdgcn_sched_barrier(0);
                     gap(pl);
                 }
