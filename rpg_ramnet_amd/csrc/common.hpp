@@ -14,7 +14,7 @@ constexpr int LDP = CK + 4;   // padded LDS row (floats) of a patch pixel / weig
 constexpr int TWID = 16;      // output tile width in pixels (tile = TH x 16)
 constexpr int WCK = 32;       // input channels per block of the weight-gradient kernel
 
-extern int g_opt_voxel_sorted, g_opt_fold_pair, g_opt_wgrad_blocks, g_opt_wgrad_wino_blocks, g_opt_wino_ksplit, g_opt_wgrad_wino_nf;     // ramnet_set_option() (pointwise.hip)
+extern int g_opt_voxel_sorted, g_opt_fold_pair, g_opt_wgrad_blocks, g_opt_wgrad_wino_blocks, g_opt_wino_ksplit, g_opt_wgrad_wino_nf, g_opt_pred_si_cap, g_opt_pred_si_bwd_cap;     // ramnet_set_option() (pointwise.hip)
 void set_error(const char *fmt, ...);
 void note_kernel(const char *fmt, ...);   // symbol (template arguments included) of the MFMA kernel a launcher enqueued: ramnet_last_kernel()
 int launch_wino(const ramnet_conv_desc &d, hipStream_t st);   // conv_wino.hip

@@ -326,7 +326,8 @@ __device__ __forceinline__ double pw_wave_sum(double v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
+constexpr int PRED_SI_THREADS = 256;       // (1024-thread workgroups, 128-256 of them: 36.7-37.6 us against 37.5 — the same floor; tools/bench_pred_si.py)
+__global__ void __launch_bounds__(PRED_SI_THREADS) pred_sigmoid_si_fwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w,
                                                                   const float *__restrict__ bias, float *__restrict__ y, size_t seg_pix,
                                                                   PredSiTargets tg, float weight, float lambda, double *__restrict__ part,
                                                                   unsigned long long *__restrict__ ticket, double *__restrict__ stats,
@@ -402,15 +403,21 @@ __global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *_
             }
         }
     }
-    __shared__ double red[3][4];
+    constexpr int NW = PRED_SI_THREADS / 64;
+    __shared__ double red[3][NW];
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     s1 = pw_wave_sum(s1), s2 = pw_wave_sum(s2), cnt = pw_wave_sum(cnt);
     if (lane == 0) red[0][wave] = s1, red[1][wave] = s2, red[2][wave] = cnt;
     __syncthreads();
+    auto fold = [&](int k) {                     // the waves' sums in a fixed order (pairs of neighbours, then the pairs in sequence)
+        double a = 0.0;
+        for (int i = 0; i < NW; i += 2) a += red[k][i] + red[k][i + 1];
+        return a;
+    };
     double *mine = part + ((size_t)seg * gridDim.x) * 3;
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 3; ++k) mine[blockIdx.x * 3 + k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        for (int k = 0; k < 3; ++k) mine[blockIdx.x * 3 + k] = fold(k);
         __threadfence();                                        // the partials are visible before the ticket
         is_last = atomicAdd(ticket + seg, 1ull) == (unsigned long long)gridDim.x - 1;
     }
@@ -426,7 +433,7 @@ __global__ void __launch_bounds__(256) pred_sigmoid_si_fwd_kernel(const float *_
     __syncthreads();
     if (threadIdx.x == 0) {
         double S[3];
-        for (int k = 0; k < 3; ++k) S[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]), stats[seg * 4 + k] = S[k];
+        for (int k = 0; k < 3; ++k) S[k] = fold(k), stats[seg * 4 + k] = S[k];
         stats[seg * 4 + 3] = 0.0;
         const double m = S[0] / S[2];
         loss[seg] = (float)((double)weight * (S[1] / S[2] - (double)lambda * m * m));
@@ -824,7 +831,7 @@ extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
 
 // Process-wide A/B options (tests and tuning runs; the environment variables they replace are gone since round 4)
 namespace ramnet {
-int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1;
+int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1, g_opt_pred_si_cap = 256, g_opt_pred_si_bwd_cap = 1024;
 }
 extern "C" int ramnet_set_option(const char *name, int value) {
     RAMNET_CHECK_ARG(name != nullptr);
@@ -834,6 +841,8 @@ extern "C" int ramnet_set_option(const char *name, int value) {
     else if (!strcmp(name, "wgrad_wino_nf")) { RAMNET_CHECK_ARG(value == 1 || value == 2); ramnet::g_opt_wgrad_wino_nf = value; }
     else if (!strcmp(name, "wino_ksplit")) { RAMNET_CHECK_ARG(value >= 0 && value <= 16); ramnet::g_opt_wino_ksplit = value; }
     else if (!strcmp(name, "wgrad_wino_blocks")) { RAMNET_CHECK_ARG(value >= 1 && value <= 384); ramnet::g_opt_wgrad_wino_blocks = value; }
+    else if (!strcmp(name, "pred_si_bwd_cap")) { RAMNET_CHECK_ARG(value >= 8 && value <= 65536); ramnet::g_opt_pred_si_bwd_cap = value; }
+    else if (!strcmp(name, "pred_si_cap")) { RAMNET_CHECK_ARG(value >= 8 && value <= 65536); ramnet::g_opt_pred_si_cap = value; }
     else RAMNET_CHECK_ARG(!"ramnet_set_option: unknown option");
     return 0;
 }
@@ -845,6 +854,8 @@ extern "C" int ramnet_get_option(const char *name) {
     if (!strcmp(name, "wgrad_wino_blocks")) return ramnet::g_opt_wgrad_wino_blocks;
     if (!strcmp(name, "wino_ksplit")) return ramnet::g_opt_wino_ksplit;
     if (!strcmp(name, "wgrad_wino_nf")) return ramnet::g_opt_wgrad_wino_nf;
+    if (!strcmp(name, "pred_si_bwd_cap")) return ramnet::g_opt_pred_si_bwd_cap;
+    if (!strcmp(name, "pred_si_cap")) return ramnet::g_opt_pred_si_cap;
     return -1;
 }
 
@@ -990,12 +1001,15 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
     return pred_bwd(x, ldx, C, w, y, dy, dx, lddx, dw, db, npix, stream);
 }
 static int pred_si_grid(size_t seg_pix, int nseg) {
-    // Workgroups per segment: at most 1024 over all segments (their partial sums meet in the segment's last workgroup), and a count that gives
-    // every 8-lane group the SAME number of 8-pixel trips (a ragged last trip left a third of the chip idle: 0.21 of the HBM peak at 2048)
+    // Workgroups per segment: at most "pred_si_cap" (256 = one per CU) over all segments — every workgroup ends with a fence and a ticket
+    // atomic on ONE address per segment, ~27 ns each and serialised: 1.41 M pixels x 32 channels take 37.5 us with 256 workgroups (0.64 of
+    // the HBM peak), 43.9 with 512, 58.3 with 1024 (the round-5 default), 86.7 with 2048; 53.6 with 128 (tools/bench_pred_si.py) — and a count
+    // that gives every 8-lane group the SAME number of 8-pixel trips (a ragged last trip left a third of the chip idle)
     const size_t groups = (seg_pix + 7) / 8;
-    const size_t cap = 1024 / (size_t)(nseg > 0 ? nseg : 1);
-    const size_t trips = (groups + cap * 32 - 1) / (cap * 32);
-    size_t g = (groups + 32 * trips - 1) / (32 * trips);
+    const size_t cap = (size_t)ramnet::g_opt_pred_si_cap / (size_t)(nseg > 0 ? nseg : 1);
+    constexpr size_t GPW = PRED_SI_THREADS / 8;                 // 8-lane groups per workgroup
+    const size_t trips = (groups + cap * GPW - 1) / (cap * GPW);
+    size_t g = (groups + GPW * trips - 1) / (GPW * trips);
     if (g > cap) g = cap;
     return g < 1 ? 1 : (int)g;
 }
@@ -1014,7 +1028,7 @@ extern "C" int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const 
     for (int i = 0; i < RAMNET_PRED_SI_MAX_SEGMENTS; ++i) tg.t[i] = i < nseg ? targets[i] : nullptr;
     for (int i = 0; i < nseg; ++i) RAMNET_CHECK_ARG(tg.t[i] != nullptr);
     const int g = pred_si_grid(seg_pix, nseg);
-    hipLaunchKernelGGL(pred_sigmoid_si_fwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, b, y, seg_pix, tg, weight, lambda,
+    hipLaunchKernelGGL(pred_sigmoid_si_fwd_kernel, dim3(g, nseg), dim3(PRED_SI_THREADS), 0, (hipStream_t)stream, x, ldx, C, w, b, y, seg_pix, tg, weight, lambda,
                        scratch, reinterpret_cast<unsigned long long *>(scratch + (size_t)nseg * g * 3), stats, loss);
     RAMNET_LAUNCH_CHECK();
     return 0;
@@ -1030,7 +1044,9 @@ extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const 
     for (int i = 0; i < RAMNET_PRED_SI_MAX_SEGMENTS; ++i) tg.t[i] = i < nseg ? targets[i] : nullptr;
     for (int i = 0; i < nseg; ++i) RAMNET_CHECK_ARG(tg.t[i] != nullptr);
     int g = grid_for(seg_pix * 8);
-    if (g > 512 / nseg) g = 512 / nseg;      // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups
+    // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups — but four loads in flight per lane want more than
+    // two workgroups per CU: 1024 in all 74.5 us (0.62 of the HBM peak), 512 (round 5) 87.5, 2048 79.8, 256 146.8 (tools/bench_pred_si.py)
+    if (g > ramnet::g_opt_pred_si_bwd_cap / nseg) g = ramnet::g_opt_pred_si_bwd_cap / nseg;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(pred_sigmoid_si_bwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, tg, stats, gscale, weight,
                        lambda, dx, lddx, dw, db, seg_pix);
