@@ -93,6 +93,8 @@ def parse():
                          "line stays exact fp32 and carries this variant as extras.split_operands")
     ap.add_argument("--wgrad-2x4", default="auto", choices=["auto", "off", "force"], help="A/B: F(2x4,3x3) backward-weights (ops.set_wgrad_winograd_2x4)")
     ap.add_argument("--no-time-batching", action="store_true", help="A/B: the pass-by-pass package loop instead of the time-batched forward (ops.set_time_batching(False))")
+    ap.add_argument("--no-relu-premask", action="store_true", help="A/B: ReLU mask of the time-batched encoders in the loaders of their backward launches "
+                    "(round 5) instead of in the fan-in of their gradient (ops.set_relu_premask)")
     ap.add_argument("--time-batch-max-decodes", type=int, default=0, help="A/B: decodes per chain of the time-batched forward (0 = a whole group)")
     ap.add_argument("--no-configs4-extra", action="store_true", help="skip extras.configs4_shape (a ~20 s run of the 480x640 / 10-bin / B=4 / L=16 workload in a process of its own)")
     ap.add_argument("--no-gru-bwd-fused", action="store_true", help="A/B: ConvGRU backward stage B as its own launch (ops.set_gru_bwd_fused(False))")
@@ -835,6 +837,7 @@ def main():
     w24 = args.wino2x4.split(",")
     ops.set_winograd_2x4(w24[0], min_wgs=int(w24[1]) if len(w24) > 1 else None)
     ops.set_split_operands(args.split_operands)
+    ops.set_relu_premask(not args.no_relu_premask)
     if args.full_frame:
         assert args.mode == "train", "--full-frame: the training step (the graph runtimes of the other modes have static 8-aligned buffers)"
         args.height, args.width, args.no_extras = 260, 346, True

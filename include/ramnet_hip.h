@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 23      /* 23: ramnet_wgrad_desc.algo = RAMNET_ALGO_DIRECT_SPLIT (direct 3x3 backward-weights on the bf16 matrix pipe, split operands: csrc/conv_wgrad_dsplit.hip) + ramnet_wgrad_dsplit_slabs; 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 24      /* 24: ramnet_cat_batch_add_masked (the gradient of a time-batched ReLU feature leaves its fan-in already masked); 23: ramnet_wgrad_desc.algo = RAMNET_ALGO_DIRECT_SPLIT (direct 3x3 backward-weights on the bf16 matrix pipe, split operands: csrc/conv_wgrad_dsplit.hip) + ramnet_wgrad_dsplit_slabs; 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -414,6 +414,11 @@ int ramnet_concat2(const float *a, int lda, int Ca, const float *b, int ldb, int
  * when base != NULL: the gradient of a feature that went through a layer chain at batch n x B and was consumed slice by slice (the n
  * state updates of a package) and, as a whole, by the next layer of the chain (ABI 19; `parts` = host array of n <= 8 device pointers). */
 int ramnet_cat_batch_add(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, float *out, void *stream);
+/* The same with the ReLU mask of the feature itself applied to the sum (ABI 24): out = (cat(parts) [+ base]) * (mask > 0), mask [n * npix][C] dense = the
+ * feature (the output of a ConvLayer with ReLU, submodules.py:26-35).  The layer's backward-data / backward-weights launches then read the gradient as
+ * ONE plain operand instead of (gradient, output) pairs through RAMNET_IN_RELUMASK / gmask: the same values, so bit-identical gradients. */
+int ramnet_cat_batch_add_masked(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, const float *mask, float *out,
+                                void *stream);
 int ramnet_split2(const float *y, int ldy, int Ca, int Cb, float *a, float *b, size_t npix, void *stream);
 
 /* ---- scale-invariant loss: model/loss.py:6-9 -------------------------------------------------- */

@@ -129,6 +129,7 @@ _SIGS = {
     "ramnet_pred_linear_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_pred_linear_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_cat_batch_add": (C.c_int, [_fp, C.c_int, C.c_size_t, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "ramnet_cat_batch_add_masked": (C.c_int, [_fp, C.c_int, C.c_size_t, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ramnet_relu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_upsample2x_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "ramnet_gru_bwd_a": (C.c_int, [_fp] * 7 + [C.c_size_t, C.c_int, C.c_int, _fp]),
@@ -210,7 +211,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
-        if l.ramnet_abi_version() != 23:
+        if l.ramnet_abi_version() != 24:
             raise RuntimeError("ABI version mismatch in %s" % LIB_PATH)
         _lib = l
     return _lib if _tracer is None else _Traced(_lib)

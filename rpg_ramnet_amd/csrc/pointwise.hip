@@ -917,7 +917,7 @@ struct CatParts {
     const float *p[8];
 };
 __global__ void cat_batch_add_kernel(const CatParts parts, int n, size_t npix, int C, int ld, const float *__restrict__ base,
-                                     float *__restrict__ out) {
+                                     const float *__restrict__ mask, float *__restrict__ out) {
     const int C4 = C / 4;
     const size_t per = npix * C4, total = per * n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -928,20 +928,32 @@ __global__ void cat_batch_add_kernel(const CatParts parts, int n, size_t npix, i
                            : k == 5 ? parts.p[5] : k == 6 ? parts.p[6] : parts.p[7];
         float4 v = ld4(src + pix * ld + c);
         if (base) v = f4add(v, ld4(base + i * 4));
+        if (mask) {             // the feature is a ReLU output: its gradient leaves here already masked (the consumer's loaders then read ONE operand)
+            const float4 m = ld4(mask + i * 4);
+            v.x = m.x > 0.f ? v.x : 0.f, v.y = m.y > 0.f ? v.y : 0.f, v.z = m.z > 0.f ? v.z : 0.f, v.w = m.w > 0.f ? v.w : 0.f;
+        }
         st4(out + i * 4, v);
     }
 }
 
-extern "C" int ramnet_cat_batch_add(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, float *out, void *stream) {
+static int cat_batch_add(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, const float *mask, float *out, void *stream) {
     RAMNET_CHECK_ARG(parts && out && n >= 1 && n <= 8 && npix > 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0);
     CatParts q;
     for (int k = 0; k < 8; ++k) {
         q.p[k] = k < n ? parts[k] : nullptr;
         if (k < n) RAMNET_CHECK_ARG(parts[k] && ((uintptr_t)parts[k] & 15) == 0);
     }
-    hipLaunchKernelGGL(cat_batch_add_kernel, dim3(grid_for((size_t)n * npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, q, n, npix, C, ld, base, out);
+    hipLaunchKernelGGL(cat_batch_add_kernel, dim3(grid_for((size_t)n * npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, q, n, npix, C, ld, base, mask, out);
     RAMNET_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int ramnet_cat_batch_add(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, float *out, void *stream) {
+    return cat_batch_add(parts, n, npix, C, ld, base, nullptr, out, stream);
+}
+extern "C" int ramnet_cat_batch_add_masked(const float *const *parts, int n, size_t npix, int C, int ld, const float *base, const float *mask, float *out,
+                                           void *stream) {
+    RAMNET_CHECK_ARG(mask != nullptr && ((uintptr_t)mask & 15) == 0);
+    return cat_batch_add(parts, n, npix, C, ld, base, mask, out, stream);
 }
 
 extern "C" int ramnet_relu_bwd(const float *dy, const float *y, float *dx, size_t n, void *stream) {

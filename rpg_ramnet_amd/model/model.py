@@ -201,11 +201,12 @@ class ERGB2DepthRecurrent(BaseERGB2Depth):
         feats = []
         for i, enc in enumerate(net.encoders_events):
             x = enc(x)
+            pm = ops.premask_relu_feature(x)       # every gradient of x arrives through the fan-in below: it applies the encoder's ReLU mask
             if i + 1 < n:          # feeds the next encoder as a whole and the K cells of its scale slice by slice
-                fan = ops.TimeFan.apply(x, K)
+                fan = ops.TimeFan.apply(x, K, pm)
                 x, parts = fan[0], fan[1:]
             else:
-                parts = ops.TimeSplit.apply(x, K)
+                parts = ops.TimeSplit.apply(x, K, pm)
             feats.append(parts)
         # slot k of arena[i] = the state of scale i after update k (slot K: after the frame); written by the cells, never by a torch op
         pair = net.state_combination == 'convlstm'           # (h, c) per scale: the decoders read h

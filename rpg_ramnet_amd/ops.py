@@ -1449,6 +1449,9 @@ class ConvAct(Function):
             conv_launch(x, Taps.get("conv", k, pad), cp.fwd(), y, cp.Cout, stride=stride, x1=skip, in_mode=mode,
                         Hin=Hin, Win=Win, bias=cp.bias(), epi=epi)
         ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode = cp, stride, relu, up, mode
+        # premask_ok: a caller that routes EVERY gradient of y through one fan-in (ops.TimeSplit / TimeFan) may have that fan-in apply the ReLU
+        # mask and set premasked (premask_relu_feature): backward then reads dy as a plain operand
+        ctx.premask_ok, ctx.premasked = bool(relu) and not up, False
         ctx.save_for_backward(x, skip, y, xpad if _SAVE_XPAD else None)
         return y
 
@@ -1456,6 +1459,7 @@ class ConvAct(Function):
     def backward(ctx, dy):
         x, skip, y, xpad = ctx.saved_tensors
         cp, stride, relu, up, mode = ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode
+        relu = relu and not ctx.premasked           # (dy == dy * (y > 0) already)
         dy = dense(dy)
         if ctx.s2d_fused:   # x is the full-resolution input; the kernels address its space-to-depth view
             sp = cp.s2d()
@@ -1779,7 +1783,32 @@ def time_batching():
     return _TIME_BATCH
 
 
-def _cat_batch_add(grads, base, shape, device):
+# A time-batched feature that is a ReLU output gets its ReLU mask where its gradient is summed (TimeSplit / TimeFan backward: one more
+# operand in an HBM-bound launch) instead of in the loaders of its layer's backward-data and backward-weights launches (two operands per
+# staged slot on the matrix kernels: RAMNET_IN_RELUMASK / gmask).  The same values reach the same products: bit-identical gradients.
+_RELU_PREMASK = True
+
+
+def set_relu_premask(on):
+    global _RELU_PREMASK
+    _RELU_PREMASK = bool(on)
+
+
+def get_relu_premask():
+    return _RELU_PREMASK
+
+
+def premask_relu_feature(y):
+    """y = the output of a ConvAct with ReLU whose ONLY consumer is the TimeSplit / TimeFan the caller builds next (model/model.py): tell the
+    layer's backward that the gradient it receives is already masked.  Returns whether the fan-in should apply the mask."""
+    fn = getattr(y, "grad_fn", None)
+    if not (_RELU_PREMASK and fn is not None and getattr(fn, "premask_ok", False)):
+        return False
+    fn.premasked = True
+    return True
+
+
+def _cat_batch_add(grads, base, shape, device, mask=None):
     """cat(grads, 0) [+ base] as ONE launch (ramnet_cat_batch_add): the slices' gradients are channel slices of wider tensors (the
     [dx | dh] of a ConvGRU backward: ld = 2C), `base` the gradient that arrived through the batched consumer."""
     n = len(grads)
@@ -1792,11 +1821,17 @@ def _cat_batch_add(grads, base, shape, device):
     if not ok:
         filled = [g if g is not None else torch.zeros((shape[0] // n,) + tuple(shape[1:]), device=device) for g in grads]
         out = torch.cat(filled, 0)
-        return out if base is None else out + base
+        out = out if base is None else out + base
+        return out if mask is None else out * (mask > 0).to(out.dtype)
     out = torch.empty(shape, device=device)
     arr = (C.c_void_p * n)(*[g.data_ptr() for g in gs])
     b = None if base is None else base.contiguous()
-    H.check(H.lib().ramnet_cat_batch_add(arr, n, shape[1] * shape[2] * (shape[0] // n), shape[3], ld(gs[0]), _p(b), _p(out), _st()), "ramnet_cat_batch_add")
+    npix = shape[1] * shape[2] * (shape[0] // n)
+    if mask is not None:
+        assert tuple(mask.shape) == tuple(shape) and mask.is_contiguous() and mask.dtype == torch.float32
+        H.check(H.lib().ramnet_cat_batch_add_masked(arr, n, npix, shape[3], ld(gs[0]), _p(b), _p(mask), _p(out), _st()), "ramnet_cat_batch_add_masked")
+    else:
+        H.check(H.lib().ramnet_cat_batch_add(arr, n, npix, shape[3], ld(gs[0]), _p(b), _p(out), _st()), "ramnet_cat_batch_add")
     return out
 
 
@@ -1816,16 +1851,22 @@ class TimeSplit(Function):
     concatenates the n gradients (ONE launch) instead of autograd's n zero-fills + n slice copies."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, premask=False):
         B = x.shape[0] // n
         ctx.meta = (n, tuple(x.shape), x.device)
         ctx.set_materialize_grads(False)
+        ctx.premask = bool(premask) and x.is_contiguous()
+        if ctx.premask:
+            ctx.save_for_backward(x)          # (the layer that made x keeps it for its own backward anyway: no extra memory)
         return tuple(x[k * B:(k + 1) * B] for k in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
         n, shape, dev = ctx.meta
-        return _cat_batch_add(list(grads), None, shape, dev), None
+        mask = ctx.saved_tensors[0] if ctx.premask else None
+        if all(g is None for g in grads):
+            return None, None, None
+        return _cat_batch_add(list(grads), None, shape, dev, mask), None, None
 
 
 class TimeFan(Function):
@@ -1834,18 +1875,30 @@ class TimeFan(Function):
     (and the concatenation) as library work."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, premask=False):
         B = x.shape[0] // n
         ctx.meta = (n, tuple(x.shape), x.device)
         ctx.set_materialize_grads(False)
+        ctx.premask = bool(premask) and x.is_contiguous()
+        if ctx.premask:
+            ctx.save_for_backward(x)
         return (x.view_as(x),) + tuple(x[k * B:(k + 1) * B] for k in range(n))
 
     @staticmethod
     def backward(ctx, g_all, *grads):
         n, shape, dev = ctx.meta
+        mask = ctx.saved_tensors[0] if ctx.premask else None
         if all(g is None for g in grads):
-            return g_all, None
-        return _cat_batch_add(list(grads), g_all, shape, dev), None
+            if mask is not None and g_all is not None:      # (the promise to the layer holds on every path)
+                if g_all.is_cuda:
+                    g_all = dense(g_all)
+                    out = torch.empty_like(g_all)
+                    H.check(H.lib().ramnet_relu_bwd(_p(g_all), _p(mask), _p(out), g_all.numel(), _st()), "ramnet_relu_bwd")
+                    g_all = out
+                else:                                       # (the autograd plumbing is exercised on CPU tensors by the tests)
+                    g_all = g_all * (mask > 0).to(g_all.dtype)
+            return g_all, None, None
+        return _cat_batch_add(list(grads), g_all, shape, dev, mask), None, None
 
 
 class TimeJoin(Function):

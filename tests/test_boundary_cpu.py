@@ -742,6 +742,38 @@ def test_time_fan_autograd_plumbing_cpu():
     torch.testing.assert_close(x.grad, torch.cat(w, 0))
 
 
+def test_time_fan_relu_premask_cpu():
+    """The fan-in of a time-batched ReLU feature applies the feature's own ReLU mask (premask=True): gradient = (sum) * (x > 0), on every path
+    of TimeFan / TimeSplit (all consumers, slices only, batched consumer only); ops.premask_relu_feature only says yes for the output of a
+    ConvAct-like node that allows it."""
+    from rpg_ramnet_amd import ops
+    n, B = 3, 2
+    torch.manual_seed(3)
+    x = torch.randn(n * B, 4, 5, 8, requires_grad=True)
+    w_all, w = torch.randn(n * B, 4, 5, 8), [torch.randn(B, 4, 5, 8) for _ in range(n)]
+    y = torch.relu(x).contiguous()
+    m = (y > 0).float()
+    out = ops.TimeFan.apply(y, n, True)
+    ((out[0] * w_all).sum() + sum((p * wk).sum() for p, wk in zip(out[1:], w))).backward()
+    torch.testing.assert_close(x.grad, (w_all + torch.cat(w, 0)) * m * m)        # (torch.relu's own backward masks once more: idempotent)
+    # the masked sum itself, without a second mask behind it
+    z = (x.detach() * 1.0).requires_grad_(True)
+    zz = z * 1.0
+    out = ops.TimeFan.apply(zz, n, True)
+    ((out[0] * w_all).sum() + sum((p * wk).sum() for p, wk in zip(out[1:], w))).backward()
+    torch.testing.assert_close(z.grad, (w_all + torch.cat(w, 0)) * (z.detach() > 0).float())
+    z.grad = None
+    out = ops.TimeFan.apply(z * 1.0, n, True)
+    (out[0] * w_all).sum().backward()                                            # the batched consumer alone
+    torch.testing.assert_close(z.grad, w_all * (z.detach() > 0).float())
+    z.grad = None
+    parts = ops.TimeSplit.apply(z * 1.0, n, True)
+    sum((p * wk).sum() for p, wk in zip(parts, w)).backward()
+    torch.testing.assert_close(z.grad, torch.cat(w, 0) * (z.detach() > 0).float())
+    assert not ops.premask_relu_feature(torch.relu(x))                           # not a node that declared premask_ok
+    assert not ops.premask_relu_feature(x.detach())
+
+
 def _bf16_rne(x):
     """float32 tensor -> the nearest bf16 value (ties to even), as float32: what v_cvt_pk_bf16_f32 / the pack kernel's bf16_rne produce."""
     u = x.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff

@@ -249,6 +249,47 @@ def test_wgrad_side_stream_gradients(wgrad_overlap):
             assert_close(grads[True][k].cpu().numpy(), grads[False][k].cpu().numpy(), 1e-4, "side stream vs single " + k, floor=1e-2 * gmax)
 
 
+def test_relu_premask_in_the_time_fan_in_same_gradients():
+    """ops.set_relu_premask: the ReLU mask of the time-batched event encoders applied where their gradient is summed (TimeSplit / TimeFan
+    backward) instead of in the loaders of their backward-data / backward-weights launches — the same values reach the same products:
+    the loss is the same number and every gradient agrees to the summation order of the launches (bit-identical where that is fixed)."""
+    from rpg_ramnet_amd import ops
+    from rpg_ramnet_amd.trainer import sequence_loss
+    cfg, _ = ref_cfg("net_seeded_ramnet.npz", every_x_rgb_frame=3, loss_composition=["image", "events2"])
+    model = build_hip_model("ERGB2DepthRecurrent", cfg).train()
+    rng = np.random.default_rng(11)
+    seq = [make_item(rng, 2, 64, 96, 3, 5, cfg["num_bins_rgb"], True, 0.1) for _ in range(2)]
+    res = {}
+    calls = {"masked": 0}
+    from rpg_ramnet_amd import _hip as Hh
+
+    def tracer(name, fn, args):
+        if name == "ramnet_cat_batch_add_masked":
+            calls["masked"] += 1
+        return fn(*args)
+    try:
+        for on in (True, False):
+            ops.set_relu_premask(on)
+            calls["masked"] = 0
+            Hh.set_tracer(tracer)
+            model.zero_grad()
+            total, _ = sequence_loss(model, seq, cfg["loss_composition"], [1, 1])
+            total.backward()
+            torch.cuda.synchronize()
+            Hh.set_tracer(None)
+            assert (calls["masked"] > 0) == on, "the masked fan-in runs exactly when the switch is on"
+            res[on] = (float(total.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    finally:
+        ops.set_relu_premask(True)
+        Hh.set_tracer(None)
+    assert res[True][0] == res[False][0]
+    gmax = max(float(v.abs().max()) for v in res[True][1].values())
+    for k in res[True][1]:
+        if k.endswith("pred.conv2d.bias"):
+            continue
+        assert_close(res[True][1][k].cpu().numpy(), res[False][1][k].cpu().numpy(), 1e-5, "premask vs loader mask " + k, floor=1e-2 * gmax)
+
+
 def test_decoder_stream_overlap_same_results():
     """Decoders on a second stream (ops.set_decoder_overlap): identical predictions, gradients equal up to atomic order."""
     from rpg_ramnet_amd import ops

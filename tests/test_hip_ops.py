@@ -924,6 +924,29 @@ def test_time_fan_gradient_kernel(n, B, H, W, C, wide):
     assert torch.equal(x.grad, torch.cat([g[..., :C] for g in wide_g], 0))
 
 
+@pytest.mark.parametrize("n,B,H,W,C,wide", [(5, 2, 8, 12, 64, True), (3, 1, 7, 13, 32, False), (2, 3, 5, 9, 128, True)])
+def test_time_fan_gradient_kernel_with_relu_mask(n, B, H, W, C, wide):
+    """ramnet_cat_batch_add_masked (ABI 24): the same sum times (feature > 0) — bit-equal to torch's cat + add + where."""
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(n)
+    x = torch.randn(n * B, H, W, C, device=dev(), requires_grad=True)
+    wide_g = [torch.randn(B, H, W, 2 * C if wide else C, device=dev()) for _ in range(n)]
+    g_all = torch.randn(n * B, H, W, C, device=dev())
+    keep = x.detach() > 0
+    zero = torch.zeros((), device=dev())
+    out = ops.TimeFan.apply(x * 1.0, n, True)
+    torch.autograd.backward([out[0]] + list(out[1:]), [g_all] + [g[..., :C] for g in wide_g])
+    assert torch.equal(x.grad, torch.where(keep, g_all + torch.cat([g[..., :C] for g in wide_g], 0), zero))
+    x.grad = None
+    parts = ops.TimeSplit.apply(x * 1.0, n, True)
+    torch.autograd.backward(list(parts), [g[..., :C] for g in wide_g])
+    assert torch.equal(x.grad, torch.where(keep, torch.cat([g[..., :C] for g in wide_g], 0), zero))
+    x.grad = None
+    out = ops.TimeFan.apply(x * 1.0, n, True)
+    out[0].backward(g_all)                                                   # the batched consumer alone: one relu_bwd launch
+    assert torch.equal(x.grad, torch.where(keep, g_all, zero))
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_conv_lstm(B, H, W, C):
     from rpg_ramnet_amd.model.submodules import ConvLSTM
