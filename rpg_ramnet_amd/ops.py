@@ -635,6 +635,19 @@ def _wgrad_cell(cp, dw, tensors, x0, taps, dout, Cout, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ parameters
+# Workspace zero-fills of the end-of-backward fold: inside _Engine.flush they are collected and issued as ONE multi-tensor launch behind the
+# last layer's fold (round 6: ~76 fills of ~5 us each at the very end of a training step, where nothing runs beside them); outside a flush
+# (a ConvParam finalised on its own) they run at once.
+_ZERO_BATCH = None
+
+
+def _zero_later(t):
+    if _ZERO_BATCH is None:
+        t.zero_()
+    else:
+        _ZERO_BATCH.append(t)
+
+
 class _Engine:
     """Per-backward-pass bookkeeping: fold weight-gradient workspaces into .grad when the autograd engine finishes the pass.
 
@@ -681,10 +694,18 @@ class _Engine:
         hook = _FINALIZE_HOOK if (_FINALIZE_HOOK is not None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())) else None
         if hook is not None:
             hook.begin(dirty)
-        for cp in dirty:
-            cp.finalize()
-            if hook is not None:
-                hook.finalized(cp)
+        global _ZERO_BATCH
+        _ZERO_BATCH = []
+        try:
+            for cp in dirty:
+                cp.finalize()
+                if hook is not None:
+                    hook.finalized(cp)
+        finally:
+            zs, _ZERO_BATCH = _ZERO_BATCH, None
+            zs = [z for z in zs if z.numel() > 0]
+            if zs:
+                torch._foreach_zero_(zs)
         if hook is not None and hasattr(hook, "end"):
             hook.end()
 
@@ -759,15 +780,20 @@ def s2d_weights(w):
     return out.reshape(O, 4 * I, 3, 3)
 
 
+_S2D_ADJ_IDX = {}
+
+
 def s2d_weights_adjoint(g3, I):
-    """Gradient w.r.t. the [O][4*I][3][3] weights -> gradient w.r.t. the 5x5 weights (reads the 25 populated slices)."""
+    """Gradient w.r.t. the [O][4*I][3][3] weights -> gradient w.r.t. the 5x5 weights (reads the 25 populated slices): tap (ky, kx) of the 5x5
+    filter is entry (parity group a*2 + b, dy + 1, dx + 1) of the 3x3 one.  ONE transposing copy + ONE gather (round 6: 25 strided slice copies
+    + a fill per encoder were 156 launches of ~5 us at the very end of a training step, where nothing runs beside them)."""
     O = g3.shape[0]
-    g3 = g3.view(O, 4, I, 3, 3)
-    out = g3.new_zeros(O, I, 5, 5)
-    for ky, (dy, a) in enumerate(S2D_TAP):
-        for kx, (dx, b) in enumerate(S2D_TAP):
-            out[:, :, ky, kx] = g3[:, a * 2 + b, :, dy + 1, dx + 1]
-    return out
+    idx = _S2D_ADJ_IDX.get(g3.device)
+    if idx is None:
+        idx = _S2D_ADJ_IDX[g3.device] = torch.tensor([(a * 2 + b) * 9 + (dy + 1) * 3 + (dx + 1) for (dy, a) in S2D_TAP for (dx, b) in S2D_TAP],
+                                                     dtype=torch.int64, device=g3.device)
+    t = g3.view(O, 4, I, 9).permute(0, 2, 1, 3).reshape(O, I, 36)           # [O][I][group * 9 + 3 * row + column]
+    return t.index_select(2, idx).view(O, I, 5, 5)
 
 
 # Packed weights are cached per parameter version (an optimizer step bumps it).  A hipGraph replays kernels, not Python: when a
@@ -1073,8 +1099,8 @@ class ConvParam:
         else:
             n, ns = self.k * self.k * self.CinWs * self.Cout, 1
         joined = ns > 1 and (w6 or wn or ds)
-        self._ws[:n if joined else min(self._ws.numel(), n * max(ns, 1))].zero_()
-        self._bws[:self.Cout if joined else self._bws.numel()].zero_()
+        _zero_later(self._ws[:n if joined else min(self._ws.numel(), n * max(ns, 1))])
+        _zero_later(self._bws[:self.Cout if joined else self._bws.numel()])
 
     def finalize(self):
         if self._fold_used:
@@ -1084,7 +1110,7 @@ class ConvParam:
         if not self._ws_used:
             if self.biases[0] is not None and self.biases[0].shape[0] == self.Cout:
                 ensure_grad(self.biases[0]).add_(self._bws[:self.Cout])
-            self._bws.zero_()
+            _zero_later(self._bws)
             self._dirty = False
             return
         off = 0
