@@ -186,7 +186,7 @@ typedef struct ramnet_wgrad_desc {
  * launches with a backward-data chain on another stream wants (training step 217 vs 211 samples/s) —
  * "wino_ksplit" (1 = the library's heuristic; 0 = ramnet_conv_splitk_floats answers 0: no launch splits its reduction; 2..16 = that many
  * splits for every launch whose epilogue can join partials: tuning runs).
- * "pred_si_cap" (256) / "pred_si_bwd_cap" (1024): workgroups per launch, over all segments, of ramnet_pred_sigmoid_si_fwd / _bwd (every
+ * "pred_si_cap" (256) / "pred_si_bwd_cap" (512): workgroups per launch, over all segments, of ramnet_pred_sigmoid_si_fwd / _bwd (every
  * workgroup ends on per-segment atomics: tools/bench_pred_si.py has the sweep); ramnet_pred_si_scratch_doubles follows the option, so set it
  * before sizing the scratch.
  * ramnet_get_option: -1 if unknown.  */

@@ -831,7 +831,7 @@ extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
 
 // Process-wide A/B options (tests and tuning runs; the environment variables they replace are gone since round 4)
 namespace ramnet {
-int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1, g_opt_pred_si_cap = 256, g_opt_pred_si_bwd_cap = 1024;
+int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1, g_opt_pred_si_cap = 256, g_opt_pred_si_bwd_cap = 512;
 }
 extern "C" int ramnet_set_option(const char *name, int value) {
     RAMNET_CHECK_ARG(name != nullptr);
@@ -1056,8 +1056,9 @@ extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const 
     for (int i = 0; i < RAMNET_PRED_SI_MAX_SEGMENTS; ++i) tg.t[i] = i < nseg ? targets[i] : nullptr;
     for (int i = 0; i < nseg; ++i) RAMNET_CHECK_ARG(tg.t[i] != nullptr);
     int g = grid_for(seg_pix * 8);
-    // every workgroup ends with 33 atomics on the SAME 33 addresses: few, fat workgroups — but four loads in flight per lane want more than
-    // two workgroups per CU: 1024 in all 74.5 us (0.62 of the HBM peak), 512 (round 5) 87.5, 2048 79.8, 256 146.8 (tools/bench_pred_si.py)
+    // every workgroup ends with 33 fp32 atomics on the SAME 33 addresses: few, fat workgroups.  "pred_si_bwd_cap" = 512 in all: 87.5 us; 1024
+    // would be 74.5 us (0.62 of the HBM peak; 2048 79.8, 256 146.8: tools/bench_pred_si.py) but doubles the summation-order noise of the bias
+    // gradient — a sum of 1.4 M terms that cancels to ~1e-6 of them — for 0.05 % of a training step: not taken
     if (g > ramnet::g_opt_pred_si_bwd_cap / nseg) g = ramnet::g_opt_pred_si_bwd_cap / nseg;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(pred_sigmoid_si_bwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, tg, stats, gscale, weight,

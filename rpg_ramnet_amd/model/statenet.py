@@ -87,13 +87,22 @@ class StateNetPhasedRecurrent(nn.Module):
                 x, enc_state = encoder(x), None
             else:
                 x, enc_state = encoder(x, prev_states_lstm['encoders'][i])
+            xc = x            # what the cell of this scale reads
+            if not feed_state_forward and enc_state is None and torch.is_grad_enabled() and ops.premask_relu_feature(x):
+                # training: the fan-in of x's gradient (cell + next encoder; autograd's own add otherwise) applies the encoder's ReLU mask,
+                # so that the encoder's backward launches read ONE plain operand (ops.set_relu_premask; as in the time-batched path)
+                if i + 1 < n:
+                    x, xc = ops.TimeFan.apply(x, 1, True)
+                else:
+                    (xc,) = ops.TimeSplit.apply(x, 1, True)
+                    x = xc
             if not feed_state_forward:
                 # RAM-Net: the shared state is updated; the ENCODER feature x feeds the next scale (statenet.py:215-237)
                 if branch and i < n - 1:
                     main, side = torch.cuda.current_stream(), ops.branch_stream(x.device, i)
                     side.wait_stream(main)                                  # x_i (and the state) are ready
                     with torch.cuda.stream(side):
-                        _, super_state = combs[i](x, prev_super_state[i], None if out is None else out[i])
+                        _, super_state = combs[i](xc, prev_super_state[i], None if out is None else out[i])
                     if not torch.cuda.is_current_stream_capturing():       # (a capture orders its private pool by the graph's own edges;
                         x.record_stream(side)                               # record_stream there left later captures crashing at replay)
                         for t in (prev_super_state[i] if isinstance(prev_super_state[i], (list, tuple)) else (prev_super_state[i],)):
@@ -102,7 +111,7 @@ class StateNetPhasedRecurrent(nn.Module):
                             t.record_stream(main)                           # consumed on the caller's stream after the join
                     joins.append(side)
                 else:
-                    _, super_state = combs[i](x, prev_super_state[i], None if out is None else out[i])       # convlstm: h and c both from the shared state
+                    _, super_state = combs[i](xc, prev_super_state[i], None if out is None else out[i])      # convlstm: h and c both from the shared state
                 state_comb = super_state
                 super_states.append(super_state)
             else:
