@@ -101,8 +101,9 @@ def parse():
     ap.add_argument("--wgrad-wino-nf", type=int, default=0, help="A/B: 32-channel output blocks per workgroup of the Winograd backward-weights kernel (1 or 2)")
     ap.add_argument("--wgrad-wino-blocks", type=int, default=0, help="A/B: workgroups per Winograd backward-weights launch (<= 384; default 384)")
     ap.add_argument("--wgrad-atomic", action="store_true", help="A/B: Winograd backward-weights splits meet by atomic adds instead of per-split slabs")
-    ap.add_argument("--wgrad-defer", type=int, default=-1, help="ConvGRU cell updates per deferred multi-segment backward-weights launch "
-                    "(ops.set_wgrad_defer; 0 = every update launches its own; default: the trainer's)")
+    ap.add_argument("--wgrad-defer", type=int, default=2, help="ConvGRU cell updates per deferred multi-segment backward-weights launch "
+                    "(ops.set_wgrad_defer; 0 = every update launches its own; 2 since round 6: 241.8 against 240.7 samples/s same-box, "
+                    "profiles/r06_h_tuning_notes.md section 6; round 5 measured 5 and more as losses)")
     ap.add_argument("--resident-inputs", action="store_true",
                     help="train: time the step on input tensors that are already resident in HBM (the definition of `value` up to round 4) "
                          "instead of the default, which voxelises fresh event lists and uploads frames / targets every step beside the compute "

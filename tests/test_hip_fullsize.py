@@ -29,13 +29,16 @@ def dev():
 
 @pytest.fixture
 def bench_schedule():
-    """bench.py's default schedule: backward-weights on a side stream, decoders on a second stream."""
+    """bench.py's default schedule: backward-weights on a side stream (the ConvGRU cells' launches in pairs of updates), decoders on a
+    second stream."""
     from rpg_ramnet_amd import ops
     ops.set_wgrad_overlap(True)
     ops.set_decoder_overlap(True)
+    ops.set_wgrad_defer(2)
     yield
     ops.set_wgrad_overlap(False)
     ops.set_decoder_overlap(False)
+    ops.set_wgrad_defer(0)
 
 
 @pytest.fixture(params=["f2x4", "f2x2"])
