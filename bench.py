@@ -227,6 +227,7 @@ HBM_CALLS = {
     "ramnet_gru_bwd_a2": lambda a: 28.0 * a[8] * a[7],     # (stage B runs in the epilogue of the candidate convolution's backward-data launch)
     "ramnet_gru_bwd_b": lambda a: 24.0 * a[6] * a[5],
     "ramnet_cat_batch_add": lambda a: 4.0 * a[1] * a[2] * a[3] * (3 if a[5] else 2),
+    "ramnet_cat_batch_add_masked": lambda a: 4.0 * a[1] * a[2] * a[3] * (4 if a[5] else 3),      # (+ the feature itself: its ReLU mask)
     "ramnet_pad2_sum": lambda a: 4.0 * a[6] * a[3] * ((2 if a[1] else 1) * a[4] * a[5] + (a[4] + 4) * (a[5] + 4)),
     "ramnet_relu_bwd": lambda a: 12.0 * a[3],
     "ramnet_unpad2_fold": lambda a: 4.0 * a[5] * a[2] * (a[3] * a[4] + (a[3] + 4) * (a[4] + 4)),
