@@ -688,8 +688,10 @@ __global__ void __launch_bounds__(1024) voxelize_sorted_kernel(const double *__r
         if (okr) atomicAdd(acc + cell + rw, (unsigned long long)__double2ll_rn((double)vr * VS_ONE));
     };
     const int4 *rg = rec + (size_t)g * rec_stride;
-    // (start, length) of this band's run in every chunk -> LDS behind the band: the walk then has ONE dependent memory round trip per stage
-    // (the records), requested a stage ahead of the votes (a workgroup holds its CU alone — 151 KB of LDS — so nothing else hides latency)
+    // This band's run in every chunk -> LDS behind the band: tl[2 w] = first record of the run in chunk w, tl[2 w + 1] = events of the band in the
+    // chunks before w (exclusive prefix; tl[2 nchunks + 1] = all of them).  The walk then goes over the band's events as ONE flat list, eight per
+    // thread and trip with their loads issued together (item j lies in the chunk a binary search of the prefixes names): two dependent memory round
+    // trips per workgroup — table, records — instead of one per four chunks with a third of the threads busy (round 6: 77 -> 66 us per 40 grids).
     int *tl = reinterpret_cast<int *>(band + cells);
     {
         const int *tg = tab + (size_t)g * nchunks * (nbands + 1) + bi;
@@ -699,30 +701,42 @@ __global__ void __launch_bounds__(1024) voxelize_sorted_kernel(const double *__r
         }
     }
     __syncthreads();
-    auto fetch = [&](int w0, int4 (&r)[4], int (&len)[4]) {
+    if (tid < 64) {                                   // exclusive scan of the run lengths, 64 chunks per trip of wave 0
+        int carry = 0;
+        for (int w0 = 0; w0 < nchunks; w0 += 64) {
+            const int w = w0 + tid;
+            const int len = w < nchunks ? tl[2 * w + 1] : 0;
+            int inc = len;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int w = w0 + u < nchunks ? w0 + u : nchunks - 1;
-            len[u] = w0 + u < nchunks ? tl[2 * w + 1] : 0;
-            r[u] = tid < len[u] ? rg[tl[2 * w] + tid] : make_int4(0, 0, 0, 0);
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(inc, o);
+                if (tid >= o) inc += up;
+            }
+            if (w < nchunks) tl[2 * w + 1] = carry + inc - len;
+            carry += __shfl(inc, 63);
         }
+        if (tid == 0) tl[2 * nchunks + 1] = carry;
+    }
+    __syncthreads();
+    const int total = tl[2 * nchunks + 1];
+    auto locate = [&](int j) {                        // record index of the band's j-th event
+        int lo = 0, hi = nchunks - 1;                 // the LAST chunk whose prefix is <= j: its run is not empty (a later prefix would be <= j too)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tl[2 * mid + 1] <= j) lo = mid; else hi = mid - 1;
+        }
+        return tl[2 * lo] + (j - tl[2 * lo + 1]);
     };
-    auto votes = [&](int w0, const int4 (&r)[4], const int (&len)[4]) {
+    for (int j0 = tid; j0 < total; j0 += 8 * 1024) {
+        int4 r[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (tid < len[u]) vote(r[u]);
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 1024;
+            r[u] = j < total ? rg[locate(j)] : make_int4(0, 0, 0, 0);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)                  // a band that holds more than 1024 events of a chunk (uneven event density)
-            for (int k = tid + 1024; k < len[u]; k += 1024) vote(rg[tl[2 * (w0 + u)] + k]);
-    };
-    int4 ra[4], rb[4];
-    int la[4], lb[4];
-    fetch(0, ra, la);
-    for (int w0 = 0; w0 < nchunks; w0 += 8) {
-        fetch(w0 + 4, rb, lb);
-        votes(w0, ra, la);
-        fetch(w0 + 8, ra, la);
-        votes(w0 + 4, rb, lb);
+        for (int u = 0; u < 8; ++u)
+            if (j0 + u * 1024 < total) vote(r[u]);
     }
     __syncthreads();
     float *grid = grids + (size_t)g * bins * plane;
