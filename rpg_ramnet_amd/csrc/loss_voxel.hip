@@ -600,13 +600,20 @@ __global__ void __launch_bounds__(1024) voxelize_bands_kernel(const double *__re
 constexpr int VS_CH = 8192;          // events per sort chunk: 1024 threads x 8
 constexpr double VS_ONE = 1099511627776.0;       // 2^40: fixed-point unit of the vote sums
 
-__global__ void __launch_bounds__(1024) voxel_sort_chunks_kernel(const double *__restrict__ ev, const long long *__restrict__ off, int W, int H,
+__global__ void __launch_bounds__(1024) voxel_sort_chunks_kernel(const double *__restrict__ ev, const long long *__restrict__ off, int bins, int W, int H,
                                                                  int rows, int nbands, int4 *__restrict__ rec, long long rec_stride,
                                                                  int *__restrict__ tab, int nchunks) {
     __shared__ int cnt[256];
     const int g = blockIdx.y, w = blockIdx.x, tid = threadIdx.x;
     const long long e0 = off[g], n = off[g + 1] - e0;
     const double2 *e2 = reinterpret_cast<const double2 *>(ev + (size_t)e0 * 4);
+    // voxel_vote_t()'s double arithmetic on t runs HERE (this pass waits for HBM; the second pass was bound by it: ~100 instructions per event,
+    // the division alone ~15): the record carries the bin code and the fp32 time fraction — the same operations in the same order, so the
+    // same cells get the same votes.  Bin code: -1 = no vote (t before the first timestamp, NaN), bins = past the last bin, else floor(ts).
+    const double t0 = n > 0 ? ev[(size_t)e0 * 4] : 0.0, t1 = n > 0 ? ev[((size_t)e0 + n - 1) * 4] : 0.0;
+    double dT = t1 - t0;
+    if (dT == 0.0) dT = 1.0;
+    const double scale = (double)(bins - 1), dbins = (double)bins;
     if (tid < 256) cnt[tid] = 0;
     __syncthreads();
     const long long j0 = (long long)w * VS_CH;
@@ -624,8 +631,11 @@ __global__ void __launch_bounds__(1024) voxel_sort_chunks_kernel(const double *_
         float pol = (float)yp.y;
         if (pol == 0.f) pol = -1.f;
         id[u] = inside ? ys / rows : 255;
-        const long long tb = __double_as_longlong(tx.x);
-        r[u] = make_int4((int)(tb & 0xffffffffll), (int)(tb >> 32), xs | (ys << 16), __float_as_int(pol));
+        const double ts = (scale * (tx.x - t0)) / dT;
+        const double tis = floor(ts);
+        const float dts = (float)(ts - tis);
+        const int tcode = !(tis >= 0.0) ? -1 : (tis < dbins ? (int)tis : bins);
+        r[u] = make_int4(tcode, __float_as_int(dts), xs | (ys << 16), __float_as_int(pol));
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) rank[u] = id[u] < 255 ? atomicAdd(&cnt[id[u]], 1) : 0;
@@ -666,23 +676,15 @@ __global__ void __launch_bounds__(1024) voxelize_sorted_kernel(const double *__r
     const int cells = bins * rows * W;
     for (int i = tid; i < cells; i += blockDim.x) band[i] = 0;
     const long long plane = (long long)W * H;
-    const double t0 = n > 0 ? e[0] : 0.0, t1 = n > 0 ? e[(n - 1) * 4] : 0.0;
-    // voxel_vote_t() on the record, with 32-bit index arithmetic: the same double operations on t (ts, floor, dt and the two fp32 votes are
-    // bit-identical), and the bin index converted only where voxel_vote_t's own guards (0 <= tis, tis [+ 1] < bins) hold — the same cells get
-    // the same votes; the 64-bit conversions and multiplications of the general form (~300 instructions per event) are what bound this pass
-    double dT = t1 - t0;
-    if (dT == 0.0) dT = 1.0;
-    const double scale = (double)(bins - 1), dbins = (double)bins;
+    // the votes of a record {bin code, fp32 time fraction, x | y << 16, polarity} (the first pass ran voxel_vote_t's double arithmetic on t):
+    // vl = pol (1 - dts) into bin code, vr = pol dts into the next one, under voxel_vote_t's own guards (0 <= tis, tis [+ 1] < bins)
     const int rw = rows * W;
     auto vote = [&](int4 r) {
-        const double t = __longlong_as_double(((long long)r.y << 32) | (unsigned long long)(unsigned)r.x);
-        const double ts = (scale * (t - t0)) / dT;
-        const double tis = floor(ts);
-        const float dts = (float)(ts - tis), pol = __int_as_float(r.w);
+        const int tc = r.x;
+        const float dts = __int_as_float(r.y), pol = __int_as_float(r.w);
         const float vl = pol * (1.0f - dts), vr = pol * dts;
-        const bool okl = tis < dbins && tis >= 0.0, okr = (tis + 1.0) < dbins && tis >= 0.0;
-        const int til = okl ? (int)tis : 0;
-        const int cell = til * rw + ((int)((unsigned)r.z >> 16) - y0) * W + (r.z & 0xffff);       // (bin * rows + y - y0) * W + x
+        const bool okl = tc >= 0 && tc < bins, okr = tc >= 0 && tc + 1 < bins;
+        const int cell = (okl ? tc : 0) * rw + ((int)((unsigned)r.z >> 16) - y0) * W + (r.z & 0xffff);       // (bin * rows + y - y0) * W + x
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(band);
         if (okl) atomicAdd(acc + cell, (unsigned long long)__double2ll_rn((double)vl * VS_ONE));
         if (okr) atomicAdd(acc + cell + rw, (unsigned long long)__double2ll_rn((double)vr * VS_ONE));
@@ -1026,7 +1028,7 @@ static int launch_voxel_bands(const double *events, const long long *offsets, lo
         if (scratch) {
             int4 *rec = reinterpret_cast<int4 *>(scratch);
             int *tab = reinterpret_cast<int *>(scratch + rec_bytes);
-            hipLaunchKernelGGL(voxel_sort_chunks_kernel, dim3(nchunks, n_grids), dim3(1024), 0, st, events, offsets, W, H, rows, nbands, rec, rstride,
+            hipLaunchKernelGGL(voxel_sort_chunks_kernel, dim3(nchunks, n_grids), dim3(1024), 0, st, events, offsets, bins, W, H, rows, nbands, rec, rstride,
                                tab, nchunks);
             RAMNET_FULL_LDS(voxelize_sorted_kernel);
             const size_t lds = (size_t)bins * rows * W * sizeof(long long) + (2 * nchunks + 16) * sizeof(int);
