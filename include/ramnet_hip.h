@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RAMNET_ABI_VERSION 24      /* 24: ramnet_cat_batch_add_masked (the gradient of a time-batched ReLU feature leaves its fan-in already masked); 23: ramnet_wgrad_desc.algo = RAMNET_ALGO_DIRECT_SPLIT (direct 3x3 backward-weights on the bf16 matrix pipe, split operands: csrc/conv_wgrad_dsplit.hip) + ramnet_wgrad_dsplit_slabs; 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
+#define RAMNET_ABI_VERSION 24      /* 24: ramnet_cat_batch_add_masked (the gradient of a time-batched ReLU feature leaves its fan-in already masked), ramnet_pred_sigmoid_si_bwd takes the forward's scratch (fixed-order join of the weight / bias partial sums); 23: ramnet_wgrad_desc.algo = RAMNET_ALGO_DIRECT_SPLIT (direct 3x3 backward-weights on the bf16 matrix pipe, split operands: csrc/conv_wgrad_dsplit.hip) + ramnet_wgrad_dsplit_slabs; 22: RAMNET_ALGO_WINOGRAD_2X4_SPLIT + ramnet_conv_wino_split_ok / ramnet_pack_weight_wino2x4_split (split bf16 operands on the F(2x4,3x3) forward / backward-data launches); 21: RAMNET_EPI_SIGMOID_HR (the ConvGRU gates launch also writes h.r: the candidate convolution and its backward-weights read a plain concatenation); 20 (never released on its own: shipped together with 21): ramnet_wgrad_desc.nseg / segs (multi-segment backward-weights launches: deferred ConvGRU cell updates); 19: ramnet_cat_batch_add (gradient of a time-batched feature); 18: RAMNET_EPI_GRU_BWD (stage B of the ConvGRU backward in the epilogue of the candidate convolution's backward-data launch) + ramnet_gru_bwd_a2; 17: ramnet_wgrad_desc.algo = RAMNET_ALGO_WINOGRAD_2X4 (F(2x4,3x3) backward-weights, csrc/conv_wgrad_wino6.hip) + ramnet_wgrad_wino2x4_slabs / ramnet_unpack_wgrad_wino2x4, option "wgrad_wino_nf"; 16: ramnet_conv_desc.splitk_ws / splitk_floats + ramnet_conv_splitk_floats (split channel reduction of latency-bound Winograd launches), option "wino_ksplit"; 15: ramnet_si_loss_from_stats (data-parallel exact loss), ramnet_si_log_loss_* / ramnet_mse_loss_*, ramnet_reflect_pad, ramnet_wgrad_desc.dw_slabs + ramnet_reduce_slabs, ramnet_set_option (environment knobs removed), fold weight-algebra kernels, RAMNET_ALGO_WINOGRAD_2X4 + ramnet_conv_wino_variant / ramnet_pack_weight_wino2x4; 14: ramnet_norm_* (BatchNorm / InstanceNorm); 13: pair layout of ramnet_pack_weight_fold_wino, head kernel for 10 input channels */
 #define RAMNET_E_BADARG 10001
 #define RAMNET_E_UNSUPPORTED 10002
 
@@ -186,7 +186,7 @@ typedef struct ramnet_wgrad_desc {
  * launches with a backward-data chain on another stream wants (training step 217 vs 211 samples/s) —
  * "wino_ksplit" (1 = the library's heuristic; 0 = ramnet_conv_splitk_floats answers 0: no launch splits its reduction; 2..16 = that many
  * splits for every launch whose epilogue can join partials: tuning runs).
- * "pred_si_cap" (256) / "pred_si_bwd_cap" (512): workgroups per launch, over all segments, of ramnet_pred_sigmoid_si_fwd / _bwd (every
+ * "pred_si_cap" (256) / "pred_si_bwd_cap" (1024): workgroups per launch, over all segments, of ramnet_pred_sigmoid_si_fwd / _bwd (every
  * workgroup ends on per-segment atomics: tools/bench_pred_si.py has the sweep); ramnet_pred_si_scratch_doubles follows the option, so set it
  * before sizing the scratch.
  * ramnet_get_option: -1 if unknown.  */
@@ -325,7 +325,9 @@ int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, cons
  * = the seg_pix target values of segment i (NaN = invalid).  fwd: y as ramnet_pred_sigmoid_fwd, stats[i][0..3] = (sum d, sum d^2, n, 0) in
  * double, loss[i] = weight * (mean d^2 - lambda * mean(d)^2); scratch = ramnet_pred_si_scratch_doubles(seg_pix, nseg) doubles, ZERO before the
  * first use (the kernel leaves the tickets at zero; the partial sums are joined in a fixed order: bit-reproducible).  bwd: the gradient of
- * sum_i gscale[i] * loss[i] (+ dy . y when dy != NULL) w.r.t. x, w and b — ramnet_si_loss_bwd and ramnet_pred_sigmoid_bwd in one pass. */
+ * sum_i gscale[i] * loss[i] (+ dy . y when dy != NULL) w.r.t. x, w and b — ramnet_si_loss_bwd and ramnet_pred_sigmoid_bwd in one pass.  Its `scratch`
+ * (ABI 24) = the buffer the forward launch used (same size, the options unchanged in between; its tail — the tickets — still zero): the workgroups' partial sums
+ * of dw / db are joined in a fixed order — bit-reproducible — by the last workgroup to arrive; NULL = fp32 atomics (arrival order = the last digits). */
 #define RAMNET_PRED_SI_MAX_SEGMENTS 8
 size_t ramnet_pred_si_scratch_doubles(size_t seg_pix, int nseg);
 int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t seg_pix, int nseg,
@@ -333,7 +335,7 @@ int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, c
                                void *stream);
 int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, size_t seg_pix, int nseg,
                                const float *const *targets, const double *stats, const float *gscale, float weight, float lambda,
-                               float *dx, int lddx, float *dw, float *db, void *stream);
+                               float *dx, int lddx, float *dw, float *db, double *scratch, void *stream);
 /* The same layer WITHOUT the sigmoid (a normalisation follows: `norm` BN / IN, submodules.py:29-33): z = conv1x1(x) [+ b] (b may be
  * NULL) and its backward dx = dz*w, dw += sum dz*x, db += sum dz (db may be NULL).                                       */
 int ramnet_pred_linear_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *z, size_t npix, void *stream);

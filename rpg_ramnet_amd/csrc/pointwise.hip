@@ -447,11 +447,21 @@ __global__ void __launch_bounds__(PRED_SI_THREADS) pred_sigmoid_si_fwd_kernel(co
 __global__ void pred_sigmoid_si_bwd_kernel(const float *__restrict__ x, int ldx, int C, const float *__restrict__ w, const float *__restrict__ y,
                                            const float *__restrict__ dy, PredSiTargets tg, const double *__restrict__ stats,
                                            const float *__restrict__ gscale, float weight, float lambda, float *__restrict__ dx, int lddx,
-                                           float *__restrict__ dw, float *__restrict__ db, size_t seg_pix) {
+                                           float *__restrict__ dw, float *__restrict__ db, size_t seg_pix, float *__restrict__ part, int ldp,
+                                           unsigned long long *__restrict__ ticket) {
+    // part != NULL (round 6): every workgroup leaves its C + 1 partial sums in part[workgroup][ldp] and the LAST one to arrive (ticket) adds them
+    // in a fixed order into dw / db — bit-reproducible weight and bias gradients (the bias gradient is a sum of ~1e6 terms that cancels to ~1e-6
+    // of their size: with fp32 atomics its last digits depended on the arrival order) and no 33 contended atomics per workgroup, so the launch
+    // can have the 1024 workgroups its loads want.  part == NULL: fp32 atomics as before.
     __shared__ float red[32 * 4 * 8 + 32];
+    __shared__ int is_last;
     const int sub = threadIdx.x & 7, slot = threadIdx.x >> 3, seg = blockIdx.y;
     const size_t stride = (size_t)gridDim.x * (blockDim.x / 8), base = (size_t)seg * seg_pix;
     const float *__restrict__ tgt = tg.t[seg];
+    constexpr int AUX_SC1 = 16;                                 // device-scope cache policy of the buffer accesses to `part`
+    const bool row = part != nullptr;
+    const int nwg = (int)(gridDim.x * gridDim.y), rowi = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const auto prs = wino_rsrc(part, part ? (unsigned)((size_t)nwg * ldp * 4) : 0u);
     const double cnt = stats[seg * 4 + 2], mean = stats[seg * 4] / cnt;
     const double s2 = 2.0 * (double)(gscale[seg] * weight) / cnt, lm = (double)lambda * mean;
     float4 dwp[4] = {f4zero(), f4zero(), f4zero(), f4zero()};   // C <= 128
@@ -499,7 +509,10 @@ __global__ void pred_sigmoid_si_bwd_kernel(const float *__restrict__ x, int ldx,
             const int c = k * 32 + threadIdx.x;
             float s = 0.f;
             for (int g = 0; g < 32; ++g) s += red[g * 32 + threadIdx.x];
-            if (c < C) atomicAdd(dw + c, s);
+            if (c < C) {
+                if (row) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), prs, (int)((rowi * ldp + c) * 4), 0, AUX_SC1);
+                else atomicAdd(dw + c, s);
+            }
         }
     }
     __syncthreads();
@@ -508,7 +521,61 @@ __global__ void pred_sigmoid_si_bwd_kernel(const float *__restrict__ x, int ldx,
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int g = 0; g < 32; ++g) s += red[g];
-        if (db) atomicAdd(db, s);
+        if (row) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), prs, (int)((rowi * ldp + C) * 4), 0, AUX_SC1);
+        else if (db) atomicAdd(db, s);
+    }
+    if (!part) return;
+    // (device-scope stores above, a WORKGROUP-scope release = the waves wait for their stores, a relaxed device-scope ticket: no cache maintenance —
+    // an agent-scope fence here writes back the L2 of the workgroup's XCD, dirty with its dx rows: 135 ns per workgroup, serialised; csrc/conv_wino.hip
+    // joins its split reductions the same way)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // two levels of tickets — groups of 32 workgroups (ticket[1 + group]), then the groups' last arrivals (ticket[0]): same-address atomics with
+        // a return value are served one at a time (~27 ns each: 28 us of a 75 us launch with ONE ticket for 1024 workgroups)
+        const int grp = rowi >> 5, ngrp = (nwg + 31) >> 5, gsize = grp == ngrp - 1 ? nwg - 32 * (ngrp - 1) : 32;
+        int last = 0;
+        if (__hip_atomic_fetch_add(ticket + 1 + grp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gsize - 1) {
+            __hip_atomic_store(ticket + 1 + grp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)ngrp - 1) {
+                __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // the last workgroup: thread (row lane rl = tid / 16, group = tid % 16) sums rows rl, rl + 16, ... of one 16-byte column group — device-scope
+    // buffer loads, 64 independent ones per thread at 1024 workgroups (relaxed atomic loads were issued one at a time: 282 us instead of 75) —,
+    // then the 16 row lanes of a group are added in order 0..15: a fixed assignment and a fixed order, whatever order the workgroups arrived in
+    const int ngroups = (C + 4) / 4, rl = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    for (int g0 = 0; g0 < ngroups; g0 += 16) {
+        const int gi = g0 + gl;
+        float4 acc = f4zero();
+        if (gi < ngroups)
+            for (int i = rl; i < nwg; i += 16 * 8) {            // eight rows requested together (a row past the buffer reads as zero), added in row order
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(prs, ((i + 16 * u) * ldp + gi * 4) * 4, 0, AUX_SC1));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = f4add(acc, v[u]);
+            }
+        __syncthreads();
+        st4(red + (rl * 16 + gl) * 4, acc);
+        __syncthreads();
+        if (rl == 0 && gi < ngroups) {
+            float4 t = ld4(red + gl * 4);
+            for (int r = 1; r < 16; ++r) t = f4add(t, ld4(red + (r * 16 + gl) * 4));
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = gi * 4 + e;
+                if (c < C) dw[c] += tv[e];
+                else if (c == C && db) db[0] += tv[e];
+            }
+        }
     }
 }
 
@@ -831,7 +898,7 @@ extern "C" int ramnet_abi_version(void) { return RAMNET_ABI_VERSION; }
 
 // Process-wide A/B options (tests and tuning runs; the environment variables they replace are gone since round 4)
 namespace ramnet {
-int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1, g_opt_pred_si_cap = 256, g_opt_pred_si_bwd_cap = 512;
+int g_opt_voxel_sorted = 1, g_opt_fold_pair = 1, g_opt_wgrad_blocks = 512, g_opt_wgrad_wino_blocks = 384, g_opt_wino_ksplit = 1, g_opt_wgrad_wino_nf = 1, g_opt_pred_si_cap = 256, g_opt_pred_si_bwd_cap = 1024;
 }
 extern "C" int ramnet_set_option(const char *name, int value) {
     RAMNET_CHECK_ARG(name != nullptr);
@@ -1026,9 +1093,15 @@ static int pred_si_grid(size_t seg_pix, int nseg) {
     return g < 1 ? 1 : (int)g;
 }
 
+constexpr int PRED_SI_BWD_LDP = 132;       // floats per workgroup row of the backward launch's partial sums (C <= 128 weights + the bias, 16-byte rows)
+static size_t pred_si_bwd_tickets() { return 1 + ((size_t)ramnet::g_opt_pred_si_bwd_cap + 31) / 32; }      // [0]: the groups' last arrivals, [1 + g]: group g of 32 workgroups
+static size_t pred_si_bwd_doubles() { return ((size_t)ramnet::g_opt_pred_si_bwd_cap * PRED_SI_BWD_LDP + 1) / 2; }
 extern "C" size_t ramnet_pred_si_scratch_doubles(size_t seg_pix, int nseg) {
-    // [nseg][workgroups][3] partial sums + [nseg] tickets (zero before the first use; the kernel leaves them at zero)
-    return nseg > 0 ? (size_t)nseg * pred_si_grid(seg_pix, nseg) * 3 + nseg : 0;
+    // forward: [nseg][workgroups][3] partial sums + [nseg] tickets (zero before the first use; the kernel leaves them at zero); the backward launch
+    // reuses the buffer: [workgroups][132] fp32 partial sums of the weight / bias gradients, its tickets in the LAST doubles (never touched by the forward)
+    if (nseg <= 0) return 0;
+    const size_t fwd = (size_t)nseg * pred_si_grid(seg_pix, nseg) * 3 + nseg, bwd = pred_si_bwd_doubles();
+    return (fwd > bwd ? fwd : bwd) + pred_si_bwd_tickets();
 }
 
 extern "C" int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t seg_pix, int nseg,
@@ -1048,7 +1121,7 @@ extern "C" int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const 
 
 extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, size_t seg_pix, int nseg,
                                           const float *const *targets, const double *stats, const float *gscale, float weight, float lambda,
-                                          float *dx, int lddx, float *dw, float *db, void *stream) {
+                                          float *dx, int lddx, float *dw, float *db, double *scratch, void *stream) {
     RAMNET_CHECK_ARG(x && w && y && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0 && seg_pix > 0);
     RAMNET_CHECK_ARG(nseg >= 1 && nseg <= RAMNET_PRED_SI_MAX_SEGMENTS && targets && stats && gscale);
     if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
@@ -1056,13 +1129,17 @@ extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const 
     for (int i = 0; i < RAMNET_PRED_SI_MAX_SEGMENTS; ++i) tg.t[i] = i < nseg ? targets[i] : nullptr;
     for (int i = 0; i < nseg; ++i) RAMNET_CHECK_ARG(tg.t[i] != nullptr);
     int g = grid_for(seg_pix * 8);
-    // every workgroup ends with 33 fp32 atomics on the SAME 33 addresses: few, fat workgroups.  "pred_si_bwd_cap" = 512 in all: 87.5 us; 1024
-    // would be 74.5 us (0.62 of the HBM peak; 2048 79.8, 256 146.8: tools/bench_pred_si.py) but doubles the summation-order noise of the bias
-    // gradient — a sum of 1.4 M terms that cancels to ~1e-6 of them — for 0.05 % of a training step: not taken
-    if (g > ramnet::g_opt_pred_si_bwd_cap / nseg) g = ramnet::g_opt_pred_si_bwd_cap / nseg;
+    // workgroups over all segments: "pred_si_bwd_cap" (1024: 74.5 us for 1.41 M pixels x 32 channels, 0.62 of the HBM peak; 512 87.5, 2048 79.8, 256
+    // 146.8: tools/bench_pred_si.py) when the partial sums are joined through `scratch`; without it every workgroup ends with 33 fp32 atomics on the
+    // SAME 33 addresses and their arrival order is the noise of the bias gradient: at most 512 then
+    const int cap = scratch ? ramnet::g_opt_pred_si_bwd_cap : (ramnet::g_opt_pred_si_bwd_cap < 512 ? ramnet::g_opt_pred_si_bwd_cap : 512);
+    if (g > cap / nseg) g = cap / nseg;
     if (g < 1) g = 1;
+    // scratch = the forward launch's buffer (ramnet_pred_si_scratch_doubles doubles, its last one zero): fixed-order join of the partial sums
+    float *part = reinterpret_cast<float *>(scratch);
+    unsigned long long *ticket = scratch ? reinterpret_cast<unsigned long long *>(scratch + ramnet_pred_si_scratch_doubles(seg_pix, nseg) - pred_si_bwd_tickets()) : nullptr;
     hipLaunchKernelGGL(pred_sigmoid_si_bwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, tg, stats, gscale, weight,
-                       lambda, dx, lddx, dw, db, seg_pix);
+                       lambda, dx, lddx, dw, db, seg_pix, part, PRED_SI_BWD_LDP, ticket);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

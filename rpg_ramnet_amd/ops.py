@@ -2053,15 +2053,15 @@ class PredSigmoidSI(Function):
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in tg])
         H.check(L.ramnet_pred_sigmoid_si_fwd(_p(x), ld(x), Cc, _p(w.detach()), _p(b.detach()), _p(y), seg_pix, n, arr, weight, n_lambda,
                                              _p(scratch), _p(stats), _p(loss), _st()), "pred_si_fwd")
-        ctx.save_for_backward(x, w, b, y, stats, *tg)
+        ctx.save_for_backward(x, w, b, y, stats, scratch, *tg)      # (scratch: the backward launch joins its partial sums through it)
         ctx.meta = (weight, n_lambda, n, seg_pix)
         ctx.set_materialize_grads(False)
         return (y,) + tuple(loss[i] for i in range(n))
 
     @staticmethod
     def backward(ctx, dy, *dloss):
-        x, w, b, y, stats = ctx.saved_tensors[:5]
-        tg = ctx.saved_tensors[5:]
+        x, w, b, y, stats, scratch = ctx.saved_tensors[:6]
+        tg = ctx.saved_tensors[6:]
         weight, n_lambda, n, seg_pix = ctx.meta
         B, Hh, W, Cc = x.shape
         dy = dy.contiguous() if dy is not None else None
@@ -2072,7 +2072,7 @@ class PredSigmoidSI(Function):
         dx = torch.empty(B, Hh, W, Cc, device=x.device) if ctx.needs_input_grad[0] else None
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in tg])
         H.check(H.lib().ramnet_pred_sigmoid_si_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), seg_pix, n, arr, _p(stats), _p(gs), weight,
-                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _st()), "pred_si_bwd")
+                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _p(scratch), _st()), "pred_si_bwd")
         return (dx, None, None, None, None) + (None,) * n
 
 

@@ -947,6 +947,50 @@ def test_time_fan_gradient_kernel_with_relu_mask(n, B, H, W, C, wide):
     assert torch.equal(x.grad, torch.where(keep, g_all, zero))
 
 
+@pytest.mark.parametrize("B,H,W,C,n", [(4, 64, 96, 32, 2), (2, 33, 47, 32, 1), (6, 16, 24, 64, 3)])
+def test_pred_sigmoid_si_matches_torch_and_is_bit_reproducible(B, H, W, C, n):
+    """ops.PredSigmoidSI (prediction layer + scale-invariant loss of its n batch segments in the layer's own launches, statenet.py:313 +
+    model/loss.py:6-9) against plain torch in float64 — losses, dx, dw, db — and, ABI 24: the weight / bias gradients are joined in a fixed
+    order through the forward's scratch, so two backward passes give the same bits (the bias gradient is a cancelling sum: with fp32 atomics
+    its last digits followed the arrival order of the workgroups)."""
+    from rpg_ramnet_amd import ops
+    torch.manual_seed(B + C)
+    x0 = torch.randn(B, H, W, C, device=dev())
+    w0 = (torch.randn(1, C, 1, 1, device=dev()) * 0.2)
+    b0 = torch.randn(1, device=dev()) * 0.1
+    tg = [torch.rand(B // n, 1, H, W, device=dev()) for _ in range(n)]
+    tg[0][0, 0, :3, :5] = float("nan")
+    dyv = torch.randn(B, 1, H, W, device=dev()) * 1e-3
+    coef = [0.7 + 0.3 * i for i in range(n)]
+
+    def run():
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = ops.PredSigmoidSI.apply(x, w, b, 1.0, 0.85, *tg)
+        total = sum(c * l for c, l in zip(coef, out[1:])) + (out[0] * dyv).sum()
+        total.backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out], x.grad.clone(), w.grad.clone(), b.grad.clone()
+
+    o1, dx1, dw1, db1 = run()
+    o2, dx2, dw2, db2 = run()
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2) and torch.equal(dx1, dx2) and all(torch.equal(a, c) for a, c in zip(o1, o2))
+    # float64 torch
+    x, w, b = x0.double().requires_grad_(True), w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    y = torch.sigmoid((x * w.view(1, 1, 1, C)).sum(-1, keepdim=True) + b).permute(0, 3, 1, 2)
+    losses = []
+    for i in range(n):
+        d = y[i * (B // n):(i + 1) * (B // n)] - tg[i].double()
+        d = d[~torch.isnan(d)]
+        losses.append((d ** 2).mean() - 0.85 * d.mean() ** 2)
+    (sum(c * l for c, l in zip(coef, losses)) + (y * dyv.double()).sum()).backward()
+    assert_close(o1[0].cpu().numpy(), y.detach().cpu().numpy(), 1e-5, "prediction")
+    for i in range(n):
+        assert abs(float(o1[1 + i]) - float(losses[i])) <= 1e-5 * abs(float(losses[i])), "loss %d" % i
+    assert_close(dx1.cpu().numpy(), x.grad.cpu().numpy(), 2e-4, "dx")
+    assert_close(dw1.cpu().numpy().reshape(-1), w.grad.cpu().numpy().reshape(-1), 2e-4, "dw")
+    assert abs(float(db1) - float(b.grad)) <= 2e-4 * float(x.grad.abs().sum() / C), "db (against the size of its terms)"
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 8, 16, 64), (1, 7, 13, 32), (2, 4, 43, 256)])
 def test_conv_lstm(B, H, W, C):
     from rpg_ramnet_amd.model.submodules import ConvLSTM

@@ -80,14 +80,18 @@ def main():
     dw, db, gs = torch.zeros(Cc, device=dev), torch.zeros(1, device=dev), torch.ones(n, device=dev)
     for cap in [64, 128, 256, 512, 1024, 2048, 4096]:
         H.check(L.ramnet_set_option(b"pred_si_bwd_cap", cap), "set_option")
-        for with_dy in (False, True):
+        scratch_b = torch.zeros(L.ramnet_pred_si_scratch_doubles(seg_pix, n), device=dev, dtype=torch.float64)
+        for joined in (False, True):
+            with_dy = True
+
             def rawb():
                 H.check(L.ramnet_pred_sigmoid_si_bwd(xd.data_ptr(), Cc, Cc, wd.data_ptr(), y.data_ptr(), dy.data_ptr() if with_dy else None, seg_pix, n, arr,
-                                                     stats.data_ptr(), gs.data_ptr(), 1.0, 0.5, dx.data_ptr(), Cc, dw.data_ptr(), db.data_ptr(), st), "rawb")
+                                                     stats.data_ptr(), gs.data_ptr(), 1.0, 0.5, dx.data_ptr(), Cc, dw.data_ptr(), db.data_ptr(),
+                                                     scratch_b.data_ptr() if joined else None, st), "rawb")
             t = timeit(rawb, 200)
             nb = B * Hh * W * 4 * (2 * Cc + 2 + (1 if with_dy else 0))
-            print("bwd cap %6d dy=%d: raw launch %7.1f us (%.3f of 8 TB/s)" % (cap, with_dy, t, nb / t / 8e6))
-    H.check(L.ramnet_set_option(b"pred_si_bwd_cap", 512), "set_option")
+            print("bwd cap %6d %s: raw launch %7.1f us (%.3f of 8 TB/s)" % (cap, "joined through scratch" if joined else "fp32 atomics (<= 512 workgroups)", t, nb / t / 8e6))
+    H.check(L.ramnet_set_option(b"pred_si_bwd_cap", 1024), "set_option")
     out = f()
     loss = out[1] + out[2]
     t_bwd = timeit(lambda: torch.autograd.grad(loss, x, retain_graph=True))
