@@ -950,7 +950,7 @@ def test_time_fan_gradient_kernel_with_relu_mask(n, B, H, W, C, wide):
 @pytest.mark.parametrize("B,C,H,W", [(3, 5, 16, 24), (2, 5, 7, 9), (2, 1, 16, 24), (2, 10, 8, 12), (1, 8, 4, 4), (40, 5, 64, 88)])
 def test_pack_input_is_the_padded_channels_last_copy(B, C, H, W):
     """ops.pack_input (model.py:177,200: the model's NCHW input -> NHWC with channels zero-padded to a multiple of 4): every layout of the
-    repack kernels (one pixel per thread; four pixels per thread for the 8-channel event grids when H * W % 4 == 0) against torch, bit for bit."""
+    repack kernel against torch, bit for bit."""
     from rpg_ramnet_amd import ops
     torch.manual_seed(C)
     x = torch.randn(B, C, H, W, device=dev())
