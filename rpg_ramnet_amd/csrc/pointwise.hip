@@ -95,24 +95,6 @@ __global__ void nchw_to_nhwc_pad_kernel(const float *__restrict__ src, float *__
     }
 }
 
-// The same for Cpad = 8 (C <= 8: the 5-bin event grids), FOUR consecutive pixels per thread: one 16-byte load per channel, eight 16-byte stores
-// = 128 contiguous bytes per thread (round 6: the one-pixel form moved 4-byte loads and half-line stores: 0.50 of the HBM peak)
-__global__ void nchw_to_nhwc8_x4_kernel(const float *__restrict__ src, float *__restrict__ dst, int B, int C, int HW) {
-    const size_t nq = (size_t)B * HW / 4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nq; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / (HW / 4), s = (i - b * (HW / 4)) * 4;
-        const float *in = src + b * C * HW + s;
-        float4 v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = c < C ? ld4(in + (size_t)c * HW) : f4zero();
-        float *out = dst + (b * HW + s) * 8;
-        st4(out + 0, make_float4(v[0].x, v[1].x, v[2].x, v[3].x)), st4(out + 4, make_float4(v[4].x, v[5].x, v[6].x, v[7].x));
-        st4(out + 8, make_float4(v[0].y, v[1].y, v[2].y, v[3].y)), st4(out + 12, make_float4(v[4].y, v[5].y, v[6].y, v[7].y));
-        st4(out + 16, make_float4(v[0].z, v[1].z, v[2].z, v[3].z)), st4(out + 20, make_float4(v[4].z, v[5].z, v[6].z, v[7].z));
-        st4(out + 24, make_float4(v[0].w, v[1].w, v[2].w, v[3].w)), st4(out + 28, make_float4(v[4].w, v[5].w, v[6].w, v[7].w));
-    }
-}
-
 // Full-frame mode (utils/inference_utils.py:287-314 CropParameters: ReflectionPad2d to the next multiple of 2^num_encoders): the model
 // input [B][C][H][W] is reflect-padded to [Hc][Wc] (top / left = ceil of half the excess) WHILE it is repacked — NHWC with channels
 // zero-padded to Cpad (nhwc = 1, the model's input repack) or NCHW (CropParameters.pad).  Reflection without the border pixel:
@@ -947,11 +929,6 @@ extern "C" int ramnet_get_option(const char *name) {
 extern "C" int ramnet_nchw_to_nhwc_pad(const float *src, float *dst, int B, int C, int H, int W, int Cpad, void *stream) {
     RAMNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 4 == 0);
     const size_t npix = (size_t)B * H * W;
-    if (Cpad == 8 && (H * W) % 4 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {      // the event grids (5 or 10 -> 8 / 12 channels: 8 here)
-        hipLaunchKernelGGL(nchw_to_nhwc8_x4_kernel, dim3(grid_for(npix / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H * W);
-        RAMNET_LAUNCH_CHECK();
-        return 0;
-    }
     hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H * W, Cpad);
     RAMNET_LAUNCH_CHECK();
     return 0;
