@@ -415,18 +415,28 @@ __global__ void __launch_bounds__(PRED_SI_THREADS) pred_sigmoid_si_fwd_kernel(co
         for (int i = 0; i < NW; i += 2) a += red[k][i] + red[k][i + 1];
         return a;
     };
-    double *mine = part + ((size_t)seg * gridDim.x) * 3;
+    // The partial sums travel as device-scope (sc1) buffer accesses behind a WORKGROUP-scope release and a relaxed device-scope ticket: no cache
+    // maintenance (round 6: the agent-scope __threadfence() in front of the ticket wrote back the L2 of the workgroup's XCD — what the "27 ns per
+    // workgroup" of the workgroup sweep was; the backward launch's join measured the same thing at 135 ns with its dx rows dirty in the cache)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int AUX_SC1 = 16;
+    const auto prs = wino_rsrc(part + ((size_t)seg * gridDim.x) * 3, (unsigned)(gridDim.x * 3 * sizeof(double)));
     if (threadIdx.x == 0) {
-        for (int k = 0; k < 3; ++k) mine[blockIdx.x * 3 + k] = fold(k);
-        __threadfence();                                        // the partials are visible before the ticket
-        is_last = atomicAdd(ticket + seg, 1ull) == (unsigned long long)gridDim.x - 1;
+        for (int k = 0; k < 3; ++k)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, fold(k)), prs, (int)((blockIdx.x * 3 + k) * 8), 0, AUX_SC1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const unsigned long long arrived = __hip_atomic_fetch_add(ticket + seg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = arrived == (unsigned long long)gridDim.x - 1;
+        if (is_last) __hip_atomic_store(ticket + seg, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     double v[3] = {0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)         // (fixed assignment of partials to threads: a fixed order)
-        for (int k = 0; k < 3; ++k) v[k] += __hip_atomic_load(mine + i * 3 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {       // (fixed assignment of partials to threads: a fixed order)
+        double t[3];
+        for (int k = 0; k < 3; ++k) t[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(prs, (i * 3 + k) * 8, 0, AUX_SC1));
+        for (int k = 0; k < 3; ++k) v[k] += t[k];
+    }
     for (int k = 0; k < 3; ++k) v[k] = pw_wave_sum(v[k]);
     __syncthreads();
     if (lane == 0) red[0][wave] = v[0], red[1][wave] = v[1], red[2][wave] = v[2];
@@ -437,7 +447,6 @@ __global__ void __launch_bounds__(PRED_SI_THREADS) pred_sigmoid_si_fwd_kernel(co
         stats[seg * 4 + 3] = 0.0;
         const double m = S[0] / S[2];
         loss[seg] = (float)((double)weight * (S[1] / S[2] - (double)lambda * m * m));
-        atomicExch(ticket + seg, 0ull);
     }
 }
 
@@ -1080,10 +1089,10 @@ extern "C" int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const flo
     return pred_bwd(x, ldx, C, w, y, dy, dx, lddx, dw, db, npix, stream);
 }
 static int pred_si_grid(size_t seg_pix, int nseg) {
-    // Workgroups per segment: at most "pred_si_cap" (256 = one per CU) over all segments — every workgroup ends with a fence and a ticket
-    // atomic on ONE address per segment, ~27 ns each and serialised: 1.41 M pixels x 32 channels take 37.5 us with 256 workgroups (0.64 of
-    // the HBM peak), 43.9 with 512, 58.3 with 1024 (the round-5 default), 86.7 with 2048; 53.6 with 128 (tools/bench_pred_si.py) — and a count
-    // that gives every 8-lane group the SAME number of 8-pixel trips (a ragged last trip left a third of the chip idle)
+    // Workgroups per segment: at most "pred_si_cap" (256 = one per CU) over all segments: 1.41 M pixels x 32 channels take 32.2 us with 256 or 512
+    // workgroups (0.745 of the HBM peak), 35.7 with 1024, 50.3 with 128 (tools/bench_pred_si.py; with an agent-scope fence in front of every
+    // workgroup's ticket it was 37.5 / 43.9 / 58.3: profiles/r06_h_tuning_notes.md sections 5 and 10) — and a count that gives every 8-lane group
+    // the SAME number of 8-pixel trips (a ragged last trip left a third of the chip idle)
     const size_t groups = (seg_pix + 7) / 8;
     const size_t cap = (size_t)ramnet::g_opt_pred_si_cap / (size_t)(nseg > 0 ? nseg : 1);
     constexpr size_t GPW = PRED_SI_THREADS / 8;                 // 8-lane groups per workgroup

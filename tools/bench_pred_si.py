@@ -27,7 +27,7 @@ def timeit(fn, reps=50):
 
 def main():
     dev = torch.device("cuda:0")
-    caps = [int(a) for a in sys.argv[1:]] or [128, 256, 512, 1024, 2048]
+    caps = [int(a) for a in sys.argv[1:]] or [128, 256, 512, 1024, 2048, 4096]
     B, Hh, W, Cc, n = 16, 256, 344, 32, 2
     torch.manual_seed(0)
     x = torch.randn(B, Hh, W, Cc, device=dev, requires_grad=True)
