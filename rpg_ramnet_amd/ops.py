@@ -2071,8 +2071,11 @@ class PredSigmoidSI(Function):
             gs = torch.stack([g.float().reshape(()) if g is not None else torch.zeros((), device=x.device) for g in dloss])
         dx = torch.empty(B, Hh, W, Cc, device=x.device) if ctx.needs_input_grad[0] else None
         arr = (C.c_void_p * n)(*[t.data_ptr() for t in tg])
+        # the fixed-order join of the weight / bias partial sums runs through the forward's scratch; its layout follows the library options
+        # ("pred_si_cap" / "pred_si_bwd_cap"): had they changed since the forward pass, fall back to the atomic form instead of a wrong layout
+        join = scratch.numel() == H.lib().ramnet_pred_si_scratch_doubles(seg_pix, n)
         H.check(H.lib().ramnet_pred_sigmoid_si_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), seg_pix, n, arr, _p(stats), _p(gs), weight,
-                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _p(scratch), _st()), "pred_si_bwd")
+                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _p(scratch) if join else None, _st()), "pred_si_bwd")
         return (dx, None, None, None, None) + (None,) * n
 
 
