@@ -327,7 +327,9 @@ int ramnet_pred_sigmoid_bwd(const float *x, int ldx, int C, const float *w, cons
  * first use (the kernel leaves the tickets at zero; the partial sums are joined in a fixed order: bit-reproducible).  bwd: the gradient of
  * sum_i gscale[i] * loss[i] (+ dy . y when dy != NULL) w.r.t. x, w and b — ramnet_si_loss_bwd and ramnet_pred_sigmoid_bwd in one pass.  Its `scratch`
  * (ABI 24) = the buffer the forward launch used (same size, the options unchanged in between; its tail — the tickets — still zero): the workgroups' partial sums
- * of dw / db are joined in a fixed order — bit-reproducible — by the last workgroup to arrive; NULL = fp32 atomics (arrival order = the last digits). */
+ * of dw / db are joined in a fixed order — bit-reproducible — by the last workgroup to arrive; NULL = fp32 atomics (arrival order = the last digits).
+ * mask_x != 0 (ABI 24): dx = dz w (x > 0) — x is the output of a ReLU layer whose only consumer this is (statenet.py:305-313: the last decoder), and its
+ * backward receives the gradient already masked. */
 #define RAMNET_PRED_SI_MAX_SEGMENTS 8
 size_t ramnet_pred_si_scratch_doubles(size_t seg_pix, int nseg);
 int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *y, size_t seg_pix, int nseg,
@@ -335,7 +337,7 @@ int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const float *w, c
                                void *stream);
 int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, size_t seg_pix, int nseg,
                                const float *const *targets, const double *stats, const float *gscale, float weight, float lambda,
-                               float *dx, int lddx, float *dw, float *db, double *scratch, void *stream);
+                               float *dx, int lddx, float *dw, float *db, double *scratch, int mask_x, void *stream);
 /* The same layer WITHOUT the sigmoid (a normalisation follows: `norm` BN / IN, submodules.py:29-33): z = conv1x1(x) [+ b] (b may be
  * NULL) and its backward dx = dz*w, dw += sum dz*x, db += sum dz (db may be NULL).                                       */
 int ramnet_pred_linear_fwd(const float *x, int ldx, int C, const float *w, const float *b, float *z, size_t npix, void *stream);

@@ -125,7 +125,7 @@ _SIGS = {
     "ramnet_pred_sigmoid_si_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float,
                                              _fp, _fp, _fp, _fp]),
     "ramnet_pred_sigmoid_si_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), _fp, _fp, C.c_float,
-                                             C.c_float, _fp, C.c_int, _fp, _fp, _fp, _fp]),
+                                             C.c_float, _fp, C.c_int, _fp, _fp, _fp, C.c_int, _fp]),
     "ramnet_pred_linear_fwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_pred_linear_bwd": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp, C.c_int, _fp, _fp, C.c_size_t, _fp]),
     "ramnet_cat_batch_add": (C.c_int, [_fp, C.c_int, C.c_size_t, C.c_int, C.c_int, _fp, _fp, _fp]),

@@ -457,7 +457,9 @@ __global__ void pred_sigmoid_si_bwd_kernel(const float *__restrict__ x, int ldx,
                                            const float *__restrict__ dy, PredSiTargets tg, const double *__restrict__ stats,
                                            const float *__restrict__ gscale, float weight, float lambda, float *__restrict__ dx, int lddx,
                                            float *__restrict__ dw, float *__restrict__ db, size_t seg_pix, float *__restrict__ part, int ldp,
-                                           unsigned long long *__restrict__ ticket) {
+                                           unsigned long long *__restrict__ ticket, int mask_x) {
+    // mask_x: x is the output of a ReLU layer with no other consumer (the last decoder): dx leaves with that layer's mask applied, dx = dz w (x > 0) —
+    // the layer's backward then skips its own mask pass over the full-resolution gradient and reads dx as one plain operand
     // part != NULL (round 6): every workgroup leaves its C + 1 partial sums in part[workgroup][ldp] and the LAST one to arrive (ticket) adds them
     // in a fixed order into dw / db — bit-reproducible weight and bias gradients (the bias gradient is a sum of ~1e6 terms that cancels to ~1e-6
     // of their size: with fp32 atomics its last digits depended on the arrival order) and no 33 contended atomics per workgroup, so the launch
@@ -502,7 +504,11 @@ __global__ void pred_sigmoid_si_bwd_kernel(const float *__restrict__ x, int ldx,
                 const int c = sub * 4 + 32 * k;
                 if (c < C) {
                     const float4 xv = k == 0 ? v[u] : ld4(x + pix * ldx + c);
-                    if (dx) st4(dx + pix * lddx + c, f4scale(ww[k], dz[u]));
+                    if (dx) {
+                        float4 g = f4scale(ww[k], dz[u]);
+                        if (mask_x) g.x = xv.x > 0.f ? g.x : 0.f, g.y = xv.y > 0.f ? g.y : 0.f, g.z = xv.z > 0.f ? g.z : 0.f, g.w = xv.w > 0.f ? g.w : 0.f;
+                        st4(dx + pix * lddx + c, g);
+                    }
                     dwp[k] = f4add(dwp[k], f4scale(xv, dz[u]));
                 }
             }
@@ -1130,7 +1136,7 @@ extern "C" int ramnet_pred_sigmoid_si_fwd(const float *x, int ldx, int C, const 
 
 extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const float *w, const float *y, const float *dy, size_t seg_pix, int nseg,
                                           const float *const *targets, const double *stats, const float *gscale, float weight, float lambda,
-                                          float *dx, int lddx, float *dw, float *db, double *scratch, void *stream) {
+                                          float *dx, int lddx, float *dw, float *db, double *scratch, int mask_x, void *stream) {
     RAMNET_CHECK_ARG(x && w && y && dw && db && C > 0 && C % 4 == 0 && C <= 128 && ldx % 4 == 0 && seg_pix > 0);
     RAMNET_CHECK_ARG(nseg >= 1 && nseg <= RAMNET_PRED_SI_MAX_SEGMENTS && targets && stats && gscale);
     if (dx) RAMNET_CHECK_ARG(lddx % 4 == 0);
@@ -1148,7 +1154,7 @@ extern "C" int ramnet_pred_sigmoid_si_bwd(const float *x, int ldx, int C, const 
     float *part = reinterpret_cast<float *>(scratch);
     unsigned long long *ticket = scratch ? reinterpret_cast<unsigned long long *>(scratch + ramnet_pred_si_scratch_doubles(seg_pix, nseg) - pred_si_bwd_tickets()) : nullptr;
     hipLaunchKernelGGL(pred_sigmoid_si_bwd_kernel, dim3(g, nseg), dim3(256), 0, (hipStream_t)stream, x, ldx, C, w, y, dy, tg, stats, gscale, weight,
-                       lambda, dx, lddx, dw, db, seg_pix, part, PRED_SI_BWD_LDP, ticket);
+                       lambda, dx, lddx, dw, db, seg_pix, part, PRED_SI_BWD_LDP, ticket, mask_x);
     RAMNET_LAUNCH_CHECK();
     return 0;
 }

@@ -151,6 +151,8 @@ class StateNetPhasedRecurrent(nn.Module):
             assert si is None, "fused SI loss: plain prediction layer only"
             return self.pred(x, act='sigmoid').permute(0, 3, 1, 2)           # NHWC [B,H,W,1] -> NCHW view
         if si is not None:
-            out = ops.PredSigmoidSI.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias, float(si[0]), float(si[1]), *si[2])
+            # (x = the last decoder's ReLU output, consumed here and nowhere else: the prediction layer's backward applies that ReLU's mask to dx)
+            pm = torch.is_grad_enabled() and ops.premask_relu_feature(x)
+            out = ops.PredSigmoidSI.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias, float(si[0]), float(si[1]), pm, *si[2])
             return out[0], list(out[1:])
         return ops.PredSigmoid.apply(x, self.pred.conv2d.weight, self.pred.conv2d.bias)

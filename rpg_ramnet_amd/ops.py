@@ -1477,7 +1477,7 @@ class ConvAct(Function):
         ctx.cp, ctx.stride, ctx.relu, ctx.up, ctx.mode = cp, stride, relu, up, mode
         # premask_ok: a caller that routes EVERY gradient of y through one fan-in (ops.TimeSplit / TimeFan) may have that fan-in apply the ReLU
         # mask and set premasked (premask_relu_feature): backward then reads dy as a plain operand
-        ctx.premask_ok, ctx.premasked = bool(relu) and not up, False
+        ctx.premask_ok, ctx.premasked = bool(relu), False
         ctx.save_for_backward(x, skip, y, xpad if _SAVE_XPAD else None)
         return y
 
@@ -2036,7 +2036,8 @@ class PredSigmoidSI(Function):
     returns (pred NCHW [B,1,H,W], loss_0, ..., loss_{n-1}).  pred stays differentiable for other consumers (a dense gradient is added)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, weight, n_lambda, *targets):
+    def forward(ctx, x, w, b, weight, n_lambda, mask_x, *targets):
+        """mask_x: x is a ReLU output whose every gradient comes from here (premask_relu_feature said yes): dx leaves with that mask applied."""
         x = dense(x)
         B, Hh, W, Cc = x.shape
         n = len(targets)
@@ -2054,7 +2055,7 @@ class PredSigmoidSI(Function):
         H.check(L.ramnet_pred_sigmoid_si_fwd(_p(x), ld(x), Cc, _p(w.detach()), _p(b.detach()), _p(y), seg_pix, n, arr, weight, n_lambda,
                                              _p(scratch), _p(stats), _p(loss), _st()), "pred_si_fwd")
         ctx.save_for_backward(x, w, b, y, stats, scratch, *tg)      # (scratch: the backward launch joins its partial sums through it)
-        ctx.meta = (weight, n_lambda, n, seg_pix)
+        ctx.meta = (weight, n_lambda, n, seg_pix, bool(mask_x))
         ctx.set_materialize_grads(False)
         return (y,) + tuple(loss[i] for i in range(n))
 
@@ -2062,7 +2063,7 @@ class PredSigmoidSI(Function):
     def backward(ctx, dy, *dloss):
         x, w, b, y, stats, scratch = ctx.saved_tensors[:6]
         tg = ctx.saved_tensors[6:]
-        weight, n_lambda, n, seg_pix = ctx.meta
+        weight, n_lambda, n, seg_pix, mask_x = ctx.meta
         B, Hh, W, Cc = x.shape
         dy = dy.contiguous() if dy is not None else None
         if all(g is None for g in dloss):
@@ -2075,8 +2076,8 @@ class PredSigmoidSI(Function):
         # ("pred_si_cap" / "pred_si_bwd_cap"): had they changed since the forward pass, fall back to the atomic form instead of a wrong layout
         join = scratch.numel() == H.lib().ramnet_pred_si_scratch_doubles(seg_pix, n)
         H.check(H.lib().ramnet_pred_sigmoid_si_bwd(_p(x), ld(x), Cc, _p(w.detach()), _p(y), _p(dy), seg_pix, n, arr, _p(stats), _p(gs), weight,
-                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _p(scratch) if join else None, _st()), "pred_si_bwd")
-        return (dx, None, None, None, None) + (None,) * n
+                                                   n_lambda, _p(dx), Cc, _p(ensure_grad(w)), _p(ensure_grad(b)), _p(scratch) if join else None, int(mask_x), _st()), "pred_si_bwd")
+        return (dx, None, None, None, None, None) + (None,) * n
 
 
 class PredLinear(Function):

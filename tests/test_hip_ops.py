@@ -979,7 +979,7 @@ def test_pred_sigmoid_si_matches_torch_and_is_bit_reproducible(B, H, W, C, n):
 
     def run():
         x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-        out = ops.PredSigmoidSI.apply(x, w, b, 1.0, 0.85, *tg)
+        out = ops.PredSigmoidSI.apply(x, w, b, 1.0, 0.85, False, *tg)
         total = sum(c * l for c, l in zip(coef, out[1:])) + (out[0] * dyv).sum()
         total.backward()
         torch.cuda.synchronize()
@@ -988,6 +988,11 @@ def test_pred_sigmoid_si_matches_torch_and_is_bit_reproducible(B, H, W, C, n):
     o1, dx1, dw1, db1 = run()
     o2, dx2, dw2, db2 = run()
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2) and torch.equal(dx1, dx2) and all(torch.equal(a, c) for a, c in zip(o1, o2))
+    # mask_x: dx leaves with the ReLU mask of x itself applied (x = the last decoder's output on the path); everything else unchanged
+    xm, wm, bm = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    outm = ops.PredSigmoidSI.apply(xm, wm, bm, 1.0, 0.85, True, *tg)
+    (sum(c * l for c, l in zip(coef, outm[1:])) + (outm[0] * dyv).sum()).backward()
+    assert torch.equal(xm.grad, torch.where(x0 > 0, dx1, torch.zeros((), device=dev()))) and torch.equal(wm.grad, dw1) and torch.equal(bm.grad, db1)
     # float64 torch
     x, w, b = x0.double().requires_grad_(True), w0.double().requires_grad_(True), b0.double().requires_grad_(True)
     y = torch.sigmoid((x * w.view(1, 1, 1, C)).sum(-1, keepdim=True) + b).permute(0, 3, 1, 2)

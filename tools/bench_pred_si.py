@@ -43,7 +43,7 @@ def main():
         H.check(H.lib().ramnet_set_option(b"pred_si_cap", cap), "set_option")
 
         def f():
-            return ops.PredSigmoidSI.apply(x, w, b, 1.0, 0.5, *tg)
+            return ops.PredSigmoidSI.apply(x, w, b, 1.0, 0.5, False, *tg)
 
         def f_cold():
             flush.zero_()
@@ -87,7 +87,7 @@ def main():
             def rawb():
                 H.check(L.ramnet_pred_sigmoid_si_bwd(xd.data_ptr(), Cc, Cc, wd.data_ptr(), y.data_ptr(), dy.data_ptr() if with_dy else None, seg_pix, n, arr,
                                                      stats.data_ptr(), gs.data_ptr(), 1.0, 0.5, dx.data_ptr(), Cc, dw.data_ptr(), db.data_ptr(),
-                                                     scratch_b.data_ptr() if joined else None, st), "rawb")
+                                                     scratch_b.data_ptr() if joined else None, 0, st), "rawb")
             t = timeit(rawb, 200)
             nb = B * Hh * W * 4 * (2 * Cc + 2 + (1 if with_dy else 0))
             print("bwd cap %6d %s: raw launch %7.1f us (%.3f of 8 TB/s)" % (cap, "joined through scratch" if joined else "fp32 atomics (<= 512 workgroups)", t, nb / t / 8e6))
